@@ -1,0 +1,213 @@
+/* sgamd.h -- C ABI of libsgamd.so: the MI355X (gfx950) native kernels behind StudioGAN's GAN training step
+ * and FID/IS feature-extraction hot path.
+ *
+ * Every entry point takes plain pointers/sizes (device pointers are what torch's tensor.data_ptr() returns),
+ * enqueues work on the given hipStream_t (pass torch.cuda.current_stream().cuda_stream), never synchronises
+ * the host, never allocates, and returns 0 on success or a negative code (message via sg_last_error()).
+ * This is the same contract as the reference's only native plugin precedent
+ * (reference src/utils/custom_ops.py:59-155, src/utils/style_ops/bias_act.cpp:35-97: validate -> RuntimeError,
+ * borrowed dense inputs, caller-owned outputs, current stream, no host sync).
+ *
+ * Activations are NHWC ("pixel-major": [N][H][W][C], C contiguous) in fp32 or bf16; the Python host mirror
+ * (pytorch-studiogan_amd/ops.py) converts at the reference's NCHW boundary. Master weights stay in the
+ * reference's OIHW fp32 layout (state_dict compatible, reference src/utils/ckpt.py:38); the spectral-norm
+ * kernels emit the [Cout][R][S][Cin] (forward) and [Cin][R'][S'][Cout] (data-gradient) operand images.
+ *
+ * Reference call sites replaced (all paths relative to /root/reference/src):
+ *   sg_conv2d_fwd / sg_conv2d_wgrad   utils/ops.py:165-173,195-204 (nn.Conv2d fwd + autograd dgrad/wgrad),
+ *                                     utils/ops.py:176-184 (ConvTranspose2d, via SG_PIX_TRANSPOSED)
+ *   sg_gemm                           utils/ops.py:187-188,219-220 (nn.Linear), utils/ops.py:93,100 (torch.bmm)
+ *   sg_sn_*                           utils/ops.py:195-224 (torch.nn.utils.spectral_norm hook)
+ *   sg_bn_* / sg_cbn_*                utils/ops.py:14-28,227-228 (BatchNorm2d eps=1e-4, ConditionalBatchNorm2d)
+ *   sg_softmax_* / sg_maxpool2_*      utils/ops.py:79-94 (SelfAttention)
+ *   sg_avgpool2_*                     models/big_resnet.py:175,219 (nn.AvgPool2d(2))
+ *   sg_relu_sum_hw_* / sg_pd_head_*   models/big_resnet.py:359-363,386-387 (D head, projection)
+ *   sg_loss_*                         utils/losses.py:197-239 (vanilla / hinge / wasserstein)
+ *   sg_embedding_*                    utils/ops.py:191-192
+ *   sg_adam_ema / sg_ema_lerp         config.py:541-563 (torch.optim.Adam eps 1e-6), utils/ema.py:27-40
+ *   sg_quantize_resize_normalize      utils/ops.py:251-263, utils/resize.py:72-93
+ */
+#ifndef SGAMD_H
+#define SGAMD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* sg_stream_t; /* hipStream_t */
+
+#define SG_DTYPE_F32 0
+#define SG_DTYPE_BF16 1
+
+/* activation-view flags (pix_flags / x_flags / g_flags) */
+#define SG_PIX_RELU 1
+#define SG_PIX_UPSAMPLE 2
+#define SG_PIX_QUAD 4
+#define SG_PIX_TRANSPOSED 8
+/* epilogue flags */
+#define SG_EPI_OUT_F32 1
+#define SG_EPI_ATOMIC 2
+#define SG_EPI_POOL 4
+#define SG_EPI_RELU 8
+#define SG_EPI_RES_F32 16
+
+const char* sg_last_error(void);
+int sg_version(void);
+
+/* out[n,ho,wo,co] = beta*res + mask(alpha * pool2x2sum(conv(x', w)) + bias), x' = [relu][upsample x2](x).
+ * Forward convolution and (with the data-gradient weight image) its data gradient. */
+typedef struct {
+  int dtype;
+  int N, Hs, Ws, C, ldx;          /* stored input [N,Hs,Ws,C], element pitch between pixels */
+  int Ho, Wo, Cout;               /* output grid (before the optional 2x2 pooling) and channels */
+  int R, S, stride, pad_h, pad_w;
+  int pix_flags, epi_flags;
+  float alpha, beta;
+  const void* x; const void* w;   /* w: [Cout][R*S*C], same dtype as x */
+  const float* bias; const void* res; const void* mask; void* out; const float* alpha_ptr;
+  int ldo, ldr, ldm;
+} sg_conv_fwd_desc;
+int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream);
+
+/* dw[co][r][s][c] += alpha * sum_{n,ho,wo} dy'[n,ho,wo,co] * x'[n, ho*stride-pad+r, wo*stride-pad+s, c] (fp32 atomics) */
+typedef struct {
+  int dtype;
+  int N;
+  int xHs, xWs, C, ldx, x_flags;
+  int gHs, gWs, Cout, ldg, g_flags;
+  int Ho, Wo;
+  int R, S, stride, pad_h, pad_w;
+  float alpha;
+  const void* x; const void* dy; float* dw;
+  int splits;                      /* 0 = auto */
+  int no_tr;                       /* 1 = use the gather fragment path instead of ds_read_b64_tr_b16 (test hook) */
+} sg_conv_wgrad_desc;
+int sg_conv2d_wgrad(const sg_conv_wgrad_desc* d, sg_stream_t stream);
+
+/* batched OUT[b][j][i] = beta*res + alpha * sum_k P(i,k) Q(j,k) + bias[i]
+ * form 0 ("KC"): operand stored [row][k] (k contiguous); form 1 ("MC"): stored [k][row] (row contiguous) */
+typedef struct {
+  int dtype, p_form, q_form;
+  int I, J, K, batch;
+  const void* p; long long p_bstride; int ldp;
+  const void* q; long long q_bstride; int ldq;
+  void* out; long long out_bstride; int ldo;
+  const float* bias; const void* res; long long res_bstride; int ldr; float beta;
+  float alpha; const float* alpha_ptr;
+  int epi_flags; int splits; int no_tr;
+} sg_gemm_desc;
+int sg_gemm(const sg_gemm_desc* d, sg_stream_t stream);
+
+/* ---- layout / elementwise ------------------------------------------------------------------------------ */
+/* fp32 NCHW -> T NHWC (ldo = channel pitch of the destination) */
+int sg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int ldo, sg_stream_t s);
+/* T NHWC -> fp32 NCHW, optional tanh */
+int sg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int lds, int apply_tanh, sg_stream_t s);
+/* d_pre(NHWC,T) = d_out(NCHW fp32) * (1 - y^2), y = NCHW fp32 tanh output (apply_tanh=0: plain layout change) */
+int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int apply_tanh, sg_stream_t s);
+int sg_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, sg_stream_t s);
+int sg_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, sg_stream_t s);
+/* 2x2 max pooling over a column slice [c0, c0+C) of a [N,H,W,ldx] tensor; idx gets the argmax (0..3) */
+int sg_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C, sg_stream_t s);
+int sg_maxpool2_bwd(int dtype, const void* dy, int ldy, const uint8_t* idx, void* dx, int ldx, int N, int H, int W, int C, sg_stream_t s);
+/* row softmax: fp32 logits [rows][cols] -> probabilities as T; bwd: ds(T) = p * (dp(fp32) - sum(dp*p)) */
+int sg_softmax_rows(int dtype, const float* s_in, void* p_out, long long rows, int cols, sg_stream_t st);
+int sg_softmax_rows_bwd(int dtype, const void* p, const float* dp, void* ds, long long rows, int cols, sg_stream_t st);
+/* y = a*x + b*y elementwise on T tensors; scalars may come from device memory */
+int sg_axpby(int dtype, const void* x, void* y, long long n, float a, float b, sg_stream_t s);
+/* out[0] (+)= sum(x*y) over n elements of T (fp32 accumulate, deterministic two-stage when accumulate=0) */
+int sg_dot(int dtype, const void* x, const void* y, long long n, float* out, float scale, const float* scale_ptr, sg_stream_t s);
+/* column sums of a [rows][C] T matrix (optionally through a >0 mask) into fp32 out[C] (+=) : conv bias gradient */
+int sg_colsum(int dtype, const void* x, int ldx, const void* mask, int ldm, long long rows, int C, float* out, float alpha, sg_stream_t s);
+
+/* ---- batch norm / conditional batch norm (reference eps = 1e-4, momentum 0.1) ---------------------------- */
+/* partial[c] = {sum x, sum x^2} in fp64 (zeroed by the caller); rows = N*H*W */
+int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_stream_t s);
+/* mean, invstd from (all-reduced) partial sums; updates running stats when running_mean != NULL
+ * (unbiased variance, momentum) -- torch.nn.functional.batch_norm training semantics */
+int sg_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd,
+                   float* running_mean, float* running_var, sg_stream_t s);
+/* eval mode: mean/invstd from running stats */
+int sg_bn_from_running(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, sg_stream_t s);
+/* y = relu?( (x-mean)*invstd * gain + bias ), gain/bias either per-channel [C] (stride_n = 0) or per-sample [N][C] */
+int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd,
+                const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s);
+/* backward, stage 1: per-(n,c) sums of dy' and dy'*xhat where dy' = dy * relu-mask; sums[N][C][2] fp32 (overwritten) */
+int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N, long long HW, int C, const float* mean, const float* invstd,
+                     const float* gain, const float* bias, int gb_stride_n, int relu, float* sums, sg_stream_t s);
+/* stage 2: from sums -> dgain/dbias ([N][C] when per-sample else [C], accumulated +=) and the per-channel
+ * batch terms chan[C][2] = {sum_n gain*S1, sum_n gain*S2} in fp64 (for the cross-rank all-reduce) */
+int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gb_stride_n, float* dgain, float* dbias,
+                       double* chan, sg_stream_t s);
+/* stage 3: dx = invstd * (gain*dy' - (chan0 + xhat*chan1)/count)   (count = global N*H*W; use_batch_stats=0 -> eval-mode BN) */
+int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean,
+                    const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu,
+                    const double* chan, double count, int use_batch_stats, sg_stream_t s);
+
+/* ---- spectral norm (torch.nn.utils.spectral_norm, eps 1e-6, one power iteration per forward) -------------- */
+typedef struct {
+  const float* w;     /* weight_orig viewed as [rows][cols] (OIHW flattened; [num_embeddings][dim] for embeddings) */
+  float* u; float* v; /* power-iteration state, updated in place (rows / cols) */
+  float* sigma;       /* out: 1 float */
+  float* u_snap; float* v_snap; /* optional copies of the updated u, v for this forward's backward (may be NULL) */
+  void* w_fwd;        /* out: W/sigma as T, [Cout][R][S][Cin] (or [rows][cols] when RS == 1) ; may be NULL */
+  void* w_dgrad;      /* out: W/sigma as T, [Cin][R-1-r][S-1-s][Cout] ; may be NULL */
+  float* w_f32;       /* out: W/sigma in fp32 [rows][cols] natural layout ; may be NULL */
+  int rows, cols;     /* rows = Cout, cols = Cin*R*S */
+  int Cin, RS;        /* cols == Cin*RS */
+  int do_power_iter;  /* module.training */
+  int apply_sn;       /* 0: plain layer, only emit operand images with sigma = 1 */
+  int rows_pad;       /* w_fwd gets rows_pad >= rows rows (extra rows zero) ; 0 = rows */
+  long long work_off; /* this layer's slice of work[]: needs 8*cols + rows floats */
+} sg_sn_layer;
+/* runs all layers of a network in 4 batched launches. `layers` is a DEVICE array of n descriptors;
+ * work[] is a device scratch of at least sg_sn_workspace_floats(max_rows_cols_sum) floats */
+int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s);
+
+typedef struct {
+  const float* dwt;   /* gradient w.r.t. the normalised weight, fp32, [Cout][R][S][Cin] (or natural [rows][cols] if natural=1) */
+  const float* w;     /* weight_orig [rows][cols] */
+  const float* u; const float* v; const float* sigma; /* snapshot of that forward */
+  float* dw;          /* grad of weight_orig, accumulated (+=), natural OIHW layout */
+  int rows, cols, Cin, RS, natural, apply_sn;
+} sg_sn_bwd_layer;
+int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s);
+
+/* ---- embedding, D head, losses ---------------------------------------------------------------------------- */
+int sg_embedding_fwd(const float* table, const int64_t* idx, float* out, int B, int dim, int num, sg_stream_t s);
+int sg_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int B, int dim, int num, sg_stream_t s);
+/* h[b][c] = sum_hw relu(x[b,hw,c]) (fp32 out) ; bwd: dx[b,hw,c] = dh[b][c] * (x>0) */
+int sg_relu_sum_hw_fwd(int dtype, const void* x, float* h, int B, int HW, int C, sg_stream_t s);
+int sg_relu_sum_hw_bwd(int dtype, const void* x, const float* dh, void* dx, int B, int HW, int C, sg_stream_t s);
+/* adv[b] = <h[b], w1> + b1 + <emb[b], h[b]>  (emb may be NULL -> unconditional) */
+int sg_pd_head_fwd(const float* h, const float* w1, const float* b1, const float* emb, float* adv, int B, int C, sg_stream_t s);
+int sg_pd_head_bwd(const float* h, const float* w1, const float* emb, const float* dadv, float* dh, float* dw1, float* db1,
+                   float* demb, int B, int C, sg_stream_t s);
+/* adversarial losses: kind 0 hinge, 1 wasserstein, 2 vanilla(BCE-with-logits). loss[0] overwritten; gradients of the
+ * mean-reduced loss written to d_real / d_fake */
+int sg_loss_d(int kind, const float* real, const float* fake, int B, float* loss, float* d_real, float* d_fake, sg_stream_t s);
+int sg_loss_g(int kind, const float* fake, int B, float* loss, float* d_fake, sg_stream_t s);
+
+/* ---- optimizer / EMA over flat arenas -------------------------------------------------------------------- */
+/* torch.optim.Adam (no amsgrad, no weight decay unless wd != 0) on a flat fp32 arena, fused with the EMA of
+ * the generator copy (ema may be NULL): p_ema = p_new.lerp(p_ema, decay) (reference utils/ema.py:27-35) */
+int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr, float beta1, float beta2,
+                float eps, float wd, int step, float ema_decay, float grad_scale, sg_stream_t s);
+int sg_ema_lerp(const float* src, float* ema, long long n, float decay, sg_stream_t s);
+
+/* ---- evaluation path -------------------------------------------------------------------------------------- */
+/* fp32 NCHW [-1,1] -> uint8 quantise (trunc((x+1)/2*255+0.5), clamp) -> bilinear (align_corners=False) resize to
+ * OHxOW -> clip(0,255) -> (x/255-0.5)/0.5 -> T NHWC.  quant_out (optional) receives the uint8 NCHW image. */
+int sg_quantize_resize_normalize(int dtype, const float* x, void* out, uint8_t* quant_out, int N, int C, int H, int W,
+                                 int OH, int OW, int quantize, sg_stream_t s);
+/* generic pooling on NHWC: mode 0 max, 1 avg (count_include_pad), 2 avg excluding padding */
+int sg_pool2d(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int mode, int ldy, int c_off, sg_stream_t s);
+/* global average pool [N,HW,C] -> fp32 [N,C] */
+int sg_global_avgpool(int dtype, const void* x, float* y, int N, int HW, int C, sg_stream_t s);
+/* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
+int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

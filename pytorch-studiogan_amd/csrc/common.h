@@ -1,0 +1,113 @@
+// Common device helpers for the gfx950 (MI355X / CDNA4) StudioGAN hot-path kernels.
+// Wave = 64 lanes everywhere in this tree; nothing here is written for 32-wide warps.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef uint16_t bf16_t;  // raw bf16 storage (torch.bfloat16 bit pattern)
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+
+#define SG_DTYPE_F32 0
+#define SG_DTYPE_BF16 1
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(((uint32_t)v) << 16); }
+// round-to-nearest-even, same rounding as torch's float->bfloat16
+__device__ __forceinline__ bf16_t f2bf(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40u);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (bf16_t)(u >> 16);
+}
+
+template <typename T> __device__ __forceinline__ float to_f(T v);
+template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }
+template <typename T> __device__ __forceinline__ T from_f(float v);
+template <> __device__ __forceinline__ float from_f<float>(float v) { return v; }
+template <> __device__ __forceinline__ bf16_t from_f<bf16_t>(float v) { return f2bf(v); }
+
+// element traits: VEC = elements per 16-byte vector, BK = GEMM k-tile in elements (always 64 bytes)
+template <typename T> struct ET;
+template <> struct ET<float> { static constexpr int VEC = 4, BK = 16; };
+template <> struct ET<bf16_t> { static constexpr int VEC = 8, BK = 32; };
+
+__device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
+
+// ReLU on a packed 16-byte vector
+template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
+template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = (v[i] & 0x80000000u) ? 0u : v[i];
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    uint32_t x = v[i];
+    uint32_t lo = (x & 0x00008000u) ? 0u : (x & 0x0000ffffu);
+    uint32_t hi = (x & 0x80000000u) ? 0u : (x & 0xffff0000u);
+    v[i] = lo | hi;
+  }
+  return v;
+}
+
+// wave-level sum (64 lanes)
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+
+// block-level sum for blockDim.x == 256 (4 waves); result valid in all threads
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */) {
+  v = wave_sum(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ double block_sum_256_d(double v, double* sm) {
+  v = wave_sum_d(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return sm[0] + sm[1] + sm[2] + sm[3];
+}
+__device__ __forceinline__ float block_max_256(float v, float* sm) {
+  v = wave_max(v);
+  int w = threadIdx.x >> 6;
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[w] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+}
+
+// error reporting shared by every C-ABI entry point (capi.cpp owns the storage)
+extern "C" void sg_set_error(const char* msg);
+#define SG_CHECK(cond, msg)                                   \
+  do {                                                        \
+    if (!(cond)) { sg_set_error(msg); return -1; }            \
+  } while (0)
+#define SG_LAUNCH_CHECK()                                     \
+  do {                                                        \
+    hipError_t e__ = hipGetLastError();                       \
+    if (e__ != hipSuccess) { sg_set_error(hipGetErrorString(e__)); return -2; } \
+  } while (0)

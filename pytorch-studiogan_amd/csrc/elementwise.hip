@@ -1,0 +1,396 @@
+// elementwise.hip -- HBM-bound glue of the hot path: layout changes at the NCHW boundary, pooling, softmax,
+// reductions, embedding gather/scatter, the projection-discriminator head and the adversarial losses.
+// All kernels are coalesced along the channel (fastest NHWC) dimension; wave = 64.
+#include "common.h"
+#include "../../include/sgamd.h"
+
+static inline int nblk(long long n, int bs) {
+  long long b = (n + bs - 1) / bs;
+  if (b > 65535ll * 32) b = 65535ll * 32;
+  if (b < 1) b = 1;
+  return (int)b;
+}
+#define DISPATCH_T(dtype, ...)                                          \
+  if ((dtype) == SG_DTYPE_F32) { typedef float T; __VA_ARGS__; }        \
+  else if ((dtype) == SG_DTYPE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { sg_set_error("bad dtype"); return -1; }
+
+// ---- layout -------------------------------------------------------------------------------------------
+template <typename T> __global__ void k_nchw_to_nhwc(const float* src, T* dst, int N, int C, int HW, int ldo) {
+  long long total = (long long)N * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    // iterate in source order (coalesced fp32 reads); C is small (3) at the image boundary
+    int hw = (int)(i % HW); long long t = i / HW; int c = (int)(t % C); int n = (int)(t / C);
+    dst[((long long)n * HW + hw) * ldo + c] = from_f<T>(src[i]);
+  }
+}
+extern "C" int sg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int ldo, sg_stream_t s) {
+  SG_CHECK(src && dst, "sg_nchw_to_nhwc: null");
+  long long total = (long long)N * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_to_nhwc<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, src, (T*)dst, N, C, H * W, ldo));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_nhwc_to_nchw(const T* src, float* dst, int N, int C, int HW, int lds, int do_tanh) {
+  long long total = (long long)N * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int hw = (int)(i % HW); long long t = i / HW; int c = (int)(t % C); int n = (int)(t / C);
+    float v = to_f<T>(src[((long long)n * HW + hw) * lds + c]);
+    if (do_tanh) v = tanhf(v);
+    dst[i] = v;
+  }
+}
+extern "C" int sg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int lds, int apply_tanh, sg_stream_t s) {
+  SG_CHECK(src && dst, "sg_nhwc_to_nchw: null");
+  long long total = (long long)N * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_nhwc_to_nchw<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)src, dst, N, C, H * W, lds, apply_tanh));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_nchw_grad_to_nhwc(const float* dy, const float* y, T* dst, int N, int C, int HW, int do_tanh) {
+  long long total = (long long)N * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int hw = (int)(i % HW); long long t = i / HW; int c = (int)(t % C); int n = (int)(t / C);
+    float g = dy[i];
+    if (do_tanh) { float yy = y[i]; g *= (1.f - yy * yy); }
+    dst[((long long)n * HW + hw) * C + c] = from_f<T>(g);
+  }
+}
+extern "C" int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int apply_tanh, sg_stream_t s) {
+  SG_CHECK(dy && dst && (y || !apply_tanh), "sg_nchw_grad_to_nhwc: null");
+  long long total = (long long)N * C * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_grad_to_nhwc<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, dy, y, (T*)dst, N, C, H * W, apply_tanh));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- 2x2 pooling ---------------------------------------------------------------------------------------
+template <typename T> __global__ void k_avgpool2_fwd(const T* x, T* y, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2;
+  long long total = (long long)N * H2 * W2 * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long long t = i / C; int w2 = (int)(t % W2); t /= W2; int h2 = (int)(t % H2); int n = (int)(t / H2);
+    const T* p = x + (((long long)n * H + 2 * h2) * W + 2 * w2) * C + c;
+    float v = to_f<T>(p[0]) + to_f<T>(p[C]) + to_f<T>(p[(long long)W * C]) + to_f<T>(p[(long long)W * C + C]);
+    y[i] = from_f<T>(0.25f * v);
+  }
+}
+extern "C" int sg_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, sg_stream_t s) {
+  SG_CHECK(x && y && H % 2 == 0 && W % 2 == 0, "sg_avgpool2_fwd: bad args");
+  long long total = (long long)N * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_avgpool2_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, H, W, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_avgpool2_bwd(const T* dy, T* dx, int N, int H, int W, int C) {
+  // H, W are the dims of dx
+  const int H2 = H / 2, W2 = W / 2;
+  long long total = (long long)N * H * W * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long long t = i / C; int w = (int)(t % W); t /= W; int h = (int)(t % H); int n = (int)(t / H);
+    float g = to_f<T>(dy[(((long long)n * H2 + (h >> 1)) * W2 + (w >> 1)) * C + c]);
+    dx[i] = from_f<T>(0.25f * g);
+  }
+}
+extern "C" int sg_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, sg_stream_t s) {
+  SG_CHECK(dy && dx && H % 2 == 0 && W % 2 == 0, "sg_avgpool2_bwd: bad args");
+  long long total = (long long)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_avgpool2_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (T*)dx, N, H, W, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_maxpool2_fwd(const T* x, int ldx, T* y, int ldy, uint8_t* idx, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2;
+  long long total = (long long)N * H2 * W2 * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long long q = i / C; long long t = q; int w2 = (int)(t % W2); t /= W2; int h2 = (int)(t % H2); int n = (int)(t / H2);
+    const T* p = x + (((long long)n * H + 2 * h2) * W + 2 * w2) * ldx + c;
+    // first maximum in (dy,dx) row-major order wins, like torch's max_pool2d
+    float v0 = to_f<T>(p[0]), v1 = to_f<T>(p[ldx]), v2 = to_f<T>(p[(long long)W * ldx]), v3 = to_f<T>(p[(long long)W * ldx + ldx]);
+    float m = v0; int a = 0;
+    if (v1 > m) { m = v1; a = 1; }
+    if (v2 > m) { m = v2; a = 2; }
+    if (v3 > m) { m = v3; a = 3; }
+    y[q * ldy + c] = from_f<T>(m);
+    if (idx) idx[i] = (uint8_t)a;
+  }
+}
+extern "C" int sg_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C, sg_stream_t s) {
+  SG_CHECK(x && y && H % 2 == 0 && W % 2 == 0, "sg_maxpool2_fwd: bad args");
+  long long total = (long long)N * (H / 2) * (W / 2) * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool2_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (T*)y, ldy, idx, N, H, W, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_maxpool2_bwd(const T* dy, int ldy, const uint8_t* idx, T* dx, int ldx, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2;
+  long long total = (long long)N * H * W * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); long long pix = i / C; long long t = pix; int w = (int)(t % W); t /= W; int h = (int)(t % H); int n = (int)(t / H);
+    long long q = ((long long)n * H2 + (h >> 1)) * W2 + (w >> 1);
+    int pos = ((h & 1) << 1) | (w & 1);
+    float g = (idx[q * C + c] == pos) ? to_f<T>(dy[q * ldy + c]) : 0.f;
+    dx[pix * ldx + c] = from_f<T>(g);
+  }
+}
+extern "C" int sg_maxpool2_bwd(int dtype, const void* dy, int ldy, const uint8_t* idx, void* dx, int ldx, int N, int H, int W, int C, sg_stream_t s) {
+  SG_CHECK(dy && dx && idx, "sg_maxpool2_bwd: null");
+  long long total = (long long)N * H * W * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool2_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, ldy, idx, (T*)dx, ldx, N, H, W, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- row softmax (attention, reference src/utils/ops.py:94) ----------------------------------------------
+// one 256-thread workgroup per row; logits arrive in fp32 from the QK^T epilogue, probabilities leave as T
+template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows(const float* s, T* p, int cols) {
+  __shared__ float sm[4];
+  const float* row = s + (long long)blockIdx.x * cols;
+  T* out = p + (long long)blockIdx.x * cols;
+  float m = -INFINITY;
+  for (int c = threadIdx.x; c < cols; c += 256) m = fmaxf(m, row[c]);
+  m = block_max_256(m, sm);
+  float sum = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) sum += __expf(row[c] - m);
+  sum = block_sum_256(sum, sm);
+  const float inv = 1.f / sum;
+  for (int c = threadIdx.x; c < cols; c += 256) out[c] = from_f<T>(__expf(row[c] - m) * inv);
+}
+extern "C" int sg_softmax_rows(int dtype, const float* s_in, void* p_out, long long rows, int cols, sg_stream_t st) {
+  SG_CHECK(s_in && p_out && rows > 0 && rows < (1ll << 31) && cols > 0, "sg_softmax_rows: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, s_in, (T*)p_out, cols));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows_bwd(const T* p, const float* dp, T* ds, int cols) {
+  __shared__ float sm[4];
+  const T* pr = p + (long long)blockIdx.x * cols;
+  const float* dr = dp + (long long)blockIdx.x * cols;
+  T* out = ds + (long long)blockIdx.x * cols;
+  float dot = 0.f;
+  for (int c = threadIdx.x; c < cols; c += 256) dot += to_f<T>(pr[c]) * dr[c];
+  dot = block_sum_256(dot, sm);
+  for (int c = threadIdx.x; c < cols; c += 256) out[c] = from_f<T>(to_f<T>(pr[c]) * (dr[c] - dot));
+}
+extern "C" int sg_softmax_rows_bwd(int dtype, const void* p, const float* dp, void* ds, long long rows, int cols, sg_stream_t st) {
+  SG_CHECK(p && dp && ds && rows > 0 && rows < (1ll << 31) && cols > 0, "sg_softmax_rows_bwd: bad args");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows_bwd<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, (const T*)p, dp, (T*)ds, cols));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- axpby / dot / column sums ---------------------------------------------------------------------------
+template <typename T> __global__ void k_axpby(const T* x, T* y, long long n, float a, float b) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    float v = a * to_f<T>(x[i]);
+    if (b != 0.f) v += b * to_f<T>(y[i]);
+    y[i] = from_f<T>(v);
+  }
+}
+extern "C" int sg_axpby(int dtype, const void* x, void* y, long long n, float a, float b, sg_stream_t s) {
+  SG_CHECK(x && y, "sg_axpby: null");
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_axpby<T>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, n, a, b));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ __launch_bounds__(256) void k_dot(const T* x, const T* y, long long n, float* out, float scale, const float* scale_ptr) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) acc += to_f<T>(x[i]) * to_f<T>(y[i]);
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) {
+    float sc = scale; if (scale_ptr) sc *= *scale_ptr;
+    unsafeAtomicAdd(out, acc * sc);
+  }
+}
+extern "C" int sg_dot(int dtype, const void* x, const void* y, long long n, float* out, float scale, const float* scale_ptr, sg_stream_t s) {
+  SG_CHECK(x && y && out, "sg_dot: null");
+  int blocks = nblk(n, 256 * 8); if (blocks > 1024) blocks = 1024;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_dot<T>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, n, out, scale, scale_ptr));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// block = 64 channel lanes x 4 row lanes; grid = (channel tiles, row chunks)
+template <typename T> __global__ __launch_bounds__(256) void k_colsum(const T* x, int ldx, const T* mask, int ldm, long long rows, int C, float* out, float alpha, long long rows_per_block) {
+  __shared__ float sm[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  long long r0 = blockIdx.y * rows_per_block, r1 = r0 + rows_per_block; if (r1 > rows) r1 = rows;
+  float acc = 0.f;
+  if (c < C) {
+    for (long long r = r0 + ry; r < r1; r += 4) {
+      float v = to_f<T>(x[r * ldx + c]);
+      if (mask) { if (!(to_f<T>(mask[r * ldm + c]) > 0.f)) v = 0.f; }
+      acc += v;
+    }
+  }
+  sm[ry][cx] = acc;
+  __syncthreads();
+  if (ry == 0 && c < C) unsafeAtomicAdd(out + c, alpha * (sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx]));
+}
+extern "C" int sg_colsum(int dtype, const void* x, int ldx, const void* mask, int ldm, long long rows, int C, float* out, float alpha, sg_stream_t s) {
+  SG_CHECK(x && out && rows > 0 && C > 0, "sg_colsum: bad args");
+  int ct = (C + 63) / 64;
+  long long want = 2048 / ct; if (want < 1) want = 1;
+  long long rpb = (rows + want - 1) / want; if (rpb < 64) rpb = 64;
+  int ry = (int)((rows + rpb - 1) / rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_colsum<T>, dim3(ct, ry), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (const T*)mask, ldm, rows, C, out, alpha, rpb));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- embedding (reference src/utils/ops.py:191-192) ------------------------------------------------------
+__global__ void k_embedding_fwd(const float* table, const int64_t* idx, float* out, int B, int dim, int num) {
+  long long total = (long long)B * dim;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int b = (int)(i / dim), d = (int)(i % dim);
+    long long r = idx[b];
+    out[i] = (r >= 0 && r < num) ? table[r * dim + d] : 0.f;
+  }
+}
+extern "C" int sg_embedding_fwd(const float* table, const int64_t* idx, float* out, int B, int dim, int num, sg_stream_t s) {
+  SG_CHECK(table && idx && out, "sg_embedding_fwd: null");
+  hipLaunchKernelGGL(k_embedding_fwd, dim3(nblk((long long)B * dim, 256)), dim3(256), 0, (hipStream_t)s, table, idx, out, B, dim, num);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int B, int dim, int num) {
+  long long total = (long long)B * dim;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int b = (int)(i / dim), d = (int)(i % dim);
+    long long r = idx[b];
+    if (r >= 0 && r < num) unsafeAtomicAdd(dtable + r * dim + d, dout[i]);
+  }
+}
+extern "C" int sg_embedding_bwd(const float* dout, const int64_t* idx, float* dtable, int B, int dim, int num, sg_stream_t s) {
+  SG_CHECK(dout && idx && dtable, "sg_embedding_bwd: null");
+  hipLaunchKernelGGL(k_embedding_bwd, dim3(nblk((long long)B * dim, 256)), dim3(256), 0, (hipStream_t)s, dout, idx, dtable, B, dim, num);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- discriminator head (reference src/models/big_resnet.py:359-363,386-387) -----------------------------
+template <typename T> __global__ void k_relu_sum_hw_fwd(const T* x, float* h, int B, int HW, int C) {
+  long long total = (long long)B * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int b = (int)(i / C), c = (int)(i % C);
+    const T* p = x + (long long)b * HW * C + c;
+    float acc = 0.f;
+    for (int k = 0; k < HW; k++) acc += fmaxf(to_f<T>(p[(long long)k * C]), 0.f);
+    h[i] = acc;
+  }
+}
+extern "C" int sg_relu_sum_hw_fwd(int dtype, const void* x, float* h, int B, int HW, int C, sg_stream_t s) {
+  SG_CHECK(x && h, "sg_relu_sum_hw_fwd: null");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_relu_sum_hw_fwd<T>, dim3(nblk((long long)B * C, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, h, B, HW, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_relu_sum_hw_bwd(const T* x, const float* dh, T* dx, int B, int HW, int C) {
+  long long total = (long long)B * HW * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(i % C); int b = (int)(i / ((long long)HW * C));
+    float g = (to_f<T>(x[i]) > 0.f) ? dh[(long long)b * C + c] : 0.f;
+    dx[i] = from_f<T>(g);
+  }
+}
+extern "C" int sg_relu_sum_hw_bwd(int dtype, const void* x, const float* dh, void* dx, int B, int HW, int C, sg_stream_t s) {
+  SG_CHECK(x && dh && dx, "sg_relu_sum_hw_bwd: null");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_relu_sum_hw_bwd<T>, dim3(nblk((long long)B * HW * C, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, dh, (T*)dx, B, HW, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(256) void k_pd_head_fwd(const float* h, const float* w1, const float* b1, const float* emb, float* adv, int C) {
+  __shared__ float sm[4];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    float w = w1[c];
+    if (emb) w += emb[(long long)b * C + c];
+    acc += h[(long long)b * C + c] * w;
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) adv[b] = acc + (b1 ? b1[0] : 0.f);
+}
+extern "C" int sg_pd_head_fwd(const float* h, const float* w1, const float* b1, const float* emb, float* adv, int B, int C, sg_stream_t s) {
+  SG_CHECK(h && w1 && adv, "sg_pd_head_fwd: null");
+  hipLaunchKernelGGL(k_pd_head_fwd, dim3(B), dim3(256), 0, (hipStream_t)s, h, w1, b1, emb, adv, C);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_pd_head_bwd(const float* h, const float* w1, const float* emb, const float* dadv, float* dh, float* dw1, float* db1, float* demb, int B, int C) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c < C) {
+    float aw = 0.f;
+    const float w = w1[c];
+    for (int b = 0; b < B; b++) {
+      const float g = dadv[b];
+      const float hv = h[(long long)b * C + c];
+      float wt = w;
+      if (emb) { wt += emb[(long long)b * C + c]; demb[(long long)b * C + c] = g * hv; }
+      dh[(long long)b * C + c] = g * wt;
+      aw += g * hv;
+    }
+    dw1[c] += aw;
+  }
+  if (c == 0 && db1) {
+    float ab = 0.f;
+    for (int b = 0; b < B; b++) ab += dadv[b];
+    db1[0] += ab;
+  }
+}
+extern "C" int sg_pd_head_bwd(const float* h, const float* w1, const float* emb, const float* dadv, float* dh, float* dw1, float* db1, float* demb, int B, int C, sg_stream_t s) {
+  SG_CHECK(h && w1 && dadv && dh && dw1 && (!emb || demb), "sg_pd_head_bwd: null");
+  hipLaunchKernelGGL(k_pd_head_bwd, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, h, w1, emb, dadv, dh, dw1, db1, demb, B, C);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- adversarial losses (reference src/utils/losses.py:197-239) ------------------------------------------
+__device__ __forceinline__ float softplusf(float x) { return (x > 20.f) ? x : log1pf(__expf(x)); }
+__device__ __forceinline__ float sigmoidf(float x) { return 1.f / (1.f + __expf(-x)); }
+__global__ __launch_bounds__(256) void k_loss_d(int kind, const float* real, const float* fake, int B, float* loss, float* d_real, float* d_fake) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const float inv = 1.f / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float r = real[b], f = fake[b];
+    if (kind == 0) {  // hinge
+      acc += fmaxf(1.f - r, 0.f) + fmaxf(1.f + f, 0.f);
+      d_real[b] = (1.f - r > 0.f) ? -inv : 0.f;
+      d_fake[b] = (1.f + f > 0.f) ? inv : 0.f;
+    } else if (kind == 1) {  // wasserstein
+      acc += f - r; d_real[b] = -inv; d_fake[b] = inv;
+    } else {  // vanilla: softplus(-r) + softplus(f)
+      acc += softplusf(-r) + softplusf(f);
+      d_real[b] = -sigmoidf(-r) * inv; d_fake[b] = sigmoidf(f) * inv;
+    }
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss[0] = acc * inv;
+}
+extern "C" int sg_loss_d(int kind, const float* real, const float* fake, int B, float* loss, float* d_real, float* d_fake, sg_stream_t s) {
+  SG_CHECK(real && fake && loss && d_real && d_fake && B > 0, "sg_loss_d: bad args");
+  hipLaunchKernelGGL(k_loss_d, dim3(1), dim3(256), 0, (hipStream_t)s, kind, real, fake, B, loss, d_real, d_fake);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(256) void k_loss_g(int kind, const float* fake, int B, float* loss, float* d_fake) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const float inv = 1.f / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float f = fake[b];
+    if (kind == 2) { acc += softplusf(-f); d_fake[b] = -sigmoidf(-f) * inv; }
+    else { acc += -f; d_fake[b] = -inv; }
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss[0] = acc * inv;
+}
+extern "C" int sg_loss_g(int kind, const float* fake, int B, float* loss, float* d_fake, sg_stream_t s) {
+  SG_CHECK(fake && loss && d_fake && B > 0, "sg_loss_g: bad args");
+  hipLaunchKernelGGL(k_loss_g, dim3(1), dim3(256), 0, (hipStream_t)s, kind, fake, B, loss, d_fake);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

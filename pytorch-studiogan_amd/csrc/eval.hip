@@ -1,0 +1,127 @@
+// eval.hip -- FID/IS feature-extraction side kernels: the on-device replacement of the reference's
+// quantize -> D2H -> per-image CPU resize -> H2D -> normalise loop (reference src/utils/ops.py:251-263,
+// src/utils/resize.py:72-93 "legacy" resizer, src/metrics/preparation.py:103-108), the Inception pooling layers
+// (reference src/metrics/inception_net.py:135-249) and the fp64 moment accumulation that replaces gathering
+// 50k x 2048 features (reference src/metrics/fid.py:65-98).
+#include "common.h"
+#include "../../include/sgamd.h"
+
+#define DISPATCH_T(dtype, ...)                                          \
+  if ((dtype) == SG_DTYPE_F32) { typedef float T; __VA_ARGS__; }        \
+  else if ((dtype) == SG_DTYPE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { sg_set_error("bad dtype"); return -1; }
+
+static inline int grid1d(long long total) { long long b = (total + 255) / 256; if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
+
+// uint8 quantisation exactly as ops.quantize_images: x=(x+1)/2 ; (255*x+0.5).clamp(0,255) ; astype(uint8) (truncation).
+// Individually rounded fp32 ops (no fma contraction) so the integer result is bit-identical to the reference.
+__device__ __forceinline__ float quant_u8(float x) {
+  float t = __fdiv_rn(__fadd_rn(x, 1.0f), 2.0f);
+  t = __fadd_rn(__fmul_rn(255.0f, t), 0.5f);
+  t = fminf(fmaxf(t, 0.0f), 255.0f);
+  return truncf(t);
+}
+__global__ void k_quantize_u8(const float* x, uint8_t* q, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) q[i] = (uint8_t)quant_u8(x[i]);
+}
+// bilinear, align_corners=False (torch area_pixel_compute_source_index): src = scale*(dst+0.5)-0.5 clamped at 0
+template <typename T> __global__ void k_qrn(const float* x, T* out, int N, int C, int H, int W, int OH, int OW, int quantize, float sh, float sw) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C); long long t = i / C; const int ow = (int)(t % OW); t /= OW; const int oh = (int)(t % OH); const int n = (int)(t / OH);
+    float fy = __fadd_rn(__fmul_rn(sh, (float)oh + 0.5f), -0.5f); if (fy < 0.f) fy = 0.f;
+    float fx = __fadd_rn(__fmul_rn(sw, (float)ow + 0.5f), -0.5f); if (fx < 0.f) fx = 0.f;
+    const int y0 = (int)fy, x0 = (int)fx;
+    const int y1 = y0 + (y0 < H - 1 ? 1 : 0), x1 = x0 + (x0 < W - 1 ? 1 : 0);
+    const float ly = fy - (float)y0, lx = fx - (float)x0;
+    const float* p = x + ((long long)n * C + c) * H * W;
+    float v00 = p[(long long)y0 * W + x0], v01 = p[(long long)y0 * W + x1], v10 = p[(long long)y1 * W + x0], v11 = p[(long long)y1 * W + x1];
+    if (quantize) { v00 = quant_u8(v00); v01 = quant_u8(v01); v10 = quant_u8(v10); v11 = quant_u8(v11); }
+    else { v00 = truncf(v00); v01 = truncf(v01); v10 = truncf(v10); v11 = truncf(v11); }
+    float v = (1.f - ly) * ((1.f - lx) * v00 + lx * v01) + ly * ((1.f - lx) * v10 + lx * v11);
+    v = fminf(fmaxf(v, 0.f), 255.f);
+    v = (v / 255.0f - 0.5f) / 0.5f;
+    out[i] = from_f<T>(v);
+  }
+}
+extern "C" int sg_quantize_resize_normalize(int dtype, const float* x, void* out, uint8_t* quant_out, int N, int C, int H, int W, int OH, int OW, int quantize, sg_stream_t s) {
+  SG_CHECK(x && out && N > 0 && C > 0, "sg_quantize_resize_normalize: bad args");
+  hipStream_t st = (hipStream_t)s;
+  if (quant_out) hipLaunchKernelGGL(k_quantize_u8, dim3(grid1d((long long)N * C * H * W)), dim3(256), 0, st, x, quant_out, (long long)N * C * H * W);
+  const float sh = (float)H / (float)OH, sw = (float)W / (float)OW;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_qrn<T>, dim3(grid1d((long long)N * OH * OW * C)), dim3(256), 0, st, x, (T*)out, N, C, H, W, OH, OW, quantize, sh, sw));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// generic NHWC pooling; output may be a channel slice [c_off, c_off+C) of a wider (ldy) concat tensor
+template <typename T> __global__ void k_pool2d(const T* x, T* y, int N, int H, int W, int C, int k, int stride, int pad, int mode, int OH, int OW, int ldy, int c_off) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C); long long t = i / C; const int ow = (int)(t % OW); t /= OW; const int oh = (int)(t % OH); const int n = (int)(t / OH);
+    float acc = (mode == 0) ? -INFINITY : 0.f; int cnt = 0;
+    for (int r = 0; r < k; r++) {
+      const int h = oh * stride - pad + r; if (h < 0 || h >= H) continue;
+      for (int q = 0; q < k; q++) {
+        const int w = ow * stride - pad + q; if (w < 0 || w >= W) continue;
+        const float v = to_f<T>(x[(((long long)n * H + h) * W + w) * C + c]);
+        if (mode == 0) acc = fmaxf(acc, v); else acc += v;
+        cnt++;
+      }
+    }
+    if (mode == 1) acc /= (float)(k * k); else if (mode == 2) acc /= (float)cnt;
+    y[(((long long)n * OH + oh) * OW + ow) * ldy + c_off + c] = from_f<T>(acc);
+  }
+}
+extern "C" int sg_pool2d(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int mode, int ldy, int c_off, sg_stream_t s) {
+  SG_CHECK(x && y && k > 0 && stride > 0, "sg_pool2d: bad args");
+  const int OH = (H + 2 * pad - k) / stride + 1, OW = (W + 2 * pad - k) / stride + 1;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_pool2d<T>, dim3(grid1d((long long)N * OH * OW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, H, W, C, k, stride, pad, mode, OH, OW, ldy, c_off));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T> __global__ void k_global_avgpool(const T* x, float* y, int N, int HW, int C) {
+  const long long total = (long long)N * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int n = (int)(i / C), c = (int)(i % C);
+    const T* p = x + (long long)n * HW * C + c;
+    float acc = 0.f;
+    for (int k = 0; k < HW; k++) acc += to_f<T>(p[(long long)k * C]);
+    y[i] = acc / (float)HW;
+  }
+}
+extern "C" int sg_global_avgpool(int dtype, const void* x, float* y, int N, int HW, int C, sg_stream_t s) {
+  SG_CHECK(x && y, "sg_global_avgpool: null");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_global_avgpool<T>, dim3(grid1d((long long)N * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, y, N, HW, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// FID moments: sum_f[c] += sum_n f[n][c]; sum_ff[c1][c2] += sum_n f[n][c1]*f[n][c2] in fp64.
+// 16x16 output tile per workgroup, features staged through LDS in chunks of 64 samples.
+__global__ __launch_bounds__(256) void k_feat_moments(const float* f, int n, int C, double* sum_f, double* sum_ff) {
+  __shared__ float a[64][17], b[64][17];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int c1 = blockIdx.y * 16 + ty, c2 = blockIdx.x * 16 + tx;
+  double acc = 0.0, accf = 0.0;
+  for (int n0 = 0; n0 < n; n0 += 64) {
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int r = e >> 4, cc = e & 15;
+      const int nn = n0 + r;
+      a[r][cc] = (nn < n && blockIdx.y * 16 + cc < C) ? f[(long long)nn * C + blockIdx.y * 16 + cc] : 0.f;
+      b[r][cc] = (nn < n && blockIdx.x * 16 + cc < C) ? f[(long long)nn * C + blockIdx.x * 16 + cc] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int r = 0; r < 64; r++) { acc += (double)a[r][ty] * (double)b[r][tx]; if (blockIdx.x == 0 && tx == 0) accf += (double)a[r][ty]; }
+    __syncthreads();
+  }
+  if (c1 < C && c2 < C) sum_ff[(long long)c1 * C + c2] += acc;
+  if (blockIdx.x == 0 && tx == 0 && c1 < C) sum_f[c1] += accf;
+}
+extern "C" int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s) {
+  SG_CHECK(f && sum_f && sum_ff && n > 0 && C > 0, "sg_feat_moments_accumulate: bad args");
+  hipLaunchKernelGGL(k_feat_moments, dim3((C + 15) / 16, (C + 15) / 16), dim3(256), 0, (hipStream_t)s, f, n, C, sum_f, sum_ff);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,238 @@
+// norm.hip -- BatchNorm2d(eps=1e-4, momentum=0.1) and ConditionalBatchNorm2d forward/backward on NHWC tensors
+// (reference src/utils/ops.py:14-28,227-228). Statistics are produced as fp64 partial sums {sum x, sum x^2}
+// so that the cross-rank reduction of sync-BN is ONE small all-reduce between sg_bn_partial_stats and
+// sg_bn_finalize (reference src/models/model.py:161-165 uses nn.SyncBatchNorm's all_gather instead).
+// HBM-bound: every kernel streams 16-byte vectors along C.
+#include "common.h"
+#include "../../include/sgamd.h"
+
+#define DISPATCH_T(dtype, ...)                                          \
+  if ((dtype) == SG_DTYPE_F32) { typedef float T; __VA_ARGS__; }        \
+  else if ((dtype) == SG_DTYPE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
+  else { sg_set_error("bad dtype"); return -1; }
+
+template <typename T> __device__ __forceinline__ void unpack16(u32x4 v, float* o);
+template <> __device__ __forceinline__ void unpack16<float>(u32x4 v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = __uint_as_float(v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(u32x4 v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* o);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* o) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = __float_as_uint(o[i]);
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* o) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+  return v;
+}
+
+// ---- statistics ------------------------------------------------------------------------------------------
+template <typename T> __global__ __launch_bounds__(256) void k_bn_partial(const T* x, int ldx, long long rows, int C, double* partial, long long rpb) {
+  __shared__ double sm[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  long long r0 = blockIdx.y * rpb, r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (long long r = r0 + ry; r < r1; r += 4) {
+      const double v = (double)to_f<T>(x[r * ldx + c]);
+      s1 += v; s2 += v * v;
+    }
+  }
+  sm[0][ry][cx] = s1; sm[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    atomicAdd(partial + 2 * c, sm[0][0][cx] + sm[0][1][cx] + sm[0][2][cx] + sm[0][3][cx]);
+    atomicAdd(partial + 2 * c + 1, sm[1][0][cx] + sm[1][1][cx] + sm[1][2][cx] + sm[1][3][cx]);
+  }
+}
+extern "C" int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_stream_t s) {
+  SG_CHECK(x && partial && rows > 0 && C > 0, "sg_bn_partial_stats: bad args");
+  int ct = (C + 63) / 64;
+  long long want = 2048 / ct; if (want < 1) want = 1;
+  long long rpb = (rows + want - 1) / want; if (rpb < 64) rpb = 64;
+  int gy = (int)((rows + rpb - 1) / rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_partial<T>, dim3(ct, gy), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, rows, C, partial, rpb));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd, float* rm, float* rv) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double m = partial[2 * c] / count;
+  double var = partial[2 * c + 1] / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  invstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (rm) {
+    const double unb = (count > 1.0) ? var * count / (count - 1.0) : var;
+    rm[c] = (1.f - momentum) * rm[c] + momentum * (float)m;
+    rv[c] = (1.f - momentum) * rv[c] + momentum * (float)unb;
+  }
+}
+extern "C" int sg_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd, float* running_mean, float* running_var, sg_stream_t s) {
+  SG_CHECK(partial && mean && invstd && count > 0, "sg_bn_finalize: bad args");
+  SG_CHECK((running_mean == nullptr) == (running_var == nullptr), "sg_bn_finalize: running stats must come as a pair");
+  hipLaunchKernelGGL(k_bn_finalize, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, partial, count, C, eps, momentum, mean, invstd, running_mean, running_var);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_bn_from_running(const float* rm, const float* rv, int C, float eps, float* mean, float* invstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = rm[c];
+  invstd[c] = 1.f / sqrtf(rv[c] + eps);
+}
+extern "C" int sg_bn_from_running(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, sg_stream_t s) {
+  SG_CHECK(running_mean && running_var && mean && invstd, "sg_bn_from_running: null");
+  hipLaunchKernelGGL(k_bn_from_running, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)s, running_mean, running_var, C, eps, mean, invstd);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- apply -------------------------------------------------------------------------------------------------
+// one thread = one 16-byte vector of channels; requires C % VEC == 0 (checked on the host; scalar kernel otherwise)
+template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_apply(const T* x, T* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu) {
+  constexpr int V = VECP ? ET<T>::VEC : 1;
+  const int CV = C / V;
+  const long long total = (long long)N * HW * CV;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cv = (int)(i % CV); const long long pix = i / CV; const int n = (int)(pix / HW);
+    const int c0 = cv * V;
+    float xv[V];
+    if (VECP) unpack16<T>(*(const u32x4*)(x + pix * C + c0), xv); else xv[0] = to_f<T>(x[pix * C + c0]);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const int c = c0 + e;
+      // same evaluation order as the backward's recomputation (xhat * gain + bias)
+      const float xh = (xv[e] - mean[c]) * invstd[c];
+      const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
+      const float bi = bias ? bias[(long long)n * gsn + c] : 0.f;
+      float v = xh * ga + bi;
+      if (relu) v = fmaxf(v, 0.f);
+      xv[e] = v;
+    }
+    if (VECP) *(u32x4*)(y + pix * C + c0) = pack16<T>(xv); else y[pix * C + c0] = from_f<T>(xv[0]);
+  }
+}
+static inline int grid_for(long long total) { long long b = (total + 255) / 256; if (b > 256 * 32) b = 256 * 32; if (b < 1) b = 1; return (int)b; }
+template <typename T> static bool vec_ok(const void* a, const void* b, int C) {
+  return (C % ET<T>::VEC == 0) && ((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0;
+}
+extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s) {
+  SG_CHECK(x && y && mean && invstd, "sg_bn_apply: null");
+  DISPATCH_T(dtype, {
+    if (vec_ok<T>(x, y, C)) hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
+    else hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
+  });
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward ----------------------------------------------------------------------------------------------
+// stage 1: sums[n][c] = {sum_hw dy', sum_hw dy' * xhat}; grid (channel tiles, hw chunks, N); caller zeroes sums
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_reduce(const T* x, const T* dy, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, float* sums, long long rpb) {
+  __shared__ float sm[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int n = blockIdx.z;
+  long long r0 = blockIdx.y * rpb, r1 = r0 + rpb; if (r1 > HW) r1 = HW;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
+    const float bi = bias ? bias[(long long)n * gsn + c] : 0.f;
+    const T* xp = x + (long long)n * HW * C + c;
+    const T* gp = dy + (long long)n * HW * C + c;
+    for (long long r = r0 + ry; r < r1; r += 4) {
+      const float xh = (to_f<T>(xp[r * C]) - mu) * is;
+      float g = to_f<T>(gp[r * C]);
+      if (relu && !(xh * ga + bi > 0.f)) g = 0.f;
+      s1 += g; s2 += g * xh;
+    }
+  }
+  sm[0][ry][cx] = s1; sm[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float* o = sums + ((long long)n * C + c) * 2;
+    unsafeAtomicAdd(o, sm[0][0][cx] + sm[0][1][cx] + sm[0][2][cx] + sm[0][3][cx]);
+    unsafeAtomicAdd(o + 1, sm[1][0][cx] + sm[1][1][cx] + sm[1][2][cx] + sm[1][3][cx]);
+  }
+}
+extern "C" int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, float* sums, sg_stream_t s) {
+  SG_CHECK(x && dy && mean && invstd && sums, "sg_bn_bwd_reduce: null");
+  SG_CHECK(N <= 65535, "sg_bn_bwd_reduce: batch too large for grid.z");
+  int ct = (C + 63) / 64;
+  long long want = 2048 / ((long long)ct * N); if (want < 1) want = 1;
+  long long rpb = (HW + want - 1) / want; if (rpb < 16) rpb = 16;
+  int gy = (int)((HW + rpb - 1) / rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd_reduce<T>, dim3(ct, gy, N), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, sums, rpb));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ void k_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gsn, float* dgain, float* dbias, double* chan) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a0 = 0.0, a1 = 0.0; float g0 = 0.f, g1 = 0.f;
+  for (int n = 0; n < N; n++) {
+    const float s1 = sums[((long long)n * C + c) * 2], s2 = sums[((long long)n * C + c) * 2 + 1];
+    const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
+    a0 += (double)ga * s1; a1 += (double)ga * s2;
+    if (gsn) {
+      if (dgain) dgain[(long long)n * C + c] += s2;
+      if (dbias) dbias[(long long)n * C + c] += s1;
+    } else { g0 += s1; g1 += s2; }
+  }
+  if (!gsn) { if (dgain) dgain[c] += g1; if (dbias) dbias[c] += g0; }
+  chan[2 * c] = a0; chan[2 * c + 1] = a1;
+}
+extern "C" int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gb_stride_n, float* dgain, float* dbias, double* chan, sg_stream_t s) {
+  SG_CHECK(sums && chan, "sg_bn_bwd_finalize: null");
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, sums, N, C, gain, gb_stride_n, dgain, dbias, chan);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* x, const T* dy, T* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch) {
+  constexpr int V = VECP ? ET<T>::VEC : 1;
+  const int CV = C / V;
+  const long long total = (long long)N * HW * CV;
+  const float invc = (float)(1.0 / count);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int cv = (int)(i % CV); const long long pix = i / CV; const int n = (int)(pix / HW);
+    const int c0 = cv * V;
+    float xv[V], gv[V];
+    if (VECP) { unpack16<T>(*(const u32x4*)(x + pix * C + c0), xv); unpack16<T>(*(const u32x4*)(dy + pix * C + c0), gv); }
+    else { xv[0] = to_f<T>(x[pix * C + c0]); gv[0] = to_f<T>(dy[pix * C + c0]); }
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const int c = c0 + e;
+      const float is = invstd[c];
+      const float xh = (xv[e] - mean[c]) * is;
+      const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
+      const float bi = bias ? bias[(long long)n * gsn + c] : 0.f;
+      float g = gv[e];
+      if (relu && !(xh * ga + bi > 0.f)) g = 0.f;
+      float d = ga * g;
+      if (use_batch) d -= ((float)chan[2 * c] + xh * (float)chan[2 * c + 1]) * invc;
+      xv[e] = d * is;
+    }
+    if (VECP) *(u32x4*)(dx + pix * C + c0) = pack16<T>(xv); else dx[pix * C + c0] = from_f<T>(xv[0]);
+  }
+}
+extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, const double* chan, double count, int use_batch_stats, sg_stream_t s) {
+  SG_CHECK(x && dy && dx && mean && invstd && chan && count > 0, "sg_bn_bwd_apply: bad args");
+  DISPATCH_T(dtype, {
+    if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0)) hipLaunchKernelGGL((k_bn_bwd_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
+    else hipLaunchKernelGGL((k_bn_bwd_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
+  });
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,190 @@
+// sn.hip -- spectral normalisation for every SN layer of a network in a handful of batched launches.
+// Follows torch.nn.utils.spectral_norm (installed torch/nn/utils/spectral_norm.py: compute_weight), which is what
+// reference src/utils/ops.py:195-224 wraps around Conv2d / Linear / Embedding with eps=1e-6:
+//     v <- normalize(W^T u, eps) ; u <- normalize(W v, eps)        (only while module.training)
+//     sigma = u . (W v) ; W_sn = W / sigma
+// The same pass casts W_sn to the compute dtype and writes the two operand images the convolution engine wants
+// ([Cout][R][S][Cin] for forward, [Cin][R-1-r][S-1-s][Cout] for the data gradient), so the normalised weight is
+// never re-laid-out again. Work is weight-sized and HBM-bound (3 reads of W per forward).
+// All reductions use a fixed order (no atomics): replicas on different GPUs stay bit-identical, which is what
+// lets the data-parallel path skip the reference's per-forward buffer broadcast (DDP broadcast_buffers).
+#include "common.h"
+#include "../../include/sgamd.h"
+
+#define SN_SPLITS 8
+
+// grid (col tiles, SN_SPLITS, layers)
+__global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* work) {
+  const sg_sn_layer l = L[blockIdx.z];
+  if (!l.apply_sn || !l.do_power_iter) return;
+  const int k = blockIdx.x * 256 + threadIdx.x;
+  if (k >= l.cols) return;
+  const int per = (l.rows + SN_SPLITS - 1) / SN_SPLITS;
+  int o0 = blockIdx.y * per, o1 = o0 + per; if (o1 > l.rows) o1 = l.rows;
+  float acc = 0.f;
+  for (int o = o0; o < o1; o++) acc += l.w[(long long)o * l.cols + k] * l.u[o];
+  work[l.work_off + (long long)blockIdx.y * l.cols + k] = acc;
+}
+// grid (layers): v = normalize(sum of partials)
+__global__ __launch_bounds__(256) void k_sn_v(const sg_sn_layer* L, float* work, float eps) {
+  __shared__ float sm[4];
+  const sg_sn_layer l = L[blockIdx.x];
+  if (!l.apply_sn || !l.do_power_iter) return;
+  float* part = work + l.work_off;
+  float nn = 0.f;
+  for (int k = threadIdx.x; k < l.cols; k += 256) {
+    float t = 0.f;
+#pragma unroll
+    for (int s = 0; s < SN_SPLITS; s++) t += part[(long long)s * l.cols + k];
+    part[k] = t;  // same thread re-reads it below
+    nn += t * t;
+  }
+  nn = block_sum_256(nn, sm);
+  const float inv = 1.f / fmaxf(sqrtf(nn), eps);
+  for (int k = threadIdx.x; k < l.cols; k += 256) l.v[k] = part[k] * inv;
+}
+// grid (row tiles of 4, layers): one wave per row, t_u[o] = W[o,:] . v
+__global__ __launch_bounds__(256) void k_sn_wv(const sg_sn_layer* L, float* work) {
+  const sg_sn_layer l = L[blockIdx.y];
+  if (!l.apply_sn) return;
+  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (o >= l.rows) return;
+  const int lane = threadIdx.x & 63;
+  const float* wr = l.w + (long long)o * l.cols;
+  float acc = 0.f;
+  for (int k = lane; k < l.cols; k += 64) acc += wr[k] * l.v[k];
+  acc = wave_sum(acc);
+  if (lane == 0) work[l.work_off + (long long)SN_SPLITS * l.cols + o] = acc;
+}
+// grid (layers): u, sigma
+__global__ __launch_bounds__(256) void k_sn_u(const sg_sn_layer* L, float* work, float eps) {
+  __shared__ float sm[4];
+  const sg_sn_layer l = L[blockIdx.x];
+  if (!l.apply_sn) { if (threadIdx.x == 0) l.sigma[0] = 1.f; return; }
+  const float* tu = work + l.work_off + (long long)SN_SPLITS * l.cols;
+  float sig;
+  if (l.do_power_iter) {
+    float nn = 0.f;
+    for (int o = threadIdx.x; o < l.rows; o += 256) nn += tu[o] * tu[o];
+    nn = block_sum_256(nn, sm);
+    const float inv = 1.f / fmaxf(sqrtf(nn), eps);
+    float dot = 0.f;
+    for (int o = threadIdx.x; o < l.rows; o += 256) { const float un = tu[o] * inv; l.u[o] = un; dot += un * tu[o]; }
+    sig = block_sum_256(dot, sm);
+  } else {
+    float dot = 0.f;
+    for (int o = threadIdx.x; o < l.rows; o += 256) dot += l.u[o] * tu[o];
+    sig = block_sum_256(dot, sm);
+  }
+  if (threadIdx.x == 0) l.sigma[0] = sig;
+  if (l.u_snap) for (int o = threadIdx.x; o < l.rows; o += 256) l.u_snap[o] = l.u[o];
+  if (l.v_snap) for (int k = threadIdx.x; k < l.cols; k += 256) l.v_snap[k] = l.v[k];
+}
+// grid (element tiles, layers): W / sigma -> operand images
+template <typename T> __global__ __launch_bounds__(256) void k_sn_pack(const sg_sn_layer* L) {
+  const sg_sn_layer l = L[blockIdx.y];
+  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;
+  const long long total = (long long)rows_out * l.cols;
+  const float sig = l.sigma[0];
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int o = (int)(i / l.cols), k = (int)(i % l.cols);
+    const int c = k / l.RS, rs = k - c * l.RS;
+    float val = 0.f;
+    if (o < l.rows) {
+      val = l.w[i] / sig;
+      if (l.w_f32) l.w_f32[i] = val;
+      if (l.w_dgrad) ((T*)l.w_dgrad)[((long long)c * l.RS + (l.RS - 1 - rs)) * l.rows + o] = from_f<T>(val);
+    }
+    if (l.w_fwd) ((T*)l.w_fwd)[((long long)o * l.RS + rs) * l.Cin + c] = from_f<T>(val);
+  }
+}
+
+extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s) {
+  SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_forward: bad args");
+  int max_rows = 1, max_cols = 1; long long max_elems = 1; bool any_sn = false, any_pi = false;
+  for (int i = 0; i < n; i++) {
+    const sg_sn_layer& l = layers_host[i];
+    SG_CHECK(l.w && l.sigma && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_forward: bad layer");
+    if (l.apply_sn) {
+      SG_CHECK(l.u && l.v, "sg_sn_forward: SN layer without u/v");
+      SG_CHECK(l.work_off >= 0 && l.work_off + (long long)SN_SPLITS * l.cols + l.rows <= work_floats, "sg_sn_forward: workspace too small");
+      any_sn = true; if (l.do_power_iter) any_pi = true;
+    }
+    if (l.rows > max_rows) max_rows = l.rows;
+    if (l.cols > max_cols) max_cols = l.cols;
+    const long long e = (long long)(l.rows_pad > l.rows ? l.rows_pad : l.rows) * l.cols;
+    if (e > max_elems) max_elems = e;
+  }
+  hipStream_t st = (hipStream_t)s;
+  if (any_pi) {
+    hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 255) / 256, SN_SPLITS, n), dim3(256), 0, st, layers_dev, work);
+    hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  }
+  if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, n), dim3(256), 0, st, layers_dev, work);
+  hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+  if (dtype == SG_DTYPE_F32) hipLaunchKernelGGL(k_sn_pack<float>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
+  else if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_sn_pack<bf16_t>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
+  else { sg_set_error("sg_sn_forward: bad dtype"); return -1; }
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- backward: dW = (dWt - <dWt, W/sigma> u v^T) / sigma --------------------------------------------------
+#define SNB_BLOCKS 64
+__device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int o, int k) {
+  if (l.natural) return (long long)o * l.cols + k;
+  const int c = k / l.RS, rs = k - c * l.RS;
+  return ((long long)o * l.RS + rs) * l.Cin + c;
+}
+// grid (SNB_BLOCKS, layers): block partials of <dWt, W>
+__global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float* work) {
+  __shared__ float sm[4];
+  const sg_sn_bwd_layer l = L[blockIdx.y];
+  if (!l.apply_sn) return;
+  const long long total = (long long)l.rows * l.cols;
+  float acc = 0.f;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
+    const int o = (int)(i / l.cols), k = (int)(i % l.cols);
+    acc += l.dwt[snb_src_index(l, o, k)] * l.w[i];
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
+}
+// grid (tiles, layers)
+__global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, const float* work) {
+  const sg_sn_bwd_layer l = L[blockIdx.y];
+  const long long total = (long long)l.rows * l.cols;
+  float sig = 1.f, coef = 0.f;
+  if (l.apply_sn) {
+    sig = l.sigma[0];
+    float d = 0.f;
+    for (int b = 0; b < SNB_BLOCKS; b++) d += work[(long long)blockIdx.y * SNB_BLOCKS + b];
+    coef = d / sig;  // <dWt, W/sigma>
+  }
+  const float inv = 1.f / sig;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int o = (int)(i / l.cols), k = (int)(i % l.cols);
+    float g = l.dwt[snb_src_index(l, o, k)];
+    if (l.apply_sn) g = (g - coef * l.u[o] * l.v[k]) * inv;
+    l.dw[i] += g;
+  }
+}
+extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s) {
+  SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_backward: bad args");
+  SG_CHECK((long long)n * SNB_BLOCKS <= work_floats, "sg_sn_backward: workspace too small");
+  long long max_elems = 1; bool any_sn = false;
+  for (int i = 0; i < n; i++) {
+    const sg_sn_bwd_layer& l = layers_host[i];
+    SG_CHECK(l.dwt && l.dw && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_backward: bad layer");
+    if (l.apply_sn) { SG_CHECK(l.w && l.u && l.v && l.sigma, "sg_sn_backward: SN layer without state"); any_sn = true; }
+    const long long e = (long long)l.rows * l.cols;
+    if (e > max_elems) max_elems = e;
+  }
+  hipStream_t st = (hipStream_t)s;
+  if (any_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
+  long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+  hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
