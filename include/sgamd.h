@@ -79,6 +79,7 @@ typedef struct {
   int R, S, stride, pad_h, pad_w;
   float alpha;
   const void* x; const void* dy; float* dw;
+  const float* alpha_ptr;          /* optional device scalar multiplied into alpha */
   int splits;                      /* 0 = auto */
   int no_tr;                       /* 1 = use the gather fragment path instead of ds_read_b64_tr_b16 (test hook) */
 } sg_conv_wgrad_desc;
@@ -113,7 +114,12 @@ int sg_maxpool2_bwd(int dtype, const void* dy, int ldy, const uint8_t* idx, void
 /* row softmax: fp32 logits [rows][cols] -> probabilities as T; bwd: ds(T) = p * (dp(fp32) - sum(dp*p)) */
 int sg_softmax_rows(int dtype, const float* s_in, void* p_out, long long rows, int cols, sg_stream_t st);
 int sg_softmax_rows_bwd(int dtype, const void* p, const float* dp, void* ds, long long rows, int cols, sg_stream_t st);
-/* y = a*x + b*y elementwise on T tensors; scalars may come from device memory */
+/* element type conversion between SG dtypes */
+int sg_convert(int src_dtype, int dst_dtype, const void* x, void* y, long long n, sg_stream_t s);
+/* out = a + relu(x) (identity-skip DiscBlock, reference models/big_resnet.py:221-242 with the in-place ReLU) ; dx = dy*(x>0) */
+int sg_add_relu(int dtype, const void* a, const void* x, void* out, long long n, sg_stream_t s);
+int sg_relu_mask(int dtype, const void* dy, const void* x, void* dx, long long n, sg_stream_t s);
+/* y = a*x + b*y elementwise on T tensors */
 int sg_axpby(int dtype, const void* x, void* y, long long n, float a, float b, sg_stream_t s);
 /* out[0] (+)= sum(x*y) over n elements of T (fp32 accumulate, deterministic two-stage when accumulate=0) */
 int sg_dot(int dtype, const void* x, const void* y, long long n, float* out, float scale, const float* scale_ptr, sg_stream_t s);

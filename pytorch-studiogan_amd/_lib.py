@@ -1,0 +1,170 @@
+"""ctypes binding of libsgamd.so (the C ABI declared in include/sgamd.h).
+
+The product path has NO fallback: if the HIP library is missing or a kernel is asked to run on a non-GPU
+tensor, we raise. (The CPU oracle under /oracle is test infrastructure and is never imported from here.)
+"""
+import ctypes as C
+import os
+import subprocess
+import sys
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsgamd.so")
+CSRC = os.path.join(_HERE, "csrc")
+
+F32, BF16 = 0, 1
+PIX_RELU, PIX_UPSAMPLE, PIX_QUAD, PIX_TRANSPOSED = 1, 2, 4, 8
+EPI_OUT_F32, EPI_ATOMIC, EPI_POOL, EPI_RELU, EPI_RES_F32 = 1, 2, 4, 8, 16
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+
+class ConvFwdDesc(C.Structure):
+    _fields_ = [("dtype", _i), ("N", _i), ("Hs", _i), ("Ws", _i), ("C", _i), ("ldx", _i), ("Ho", _i), ("Wo", _i), ("Cout", _i),
+                ("R", _i), ("S", _i), ("stride", _i), ("pad_h", _i), ("pad_w", _i), ("pix_flags", _i), ("epi_flags", _i),
+                ("alpha", _f), ("beta", _f), ("x", _vp), ("w", _vp), ("bias", _vp), ("res", _vp), ("mask", _vp), ("out", _vp),
+                ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i)]
+
+
+class ConvWgradDesc(C.Structure):
+    _fields_ = [("dtype", _i), ("N", _i), ("xHs", _i), ("xWs", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("gHs", _i), ("gWs", _i),
+                ("Cout", _i), ("ldg", _i), ("g_flags", _i), ("Ho", _i), ("Wo", _i), ("R", _i), ("S", _i), ("stride", _i),
+                ("pad_h", _i), ("pad_w", _i), ("alpha", _f), ("x", _vp), ("dy", _vp), ("dw", _vp), ("alpha_ptr", _vp),
+                ("splits", _i), ("no_tr", _i)]
+
+
+class GemmDesc(C.Structure):
+    _fields_ = [("dtype", _i), ("p_form", _i), ("q_form", _i), ("I", _i), ("J", _i), ("K", _i), ("batch", _i),
+                ("p", _vp), ("p_bstride", _ll), ("ldp", _i), ("q", _vp), ("q_bstride", _ll), ("ldq", _i),
+                ("out", _vp), ("out_bstride", _ll), ("ldo", _i), ("bias", _vp), ("res", _vp), ("res_bstride", _ll), ("ldr", _i),
+                ("beta", _f), ("alpha", _f), ("alpha_ptr", _vp), ("epi_flags", _i), ("splits", _i), ("no_tr", _i)]
+
+
+class SnLayer(C.Structure):
+    _fields_ = [("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("u_snap", _vp), ("v_snap", _vp), ("w_fwd", _vp), ("w_dgrad", _vp),
+                ("w_f32", _vp), ("rows", _i), ("cols", _i), ("Cin", _i), ("RS", _i), ("do_power_iter", _i), ("apply_sn", _i),
+                ("rows_pad", _i), ("work_off", _ll)]
+
+
+class SnBwdLayer(C.Structure):
+    _fields_ = [("dwt", _vp), ("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("dw", _vp), ("rows", _i), ("cols", _i),
+                ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i)]
+
+
+_lib = None
+
+
+def build(force=False, verbose=False):
+    """Compile every HIP source for gfx950 into libsgamd.so (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", CSRC, "-j", str(max(2, os.cpu_count() or 2))]
+    if force:
+        subprocess.run(["make", "-C", CSRC, "clean"], check=True, stdout=subprocess.DEVNULL)
+    res = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if verbose or res.returncode != 0:
+        sys.stderr.write(res.stdout)
+    if res.returncode != 0:
+        raise RuntimeError("building libsgamd.so failed")
+    return LIB_PATH
+
+
+_PROTOS = {
+    "sg_conv2d_fwd": [C.POINTER(ConvFwdDesc), _vp],
+    "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
+    "sg_gemm": [C.POINTER(GemmDesc), _vp],
+    "sg_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_nhwc_to_nchw": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_nchw_grad_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_avgpool2_fwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sg_avgpool2_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sg_maxpool2_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],
+    "sg_maxpool2_bwd": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_softmax_rows": [_i, _vp, _vp, _ll, _i, _vp],
+    "sg_softmax_rows_bwd": [_i, _vp, _vp, _vp, _ll, _i, _vp],
+    "sg_axpby": [_i, _vp, _vp, _ll, _f, _f, _vp],
+    "sg_convert": [_i, _i, _vp, _vp, _ll, _vp],
+    "sg_add_relu": [_i, _vp, _vp, _vp, _ll, _vp],
+    "sg_relu_mask": [_i, _vp, _vp, _vp, _ll, _vp],
+    "sg_dot": [_i, _vp, _vp, _ll, _vp, _f, _vp, _vp],
+    "sg_colsum": [_i, _vp, _i, _vp, _i, _ll, _i, _vp, _f, _vp],
+    "sg_bn_partial_stats": [_i, _vp, _i, _ll, _i, _vp, _vp],
+    "sg_bn_finalize": [_vp, C.c_double, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_bn_from_running": [_vp, _vp, _i, _f, _vp, _vp, _vp],
+    "sg_bn_apply": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sg_bn_bwd_reduce": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
+    "sg_bn_bwd_finalize": [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
+    "sg_bn_bwd_apply": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _i, _vp],
+    "sg_sn_forward": [_i, _vp, C.POINTER(SnLayer), _i, _f, _vp, _ll, _vp],
+    "sg_sn_backward": [_vp, C.POINTER(SnBwdLayer), _i, _vp, _ll, _vp],
+    "sg_embedding_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sg_embedding_bwd": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sg_relu_sum_hw_fwd": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "sg_relu_sum_hw_bwd": [_i, _vp, _vp, _vp, _i, _i, _i, _vp],
+    "sg_pd_head_fwd": [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sg_pd_head_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sg_loss_d": [_i, _vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "sg_loss_g": [_i, _vp, _i, _vp, _vp, _vp],
+    "sg_adam_ema": [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _f, _vp],
+    "sg_ema_lerp": [_vp, _vp, _ll, _f, _vp],
+    "sg_quantize_resize_normalize": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_pool2d": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
+    "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
+}
+
+
+def exported_symbols():
+    """Names every entry point include/sgamd.h declares (used by the CPU-side ABI test)."""
+    return sorted(list(_PROTOS.keys()) + ["sg_last_error", "sg_version"])
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"{LIB_PATH} is missing: run `python -c 'import __graft_entry__ as g; g.build()'` (make -C {CSRC}). "
+                "There is no CPU/eager fallback on the product path.")
+        l = C.CDLL(LIB_PATH)
+        l.sg_last_error.restype = C.c_char_p
+        l.sg_version.restype = _i
+        for name, args in _PROTOS.items():
+            fn = getattr(l, name)
+            fn.argtypes = args
+            fn.restype = _i
+        _lib = l
+    return _lib
+
+
+def check(rc, name=""):
+    if rc != 0:
+        raise RuntimeError(f"{name}: {lib().sg_last_error().decode()} (rc={rc})")
+
+
+def call(name, *args):
+    rc = getattr(lib(), name)(*args)
+    if rc != 0:
+        raise RuntimeError(f"{name}: {lib().sg_last_error().decode()} (rc={rc})")
+
+
+def stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dt(t):
+    """SG dtype code of a tensor / torch dtype."""
+    d = t if isinstance(t, torch.dtype) else t.dtype
+    if d == torch.float32:
+        return F32
+    if d == torch.bfloat16:
+        return BF16
+    raise RuntimeError(f"unsupported dtype {d} (float32 / bfloat16 only)")
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("studiogan_amd kernels need a GPU tensor (no CPU fallback on the product path)")
+    return t.data_ptr()

@@ -1,0 +1,274 @@
+"""BigGAN generator / discriminator with the reference's constructor and forward contracts
+(reference src/models/big_resnet.py:45-158, 245-428; imported by name through src/models/model.py:22), built from
+studiogan_amd.ops modules. Module / parameter / buffer names are identical to the reference's, so state_dicts
+interchange. Each block is a short chain of fused launches:
+
+  GenBlock   cBN+ReLU -> [up x2 + conv3x3] -> cBN+ReLU -> conv3x3 -> [up x2 + conv1x1 + residual add]     (5 launches + 4 tiny GEMMs)
+  DiscBlock  [ReLU + conv3x3] -> [ReLU + conv3x3 + avgpool] -> [ReLU + conv1x1 + avgpool + residual add]  (3 launches)
+
+compute dtype: bf16 activations / weight images with fp32 accumulation, statistics, master weights and gradients when
+`mixed_precision=True` (the reference's fp16 autocast + GradScaler, big_resnet.py:124,350, becomes scaler-free bf16),
+fp32 otherwise.
+"""
+import torch
+import torch.nn as nn
+
+from .. import functional as F
+from .. import ops
+from ..bank import get_bank
+
+
+def _dtype(mixed_precision):
+    return torch.bfloat16 if mixed_precision else torch.float32
+
+
+def _need_graph(module, *inputs):
+    if not torch.is_grad_enabled():
+        return False
+    for t in inputs:
+        if torch.is_tensor(t) and t.requires_grad:
+            return True
+    for p in module.parameters():
+        return p.requires_grad
+    return False
+
+
+class GenBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, g_cond_mtd, affine_input_dim, MODULES):
+        super().__init__()
+        self.g_cond_mtd = g_cond_mtd
+        self.bn1 = MODULES.g_bn(affine_input_dim, in_channels, MODULES)
+        self.bn2 = MODULES.g_bn(affine_input_dim, out_channels, MODULES)
+        self.activation = MODULES.g_act_fn
+        self.conv2d0 = MODULES.g_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, stride=1, padding=0)
+        self.conv2d1 = MODULES.g_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv2d2 = MODULES.g_conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+
+    def forward_nhwc(self, x, affine, slot):
+        h = self.bn1.forward_nhwc(x, affine, slot, relu=True)
+        h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True)
+        h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
+        h = self.conv2d2.forward_nhwc(h, slot)
+        return self.conv2d0.forward_nhwc(x, slot, in_upsample=True, res=h)
+
+
+class Generator(nn.Module):
+    def __init__(self, z_dim, g_shared_dim, img_size, g_conv_dim, apply_attn, attn_g_loc, g_cond_mtd, num_classes, g_init, g_depth,
+                 mixed_precision, MODULES, MODEL):
+        super().__init__()
+        g_in_dims_collection = {
+            "32": [g_conv_dim * 4, g_conv_dim * 4, g_conv_dim * 4],
+            "64": [g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2],
+            "128": [g_conv_dim * 16, g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2],
+            "256": [g_conv_dim * 16, g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2],
+            "512": [g_conv_dim * 16, g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2, g_conv_dim]
+        }
+        g_out_dims_collection = {
+            "32": [g_conv_dim * 4, g_conv_dim * 4, g_conv_dim * 4],
+            "64": [g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2, g_conv_dim],
+            "128": [g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2, g_conv_dim],
+            "256": [g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2, g_conv_dim],
+            "512": [g_conv_dim * 16, g_conv_dim * 8, g_conv_dim * 8, g_conv_dim * 4, g_conv_dim * 2, g_conv_dim, g_conv_dim]
+        }
+        self.z_dim = z_dim
+        self.g_shared_dim = g_shared_dim
+        self.g_cond_mtd = g_cond_mtd
+        self.num_classes = num_classes
+        self.mixed_precision = mixed_precision
+        self.MODEL = MODEL
+        self.in_dims = g_in_dims_collection[str(img_size)]
+        self.out_dims = g_out_dims_collection[str(img_size)]
+        self.bottom = 4
+        self.num_blocks = len(self.in_dims)
+        self.chunk_size = z_dim // (self.num_blocks + 1)
+        self.affine_input_dim = self.chunk_size
+        assert self.z_dim % (self.num_blocks + 1) == 0, "z_dim should be divided by the number of blocks"
+        if getattr(MODEL, "info_type", "N/A") != "N/A":
+            raise NotImplementedError("InfoGAN heads are outside the benchmarked hot path (SURVEY.md §8f)")
+
+        self.linear0 = MODULES.g_linear(in_features=self.chunk_size, out_features=self.in_dims[0] * self.bottom * self.bottom, bias=True)
+        if self.g_cond_mtd != "W/O":
+            self.affine_input_dim += self.g_shared_dim
+            self.shared = ops.embedding(num_embeddings=self.num_classes, embedding_dim=self.g_shared_dim)
+
+        blocks = []
+        for index in range(self.num_blocks):
+            blocks += [[GenBlock(in_channels=self.in_dims[index], out_channels=self.out_dims[index], g_cond_mtd=self.g_cond_mtd,
+                                 affine_input_dim=self.affine_input_dim, MODULES=MODULES)]]
+            if index + 1 in attn_g_loc and apply_attn:
+                blocks += [[ops.SelfAttention(self.out_dims[index], is_generator=True, MODULES=MODULES)]]
+        self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])
+
+        self.bn4 = ops.batchnorm_2d(in_features=self.out_dims[-1])
+        self.activation = MODULES.g_act_fn
+        self.conv2d5 = MODULES.g_conv2d(in_channels=self.out_dims[-1], out_channels=3, kernel_size=3, stride=1, padding=1)
+        self.tanh = nn.Tanh()
+        ops.init_weights(self.modules, g_init)
+        ops.adopt(self, _dtype(mixed_precision))
+
+    def forward(self, z, label, shared_label=None, eval=False):
+        dtype = self.compute_dtype
+        bank = get_bank(self, dtype)
+        slot = bank.begin_forward(_need_graph(self, z, shared_label))
+        zs = torch.split(z, self.chunk_size, 1)
+        z0 = zs[0]
+        affine_list = []
+        if self.g_cond_mtd != "W/O":
+            if shared_label is None:
+                shared_label = self.shared(label)
+            affine_list.append(shared_label)
+        if len(affine_list) == 0:
+            affines = [item for item in zs[1:]]
+        else:
+            affines = [torch.cat(affine_list + [item], 1) for item in zs[1:]]
+
+        act = self.linear0.forward_rt(z0, slot)
+        act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
+        counter = 0
+        for blocklist in self.blocks:
+            for block in blocklist:
+                if isinstance(block, ops.SelfAttention):
+                    act = block.forward_nhwc(act, slot)
+                else:
+                    act = block.forward_nhwc(act, affines[counter], slot)
+                    counter += 1
+        act = self.bn4.forward_nhwc(act, relu=True)
+        act = self.conv2d5.forward_nhwc(act, slot)
+        return F.NhwcToNchwFn.apply(act, True)
+
+
+class DiscOptBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, apply_d_sn, MODULES):
+        super().__init__()
+        self.apply_d_sn = apply_d_sn
+        self.conv2d0 = MODULES.d_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, stride=1, padding=0)
+        self.conv2d1 = MODULES.d_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv2d2 = MODULES.d_conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+        if not apply_d_sn:
+            self.bn0 = MODULES.d_bn(in_features=in_channels)
+            self.bn1 = MODULES.d_bn(in_features=out_channels)
+        self.activation = MODULES.d_act_fn
+        self.average_pooling = nn.AvgPool2d(2)
+
+    def forward_nhwc(self, x, slot):
+        h = self.conv2d1.forward_nhwc(x, slot)
+        if not self.apply_d_sn:
+            h = self.bn1.forward_nhwc(h, relu=True)
+            h = self.conv2d2.forward_nhwc(h, slot, out_pool=True)
+        else:
+            h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=True)
+        x0 = F.AvgPool2Fn.apply(x)
+        if not self.apply_d_sn:
+            x0 = self.bn0.forward_nhwc(x0)
+        return self.conv2d0.forward_nhwc(x0, slot, res=h)
+
+
+class DiscBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, apply_d_sn, MODULES, downsample=True):
+        super().__init__()
+        self.apply_d_sn = apply_d_sn
+        self.downsample = downsample
+        self.activation = MODULES.d_act_fn
+        self.ch_mismatch = in_channels != out_channels
+        if self.ch_mismatch or downsample:
+            self.conv2d0 = MODULES.d_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=1, stride=1, padding=0)
+            if not apply_d_sn:
+                self.bn0 = MODULES.d_bn(in_features=in_channels)
+        self.conv2d1 = MODULES.d_conv2d(in_channels=in_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+        self.conv2d2 = MODULES.d_conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
+        if not apply_d_sn:
+            self.bn1 = MODULES.d_bn(in_features=in_channels)
+            self.bn2 = MODULES.d_bn(in_features=out_channels)
+        self.average_pooling = nn.AvgPool2d(2)
+
+    def forward_nhwc(self, x, slot):
+        if self.apply_d_sn:
+            # nn.ReLU(inplace=True) on x also rewrites the skip tensor x0 (same storage) in the reference:
+            # both paths see relu(x)  (reference big_resnet.py:221-242, config.py:476)
+            h = self.conv2d1.forward_nhwc(x, slot, in_relu=True)
+            h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=self.downsample)
+            if self.downsample or self.ch_mismatch:
+                return self.conv2d0.forward_nhwc(x, slot, in_relu=True, out_pool=self.downsample, res=h)
+            return F.AddReluFn.apply(h, x)
+        h = self.bn1.forward_nhwc(x, relu=True)
+        h = self.conv2d1.forward_nhwc(h, slot)
+        h = self.bn2.forward_nhwc(h, relu=True)
+        h = self.conv2d2.forward_nhwc(h, slot, out_pool=self.downsample)
+        if self.downsample or self.ch_mismatch:
+            x0 = self.bn0.forward_nhwc(x)
+            return self.conv2d0.forward_nhwc(x0, slot, out_pool=self.downsample, res=h)
+        return F.AddFn.apply(h, x)
+
+
+class Discriminator(nn.Module):
+    def __init__(self, img_size, d_conv_dim, apply_d_sn, apply_attn, attn_d_loc, d_cond_mtd, aux_cls_type, d_embed_dim, normalize_d_embed,
+                 num_classes, d_init, d_depth, mixed_precision, MODULES, MODEL):
+        super().__init__()
+        d_in_dims_collection = {
+            "32": [3] + [d_conv_dim * 2, d_conv_dim * 2, d_conv_dim * 2],
+            "64": [3] + [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8],
+            "128": [3] + [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 16],
+            "256": [3] + [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 8, d_conv_dim * 16],
+            "512": [3] + [d_conv_dim, d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 8, d_conv_dim * 16]
+        }
+        d_out_dims_collection = {
+            "32": [d_conv_dim * 2, d_conv_dim * 2, d_conv_dim * 2, d_conv_dim * 2],
+            "64": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 16],
+            "128": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 16, d_conv_dim * 16],
+            "256": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 8, d_conv_dim * 16, d_conv_dim * 16],
+            "512": [d_conv_dim, d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 8, d_conv_dim * 16, d_conv_dim * 16]
+        }
+        d_down = {
+            "32": [True, True, False, False],
+            "64": [True, True, True, True, False],
+            "128": [True, True, True, True, True, False],
+            "256": [True, True, True, True, True, True, False],
+            "512": [True, True, True, True, True, True, True, False]
+        }
+        self.d_cond_mtd = d_cond_mtd
+        self.aux_cls_type = aux_cls_type
+        self.normalize_d_embed = normalize_d_embed
+        self.num_classes = num_classes
+        self.mixed_precision = mixed_precision
+        self.in_dims = d_in_dims_collection[str(img_size)]
+        self.out_dims = d_out_dims_collection[str(img_size)]
+        self.MODEL = MODEL
+        down = d_down[str(img_size)]
+        if d_cond_mtd not in ("W/O", "PD") or aux_cls_type not in ("W/O", "N/A") or getattr(MODEL, "info_type", "N/A") != "N/A":
+            raise NotImplementedError("only the unconditional and projection (PD) heads are on the benchmarked hot path (SURVEY.md §8f)")
+
+        blocks = []
+        for index in range(len(self.in_dims)):
+            if index == 0:
+                blocks += [[DiscOptBlock(in_channels=self.in_dims[index], out_channels=self.out_dims[index], apply_d_sn=apply_d_sn, MODULES=MODULES)]]
+            else:
+                blocks += [[DiscBlock(in_channels=self.in_dims[index], out_channels=self.out_dims[index], apply_d_sn=apply_d_sn,
+                                      MODULES=MODULES, downsample=down[index])]]
+            if index + 1 in attn_d_loc and apply_attn:
+                blocks += [[ops.SelfAttention(self.out_dims[index], is_generator=False, MODULES=MODULES)]]
+        self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])
+        self.activation = MODULES.d_act_fn
+        self.linear1 = MODULES.d_linear(in_features=self.out_dims[-1], out_features=1, bias=True)
+        if self.d_cond_mtd == "PD":
+            self.embedding = MODULES.d_embedding(num_classes, self.out_dims[-1])
+        if d_init:
+            ops.init_weights(self.modules, d_init)
+        ops.adopt(self, _dtype(mixed_precision))
+
+    def forward(self, x, label, eval=False, adc_fake=False):
+        dtype = self.compute_dtype
+        bank = get_bank(self, dtype)
+        slot = bank.begin_forward(_need_graph(self, x))
+        h = ops.to_nhwc(x, dtype)
+        for blocklist in self.blocks:
+            for block in blocklist:
+                h = block.forward_nhwc(h, slot)
+        h = F.ReluSumFn.apply(h)
+        pd = self.d_cond_mtd == "PD"
+        adv_output = F.PDHeadFn.apply(h, self.linear1.master_weight, self.linear1.bias, self.embedding.master_weight if pd else None,
+                                      label if pd else None, self.linear1._sg_rt, self.embedding._sg_rt if pd else None, slot)
+        return {
+            "h": h, "adv_output": adv_output, "embed": None, "proxy": None, "cls_output": None, "label": label,
+            "mi_embed": None, "mi_proxy": None, "mi_cls_output": None,
+            "info_discrete_c_logits": None, "info_conti_mu": None, "info_conti_var": None
+        }

@@ -1,0 +1,342 @@
+"""Flat parameter arenas and the per-network weight bank.
+
+MI355X-first layout of the *weight side* of the hot path:
+
+* every fp32 master parameter of a network lives in ONE contiguous arena (and its gradient in a twin arena), so the
+  optimizer step (+EMA) is one launch and the data-parallel gradient exchange is one RCCL all-reduce of one buffer
+  (replaces DDP's 25 MB buckets, reference src/models/model.py:171-180);
+* spectral norm (reference src/utils/ops.py:195-224) runs for ALL layers of the network in 4-5 batched launches at the
+  start of each forward (`WeightBank.begin_forward`), emitting the normalised weight directly in the compute dtype and
+  in the two operand layouts the convolution engine reads;
+* the backward of the normalisation is likewise batched: convolution backward kernels drop dL/dW_sn into a per-forward
+  fp32 arena and one `sg_sn_backward` per forward (queued as an autograd engine callback) folds them into the
+  gradient arena.
+
+Parameter names/shapes stay exactly the reference's (`weight_orig`, `weight_u`, `weight_v`, `bias`, ...), so
+`state_dict()` / `load_state_dict(strict=True)` interchange with StudioGAN checkpoints (reference src/utils/ckpt.py:38).
+"""
+import ctypes as C
+import weakref
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+
+_ARENA_OF = weakref.WeakKeyDictionary()  # Parameter -> (ParamArena, offset)
+
+
+def _align(n, a=4):
+    return (n + a - 1) // a * a
+
+
+class ParamArena:
+    """Contiguous fp32 storage for a list of parameters plus a twin gradient arena."""
+
+    def __init__(self, params):
+        params = [p for p in params]
+        assert len(params) > 0
+        dev = params[0].device
+        offs, total = [], 0
+        for p in params:
+            assert p.dtype == torch.float32 and p.device == dev
+            offs.append(total)
+            total += _align(p.numel())
+        self.params = params
+        self.offsets = offs
+        self.numel = total
+        self.data = torch.zeros(total, device=dev, dtype=torch.float32)
+        self.grad = torch.zeros(total, device=dev, dtype=torch.float32)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.data[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+                p.grad = None
+                _ARENA_OF[p] = (self, o)
+
+    def grad_view(self, p):
+        a, o = _ARENA_OF[p]
+        return a.grad[o:o + p.numel()].view(p.shape)
+
+    def intact(self):
+        p, o = self.params[0], self.offsets[0]
+        q, oq = self.params[-1], self.offsets[-1]
+        return p.data_ptr() == self.data.data_ptr() + 4 * o and q.data_ptr() == self.data.data_ptr() + 4 * oq
+
+
+def arena_of(p):
+    return _ARENA_OF.get(p)
+
+
+def ensure_grad(p):
+    """Gradient tensor of a parameter that our kernels accumulate into (a view of the gradient arena when the
+    parameter lives in one). Honour optimizer.zero_grad(set_to_none=True): a None grad is re-created zeroed."""
+    g = p.grad
+    if g is not None:
+        return g
+    ent = _ARENA_OF.get(p)
+    if ent is not None:
+        a, o = ent
+        g = a.grad[o:o + p.numel()].view(p.shape)
+        g.zero_()
+    else:
+        g = torch.zeros_like(p.data)
+    p.grad = g
+    return g
+
+
+class BufferArena:
+    """Contiguous storage for the float buffers of a network (BN running stats, SN u/v) -> one fused EMA launch."""
+
+    def __init__(self, named_buffers):
+        bufs = [(n, b) for n, b in named_buffers if b is not None and b.dtype == torch.float32]
+        self.names = [n for n, _ in bufs]
+        self.offsets, total = [], 0
+        for _, b in bufs:
+            self.offsets.append(total)
+            total += _align(b.numel())
+        dev = bufs[0][1].device if bufs else torch.device("cpu")
+        self.data = torch.zeros(max(total, 4), device=dev, dtype=torch.float32)
+        self.numel = total
+        self.bufs = [b for _, b in bufs]
+        with torch.no_grad():
+            for b, o in zip(self.bufs, self.offsets):
+                view = self.data[o:o + b.numel()].view(b.shape)
+                view.copy_(b)
+                b.set_(view)  # in place: the module's registered buffer object now aliases the arena
+
+
+class _Holder:
+    """Keeps runtime state (ctypes tables, arenas) out of copy.deepcopy / pickling of the owning nn.Module."""
+
+    def __init__(self):
+        self.obj = None
+
+    def __deepcopy__(self, memo):
+        return _Holder()
+
+    def __getstate__(self):
+        return {}
+
+    def __setstate__(self, st):
+        self.obj = None
+
+
+class LayerRT:
+    """Runtime record of one weight-bearing layer inside a bank."""
+    __slots__ = ("module", "index", "param", "kind", "rows", "cols", "Cin", "RS", "apply_sn", "rows_pad", "want_fwd", "want_dgrad",
+                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank")
+
+
+class _Slot:
+    pass
+
+
+class WeightBank:
+    SN_SPLITS = 8
+
+    def __init__(self, root, compute_dtype, nslots=4, eps=1e-6):
+        self.root_ref = weakref.ref(root)
+        self.dtype = compute_dtype
+        self.sgdt = L.dt(compute_dtype)
+        self.eps = eps
+        self.nslots = nslots
+        layers = []
+        for m in root.modules():
+            if getattr(m, "_sg_weight_layer", False):
+                layers.append(m)
+        assert layers, "no weight layers found"
+        dev = next(root.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("studiogan_amd modules run on the GPU only (no CPU fallback on the product path)")
+        self.device = dev
+        # 1. flatten parameters / buffers of the whole network (not only weight layers)
+        params = list(root.parameters())
+        if not all((arena_of(p) is not None) for p in params) or len({id(arena_of(p)[0]) for p in params}) != 1 \
+                or not arena_of(params[0])[0].intact():
+            self.params = ParamArena(params)
+        else:
+            self.params = arena_of(params[0])[0]
+        self.buffers = BufferArena(list(root.named_buffers()))
+        # 2. per-layer records and arena offsets
+        es = 2 if compute_dtype == torch.bfloat16 else 4
+        self.layers = []
+        img_elems = f32_elems = dwt_elems = uv_elems = work = 0
+        for i, m in enumerate(layers):
+            r = LayerRT()
+            r.module, r.index, r.bank = weakref.ref(m), i, weakref.ref(self)
+            r.param = m.weight_orig if m._sg_sn else m.weight
+            r.kind = m._sg_kind
+            r.rows, r.cols, r.Cin, r.RS = m._sg_rows, m._sg_cols, m._sg_cin, m._sg_rs
+            r.apply_sn = 1 if m._sg_sn else 0
+            r.rows_pad = getattr(m, "_sg_rows_pad", 0) or r.rows
+            r.want_fwd = r.kind == "conv"
+            r.want_dgrad = r.kind == "conv"
+            r.want_f32 = r.kind in ("linear", "embedding")
+            r.natural_dwt = 0 if r.kind == "conv" else 1
+            r.fwd_off = r.dgrad_off = r.f32_off = -1
+            if r.want_fwd:
+                r.fwd_off = img_elems
+                img_elems += _align(r.rows_pad * r.cols, 16)
+            if r.want_dgrad:
+                r.dgrad_off = img_elems
+                img_elems += _align(r.rows * r.cols, 16)
+            if r.want_f32:
+                r.f32_off = f32_elems
+                f32_elems += _align(r.rows * r.cols)
+            r.dwt_off = dwt_elems
+            dwt_elems += _align(r.rows_pad * r.cols)
+            r.uv_off = uv_elems
+            uv_elems += _align(r.rows) + _align(r.cols)
+            r.work_off = work
+            work += self.SN_SPLITS * r.cols + r.rows
+            m._sg_rt = r
+            self.layers.append(r)
+        self.work = torch.zeros(max(work, 64 * len(layers)) + 64, device=dev, dtype=torch.float32)
+        self.slots = []
+        for s in range(nslots):
+            sl = _Slot()
+            sl.index = s
+            sl.img = torch.zeros(max(img_elems, 16), device=dev, dtype=compute_dtype)
+            sl.f32 = torch.zeros(max(f32_elems, 4), device=dev, dtype=torch.float32)
+            sl.dwt = torch.zeros(max(dwt_elems, 4), device=dev, dtype=torch.float32) if s > 0 else None
+            sl.uv = torch.zeros(max(uv_elems, 4), device=dev, dtype=torch.float32)
+            sl.sigma = torch.ones(len(layers), device=dev, dtype=torch.float32)
+            sl.dwt_zeroed = False
+            sl.pending = []
+            sl.desc_cache = {}
+            sl.bwd_cache = {}
+            self.slots.append(sl)
+        self._ring = 0
+        self.current = self.slots[0]
+        self._cb_queued = False
+        self.es = es
+
+    # -- forward ------------------------------------------------------------------------------------------
+    def _desc(self, slot, flags):
+        ent = slot.desc_cache.get(flags)
+        if ent is not None:
+            return ent
+        n = len(self.layers)
+        arr = (L.SnLayer * n)()
+        es = self.es
+        for r, pi in zip(self.layers, flags):
+            m = r.module()
+            d = arr[r.index]
+            d.w = r.param.data_ptr()
+            if r.apply_sn:
+                d.u, d.v = m.weight_u.data_ptr(), m.weight_v.data_ptr()
+            d.sigma = slot.sigma.data_ptr() + 4 * r.index
+            d.u_snap = slot.uv.data_ptr() + 4 * r.uv_off
+            d.v_snap = slot.uv.data_ptr() + 4 * (r.uv_off + _align(r.rows))
+            d.w_fwd = slot.img.data_ptr() + es * r.fwd_off if r.want_fwd else None
+            d.w_dgrad = slot.img.data_ptr() + es * r.dgrad_off if (r.want_dgrad and slot.dwt is not None) else None
+            d.w_f32 = slot.f32.data_ptr() + 4 * r.f32_off if r.want_f32 else None
+            d.rows, d.cols, d.Cin, d.RS = r.rows, r.cols, r.Cin, r.RS
+            d.do_power_iter = 1 if pi else 0
+            d.apply_sn = r.apply_sn
+            d.rows_pad = r.rows_pad
+            d.work_off = r.work_off
+        dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
+        ent = (arr, dev_tab)
+        slot.desc_cache[flags] = ent
+        return ent
+
+    def intact(self):
+        return self.params.intact()
+
+    def begin_forward(self, need_graph):
+        """One spectral-norm power iteration + weight image emission for every layer; returns the slot."""
+        if need_graph:
+            self._ring = self._ring % (self.nslots - 1) + 1
+            slot = self.slots[self._ring]
+            slot.dwt_zeroed = False
+            slot.pending = []
+        else:
+            slot = self.slots[0]
+        flags = tuple(bool(r.module().training) for r in self.layers)
+        arr, dev_tab = self._desc(slot, flags)
+        L.call("sg_sn_forward", self.sgdt, dev_tab.data_ptr(), arr, len(self.layers), self.eps, self.work.data_ptr(),
+               self.work.numel(), L.stream())
+        self.current = slot
+        return slot
+
+    # -- pointers -----------------------------------------------------------------------------------------
+    def w_fwd(self, slot, r):
+        return slot.img.data_ptr() + self.es * r.fwd_off
+
+    def w_dgrad(self, slot, r):
+        return slot.img.data_ptr() + self.es * r.dgrad_off
+
+    def w_f32(self, slot, r):
+        return slot.f32.data_ptr() + 4 * r.f32_off
+
+    def w_f32_tensor(self, slot, r):
+        return slot.f32[r.f32_off:r.f32_off + r.rows * r.cols].view(r.rows, r.cols)
+
+    def dwt(self, slot, r):
+        """fp32 scratch for dL/dW_sn of this forward (zeroed once per backward pass), registers the layer for the
+        batched normalisation backward."""
+        if slot.dwt is None:
+            raise RuntimeError("weight gradient requested for a forward that was run without a graph")
+        if not slot.dwt_zeroed:
+            slot.dwt.zero_()
+            slot.dwt_zeroed = True
+        if r.index not in slot.pending:
+            slot.pending.append(r.index)
+        if not self._cb_queued:
+            self._cb_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.flush)
+        return slot.dwt.data_ptr() + 4 * r.dwt_off
+
+    def dwt_tensor(self, slot, r):
+        self.dwt(slot, r)
+        return slot.dwt[r.dwt_off:r.dwt_off + r.rows_pad * r.cols].view(r.rows_pad, r.cols)
+
+    # -- backward of the normalisation, batched ----------------------------------------------------------------
+    def flush(self):
+        self._cb_queued = False
+        for slot in self.slots[1:]:
+            if not slot.pending:
+                continue
+            key = tuple(sorted(slot.pending))
+            slot.pending = []
+            ent = slot.bwd_cache.get(key)
+            if ent is None:
+                arr = (L.SnBwdLayer * len(key))()
+                for j, idx in enumerate(key):
+                    r = self.layers[idx]
+                    d = arr[j]
+                    d.dwt = slot.dwt.data_ptr() + 4 * r.dwt_off
+                    d.w = r.param.data_ptr()
+                    d.u = slot.uv.data_ptr() + 4 * r.uv_off
+                    d.v = slot.uv.data_ptr() + 4 * (r.uv_off + _align(r.rows))
+                    d.sigma = slot.sigma.data_ptr() + 4 * r.index
+                    d.dw = 0
+                    d.rows, d.cols, d.Cin, d.RS = r.rows, r.cols, r.Cin, r.RS
+                    d.natural = r.natural_dwt
+                    d.apply_sn = r.apply_sn
+                ent = [arr, None, None]
+                slot.bwd_cache[key] = ent
+            arr = ent[0]
+            grads = tuple(ensure_grad(self.layers[idx].param).data_ptr() for idx in key)
+            if ent[2] != grads:  # gradient tensors may be re-created by zero_grad(set_to_none=True)
+                for j, gp in enumerate(grads):
+                    arr[j].dw = gp
+                ent[1] = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
+                ent[2] = grads
+            L.call("sg_sn_backward", ent[1].data_ptr(), arr, len(key), self.work.data_ptr(), self.work.numel(), L.stream())
+
+
+def get_bank(root, compute_dtype):
+    """Bank of a network (built lazily at the first forward, rebuilt if .to()/deepcopy invalidated the arenas)."""
+    h = root.__dict__.get("_sg_bank_holder")
+    if h is None:
+        h = _Holder()
+        root.__dict__["_sg_bank_holder"] = h
+    b = h.obj
+    if b is None or b.dtype != compute_dtype or not b.intact():
+        b = WeightBank(root, compute_dtype)
+        h.obj = b
+    return b

@@ -79,7 +79,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   lq.rows = J; lq.K = K;
   Epilogue<T> e;
   e.out = d->dw; e.out_bstride = 0; e.ldo = I; e.bias = nullptr; e.res = nullptr; e.res_bstride = 0; e.ldr = 0; e.beta = 0.f;
-  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.alpha = d->alpha; e.alpha_ptr = nullptr;
+  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr;
   e.flags = SG_EPI_ATOMIC | SG_EPI_OUT_F32; e.I = I; e.J = J;
   // tile config by output-channel count, then enough k-splits to fill 256 CUs a few times over
   int BI, BJ;

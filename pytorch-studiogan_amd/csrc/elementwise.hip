@@ -394,3 +394,43 @@ extern "C" int sg_loss_g(int kind, const float* fake, int B, float* loss, float*
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- dtype conversion, residual add with ReLU (DiscBlock identity skip sees the in-place ReLU'd input) -----
+template <typename TS, typename TD> __global__ void k_convert(const TS* x, TD* y, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) y[i] = from_f<TD>(to_f<TS>(x[i]));
+}
+extern "C" int sg_convert(int src_dtype, int dst_dtype, const void* x, void* y, long long n, sg_stream_t s) {
+  SG_CHECK(x && y, "sg_convert: null");
+  if (n <= 0) return 0;
+  hipStream_t st = (hipStream_t)s;
+  dim3 g(nblk(n, 256)), b(256);
+  if (src_dtype == SG_DTYPE_F32 && dst_dtype == SG_DTYPE_BF16) hipLaunchKernelGGL((k_convert<float, bf16_t>), g, b, 0, st, (const float*)x, (bf16_t*)y, n);
+  else if (src_dtype == SG_DTYPE_BF16 && dst_dtype == SG_DTYPE_F32) hipLaunchKernelGGL((k_convert<bf16_t, float>), g, b, 0, st, (const bf16_t*)x, (float*)y, n);
+  else if (src_dtype == SG_DTYPE_F32 && dst_dtype == SG_DTYPE_F32) hipLaunchKernelGGL((k_convert<float, float>), g, b, 0, st, (const float*)x, (float*)y, n);
+  else if (src_dtype == SG_DTYPE_BF16 && dst_dtype == SG_DTYPE_BF16) hipLaunchKernelGGL((k_convert<bf16_t, bf16_t>), g, b, 0, st, (const bf16_t*)x, (bf16_t*)y, n);
+  else { sg_set_error("sg_convert: bad dtype"); return -1; }
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// out = a + relu(x)
+template <typename T> __global__ void k_add_relu(const T* a, const T* x, T* out, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) out[i] = from_f<T>(to_f<T>(a[i]) + fmaxf(to_f<T>(x[i]), 0.f));
+}
+extern "C" int sg_add_relu(int dtype, const void* a, const void* x, void* out, long long n, sg_stream_t s) {
+  SG_CHECK(a && x && out, "sg_add_relu: null");
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_add_relu<T>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)s, (const T*)a, (const T*)x, (T*)out, n));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// dx = dy * (x > 0)
+template <typename T> __global__ void k_relu_mask(const T* dy, const T* x, T* dx, long long n) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dx[i] = (to_f<T>(x[i]) > 0.f) ? dy[i] : from_f<T>(0.f);
+}
+extern "C" int sg_relu_mask(int dtype, const void* dy, const void* x, void* dx, long long n, sg_stream_t s) {
+  SG_CHECK(dy && x && dx, "sg_relu_mask: null");
+  if (n <= 0) return 0;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_relu_mask<T>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (const T*)x, (T*)dx, n));
+  SG_LAUNCH_CHECK();
+  return 0;
+}

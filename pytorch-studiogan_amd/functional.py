@@ -1,0 +1,656 @@
+"""autograd.Function wrappers: every forward/backward below is one or more launches of libsgamd.so kernels.
+
+Internal activation layout is NHWC ([N,H,W,C] contiguous, fp32 or bf16). Weight operands come from the network's
+WeightBank slot of the current forward (see bank.py). Gradients w.r.t. parameters are written by the kernels straight
+into the gradient arena (``p.grad`` views) -- the Functions return None for parameter inputs on purpose.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .bank import ensure_grad
+
+
+def _c(t):
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+# raw launch helpers (also used directly by the kernel-level tests)
+# ---------------------------------------------------------------------------------------------------------
+def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None,
+               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None):
+    """x: [N,Hs,Ws,ldx] NHWC; returns [N,Ho',Wo',Cout]. w_ptr -> [Cout][R*S*Cin] in x.dtype."""
+    N, Hs, Ws = x.shape[0], x.shape[1], x.shape[2]
+    ldx = x.shape[3] if ldx is None else ldx
+    up = 2 if (pix_flags & L.PIX_UPSAMPLE) else 1
+    Hin, Win = Hs * up, Ws * up
+    if pix_flags & L.PIX_TRANSPOSED:
+        Ho, Wo = transposed_out_hw
+    else:
+        Ho = (Hin + 2 * pad_h - R) // stride + 1
+        Wo = (Win + 2 * pad_w - S) // stride + 1
+    pool = bool(epi_flags & L.EPI_POOL)
+    Hy, Wy = (Ho // 2, Wo // 2) if pool else (Ho, Wo)
+    if out is None:
+        odt = torch.float32 if (epi_flags & L.EPI_OUT_F32) else x.dtype
+        out = torch.empty((N, Hy, Wy, Cout), dtype=odt, device=x.device)
+    d = L.ConvFwdDesc()
+    d.dtype = L.dt(x)
+    d.N, d.Hs, d.Ws, d.C, d.ldx = N, Hs, Ws, Cin, ldx
+    d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
+    d.R, d.S, d.stride, d.pad_h, d.pad_w = R, S, stride, pad_h, pad_w
+    d.pix_flags, d.epi_flags = pix_flags, epi_flags
+    d.alpha, d.beta = alpha, beta
+    d.x, d.w = L.ptr(x), w_ptr
+    d.bias = L.ptr(bias)
+    d.res = L.ptr(res)
+    d.mask = L.ptr(mask)
+    d.out = L.ptr(out)
+    d.alpha_ptr = L.ptr(alpha_ptr)
+    d.ldo = out.shape[-1]
+    d.ldr = res.shape[-1] if res is not None else 0
+    d.ldm = mask.shape[-1] if mask is not None else 0
+    L.call("sg_conv2d_fwd", d, L.stream())
+    return out
+
+
+def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, pad_w=0, x_flags=0, g_flags=0, alpha=1.0,
+                     alpha_ptr=None, splits=0, no_tr=0, ldg=None):
+    d = L.ConvWgradDesc()
+    d.dtype = L.dt(x)
+    d.N = x.shape[0]
+    d.xHs, d.xWs, d.C, d.ldx, d.x_flags = x.shape[1], x.shape[2], Cin, x.shape[3], x_flags
+    d.gHs, d.gWs, d.Cout, d.ldg, d.g_flags = dy.shape[1], dy.shape[2], Cout, (dy.shape[3] if ldg is None else ldg), g_flags
+    d.Ho, d.Wo = Ho, Wo
+    d.R, d.S, d.stride, d.pad_h, d.pad_w = R, S, stride, pad_h, pad_w
+    d.alpha = alpha
+    d.x, d.dy, d.dw = L.ptr(x), L.ptr(dy), dw_ptr
+    d.alpha_ptr = L.ptr(alpha_ptr)
+    d.splits, d.no_tr = splits, no_tr
+    L.call("sg_conv2d_wgrad", d, L.stream())
+
+
+def gemm_raw(dtype, p, p_form, ldp, q, q_form, ldq, out, ldo, I, J, K, batch=1, p_bs=0, q_bs=0, out_bs=0, bias=None, res=None,
+             res_bs=0, ldr=0, beta=1.0, alpha=1.0, alpha_ptr=None, epi_flags=0, splits=1, no_tr=0):
+    """OUT[b][j][i] = beta*res + alpha * sum_k P(i,k) Q(j,k) + bias[i]; p/q/out may be tensors or raw pointers."""
+    d = L.GemmDesc()
+    d.dtype, d.p_form, d.q_form = dtype, p_form, q_form
+    d.I, d.J, d.K, d.batch = I, J, K, batch
+    d.p = p if isinstance(p, int) else L.ptr(p)
+    d.q = q if isinstance(q, int) else L.ptr(q)
+    d.out = out if isinstance(out, int) else L.ptr(out)
+    d.p_bstride, d.ldp, d.q_bstride, d.ldq, d.out_bstride, d.ldo = p_bs, ldp, q_bs, ldq, out_bs, ldo
+    d.bias = bias if (bias is None or isinstance(bias, int)) else L.ptr(bias)
+    d.res = res if (res is None or isinstance(res, int)) else L.ptr(res)
+    d.res_bstride, d.ldr, d.beta = res_bs, ldr, beta
+    d.alpha = alpha
+    d.alpha_ptr = L.ptr(alpha_ptr)
+    d.epi_flags, d.splits, d.no_tr = epi_flags, splits, no_tr
+    L.call("sg_gemm", d, L.stream())
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layout at the reference's NCHW fp32 boundary
+# ---------------------------------------------------------------------------------------------------------
+class NchwToNhwcFn(torch.autograd.Function):
+    """fp32 NCHW -> compute-dtype NHWC (D input image; G's linear0 output)."""
+
+    @staticmethod
+    def forward(ctx, x, dtype):
+        x = _c(x)
+        N, Cc, H, W = x.shape
+        y = torch.empty((N, H, W, Cc), dtype=dtype, device=x.device)
+        L.call("sg_nchw_to_nhwc", L.dt(dtype), L.ptr(x), L.ptr(y), N, Cc, H, W, Cc, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W, Cc = dy.shape
+        dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dy.device)
+        L.call("sg_nhwc_to_nchw", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Cc, H, W, Cc, 0, L.stream())
+        return dx, None
+
+
+class NhwcToNchwFn(torch.autograd.Function):
+    """compute-dtype NHWC -> fp32 NCHW with optional tanh (G output image)."""
+
+    @staticmethod
+    def forward(ctx, x, apply_tanh):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+        L.call("sg_nhwc_to_nchw", L.dt(x), L.ptr(x), L.ptr(y), N, Cc, H, W, Cc, 1 if apply_tanh else 0, L.stream())
+        ctx.apply_tanh = apply_tanh
+        ctx.in_dtype = x.dtype
+        if apply_tanh:
+            ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy.float())
+        N, Cc, H, W = dy.shape
+        y = ctx.saved_tensors[0] if ctx.apply_tanh else None
+        dx = torch.empty((N, H, W, Cc), dtype=ctx.in_dtype, device=dy.device)
+        L.call("sg_nchw_grad_to_nhwc", L.dt(ctx.in_dtype), L.ptr(dy), L.ptr(y), L.ptr(dx), N, Cc, H, W, 1 if ctx.apply_tanh else 0, L.stream())
+        return dx, None
+
+
+class ConvertFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, dtype):
+        ctx.src = x.dtype
+        x = _c(x)
+        y = torch.empty(x.shape, dtype=dtype, device=x.device)
+        L.call("sg_convert", L.dt(x), L.dt(dtype), L.ptr(x), L.ptr(y), x.numel(), L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        dx = torch.empty(dy.shape, dtype=ctx.src, device=dy.device)
+        L.call("sg_convert", L.dt(dy), L.dt(ctx.src), L.ptr(dy), L.ptr(dx), dy.numel(), L.stream())
+        return dx, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# convolution
+# ---------------------------------------------------------------------------------------------------------
+class ConvCfg:
+    __slots__ = ("R", "S", "stride", "pad_h", "pad_w", "in_relu", "in_upsample", "out_pool")
+
+    def __init__(self, R, S, stride=1, pad_h=0, pad_w=0, in_relu=False, in_upsample=False, out_pool=False):
+        self.R, self.S, self.stride, self.pad_h, self.pad_w = R, S, stride, pad_h, pad_w
+        self.in_relu, self.in_upsample, self.out_pool = in_relu, in_upsample, out_pool
+
+
+class ConvFn(torch.autograd.Function):
+    """y = [res +] avgpool2?( conv( upsample2?( relu?(x) ) ) + bias )      (one fused implicit-GEMM launch)
+
+    backward: data gradient = same engine with the flipped/transposed weight image, ReLU mask / 2x2 pooling-sum /
+    pooled-gradient broadcast fused; weight gradient = split-K MFMA contraction over pixels into the bank's fp32 scratch;
+    bias gradient = column sums.  Replaces nn.Conv2d fwd/bwd + ReLU + F.interpolate + AvgPool2d + add of
+    reference src/models/big_resnet.py:28-42,177-242.
+    """
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, res, rt, slot, cfg):
+        bank = rt.bank()
+        x = _c(x)
+        N, Hs, Ws, Cin = x.shape
+        assert Cin == rt.Cin, f"conv input channels {Cin} != {rt.Cin}"
+        assert bias is None or rt.rows_pad == rt.rows
+        pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
+        ef = L.EPI_POOL if cfg.out_pool else 0
+        if res is not None:
+            res = _c(res)
+        y = conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, pf, ef, bias=bias, res=res,
+                       alpha=0.25 if cfg.out_pool else 1.0)
+        ctx.save_for_backward(x)
+        ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
+        ctx.bias = bias
+        ctx.has_res = res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        rt, slot, cfg = ctx.rt, ctx.slot, ctx.cfg
+        bank = rt.bank()
+        dy = _c(dy)
+        N, Hs, Ws, Cin = x.shape
+        up = 2 if cfg.in_upsample else 1
+        Hin, Win = Hs * up, Ws * up
+        Ho = (Hin + 2 * cfg.pad_h - cfg.R) // cfg.stride + 1
+        Wo = (Win + 2 * cfg.pad_w - cfg.S) // cfg.stride + 1
+        pool = cfg.out_pool
+        scale = 0.25 if pool else 1.0
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cfg.stride != 1:
+                raise NotImplementedError("data gradient of strided convolution goes through ConvTransposeFn")
+            pf = L.PIX_UPSAMPLE if pool else 0
+            ef = L.EPI_POOL if cfg.in_upsample else 0
+            # dy has rows_pad channels, the dgrad image has K = R*S*rows: read the first `rows` channels at pitch rows_pad
+            dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
+                            mask=x if cfg.in_relu else None, alpha=scale, ldx=dy.shape[3])
+        if ctx.needs_input_grad[1]:
+            xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
+            gf = L.PIX_UPSAMPLE if pool else 0
+            conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w, xf, gf, alpha=scale)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            g = ensure_grad(ctx.bias)
+            rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
+            L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())
+        dres = dy if ctx.has_res else None
+        return dx, None, None, dres, None, None, None
+
+
+class LinearFn(torch.autograd.Function):
+    """y = x W_sn^T + b in fp32 (nn.Linear, reference src/utils/ops.py:187-188,219-220). const_bias: non-trainable bias
+    vector (the '1 +' of ConditionalBatchNorm2d's gain, reference src/utils/ops.py:25)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rt, slot, const_bias):
+        bank = rt.bank()
+        x = _c(x.float())
+        B, K = x.shape
+        assert K == rt.cols
+        y = torch.empty((B, rt.rows), dtype=torch.float32, device=x.device)
+        b = bias if bias is not None else const_bias
+        gemm_raw(L.F32, bank.w_f32(slot, rt), 0, K, x, 0, K, y, rt.rows, rt.rows, B, K, bias=b)
+        ctx.save_for_backward(x)
+        ctx.rt, ctx.slot, ctx.bias = rt, slot, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        rt, slot = ctx.rt, ctx.slot
+        bank = rt.bank()
+        dy = _c(dy.float())
+        B, K = x.shape
+        O = rt.rows
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((B, K), dtype=torch.float32, device=x.device)
+            # dx[b][k] = sum_o dy[b][o] W[o][k] : P(i=k, red=o) = W stored [o][k] -> row-contiguous form
+            gemm_raw(L.F32, bank.w_f32(slot, rt), 1, K, dy, 0, O, dx, K, K, B, O)
+        if ctx.needs_input_grad[1]:
+            # dW[o][k] = sum_b dy[b][o] x[b][k]
+            gemm_raw(L.F32, x, 1, K, dy, 1, O, bank.dwt(slot, rt), K, K, O, B)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            g = ensure_grad(ctx.bias)
+            L.call("sg_colsum", L.F32, L.ptr(dy), O, None, 0, B, O, L.ptr(g), 1.0, L.stream())
+        return dx, None, None, None, None, None
+
+
+class EmbeddingFn(torch.autograd.Function):
+    """Plain (non-SN) embedding lookup, e.g. G's shared class embedding (reference src/models/big_resnet.py:98,136)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx):
+        idx = _c(idx.long())
+        B = idx.numel()
+        num, dim = weight.shape
+        out = torch.empty((B, dim), dtype=torch.float32, device=weight.device)
+        L.call("sg_embedding_fwd", L.ptr(weight), L.ptr(idx), L.ptr(out), B, dim, num, L.stream())
+        ctx.save_for_backward(idx)
+        ctx.weight = weight
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        w = ctx.weight
+        if ctx.needs_input_grad[0]:
+            g = ensure_grad(w)
+            dout = _c(dout.float())
+            L.call("sg_embedding_bwd", L.ptr(dout), L.ptr(idx), L.ptr(g), idx.numel(), w.shape[1], w.shape[0], L.stream())
+        return None, None
+
+
+class SNEmbeddingFn(torch.autograd.Function):
+    """Embedding lookup in the spectrally normalised table held by the bank (sn_embedding, reference ops.py:223-224)."""
+
+    @staticmethod
+    def forward(ctx, weight, idx, rt, slot):
+        bank = rt.bank()
+        idx = _c(idx.long())
+        B = idx.numel()
+        out = torch.empty((B, rt.cols), dtype=torch.float32, device=weight.device)
+        L.call("sg_embedding_fwd", bank.w_f32(slot, rt), L.ptr(idx), L.ptr(out), B, rt.cols, rt.rows, L.stream())
+        ctx.save_for_backward(idx)
+        ctx.rt, ctx.slot = rt, slot
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (idx,) = ctx.saved_tensors
+        rt, slot = ctx.rt, ctx.slot
+        if ctx.needs_input_grad[0]:
+            dout = _c(dout.float())
+            L.call("sg_embedding_bwd", L.ptr(dout), L.ptr(idx), rt.bank().dwt(slot, rt), idx.numel(), rt.cols, rt.rows, L.stream())
+        return None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# (conditional) batch norm
+# ---------------------------------------------------------------------------------------------------------
+class BNCfg:
+    __slots__ = ("batch_stats", "track", "eps", "momentum", "relu", "group")
+
+    def __init__(self, batch_stats, track, eps, momentum, relu, group=None):
+        self.batch_stats, self.track, self.eps, self.momentum, self.relu, self.group = batch_stats, track, eps, momentum, relu, group
+
+
+def _world(group):
+    if group is not None and dist.is_available() and dist.is_initialized():
+        return dist.get_world_size(group if group is not True else None)
+    return 1
+
+
+class BNFn(torch.autograd.Function):
+    """y = relu?( (x - mean) * invstd * gain + bias ) with batch or running statistics.
+
+    gain/bias: None, per-channel [C] (nn.BatchNorm2d affine) or per-sample [N,C] (ConditionalBatchNorm2d: gain already
+    holds 1 + W_g y). Sync-BN = one all-reduce of the fp64 partial sums between the two kernels
+    (reference src/utils/ops.py:14-28,227-228; src/models/model.py:161-165)."""
+
+    @staticmethod
+    def forward(ctx, x, gain, bias, running_mean, running_var, cfg):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        HW = H * W
+        dev = x.device
+        mean = torch.empty(Cc, dtype=torch.float32, device=dev)
+        invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
+        count = float(N * HW)
+        if cfg.batch_stats:
+            partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+            L.call("sg_bn_partial_stats", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), L.stream())
+            ws = _world(cfg.group)
+            if ws > 1:
+                dist.all_reduce(partial, group=None if cfg.group is True else cfg.group)
+                count *= ws
+            rm = running_mean if cfg.track else None
+            rv = running_var if cfg.track else None
+            L.call("sg_bn_finalize", L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
+        else:
+            L.call("sg_bn_from_running", L.ptr(running_mean), L.ptr(running_var), Cc, cfg.eps, L.ptr(mean), L.ptr(invstd), L.stream())
+        gsn = 0
+        if gain is not None:
+            gain = _c(gain.float())
+            gsn = Cc if gain.dim() == 2 else 0
+        if bias is not None:
+            bias = _c(bias.float())
+            assert (Cc if bias.dim() == 2 else 0) == gsn or gain is None
+            if gain is None:
+                gsn = Cc if bias.dim() == 2 else 0
+        y = torch.empty_like(x)
+        L.call("sg_bn_apply", L.dt(x), L.ptr(x), L.ptr(y), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), gsn, 1 if cfg.relu else 0, L.stream())
+        ctx.save_for_backward(x, gain, bias, mean, invstd)
+        ctx.cfg, ctx.gsn, ctx.count = cfg, gsn, count
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gain, bias, mean, invstd = ctx.saved_tensors
+        cfg, gsn = ctx.cfg, ctx.gsn
+        dy = _c(dy)
+        N, H, W, Cc = x.shape
+        HW = H * W
+        dev = x.device
+        sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
+        L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), gsn,
+               1 if cfg.relu else 0, L.ptr(sums), L.stream())
+        chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        dgain = torch.zeros_like(gain) if (gain is not None and ctx.needs_input_grad[1]) else None
+        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), gsn, L.ptr(dgain), L.ptr(dbias), L.ptr(chan), L.stream())
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if cfg.batch_stats and _world(cfg.group) > 1:
+                dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+            dx = torch.empty_like(x)
+            L.call("sg_bn_bwd_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
+                   gsn, 1 if cfg.relu else 0, L.ptr(chan), ctx.count, 1 if cfg.batch_stats else 0, L.stream())
+        return dx, dgain, dbias, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# small elementwise ops of the D blocks
+# ---------------------------------------------------------------------------------------------------------
+class AvgPool2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        N, H, W, Cc = x.shape
+        y = torch.empty((N, H // 2, W // 2, Cc), dtype=x.dtype, device=x.device)
+        L.call("sg_avgpool2_fwd", L.dt(x), L.ptr(x), L.ptr(y), N, H, W, Cc, L.stream())
+        ctx.shape = (N, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        dy = _c(dy)
+        N, H, W, Cc = ctx.shape
+        dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
+        L.call("sg_avgpool2_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, H, W, Cc, L.stream())
+        return dx
+
+
+class AddFn(torch.autograd.Function):
+    """out = a + x (identity skip of a BN DiscBlock)."""
+
+    @staticmethod
+    def forward(ctx, a, x):
+        a, x = _c(a), _c(x)
+        out = torch.empty_like(a)
+        L.call("sg_convert", L.dt(a), L.dt(a), L.ptr(a), L.ptr(out), a.numel(), L.stream())
+        L.call("sg_axpby", L.dt(a), L.ptr(x), L.ptr(out), a.numel(), 1.0, 1.0, L.stream())
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        return dy, dy
+
+
+class AddReluFn(torch.autograd.Function):
+    """out = a + relu(x): the identity-skip DiscBlock (its in-place ReLU also rewrites the skip tensor;
+    reference src/models/big_resnet.py:221-242 with nn.ReLU(inplace=True), src/config.py:476)."""
+
+    @staticmethod
+    def forward(ctx, a, x):
+        a, x = _c(a), _c(x)
+        out = torch.empty_like(a)
+        L.call("sg_add_relu", L.dt(a), L.ptr(a), L.ptr(x), L.ptr(out), a.numel(), L.stream())
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            L.call("sg_relu_mask", L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream())
+        return dy, dx
+
+
+# ---------------------------------------------------------------------------------------------------------
+# self-attention core (reference src/utils/ops.py:83-103)
+# ---------------------------------------------------------------------------------------------------------
+class AttnCoreFn(torch.autograd.Function):
+    """o = softmax(theta . maxpool(phi)^T) . maxpool(g)   per image; theta/phi: [B,H,W,Dp], g: [B,H,W,Cg]."""
+
+    @staticmethod
+    def forward(ctx, theta, phi_full, g_full):
+        theta, phi_full, g_full = _c(theta), _c(phi_full), _c(g_full)
+        B, H, W, Dp = theta.shape
+        Cg = g_full.shape[3]
+        HW, HW4 = H * W, (H // 2) * (W // 2)
+        dev, T = theta.device, theta.dtype
+        sd = L.dt(T)
+        phi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
+        g = torch.empty((B, HW4, Cg), dtype=T, device=dev)
+        idx_phi = torch.empty((B, HW4, Dp), dtype=torch.uint8, device=dev)
+        idx_g = torch.empty((B, HW4, Cg), dtype=torch.uint8, device=dev)
+        L.call("sg_maxpool2_fwd", sd, L.ptr(phi_full), Dp, L.ptr(phi), Dp, L.ptr(idx_phi), B, H, W, Dp, L.stream())
+        L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
+        S = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
+        # S[q][k] = theta_q . phi_k
+        gemm_raw(sd, phi, 0, Dp, theta, 0, Dp, S, HW4, HW4, HW, Dp, batch=B, p_bs=HW4 * Dp, q_bs=HW * Dp, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+        P = torch.empty((B, HW, HW4), dtype=T, device=dev)
+        L.call("sg_softmax_rows", sd, L.ptr(S), L.ptr(P), B * HW, HW4, L.stream())
+        del S
+        o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
+        # o[q][c] = sum_k P[q][k] g[k][c]
+        gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
+        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P)
+        ctx.dims = (B, H, W, Dp, Cg)
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        theta, phi, g, idx_phi, idx_g, P = ctx.saved_tensors
+        B, H, W, Dp, Cg = ctx.dims
+        HW, HW4 = H * W, (H // 2) * (W // 2)
+        do = _c(do)
+        dev, T = do.device, do.dtype
+        sd = L.dt(T)
+        # dP[q][k] = sum_c do[q][c] g[k][c]
+        dP = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
+        gemm_raw(sd, g, 0, Cg, do, 0, Cg, dP, HW4, HW4, HW, Cg, batch=B, p_bs=HW4 * Cg, q_bs=HW * Cg, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+        # dg[k][c] = sum_q P[q][k] do[q][c]
+        dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
+        gemm_raw(sd, do, 1, Cg, P, 1, HW4, dg, Cg, Cg, HW4, HW, batch=B, p_bs=HW * Cg, q_bs=HW * HW4, out_bs=HW4 * Cg)
+        dS = torch.empty((B, HW, HW4), dtype=T, device=dev)
+        L.call("sg_softmax_rows_bwd", sd, L.ptr(P), L.ptr(dP), L.ptr(dS), B * HW, HW4, L.stream())
+        del dP
+        # dtheta[q][d] = sum_k dS[q][k] phi[k][d]
+        dtheta = torch.empty((B, H, W, Dp), dtype=T, device=dev)
+        gemm_raw(sd, phi, 1, Dp, dS, 0, HW4, dtheta, Dp, Dp, HW, HW4, batch=B, p_bs=HW4 * Dp, q_bs=HW * HW4, out_bs=HW * Dp)
+        # dphi[k][d] = sum_q dS[q][k] theta[q][d]
+        dphi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
+        gemm_raw(sd, theta, 1, Dp, dS, 1, HW4, dphi, Dp, Dp, HW4, HW, batch=B, p_bs=HW * Dp, q_bs=HW * HW4, out_bs=HW4 * Dp)
+        dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
+        dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)
+        L.call("sg_maxpool2_bwd", sd, L.ptr(dphi), Dp, L.ptr(idx_phi), L.ptr(dphi_full), Dp, B, H, W, Dp, L.stream())
+        L.call("sg_maxpool2_bwd", sd, L.ptr(dg), Cg, L.ptr(idx_g), L.ptr(dg_full), Cg, B, H, W, Cg, L.stream())
+        return dtheta, dphi_full, dg_full
+
+
+class AttnOutFn(torch.autograd.Function):
+    """y = x + sigma * conv1x1(o)   (reference src/utils/ops.py:102-103), sigma read from device memory."""
+
+    @staticmethod
+    def forward(ctx, x, o, weight, sigma, rt, slot):
+        bank = rt.bank()
+        x, o = _c(x), _c(o)
+        y = conv2d_raw(o, bank.w_fwd(slot, rt), rt.Cin, rt.rows, 1, 1, res=x, alpha_ptr=sigma)
+        ctx.save_for_backward(o, sigma)
+        ctx.rt, ctx.slot = rt, slot
+        ctx.sigma_param = sigma
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        o, sigma = ctx.saved_tensors
+        rt, slot = ctx.rt, ctx.slot
+        bank = rt.bank()
+        dy = _c(dy)
+        N, H, W, Cc = dy.shape
+        do = None
+        if ctx.needs_input_grad[3]:
+            t = conv2d_raw(o, bank.w_fwd(slot, rt), rt.Cin, rt.rows, 1, 1)  # recompute conv1x1(o)
+            g = ensure_grad(ctx.sigma_param)
+            L.call("sg_dot", L.dt(dy), L.ptr(dy), L.ptr(t), dy.numel(), L.ptr(g), 1.0, None, L.stream())
+        if ctx.needs_input_grad[1]:
+            do = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, rt.Cin, 1, 1, alpha_ptr=sigma)
+        if ctx.needs_input_grad[2]:
+            conv2d_wgrad_raw(o, dy, bank.dwt(slot, rt), rt.Cin, rt.rows, 1, 1, H, W, alpha_ptr=sigma)
+        return dy, do, None, None, None, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# discriminator head + losses
+# ---------------------------------------------------------------------------------------------------------
+class ReluSumFn(torch.autograd.Function):
+    """h[b,c] = sum_hw relu(x[b,hw,c])  (reference src/models/big_resnet.py:359-360)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        B, H, W, Cc = x.shape
+        h = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        L.call("sg_relu_sum_hw_fwd", L.dt(x), L.ptr(x), L.ptr(h), B, H * W, Cc, L.stream())
+        ctx.save_for_backward(x)
+        return h
+
+    @staticmethod
+    def backward(ctx, dh):
+        (x,) = ctx.saved_tensors
+        B, H, W, Cc = x.shape
+        dh = _c(dh.float())
+        dx = torch.empty_like(x)
+        L.call("sg_relu_sum_hw_bwd", L.dt(x), L.ptr(x), L.ptr(dh), L.ptr(dx), B, H * W, Cc, L.stream())
+        return dx
+
+
+class PDHeadFn(torch.autograd.Function):
+    """adv[b] = linear1(h)[b] + <embed_sn(y_b), h_b>  (projection discriminator, reference big_resnet.py:363,387)."""
+
+    @staticmethod
+    def forward(ctx, h, w1, b1, emb_w, labels, rt_lin, rt_emb, slot):
+        bank = rt_lin.bank()
+        h = _c(h)
+        B, Cc = h.shape
+        dev = h.device
+        emb = None
+        if rt_emb is not None:
+            labels = _c(labels.long())
+            emb = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+            L.call("sg_embedding_fwd", bank.w_f32(slot, rt_emb), L.ptr(labels), L.ptr(emb), B, Cc, rt_emb.rows, L.stream())
+        adv = torch.empty(B, dtype=torch.float32, device=dev)
+        L.call("sg_pd_head_fwd", L.ptr(h), bank.w_f32(slot, rt_lin), L.ptr(b1), L.ptr(emb), L.ptr(adv), B, Cc, L.stream())
+        ctx.save_for_backward(h, emb, labels if rt_emb is not None else None)
+        ctx.rts = (rt_lin, rt_emb, slot)
+        ctx.b1 = b1
+        return adv
+
+    @staticmethod
+    def backward(ctx, dadv):
+        h, emb, labels = ctx.saved_tensors
+        rt_lin, rt_emb, slot = ctx.rts
+        bank = rt_lin.bank()
+        B, Cc = h.shape
+        dadv = _c(dadv.float())
+        dh = torch.empty_like(h)
+        train_w = ctx.needs_input_grad[1]
+        dw1 = bank.dwt(slot, rt_lin) if train_w else L.ptr(torch.zeros(Cc, dtype=torch.float32, device=h.device))
+        db1 = L.ptr(ensure_grad(ctx.b1)) if (ctx.b1 is not None and train_w) else None
+        demb = torch.empty_like(emb) if emb is not None else None
+        L.call("sg_pd_head_bwd", L.ptr(h), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(dh), dw1, db1, L.ptr(demb), B, Cc, L.stream())
+        if emb is not None and ctx.needs_input_grad[3]:
+            L.call("sg_embedding_bwd", L.ptr(demb), L.ptr(labels), bank.dwt(slot, rt_emb), B, Cc, rt_emb.rows, L.stream())
+        return dh, None, None, None, None, None, None, None
+
+
+_LOSS_KIND = {"hinge": 0, "wasserstein": 1, "vanilla": 2}
+
+
+class DLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, real, fake, kind):
+        real, fake = _c(real.float()), _c(fake.float())
+        B = real.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=real.device)
+        dr, df = torch.empty_like(real), torch.empty_like(fake)
+        L.call("sg_loss_d", kind, L.ptr(real), L.ptr(fake), B, L.ptr(loss), L.ptr(dr), L.ptr(df), L.stream())
+        ctx.save_for_backward(dr, df)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dr, df = ctx.saved_tensors
+        return dr * g, df * g, None
+
+
+class GLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, fake, kind):
+        fake = _c(fake.float())
+        loss = torch.empty(1, dtype=torch.float32, device=fake.device)
+        df = torch.empty_like(fake)
+        L.call("sg_loss_g", kind, L.ptr(fake), fake.numel(), L.ptr(loss), L.ptr(df), L.stream())
+        ctx.save_for_backward(df)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return df * g, None

@@ -1,0 +1,321 @@
+"""Host-side mirror of the reference's operator module (reference src/utils/ops.py): same factory names, same ctor
+arguments, same parameter / buffer names -- so it plugs into `cfgs.MODULES` (reference src/config.py:435-495) -- but every
+forward/backward runs on libsgamd.so's gfx950 kernels.
+
+Module-level tensors are logical NCHW like the reference's; internally they are NHWC (zero-copy when the incoming
+tensor is already channels_last). The backbones in `backbones/` call the `*_nhwc` methods directly.
+"""
+import torch
+import torch.nn as nn
+from torch.nn import init
+import torch.nn.functional as F_
+
+from . import _lib as L
+from . import functional as F
+from .bank import get_bank
+
+COMPUTE_DTYPE = torch.float32  # default compute dtype of standalone modules (backbones set it per network)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# helpers
+# ---------------------------------------------------------------------------------------------------------
+def to_nhwc(x, dtype):
+    """logical NCHW tensor -> internal NHWC tensor of the compute dtype."""
+    if x.dim() != 4:
+        raise RuntimeError("expected a 4-D NCHW tensor")
+    if x.dtype == dtype and x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] > 1 and x.is_contiguous() and x.shape[2] * x.shape[3] > 1):
+        return x.permute(0, 2, 3, 1)
+    if x.dtype == torch.float32 and x.is_contiguous():
+        return F.NchwToNhwcFn.apply(x, dtype)
+    y = x.permute(0, 2, 3, 1).contiguous()
+    if y.dtype != dtype:
+        y = F.ConvertFn.apply(y, dtype)
+    return y
+
+
+def to_nchw(y):
+    return y.permute(0, 3, 1, 2)
+
+
+def _root_and_bank(m):
+    """Bank that serves module m: the enclosing network's (set by the backbone) or a private single-layer one."""
+    root = m.__dict__.get("_sg_root")
+    root = root() if root is not None else None
+    if root is None:
+        root = m
+    dtype = getattr(root, "compute_dtype", None) or getattr(m, "compute_dtype", None) or COMPUTE_DTYPE
+    return root, get_bank(root, dtype)
+
+
+def _standalone_slot(m, x):
+    """Standalone use of an op module (operator-factory seam): run the spectral-norm step for this module's own
+    bank right here, exactly like torch's forward pre-hook does for the reference."""
+    root, bank = _root_and_bank(m)
+    if root is m:
+        need_graph = torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in m.parameters()))
+        return bank.begin_forward(need_graph)
+    return bank.current
+
+
+class _WeightLayerMixin:
+    """Bookkeeping shared by Conv2d / Linear / Embedding: optional spectral norm state with torch's names
+    (weight_orig, weight_u, weight_v) and the matrix view the bank normalises."""
+    _sg_weight_layer = True
+
+    def _sg_setup(self, kind, rows, cols, cin, rs, sn, eps=1e-6):
+        self._sg_kind, self._sg_rows, self._sg_cols, self._sg_cin, self._sg_rs = kind, rows, cols, cin, rs
+        self._sg_sn = bool(sn)
+        self._sg_eps = eps
+        if sn:
+            w = self.weight
+            del self._parameters["weight"]
+            self.register_parameter("weight_orig", w)
+            with torch.no_grad():
+                mat = w.reshape(rows, cols)
+                u = F_.normalize(w.new_empty(rows).normal_(0, 1), dim=0, eps=eps)
+                v = F_.normalize(w.new_empty(cols).normal_(0, 1), dim=0, eps=eps)
+            self.register_buffer("weight_u", u)
+            self.register_buffer("weight_v", v)
+
+    @property
+    def master_weight(self):
+        return self.weight_orig if self._sg_sn else self.weight
+
+    def __getattr__(self, name):
+        # `module.weight` on a spectral-norm layer: the reference exposes the (last) normalised weight as a plain
+        # attribute sharing storage with weight_orig right after construction -- init_weights relies on that.
+        if name == "weight" and "weight_orig" in self.__dict__.get("_parameters", {}):
+            return self._parameters["weight_orig"].data
+        return super().__getattr__(name)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# layers
+# ---------------------------------------------------------------------------------------------------------
+class Conv2d(_WeightLayerMixin, nn.Conv2d):
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True, sn=False,
+                 cout_pad=0):
+        nn.Conv2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias)
+        if self.dilation != (1, 1) or self.groups != 1:
+            raise NotImplementedError("dilation/groups are not on the StudioGAN hot path")
+        if self.kernel_size[0] != self.kernel_size[1] and self.stride != (1, 1):
+            raise NotImplementedError
+        kh, kw = self.kernel_size
+        self._sg_rows_pad = cout_pad
+        self._sg_setup("conv", out_channels, in_channels * kh * kw, in_channels, kh * kw, sn)
+
+    def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None):
+        rt = self._sg_rt
+        slot = slot if slot is not None else rt.bank().current
+        kh, kw = self.kernel_size
+        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool)
+        return F.ConvFn.apply(x, self.master_weight, self.bias, res, rt, slot, cfg)
+
+    def forward(self, x):
+        slot = _standalone_slot(self, x)
+        _, bank = _root_and_bank(self)
+        y = self.forward_nhwc(to_nhwc(x, bank.dtype), slot)
+        if self._sg_rows_pad and self._sg_rows_pad != self.out_channels:
+            y = y[..., :self.out_channels]
+        return to_nchw(y)
+
+
+class Linear(_WeightLayerMixin, nn.Linear):
+    def __init__(self, in_features, out_features, bias=True, sn=False):
+        nn.Linear.__init__(self, in_features, out_features, bias)
+        self._sg_setup("linear", out_features, in_features, in_features, 1, sn)
+
+    def forward_rt(self, x, slot=None, const_bias=None):
+        rt = self._sg_rt
+        slot = slot if slot is not None else rt.bank().current
+        return F.LinearFn.apply(x, self.master_weight, self.bias, rt, slot, const_bias)
+
+    def forward(self, x):
+        slot = _standalone_slot(self, x)
+        shp = x.shape
+        y = self.forward_rt(x.reshape(-1, shp[-1]), slot)
+        return y.reshape(*shp[:-1], self.out_features)
+
+
+class Embedding(_WeightLayerMixin, nn.Embedding):
+    def __init__(self, num_embeddings, embedding_dim, sn=False):
+        nn.Embedding.__init__(self, num_embeddings, embedding_dim)
+        self._sg_setup("embedding", num_embeddings, embedding_dim, embedding_dim, 1, sn)
+
+    def forward(self, idx):
+        if not self._sg_sn:
+            return F.EmbeddingFn.apply(self.weight, idx.reshape(-1)).reshape(*idx.shape, self.embedding_dim)
+        slot = _standalone_slot(self, idx)
+        rt = self._sg_rt
+        return F.SNEmbeddingFn.apply(self.weight_orig, idx.reshape(-1), rt, slot).reshape(*idx.shape, self.embedding_dim)
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    """nn.BatchNorm2d(eps=1e-4, momentum=0.1) semantics (reference src/utils/ops.py:227-228) incl. the
+    track_running_stats toggling the driver does (reference src/utils/misc.py:239-267)."""
+    sync_group = None  # set to a process group (or True for WORLD) to get synchronised statistics
+
+    def _cfg(self, relu):
+        if self.training:
+            batch_stats = True
+        else:
+            batch_stats = (self.running_mean is None) or (not self.track_running_stats)
+        # F.batch_norm gets running stats only `if not self.training or self.track_running_stats`
+        track = self.training and self.track_running_stats and self.running_mean is not None
+        mom = 0.0 if self.momentum is None else self.momentum
+        return F.BNCfg(batch_stats, track, self.eps, mom, relu, self.sync_group)
+
+    def forward_nhwc(self, x, gain=None, bias=None, relu=False):
+        cfg = self._cfg(relu)
+        if cfg.track and self.num_batches_tracked is not None:
+            self.num_batches_tracked.add_(1)
+        if gain is None and self.affine:
+            gain, bias = self.weight, self.bias
+        return F.BNFn.apply(x, gain, bias, self.running_mean, self.running_var, cfg)
+
+    def forward(self, x):
+        dtype = getattr(self, "compute_dtype", None) or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else COMPUTE_DTYPE)
+        return to_nchw(self.forward_nhwc(to_nhwc(x, dtype)))
+
+
+class ConditionalBatchNorm2d(nn.Module):
+    """reference src/utils/ops.py:14-28:  bn(x) * (1 + gain(y)) + bias(y)"""
+
+    def __init__(self, in_features, out_features, MODULES):
+        super().__init__()
+        self.in_features = in_features
+        self.bn = batchnorm_2d(out_features, eps=1e-4, momentum=0.1, affine=False)
+        self.gain = MODULES.g_linear(in_features=in_features, out_features=out_features, bias=False)
+        self.bias = MODULES.g_linear(in_features=in_features, out_features=out_features, bias=False)
+        self.register_buffer("_ones", torch.ones(out_features), persistent=False)
+
+    def forward_nhwc(self, x, y, slot=None, relu=False):
+        gain = self.gain.forward_rt(y, slot, const_bias=self._ones)  # 1 + gain(y) through the GEMM epilogue bias
+        bias = self.bias.forward_rt(y, slot)
+        return self.bn.forward_nhwc(x, gain, bias, relu)
+
+    def forward(self, x, y):
+        _, bank = _root_and_bank(self.gain)
+        if self.gain.__dict__.get("_sg_root") is None:
+            raise RuntimeError("ConditionalBatchNorm2d must live inside a studiogan_amd backbone (its two linears share the network's bank)")
+        return to_nchw(self.forward_nhwc(to_nhwc(x, bank.dtype), y))
+
+
+class SelfAttention(nn.Module):
+    """reference src/utils/ops.py:31-103. theta/phi outputs are padded to a multiple of 8 channels internally."""
+
+    def __init__(self, in_channels, is_generator, MODULES):
+        super().__init__()
+        self.in_channels = in_channels
+        conv = MODULES.g_conv2d if is_generator else MODULES.d_conv2d
+        c8, c2 = in_channels // 8, in_channels // 2
+        pad8 = (c8 + 7) // 8 * 8
+        self.conv1x1_theta = conv(in_channels=in_channels, out_channels=c8, kernel_size=1, stride=1, padding=0, bias=False)
+        self.conv1x1_phi = conv(in_channels=in_channels, out_channels=c8, kernel_size=1, stride=1, padding=0, bias=False)
+        self.conv1x1_g = conv(in_channels=in_channels, out_channels=c2, kernel_size=1, stride=1, padding=0, bias=False)
+        self.conv1x1_attn = conv(in_channels=c2, out_channels=in_channels, kernel_size=1, stride=1, padding=0, bias=False)
+        for m in (self.conv1x1_theta, self.conv1x1_phi):
+            m._sg_rows_pad = pad8
+        self.sigma = nn.Parameter(torch.zeros(1), requires_grad=True)
+
+    def forward_nhwc(self, x, slot=None):
+        theta = self.conv1x1_theta.forward_nhwc(x, slot)
+        phi = self.conv1x1_phi.forward_nhwc(x, slot)
+        g = self.conv1x1_g.forward_nhwc(x, slot)
+        o = F.AttnCoreFn.apply(theta, phi, g)
+        rt = self.conv1x1_attn._sg_rt
+        slot = slot if slot is not None else rt.bank().current
+        return F.AttnOutFn.apply(x, o, self.conv1x1_attn.master_weight, self.sigma, rt, slot)
+
+    def forward(self, x):
+        _, bank = _root_and_bank(self.conv1x1_theta)
+        return to_nchw(self.forward_nhwc(to_nhwc(x, bank.dtype)))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# factory functions with the reference's names/signatures (reference src/utils/ops.py:165-228)
+# ---------------------------------------------------------------------------------------------------------
+def conv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+    return Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, sn=False)
+
+
+def snconv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, bias=True):
+    return Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, sn=True)
+
+
+def linear(in_features, out_features, bias=True):
+    return Linear(in_features, out_features, bias, sn=False)
+
+
+def snlinear(in_features, out_features, bias=True):
+    return Linear(in_features, out_features, bias, sn=True)
+
+
+def embedding(num_embeddings, embedding_dim):
+    return Embedding(num_embeddings, embedding_dim, sn=False)
+
+
+def sn_embedding(num_embeddings, embedding_dim):
+    return Embedding(num_embeddings, embedding_dim, sn=True)
+
+
+def batchnorm_2d(in_features, eps=1e-4, momentum=0.1, affine=True):
+    return BatchNorm2d(in_features, eps=eps, momentum=momentum, affine=affine, track_running_stats=True)
+
+
+def init_weights(modules, initialize):
+    """reference src/utils/ops.py:135-162 (orthogonal / N(0,0.02) / xavier on conv, linear, embedding weights)."""
+    for module in modules():
+        if isinstance(module, (nn.Conv2d, nn.ConvTranspose2d, nn.Linear)):
+            w = module.master_weight if hasattr(module, "master_weight") else module.weight
+            if initialize == "ortho":
+                init.orthogonal_(w)
+            elif initialize == "N02":
+                init.normal_(w, 0, 0.02)
+            elif initialize in ["glorot", "xavier"]:
+                init.xavier_uniform_(w)
+            else:
+                continue
+            if module.bias is not None:
+                module.bias.data.fill_(0.)
+        elif isinstance(module, nn.Embedding):
+            w = module.master_weight if hasattr(module, "master_weight") else module.weight
+            if initialize == "ortho":
+                init.orthogonal_(w)
+            elif initialize == "N02":
+                init.normal_(w, 0, 0.02)
+            elif initialize in ["glorot", "xavier"]:
+                init.xavier_uniform_(w)
+
+
+def adopt(root, compute_dtype):
+    """Mark every op module under `root` as belonging to root's weight bank."""
+    import weakref
+    root.compute_dtype = compute_dtype
+    ref = weakref.ref(root)
+    for m in root.modules():
+        if m is not root:
+            m.__dict__["_sg_root"] = ref
+
+
+class Modules:
+    """Drop-in for `cfgs.MODULES` (reference src/config.py:435-495) built from the same MODEL flags."""
+
+    def __init__(self, apply_g_sn=False, apply_d_sn=False, g_cond_mtd="W/O", backbone="big_resnet", g_act_fn="ReLU", d_act_fn="ReLU"):
+        self.g_conv2d = snconv2d if apply_g_sn else conv2d
+        self.g_linear = snlinear if apply_g_sn else linear
+        self.g_embedding = sn_embedding if apply_g_sn else embedding
+        self.d_conv2d = snconv2d if apply_d_sn else conv2d
+        self.d_linear = snlinear if apply_d_sn else linear
+        self.d_embedding = sn_embedding if apply_d_sn else embedding
+        if g_cond_mtd == "cBN" or backbone == "big_resnet":
+            self.g_bn = ConditionalBatchNorm2d
+        else:
+            self.g_bn = batchnorm_2d
+        if not apply_d_sn:
+            self.d_bn = batchnorm_2d
+        if g_act_fn != "ReLU" or d_act_fn != "ReLU":
+            raise NotImplementedError("only ReLU is on the benchmarked hot path")
+        self.g_act_fn = nn.ReLU(inplace=True)
+        self.d_act_fn = nn.ReLU(inplace=True)
