@@ -1,0 +1,174 @@
+"""Generate tests/golden/*.npz by running the REAL reference (imported from /root/reference with stubs) on CPU and
+check the restatement (oracle/restate.py) against it on the same inputs.
+
+    python oracle/make_golden.py            # writes fixtures, prints max |restate - reference| per tensor family
+
+Runs only in the authoring container (needs /root/reference). The fixtures are committed; the GPU box never needs the
+reference. TEST INFRASTRUCTURE ONLY.
+
+A fixture holds, for one small configuration: the initial G/D parameters + buffers, the synthetic inputs (z, labels,
+uint8-grid real images; all from a seeded CPU generator as SURVEY.md §8d prescribes), and what the reference produced
+over one training step (n_d discriminator updates + one generator update, reference src/loader.py:392-405):
+fake images, logits, losses, every parameter gradient of the first D update and of the G update, and the final
+parameters / buffers (spectral-norm u,v; BN running statistics) after the Adam steps.
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import ref_import as R  # noqa: E402
+from oracle import restate as O  # noqa: E402
+
+GOLDEN_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+CONFIGS = {
+    # small BigGAN (same code path as C3: cBN + PD + SN on both + attention in G and D, hinge)
+    "biggan32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "big_resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [2], "attn_d_loc": [1], "z_dim": 40, "g_shared_dim": 16, "g_conv_dim": 8, "d_conv_dim": 8},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=1234),
+}
+
+
+def oracle_cfg(y):
+    M, D = y["MODEL"], y["DATA"]
+    return dict(img_size=D["img_size"], num_classes=D["num_classes"], g_conv_dim=M.get("g_conv_dim", 64), d_conv_dim=M.get("d_conv_dim", 64),
+                z_dim=M.get("z_dim", 128), attn_g_loc=M.get("attn_g_loc", []), attn_d_loc=M.get("attn_d_loc", []), apply_attn=M.get("apply_attn", False),
+                g_cond_mtd=M.get("g_cond_mtd", "W/O"), d_cond_mtd=M.get("d_cond_mtd", "W/O"), apply_g_sn=M.get("apply_g_sn", False),
+                apply_d_sn=M.get("apply_d_sn", False), backbone=M.get("backbone", "resnet"), g_shared_dim=M.get("g_shared_dim", 0))
+
+
+def synth_inputs(seed, n_d, batch, z_dim, num_classes, img_size):
+    g = torch.Generator().manual_seed(seed)
+    ins = {}
+    for i in range(n_d + 1):
+        ins[f"z{i}"] = torch.randn(batch, z_dim, generator=g)
+        ins[f"fl{i}"] = torch.randint(0, num_classes, (batch,), generator=g)
+    for i in range(n_d):
+        k = torch.randint(0, 256, (batch, 3, img_size, img_size), generator=g)
+        ins[f"real{i}"] = k.float() / 127.5 - 1.0
+        ins[f"rl{i}"] = torch.randint(0, num_classes, (batch,), generator=g)
+    return ins
+
+
+def run_reference(cfgs, Gen, Dis, ins, n_d):
+    misc = importlib.import_module("utils.misc")
+    cfgs.define_losses()
+    cfgs.define_optimizer(Gen, Dis)
+    g_opt, d_opt = cfgs.OPTIMIZATION.g_optimizer, cfgs.OPTIMIZATION.d_optimizer
+    exp = {}
+    for i in range(n_d):  # worker.train_discriminator (src/worker.py:213-497)
+        misc.make_GAN_trainable(Gen, None, Dis)
+        misc.toggle_grad(Gen, False)
+        misc.toggle_grad(Dis, True)
+        Gen.apply(misc.untrack_bn_statistics)
+        d_opt.zero_grad()
+        fake = Gen(ins[f"z{i}"], ins[f"fl{i}"])
+        rd = Dis(ins[f"real{i}"], ins[f"rl{i}"])
+        fd = Dis(fake, ins[f"fl{i}"])
+        loss = cfgs.LOSS.d_loss(rd["adv_output"], fd["adv_output"], DDP=False)
+        loss.backward()
+        if i == 0:
+            exp["fake0"], exp["adv_r0"], exp["adv_f0"] = fake.detach().clone(), rd["adv_output"].detach().clone(), fd["adv_output"].detach().clone()
+            exp["d_loss0"] = loss.detach().clone()
+            for k, p in Dis.named_parameters():
+                exp["D_grad0/" + k] = p.grad.detach().clone()
+        d_opt.step()
+    misc.make_GAN_trainable(Gen, None, Dis)  # worker.train_generator (src/worker.py:502-681)
+    misc.toggle_grad(Dis, False)
+    misc.toggle_grad(Gen, True)
+    Gen.apply(misc.track_bn_statistics)
+    g_opt.zero_grad()
+    fake = Gen(ins[f"z{n_d}"], ins[f"fl{n_d}"])
+    fd = Dis(fake, ins[f"fl{n_d}"])
+    loss = cfgs.LOSS.g_loss(fd["adv_output"], DDP=False)
+    loss.backward()
+    exp["g_loss"] = loss.detach().clone()
+    exp["fake_g"] = fake.detach().clone()
+    for k, p in Gen.named_parameters():
+        exp["G_grad/" + k] = p.grad.detach().clone()
+    g_opt.step()
+    for k, v in list(Gen.named_parameters()) + list(Gen.named_buffers()):
+        exp["G_final/" + k] = v.detach().clone()
+    for k, v in list(Dis.named_parameters()) + list(Dis.named_buffers()):
+        exp["D_final/" + k] = v.detach().clone()
+    return exp
+
+
+def run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d):
+    """Same step through oracle/restate.py (this is also what the GPU tests execute as the checker)."""
+    opt = y.get("OPTIMIZATION", {})
+    g_lr, d_lr = opt.get("g_lr", 0.0002), opt.get("d_lr", 0.0002)
+    b1, b2 = opt.get("beta1", 0.5), opt.get("beta2", 0.999)
+    kind = y.get("LOSS", {}).get("adv_loss", "vanilla")
+    gen_fn, dis_fn = O.model_fns(ocfg)
+    g_opt, d_opt = O.AdamState(GP, g_lr, b1, b2), O.AdamState(DP, d_lr, b1, b2)
+    exp = {}
+    for i in range(n_d):
+        out = O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [ins[f"real{i}"]], [ins[f"rl{i}"]], [ins[f"z{i}"]], [ins[f"fl{i}"]], kind,
+                         record=(i == 0))
+        if i == 0:
+            exp["fake0"], exp["adv_r0"], exp["adv_f0"] = out["fake"], out["adv_r"], out["adv_f"]
+            exp["d_loss0"] = torch.tensor(out["loss"])
+            for k, g in out["grads"].items():
+                exp["D_grad0/" + k] = g
+    out = O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [ins[f"z{n_d}"]], [ins[f"fl{n_d}"]], kind, record=True)
+    exp["g_loss"] = torch.tensor(out["loss"])
+    exp["fake_g"] = out["fake"]
+    for k, g in out["grads"].items():
+        exp["G_grad/" + k] = g
+    for k, v in list(GP.items()) + list(GB.items()):
+        exp["G_final/" + k] = v.detach().clone()
+    for k, v in list(DP.items()) + list(DB.items()):
+        exp["D_final/" + k] = v.detach().clone()
+    return exp
+
+
+def main():
+    os.makedirs(GOLDEN_DIR, exist_ok=True)
+    assert R.available(), "/root/reference is required to (re)generate the golden fixtures"
+    for name, c in CONFIGS.items():
+        y = c["yaml"]
+        cfgs = R.load_cfgs(y)
+        torch.manual_seed(c["seed"])
+        Gen, Dis = R.build_models(cfgs)
+        GP, GB = R.split_state(Gen)
+        DP, DB = R.split_state(Dis)
+        ocfg = oracle_cfg(y)
+        ins = synth_inputs(c["seed"] + 1, c["n_d"], c["batch"], ocfg["z_dim"], ocfg["num_classes"], ocfg["img_size"])
+        fix = {}
+        for k, v in list(GP.items()) + list(GB.items()):
+            fix["G_init/" + k] = v.clone()
+        for k, v in list(DP.items()) + list(DB.items()):
+            fix["D_init/" + k] = v.clone()
+        for k, v in ins.items():
+            fix["in/" + k] = v
+        exp_ref = run_reference(cfgs, Gen, Dis, ins, c["n_d"])
+        exp_res = run_restatement(ocfg, y, GP, GB, DP, DB, ins, c["n_d"])
+        worst = {}
+        for k, v in exp_ref.items():
+            fam = k.split("/")[0]
+            a, b = v.double(), exp_res[k].double()
+            err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
+            worst[fam] = max(worst.get(fam, 0.0), err)
+            fix["exp/" + k] = v
+        print(name, "restatement vs reference, max relative-to-range error per family:")
+        for fam, e in sorted(worst.items()):
+            print(f"   {fam:10s} {e:.3e}")
+        assert max(worst.values()) < 2e-5, "oracle restatement disagrees with the reference"
+        np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **{k: v.numpy() for k, v in fix.items()})
+        import json
+        with open(os.path.join(GOLDEN_DIR, name + ".json"), "w") as f:
+            json.dump({"yaml": y, "batch": c["batch"], "n_d": c["n_d"], "seed": c["seed"]}, f, indent=1)
+        print("   wrote", name + ".npz", os.path.getsize(os.path.join(GOLDEN_DIR, name + ".npz")) // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,313 @@
+"""CPU oracle: a plain-torch (CPU, fp32/fp64) functional RESTATEMENT of the StudioGAN hot path.
+
+TEST INFRASTRUCTURE ONLY. Nothing under studiogan_amd/ (the product path) imports this file; only tests/,
+__graft_entry__.smoke() and bench.py's cpu_baseline leg do, and only as the checker / timed CPU baseline.
+
+Every function cites the reference lines it restates (paths relative to /root/reference/src). The restatement is
+validated against the real reference (imported with stubs by oracle/ref_import.py in the authoring container) by
+oracle/make_golden.py, which also writes the committed fixtures in tests/golden/.  Pin status: the reference has no
+tests or golden vectors of its own; the pins are (i) outputs of the reference code itself run on CPU
+(tests/golden/*.npz) and (ii) the parameter counts printed in the reference's training logs.
+
+State convention: `P` maps reference parameter names to tensors, `B` maps buffer names to tensors (updated in place,
+like the modules do). Names are the reference's state_dict keys.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+
+
+# ---------------------------------------------------------------------------------------------------------
+# spectral norm -- torch.nn.utils.spectral_norm (installed torch/nn/utils/spectral_norm.py:92-114) as applied by
+# utils/ops.py:195-224 with eps=1e-6, one power iteration per forward call while the module is in .train()
+# ---------------------------------------------------------------------------------------------------------
+def _l2n(v, eps):
+    # F.normalize(v, dim=0, eps): v / max(||v||_2, eps)
+    return v / torch.clamp(v.norm(), min=eps)
+
+
+def weight_of(P, B, name, power_iterate=True, eps=1e-6):
+    """Effective weight of layer `name`: W/sigma for spectral-norm layers (power iteration updates B in place)."""
+    if name + ".weight_orig" not in P:
+        return P[name + ".weight"]
+    w = P[name + ".weight_orig"]
+    u, v = B[name + ".weight_u"], B[name + ".weight_v"]
+    mat = w.reshape(w.shape[0], -1)
+    if power_iterate:
+        with torch.no_grad():
+            v_new = _l2n(mat.t().mv(u), eps)
+            u_new = _l2n(mat.mv(v_new), eps)
+            v.copy_(v_new)
+            u.copy_(u_new)
+    u_c, v_c = u.clone(), v.clone()
+    sigma = torch.dot(u_c, mat.mv(v_c))
+    return w / sigma
+
+
+def conv(x, P, B, name, padding, sn_iter=True):
+    w = weight_of(P, B, name, sn_iter)
+    return F.conv2d(x, w, P.get(name + ".bias"), stride=1, padding=padding)
+
+
+def linear(x, P, B, name, sn_iter=True):
+    return F.linear(x, weight_of(P, B, name, sn_iter), P.get(name + ".bias"))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# batch norm (utils/ops.py:227-228: eps 1e-4, momentum 0.1) and conditional batch norm (utils/ops.py:14-28)
+# bn_mode: "track"   = .train() with running-stat updates (G-update, worker.py:513)
+#          "untrack" = batch statistics, running stats untouched (D-update, worker.py:225, utils/misc.py:244-246)
+#          "eval"    = running statistics
+# ---------------------------------------------------------------------------------------------------------
+def batch_norm(x, P, B, name, bn_mode, eps=1e-4, momentum=0.1):
+    w, b = P.get(name + ".weight"), P.get(name + ".bias")
+    if bn_mode == "untrack":
+        return F.batch_norm(x, None, None, w, b, True, momentum, eps)
+    rm, rv = B[name + ".running_mean"], B[name + ".running_var"]
+    if bn_mode == "track":
+        B[name + ".num_batches_tracked"] += 1
+        return F.batch_norm(x, rm, rv, w, b, True, momentum, eps)
+    return F.batch_norm(x, rm, rv, w, b, False, momentum, eps)
+
+
+def cond_batch_norm(x, y, P, B, name, bn_mode, sn_iter=True):
+    gain = (1 + linear(y, P, B, name + ".gain", sn_iter)).view(y.size(0), -1, 1, 1)
+    bias = linear(y, P, B, name + ".bias", sn_iter).view(y.size(0), -1, 1, 1)
+    return batch_norm(x, P, B, name + ".bn", bn_mode) * gain + bias
+
+
+# ---------------------------------------------------------------------------------------------------------
+# self attention (utils/ops.py:83-103)
+# ---------------------------------------------------------------------------------------------------------
+def self_attention(x, P, B, name, sn_iter=True):
+    n, ch, h, w = x.shape
+    theta = conv(x, P, B, name + ".conv1x1_theta", 0, sn_iter).view(n, ch // 8, h * w)
+    phi = F.max_pool2d(conv(x, P, B, name + ".conv1x1_phi", 0, sn_iter), 2, 2).view(n, ch // 8, h * w // 4)
+    attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
+    g = F.max_pool2d(conv(x, P, B, name + ".conv1x1_g", 0, sn_iter), 2, 2).view(n, ch // 2, h * w // 4)
+    attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(n, ch // 2, h, w)
+    attn_g = conv(attn_g, P, B, name + ".conv1x1_attn", 0, sn_iter)
+    return x + P[name + ".sigma"] * attn_g
+
+
+# ---------------------------------------------------------------------------------------------------------
+# BigGAN (models/big_resnet.py)
+# ---------------------------------------------------------------------------------------------------------
+def biggan_dims(img_size, ch):
+    g_in = {32: [4, 4, 4], 64: [16, 8, 4, 2], 128: [16, 16, 8, 4, 2], 256: [16, 16, 8, 8, 4, 2]}[img_size]
+    g_out = {32: [4, 4, 4], 64: [8, 4, 2, 1], 128: [16, 8, 4, 2, 1], 256: [16, 8, 8, 4, 2, 1]}[img_size]
+    d_in = {32: [2, 2, 2], 64: [1, 2, 4, 8], 128: [1, 2, 4, 8, 16], 256: [1, 2, 4, 8, 8, 16]}[img_size]
+    d_out = {32: [2, 2, 2, 2], 64: [1, 2, 4, 8, 16], 128: [1, 2, 4, 8, 16, 16], 256: [1, 2, 4, 8, 8, 16, 16]}[img_size]
+    d_down = {32: [True, True, False, False], 64: [True] * 4 + [False], 128: [True] * 5 + [False], 256: [True] * 6 + [False]}[img_size]
+    return [c * ch for c in g_in], [c * ch for c in g_out], [3] + [c * ch for c in d_in], [c * ch for c in d_out], d_down
+
+
+def biggan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet.py:122-158 (Generator.forward) + GenBlock.forward :28-42.
+    cfg: dict(img_size, g_conv_dim, z_dim, attn_g_loc, apply_attn, g_cond_mtd)."""
+    g_in, g_out, _, _, _ = biggan_dims(cfg["img_size"], cfg["g_conv_dim"])
+    nb = len(g_in)
+    chunk = cfg["z_dim"] // (nb + 1)
+    zs = torch.split(z, chunk, 1)
+    if cfg.get("g_cond_mtd", "cBN") != "W/O":
+        shared = F.embedding(label, P["shared.weight"])
+        affines = [torch.cat([shared, item], 1) for item in zs[1:]]
+    else:
+        affines = list(zs[1:])
+    act = linear(zs[0], P, B, "linear0", sn_iter).view(-1, g_in[0], 4, 4)
+    bi = 0
+    for index in range(nb):
+        pre = f"blocks.{bi}.0"
+        x0 = act
+        x = torch.relu(cond_batch_norm(act, affines[index], P, B, pre + ".bn1", bn_mode, sn_iter))
+        x = F.interpolate(x, scale_factor=2, mode="nearest")
+        x = conv(x, P, B, pre + ".conv2d1", 1, sn_iter)
+        x = torch.relu(cond_batch_norm(x, affines[index], P, B, pre + ".bn2", bn_mode, sn_iter))
+        x = conv(x, P, B, pre + ".conv2d2", 1, sn_iter)
+        x0 = conv(F.interpolate(x0, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter)
+        act = x + x0
+        bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            bi += 1
+    act = torch.relu(batch_norm(act, P, B, "bn4", bn_mode))
+    return torch.tanh(conv(act, P, B, "conv2d5", 1, sn_iter))
+
+
+def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet.py:349-428 (Discriminator.forward), DiscOptBlock :177-192, DiscBlock :221-242.
+    With apply_d_sn the blocks have no BN and nn.ReLU(inplace=True) (config.py:476) rewrites the block input, so the
+    shortcut branch of DiscBlock ALSO sees relu(x) -- restated explicitly here (r = relu(x))."""
+    _, _, d_in, d_out, d_down = biggan_dims(cfg["img_size"], cfg["d_conv_dim"])
+    sn = cfg["apply_d_sn"]
+    h = x
+    bi = 0
+    for index in range(len(d_in)):
+        pre = f"blocks.{bi}.0"
+        if index == 0:
+            x0 = h
+            y = conv(h, P, B, pre + ".conv2d1", 1, sn_iter)
+            if not sn:
+                y = batch_norm(y, P, B, pre + ".bn1", bn_mode)
+            y = F.avg_pool2d(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter), 2)
+            x0 = F.avg_pool2d(x0, 2)
+            if not sn:
+                x0 = batch_norm(x0, P, B, pre + ".bn0", bn_mode)
+            h = y + conv(x0, P, B, pre + ".conv2d0", 0, sn_iter)
+        else:
+            down, mismatch = d_down[index], d_in[index] != d_out[index]
+            if sn:
+                r = torch.relu(h)
+                x0 = r
+                y = r
+            else:
+                x0 = h
+                y = torch.relu(batch_norm(h, P, B, pre + ".bn1", bn_mode))
+            y = conv(y, P, B, pre + ".conv2d1", 1, sn_iter)
+            if not sn:
+                y = batch_norm(y, P, B, pre + ".bn2", bn_mode)
+            y = conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter)
+            if down:
+                y = F.avg_pool2d(y, 2)
+            if down or mismatch:
+                if not sn:
+                    x0 = batch_norm(x0, P, B, pre + ".bn0", bn_mode)
+                x0 = conv(x0, P, B, pre + ".conv2d0", 0, sn_iter)
+                if down:
+                    x0 = F.avg_pool2d(x0, 2)
+            h = y + x0
+        bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter)
+            bi += 1
+    h = torch.sum(torch.relu(h), dim=[2, 3])
+    adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
+    if cfg.get("d_cond_mtd", "W/O") == "PD":
+        emb = F.embedding(label, weight_of(P, B, "embedding", sn_iter))
+        adv = adv + torch.sum(emb * h, 1)
+    return adv, h
+
+
+# ---------------------------------------------------------------------------------------------------------
+# losses (utils/losses.py:197-239) / gradient penalty (utils/losses.py:268-275,301-316)
+# ---------------------------------------------------------------------------------------------------------
+def d_loss(kind, real, fake):
+    if kind == "hinge":
+        return torch.mean(F.relu(1. - real)) + torch.mean(F.relu(1. + fake))
+    if kind == "wasserstein":
+        return torch.mean(fake - real)
+    if kind == "vanilla":
+        return torch.mean(F.softplus(-real)) + torch.mean(F.softplus(fake))
+    raise ValueError(kind)
+
+
+def g_loss(kind, fake):
+    if kind in ("hinge", "wasserstein"):
+        return -torch.mean(fake)
+    if kind == "vanilla":
+        return torch.mean(F.softplus(-fake))
+    raise ValueError(kind)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# optimizer / EMA (config.py:541-563 torch.optim.Adam eps=1e-6; utils/ema.py:27-40)
+# ---------------------------------------------------------------------------------------------------------
+def adam_step(p, g, m, v, step, lr, beta1, beta2, eps=1e-6):
+    """In-place torch.optim.Adam single-tensor update (installed torch/optim/adam.py _single_tensor_adam)."""
+    m.lerp_(g, 1 - beta1)
+    v.mul_(beta2).addcmul_(g, g, value=1 - beta2)
+    bc1 = 1 - beta1 ** step
+    bc2 = 1 - beta2 ** step
+    denom = (v.sqrt() / math.sqrt(bc2)).add_(eps)
+    p.addcdiv_(m, denom, value=-(lr / bc1))
+
+
+def ema_update(src_P, src_B, ema_P, ema_B, step, decay=0.9999, start_iter=0):
+    d = 0.0 if (0 <= step < start_iter) else decay
+    with torch.no_grad():
+        for k in ema_P:
+            ema_P[k].copy_(src_P[k].lerp(ema_P[k], d))
+        for k in ema_B:
+            if "num_batches_tracked" in k:
+                ema_B[k].copy_(src_B[k])
+            else:
+                ema_B[k].copy_(src_B[k].lerp(ema_B[k], d))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# one training step, re-enacting worker.py:213-497 (train_discriminator) and :502-681 (train_generator) for the
+# conv-GAN family without augmentation: returns losses; updates P/B/optimizer state in place
+# ---------------------------------------------------------------------------------------------------------
+class AdamState:
+    def __init__(self, P, lr, beta1, beta2, eps=1e-6):
+        self.lr, self.b1, self.b2, self.eps = lr, beta1, beta2, eps
+        self.m = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in P.items()}
+        self.t = 0
+
+    def step(self, P, grads):
+        self.t += 1
+        with torch.no_grad():
+            for k, p in P.items():
+                if grads.get(k) is None:
+                    continue
+                adam_step(p, grads[k], self.m[k], self.v[k], self.t, self.lr, self.b1, self.b2, self.eps)
+
+
+def _leaves(P):
+    return {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
+
+
+def d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, real, real_labels, z, fake_labels, loss_kind="hinge", record=False):
+    """One discriminator update on pre-drawn (z, fake_labels, real) micro-batches (lists of length acml).
+    G runs in train mode without BN-stat tracking and without a graph (worker.py:216-225)."""
+    acml = len(z)
+    leaves = _leaves(DP)
+    out = {"loss": 0.0}
+    for i in range(acml):
+        with torch.no_grad():
+            fake = gen_fn(z[i], fake_labels[i], GP, GB, bn_mode="untrack")
+        adv_r, _ = dis_fn(real[i], real_labels[i], leaves, DB)
+        adv_f, _ = dis_fn(fake, fake_labels[i], leaves, DB)
+        loss = d_loss(loss_kind, adv_r, adv_f) / acml
+        loss.backward()
+        out["loss"] += float(loss)
+        if record and i == 0:
+            out["fake"], out["adv_r"], out["adv_f"] = fake.detach(), adv_r.detach(), adv_f.detach()
+    grads = {k: v.grad for k, v in leaves.items()}
+    out["grads"] = grads
+    d_opt.step(DP, grads)
+    return out
+
+
+def g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, z, fake_labels, loss_kind="hinge", record=False):
+    """One generator update (worker.py:502-681): G tracks BN stats; D weights frozen but its SN still iterates."""
+    acml = len(z)
+    leaves = _leaves(GP)
+    out = {"loss": 0.0}
+    for i in range(acml):
+        fake = gen_fn(z[i], fake_labels[i], leaves, GB, bn_mode="track")
+        adv_f, _ = dis_fn(fake, fake_labels[i], DP, DB)
+        loss = g_loss(loss_kind, adv_f) / acml
+        loss.backward()
+        out["loss"] += float(loss)
+        if record and i == 0:
+            out["fake"], out["adv_f"] = fake.detach(), adv_f.detach()
+    grads = {k: v.grad for k, v in leaves.items()}
+    out["grads"] = grads
+    g_opt.step(GP, grads)
+    return out
+
+
+def model_fns(cfg):
+    """(generator_fn, discriminator_fn) closures for a configuration dict (see oracle/make_golden.py:oracle_cfg)."""
+    bb = cfg.get("backbone", "big_resnet")
+    if bb == "big_resnet":
+        def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_generator(z, y, P, B, cfg, bn_mode, sn_iter)
+
+        def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
+        return gen_fn, dis_fn
+    raise NotImplementedError(bb)

@@ -106,6 +106,24 @@ class BufferArena:
                 view.copy_(b)
                 b.set_(view)  # in place: the module's registered buffer object now aliases the arena
 
+    def intact(self, root):
+        bufs = [b for _, b in root.named_buffers() if b is not None and b.dtype == torch.float32]
+        if len(bufs) != len(self.bufs):
+            return False
+        base = self.data.data_ptr()
+        return all(b.data_ptr() == base + 4 * o for b, o in zip(bufs, self.offsets))
+
+
+def get_buffer_arena(root):
+    """The (single) buffer arena of a network; rebuilt when .to()/deepcopy replaced the buffer tensors."""
+    h = root.__dict__.get("_sg_buf_holder")
+    if h is None:
+        h = _Holder()
+        root.__dict__["_sg_buf_holder"] = h
+    if h.obj is None or not h.obj.intact(root):
+        h.obj = BufferArena(list(root.named_buffers()))
+    return h.obj
+
 
 class _Holder:
     """Keeps runtime state (ctypes tables, arenas) out of copy.deepcopy / pickling of the owning nn.Module."""
@@ -158,7 +176,7 @@ class WeightBank:
             self.params = ParamArena(params)
         else:
             self.params = arena_of(params[0])[0]
-        self.buffers = BufferArena(list(root.named_buffers()))
+        self.buffers = get_buffer_arena(root)
         # 2. per-layer records and arena offsets
         es = 2 if compute_dtype == torch.bfloat16 else 4
         self.layers = []
@@ -244,7 +262,8 @@ class WeightBank:
         return ent
 
     def intact(self):
-        return self.params.intact()
+        root = self.root_ref()
+        return self.params.intact() and root is not None and self.buffers.intact(root) and get_buffer_arena(root) is self.buffers
 
     def begin_forward(self, need_graph):
         """One spectral-norm power iteration + weight image emission for every layer; returns the slot."""

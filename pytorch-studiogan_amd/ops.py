@@ -157,10 +157,8 @@ class BatchNorm2d(nn.BatchNorm2d):
     sync_group = None  # set to a process group (or True for WORLD) to get synchronised statistics
 
     def _cfg(self, relu):
-        if self.training:
-            batch_stats = True
-        else:
-            batch_stats = (self.running_mean is None) or (not self.track_running_stats)
+        # torch: bn_training = self.training or (running_mean is None and running_var is None)
+        batch_stats = self.training or (self.running_mean is None)
         # F.batch_norm gets running stats only `if not self.training or self.track_running_stats`
         track = self.training and self.track_running_stats and self.running_mean is not None
         mom = 0.0 if self.momentum is None else self.momentum

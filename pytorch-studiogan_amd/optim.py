@@ -1,0 +1,138 @@
+"""Fused Adam (+EMA) over the flat parameter arena and the explicit data-parallel gradient exchange.
+
+Replaces torch.optim.Adam(eps=1e-6) (reference src/config.py:541-563), utils/ema.py:27-40 and DistributedDataParallel's
+bucketed all-reduce (reference src/models/model.py:171-180): gradients of a network already sit in ONE contiguous fp32
+buffer, so the exchange is a few large RCCL all-reduces issued once per update (not per accumulation micro-step),
+pipelined against the optimizer kernel chunk by chunk.
+"""
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from .bank import ParamArena, arena_of, get_buffer_arena
+
+
+def _arena_for(params):
+    ents = [arena_of(p) for p in params]
+    if any(e is None for e in ents) or len({id(e[0]) for e in ents}) != 1 or not ents[0][0].intact():
+        return ParamArena(params)
+    return ents[0][0]
+
+
+class FusedAdam(torch.optim.Optimizer):
+    """torch.optim.Adam semantics (no amsgrad) for ALL parameters of one network in one launch."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.0, comm_chunks=4):
+        defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
+        super().__init__(params, defaults)
+        assert len(self.param_groups) == 1, "one parameter group per network"
+        self._arena = None
+        self._m = self._v = None
+        self._t = 0
+        self.comm_chunks = comm_chunks
+
+    def _state(self):
+        params = self.param_groups[0]["params"]
+        a = _arena_for(params)
+        if a is not self._arena:
+            m = torch.zeros_like(a.data)
+            v = torch.zeros_like(a.data)
+            if self._arena is not None:  # arena was rebuilt (module.to()/deepcopy): carry the moments over
+                old = self._arena
+                for p, o_new in zip(a.params, a.offsets):
+                    for q, o_old in zip(old.params, old.offsets):
+                        if q is p:
+                            m[o_new:o_new + p.numel()] = self._m[o_old:o_old + p.numel()]
+                            v[o_new:o_new + p.numel()] = self._v[o_old:o_old + p.numel()]
+            self._arena, self._m, self._v = a, m, v
+        return a
+
+    def zero_grad(self, set_to_none=False):
+        a = self._state()
+        a.grad.zero_()
+        for p, o in zip(a.params, a.offsets):
+            p.grad = a.grad[o:o + p.numel()].view(p.shape)
+
+    @torch.no_grad()
+    def step(self, closure=None, ema=None, iteration=None, group=None):
+        """ema: optional `Ema` whose target shares this network's arena layout -> fused into the same launch."""
+        a = self._state()
+        g = self.param_groups[0]
+        for p, o in zip(a.params, a.offsets):
+            if p.grad is None or p.grad.data_ptr() != a.grad.data_ptr() + 4 * o:
+                # a foreign gradient tensor (e.g. produced by plain autograd): fold it into the arena
+                if p.grad is not None:
+                    a.grad[o:o + p.numel()].copy_(p.grad.reshape(-1))
+                p.grad = a.grad[o:o + p.numel()].view(p.shape)
+        self._t += 1
+        ema_ptr, decay = None, 0.0
+        if ema is not None:
+            ema_ptr = ema.target_arena().data.data_ptr()
+            decay = ema.decay_at(iteration)
+        world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+        n = a.numel
+        st = L.stream()
+        if world > 1:
+            # pipelined all-reduce(sum) -> Adam(grad/world): chunk i+1 is on the wire while chunk i is being applied
+            nch = max(1, min(self.comm_chunks, n // (1 << 20) or 1))
+            per = ((n + nch - 1) // nch + 3) // 4 * 4
+            works = []
+            for c in range(nch):
+                lo, hi = c * per, min(n, (c + 1) * per)
+                if lo >= hi:
+                    break
+                works.append((lo, hi, dist.all_reduce(a.grad[lo:hi], group=group, async_op=True)))
+            for lo, hi, w in works:
+                w.wait()
+                L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                       self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)
+        else:
+            L.call("sg_adam_ema", a.data.data_ptr(), a.grad.data_ptr(), self._m.data_ptr(), self._v.data_ptr(), ema_ptr, n, g["lr"],
+                   g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t, decay, 1.0, st)
+        if ema is not None:
+            ema.update_buffers(decay)
+
+
+class Ema:
+    """reference src/utils/ema.py:11-40 on the flat arenas: parameters are lerped inside the fused Adam launch (or by
+    `update()` when driven like the reference does), buffers by one more launch."""
+
+    def __init__(self, source, target, decay=0.9999, start_iter=0):
+        self.source, self.target = source, target
+        self.decay, self.start_iter = decay, start_iter
+        with torch.no_grad():
+            for p_ema, p in zip(target.parameters(), source.parameters()):
+                p_ema.copy_(p)
+            for b_ema, b in zip(target.buffers(), source.buffers()):
+                b_ema.copy_(b)
+
+    def decay_at(self, iteration):
+        if iteration is not None and 0 <= iteration < self.start_iter:
+            return 0.0
+        return self.decay
+
+    def source_arena(self):
+        return _arena_for(list(self.source.parameters()))
+
+    def target_arena(self):
+        return _arena_for(list(self.target.parameters()))
+
+    def _buffers(self):
+        return get_buffer_arena(self.source), get_buffer_arena(self.target)
+
+    @torch.no_grad()
+    def update_buffers(self, decay):
+        sb, tb = self._buffers()
+        if sb.numel:
+            L.call("sg_ema_lerp", sb.data.data_ptr(), tb.data.data_ptr(), sb.numel, decay, L.stream())
+        for (n_t, b_t), (n_s, b_s) in zip(self.target.named_buffers(), self.source.named_buffers()):
+            if b_t.dtype != torch.float32:
+                b_t.copy_(b_s)  # num_batches_tracked
+
+    @torch.no_grad()
+    def update(self, iter=None):
+        decay = self.decay_at(iter)
+        sa, ta = self.source_arena(), self.target_arena()
+        L.call("sg_ema_lerp", sa.data.data_ptr(), ta.data.data_ptr(), sa.numel, decay, L.stream())
+        self.update_buffers(decay)

@@ -1,0 +1,134 @@
+"""Training-step driver with the structure of the reference's WORKER (reference src/worker.py:213-497
+train_discriminator, :502-681 train_generator, loop body src/loader.py:392-405), minus everything §8 marks out of scope
+(augmentation, logging, checkpointing, StyleGAN paths). bench.py, __graft_entry__.smoke() and the step-parity tests run
+this; on a StudioGAN checkout the unmodified reference worker drives the same modules through the backbone seam
+(INTEGRATION.md).
+"""
+import copy
+
+import torch
+
+from . import losses as sg_losses
+from . import ops
+from .optim import FusedAdam, Ema
+
+
+def toggle_grad(model, grad):
+    """reference src/utils/misc.py:190-216 (num_freeze_layers = -1)."""
+    for p in model.parameters():
+        p.requires_grad = grad
+
+
+def untrack_bn_statistics(m):
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.track_running_stats = False
+
+
+def track_bn_statistics(m):
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.track_running_stats = True
+
+
+def set_deterministic_op_trainable(m):
+    """reference src/utils/misc.py:254-262: conv/linear/embedding stay in .train() so spectral norm keeps iterating."""
+    if isinstance(m, (torch.nn.Conv2d, torch.nn.ConvTranspose2d, torch.nn.Linear, torch.nn.Embedding)):
+        m.train()
+
+
+def make_GAN_trainable(Gen, Gen_ema, Dis):
+    Gen.train()
+    Gen.apply(track_bn_statistics)
+    if Gen_ema is not None:
+        Gen_ema.train()
+        Gen_ema.apply(track_bn_statistics)
+    Dis.train()
+    Dis.apply(track_bn_statistics)
+
+
+def make_GAN_untrainable(Gen, Gen_ema, Dis):
+    Gen.eval()
+    Gen.apply(set_deterministic_op_trainable)
+    if Gen_ema is not None:
+        Gen_ema.eval()
+        Gen_ema.apply(set_deterministic_op_trainable)
+    Dis.eval()
+    Dis.apply(set_deterministic_op_trainable)
+
+
+def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
+    """reference src/utils/sample.py:33-88 (gaussian prior, 'totally_random' labels), drawn on the device."""
+    zs = torch.randn(batch_size, z_dim, device=device, generator=generator)
+    ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device, generator=generator)
+    return zs, ys
+
+
+class Worker:
+    def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
+                 d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
+                 group=None):
+        self.Gen, self.Dis = Gen, Dis
+        self.z_dim, self.num_classes, self.batch_size = z_dim, num_classes, batch_size
+        self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
+        self.n_d, self.n_g, self.acml = d_updates_per_step, g_updates_per_step, acml_steps
+        self.device = next(Gen.parameters()).device
+        self.g_optimizer = FusedAdam(Gen.parameters(), lr=g_lr, betas=(beta1, beta2), eps=1e-6)
+        self.d_optimizer = FusedAdam(Dis.parameters(), lr=d_lr, betas=(beta1, beta2), eps=1e-6)
+        self.Gen_ema, self.ema = None, None
+        if apply_g_ema:
+            self.Gen_ema = copy.deepcopy(Gen)
+            self.ema = Ema(source=Gen, target=self.Gen_ema, decay=g_ema_decay, start_iter=g_ema_start)
+        self.group = group
+
+    # -- src/worker.py:213-497 ------------------------------------------------------------------------------------
+    def train_discriminator(self, current_step, real_batches, injected=None):
+        """real_batches: list (n_d * acml) of (images NCHW fp32 in [-1,1], labels). injected: optional list of (z, y)."""
+        make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
+        toggle_grad(self.Gen, False)
+        toggle_grad(self.Dis, True)
+        self.Gen.apply(untrack_bn_statistics)
+        k = 0
+        dis_acml_loss = None
+        for _ in range(self.n_d):
+            self.d_optimizer.zero_grad()
+            for _ in range(self.acml):
+                real_images, real_labels = real_batches[k]
+                zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+                k += 1
+                fake_images = self.Gen(zs, fake_labels)
+                real_dict = self.Dis(real_images, real_labels)
+                fake_dict = self.Dis(fake_images, fake_labels)
+                self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
+                dis_acml_loss = self.d_loss(real_dict["adv_output"], fake_dict["adv_output"], DDP=self.group is not None)
+                dis_acml_loss = dis_acml_loss / self.acml
+                dis_acml_loss.backward()
+            self.d_optimizer.step(group=self.group)
+        return dis_acml_loss
+
+    # -- src/worker.py:502-681 ------------------------------------------------------------------------------------
+    def train_generator(self, current_step, injected=None):
+        make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
+        toggle_grad(self.Dis, False)
+        toggle_grad(self.Gen, True)
+        self.Gen.apply(track_bn_statistics)
+        k = 0
+        gen_acml_loss = None
+        for _ in range(self.n_g):
+            self.g_optimizer.zero_grad()
+            for _ in range(self.acml):
+                zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+                k += 1
+                fake_images = self.Gen(zs, fake_labels)
+                fake_dict = self.Dis(fake_images, fake_labels)
+                self.last_g = (fake_images.detach(), fake_dict["adv_output"].detach())
+                gen_acml_loss = self.g_loss(fake_dict["adv_output"], DDP=self.group is not None)
+                gen_acml_loss = gen_acml_loss / self.acml
+                gen_acml_loss.backward()
+            # Adam and the EMA of the generator copy (src/worker.py:630-634,675-676) in one launch
+            self.g_optimizer.step(ema=self.ema, iteration=current_step, group=self.group)
+        return gen_acml_loss
+
+    # -- src/loader.py:392-405 ------------------------------------------------------------------------------------
+    def step(self, current_step, real_batches, injected_d=None, injected_g=None):
+        d = self.train_discriminator(current_step, real_batches, injected_d)
+        g = self.train_generator(current_step, injected_g)
+        return d, g

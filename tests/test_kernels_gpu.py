@@ -1,0 +1,401 @@
+"""GPU: every kernel family of libsgamd.so, called through the C ABI, against CPU torch (fp64/fp32) restatements of
+the same op on the same seeded inputs. Tolerances: fp32 path 2e-4 of range (exact-fp32 MFMA; only summation order
+differs), bf16 path 3e-2 (inputs are rounded to bf16 before BOTH computations, so what is measured is the kernel,
+not the input quantisation; accumulation is fp32)."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from util import check, tol_for
+
+pytestmark = pytest.mark.gpu
+
+DT = [torch.float32, torch.bfloat16]
+
+
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda:0")
+
+
+def rnd(shape, dtype, seed, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(shape, generator=g) * scale).to(dtype)
+    return x  # CPU tensor already rounded to the compute dtype
+
+
+def nhwc(x_nchw):
+    return x_nchw.permute(0, 2, 3, 1).contiguous()
+
+
+def nchw(x_nhwc):
+    return x_nhwc.permute(0, 3, 1, 2).contiguous()
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("pf,qf", [(0, 0), (0, 1), (1, 0), (1, 1)])
+@pytest.mark.parametrize("I,J,K,batch", [(256, 192, 128, 2), (100, 70, 52, 3), (96, 300, 64, 1), (16, 520, 40, 2)])
+def test_gemm_forms(sg, dtype, pf, qf, I, J, K, batch):
+    from studiogan_amd import functional as F, _lib as L
+    P = rnd((batch, I, K) if pf == 0 else (batch, K, I), dtype, 1)
+    Q = rnd((batch, J, K) if qf == 0 else (batch, K, J), dtype, 2)
+    bias = rnd((I,), torch.float32, 3)
+    Pm = P.double() if pf == 0 else P.double().transpose(1, 2)
+    Qm = Q.double() if qf == 0 else Q.double().transpose(1, 2)
+    ref = torch.einsum("bik,bjk->bji", Pm, Qm) * 0.5 + bias.double()
+    d = dev()
+    out = torch.empty((batch, J, I), dtype=torch.float32, device=d)
+    Pd, Qd, bd = P.to(d), Q.to(d), bias.to(d)
+    for no_tr in ([0, 1] if dtype == torch.bfloat16 and (pf or qf) else [0]):
+        out.zero_()
+        F.gemm_raw(L.dt(dtype), Pd, pf, P.shape[2], Qd, qf, Q.shape[2], out, I, I, J, K, batch=batch, p_bs=P.shape[1] * P.shape[2],
+                   q_bs=Q.shape[1] * Q.shape[2], out_bs=J * I, bias=bd, alpha=0.5, epi_flags=L.EPI_OUT_F32, no_tr=no_tr)
+        torch.cuda.synchronize()
+        check(f"gemm p{pf}q{qf} {I}x{J}x{K} b{batch} no_tr={no_tr}", out, ref, 2e-4 if dtype == torch.float32 else 2e-3)
+
+
+def _conv_ref(x, w, stride, pad, relu_in=False, up=False, pool=False, bias=None, res=None):
+    x = x.double()
+    if relu_in:
+        x = torch.relu(x)
+    if up:
+        x = TF.interpolate(x, scale_factor=2, mode="nearest")
+    y = TF.conv2d(x, w.double(), None if bias is None else bias.double(), stride=stride, padding=pad)
+    if pool:
+        y = TF.avg_pool2d(y, 2)
+    if res is not None:
+        y = y + res.double()
+    return y
+
+
+CONV_CASES = [
+    # N, Cin, Cout, H, W, R, S, stride, (ph, pw)
+    (2, 32, 64, 8, 8, 3, 3, 1, (1, 1)),
+    (3, 96, 96, 8, 8, 3, 3, 1, (1, 1)),
+    (2, 48, 192, 4, 4, 1, 1, 1, (0, 0)),
+    (2, 3, 96, 16, 16, 3, 3, 1, (1, 1)),
+    (2, 96, 3, 16, 16, 3, 3, 1, (1, 1)),
+    (1, 20, 12, 9, 7, 3, 3, 1, (1, 1)),
+    (2, 16, 40, 9, 9, 1, 7, 1, (0, 3)),
+    (2, 16, 24, 11, 11, 3, 3, 2, (0, 0)),
+    (2, 8, 16, 8, 8, 4, 4, 2, (1, 1)),
+    (1, 384, 128, 4, 4, 3, 3, 1, (1, 1)),
+]
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_fwd_dgrad_wgrad(sg, dtype, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, W, R, S, stride, (ph, pw) = case
+    d = dev()
+    x = rnd((N, Cin, H, W), dtype, 11)
+    w = rnd((Cout, Cin, R, S), dtype, 12, 0.2)
+    bias = rnd((Cout,), torch.float32, 13)
+    tol = 2e-4 if dtype == torch.float32 else 4e-3
+    # forward
+    xr = x.double().requires_grad_(True)
+    wr = w.double().requires_grad_(True)
+    yref = TF.conv2d(xr, wr, bias.double(), stride=stride, padding=(ph, pw))
+    w_fwd = w.permute(0, 2, 3, 1).contiguous().to(d)      # [Cout][R][S][Cin]
+    xd = nhwc(x).to(d)
+    y = F.conv2d_raw(xd, w_fwd.data_ptr(), Cin, Cout, R, S, stride, ph, pw, bias=bias.to(d))
+    torch.cuda.synchronize()
+    check(f"conv fwd {case}", nchw(y.float().cpu()), yref, tol)
+    # backward references
+    gy = rnd(tuple(yref.shape), dtype, 14)
+    yref.backward(gy.double())
+    gyd = nhwc(gy).to(d)
+    Ho, Wo = yref.shape[2], yref.shape[3]
+    if stride == 1:
+        w_dg = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(d)  # [Cin][R'][S'][Cout]
+        dx = F.conv2d_raw(gyd, w_dg.data_ptr(), Cout, Cin, R, S, 1, R - 1 - ph, S - 1 - pw)
+        torch.cuda.synchronize()
+        check(f"conv dgrad {case}", nchw(dx.float().cpu()), xr.grad, tol)
+    for no_tr in ([0, 1] if dtype == torch.bfloat16 else [0]):
+        dw = torch.zeros((Cout, R, S, Cin), dtype=torch.float32, device=d)
+        F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, S, Ho, Wo, stride, ph, pw, no_tr=no_tr)
+        torch.cuda.synchronize()
+        check(f"conv wgrad {case} no_tr={no_tr}", dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_fused_flags(sg, dtype):
+    """ReLU-on-load, nearest x2 upsample-on-load, fused 2x2 average pooling, residual add, ReLU mask, and the matching
+    backward views (pooled-gradient broadcast, pooling-sum of the upsample) -- the GenBlock / DiscBlock fusions."""
+    from studiogan_amd import functional as F, _lib as L
+    d = dev()
+    N, Cin, Cout, H, W = 2, 32, 96, 8, 8
+    tol = 2e-4 if dtype == torch.float32 else 4e-3
+    x = rnd((N, Cin, H, W), dtype, 21)
+    w = rnd((Cout, Cin, 3, 3), dtype, 22, 0.2)
+    w_fwd = w.permute(0, 2, 3, 1).contiguous().to(d)
+    w_dg = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(d)
+    xd = nhwc(x).to(d)
+    for relu_in, up, pool in [(True, False, True), (False, True, False), (True, True, True), (True, False, False)]:
+        Ho = H * (2 if up else 1)
+        Hy = Ho // 2 if pool else Ho
+        res = rnd((N, Cout, Hy, Hy), dtype, 23)
+        xr = x.double().requires_grad_(True)
+        wr = w.double().requires_grad_(True)
+        yref = _conv_ref(xr, wr, 1, 1, relu_in, up, pool, None, res)
+        pf = (L.PIX_RELU if relu_in else 0) | (L.PIX_UPSAMPLE if up else 0)
+        ef = L.EPI_POOL if pool else 0
+        y = F.conv2d_raw(xd, w_fwd.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        tag = f"relu={relu_in} up={up} pool={pool}"
+        check("conv fused fwd " + tag, nchw(y.float().cpu()), yref, tol)
+        gy = rnd(tuple(yref.shape), dtype, 24)
+        yref.backward(gy.double())
+        gyd = nhwc(gy).to(d)
+        dx = F.conv2d_raw(gyd, w_dg.data_ptr(), Cout, Cin, 3, 3, 1, 1, 1, L.PIX_UPSAMPLE if pool else 0, L.EPI_POOL if up else 0,
+                          mask=xd if relu_in else None, alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        check("conv fused dgrad " + tag, nchw(dx.float().cpu()), xr.grad, tol)
+        dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=d)
+        F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, 3, 3, Ho, Ho, 1, 1, 1, pf, L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        check("conv fused wgrad " + tag, dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_conv_large_splitk_and_tiles(sg, dtype):
+    """A BigGAN-sized layer slice (many k-splits, 96-wide tile config, XCD remap with a non-multiple-of-8 tile count)."""
+    from studiogan_amd import functional as F
+    d = dev()
+    N, Cin, Cout, H = 4, 96, 192, 32
+    tol = 2e-4 if dtype == torch.float32 else 5e-3
+    x = rnd((N, Cin, H, H), dtype, 31)
+    w = rnd((Cout, Cin, 3, 3), dtype, 32, 0.1)
+    xr, wr = x.float().requires_grad_(True), w.float().requires_grad_(True)
+    yref = TF.conv2d(xr, wr, None, 1, 1)
+    gy = rnd(tuple(yref.shape), dtype, 33)
+    yref.backward(gy.float())
+    xd, gyd = nhwc(x).to(d), nhwc(gy).to(d)
+    y = F.conv2d_raw(xd, w.permute(0, 2, 3, 1).contiguous().to(d).data_ptr(), Cin, Cout, 3, 3, 1, 1, 1)
+    dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=d)
+    F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, 3, 3, H, H, 1, 1, 1)
+    torch.cuda.synchronize()
+    check("conv fwd large", nchw(y.float().cpu()), yref, tol)
+    check("conv wgrad large", dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
+
+
+# ---------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("mode", ["cbn_relu", "affine", "plain_eval"])
+def test_batchnorm(sg, dtype, mode):
+    from studiogan_amd import functional as F
+    d = dev()
+    N, Cc, H = 4, 24, 6
+    tol = 2e-4 if dtype == torch.float32 else 2e-2
+    x = rnd((N, Cc, H, H), dtype, 41) * 2 + 0.5
+    x = x.to(dtype)
+    rm, rv = torch.randn(Cc) * 0.1, torch.rand(Cc) + 0.5
+    xr = x.double().requires_grad_(True)
+    if mode == "cbn_relu":
+        gain = (1 + 0.3 * torch.randn(N, Cc)).requires_grad_(True)
+        bias = (0.3 * torch.randn(N, Cc)).requires_grad_(True)
+        rm2, rv2 = rm.clone().double(), rv.clone().double()
+        bn = TF.batch_norm(xr, rm2, rv2, None, None, True, 0.1, 1e-4)
+        yref = torch.relu(bn * gain.double().view(N, Cc, 1, 1) + bias.double().view(N, Cc, 1, 1))
+        cfg = F.BNCfg(True, True, 1e-4, 0.1, True)
+    elif mode == "affine":
+        gain = (1 + 0.3 * torch.randn(Cc)).requires_grad_(True)
+        bias = (0.3 * torch.randn(Cc)).requires_grad_(True)
+        rm2, rv2 = rm.clone().double(), rv.clone().double()
+        yref = TF.batch_norm(xr, rm2, rv2, gain.double(), bias.double(), True, 0.1, 1e-4)
+        cfg = F.BNCfg(True, True, 1e-4, 0.1, False)
+    else:
+        gain = bias = None
+        rm2, rv2 = rm.clone().double(), rv.clone().double()
+        yref = TF.batch_norm(xr, rm2, rv2, None, None, False, 0.1, 1e-4)
+        cfg = F.BNCfg(False, False, 1e-4, 0.1, False)
+    gy = rnd(tuple(yref.shape), dtype, 42)
+    yref.backward(gy.double())
+    xd = nhwc(x).to(d).requires_grad_(True)
+    gd = gain.detach().float().to(d).requires_grad_(True) if gain is not None else None
+    bd = bias.detach().float().to(d).requires_grad_(True) if bias is not None else None
+    rmd, rvd = rm.clone().to(d), rv.clone().to(d)
+    y = F.BNFn.apply(xd, gd, bd, rmd, rvd, cfg)
+    y.backward(nhwc(gy).to(d))
+    torch.cuda.synchronize()
+    check(f"bn {mode} fwd", nchw(y.detach().float().cpu()), yref, tol)
+    check(f"bn {mode} dx", nchw(xd.grad.float().cpu()), xr.grad, tol)
+    if gain is not None:
+        check(f"bn {mode} dgain", gd.grad.cpu(), gain.grad, tol)
+        check(f"bn {mode} dbias", bd.grad.cpu(), bias.grad, tol)
+    if mode != "plain_eval":
+        check(f"bn {mode} running_mean", rmd.cpu(), rm2, tol)
+        check(f"bn {mode} running_var", rvd.cpu(), rv2, tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_softmax_pool_misc(sg, dtype):
+    from studiogan_amd import functional as F, _lib as L
+    d = dev()
+    tol = 1e-5 if dtype == torch.float32 else 1e-2
+    # softmax fwd / bwd
+    S = torch.randn(37, 200) * 3
+    P = torch.softmax(S.double(), -1)
+    Sd = S.to(d)
+    Pd = torch.empty((37, 200), dtype=dtype, device=d)
+    L.call("sg_softmax_rows", L.dt(dtype), Sd.data_ptr(), Pd.data_ptr(), 37, 200, L.stream())
+    check("softmax fwd", Pd.float().cpu(), P, tol)
+    dP = torch.randn(37, 200)
+    Pq = Pd.float().cpu().double()
+    dS_ref = Pq * (dP.double() - (dP.double() * Pq).sum(-1, keepdim=True))
+    dSd = torch.empty((37, 200), dtype=dtype, device=d)
+    L.call("sg_softmax_rows_bwd", L.dt(dtype), Pd.data_ptr(), dP.to(d).data_ptr(), dSd.data_ptr(), 37, 200, L.stream())
+    check("softmax bwd", dSd.float().cpu(), dS_ref, tol)
+    # avg / max pooling through autograd
+    x = rnd((2, 12, 8, 8), dtype, 51)
+    xr = x.double().requires_grad_(True)
+    xd = nhwc(x).to(d).requires_grad_(True)
+    y = F.AvgPool2Fn.apply(xd)
+    yr = TF.avg_pool2d(xr, 2)
+    gy = rnd(tuple(yr.shape), dtype, 52)
+    y.backward(nhwc(gy).to(d)); yr.backward(gy.double())
+    check("avgpool fwd", nchw(y.detach().float().cpu()), yr, tol)
+    check("avgpool bwd", nchw(xd.grad.float().cpu()), xr.grad, tol)
+    # add_relu
+    a = rnd((2, 8, 4, 4), dtype, 53)
+    ar, xr2 = a.double().requires_grad_(True), x[:, :8, :4, :4].double().requires_grad_(True)
+    ad, xd2 = a.to(d).requires_grad_(True), x[:, :8, :4, :4].contiguous().to(d).requires_grad_(True)
+    o = F.AddReluFn.apply(ad, xd2)
+    orf = ar + torch.relu(xr2)
+    g = rnd(tuple(orf.shape), dtype, 54)
+    o.backward(g.to(d)); orf.backward(g.double())
+    check("add_relu fwd", o.detach().float().cpu(), orf, tol)
+    check("add_relu dx", xd2.grad.float().cpu(), xr2.grad, tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+def test_attention_core(sg, dtype):
+    """AttnCoreFn = maxpool + QK^T + softmax + PV and its backward vs the reference formulation (utils/ops.py:83-100)."""
+    from studiogan_amd import functional as F
+    d = dev()
+    B, H, W, Dp, Dv, Cg = 2, 8, 8, 8, 4, 16
+    tol = 5e-4 if dtype == torch.float32 else 3e-2
+    th = rnd((B, Dp, H, W), dtype, 61); th[:, Dv:] = 0
+    ph = rnd((B, Dp, H, W), dtype, 62); ph[:, Dv:] = 0
+    g = rnd((B, Cg, H, W), dtype, 63)
+    thr, phr, gr = [t.double().requires_grad_(True) for t in (th, ph, g)]
+    theta = thr.view(B, Dp, H * W)
+    phi = TF.max_pool2d(phr, 2, 2).view(B, Dp, H * W // 4)
+    attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), -1)
+    gg = TF.max_pool2d(gr, 2, 2).view(B, Cg, H * W // 4)
+    oref = torch.bmm(gg, attn.permute(0, 2, 1)).view(B, Cg, H, W)
+    go = rnd(tuple(oref.shape), dtype, 64)
+    oref.backward(go.double())
+    thd, phd, gd = [nhwc(t).to(d).requires_grad_(True) for t in (th, ph, g)]
+    o = F.AttnCoreFn.apply(thd, phd, gd)
+    o.backward(nhwc(go).to(d))
+    torch.cuda.synchronize()
+    check("attn core fwd", nchw(o.detach().float().cpu()), oref, tol)
+    check("attn dtheta", nchw(thd.grad.float().cpu())[:, :Dv], thr.grad[:, :Dv], tol)
+    check("attn dphi", nchw(phd.grad.float().cpu())[:, :Dv], phr.grad[:, :Dv], tol)
+    check("attn dg", nchw(gd.grad.float().cpu()), gr.grad, tol)
+
+
+def test_head_losses_embedding(sg):
+    from studiogan_amd import functional as F, _lib as L
+    d = dev()
+    # losses
+    r, f = torch.randn(19), torch.randn(19)
+    for kind, name in [(0, "hinge"), (1, "wasserstein"), (2, "vanilla")]:
+        rr, fr = r.double().requires_grad_(True), f.double().requires_grad_(True)
+        from oracle import restate as O
+        lref = O.d_loss(name, rr, fr); lref.backward()
+        rd, fd = r.to(d).requires_grad_(True), f.to(d).requires_grad_(True)
+        l = F.DLossFn.apply(rd, fd, kind); (l * 0.5).backward()
+        check(f"d_loss {name}", l.detach().cpu(), lref, 1e-5)
+        check(f"d_loss {name} d_real", rd.grad.cpu() * 2, rr.grad, 1e-5)
+        check(f"d_loss {name} d_fake", fd.grad.cpu() * 2, fr.grad, 1e-5)
+        fr2 = f.double().requires_grad_(True)
+        gref = O.g_loss(name, fr2); gref.backward()
+        fd2 = f.to(d).requires_grad_(True)
+        gl = F.GLossFn.apply(fd2, kind); gl.backward()
+        check(f"g_loss {name}", gl.detach().cpu(), gref, 1e-5)
+        check(f"g_loss {name} d_fake", fd2.grad.cpu(), fr2.grad, 1e-5)
+    # relu-sum over HW
+    x = torch.randn(3, 4, 4, 20)
+    xr = x.double().requires_grad_(True)
+    href = torch.relu(xr).sum(dim=[1, 2])
+    xd = x.to(d).requires_grad_(True)
+    h = F.ReluSumFn.apply(xd)
+    gh = torch.randn(3, 20)
+    h.backward(gh.to(d)); href.backward(gh.double())
+    check("relu_sum fwd", h.detach().cpu(), href, 1e-5)
+    check("relu_sum bwd", xd.grad.cpu(), xr.grad, 1e-5)
+    # plain embedding
+    tab = torch.randn(10, 16)
+    idx = torch.tensor([1, 3, 3, 9, 0])
+    tr = tab.double().requires_grad_(True)
+    eref = TF.embedding(idx, tr)
+    td = torch.nn.Parameter(tab.to(d))
+    e = F.EmbeddingFn.apply(td, idx.to(d))
+    ge = torch.randn(5, 16)
+    e.backward(ge.to(d)); eref.backward(ge.double())
+    check("embedding fwd", e.detach().cpu(), eref, 1e-6)
+    check("embedding bwd", td.grad.cpu(), tr.grad, 1e-6)
+
+
+def test_adam_ema_and_lerp(sg):
+    from studiogan_amd import _lib as L
+    d = dev()
+    n = 10007
+    p, g = torch.randn(n), torch.randn(n)
+    ema0 = torch.randn(n)
+    pr = torch.nn.Parameter(p.clone())
+    opt = torch.optim.Adam([pr], lr=2e-4, betas=(0.5, 0.999), eps=1e-6)
+    pd, md, vd, ed = p.to(d).contiguous(), torch.zeros(n, device=d), torch.zeros(n, device=d), ema0.to(d)
+    er = ema0.clone()
+    for t in range(1, 4):
+        gt = g * t
+        pr.grad = gt.clone()
+        opt.step()
+        er = pr.detach().lerp(er, 0.9)
+        L.call("sg_adam_ema", pd.data_ptr(), gt.to(d).data_ptr(), md.data_ptr(), vd.data_ptr(), ed.data_ptr(), n, 2e-4, 0.5, 0.999, 1e-6, 0.0, t, 0.9, 1.0, L.stream())
+    check("adam p", pd.cpu(), pr.detach(), 1e-6)
+    check("adam ema", ed.cpu(), er, 1e-6)
+    # beta1 = 0 (BigGAN) and decay 0 (before g_ema_start: hard copy)
+    pr2 = torch.nn.Parameter(p.clone())
+    opt2 = torch.optim.Adam([pr2], lr=5e-5, betas=(0.0, 0.999), eps=1e-6)
+    pr2.grad = g.clone(); opt2.step()
+    pd2, md2, vd2, ed2 = p.to(d).contiguous(), torch.zeros(n, device=d), torch.zeros(n, device=d), ema0.to(d)
+    L.call("sg_adam_ema", pd2.data_ptr(), g.to(d).data_ptr(), md2.data_ptr(), vd2.data_ptr(), ed2.data_ptr(), n, 5e-5, 0.0, 0.999, 1e-6, 0.0, 1, 0.0, 1.0, L.stream())
+    check("adam beta1=0", pd2.cpu(), pr2.detach(), 1e-6)
+    assert torch.equal(ed2.cpu(), pd2.cpu()), "EMA with decay 0 must be a hard copy"
+
+
+def test_quantize_bit_exact_and_resize(sg):
+    """uint8 quantisation (utils/ops.py:251-255) must be bit-exact; the legacy bilinear resize (utils/resize.py:87-91)
+    within fp32 tolerance."""
+    from studiogan_amd import _lib as L
+    import numpy as np
+    d = dev()
+    g = torch.Generator().manual_seed(7)
+    x = torch.rand(3, 3, 32, 32, generator=g) * 2.2 - 1.1
+    # include exact grid points and half-way cases
+    x[0, 0, 0, :] = torch.arange(32).float() / 127.5 - 1.0
+    x[0, 0, 1, :] = (torch.arange(32).float() + 0.5) / 127.5 - 1.0
+    xq = (x + 1) / 2
+    xq = (255.0 * xq + 0.5).clamp(0.0, 255.0)
+    q_ref = xq.numpy().astype(np.uint8)
+    xd = x.to(d)
+    out = torch.empty((3, 299, 299, 3), dtype=torch.float32, device=d)
+    qd = torch.empty((3, 3, 32, 32), dtype=torch.uint8, device=d)
+    L.call("sg_quantize_resize_normalize", 0, xd.data_ptr(), out.data_ptr(), qd.data_ptr(), 3, 3, 32, 32, 299, 299, 1, L.stream())
+    assert np.array_equal(qd.cpu().numpy(), q_ref), "uint8 quantisation is not bit-exact"
+    r = TF.interpolate(torch.from_numpy(q_ref).float(), size=(299, 299), mode="bilinear", align_corners=False).clamp(0, 255)
+    r = (r / 255.0 - 0.5) / 0.5
+    check("resize+normalize", out.cpu().permute(0, 3, 1, 2), r, 1e-5)
+
+
+def test_no_cpu_fallback(sg):
+    """The product path must fail loudly on CPU tensors (no silent eager fallback)."""
+    from studiogan_amd import ops
+    m = ops.snconv2d(4, 8, 3, 1, 1)
+    with pytest.raises(RuntimeError):
+        m(torch.randn(1, 4, 8, 8))

@@ -1,0 +1,82 @@
+"""CPU: the oracle restatement against the committed golden vectors (produced by the real reference), against the
+reference itself when /root/reference is present, and analytic known-answer tests."""
+import copy
+import os
+import sys
+
+import pytest
+import torch
+
+from util import check, load_golden, sub
+from oracle import restate as O
+from oracle import make_golden as MG
+
+
+def _run_restatement(name):
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    GI, DI = sub(fix, "G_init/"), sub(fix, "D_init/")
+    pnames = lambda d: {k: v.clone() for k, v in d.items() if not any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))}
+    bnames = lambda d: {k: v.clone() for k, v in d.items() if any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))}
+    GP, GB, DP, DB = pnames(GI), bnames(GI), pnames(DI), bnames(DI)
+    ins = sub(fix, "in/")
+    exp = MG.run_restatement(ocfg, y, GP, GB, DP, DB, ins, meta["n_d"])
+    return fix, exp
+
+
+def test_restatement_matches_golden_biggan32():
+    fix, exp = _run_restatement("biggan32")
+    gold = sub(fix, "exp/")
+    assert set(gold.keys()) == set(exp.keys())
+    for k in sorted(gold.keys()):
+        check(k, exp[k], gold[k], 1e-5)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_golden_regenerates_from_reference(tmp_path, monkeypatch):
+    """The committed fixture is exactly what the reference produces today (guards against stale fixtures)."""
+    from oracle import ref_import as R
+    fix, meta = load_golden("biggan32")
+    c = MG.CONFIGS["biggan32"]
+    cfgs = R.load_cfgs(c["yaml"])
+    torch.manual_seed(c["seed"])
+    Gen, Dis = R.build_models(cfgs)
+    ocfg = MG.oracle_cfg(c["yaml"])
+    ins = MG.synth_inputs(c["seed"] + 1, c["n_d"], c["batch"], ocfg["z_dim"], ocfg["num_classes"], ocfg["img_size"])
+    exp = MG.run_reference(cfgs, Gen, Dis, ins, c["n_d"])
+    for k in ("fake0", "adv_r0", "d_loss0", "g_loss"):
+        check("ref:" + k, exp[k], fix["exp/" + k], 1e-6)
+
+
+def test_param_counts_match_reference_logs():
+    """Known-answer: BigGAN-128 G=70,433,988 / D=87,982,370 (reference logs/IMAGENET/BigGAN256-train-2021_01_24_03_52_15.log:11,122)."""
+    from studiogan_amd import ops
+    from studiogan_amd.backbones import big_resnet
+
+    class M:
+        info_type = "N/A"
+    MOD = ops.Modules(apply_g_sn=True, apply_d_sn=True, g_cond_mtd="cBN", backbone="big_resnet")
+    G = big_resnet.Generator(120, 128, 128, 96, True, [4], "cBN", 1000, "ortho", "N/A", True, MOD, M)
+    D = big_resnet.Discriminator(128, 96, True, True, [1], "PD", "W/O", "N/A", False, 1000, "ortho", "N/A", True, MOD, M)
+    assert sum(p.numel() for p in G.parameters()) == 70433988
+    assert sum(p.numel() for p in D.parameters()) == 87982370
+
+
+def test_analytic_kats():
+    z = torch.zeros(8)
+    assert float(O.d_loss("hinge", z, z)) == 2.0            # utils/losses.py:226-227
+    assert float(O.g_loss("hinge", z)) == 0.0               # utils/losses.py:230-231
+    assert abs(float(O.d_loss("vanilla", z, z)) - 2 * 0.6931471805599453) < 1e-6
+    # SelfAttention is the identity at initialisation (sigma = 0, utils/ops.py:81,103)
+    torch.manual_seed(0)
+    P = {"a.conv1x1_theta.weight": torch.randn(2, 16, 1, 1), "a.conv1x1_phi.weight": torch.randn(2, 16, 1, 1),
+         "a.conv1x1_g.weight": torch.randn(8, 16, 1, 1), "a.conv1x1_attn.weight": torch.randn(16, 8, 1, 1), "a.sigma": torch.zeros(1)}
+    x = torch.randn(2, 16, 8, 8)
+    assert torch.equal(O.self_attention(x, P, {}, "a"), x)
+    # spectral norm: sigma of the normalised weight is ~1 after convergence
+    P = {"l.weight_orig": torch.randn(12, 20)}
+    B = {"l.weight_u": torch.nn.functional.normalize(torch.randn(12), dim=0), "l.weight_v": torch.nn.functional.normalize(torch.randn(20), dim=0)}
+    for _ in range(200):
+        w = O.weight_of(P, B, "l")
+    assert abs(float(torch.linalg.matrix_norm(w, 2)) - 1.0) < 1e-4
