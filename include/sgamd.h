@@ -167,7 +167,7 @@ typedef struct {
   long long work_off; /* this layer's slice of work[]: needs 8*cols + rows floats */
 } sg_sn_layer;
 /* runs all layers of a network in 4 batched launches. `layers` is a DEVICE array of n descriptors;
- * work[] is a device scratch of at least sg_sn_workspace_floats(max_rows_cols_sum) floats */
+ * work[] is a device scratch; each layer owns the slice [work_off, work_off + 8*cols + rows) */
 int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s);
 
 typedef struct {

@@ -23,7 +23,24 @@ import torch.nn as nn
 
 from . import _lib as L
 
-_ARENA_OF = weakref.WeakKeyDictionary()  # Parameter -> (ParamArena, offset)
+_ARENA_BY_ID = {}  # id(Parameter) -> (weakref to the Parameter, ParamArena, offset); keyed by identity, never by ==
+
+
+def _register(p, arena, off):
+    key = id(p)
+
+    def _gone(_ref, key=key):
+        ent = _ARENA_BY_ID.get(key)
+        if ent is not None and ent[0] is _ref:
+            del _ARENA_BY_ID[key]
+    _ARENA_BY_ID[key] = (weakref.ref(p, _gone), arena, off)
+
+
+def arena_of(p):
+    ent = _ARENA_BY_ID.get(id(p))
+    if ent is None or ent[0]() is not p:
+        return None
+    return ent[1], ent[2]
 
 
 def _align(n, a=4):
@@ -53,10 +70,10 @@ class ParamArena:
                 view.copy_(p.data)
                 p.data = view
                 p.grad = None
-                _ARENA_OF[p] = (self, o)
+                _register(p, self, o)
 
     def grad_view(self, p):
-        a, o = _ARENA_OF[p]
+        a, o = arena_of(p)
         return a.grad[o:o + p.numel()].view(p.shape)
 
     def intact(self):
@@ -65,17 +82,13 @@ class ParamArena:
         return p.data_ptr() == self.data.data_ptr() + 4 * o and q.data_ptr() == self.data.data_ptr() + 4 * oq
 
 
-def arena_of(p):
-    return _ARENA_OF.get(p)
-
-
 def ensure_grad(p):
     """Gradient tensor of a parameter that our kernels accumulate into (a view of the gradient arena when the
     parameter lives in one). Honour optimizer.zero_grad(set_to_none=True): a None grad is re-created zeroed."""
     g = p.grad
     if g is not None:
         return g
-    ent = _ARENA_OF.get(p)
+    ent = arena_of(p)
     if ent is not None:
         a, o = ent
         g = a.grad[o:o + p.numel()].view(p.shape)

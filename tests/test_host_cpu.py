@@ -1,0 +1,104 @@
+"""CPU: host-side logic that needs no GPU -- flat arenas, state_dict naming, the C ABI surface."""
+import copy
+import os
+import re
+
+import pytest
+import torch
+import torch.nn as nn
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_param_arena_views_and_grad_views():
+    from studiogan_amd.bank import ParamArena, arena_of, ensure_grad, get_buffer_arena
+    net = nn.Sequential(nn.Linear(5, 7), nn.BatchNorm1d(7), nn.Linear(7, 3))
+    ref = [p.detach().clone() for p in net.parameters()]
+    a = ParamArena(list(net.parameters()))
+    assert a.intact()
+    for p, r in zip(net.parameters(), ref):
+        assert torch.equal(p.detach(), r)
+        ent = arena_of(p)
+        assert ent is not None and ent[0] is a
+        assert p.data_ptr() == a.data.data_ptr() + 4 * ent[1]
+        g = ensure_grad(p)
+        assert g.data_ptr() == a.grad.data_ptr() + 4 * ent[1] and float(g.abs().sum()) == 0.0
+    # arena values follow in-place parameter updates and vice versa
+    with torch.no_grad():
+        net[0].weight.add_(1.0)
+    assert torch.equal(a.data[:35].view(7, 5), net[0].weight.detach())
+    # buffers
+    rm = net[1].running_mean
+    ba = get_buffer_arena(net)
+    assert net[1].running_mean is rm and ba.intact(net)
+    net(torch.randn(4, 5))
+    assert torch.equal(ba.data[ba.offsets[0]:ba.offsets[0] + 7], net[1].running_mean)
+    # deepcopy detaches from the arenas and builds its own lazily
+    net2 = copy.deepcopy(net)
+    assert get_buffer_arena(net2) is not ba
+    assert arena_of(next(net2.parameters())) is None
+
+
+def test_abi_symbols_match_header():
+    """libsgamd.so loads and exports every function include/sgamd.h declares (no compute calls without a GPU)."""
+    import studiogan_amd
+    from studiogan_amd import _lib
+    hdr = open(os.path.join(ROOT, "include", "sgamd.h")).read()
+    declared = set(re.findall(r"\b(sg_[a-z0-9_]+)\s*\(", hdr))
+    assert declared, "no declarations parsed"
+    lib = studiogan_amd.lib()
+    for name in sorted(declared):
+        assert hasattr(lib, name), f"{name} declared in sgamd.h but not exported"
+    assert declared == set(_lib.exported_symbols()), (declared ^ set(_lib.exported_symbols()))
+    assert lib.sg_version() >= 1
+
+
+def test_struct_layouts_match_c():
+    """ctypes mirrors of the descriptor structs have the sizes the C compiler gives them."""
+    import ctypes
+    import subprocess
+    import tempfile
+    from studiogan_amd import _lib
+    src = ('#include <stdio.h>\n#include "sgamd.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(sg_conv_fwd_desc), '
+           'sizeof(sg_conv_wgrad_desc), sizeof(sg_gemm_desc), sizeof(sg_sn_layer), sizeof(sg_sn_bwd_layer));return 0;}\n')
+    with tempfile.TemporaryDirectory() as d:
+        c = os.path.join(d, "s.c")
+        open(c, "w").write(src)
+        exe = os.path.join(d, "s")
+        subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
+        out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
+    sizes = [ctypes.sizeof(x) for x in (_lib.ConvFwdDesc, _lib.ConvWgradDesc, _lib.GemmDesc, _lib.SnLayer, _lib.SnBwdLayer)]
+    assert [int(v) for v in out] == sizes
+
+
+def test_module_names_and_sn_state():
+    from studiogan_amd import ops
+    m = ops.snconv2d(8, 16, 3, 1, 1)
+    sd = m.state_dict()
+    assert set(sd.keys()) == {"weight_orig", "weight_u", "weight_v", "bias"}
+    assert sd["weight_orig"].shape == (16, 8, 3, 3) and sd["weight_u"].shape == (16,) and sd["weight_v"].shape == (72,)
+    assert abs(float(sd["weight_u"].norm()) - 1) < 1e-5
+    assert isinstance(m, nn.Conv2d)
+    e = ops.sn_embedding(10, 6)
+    assert set(e.state_dict().keys()) == {"weight_orig", "weight_u", "weight_v"} and isinstance(e, nn.Embedding)
+    lin = ops.linear(4, 5)
+    assert set(lin.state_dict().keys()) == {"weight", "bias"} and isinstance(lin, nn.Linear)
+    bn = ops.batchnorm_2d(6)
+    assert bn.eps == 1e-4 and bn.momentum == 0.1 and isinstance(bn, nn.modules.batchnorm._BatchNorm)
+    # orthogonal init reaches weight_orig (reference init_weights goes through module.weight's shared storage)
+    ops.init_weights(lambda: [m], "ortho")
+    w = m.weight_orig.detach().reshape(16, -1)
+    assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-4)
+
+
+def test_golden_state_dict_keys_match_backbone():
+    from util import load_golden, sub
+    from test_model_gpu import build_from_yaml
+    fix, meta = load_golden("biggan32")
+    G, D = build_from_yaml(meta["yaml"], False, torch.device("cpu"))
+    assert set(G.state_dict().keys()) == set(sub(fix, "G_init/").keys())
+    assert set(D.state_dict().keys()) == set(sub(fix, "D_init/").keys())
+    G.load_state_dict(sub(fix, "G_init/"), strict=True)
+    D.load_state_dict(sub(fix, "D_init/"), strict=True)
+    with pytest.raises(RuntimeError):
+        G(torch.randn(2, 40), torch.zeros(2, dtype=torch.long))  # CPU tensors: no fallback on the product path
