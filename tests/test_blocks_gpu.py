@@ -1,0 +1,114 @@
+"""GPU: whole-network forward/backward of the BigGAN G and D against the CPU oracle with NON-initial parameters
+(attention gate sigma != 0, random biases) -- exercises every backward path including the ones that are dead at
+initialisation (attention branch, gradient w.r.t. the input image, the identity-skip block)."""
+import pytest
+import torch
+
+from util import Collector, load_golden, sub
+from oracle import make_golden as MG
+from oracle import restate as O
+from test_model_gpu import build_from_yaml
+
+pytestmark = pytest.mark.gpu
+
+
+def _split(init):
+    isb = lambda k: any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))
+    P = {k: v.clone() for k, v in init.items() if not isb(k)}
+    B = {k: v.clone() for k, v in init.items() if isb(k)}
+    return P, B
+
+
+def _perturb(P, seed):
+    g = torch.Generator().manual_seed(seed)
+    for k in P:
+        if k.endswith("sigma"):
+            P[k] = torch.full_like(P[k], 0.6)
+        elif k.endswith(".bias") and P[k].dim() == 1:
+            P[k] = 0.1 * torch.randn(P[k].shape, generator=g)
+        elif k.endswith("bn4.weight"):
+            P[k] = 1 + 0.2 * torch.randn(P[k].shape, generator=g)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+def test_discriminator_fwd_bwd(sg, mixed):
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("biggan32")
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 3)
+    _, D = build_from_yaml(y, mixed, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    x = fix["in/real0"].clone()
+    lab = fix["in/rl0"]
+    gadv = torch.tensor([0.3, -1.0, 0.7, 0.5])
+    # oracle
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    xo = x.clone().requires_grad_(True)
+    adv_o, h_o = O.biggan_discriminator(xo, lab, leaves, B, ocfg)
+    (adv_o * gadv).sum().backward()
+    # HIP path
+    xd = x.to(dev).requires_grad_(True)
+    for p in D.parameters():
+        p.grad = None
+    out = D(xd, lab.to(dev))
+    (out["adv_output"] * gadv.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    C = Collector()
+    t = 2e-4 if not mixed else 5e-2
+    C.check("D adv", out["adv_output"], adv_o, t)
+    C.check("D h", out["h"], h_o, t)
+    C.check("D dx (input image gradient)", xd.grad, xo.grad, 2 * t)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    for k, p in D.named_parameters():
+        C.check("D grad " + k, p.grad, leaves[k].grad, 2 * t, floor=1e-3 * gmax)
+    for k, b in D.named_buffers():
+        C.check("D buf " + k, b, B[k], t)
+    C.finish()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("bn_mode", ["track", "untrack", "eval"])
+def test_generator_fwd_bwd(sg, mixed, bn_mode):
+    from studiogan_amd import worker as W
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("biggan32")
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "G_init/"))
+    _perturb(P, 4)
+    for k in B:
+        if "running_mean" in k:
+            B[k] = 0.1 * torch.randn(B[k].shape, generator=torch.Generator().manual_seed(9))
+        if "running_var" in k:
+            B[k] = 0.5 + torch.rand(B[k].shape, generator=torch.Generator().manual_seed(10))
+    G, _ = build_from_yaml(y, mixed, dev)
+    G.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    if bn_mode == "eval":
+        G.eval()
+        G.apply(W.set_deterministic_op_trainable)   # reference utils/misc.py:254-262: SN layers keep iterating in eval
+    else:
+        G.train()
+        G.apply(W.track_bn_statistics if bn_mode == "track" else W.untrack_bn_statistics)
+    z, lab = fix["in/z0"], fix["in/fl0"]
+    gimg = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    img_o = O.biggan_generator(z, lab, leaves, B, ocfg, bn_mode=bn_mode)
+    (img_o * gimg).sum().backward()
+    for p in G.parameters():
+        p.grad = None
+    img = G(z.to(dev), lab.to(dev))
+    (img * gimg.to(dev)).sum().backward()
+    torch.cuda.synchronize()
+    C = Collector()
+    t = 2e-4 if not mixed else 5e-2
+    C.check(f"G img [{bn_mode}]", img, img_o, t)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    for k, p in G.named_parameters():
+        C.check("G grad " + k, p.grad, leaves[k].grad, 2 * t, floor=1e-3 * gmax)
+    for k, b in G.named_buffers():
+        if "_ones" not in k:
+            C.check("G buf " + k, b, B[k], t)
+    C.finish()

@@ -41,3 +41,26 @@ def sub(fix, prefix):
 def tol_for(dtype):
     # fp32 path: exact-fp32 MFMA, only summation order differs; bf16 path vs the fp32 oracle
     return 2e-4 if dtype == torch.float32 else 3e-2
+
+
+class Collector:
+    """Record every comparison, fail once at the end (so one GPU run shows all mismatches)."""
+
+    def __init__(self):
+        self.rows = []
+
+    def check(self, name, a, b, tol, floor=0.0):
+        """err = max|a-b| / max(max|b|, floor): `floor` keeps tensors that are analytically ~0 (e.g. the bias of a
+        convolution feeding a batch norm) from being judged against their own rounding noise."""
+        a = a.detach().double().cpu().reshape(-1)
+        b = b.detach().double().cpu().reshape(-1)
+        assert a.shape == b.shape, f"{name}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
+        finite = bool(torch.isfinite(a).all())
+        e = float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30)) if finite else float("inf")
+        self.rows.append((name, e, tol))
+        print(f"{name:52s} err={e:.3e} tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
+        return e
+
+    def finish(self):
+        bad = [(n, e, t) for n, e, t in self.rows if not e <= t]
+        assert not bad, "mismatches: " + "; ".join(f"{n} err={e:.2e} tol={t:.0e}" for n, e, t in bad[:12]) + (f" (+{len(bad) - 12} more)" if len(bad) > 12 else "")
