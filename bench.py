@@ -1,0 +1,219 @@
+"""bench.py -- images/sec of one StudioGAN training step (n_d discriminator updates + 1 generator update incl. optimizer,
+EMA and gradient exchange; reference src/loader.py:392-405) on the HIP path.
+
+    python bench.py --gpus 1 --steps 5 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...
+
+Workload (BASELINE.json metric): BigGAN ImageNet-128 (big_resnet, ch 96, cBN + projection D, SN on G and D, attention
+G@64^2 / D@64^2, hinge, Adam(5e-5/2e-4, betas (0, .999), eps 1e-6), d_updates_per_step 2, EMA on), batch 256 per GPU,
+bf16 compute (fp32 master weights / statistics / optimizer), synthetic ImageNet-shaped inputs resident in HBM.
+Weak scaling: every rank runs batch 256; gradients are all-reduced over RCCL once per update, G's batch norms are
+synchronised (one fp64 all-reduce per BN layer and direction).
+
+Prints ONE JSON line (rank 0): value = global images per second; roofline = achieved algorithmic TFLOP/s of the dominant
+kernel family (the MFMA implicit-GEMM convolution engine) measured live with hipEvents on the launch stream;
+cpu_baseline = the CPU oracle (restatement of the reference, oracle/restate.py) timed on the host cores at a reduced batch.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+# algorithmic conv/matmul FLOPs per image of batch per step for C3: 2*D_upd + 1*G_upd
+C3_GFLOP_PER_IMG_STEP = 514.79
+PEAK_BF16_TFLOPS = 2500.0   # dense MFMA bf16 peak, /opt/skills/guides/MI355X_MICROARCH.md
+PEAK_F32_TFLOPS = 157.3
+
+
+class _MODEL:
+    info_type = "N/A"
+
+
+WORKLOADS = {
+    # name: (img_size, ch, z_dim, shared_dim, num_classes, attn_g, attn_d, n_d, g_lr, d_lr, beta1, beta2, gflop_per_img_step)
+    "biggan128": dict(img_size=128, ch=96, z_dim=120, shared=128, classes=1000, attn_g=[4], attn_d=[1], n_d=2, g_lr=5e-5, d_lr=2e-4,
+                      beta1=0.0, beta2=0.999, gflop=C3_GFLOP_PER_IMG_STEP, desc="BigGAN ImageNet-128 cBN+PD hinge + self-attention, EMA on (C3)"),
+    "biggan32": dict(img_size=32, ch=96, z_dim=80, shared=128, classes=10, attn_g=[2], attn_d=[1], n_d=2, g_lr=5e-5, d_lr=2e-4,
+                     beta1=0.0, beta2=0.999, gflop=None, desc="BigGAN CIFAR-sized smoke workload (not a benchmark configuration)"),
+}
+
+
+def build(wl, mixed, device):
+    from studiogan_amd import ops
+    from studiogan_amd.backbones import big_resnet
+    MOD = ops.Modules(apply_g_sn=True, apply_d_sn=True, g_cond_mtd="cBN", backbone="big_resnet")
+    G = big_resnet.Generator(wl["z_dim"], wl["shared"], wl["img_size"], wl["ch"], True, wl["attn_g"], "cBN", wl["classes"], "ortho", "N/A",
+                             mixed, MOD, _MODEL).to(device)
+    D = big_resnet.Discriminator(wl["img_size"], wl["ch"], True, True, wl["attn_d"], "PD", "W/O", "N/A", False, wl["classes"], "ortho", "N/A",
+                                 mixed, MOD, _MODEL).to(device)
+    return G, D
+
+
+def synth_batches(n, batch, img_size, classes, device, seed):
+    """uint8-grid 'real' images in [-1,1] and labels, generated on the CPU with a seeded generator."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for _ in range(n):
+        k = torch.randint(0, 256, (batch, 3, img_size, img_size), generator=g, dtype=torch.int32)
+        x = (k.float() / 127.5 - 1.0).to(device)
+        y = torch.randint(0, classes, (batch,), generator=g).to(device)
+        out.append((x, y))
+    return out
+
+
+def cpu_baseline(G, wl, cpu_batch, budget_s=40.0):
+    """The reference path restated on CPU (oracle/restate.py), fp32, all host cores, same architecture and step
+    structure, reduced batch. Timed here only -- never used to produce the GPU result."""
+    from oracle import restate as O
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    ocfg = dict(img_size=wl["img_size"], g_conv_dim=wl["ch"], d_conv_dim=wl["ch"], z_dim=wl["z_dim"], attn_g_loc=wl["attn_g"],
+                attn_d_loc=wl["attn_d"], apply_attn=True, g_cond_mtd="cBN", d_cond_mtd="PD", apply_d_sn=True, backbone="big_resnet")
+    Gc, Dc = build(wl, False, torch.device("cpu"))
+    isb = lambda k: any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))
+    GP = {k: v.detach().clone() for k, v in Gc.state_dict().items() if not isb(k)}
+    GB = {k: v.detach().clone() for k, v in Gc.state_dict().items() if isb(k)}
+    DP = {k: v.detach().clone() for k, v in Dc.state_dict().items() if not isb(k)}
+    DB = {k: v.detach().clone() for k, v in Dc.state_dict().items() if isb(k)}
+    del Gc, Dc
+    gen_fn, dis_fn = O.model_fns(ocfg)
+    g_opt, d_opt = O.AdamState(GP, wl["g_lr"], wl["beta1"], wl["beta2"]), O.AdamState(DP, wl["d_lr"], wl["beta1"], wl["beta2"])
+    gen = torch.Generator().manual_seed(99)
+    def one_step():
+        for _ in range(wl["n_d"]):
+            z = torch.randn(cpu_batch, wl["z_dim"], generator=gen)
+            fl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
+            real = torch.randint(0, 256, (cpu_batch, 3, wl["img_size"], wl["img_size"]), generator=gen).float() / 127.5 - 1.0
+            rl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
+            O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [real], [rl], [z], [fl], "hinge")
+        z = torch.randn(cpu_batch, wl["z_dim"], generator=gen)
+        fl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
+        O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [z], [fl], "hinge")
+    t0 = time.time()
+    one_step()  # warm-up (allocations, oneDNN primitive creation)
+    warm = time.time() - t0
+    steps, t0 = 0, time.time()
+    while True:
+        one_step()
+        steps += 1
+        if time.time() - t0 + warm > budget_s or steps >= 3:
+            break
+    dt = (time.time() - t0) / steps
+    return {"value": round(cpu_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": f"{steps} step(s) of the same G+D step at batch {cpu_batch} (fp32, torch CPU ops via oracle/restate.py), {dt:.2f} s/step"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default="biggan128")
+    ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
+    ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 (not the benchmark configuration)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=4)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    group = None
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        group = dist.group.WORLD
+    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    import studiogan_amd
+    from studiogan_amd import _lib as L
+    from studiogan_amd import ops
+    from studiogan_amd.worker import Worker
+
+    wl = WORKLOADS[args.workload]
+    mixed = not args.fp32
+    torch.manual_seed(1234)  # identical initial weights on every rank (what DDP's initial broadcast guarantees)
+    G, D = build(wl, mixed, device)
+    if world > 1:
+        for m in G.modules():
+            if isinstance(m, ops.BatchNorm2d):
+                m.sync_group = True
+    w = Worker(G, D, wl["z_dim"], wl["classes"], args.batch, "hinge", wl["g_lr"], wl["d_lr"], wl["beta1"], wl["beta2"],
+               d_updates_per_step=wl["n_d"], apply_g_ema=True, g_ema_decay=0.9999, g_ema_start=20000, group=group)
+    torch.manual_seed(1234 + rank)  # per-rank sampling streams (reference src/loader.py:99)
+    real = synth_batches(wl["n_d"], args.batch, wl["img_size"], wl["classes"], device, 1234 + rank)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(args.warmup):
+        w.step(i, real)
+    barrier()
+    L.call("sg_prof_enable", 1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        w.step(args.warmup + i, real)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    prof = (ctypes.c_double * 9)()
+    L.call("sg_prof_collect", prof, 3)
+    L.call("sg_prof_enable", 0)
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    global_batch = args.batch * world
+    value = global_batch * args.steps / elapsed
+    n_launch = prof[0] + prof[3]
+    conv_ms = prof[1] + prof[4]
+    conv_flop = prof[2] + prof[5]
+    achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
+    peak = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
+    out = {
+        "metric": "images/sec (G+D step) BigGAN ImageNet-128 bs256",
+        "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16" if mixed else "f32", "data": "synthetic",
+        "config": {"workload": wl["desc"], "per_gpu_batch": args.batch, "global_batch": global_batch, "d_updates_per_step": wl["n_d"],
+                   "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
+        "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
+                     "traffic": None,
+                     "kernel": "sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
+                     "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
+                     "conv_ms_per_step": round(conv_ms / args.steps, 2),
+                     "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
+    }
+    if wl["gflop"]:
+        out["step_tflops"] = round(wl["gflop"] * global_batch / 1e3 / (ms_per_step * 1e-3), 2)  # whole-step algorithmic TFLOP/s
+    if not args.no_cpu_baseline and world == 1:
+        del w, G, D, real
+        torch.cuda.empty_cache()
+        out["cpu_baseline"] = cpu_baseline(None, wl, args.cpu_batch)
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,6 +53,11 @@ typedef void* sg_stream_t; /* hipStream_t */
 
 const char* sg_last_error(void);
 int sg_version(void);
+/* launch profiler used by bench.py's roofline leg: hipEvent pairs around every contraction-engine launch, recorded on the
+ * launch stream. collect: out[kind*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; kind 0 = conv fwd/dgrad,
+ * 1 = conv wgrad, 2 = gemm. Synchronise the device before collecting. */
+int sg_prof_enable(int on);
+int sg_prof_collect(double* out, int nkinds);
 
 /* out[n,ho,wo,co] = beta*res + mask(alpha * pool2x2sum(conv(x', w)) + bias), x' = [relu][upsample x2](x).
  * Forward convolution and (with the data-gradient weight image) its data gradient. */

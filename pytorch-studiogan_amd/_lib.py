@@ -70,6 +70,8 @@ def build(force=False, verbose=False):
 
 
 _PROTOS = {
+    "sg_prof_enable": [_i],
+    "sg_prof_collect": [C.POINTER(C.c_double), _i],
     "sg_conv2d_fwd": [C.POINTER(ConvFwdDesc), _vp],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_gemm": [C.POINTER(GemmDesc), _vp],

@@ -11,3 +11,51 @@ extern "C" void sg_set_error(const char* msg) {
 }
 extern "C" const char* sg_last_error(void) { return g_err; }
 extern "C" int sg_version(void) { return 1; }
+
+// ---- in-library launch profiler (bench.py's roofline leg) --------------------------------------------------------
+// When enabled, every launch of the MFMA contraction engine (conv fwd/dgrad/wgrad, gemm) is bracketed by a pair of
+// hipEvents recorded on the SAME stream the kernel is launched on; sg_prof_collect() sums the elapsed times and the
+// algorithmic FLOPs after the caller has synchronised. Off by default: zero overhead on the normal path.
+#define SG_PROF_MAX 16384
+static int g_prof_on = 0;
+static int g_prof_n = 0;
+static hipEvent_t g_ev0[SG_PROF_MAX], g_ev1[SG_PROF_MAX];
+static double g_flops[SG_PROF_MAX];
+static int g_kind[SG_PROF_MAX];
+static int g_ev_created = 0;
+
+extern "C" int sg_prof_enable(int on) {
+  if (on && g_ev_created < SG_PROF_MAX) {
+    for (int i = g_ev_created; i < SG_PROF_MAX; i++) {
+      if (hipEventCreate(&g_ev0[i]) != hipSuccess || hipEventCreate(&g_ev1[i]) != hipSuccess) { sg_set_error("sg_prof_enable: hipEventCreate failed"); return -2; }
+    }
+    g_ev_created = SG_PROF_MAX;
+  }
+  g_prof_on = on ? 1 : 0;
+  g_prof_n = 0;
+  return 0;
+}
+// returns the slot index or -1
+extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind) {
+  if (!g_prof_on || g_prof_n >= SG_PROF_MAX) return -1;
+  const int i = g_prof_n++;
+  g_flops[i] = flops; g_kind[i] = kind;
+  hipEventRecord(g_ev0[i], st);
+  return i;
+}
+extern "C" void sg_prof_end(hipStream_t st, int slot) {
+  if (slot >= 0) hipEventRecord(g_ev1[slot], st);
+}
+// out[kind*3 + {0,1,2}] = {launches, total ms, total flops} for kind in 0..3 (0 conv fwd/dgrad, 1 conv wgrad, 2 gemm)
+extern "C" int sg_prof_collect(double* out, int nkinds) {
+  for (int k = 0; k < nkinds * 3; k++) out[k] = 0.0;
+  for (int i = 0; i < g_prof_n; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev0[i], g_ev1[i]) != hipSuccess) { sg_set_error("sg_prof_collect: events not complete (synchronise first)"); return -2; }
+    const int k = g_kind[i];
+    if (k < 0 || k >= nkinds) continue;
+    out[k * 3 + 0] += 1.0; out[k * 3 + 1] += ms; out[k * 3 + 2] += g_flops[i];
+  }
+  g_prof_n = 0;
+  return 0;
+}

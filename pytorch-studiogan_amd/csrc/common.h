@@ -102,6 +102,8 @@ __device__ __forceinline__ float block_max_256(float v, float* sm) {
 
 // error reporting shared by every C-ABI entry point (capi.cpp owns the storage)
 extern "C" void sg_set_error(const char* msg);
+extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind);
+extern "C" void sg_prof_end(hipStream_t st, int slot);
 #define SG_CHECK(cond, msg)                                   \
   do {                                                        \
     if (!(cond)) { sg_set_error(msg); return -1; }            \

@@ -47,9 +47,11 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.res = d->res; e.res_bstride = 0; e.ldr = d->ldr; e.beta = d->beta;
   e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
+  const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
   if (I <= 32) sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 32, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
   else if (I % 128 != 0 && (I % 96 == 0 || (I < 128 && I > 64))) sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 96, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
   else sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 128, 128, 2, 2>(lp, lq, e, I, J, K, 1, 1, st);
+  sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;
 }
@@ -96,10 +98,12 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
     if (splits > maxs) splits = maxs;
     if (splits > 1024) splits = 1024;
   }
+  const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
   if (BI == 32) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, 1, st);
   else if (BJ == 32) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 256, 32, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
   else if (BJ == 96) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 256, 96, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
   else sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;
 }

@@ -9,9 +9,11 @@ template <typename T, class LP, class LQ, bool TR>
 static int gemm_launch(const LP& lp, const LQ& lq, const Epilogue<T>& e, const sg_gemm_desc* d, hipStream_t st) {
   const int I = d->I, J = d->J, K = d->K;
   const int splits = d->splits > 1 ? d->splits : 1;
+  const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K * (double)d->batch, 2);
   if (I <= 32) sg_launch_gemm<T, LP, LQ, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, d->batch, st);
   else if (I % 128 != 0 && (I % 96 == 0 || (I < 128 && I > 64))) sg_launch_gemm<T, LP, LQ, 96, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, d->batch, st);
   else sg_launch_gemm<T, LP, LQ, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, d->batch, st);
+  sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;
 }

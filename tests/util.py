@@ -49,16 +49,23 @@ class Collector:
     def __init__(self):
         self.rows = []
 
-    def check(self, name, a, b, tol, floor=0.0):
+    def check(self, name, a, b, tol, floor=0.0, l2=False):
         """err = max|a-b| / max(max|b|, floor): `floor` keeps tensors that are analytically ~0 (e.g. the bias of a
-        convolution feeding a batch norm) from being judged against their own rounding noise."""
+        convolution feeding a batch norm) from being judged against their own rounding noise.
+        l2=True: err = ||a-b||_2 / max(||b||_2, floor*sqrt(n)) -- the robust metric for bf16 gradients, where a few
+        ReLU units flipping under 2^-9 relative rounding produce sparse O(1) element errors."""
         a = a.detach().double().cpu().reshape(-1)
         b = b.detach().double().cpu().reshape(-1)
         assert a.shape == b.shape, f"{name}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
         finite = bool(torch.isfinite(a).all())
-        e = float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30)) if finite else float("inf")
+        if not finite:
+            e = float("inf")
+        elif l2:
+            e = float((a - b).norm() / max(float(b.norm()), floor * (a.numel() ** 0.5), 1e-30))
+        else:
+            e = float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
         self.rows.append((name, e, tol))
-        print(f"{name:52s} err={e:.3e} tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
+        print(f"{name:52s} {'l2' if l2 else 'mx'}err={e:.3e} tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
         return e
 
     def finish(self):
