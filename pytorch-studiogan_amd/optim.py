@@ -12,6 +12,23 @@ from . import _lib as L
 from .bank import ParamArena, arena_of, get_buffer_arena
 
 
+def chunk_ranges(n, nch, min_chunk=1 << 20):
+    """Split [0, n) into at most nch contiguous 16-byte-aligned ranges of >= min_chunk elements."""
+    nch = max(1, min(nch, n // min_chunk or 1))
+    per = ((n + nch - 1) // nch + 3) // 4 * 4
+    return [(lo, min(n, lo + per)) for lo in range(0, n, per)]
+
+
+def pipelined_allreduce(flat, ranges, group=None):
+    """Issue one async all-reduce(sum) per range up front (they queue on the RCCL stream back to back) and yield each
+    range as soon as ITS reduction is complete, so the consumer (the fused Adam launch of that slice) overlaps with the
+    ranges still on the wire."""
+    works = [(lo, hi, dist.all_reduce(flat[lo:hi], group=group, async_op=True)) for lo, hi in ranges]
+    for lo, hi, w in works:
+        w.wait()
+        yield lo, hi
+
+
 def _arena_for(params):
     ents = [arena_of(p) for p in params]
     if any(e is None for e in ents) or len({id(e[0]) for e in ents}) != 1 or not ents[0][0].intact():
@@ -74,16 +91,7 @@ class FusedAdam(torch.optim.Optimizer):
         st = L.stream()
         if world > 1:
             # pipelined all-reduce(sum) -> Adam(grad/world): chunk i+1 is on the wire while chunk i is being applied
-            nch = max(1, min(self.comm_chunks, n // (1 << 20) or 1))
-            per = ((n + nch - 1) // nch + 3) // 4 * 4
-            works = []
-            for c in range(nch):
-                lo, hi = c * per, min(n, (c + 1) * per)
-                if lo >= hi:
-                    break
-                works.append((lo, hi, dist.all_reduce(a.grad[lo:hi], group=group, async_op=True)))
-            for lo, hi, w in works:
-                w.wait()
+            for lo, hi in pipelined_allreduce(a.grad, chunk_ranges(n, self.comm_chunks), group):
                 L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
                        self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)

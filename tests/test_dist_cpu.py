@@ -1,0 +1,142 @@
+"""CPU, world_size 2 over gloo: the host-side data-parallel logic of the N>1 path (the kernels themselves need a GPU):
+ * chunking + pipelined all-reduce of the flat gradient arena used by FusedAdam (studiogan_amd/optim.py),
+ * the sync-BN contract: all-reducing the per-rank fp64 partial sums {sum x, sum x^2} (count * world) and the backward
+   channel terms reproduces full-batch batch-norm forward/backward exactly (what sg_bn_partial_stats / sg_bn_finalize /
+   sg_bn_bwd_finalize compute around the all-reduce in studiogan_amd/functional.py:BNFn),
+ * gradient averaging across ranks == full-batch gradient for a mean-reduced loss."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+import torch.nn.functional as TF
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, fn, ret):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = fn(rank, world)
+    finally:
+        dist.destroy_process_group()
+
+
+def _spawn(fn, world=2):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), fn, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+def test_chunk_ranges_cover_and_align():
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd.optim import chunk_ranges
+    for n in (5, 1 << 20, (1 << 22) + 12, 88_000_004):
+        for nch in (1, 4, 7):
+            r = chunk_ranges(n, nch)
+            assert r[0][0] == 0 and r[-1][1] == n
+            for (a, b), (c, d) in zip(r[:-1], r[1:]):
+                assert b == c and a % 4 == 0 and c % 4 == 0 and b > a
+            assert len(r) <= nch
+
+
+def _pipeline_job(rank, world):
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd.optim import chunk_ranges, pipelined_allreduce
+    n = (1 << 21) + 36
+    g = torch.Generator().manual_seed(100 + rank)
+    grad = torch.randn(n, generator=g)
+    p = torch.zeros(n)
+    seen = []
+    for lo, hi in pipelined_allreduce(grad, chunk_ranges(n, 4, min_chunk=1 << 18)):
+        p[lo:hi] -= 0.1 * grad[lo:hi] / world      # the "optimizer" consumes each slice as it lands
+        seen.append((lo, hi))
+    return p, seen
+
+
+def test_pipelined_allreduce_gloo():
+    out = _spawn(_pipeline_job)
+    n = (1 << 21) + 36
+    full = sum(torch.randn(n, generator=torch.Generator().manual_seed(100 + r)) for r in range(2)) / 2
+    for r in range(2):
+        p, seen = out[r]
+        assert seen[0][0] == 0 and seen[-1][1] == n and len(seen) > 1
+        assert torch.allclose(p, -0.1 * full, atol=1e-6)
+    assert torch.equal(out[0][0], out[1][0]), "ranks must end bit-identical"
+
+
+def _syncbn_job(rank, world):
+    """Each rank holds half of the batch; statistics and backward channel terms are exchanged exactly the way BNFn does."""
+    g = torch.Generator().manual_seed(7)
+    N, C, H = 8, 6, 5
+    x_full = torch.randn(N, C, H, H, generator=g, dtype=torch.float64) * 2 + 0.3
+    gy_full = torch.randn(N, C, H, H, generator=g, dtype=torch.float64)
+    gain_full = 1 + 0.2 * torch.randn(N, C, generator=g, dtype=torch.float64)
+    sl = slice(rank * N // world, (rank + 1) * N // world)
+    x, gy, gain = x_full[sl], gy_full[sl], gain_full[sl]
+    eps = 1e-4
+    # forward: partial sums -> all-reduce -> finalize (sg_bn_partial_stats / sg_bn_finalize)
+    partial = torch.stack([x.sum(dim=(0, 2, 3)), (x * x).sum(dim=(0, 2, 3))], dim=1).reshape(-1).clone()
+    dist.all_reduce(partial)
+    count = x[:, 0].numel() * world
+    p = partial.view(C, 2)
+    mean = p[:, 0] / count
+    var = p[:, 1] / count - mean * mean
+    invstd = 1.0 / torch.sqrt(var + eps)
+    xh = (x - mean.view(1, C, 1, 1)) * invstd.view(1, C, 1, 1)
+    y = xh * gain.view(-1, C, 1, 1)
+    # backward: per-(n,c) sums -> per-channel terms -> all-reduce -> apply (sg_bn_bwd_reduce/finalize/apply)
+    s1 = gy.sum(dim=(2, 3))
+    s2 = (gy * xh).sum(dim=(2, 3))
+    chan = torch.stack([(gain * s1).sum(0), (gain * s2).sum(0)], dim=1).reshape(-1).clone()
+    dist.all_reduce(chan)
+    ch = chan.view(C, 2)
+    dx = invstd.view(1, C, 1, 1) * (gain.view(-1, C, 1, 1) * gy - (ch[:, 0].view(1, C, 1, 1) + xh * ch[:, 1].view(1, C, 1, 1)) / count)
+    # full-batch reference through autograd
+    xr = x_full.clone().requires_grad_(True)
+    yr = TF.batch_norm(xr, None, None, None, None, True, 0.1, eps) * gain_full.view(N, C, 1, 1)
+    yr.backward(gy_full)
+    return float((y - yr.detach()[sl]).abs().max()), float((dx - xr.grad[sl]).abs().max())
+
+
+def test_sync_bn_contract_gloo():
+    out = _spawn(_syncbn_job)
+    for r in range(2):
+        ef, eb = out[r]
+        assert ef < 1e-10 and eb < 1e-10, (ef, eb)
+
+
+def _grad_avg_job(rank, world):
+    torch.manual_seed(0)
+    lin = torch.nn.Linear(6, 3)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 6, generator=g)
+    sl = slice(rank * 4, rank * 4 + 4)
+    loss = TF.relu(1.0 - lin(x[sl]).sum(1)).mean()          # hinge-style, mean over the LOCAL batch
+    loss.backward()
+    flat = torch.cat([p.grad.reshape(-1) for p in lin.parameters()])
+    dist.all_reduce(flat)
+    flat /= world                                            # == grad_scale = 1/world in sg_adam_ema
+    lin2 = torch.nn.Linear(6, 3)
+    lin2.load_state_dict(lin.state_dict())
+    TF.relu(1.0 - lin2(x).sum(1)).mean().backward()
+    ref = torch.cat([p.grad.reshape(-1) for p in lin2.parameters()])
+    return float((flat - ref).abs().max())
+
+
+def test_gradient_average_equals_full_batch_gloo():
+    out = _spawn(_grad_avg_job)
+    assert max(out.values()) < 1e-6
