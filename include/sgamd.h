@@ -87,8 +87,12 @@ typedef struct {
   const float* alpha_ptr;          /* optional device scalar multiplied into alpha */
   int splits;                      /* 0 = auto */
   int no_tr;                       /* 1 = use the gather fragment path instead of ds_read_b64_tr_b16 (test hook) */
+  float* work; long long work_floats; /* optional scratch for the deterministic two-stage split-K (see sg_conv2d_wgrad_plan);
+                                         without it k-splits fall back to fp32 atomics */
 } sg_conv_wgrad_desc;
 int sg_conv2d_wgrad(const sg_conv_wgrad_desc* d, sg_stream_t stream);
+/* the k-split count the launcher will use for this problem and the scratch floats its two-stage reduction wants */
+int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, long long* work_floats);
 
 /* batched OUT[b][j][i] = beta*res + alpha * sum_k P(i,k) Q(j,k) + bias[i]
  * form 0 ("KC"): operand stored [row][k] (k contiguous); form 1 ("MC"): stored [k][row] (row contiguous) */

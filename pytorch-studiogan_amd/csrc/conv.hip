@@ -23,11 +23,27 @@ static void fill_geom(PixGeom<T>& g, const void* x, int N, int Hs, int Ws, int C
   g.wshift = ilog2_exact(Wo); g.hshift = ilog2_exact(Ho);
 }
 
+template <typename T, bool FAST>
+static void conv_fwd_launch(const sg_conv_fwd_desc* d, const Epilogue<T>& e, int I, int J, int K, int pflags, hipStream_t st) {
+  typedef StridedKC<T, FAST> LP;
+  typedef ConvPixKC<T, FAST> LQ;
+  LP lp;
+  lp.base = (const T*)d->w; lp.bstride = 0; lp.ld = K; lp.rows = I; lp.K = K;
+  lp.vec_ok = (K % ET<T>::VEC == 0) && aligned16(d->w);
+  LQ lq;
+  fill_geom<T>(lq.g, d->x, d->N, d->Hs, d->Ws, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w, pflags);
+  lq.rows = J; lq.K = K;
+  if (I <= 32) sg_launch_gemm<T, LP, LQ, 32, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
+  else if (I % 128 != 0 && (I % 96 == 0 || (I < 128 && I > 64))) sg_launch_gemm<T, LP, LQ, 96, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
+  else sg_launch_gemm<T, LP, LQ, 128, 128, 2, 2>(lp, lq, e, I, J, K, 1, 1, st);
+}
+
 template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream_t st) {
   const int K = d->R * d->S * d->C;
   const int I = d->Cout;
   const long long Jll = (long long)d->N * d->Ho * d->Wo;
   SG_CHECK(Jll < (1ll << 31), "sg_conv2d_fwd: too many output pixels");
+  SG_CHECK((long long)d->N * d->Hs * d->Ws * d->ldx < (1ll << 31), "sg_conv2d_fwd: input tensor too large for 32-bit element offsets");
   const int J = (int)Jll;
   int pflags = d->pix_flags;
   if (d->epi_flags & SG_EPI_POOL) {
@@ -36,21 +52,16 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   } else {
     pflags &= ~SG_PIX_QUAD;
   }
-  StridedKC<T> lp;
-  lp.base = (const T*)d->w; lp.bstride = 0; lp.ld = K; lp.rows = I; lp.K = K;
-  lp.vec_ok = (K % ET<T>::VEC == 0) && aligned16(d->w);
-  ConvPixKC<T> lq;
-  fill_geom<T>(lq.g, d->x, d->N, d->Hs, d->Ws, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w, pflags);
-  lq.rows = J; lq.K = K;
+  const bool w_vec = (K % ET<T>::VEC == 0) && aligned16(d->w);
+  const bool x_vec = (d->C % ET<T>::VEC == 0) && (d->ldx % ET<T>::VEC == 0) && aligned16(d->x);
   Epilogue<T> e;
   e.out = d->out; e.out_bstride = 0; e.ldo = d->ldo; e.bias = d->bias;
   e.res = d->res; e.res_bstride = 0; e.ldr = d->ldr; e.beta = d->beta;
-  e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm;
+  e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
-  if (I <= 32) sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 32, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
-  else if (I % 128 != 0 && (I % 96 == 0 || (I < 128 && I > 64))) sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 96, 256, 1, 4>(lp, lq, e, I, J, K, 1, 1, st);
-  else sg_launch_gemm<T, StridedKC<T>, ConvPixKC<T>, 128, 128, 2, 2>(lp, lq, e, I, J, K, 1, 1, st);
+  if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
+  else conv_fwd_launch<T, false>(d, e, I, J, K, pflags, st);
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;
@@ -66,43 +77,90 @@ extern "C" int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream) {
   return -1;
 }
 
-template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc* d, hipStream_t st) {
-  const int I = d->R * d->S * d->C;
-  const int J = d->Cout;
-  const long long Kll = (long long)d->N * d->Ho * d->Wo;
-  SG_CHECK(Kll < (1ll << 31), "sg_conv2d_wgrad: too many pixels");
-  const int K = (int)Kll;
-  ConvPixMC<T> lp;
-  fill_geom<T>(lp.g, d->x, d->N, d->xHs, d->xWs, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w,
-               d->x_flags & ~SG_PIX_QUAD);
-  lp.rows = I; lp.K = K;
-  ConvPixMC<T> lq;
-  fill_geom<T>(lq.g, d->dy, d->N, d->gHs, d->gWs, d->Cout, d->ldg, d->Ho, d->Wo, 1, 1, 1, 0, 0, d->g_flags & ~SG_PIX_QUAD);
-  lq.rows = J; lq.K = K;
-  Epilogue<T> e;
-  e.out = d->dw; e.out_bstride = 0; e.ldo = I; e.bias = nullptr; e.res = nullptr; e.res_bstride = 0; e.ldr = 0; e.beta = 0.f;
-  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr;
-  e.flags = SG_EPI_ATOMIC | SG_EPI_OUT_F32; e.I = I; e.J = J;
-  // tile config by output-channel count, then enough k-splits to fill 256 CUs a few times over
-  int BI, BJ;
+// tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)
+static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, int& BJ, int& splits) {
   if (I <= 32) { BI = 32; BJ = 256; }
   else if (J <= 32) { BI = 256; BJ = 32; }
   else if (J % 128 != 0 && (J % 96 == 0 || (J < 128 && J > 64))) { BI = 256; BJ = 96; }
   else { BI = 128; BJ = 128; }
   const int tiles = ((I + BI - 1) / BI) * ((J + BJ - 1) / BJ);
-  int splits = d->splits;
+  splits = want_splits;
   if (splits <= 0) {
-    splits = (1024 + tiles - 1) / tiles;
-    int maxs = K / (ET<T>::BK * 8);
-    if (maxs < 1) maxs = 1;
+    splits = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU
+    int maxs = K / (bk * 16); if (maxs < 1) maxs = 1;
     if (splits > maxs) splits = maxs;
-    if (splits > 1024) splits = 1024;
+    if (splits > 512) splits = 512;
   }
+  if (splits > 1) {  // what sg_launch_gemm will really use after rounding klen up to a multiple of bk
+    int klen = (K + splits - 1) / splits; klen = ((klen + bk - 1) / bk) * bk;
+    splits = (K + klen - 1) / klen;
+  }
+}
+
+extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, long long* work_floats) {
+  SG_CHECK(d && splits && work_floats, "sg_conv2d_wgrad_plan: null");
+  const int I = d->R * d->S * d->C, J = d->Cout;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  int BI, BJ, sp;
+  wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp);
+  *splits = sp;
+  *work_floats = sp > 1 ? (long long)sp * I * J : 0;
+  return 0;
+}
+
+// out[i] += sum_s partial[s][i]   (fixed summation order: deterministic weight gradients)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* partial, float* out, int splits, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int s = 0; s < splits; s++) acc += partial[(long long)s * n + i];
+    out[i] += acc;
+  }
+}
+
+template <typename T, bool TR, bool FAST>
+static void conv_wgrad_launch(const sg_conv_wgrad_desc* d, const Epilogue<T>& e, int I, int J, int K, int BI, int BJ, int splits, hipStream_t st) {
+  typedef ConvPixMC<T, FAST> LM;
+  LM lp;
+  fill_geom<T>(lp.g, d->x, d->N, d->xHs, d->xWs, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w,
+               d->x_flags & ~SG_PIX_QUAD);
+  lp.rows = I; lp.K = K;
+  LM lq;
+  fill_geom<T>(lq.g, d->dy, d->N, d->gHs, d->gWs, d->Cout, d->ldg, d->Ho, d->Wo, 1, 1, 1, 0, 0, d->g_flags & ~SG_PIX_QUAD);
+  lq.rows = J; lq.K = K;
+  if (BI == 32) sg_launch_gemm<T, LM, LM, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else if (BJ == 32) sg_launch_gemm<T, LM, LM, 256, 32, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else if (BJ == 96) sg_launch_gemm<T, LM, LM, 256, 96, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else sg_launch_gemm<T, LM, LM, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, 1, st);
+}
+
+template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc* d, hipStream_t st) {
+  const int I = d->R * d->S * d->C;
+  const int J = d->Cout;
+  const long long Kll = (long long)d->N * d->Ho * d->Wo;
+  SG_CHECK(Kll < (1ll << 31), "sg_conv2d_wgrad: too many pixels");
+  SG_CHECK((long long)d->N * d->xHs * d->xWs * d->ldx < (1ll << 31) && (long long)d->N * d->gHs * d->gWs * d->ldg < (1ll << 31),
+           "sg_conv2d_wgrad: tensor too large for 32-bit element offsets");
+  const int K = (int)Kll;
+  int BI, BJ, splits;
+  wgrad_plan(I, J, K, ET<T>::BK, d->splits, BI, BJ, splits);
+  const long long n = (long long)I * J;
+  const bool two_stage = splits > 1 && d->work && d->work_floats >= (long long)splits * n;
+  Epilogue<T> e;
+  e.out = d->dw; e.out_bstride = 0; e.ldo = I; e.bias = nullptr; e.res = nullptr; e.res_bstride = 0; e.ldr = 0; e.beta = 0.f;
+  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.split_stride = 0;
+  e.flags = SG_EPI_OUT_F32; e.I = I; e.J = J;
+  if (splits == 1) { e.res = d->dw; e.ldr = I; e.beta = 1.f; e.flags |= SG_EPI_RES_F32; }   // single writer: dw += tile, no atomics
+  else if (two_stage) { e.out = d->work; e.split_stride = n; }                                 // partial tiles, reduced below
+  else e.flags |= SG_EPI_ATOMIC;                                                               // no workspace: fp32 atomics
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
-  if (BI == 32) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, 1, st);
-  else if (BJ == 32) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 256, 32, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
-  else if (BJ == 96) sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 256, 96, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
-  else sg_launch_gemm<T, ConvPixMC<T>, ConvPixMC<T>, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  const bool fast = (d->C % ET<T>::VEC == 0) && (d->ldx % ET<T>::VEC == 0) && aligned16(d->x) &&
+                    (d->Cout % ET<T>::VEC == 0) && (d->ldg % ET<T>::VEC == 0) && aligned16(d->dy);
+  if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
+  else conv_wgrad_launch<T, TR, false>(d, e, I, J, K, BI, BJ, splits, st);
+  if (two_stage) {
+    long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, splits, n);
+  }
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;

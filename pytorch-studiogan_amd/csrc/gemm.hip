@@ -18,35 +18,48 @@ static int gemm_launch(const LP& lp, const LQ& lq, const Epilogue<T>& e, const s
   return 0;
 }
 
-template <typename T> static void fill_kc(StridedKC<T>& l, const void* p, long long bs, int ld, int rows, int K) {
+template <typename T, bool F> static void fill_kc(StridedKC<T, F>& l, const void* p, long long bs, int ld, int rows, int K) {
   l.base = (const T*)p; l.bstride = bs; l.ld = ld; l.rows = rows; l.K = K;
   l.vec_ok = (K % ET<T>::VEC == 0) && (ld % ET<T>::VEC == 0) && (bs % ET<T>::VEC == 0) && aligned16(p);
 }
-template <typename T> static void fill_mc(StridedMC<T>& l, const void* p, long long bs, int ld, int rows, int K) {
+template <typename T, bool F> static void fill_mc(StridedMC<T, F>& l, const void* p, long long bs, int ld, int rows, int K) {
   l.base = (const T*)p; l.bstride = bs; l.ld = ld; l.rows = rows; l.K = K;
   l.vec_ok = (rows % ET<T>::VEC == 0) && (ld % ET<T>::VEC == 0) && (bs % ET<T>::VEC == 0) && aligned16(p);
+}
+
+template <typename T, bool TR, bool FAST> static int gemm_forms(const Epilogue<T>& e, const sg_gemm_desc* d, hipStream_t st) {
+  typedef StridedKC<T, FAST> KCL;
+  typedef StridedMC<T, FAST> MCL;
+  if (d->p_form == 0 && d->q_form == 0) {
+    KCL lp, lq; fill_kc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_kc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
+    return gemm_launch<T, KCL, KCL, TR>(lp, lq, e, d, st);
+  } else if (d->p_form == 0 && d->q_form == 1) {
+    KCL lp; MCL lq; fill_kc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_mc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
+    return gemm_launch<T, KCL, MCL, TR>(lp, lq, e, d, st);
+  } else if (d->p_form == 1 && d->q_form == 0) {
+    MCL lp; KCL lq; fill_mc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_kc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
+    return gemm_launch<T, MCL, KCL, TR>(lp, lq, e, d, st);
+  } else {
+    MCL lp, lq; fill_mc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_mc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
+    return gemm_launch<T, MCL, MCL, TR>(lp, lq, e, d, st);
+  }
 }
 
 template <typename T, bool TR> static int gemm_t(const sg_gemm_desc* d, hipStream_t st) {
   Epilogue<T> e;
   e.out = d->out; e.out_bstride = d->out_bstride; e.ldo = d->ldo; e.bias = d->bias;
   e.res = d->res; e.res_bstride = d->res_bstride; e.ldr = d->ldr; e.beta = d->beta;
-  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0;
+  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = d->I; e.J = d->J;
   if (d->splits > 1) SG_CHECK(d->epi_flags & SG_EPI_ATOMIC, "sg_gemm: split-K needs the atomic epilogue");
-  if (d->p_form == 0 && d->q_form == 0) {
-    StridedKC<T> lp, lq; fill_kc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_kc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
-    return gemm_launch<T, StridedKC<T>, StridedKC<T>, TR>(lp, lq, e, d, st);
-  } else if (d->p_form == 0 && d->q_form == 1) {
-    StridedKC<T> lp; StridedMC<T> lq; fill_kc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_mc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
-    return gemm_launch<T, StridedKC<T>, StridedMC<T>, TR>(lp, lq, e, d, st);
-  } else if (d->p_form == 1 && d->q_form == 0) {
-    StridedMC<T> lp; StridedKC<T> lq; fill_mc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_kc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
-    return gemm_launch<T, StridedMC<T>, StridedKC<T>, TR>(lp, lq, e, d, st);
-  } else {
-    StridedMC<T> lp, lq; fill_mc<T>(lp, d->p, d->p_bstride, d->ldp, d->I, d->K); fill_mc<T>(lq, d->q, d->q_bstride, d->ldq, d->J, d->K);
-    return gemm_launch<T, StridedMC<T>, StridedMC<T>, TR>(lp, lq, e, d, st);
-  }
+  const int V = ET<T>::VEC;
+  auto vec = [&](int form, const void* p, long long bs, int ld, int rows) {
+    const bool common = (ld % V == 0) && (bs % V == 0) && aligned16(p);
+    return common && (form == 0 ? (d->K % V == 0) : (rows % V == 0));
+  };
+  if (vec(d->p_form, d->p, d->p_bstride, d->ldp, d->I) && vec(d->q_form, d->q, d->q_bstride, d->ldq, d->J))
+    return gemm_forms<T, TR, true>(e, d, st);
+  return gemm_forms<T, TR, false>(e, d, st);
 }
 
 extern "C" int sg_gemm(const sg_gemm_desc* d, sg_stream_t stream) {

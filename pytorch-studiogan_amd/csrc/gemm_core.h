@@ -45,7 +45,7 @@ template <> __device__ __forceinline__ void set_elem<bf16_t>(u32x4& v, int e, bf
 //   MC form ("row contiguous"): chunk = elements (row .. row+VEC-1, k)    -> LDS image [k][row]
 // init() is called once per thread-chunk, load() every k-tile, advance() steps k by BK.
 // ---------------------------------------------------------------------------------------------------
-template <typename T> struct StridedKC {
+template <typename T, bool FAST = false> struct StridedKC {
   static constexpr bool KC = true;
   static constexpr int VEC = ET<T>::VEC, BK = ET<T>::BK;
   const T* base; long long bstride; int ld; int rows; int K; int vec_ok;
@@ -56,8 +56,13 @@ template <typename T> struct StridedKC {
   }
   __device__ __forceinline__ u32x4 load(const Chunk& ch) const {
     u32x4 v = zero16();
+    if (FAST || vec_ok) {
+      const bool ok = ch.valid & (ch.k < K);
+      const u32x4 t = *(const u32x4*)(ok ? (ch.p + ch.k) : base);
+      return ok ? t : v;
+    }
+    if constexpr (FAST) return v;
     if (!ch.valid || ch.k >= K) return v;
-    if (vec_ok) return *(const u32x4*)(ch.p + ch.k);
 #pragma unroll
     for (int e = 0; e < VEC; e++) if (ch.k + e < K) set_elem<T>(v, e, ch.p[ch.k + e]);
     return v;
@@ -65,7 +70,7 @@ template <typename T> struct StridedKC {
   __device__ __forceinline__ void advance(Chunk& ch) const { ch.k += BK; }
 };
 
-template <typename T> struct StridedMC {
+template <typename T, bool FAST = false> struct StridedMC {
   static constexpr bool KC = false;
   static constexpr int VEC = ET<T>::VEC, BK = ET<T>::BK;
   const T* base; long long bstride; int ld; int rows; int K; int vec_ok;
@@ -74,9 +79,14 @@ template <typename T> struct StridedMC {
   __device__ __forceinline__ void init(Chunk& ch, int row, int k) const { ch.row = row; ch.k = k; }
   __device__ __forceinline__ u32x4 load(const Chunk& ch) const {
     u32x4 v = zero16();
+    if (FAST || vec_ok) {
+      const bool ok = (ch.k < K) & (ch.row < rows);
+      const u32x4 t = *(const u32x4*)(ok ? (base + (long long)ch.k * ld + ch.row) : base);
+      return ok ? t : v;
+    }
+    if constexpr (FAST) return v;
     if (ch.k >= K || ch.row >= rows) return v;
     const T* p = base + (long long)ch.k * ld + ch.row;
-    if (vec_ok) return *(const u32x4*)p;
 #pragma unroll
     for (int e = 0; e < VEC; e++) if (ch.row + e < rows) set_elem<T>(v, e, p[e]);
     return v;
@@ -108,6 +118,27 @@ template <typename T> struct PixGeom {
       wo = pix % Wo; int t = pix / Wo; ho = t % Ho; n = t / Ho;
     }
   }
+  // branch-free form for the vector path: offset (elements) of the tapped pixel, 0 + valid=false when it is padding.
+  // (No early return: a branch in front of every global load makes the compiler wait for each load before issuing
+  // the next one -- measured 3-5x on the weight-gradient k-loop.)
+  __device__ __forceinline__ unsigned tap_off(int n, int ho, int wo, int r, int s, bool& valid) const {
+    int h, w;
+    bool ok = true;
+    if (flags & SG_PIX_TRANSPOSED) {
+      int hn = ho + pad_h - r, wn = wo + pad_w - s;
+      ok = (hn >= 0) & (wn >= 0);
+      if (stride == 2) { ok &= (((hn | wn) & 1) == 0); hn >>= 1; wn >>= 1; }
+      else if (stride != 1) { ok &= ((hn % stride) == 0) & ((wn % stride) == 0); hn /= stride; wn /= stride; }
+      h = hn; w = wn;
+    } else {
+      h = ho * stride - pad_h + r; w = wo * stride - pad_w + s;
+    }
+    ok &= ((unsigned)h < (unsigned)Hin) & ((unsigned)w < (unsigned)Win);
+    if (flags & SG_PIX_UPSAMPLE) { h >>= 1; w >>= 1; }
+    valid = ok;
+    const unsigned off = ((unsigned)(n * Hs + h) * (unsigned)Ws + (unsigned)w) * (unsigned)ldx;
+    return ok ? off : 0u;
+  }
   // address of input pixel feeding output (n,ho,wo) through tap (r,s); returns false when the tap is padding
   __device__ __forceinline__ bool tap(int n, int ho, int wo, int r, int s, const T*& p) const {
     int h, w;
@@ -122,13 +153,13 @@ template <typename T> struct PixGeom {
     }
     if (h < 0 || h >= Hin || w < 0 || w >= Win) return false;
     if (flags & SG_PIX_UPSAMPLE) { h >>= 1; w >>= 1; }
-    p = x + (((long long)n * Hs + h) * Ws + w) * ldx;
+    p = x + (unsigned)(((unsigned)(n * Hs + h) * (unsigned)Ws + (unsigned)w) * (unsigned)ldx);  // host checks the tensor has < 2^31 elements
     return true;
   }
 };
 
 // pixel-side operand of forward / data-gradient convolution: row = output pixel, k = (r,s,c)
-template <typename T> struct ConvPixKC {
+template <typename T, bool FAST = false> struct ConvPixKC {
   static constexpr bool KC = true;
   static constexpr int VEC = ET<T>::VEC, BK = ET<T>::BK;
   PixGeom<T> g; int rows; int K;
@@ -149,12 +180,14 @@ template <typename T> struct ConvPixKC {
   }
   __device__ __forceinline__ u32x4 load(const Chunk& ch) const {
     u32x4 v = zero16();
-    if (!ch.valid || ch.r >= g.R) return v;
-    if (g.vec_ok) {
-      const T* p;
-      if (!g.tap(ch.n, ch.ho, ch.wo, ch.r, ch.s, p)) return v;
-      v = *(const u32x4*)(p + ch.c);
-    } else {
+    if (FAST || g.vec_ok) {
+      bool ok;
+      const unsigned off = g.tap_off(ch.n, ch.ho, ch.wo, ch.r, ch.s, ok);
+      ok = ok & ch.valid & (ch.r < g.R);
+      const u32x4 t = *(const u32x4*)(g.x + (ok ? off + (unsigned)ch.c : 0u));   // unconditional load, select after
+      v = ok ? t : v;
+    } else if constexpr (!FAST) {
+      if (!ch.valid || ch.r >= g.R) return v;
       int r = ch.r, s = ch.s, c = ch.c;
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
@@ -177,7 +210,7 @@ template <typename T> struct ConvPixKC {
 // activation operand of weight-gradient convolution: row = (r,s,c) flattened, k = output pixel (n,ho,wo).
 // With R=S=1 it is also the loader for the output-gradient operand (row = cout), including the
 // "gradient of a fused 2x2 pooling" view (SG_PIX_UPSAMPLE).
-template <typename T> struct ConvPixMC {
+template <typename T, bool FAST = false> struct ConvPixMC {
   static constexpr bool KC = false;
   static constexpr int VEC = ET<T>::VEC, BK = ET<T>::BK;
   PixGeom<T> g; int rows; int K;  // rows = R*S*C, K = N*Ho*Wo
@@ -190,14 +223,18 @@ template <typename T> struct ConvPixMC {
   }
   __device__ __forceinline__ u32x4 load(const Chunk& ch) const {
     u32x4 v = zero16();
-    if (!ch.valid || ch.pix >= K) return v;
     int n, ho, wo;
-    g.pix_decompose(ch.pix, n, ho, wo);
-    if (g.vec_ok) {
-      const T* p;
-      if (!g.tap(n, ho, wo, ch.r, ch.s, p)) return v;
-      v = *(const u32x4*)(p + ch.c);
-    } else {
+    if (FAST || g.vec_ok) {
+      const bool inb = ch.valid & (ch.pix < K);
+      g.pix_decompose(inb ? ch.pix : 0, n, ho, wo);
+      bool ok;
+      const unsigned off = g.tap_off(n, ho, wo, ch.r, ch.s, ok);
+      ok = ok & inb;
+      const u32x4 t = *(const u32x4*)(g.x + (ok ? off + (unsigned)ch.c : 0u));   // unconditional load, select after
+      v = ok ? t : v;
+    } else if constexpr (!FAST) {
+      if (!ch.valid || ch.pix >= K) return v;
+      g.pix_decompose(ch.pix, n, ho, wo);
       int r = ch.r, s = ch.s, c = ch.c;
 #pragma unroll
       for (int e = 0; e < VEC; e++) {
@@ -230,6 +267,7 @@ template <typename T> struct Epilogue {
   const T* mask; long long mask_bstride; int ldm;
   float alpha; const float* alpha_ptr;
   int flags; int I; int J;
+  long long split_stride;  // != 0: k-split s writes its partial tile to out + s*split_stride (two-stage split-K)
 
   __device__ __forceinline__ void set_batch(int b) {
     if (flags & (SG_EPI_OUT_F32 | SG_EPI_ATOMIC)) out = (float*)out + (long long)b * out_bstride;
@@ -388,6 +426,7 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(LP lp, LQ lq, Epilogue<T> 
   const int k_begin = blockIdx.y * klen;
   const int k_end = (k_begin + klen < K) ? (k_begin + klen) : K;
   if (gridDim.z > 1) { lp.set_batch(blockIdx.z); lq.set_batch(blockIdx.z); epi.set_batch(blockIdx.z); }
+  if (epi.split_stride) epi.out = (float*)epi.out + (long long)blockIdx.y * epi.split_stride;
 
   typename LP::Chunk pc[NP];
   typename LQ::Chunk qc[NQ];

@@ -68,6 +68,12 @@ def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, 
     d.x, d.dy, d.dw = L.ptr(x), L.ptr(dy), dw_ptr
     d.alpha_ptr = L.ptr(alpha_ptr)
     d.splits, d.no_tr = splits, no_tr
+    sp, wf = L.C.c_int(0), L.C.c_longlong(0)
+    L.call("sg_conv2d_wgrad_plan", d, L.C.byref(sp), L.C.byref(wf))
+    work = None
+    if wf.value > 0:
+        work = torch.empty(wf.value, dtype=torch.float32, device=x.device)   # scratch of the deterministic two-stage split-K
+        d.splits, d.work, d.work_floats = sp.value, work.data_ptr(), wf.value
     L.call("sg_conv2d_wgrad", d, L.stream())
 
 
