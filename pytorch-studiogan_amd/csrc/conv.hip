@@ -1,7 +1,9 @@
 // conv.hip -- convolution forward / data-gradient / weight-gradient as implicit GEMM on the MFMA engine
 // (gemm_core.h). Replaces nn.Conv2d + autograd's convolution_backward on the StudioGAN hot path
 // (reference src/utils/ops.py:165-173,195-204; call sites models/big_resnet.py:28-42,177-242).
+#include <stdlib.h>
 #include "gemm_core.h"
+#include "conv_v2.h"
 #include "../../include/sgamd.h"
 
 static inline int ilog2_exact(int v) {
@@ -38,6 +40,40 @@ static void conv_fwd_launch(const sg_conv_fwd_desc* d, const Epilogue<T>& e, int
   else sg_launch_gemm<T, LP, LQ, 128, 128, 2, 2>(lp, lq, e, I, J, K, 1, 1, st);
 }
 
+// second-generation kernel (conv_v2.h) for the hot bf16 shapes; returns false when the problem is not eligible
+template <typename T> static bool conv_fwd_v2_try(const sg_conv_fwd_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
+  // SG_CONV_V2=0 disables the kernel, =force skips the "enough tiles to fill the chip" heuristic (used by the tests)
+  const char* mode = getenv("SG_CONV_V2");
+  const bool disabled = mode && mode[0] == '0';
+  const bool force = mode && mode[0] == 'f';
+  if (disabled || d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
+  if (d->C % 8 || d->ldx % 8 || d->C < 64 || d->R * d->S > 32 || J < 256) return false;
+  if (!aligned16(d->x) || !aligned16(d->w)) return false;
+  const int tj = (J + 255) / 256;
+  const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile spills with hipcc 7.2: left out)
+  int best = 0, best_tiles = 0;
+  for (int c = 0; c < 3; c++) {
+    if (I % cands[c]) continue;
+    const int tiles = (I / cands[c]) * tj;
+    if (tiles >= 512) { best = cands[c]; best_tiles = tiles; break; }
+    if (tiles > best_tiles) { best = cands[c]; best_tiles = tiles; }
+  }
+  if (!best || (best_tiles < 160 && !force)) return false;
+  ConvV2Params p;
+  p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;
+  p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.C = d->C; p.ldx = d->ldx;
+  const int up = (pflags & SG_PIX_UPSAMPLE) ? 2 : 1;
+  p.Hin = d->Hs * up; p.Win = d->Ws * up; p.Ho = d->Ho; p.Wo = d->Wo;
+  p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags;
+  p.I = I; p.J = J; p.K = K; p.cpt = d->C / 8; p.ntap = d->R * d->S;
+  int rc = 0;
+  if (best == 192) rc = sg_launch_conv_v2<192, 4, 2>(p, e, st);
+  else if (best == 128) rc = sg_launch_conv_v2<128, 4, 2>(p, e, st);
+  else rc = sg_launch_conv_v2<96, 8, 1>(p, e, st);
+  return rc == 0;
+}
+
 template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream_t st) {
   const int K = d->R * d->S * d->C;
   const int I = d->Cout;
@@ -60,7 +96,8 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
-  if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
+  if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}
+  else if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
   else conv_fwd_launch<T, false>(d, e, I, J, K, pflags, st);
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();

@@ -1,0 +1,196 @@
+// conv_v2.h -- second-generation forward / data-gradient convolution kernel for the hot bf16 shapes.
+//
+// Same contraction and the same epilogue as gemm_core.h (OUT[pixel j][cout i] = sum_k W(i,k) X(j,k)), restructured
+// along cdna_hip_programming.md §5 ("256-wide tile, BK=64, LDS-DMA staging, two LDS buffers"):
+//   * 512 threads = 8 waves (2 per SIMD), pixel tile BJ = 256, cout tile BI in {96,128,192,256}, BK = 64 (128-byte rows)
+//   * global -> LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write): one instruction moves 8 rows x 128 B.
+//     The LDS image is lane-linear, so the bank-conflict swizzle is applied to the SOURCE address: lane (row, slot)
+//     fetches logical 16-byte chunk  slot ^ ((row >> 1) & 7); fragment reads apply the same involution
+//     (guide §5.4 rule 21). Conflict-free for the 16-lane service groups of ds_read_b128.
+//   * convolution halo / k-tail / row-tail: the lane's source pointer is redirected to a 16-byte zero page
+//   * the (tap, channel-chunk) position of a lane is advanced incrementally (no division in the k-loop); the
+//     per-row halo test is a precomputed bit mask
+//   * next k-tile's DMA is issued before the current tile's MFMAs; one barrier per k-tile.
+#pragma once
+#include "gemm_core.h"
+
+__device__ u32x4 sg_zero_page[4];
+
+struct ConvV2Params {
+  const bf16_t* x; const bf16_t* w;
+  int N, Hs, Ws, C, ldx;
+  int Hin, Win, Ho, Wo;
+  int R, S, pad_h, pad_w;
+  int flags;
+  int I, J, K;
+  int cpt;    // 16-byte chunks per tap = C / 8
+  int ntap;   // R * S
+};
+
+typedef __attribute__((address_space(1))) const void* sg_gptr_t;
+typedef __attribute__((address_space(3))) void* sg_lptr_t;
+
+template <int BI, int WJ, int WI>
+__global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int BJ = 256;
+  constexpr int QB = BJ * 128, PB = BI * 128, BUF = QB + PB;
+  constexpr int NQ = BJ / 64;                 // Q DMA instructions per wave per k-tile (8 rows each, 8 waves)
+  constexpr int NPI = (BI / 8 + 7) / 8;       // P DMA instructions per wave per k-tile (upper bound)
+  constexpr int TJ = BJ / WJ / 32, TI = BI / WI / 32;
+  static_assert(WJ * WI == 8, "8 waves");
+  static_assert(BJ % (WJ * 32) == 0 && BI % (WI * 32) == 0, "tile/wave mismatch");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = tilesI * tilesJ;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tI = bid % tilesI, tJ = bid / tilesI;
+  const int i0 = tI * BI, j0 = tJ * BJ;
+
+  // ---- per-lane DMA state ------------------------------------------------------------------------------
+  const int sub = lane >> 3;                                        // row within the 8-row DMA group
+  const int lc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical chunk this lane fetches (same for all its rows)
+  const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0;
+  unsigned qbase[NQ]; unsigned qmask[NQ]; int qpar[NQ];
+#pragma unroll
+  for (int i = 0; i < NQ; i++) {
+    const int row = j0 + 8 * (wave + 8 * i) + sub;
+    int n, ho, wo;
+    if (p.flags & SG_PIX_QUAD) {
+      const int q = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
+      const int Wq = p.Wo >> 1, Hq = p.Ho >> 1;
+      const int wq = q % Wq; const int t = q / Wq; const int hq = t % Hq; n = t / Hq;
+      ho = 2 * hq + dy; wo = 2 * wq + dx;
+    } else {
+      wo = row % p.Wo; const int t = row / p.Wo; ho = t % p.Ho; n = t / p.Ho;
+    }
+    unsigned m = 0;
+    if (row < p.J) {
+      for (int t = 0; t < p.ntap; t++) {
+        const int h = ho - p.pad_h + t / p.S, w = wo - p.pad_w + t % p.S;
+        if ((unsigned)h < (unsigned)p.Hin && (unsigned)w < (unsigned)p.Win) m |= 1u << t;
+      }
+    }
+    qmask[i] = m;
+    qpar[i] = up ? ((ho & 1) | ((wo & 1) << 1)) : 0;
+    const int hs = up ? (ho >> 1) : ho, ws = up ? (wo >> 1) : wo;
+    qbase[i] = ((unsigned)(n * p.Hs + hs) * (unsigned)p.Ws + (unsigned)ws) * (unsigned)p.ldx;
+  }
+  unsigned pbase[NPI]; bool pok[NPI];
+#pragma unroll
+  for (int i = 0; i < NPI; i++) {
+    const int g = wave + 8 * i;                 // DMA group index inside the P tile
+    const int row = i0 + 8 * g + sub;
+    pok[i] = (g < BI / 8) && (row < p.I);
+    pbase[i] = (unsigned)row * (unsigned)p.K;
+  }
+  // position of this lane inside K: tap (r,s) and chunk-in-tap c8; q = global chunk index
+  int tap = 0, tr = 0, ts = 0, c8 = lc, q = lc;
+
+  auto issue = [&](int buf) {
+    char* qd = smem + buf * BUF;
+    char* pd = qd + QB;
+    const bool tap_ok = tap < p.ntap;
+    const int dr = tr - p.pad_h, ds = ts - p.pad_w;
+    const unsigned coff = (unsigned)c8 * 8u;
+#pragma unroll
+    for (int i = 0; i < NQ; i++) {
+      int dh = dr, dw = ds;
+      if (up) { dh = ((qpar[i] & 1) + dr) >> 1; dw = ((qpar[i] >> 1) + ds) >> 1; }
+      const unsigned off = qbase[i] + (unsigned)((dh * p.Ws + dw) * p.ldx) + coff;
+      const bool ok = tap_ok && ((qmask[i] >> tap) & 1u);
+      const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
+      __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(qd + (wave + 8 * i) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < NPI; i++) {
+      if (wave + 8 * i < BI / 8) {              // wave-uniform
+        const bool ok = pok[i] && tap_ok;
+        const bf16_t* src = ok ? (p.w + pbase[i] + (unsigned)q * 8u) : (const bf16_t*)sg_zero_page;
+        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(pd + (wave + 8 * i) * 1024), 16, 0, 0);
+      }
+    }
+    // advance to the next k-tile: 8 chunks further
+    q += 8; c8 += 8;
+    if (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }
+  };
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; a++)
+#pragma unroll
+    for (int b = 0; b < TJ; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int wj = wave % WJ, wi = wave / WJ;
+  const int wj0 = wj * (BJ / WJ), wi0 = wi * (BI / WI);
+  const int frow = lane & 31, fhi = lane >> 5;
+  const bool relu = (p.flags & SG_PIX_RELU) != 0;
+
+  const int nk = (p.K / 8 + 7) / 8;   // k-tiles of 8 chunks
+  issue(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) issue((kt + 1) & 1);
+    const char* qs = smem + (kt & 1) * BUF;
+    const char* ps = qs + QB;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bf16x8_t pf[TI], qf[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; a++) {
+        const int row = wi0 + a * 32 + frow;
+        const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+        u32x4 v = *(const u32x4*)(ps + row * 128 + ch * 16);
+        pf[a] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        const int row = wj0 + b * 32 + frow;
+        const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+        u32x4 v = *(const u32x4*)(qs + row * 128 + ch * 16);
+        if (relu) v = relu16<bf16_t>(v);
+        qf[b] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int a = 0; a < TI; a++)
+#pragma unroll
+        for (int b = 0; b < TJ; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float al = epi.alpha;
+  if (epi.alpha_ptr) al *= *epi.alpha_ptr;
+#pragma unroll
+  for (int ta = 0; ta < TI; ta++)
+#pragma unroll
+    for (int tb = 0; tb < TJ; tb++) {
+      const int j = j0 + wj0 + tb * 32 + (lane & 31);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int ii = i0 + wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
+        float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
+        epi.store(j, ii, v, al);
+      }
+    }
+}
+
+template <int BI, int WJ, int WI>
+static inline int sg_launch_conv_v2(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  constexpr int BUF = (256 + BI) * 128;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + 255) / 256;
+  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI>), dim3(tilesI * tilesJ), dim3(512), 2 * BUF, st, p, e, tilesI, tilesJ);
+  return 0;
+}
