@@ -4,6 +4,7 @@
 #include <stdlib.h>
 #include "gemm_core.h"
 #include "conv_v2.h"
+#include "wgrad_v2.h"
 #include "../../include/sgamd.h"
 
 static inline int ilog2_exact(int v) {
@@ -115,8 +116,23 @@ extern "C" int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream) {
 }
 
 // tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)
-static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, int& BJ, int& splits) {
-  if (I <= 32) { BI = 32; BJ = 256; }
+static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
+  const char* mode = getenv("SG_CONV_V2");
+  if (mode && mode[0] == '0') return false;
+  const bool force = mode && mode[0] == 'f';
+  if (d->dtype != SG_DTYPE_BF16 || d->stride != 1 || d->no_tr) return false;
+  if ((d->x_flags | d->g_flags) & SG_PIX_TRANSPOSED) return false;
+  if (ilog2_exact(d->Ho) < 0 || ilog2_exact(d->Wo) < 0) return false;
+  if (d->C % 8 || d->ldx % 8 || d->Cout % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return false;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  const int I = d->R * d->S * d->C;
+  if (!force && (I < 256 || d->Cout < 64 || K < 4096)) return false;
+  return true;
+}
+
+static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, int& BJ, int& splits, bool v2 = false) {
+  if (v2) { BI = 256; BJ = 128; bk = 64; }
+  else if (I <= 32) { BI = 32; BJ = 256; }
   else if (J <= 32) { BI = 256; BJ = 32; }
   else if (J % 128 != 0 && (J % 96 == 0 || (J < 128 && J > 64))) { BI = 256; BJ = 96; }
   else { BI = 128; BJ = 128; }
@@ -139,7 +155,7 @@ extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, lo
   const int I = d->R * d->S * d->C, J = d->Cout;
   const long long K = (long long)d->N * d->Ho * d->Wo;
   int BI, BJ, sp;
-  wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp);
+  wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp, wgrad_v2_ok(d));
   *splits = sp;
   *work_floats = sp > 1 ? (long long)sp * I * J : 0;
   return 0;
@@ -170,6 +186,23 @@ static void conv_wgrad_launch(const sg_conv_wgrad_desc* d, const Epilogue<T>& e,
   else sg_launch_gemm<T, LM, LM, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, 1, st);
 }
 
+template <typename T> static bool wgrad_v2_launch(const sg_conv_wgrad_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool wgrad_v2_launch<bf16_t>(const sg_conv_wgrad_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int splits, hipStream_t st) {
+  WgradV2Params p;
+  p.x = (const bf16_t*)d->x; p.dy = (const bf16_t*)d->dy;
+  p.xHs = d->xHs; p.xWs = d->xWs; p.C = d->C; p.ldx = d->ldx;
+  p.x_up = (d->x_flags & SG_PIX_UPSAMPLE) ? 1 : 0; p.x_relu = (d->x_flags & SG_PIX_RELU) ? 1 : 0;
+  p.Hin = d->xHs * (p.x_up ? 2 : 1); p.Win = d->xWs * (p.x_up ? 2 : 1);
+  p.gHs = d->gHs; p.gWs = d->gWs; p.Cout = d->Cout; p.ldg = d->ldg; p.g_up = (d->g_flags & SG_PIX_UPSAMPLE) ? 1 : 0;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
+  p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.I = I; p.J = J; p.K = K;
+  int klen = K;
+  if (splits > 1) { klen = (K + splits - 1) / splits; klen = ((klen + 63) / 64) * 64; splits = (K + klen - 1) / klen; }
+  p.klen = klen;
+  return sg_launch_wgrad_v2(p, e, splits, st) == 0;
+}
+
 template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc* d, hipStream_t st) {
   const int I = d->R * d->S * d->C;
   const int J = d->Cout;
@@ -179,7 +212,8 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
            "sg_conv2d_wgrad: tensor too large for 32-bit element offsets");
   const int K = (int)Kll;
   int BI, BJ, splits;
-  wgrad_plan(I, J, K, ET<T>::BK, d->splits, BI, BJ, splits);
+  const bool v2 = wgrad_v2_ok(d);
+  wgrad_plan(I, J, K, ET<T>::BK, d->splits, BI, BJ, splits, v2);
   const long long n = (long long)I * J;
   const bool two_stage = splits > 1 && d->work && d->work_floats >= (long long)splits * n;
   Epilogue<T> e;
@@ -192,7 +226,8 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
   const bool fast = (d->C % ET<T>::VEC == 0) && (d->ldx % ET<T>::VEC == 0) && aligned16(d->x) &&
                     (d->Cout % ET<T>::VEC == 0) && (d->ldg % ET<T>::VEC == 0) && aligned16(d->dy);
-  if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
+  if (v2 && wgrad_v2_launch<T>(d, e, I, J, K, splits, st)) {}
+  else if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
   else conv_wgrad_launch<T, TR, false>(d, e, I, J, K, BI, BJ, splits, st);
   if (two_stage) {
     long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;

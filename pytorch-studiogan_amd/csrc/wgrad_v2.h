@@ -1,0 +1,173 @@
+// wgrad_v2.h -- second-generation weight-gradient kernel for the hot bf16 shapes.
+//
+//   dW[co][(tap,ci)] (+)= alpha * sum_pix dy'[pix][co] * x'[pix + tap][ci]
+//
+// Same contraction/epilogue as gemm_core.h's ConvPixMC x ConvPixMC path, restructured like conv_v2.h:
+//   * 512 threads = 8 waves, tile = 256 (tap,ci) rows x 128 couts, BK = 64 pixels, two LDS buffers filled by
+//     global_load_lds_dwordx4 (one instruction = 4 pixels x 128 channels = 1 KiB); 4(I) x 2(J) waves, 64x64 per wave
+//   * both operands have the reduction index (pixel) as the slow memory index -> LDS image [pixel][channel] read with
+//     ds_read_b64_tr_b16. The 4 pixel-rows one transpose-read touches must sit on 4 disjoint 16-bank windows; with a
+//     lane-linear DMA image this is done on the SOURCE side: lane (pixel p, slot s) fetches channel chunk s ^ 4*(p&3)
+//     and the fragment read applies the same involution (conflict-free, MI355X_MICROARCH.md §LDS)
+//   * a lane's (tap, channel) is fixed for the whole k-loop; per k-tile it decomposes TWO pixel indices (shifts) and
+//     derives six source addresses; halo / tails go to the zero page
+#pragma once
+#include "gemm_core.h"
+#include "conv_v2.h"
+
+struct WgradV2Params {
+  const bf16_t* x; const bf16_t* dy;
+  int xHs, xWs, C, ldx, x_up, x_relu, Hin, Win;
+  int gHs, gWs, Cout, ldg, g_up;
+  int Ho, Wo, wshift, hshift;
+  int R, S, pad_h, pad_w;
+  int I, J, K, klen;
+};
+
+__device__ __forceinline__ bf16x8_t sg_frag_tr_swz(const char* img, int col0, int ks) {
+  // img: [64 pixels][128 channels] bf16 (256-byte rows), swizzled slots. Returns the MFMA fragment
+  // {pixel = ks*16 + 8*(l>>5) + 0..7} x {channel col0 + (l&31)}.
+  const int l = threadIdx.x & 63;
+  const int g16 = l >> 4, t = l & 15;
+  const int prow = ks * 16 + 8 * (g16 >> 1) + (t >> 2);
+  const int col16 = col0 + 16 * (g16 & 1);
+  const int slot = ((col16 >> 3) + ((t & 3) >> 1)) ^ (4 * (t >> 2));
+  const char* p = img + prow * 256 + slot * 16 + 8 * (t & 1);
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)p);
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(p + 4 * 256));
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+__global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int IMG = 64 * 256;              // one [64][128] bf16 image
+  constexpr int BUF = 3 * IMG;               // P sub-image 0, P sub-image 1, Q
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int nt = tilesI * tilesJ;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tI = bid % tilesI, tJ = bid / tilesI;
+  const int i0 = tI * 256, j0 = tJ * 128;
+  const int k_begin = blockIdx.y * p.klen;
+  const int k_end = (k_begin + p.klen < p.K) ? (k_begin + p.klen) : p.K;
+  if (epi.split_stride) epi.out = (float*)epi.out + (long long)blockIdx.y * epi.split_stride;
+
+  // ---- per-lane DMA state (fixed over the k-loop) ---------------------------------------------------------
+  const int lrow = lane >> 4;                                    // pixel row inside a 4-pixel DMA group
+  const int lc = (lane & 15) ^ (4 * (lrow & 3));                 // logical 8-channel chunk this lane fetches
+  int pr[2], ps[2]; unsigned pc[2]; bool pv[2];
+#pragma unroll
+  for (int h = 0; h < 2; h++) {
+    const int irow = i0 + 128 * h + 8 * lc;
+    pv[h] = irow < p.I;
+    const int tap = irow / p.C;
+    pc[h] = (unsigned)(irow - tap * p.C);
+    pr[h] = tap / p.S - p.pad_h;
+    ps[h] = tap % p.S - p.pad_w;
+  }
+  const int qcol = j0 + 8 * lc;
+  const bool qv = qcol < p.J;
+
+  auto issue = [&](int buf, int kt) {
+    char* base = smem + buf * BUF;
+#pragma unroll
+    for (int e = 0; e < 2; e++) {
+      const int pg = wave + 8 * e;                               // pixel group (4 pixels) inside the 64-pixel tile
+      const int pix = k_begin + kt * 64 + 4 * pg + lrow;
+      const bool inb = pix < k_end;
+      const int pp = inb ? pix : 0;
+      const int wo = pp & (p.Wo - 1);
+      const int t = pp >> p.wshift;
+      const int ho = t & (p.Ho - 1);
+      const int n = t >> p.hshift;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        int hh = ho + pr[h], ww = wo + ps[h];
+        const bool ok = inb & pv[h] & ((unsigned)hh < (unsigned)p.Hin) & ((unsigned)ww < (unsigned)p.Win);
+        if (p.x_up) { hh >>= 1; ww >>= 1; }
+        const unsigned off = ((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + pc[h];
+        const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
+        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + h * IMG + pg * 1024), 16, 0, 0);
+      }
+      {
+        const int hg = p.g_up ? (ho >> 1) : ho, wg = p.g_up ? (wo >> 1) : wo;
+        const unsigned off = ((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol;
+        const bf16_t* src = (inb & qv) ? (p.dy + off) : (const bf16_t*)sg_zero_page;
+        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + 2 * IMG + pg * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; a++)
+#pragma unroll
+    for (int b = 0; b < 2; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int wi = wave & 3, wj = wave >> 2;
+  const int nk = (k_end - k_begin + 63) / 64;
+  issue(0, 0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; kt++) {
+    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+    const char* base = smem + (kt & 1) * BUF;
+    const char* pimg = base + (wi >> 1) * IMG;
+    const char* qimg = base + 2 * IMG;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++) {
+      bf16x8_t pf[2], qf[2];
+#pragma unroll
+      for (int a = 0; a < 2; a++) {
+        pf[a] = sg_frag_tr_swz(pimg, 64 * (wi & 1) + 32 * a, ks);
+        if (p.x_relu) {
+          u32x4 v = __builtin_bit_cast(u32x4, pf[a]);
+          v = relu16<bf16_t>(v);
+          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      }
+#pragma unroll
+      for (int b = 0; b < 2; b++) qf[b] = sg_frag_tr_swz(qimg, 64 * wj + 32 * b, ks);
+#pragma unroll
+      for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int b = 0; b < 2; b++)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+
+  float al = epi.alpha;
+  if (epi.alpha_ptr) al *= *epi.alpha_ptr;
+#pragma unroll
+  for (int ta = 0; ta < 2; ta++)
+#pragma unroll
+    for (int tb = 0; tb < 2; tb++) {
+      const int j = j0 + 64 * wj + tb * 32 + (lane & 31);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int ii = i0 + 64 * wi + ta * 32 + 8 * g4 + 4 * (lane >> 5);
+        float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
+        epi.store(j, ii, v, al);
+      }
+    }
+}
+
+static inline int sg_launch_wgrad_v2(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
+  constexpr int LDS = 2 * 3 * 64 * 256;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  const int tilesI = (p.I + 255) / 256, tilesJ = (p.J + 127) / 128;
+  hipLaunchKernelGGL(sg_wgrad_v2_kernel, dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
+  return 0;
+}

@@ -66,3 +66,44 @@ def test_conv_v2_matches_reference_and_v1(sg, case):
         torch.cuda.synchronize()
         os.environ.pop("SG_CONV_V2", None)
         check(f"conv v2 dgrad {case}", nchw(dx.float().cpu()), xr.grad, 4e-3)
+
+
+WG_CASES = [
+    # N, Cin, Cout, H, R, relu, up, pool
+    (2, 64, 96, 16, 3, False, False, False),
+    (2, 96, 96, 16, 3, True, False, True),
+    (2, 96, 192, 16, 3, False, True, False),
+    (1, 128, 128, 16, 3, True, True, True),
+    (2, 192, 384, 16, 1, False, False, False),
+    (3, 72, 200, 8, 3, True, False, False),       # partial I tile (648 rows), partial J tile, k tail
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad_v2_matches_reference_and_v1(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, R, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    pad = R // 2
+    x = rnd((N, Cin, H, H), dt, 81)
+    w = rnd((Cout, Cin, R, R), dt, 82, 0.1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    y = _conv_ref(xr, wr, 1, pad, relu, up, pool, None, None)
+    gy = rnd(tuple(y.shape), dt, 83)
+    y.backward(gy.double())
+    Ho = H * (2 if up else 1)
+    xd, gyd = nhwc(x).to(d), nhwc(gy).to(d)
+    xf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    gf = L.PIX_UPSAMPLE if pool else 0
+    outs = {}
+    for mode in ("force", "0"):
+        os.environ["SG_CONV_V2"] = mode
+        for splits in (0, 3):
+            dw = torch.zeros((Cout, R, R, Cin), dtype=torch.float32, device=d)
+            F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, splits=splits)
+            torch.cuda.synchronize()
+            outs[(mode, splits)] = dw.cpu()
+            check(f"wgrad {mode} splits={splits} {case}", dw.cpu().permute(0, 3, 1, 2), wr.grad, 2e-3)
+    os.environ.pop("SG_CONV_V2", None)
+    check(f"wgrad v2 vs v1 {case}", outs[("force", 0)], outs[("0", 0)], 1e-4)
