@@ -156,9 +156,29 @@ template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows(cons
   const float inv = 1.f / sum;
   for (int c = threadIdx.x; c < cols; c += 256) out[c] = from_f<T>(__expf(row[c] - m) * inv);
 }
+// single-pass variant for rows of exactly 1024 logits (the 64x64 attention of the 128-px models): each thread keeps
+// its 4 logits in registers -> one 16-byte load and one 8/16-byte store per thread, 6 B/logit of HBM traffic
+template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows_1024(const float* s, T* p) {
+  __shared__ float sm[4];
+  const f32x4 v = ((const f32x4*)(s + (long long)blockIdx.x * 1024))[threadIdx.x];
+  float m = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
+  m = block_max_256(m, sm);
+  float e[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) e[i] = __expf(v[i] - m);
+  const float sum = block_sum_256(e[0] + e[1] + e[2] + e[3], sm);
+  const float inv = 1.f / sum;
+  T* o = p + (long long)blockIdx.x * 1024 + threadIdx.x * 4;
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = from_f<T>(e[i] * inv);
+}
 extern "C" int sg_softmax_rows(int dtype, const float* s_in, void* p_out, long long rows, int cols, sg_stream_t st) {
   SG_CHECK(s_in && p_out && rows > 0 && rows < (1ll << 31) && cols > 0, "sg_softmax_rows: bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, s_in, (T*)p_out, cols));
+  if (cols == 1024 && ((((uintptr_t)s_in) | ((uintptr_t)p_out)) & 15) == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows_1024<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, s_in, (T*)p_out));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, s_in, (T*)p_out, cols));
+  }
   SG_LAUNCH_CHECK();
   return 0;
 }
@@ -172,9 +192,25 @@ template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows_bwd(
   dot = block_sum_256(dot, sm);
   for (int c = threadIdx.x; c < cols; c += 256) out[c] = from_f<T>(to_f<T>(pr[c]) * (dr[c] - dot));
 }
+template <typename T> __global__ __launch_bounds__(256) void k_softmax_rows_bwd_1024(const T* p, const float* dp, T* ds) {
+  __shared__ float sm[4];
+  const long long base = (long long)blockIdx.x * 1024 + threadIdx.x * 4;
+  const f32x4 g = *(const f32x4*)(dp + base);
+  float pv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) pv[i] = to_f<T>(p[base + i]);
+  float dot = pv[0] * g[0] + pv[1] * g[1] + pv[2] * g[2] + pv[3] * g[3];
+  dot = block_sum_256(dot, sm);
+#pragma unroll
+  for (int i = 0; i < 4; i++) ds[base + i] = from_f<T>(pv[i] * (g[i] - dot));
+}
 extern "C" int sg_softmax_rows_bwd(int dtype, const void* p, const float* dp, void* ds, long long rows, int cols, sg_stream_t st) {
   SG_CHECK(p && dp && ds && rows > 0 && rows < (1ll << 31) && cols > 0, "sg_softmax_rows_bwd: bad args");
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows_bwd<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, (const T*)p, dp, (T*)ds, cols));
+  if (cols == 1024 && (((uintptr_t)dp) & 15) == 0) {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows_bwd_1024<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, (const T*)p, dp, (T*)ds));
+  } else {
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_softmax_rows_bwd<T>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)st, (const T*)p, dp, (T*)ds, cols));
+  }
   SG_LAUNCH_CHECK();
   return 0;
 }
