@@ -219,6 +219,8 @@ int sg_quantize_resize_normalize(int dtype, const float* x, void* out, uint8_t* 
 int sg_pool2d(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int mode, int ldy, int c_off, sg_stream_t s);
 /* global average pool [N,HW,C] -> fp32 [N,C] */
 int sg_global_avgpool(int dtype, const void* x, float* y, int N, int HW, int C, sg_stream_t s);
+/* hits[n] = 1 iff the true class is within the top k of scores[n][0..ncls) with sklearn's tie rule (higher index wins a tie) */
+int sg_topk_hits(const float* scores, int ld, int ncls, const int64_t* labels, int k, int N, uint8_t* hits, sg_stream_t s);
 /* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
 int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
 

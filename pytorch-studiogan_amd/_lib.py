@@ -114,6 +114,7 @@ _PROTOS = {
     "sg_pool2d": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
+    "sg_topk_hits": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
 }
 
 

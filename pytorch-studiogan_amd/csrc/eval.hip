@@ -125,3 +125,29 @@ extern "C" int sg_feat_moments_accumulate(const float* f, int n, int C, double* 
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// top-k hit test with sklearn.metrics.top_k_accuracy_score's tie rule (stable ascending argsort, reversed: among equal
+// scores the HIGHER class index ranks first). One wave per sample. hits[n] = 1 iff fewer than k classes beat the true one.
+// (reference src/metrics/ins.py:62-76 runs this on the host through sklearn)
+__global__ __launch_bounds__(256) void k_topk_hits(const float* scores, int ld, int ncls, const int64_t* labels, int k, int N, uint8_t* hits) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int lane = threadIdx.x & 63;
+  const float* s = scores + (long long)n * ld;
+  const int t = (int)labels[n];
+  const float st = (t >= 0 && t < ncls) ? s[t] : INFINITY;
+  int beat = 0;
+  for (int c = lane; c < ncls; c += 64) {
+    const float v = s[c];
+    beat += (v > st) || (v == st && c > t);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) beat += __shfl_xor(beat, o, 64);
+  if (lane == 0) hits[n] = (t >= 0 && t < ncls && beat < k) ? 1 : 0;
+}
+extern "C" int sg_topk_hits(const float* scores, int ld, int ncls, const int64_t* labels, int k, int N, uint8_t* hits, sg_stream_t s) {
+  SG_CHECK(scores && labels && hits && N > 0 && ncls > 0 && k > 0, "sg_topk_hits: bad args");
+  hipLaunchKernelGGL(k_topk_hits, dim3((N + 3) / 4), dim3(256), 0, (hipStream_t)s, scores, ld, ncls, labels, k, N, hits);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

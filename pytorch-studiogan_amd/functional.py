@@ -19,7 +19,7 @@ def _c(t):
 # raw launch helpers (also used directly by the kernel-level tests)
 # ---------------------------------------------------------------------------------------------------------
 def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None,
-               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None):
+               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0):
     """x: [N,Hs,Ws,ldx] NHWC; returns [N,Ho',Wo',Cout]. w_ptr -> [Cout][R*S*Cin] in x.dtype."""
     N, Hs, Ws = x.shape[0], x.shape[1], x.shape[2]
     ldx = x.shape[3] if ldx is None else ldx
@@ -46,7 +46,7 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
     d.bias = L.ptr(bias)
     d.res = L.ptr(res)
     d.mask = L.ptr(mask)
-    d.out = L.ptr(out)
+    d.out = L.ptr(out) + out_coff * out.element_size()   # out_coff: write into a channel slice of a wider (concat) tensor
     d.alpha_ptr = L.ptr(alpha_ptr)
     d.ldo = out.shape[-1]
     d.ldr = res.shape[-1] if res is not None else 0

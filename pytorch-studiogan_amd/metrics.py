@@ -1,0 +1,307 @@
+"""FID / IS feature-extraction path on the GPU, mirroring the reference's evaluation interfaces:
+
+  LoadEvalModel(...).get_outputs(x, quantize)           reference src/metrics/preparation.py:43-122
+  generate_images_and_stack_features(...)               reference src/metrics/features.py:17-65
+  calculate_moments / frechet_inception_distance        reference src/metrics/fid.py:34-98
+  calculate_kl_div / top-k accuracy                     reference src/metrics/ins.py:28-79
+
+What changes underneath: the per-batch GPU->CPU->per-image-resize->GPU round trip (reference src/utils/ops.py:251-263) is
+ONE kernel (`sg_quantize_resize_normalize`: bit-exact uint8 quantisation, bilinear align_corners=False, normalise,
+NHWC); InceptionV3 runs as 94 fused conv+foldedBN+ReLU launches writing straight into the concat buffers (no cat
+copies), pools and the fc on libsgamd.so; FID moments are accumulated on the device in fp64 instead of gathering
+50k x 2048 features to the host. The matrix square root stays on the host in fp64 like the reference.
+"""
+import math
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from . import functional as F
+
+BN_EPS = 1e-3
+
+
+def _spec():
+    def A(p, c, pf):
+        return [(p + ".branch1x1", c, 64, 1, 1, 1, 0, 0), (p + ".branch5x5_1", c, 48, 1, 1, 1, 0, 0), (p + ".branch5x5_2", 48, 64, 5, 5, 1, 2, 2),
+                (p + ".branch3x3dbl_1", c, 64, 1, 1, 1, 0, 0), (p + ".branch3x3dbl_2", 64, 96, 3, 3, 1, 1, 1), (p + ".branch3x3dbl_3", 96, 96, 3, 3, 1, 1, 1),
+                (p + ".branch_pool", c, pf, 1, 1, 1, 0, 0)]
+
+    def B(p, c):
+        return [(p + ".branch3x3", c, 384, 3, 3, 2, 0, 0), (p + ".branch3x3dbl_1", c, 64, 1, 1, 1, 0, 0), (p + ".branch3x3dbl_2", 64, 96, 3, 3, 1, 1, 1),
+                (p + ".branch3x3dbl_3", 96, 96, 3, 3, 2, 0, 0)]
+
+    def Cb(p, c, c7):
+        return [(p + ".branch1x1", c, 192, 1, 1, 1, 0, 0), (p + ".branch7x7_1", c, c7, 1, 1, 1, 0, 0), (p + ".branch7x7_2", c7, c7, 1, 7, 1, 0, 3),
+                (p + ".branch7x7_3", c7, 192, 7, 1, 1, 3, 0), (p + ".branch7x7dbl_1", c, c7, 1, 1, 1, 0, 0), (p + ".branch7x7dbl_2", c7, c7, 7, 1, 1, 3, 0),
+                (p + ".branch7x7dbl_3", c7, c7, 1, 7, 1, 0, 3), (p + ".branch7x7dbl_4", c7, c7, 7, 1, 1, 3, 0), (p + ".branch7x7dbl_5", c7, 192, 1, 7, 1, 0, 3),
+                (p + ".branch_pool", c, 192, 1, 1, 1, 0, 0)]
+
+    def D(p, c):
+        return [(p + ".branch3x3_1", c, 192, 1, 1, 1, 0, 0), (p + ".branch3x3_2", 192, 320, 3, 3, 2, 0, 0), (p + ".branch7x7x3_1", c, 192, 1, 1, 1, 0, 0),
+                (p + ".branch7x7x3_2", 192, 192, 1, 7, 1, 0, 3), (p + ".branch7x7x3_3", 192, 192, 7, 1, 1, 3, 0), (p + ".branch7x7x3_4", 192, 192, 3, 3, 2, 0, 0)]
+
+    def E(p, c):
+        return [(p + ".branch1x1", c, 320, 1, 1, 1, 0, 0), (p + ".branch3x3_1", c, 384, 1, 1, 1, 0, 0), (p + ".branch3x3_2a", 384, 384, 1, 3, 1, 0, 1),
+                (p + ".branch3x3_2b", 384, 384, 3, 1, 1, 1, 0), (p + ".branch3x3dbl_1", c, 448, 1, 1, 1, 0, 0), (p + ".branch3x3dbl_2", 448, 384, 3, 3, 1, 1, 1),
+                (p + ".branch3x3dbl_3a", 384, 384, 1, 3, 1, 0, 1), (p + ".branch3x3dbl_3b", 384, 384, 3, 1, 1, 1, 0), (p + ".branch_pool", c, 192, 1, 1, 1, 0, 0)]
+    stem = [("Conv2d_1a_3x3", 3, 32, 3, 3, 2, 0, 0), ("Conv2d_2a_3x3", 32, 32, 3, 3, 1, 0, 0), ("Conv2d_2b_3x3", 32, 64, 3, 3, 1, 1, 1),
+            ("Conv2d_3b_1x1", 64, 80, 1, 1, 1, 0, 0), ("Conv2d_4a_3x3", 80, 192, 3, 3, 1, 0, 0)]
+    layers = (stem + A("Mixed_5b", 192, 32) + A("Mixed_5c", 256, 64) + A("Mixed_5d", 288, 64) + B("Mixed_6a", 288) + Cb("Mixed_6b", 768, 128) +
+              Cb("Mixed_6c", 768, 160) + Cb("Mixed_6d", 768, 160) + Cb("Mixed_6e", 768, 192) + D("Mixed_7a", 768) + E("Mixed_7b", 1280) + E("Mixed_7c", 2048))
+    return {l[0]: l for l in layers}
+
+
+SPEC = _spec()
+
+
+class InceptionV3:
+    """FID InceptionV3 (torchvision structure + the reference's FID patches, src/metrics/inception_net.py:135-249),
+    inference only, BN folded into the convolutions at load time. `state_dict` uses torchvision's key names, i.e. the
+    reference's `pt_inception-2015-12-05-6726825d.pth` loads as is."""
+
+    def __init__(self, state_dict, device, dtype=torch.float32):
+        self.device, self.dtype = device, dtype
+        self.w, self.b = {}, {}
+        with torch.no_grad():
+            for name, (_, cin, cout, kh, kw, stride, ph, pw) in SPEC.items():
+                w = state_dict[name + ".conv.weight"].to(device=device, dtype=torch.float32)
+                assert tuple(w.shape) == (cout, cin, kh, kw), f"{name}: weight shape {tuple(w.shape)}"
+                g, be = state_dict[name + ".bn.weight"].to(device).float(), state_dict[name + ".bn.bias"].to(device).float()
+                mu, var = state_dict[name + ".bn.running_mean"].to(device).float(), state_dict[name + ".bn.running_var"].to(device).float()
+                scale = g / torch.sqrt(var + BN_EPS)
+                self.w[name] = (w * scale.view(-1, 1, 1, 1)).permute(0, 2, 3, 1).contiguous().to(dtype)   # [Cout][R][S][Cin]
+                self.b[name] = (be - mu * scale).contiguous()
+            self.fc_w = state_dict["fc.weight"].to(device=device, dtype=torch.float32).contiguous()
+            self.fc_b = state_dict["fc.bias"].to(device=device, dtype=torch.float32).contiguous()
+
+    # -- building blocks ---------------------------------------------------------------------------------------
+    def _bc(self, x, name, out=None, coff=0):
+        _, cin, cout, kh, kw, stride, ph, pw = SPEC[name]
+        return F.conv2d_raw(x, self.w[name].data_ptr(), cin, cout, kh, kw, stride, ph, pw, 0, L.EPI_RELU, bias=self.b[name], out=out, out_coff=coff)
+
+    def _pool(self, x, k, stride, pad, mode, out=None, coff=0):
+        N, H, W, Cc = x.shape
+        OH, OW = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+        if out is None:
+            out = torch.empty((N, OH, OW, Cc), dtype=x.dtype, device=x.device)
+        L.call("sg_pool2d", L.dt(x), L.ptr(x), L.ptr(out), N, H, W, Cc, k, stride, pad, mode, out.shape[-1], coff, L.stream())
+        return out
+
+    def _cat(self, x, ch, stride=1):
+        N, H, W, _ = x.shape
+        if stride == 2:
+            H, W = (H - 3) // 2 + 1, (W - 3) // 2 + 1
+        return torch.empty((N, H, W, ch), dtype=x.dtype, device=x.device)
+
+    def _A(self, x, p, pf):
+        o = self._cat(x, 64 + 64 + 96 + pf)
+        self._bc(x, p + ".branch1x1", o, 0)
+        self._bc(self._bc(x, p + ".branch5x5_1"), p + ".branch5x5_2", o, 64)
+        self._bc(self._bc(self._bc(x, p + ".branch3x3dbl_1"), p + ".branch3x3dbl_2"), p + ".branch3x3dbl_3", o, 128)
+        self._bc(self._pool(x, 3, 1, 1, 2), p + ".branch_pool", o, 224)
+        return o
+
+    def _B(self, x, p):
+        cin = x.shape[3]
+        o = self._cat(x, 384 + 96 + cin, stride=2)
+        self._bc(x, p + ".branch3x3", o, 0)
+        self._bc(self._bc(self._bc(x, p + ".branch3x3dbl_1"), p + ".branch3x3dbl_2"), p + ".branch3x3dbl_3", o, 384)
+        self._pool(x, 3, 2, 0, 0, o, 480)
+        return o
+
+    def _C(self, x, p):
+        o = self._cat(x, 768)
+        self._bc(x, p + ".branch1x1", o, 0)
+        self._bc(self._bc(self._bc(x, p + ".branch7x7_1"), p + ".branch7x7_2"), p + ".branch7x7_3", o, 192)
+        t = x
+        for i in range(1, 5):
+            t = self._bc(t, p + f".branch7x7dbl_{i}")
+        self._bc(t, p + ".branch7x7dbl_5", o, 384)
+        self._bc(self._pool(x, 3, 1, 1, 2), p + ".branch_pool", o, 576)
+        return o
+
+    def _D(self, x, p):
+        cin = x.shape[3]
+        o = self._cat(x, 320 + 192 + cin, stride=2)
+        self._bc(self._bc(x, p + ".branch3x3_1"), p + ".branch3x3_2", o, 0)
+        t = x
+        for i in range(1, 4):
+            t = self._bc(t, p + f".branch7x7x3_{i}")
+        self._bc(t, p + ".branch7x7x3_4", o, 320)
+        self._pool(x, 3, 2, 0, 0, o, 512)
+        return o
+
+    def _E(self, x, p, pool_mode):
+        o = self._cat(x, 2048)
+        self._bc(x, p + ".branch1x1", o, 0)
+        t = self._bc(x, p + ".branch3x3_1")
+        self._bc(t, p + ".branch3x3_2a", o, 320)
+        self._bc(t, p + ".branch3x3_2b", o, 704)
+        t = self._bc(self._bc(x, p + ".branch3x3dbl_1"), p + ".branch3x3dbl_2")
+        self._bc(t, p + ".branch3x3dbl_3a", o, 1088)
+        self._bc(t, p + ".branch3x3dbl_3b", o, 1472)
+        self._bc(self._pool(x, 3, 1, 1, pool_mode), p + ".branch_pool", o, 1856)
+        return o
+
+    @torch.no_grad()
+    def forward_nhwc(self, x):
+        """x: [B,299,299,3] NHWC in the compute dtype, values in [-1,1] -> (pool3 features [B,2048], logits [B,1008]), fp32."""
+        x = self._bc(self._bc(self._bc(x, "Conv2d_1a_3x3"), "Conv2d_2a_3x3"), "Conv2d_2b_3x3")
+        x = self._pool(x, 3, 2, 0, 0)
+        x = self._bc(self._bc(x, "Conv2d_3b_1x1"), "Conv2d_4a_3x3")
+        x = self._pool(x, 3, 2, 0, 0)
+        x = self._A(x, "Mixed_5b", 32); x = self._A(x, "Mixed_5c", 64); x = self._A(x, "Mixed_5d", 64)
+        x = self._B(x, "Mixed_6a")
+        for n in ("Mixed_6b", "Mixed_6c", "Mixed_6d", "Mixed_6e"):
+            x = self._C(x, n)
+        x = self._D(x, "Mixed_7a")
+        x = self._E(x, "Mixed_7b", 2)   # average pool without padded zeros (count_include_pad=False)
+        x = self._E(x, "Mixed_7c", 0)   # max pool
+        N, H, W, Cc = x.shape
+        feat = torch.empty((N, Cc), dtype=torch.float32, device=x.device)
+        L.call("sg_global_avgpool", L.dt(x), L.ptr(x), L.ptr(feat), N, H * W, Cc, L.stream())
+        logits = torch.empty((N, 1008), dtype=torch.float32, device=x.device)
+        F.gemm_raw(L.F32, self.fc_w, 0, 2048, feat, 0, 2048, logits, 1008, 1008, N, 2048, bias=self.fc_b)
+        return feat, logits
+
+
+def preprocess(x, dtype, quantize=True, size=299, want_uint8=False):
+    """ops.quantize_images + resize_images('legacy') + normalise on the device (reference utils/ops.py:251-263)."""
+    x = x.float().contiguous()
+    N, Cc, H, W = x.shape
+    out = torch.empty((N, size, size, Cc), dtype=dtype, device=x.device)
+    q = torch.empty((N, Cc, H, W), dtype=torch.uint8, device=x.device) if want_uint8 else None
+    L.call("sg_quantize_resize_normalize", L.dt(dtype), L.ptr(x), L.ptr(out), L.ptr(q), N, Cc, H, W, size, size, 1 if quantize else 0, L.stream())
+    return (out, q) if want_uint8 else out
+
+
+class LoadEvalModel:
+    """reference src/metrics/preparation.py:43-122 for eval_backbone == "InceptionV3_tf", post_resizer == "legacy"."""
+
+    def __init__(self, eval_backbone="InceptionV3_tf", post_resizer="legacy", world_size=1, distributed_data_parallel=False, device="cuda",
+                 state_dict=None, dtype=torch.float32):
+        if eval_backbone != "InceptionV3_tf" or post_resizer != "legacy":
+            raise NotImplementedError("only the InceptionV3_tf backbone with the legacy resizer is on the hot path (SURVEY §2)")
+        if state_dict is None:
+            raise RuntimeError("pass the FID Inception state_dict (pt_inception-2015-12-05-6726825d.pth); there is no network access here")
+        self.eval_backbone, self.post_resizer, self.device = eval_backbone, post_resizer, torch.device(device)
+        self.res = 299
+        self.model = InceptionV3(state_dict, self.device, dtype)
+        self.dtype = dtype
+
+    def eval(self):
+        pass
+
+    @torch.no_grad()
+    def get_outputs(self, x, quantize=False):
+        return self.model.forward_nhwc(preprocess(x, self.dtype, quantize, self.res))
+
+
+def softmax_rows(logits):
+    p = torch.empty_like(logits)
+    L.call("sg_softmax_rows", L.F32, L.ptr(logits), L.ptr(p), logits.shape[0], logits.shape[1], L.stream())
+    return p
+
+
+@torch.no_grad()
+def generate_images_and_stack_features(generator, eval_model, num_generate, batch_size, z_dim, num_classes, quantize=True, world_size=1,
+                                       DDP=False, device="cuda", moments=None):
+    """reference src/metrics/features.py:17-65. Returns (features [n,2048], probs [n,1008], labels list).
+    moments: optional `FeatureMoments` accumulator that receives every feature batch on the device."""
+    from .worker import sample_zy
+    num_batches = int(math.ceil(float(num_generate) / float(batch_size)))
+    if DDP:
+        num_batches = num_batches // world_size + 1
+    feats, probs, labels = [], [], []
+    for _ in range(num_batches):
+        zs, ys = sample_zy(batch_size, z_dim, num_classes, device)
+        fake = generator(zs, ys, eval=True)
+        f, logit = eval_model.get_outputs(fake, quantize=quantize)
+        if moments is not None:
+            moments.add(f)
+        feats.append(f)
+        probs.append(softmax_rows(logit))
+        labels.append(ys)
+    feats, probs, labels = torch.cat(feats, 0), torch.cat(probs, 0), torch.cat(labels, 0)
+    if DDP and world_size > 1:
+        import torch.distributed as dist
+        def gather(t):
+            out = [torch.zeros_like(t) for _ in range(world_size)]
+            dist.all_gather(out, t)
+            return torch.cat(out, 0)
+        feats, probs, labels = gather(feats), gather(probs), gather(labels)
+    return feats, probs, list(labels.detach().cpu().numpy())
+
+
+class FeatureMoments:
+    """sum f and sum f f^T in fp64 on the device (replaces np.mean / np.cov over gathered features, fid.py:96-97); in
+    data-parallel runs the two accumulators are all-reduced instead of gathering 50k x 2048 floats per rank."""
+
+    def __init__(self, dim, device):
+        self.dim, self.n = dim, 0
+        self.s1 = torch.zeros(dim, dtype=torch.float64, device=device)
+        self.s2 = torch.zeros(dim, dim, dtype=torch.float64, device=device)
+
+    def add(self, f):
+        f = f.float().contiguous()
+        L.call("sg_feat_moments_accumulate", L.ptr(f), f.shape[0], self.dim, L.ptr(self.s1), L.ptr(self.s2), L.stream())
+        self.n += f.shape[0]
+
+    def finalize(self, group=None):
+        n = self.n
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(self.s1, group=group); dist.all_reduce(self.s2, group=group)
+            t = torch.tensor([n], dtype=torch.float64, device=self.s1.device); dist.all_reduce(t, group=group); n = int(t.item())
+        mu = (self.s1 / n).cpu().numpy()
+        s2 = self.s2.cpu().numpy()
+        sigma = (s2 - n * np.outer(mu, mu)) / (n - 1)      # np.cov(rowvar=False): unbiased
+        return mu, sigma
+
+
+def calculate_moments(feats, num_generate=None):
+    f = feats[:num_generate] if num_generate else feats
+    m = FeatureMoments(f.shape[1], f.device)
+    for i in range(0, f.shape[0], 4096):
+        m.add(f[i:i + 4096])
+    return m.finalize()
+
+
+def frechet_inception_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """reference src/metrics/fid.py:34-62 (host fp64, scipy.linalg.sqrtm)."""
+    from scipy import linalg
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        covmean = covmean.real
+    return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
+
+
+def calculate_kl_div(ps, splits):
+    """reference src/metrics/ins.py:28-42 (device tensors in, numpy scalars out)."""
+    scores = []
+    n = ps.shape[0]
+    with torch.no_grad():
+        for j in range(splits):
+            part = ps[(j * n // splits):((j + 1) * n // splits), :]
+            kl = part * (torch.log(part) - torch.log(torch.unsqueeze(torch.mean(part, 0), 0)))
+            scores.append(torch.exp(torch.mean(torch.sum(kl, 1))).unsqueeze(0))
+        scores = torch.cat(scores, 0)
+        return torch.mean(scores).detach().cpu().numpy(), torch.std(scores).detach().cpu().numpy()
+
+
+def top_k_accuracy(probs, labels, k, c0=1, ncls=1000):
+    """Top-k accuracy over probs[:, c0:c0+ncls] with sklearn's tie rule, decided on the device (bit-exact integer
+    logic; reference ins.py:75-76 slices classes 1..1000 and offsets the TF label by +1 -> pass 0-based class here)."""
+    probs = probs.float().contiguous()
+    lab = torch.as_tensor(labels, device=probs.device).long().contiguous()
+    hits = torch.empty(probs.shape[0], dtype=torch.uint8, device=probs.device)
+    L.call("sg_topk_hits", L.ptr(probs) + 4 * c0, probs.shape[1], ncls, L.ptr(lab), k, probs.shape[0], L.ptr(hits), L.stream())
+    return float(hits.float().mean().item())

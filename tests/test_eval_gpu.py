@@ -1,0 +1,86 @@
+"""GPU: FID/IS feature-extraction path (studiogan_amd/metrics.py) against the CPU oracle (oracle/inception.py) with the
+same seeded random Inception weights (pretrained weights are unavailable offline: parity is structural, see the oracle
+header), plus the integer parts that must be bit-exact (uint8 quantisation, top-k with sklearn's tie rule)."""
+import numpy as np
+import pytest
+import torch
+
+from util import check
+from oracle import inception as OI
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype,tol", [(torch.float32, 2e-4), (torch.bfloat16, 6e-2)])
+def test_inception_features_vs_oracle(sg, dtype, tol):
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    sd = OI.random_state_dict(0)
+    g = torch.Generator().manual_seed(5)
+    imgs = torch.rand(2, 3, 64, 64, generator=g) * 2 - 1
+    x299, q = OI.quantize_resize_normalize(imgs, quantize=True)
+    feat_o, logit_o = OI.inception_forward(x299, sd)
+    model = M.LoadEvalModel("InceptionV3_tf", "legacy", 1, False, dev, state_dict=sd, dtype=dtype)
+    feat, logit = model.get_outputs(imgs.to(dev), quantize=True)
+    torch.cuda.synchronize()
+    check(f"inception pool3 features {dtype}", feat, feat_o, tol)
+    check(f"inception logits {dtype}", logit, logit_o, tol)
+    p = M.softmax_rows(logit)
+    check("softmax(logits)", p, torch.softmax(logit.cpu().double(), 1), 1e-5)
+
+
+def test_preprocess_bit_exact_quantisation(sg):
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(6)
+    imgs = torch.rand(3, 3, 32, 32, generator=g) * 2.4 - 1.2
+    x_o, q_o = OI.quantize_resize_normalize(imgs, quantize=True)
+    x, q = M.preprocess(imgs.to(dev), torch.float32, True, 299, want_uint8=True)
+    assert np.array_equal(q.cpu().numpy(), q_o), "uint8 quantisation must be bit-exact"
+    check("resize+normalise", x.cpu().permute(0, 3, 1, 2), x_o, 1e-5)
+
+
+def test_topk_moments_is_fid(sg):
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    probs = torch.softmax(torch.randn(300, 1008, generator=g), 1)
+    probs[:50, 1:1001] = probs[:50, 1:2]            # exact ties across all classes for the first rows
+    probs[50:80, 5] = probs[50:80, 9]               # pairwise ties
+    labels = torch.randint(0, 1000, (300,), generator=g)
+    for k in (1, 5):
+        ref = OI.topk_hits(probs[:, 1:1001], labels, k).double().mean().item()
+        got = M.top_k_accuracy(probs.to(dev), labels, k, c0=1, ncls=1000)
+        assert abs(ref - got) < 1e-6, (k, ref, got)
+    # sklearn agrees with the restated tie rule
+    from sklearn.metrics import top_k_accuracy_score
+    sk = top_k_accuracy_score(labels.numpy(), probs[:, 1:1001].numpy(), k=5, labels=range(1000))
+    assert abs(sk - OI.topk_hits(probs[:, 1:1001], labels, 5).double().mean().item()) < 1e-12
+    # moments
+    f = torch.randn(1000, 64, generator=g) * 2 + 0.5
+    mu, sigma = M.calculate_moments(f.to(dev))
+    check("moments mean", torch.from_numpy(mu), f.double().mean(0), 1e-6)
+    check("moments cov", torch.from_numpy(sigma), torch.from_numpy(np.cov(f.double().numpy(), rowvar=False)), 1e-5)
+    assert abs(M.frechet_inception_distance(mu, sigma, mu, sigma)) < 1e-6          # KAT: FID(x, x) = 0 (fid.py:34-62)
+    u = torch.full((64, 1008), 1.0 / 1008, device=dev)
+    m, _ = M.calculate_kl_div(u, 1)
+    assert abs(float(m) - 1.0) < 1e-6                                                # KAT: IS of uniform predictions = 1
+
+
+def test_feature_loop_with_generator(sg):
+    """generate_images_and_stack_features end to end with a small BigGAN generator (reference features.py:17-65)."""
+    from studiogan_amd import metrics as M
+    from util import load_golden, sub
+    from test_model_gpu import build_from_yaml
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("biggan32")
+    G, _ = build_from_yaml(meta["yaml"], False, dev)
+    G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+    G.eval()
+    model = M.LoadEvalModel(device=dev, state_dict=OI.random_state_dict(0), dtype=torch.bfloat16)
+    mom = M.FeatureMoments(2048, dev)
+    feats, probs, labels = M.generate_images_and_stack_features(G, model, 10, 4, 40, 10, quantize=True, device=dev, moments=mom)
+    assert feats.shape == (12, 2048) and probs.shape == (12, 1008) and len(labels) == 12
+    assert torch.isfinite(feats).all() and abs(float(probs.sum(1).mean()) - 1) < 1e-4
+    mu, sigma = mom.finalize()
+    check("loop moments", torch.from_numpy(mu), feats.double().mean(0).cpu(), 1e-5)

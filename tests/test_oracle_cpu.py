@@ -80,3 +80,21 @@ def test_analytic_kats():
     for _ in range(200):
         w = O.weight_of(P, B, "l")
     assert abs(float(torch.linalg.matrix_norm(w, 2)) - 1.0) < 1e-4
+
+
+def test_inception_oracle_structure_and_kats():
+    from oracle import inception as OI
+    sd = OI.random_state_dict(0)
+    assert len([k for k in sd if k.endswith(".conv.weight")]) == 94          # torchvision inception_v3 has 94 BasicConv2d
+    assert sd["fc.weight"].shape == (1008, 2048)                              # FID weights: 1008-way fc (inception_net.py:117)
+    x = torch.rand(1, 3, 299, 299) * 2 - 1
+    feat, logits = OI.inception_forward(x, sd)
+    assert feat.shape == (1, 2048) and logits.shape == (1, 1008) and bool((feat >= 0).all())
+    u = torch.full((32, 1008), 1.0 / 1008)
+    assert abs(float(OI.inception_score(u)[0]) - 1.0) < 1e-6                  # IS of uniform predictions = 1 (ins.py:28-42)
+    import numpy as np
+    mu, s = np.arange(4.0), np.eye(4) * 2
+    assert abs(OI.frechet_distance(mu, s, mu, s)) < 1e-9                      # FID(x,x) = 0 (fid.py:34-62)
+    imgs = torch.tensor([[[[-1.0, 1.0], [0.0, 0.00392]]]]).repeat(1, 3, 1, 1)
+    _, q = OI.quantize_resize_normalize(imgs, size=4)
+    assert q[0, 0].tolist() == [[0, 255], [128, 128]]                         # uint8 truncation of (x+1)/2*255+0.5
