@@ -157,6 +157,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256, help="per-GPU batch")
     ap.add_argument("--fp32", action="store_true", help="fp32 compute instead of bf16 (not the benchmark configuration)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--fid-samples", type=int, default=50000, help="samples of the FID feature-extraction leg (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=2)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -220,6 +221,36 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- second metric: FID-50k feature extraction (reference src/metrics/features.py:17-65) ------------------------
+    fid = None
+    if args.fid_samples > 0 and args.workload == "biggan128":
+        from studiogan_amd import metrics as M
+        from studiogan_amd.worker import make_GAN_untrainable
+        from oracle.inception import random_state_dict     # seeded random Inception weights (the real ones need network access)
+        make_GAN_untrainable(G, w.Gen_ema, D)
+        per_rank = (args.fid_samples + world - 1) // world
+        fid = {}
+        for name, idt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
+            model = M.LoadEvalModel(device=device, state_dict=random_state_dict(0), dtype=idt)
+            M.generate_images_and_stack_features(w.Gen_ema, model, 2 * args.batch, args.batch, wl["z_dim"], wl["classes"], device=device)  # warm-up
+            barrier()
+            mom = M.FeatureMoments(2048, device)
+            t1 = time.perf_counter()
+            feats, probs, _ = M.generate_images_and_stack_features(w.Gen_ema, model, per_rank, args.batch, wl["z_dim"], wl["classes"], quantize=True,
+                                                                   device=device, moments=mom)
+            mu, sigma = mom.finalize(group)
+            barrier()
+            dt_f = time.perf_counter() - t1
+            if world > 1:
+                t = torch.tensor([dt_f], dtype=torch.float64, device=device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt_f = float(t.item())
+            fid[name] = {"samples_per_sec": round(per_rank * world / dt_f, 1), "seconds": round(dt_f, 2)}
+            del model, feats, probs
+        fid = {"metric": "FID-50k feature-extract samples/sec", "samples": per_rank * world, "batch": args.batch,
+               "value": fid["f32"]["samples_per_sec"], "unit": "samples/sec", "inception_f32": fid["f32"], "inception_bf16": fid["bf16"],
+               "includes": "G_ema forward (bf16) + on-device quantize/resize + InceptionV3 + softmax + fp64 moment accumulation",
+               "weights": "seeded random (pretrained FID Inception weights are not available offline)"}
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -248,6 +279,8 @@ def main():
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),
                      "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
     }
+    if fid is not None:
+        out["fid_extract"] = fid
     if wl["gflop"]:
         out["step_tflops"] = round(wl["gflop"] * global_batch / 1e3 / (ms_per_step * 1e-3), 2)  # whole-step algorithmic TFLOP/s
     if not args.no_cpu_baseline and world == 1:
