@@ -174,6 +174,8 @@ typedef struct {
   int apply_sn;       /* 0: plain layer, only emit operand images with sigma = 1 */
   int rows_pad;       /* w_fwd gets rows_pad >= rows rows (extra rows zero) ; 0 = rows */
   long long work_off; /* this layer's slice of work[]: needs 8*cols + rows floats */
+  int trans;          /* 1: ConvTranspose2d weight [Cin][Cout][R][S] (spectral norm over dim 1, rows = Cout) */
+  int dgrad_noflip;   /* 1: w_dgrad = [Cin][r][s][Cout] without the spatial flip (strided / transposed convolutions) */
 } sg_sn_layer;
 /* runs all layers of a network in 4 batched launches. `layers` is a DEVICE array of n descriptors;
  * work[] is a device scratch; each layer owns the slice [work_off, work_off + 8*cols + rows) */
@@ -184,7 +186,7 @@ typedef struct {
   const float* w;     /* weight_orig [rows][cols] */
   const float* u; const float* v; const float* sigma; /* snapshot of that forward */
   float* dw;          /* grad of weight_orig, accumulated (+=), natural OIHW layout */
-  int rows, cols, Cin, RS, natural, apply_sn;
+  int rows, cols, Cin, RS, natural, apply_sn, trans;
 } sg_sn_bwd_layer;
 int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s);
 

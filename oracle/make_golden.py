@@ -13,8 +13,11 @@ fake images, logits, losses, every parameter gradient of the first D update and 
 parameters / buffers (spectral-norm u,v; BN running statistics) after the Adam steps.
 """
 import importlib
+import json
+import math
 import os
 import sys
+import zlib
 
 import numpy as np
 import torch
@@ -34,7 +37,81 @@ CONFIGS = {
               "LOSS": {"adv_loss": "hinge"},
               "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
         batch=4, n_d=2, seed=1234),
+    # SNGAN on the ResNet backbone (C2 family: reference configs/CIFAR10/SNGAN.yaml at width 8): cBN on the one-hot label, PD, SN in D only
+    "sngan32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 32, "g_conv_dim": 8, "d_conv_dim": 8},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.0002, "d_lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=4321),
+    # unconditional ResNet GAN with batch norm in D (no SN anywhere; the C5 WGAN-GP model family with the vanilla loss)
+    "resgan32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "resnet", "z_dim": 32, "g_conv_dim": 8, "d_conv_dim": 8},
+              "LOSS": {"adv_loss": "vanilla"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.0002, "d_lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=777),
+    # DCGAN exactly as configs/CIFAR10/DCGAN.yaml (C1): widths are hard-coded in models/deep_conv.py (6.7 M parameters),
+    # so the fixture is COMPACT: formula-generated initial state + samples/norms of the large expected tensors
+    "dcgan32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "deep_conv", "g_conv_dim": "N/A", "d_conv_dim": "N/A"},
+              "OPTIMIZATION": {"batch_size": 8, "d_updates_per_step": 2}},
+        batch=8, n_d=2, seed=99, compact=True),
+    # DCGAN widths with spectral norm on G (ConvTranspose2d, dim=1) and D, cBN + PD, hinge
+    "sndcgan32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "deep_conv", "g_conv_dim": "N/A", "d_conv_dim": "N/A", "g_cond_mtd": "cBN", "d_cond_mtd": "PD",
+                        "apply_g_sn": True, "apply_d_sn": True},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 8, "d_updates_per_step": 2}},
+        batch=8, n_d=2, seed=100, compact=True),
 }
+
+SAMPLE = 2048          # compact fixtures: tensors above FULL_MAX elements keep SAMPLE evenly spaced values + [sum, l2]
+FULL_MAX = 8192
+
+
+def sample_index(numel):
+    return (torch.arange(SAMPLE, dtype=torch.int64) * numel) // SAMPLE
+
+
+def formula_state(spec, seed):
+    """Deterministic initial state for compact fixtures: numpy RandomState (bit-stable by specification) keyed by the
+    tensor name. spec: {name: shape}. Weights ~ N(0, 1/fan_in), BN gains 1 + 0.1 N, biases 0.1 N, unit u / v."""
+    out = {}
+    for name, shape in spec.items():
+        rs = np.random.RandomState((seed * 1000003 + zlib.crc32(name.encode())) % (2 ** 32))
+        leaf = name.rsplit(".", 1)[-1]
+        shape = tuple(shape)
+        if leaf == "num_batches_tracked":
+            t = torch.zeros(shape, dtype=torch.int64)
+        elif leaf == "running_mean":
+            t = torch.zeros(shape)
+        elif leaf == "running_var":
+            t = torch.ones(shape)
+        else:
+            v = rs.standard_normal(shape).astype(np.float64)
+            if leaf in ("weight_u", "weight_v"):
+                v = v / np.linalg.norm(v)
+            elif len(shape) >= 2:
+                v = v / math.sqrt(int(np.prod(shape[1:])))
+            elif leaf == "weight":
+                v = 1.0 + 0.1 * v
+            else:
+                v = 0.1 * v
+            t = torch.from_numpy(v.astype(np.float32))
+        out[name] = t
+    return out
+
+
+def compact_entries(key, v):
+    """fixture entries for one expected tensor of a compact fixture."""
+    if v.numel() <= FULL_MAX:
+        return {"exp/" + key: v}
+    flat = v.reshape(-1)
+    return {"exps/" + key: flat[sample_index(flat.numel())].clone(),
+            "expn/" + key: torch.tensor([float(flat.double().sum()), float(flat.double().norm())], dtype=torch.float64)}
 
 
 def oracle_cfg(y):
@@ -134,20 +211,32 @@ def run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d):
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
     assert R.available(), "/root/reference is required to (re)generate the golden fixtures"
+    only = sys.argv[1:]
     for name, c in CONFIGS.items():
+        if only and name not in only:
+            continue
         y = c["yaml"]
         cfgs = R.load_cfgs(y)
         torch.manual_seed(c["seed"])
         Gen, Dis = R.build_models(cfgs)
+        compact = c.get("compact", False)
+        meta = {"yaml": y, "batch": c["batch"], "n_d": c["n_d"], "seed": c["seed"]}
+        if compact:
+            meta["compact"] = True
+            meta["G_spec"] = {k: list(v.shape) for k, v in Gen.state_dict().items()}
+            meta["D_spec"] = {k: list(v.shape) for k, v in Dis.state_dict().items()}
+            Gen.load_state_dict(formula_state(meta["G_spec"], c["seed"]), strict=True)
+            Dis.load_state_dict(formula_state(meta["D_spec"], c["seed"] + 1), strict=True)
         GP, GB = R.split_state(Gen)
         DP, DB = R.split_state(Dis)
         ocfg = oracle_cfg(y)
         ins = synth_inputs(c["seed"] + 1, c["n_d"], c["batch"], ocfg["z_dim"], ocfg["num_classes"], ocfg["img_size"])
         fix = {}
-        for k, v in list(GP.items()) + list(GB.items()):
-            fix["G_init/" + k] = v.clone()
-        for k, v in list(DP.items()) + list(DB.items()):
-            fix["D_init/" + k] = v.clone()
+        if not compact:
+            for k, v in list(GP.items()) + list(GB.items()):
+                fix["G_init/" + k] = v.clone()
+            for k, v in list(DP.items()) + list(DB.items()):
+                fix["D_init/" + k] = v.clone()
         for k, v in ins.items():
             fix["in/" + k] = v
         exp_ref = run_reference(cfgs, Gen, Dis, ins, c["n_d"])
@@ -158,15 +247,17 @@ def main():
             a, b = v.double(), exp_res[k].double()
             err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
             worst[fam] = max(worst.get(fam, 0.0), err)
-            fix["exp/" + k] = v
+            if compact:
+                fix.update(compact_entries(k, v))
+            else:
+                fix["exp/" + k] = v
         print(name, "restatement vs reference, max relative-to-range error per family:")
         for fam, e in sorted(worst.items()):
             print(f"   {fam:10s} {e:.3e}")
         assert max(worst.values()) < 2e-5, "oracle restatement disagrees with the reference"
         np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".npz"), **{k: v.numpy() for k, v in fix.items()})
-        import json
         with open(os.path.join(GOLDEN_DIR, name + ".json"), "w") as f:
-            json.dump({"yaml": y, "batch": c["batch"], "n_d": c["n_d"], "seed": c["seed"]}, f, indent=1)
+            json.dump(meta, f, indent=1)
         print("   wrote", name + ".npz", os.path.getsize(os.path.join(GOLDEN_DIR, name + ".npz")) // 1024, "KiB")
 
 

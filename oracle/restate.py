@@ -27,13 +27,14 @@ def _l2n(v, eps):
     return v / torch.clamp(v.norm(), min=eps)
 
 
-def weight_of(P, B, name, power_iterate=True, eps=1e-6):
+def weight_of(P, B, name, power_iterate=True, eps=1e-6, deconv=False):
     """Effective weight of layer `name`: W/sigma for spectral-norm layers (power iteration updates B in place)."""
     if name + ".weight_orig" not in P:
         return P[name + ".weight"]
     w = P[name + ".weight_orig"]
     u, v = B[name + ".weight_u"], B[name + ".weight_v"]
-    mat = w.reshape(w.shape[0], -1)
+    # torch.nn.utils.spectral_norm picks dim=1 for ConvTranspose{1,2,3}d (spectral_norm.py:272-276): rows = out channels
+    mat = w.permute(1, 0, 2, 3).reshape(w.shape[1], -1) if deconv else w.reshape(w.shape[0], -1)
     if power_iterate:
         with torch.no_grad():
             v_new = _l2n(mat.t().mv(u), eps)
@@ -48,6 +49,16 @@ def weight_of(P, B, name, power_iterate=True, eps=1e-6):
 def conv(x, P, B, name, padding, sn_iter=True):
     w = weight_of(P, B, name, sn_iter)
     return F.conv2d(x, w, P.get(name + ".bias"), stride=1, padding=padding)
+
+
+def conv_strided(x, P, B, name, stride, padding, sn_iter=True):
+    return F.conv2d(x, weight_of(P, B, name, sn_iter), P.get(name + ".bias"), stride=stride, padding=padding)
+
+
+def deconv(x, P, B, name, stride, padding, sn_iter=True):
+    """nn.ConvTranspose2d (utils/ops.py:176-184); weight [Cin][Cout][kh][kw]. Spectral-norm variant (ops.py:207-216)
+    normalises over dim 1."""
+    return F.conv_transpose2d(x, weight_of(P, B, name, sn_iter, deconv=True), P.get(name + ".bias"), stride=stride, padding=padding)
 
 
 def linear(x, P, B, name, sn_iter=True):
@@ -190,6 +201,86 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# SNGAN-style ResNet generator (models/resnet.py:15-158); its discriminator is line-for-line models/big_resnet.py's
+# ---------------------------------------------------------------------------------------------------------
+def resnet_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/resnet.py:126-158 (Generator.forward), GenBlock.forward :36-60. Conditioning: cBN on the ONE-HOT label
+    (resnet.py:128-129,140-141) -- no shared embedding, no z chunks; unconditional: plain BN (resnet.py:21-23)."""
+    g_in, g_out, _, _, _ = biggan_dims(cfg["img_size"], cfg["g_conv_dim"])
+    cond = cfg.get("g_cond_mtd", "W/O") != "W/O"
+    aff = F.one_hot(label, num_classes=cfg["num_classes"]).to(torch.float32) if cond else None
+
+    def bn(x, name):
+        return cond_batch_norm(x, aff, P, B, name, bn_mode, sn_iter) if cond else batch_norm(x, P, B, name, bn_mode)
+
+    act = linear(z, P, B, "linear0", sn_iter).view(-1, g_in[0], 4, 4)
+    bi = 0
+    for index in range(len(g_in)):
+        pre = f"blocks.{bi}.0"
+        x0 = act
+        x = torch.relu(bn(act, pre + ".bn1"))
+        x = conv(F.interpolate(x, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d1", 1, sn_iter)
+        x = conv(torch.relu(bn(x, pre + ".bn2")), P, B, pre + ".conv2d2", 1, sn_iter)
+        x0 = conv(F.interpolate(x0, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter)
+        act = x + x0
+        bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            bi += 1
+    act = torch.relu(batch_norm(act, P, B, "bn4", bn_mode))
+    return torch.tanh(conv(act, P, B, "conv2d5", 1, sn_iter))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DCGAN (models/deep_conv.py): fixed widths 512-256-128-64 / 64-128-256-512, 32x32 images
+# ---------------------------------------------------------------------------------------------------------
+def dcgan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/deep_conv.py:90-121 (Generator.forward), GenBlock.forward :32-39."""
+    cond = cfg.get("g_cond_mtd", "W/O") != "W/O"
+    aff = F.one_hot(label, num_classes=cfg["num_classes"]).to(torch.float32) if cond else None
+    act = linear(z, P, B, "linear0", sn_iter).view(-1, 512, 4, 4)
+    bi = 0
+    for index in range(3):
+        pre = f"blocks.{bi}.0"
+        x = deconv(act, P, B, pre + ".deconv0", 2, 1, sn_iter)
+        x = cond_batch_norm(x, aff, P, B, pre + ".bn0", bn_mode, sn_iter) if cond else batch_norm(x, P, B, pre + ".bn0", bn_mode)
+        act = torch.relu(x)
+        bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            bi += 1
+    return torch.tanh(conv(act, P, B, "conv4", 1, sn_iter))
+
+
+def dcgan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/deep_conv.py:232-247,270-271 (Discriminator.forward), DiscBlock.forward :139-149."""
+    sn = cfg["apply_d_sn"]
+    h = x
+    bi = 0
+    for index in range(3):
+        pre = f"blocks.{bi}.0"
+        h = conv(h, P, B, pre + ".conv0", 1, sn_iter)
+        if not sn:
+            h = batch_norm(h, P, B, pre + ".bn0", bn_mode)
+        h = conv_strided(torch.relu(h), P, B, pre + ".conv1", 2, 1, sn_iter)
+        if not sn:
+            h = batch_norm(h, P, B, pre + ".bn1", bn_mode)
+        h = torch.relu(h)
+        bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter)
+            bi += 1
+    h = conv(h, P, B, "conv1", 1, sn_iter)
+    if not sn:
+        h = batch_norm(h, P, B, "bn1", bn_mode)
+    h = torch.sum(torch.relu(h), dim=[2, 3])
+    adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
+    if cfg.get("d_cond_mtd", "W/O") == "PD":
+        adv = adv + torch.sum(F.embedding(label, weight_of(P, B, "embedding", sn_iter)) * h, 1)
+    return adv, h
+
+
+# ---------------------------------------------------------------------------------------------------------
 # losses (utils/losses.py:197-239) / gradient penalty (utils/losses.py:268-275,301-316)
 # ---------------------------------------------------------------------------------------------------------
 def d_loss(kind, real, fake):
@@ -272,7 +363,7 @@ def d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, real, real_labels, z, fake_l
         adv_f, _ = dis_fn(fake, fake_labels[i], leaves, DB)
         loss = d_loss(loss_kind, adv_r, adv_f) / acml
         loss.backward()
-        out["loss"] += float(loss)
+        out["loss"] += float(loss.detach())
         if record and i == 0:
             out["fake"], out["adv_r"], out["adv_f"] = fake.detach(), adv_r.detach(), adv_f.detach()
     grads = {k: v.grad for k, v in leaves.items()}
@@ -291,7 +382,7 @@ def g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, z, fake_labels, loss_kind="h
         adv_f, _ = dis_fn(fake, fake_labels[i], DP, DB)
         loss = g_loss(loss_kind, adv_f) / acml
         loss.backward()
-        out["loss"] += float(loss)
+        out["loss"] += float(loss.detach())
         if record and i == 0:
             out["fake"], out["adv_f"] = fake.detach(), adv_f.detach()
     grads = {k: v.grad for k, v in leaves.items()}
@@ -309,5 +400,19 @@ def model_fns(cfg):
 
         def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
             return biggan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
+        return gen_fn, dis_fn
+    if bb == "resnet":
+        def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):
+            return resnet_generator(z, y, P, B, cfg, bn_mode, sn_iter)
+
+        def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
+        return gen_fn, dis_fn
+    if bb == "deep_conv":
+        def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):
+            return dcgan_generator(z, y, P, B, cfg, bn_mode, sn_iter)
+
+        def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
+            return dcgan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
         return gen_fn, dis_fn
     raise NotImplementedError(bb)

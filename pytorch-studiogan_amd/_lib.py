@@ -45,12 +45,12 @@ class GemmDesc(C.Structure):
 class SnLayer(C.Structure):
     _fields_ = [("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("u_snap", _vp), ("v_snap", _vp), ("w_fwd", _vp), ("w_dgrad", _vp),
                 ("w_f32", _vp), ("rows", _i), ("cols", _i), ("Cin", _i), ("RS", _i), ("do_power_iter", _i), ("apply_sn", _i),
-                ("rows_pad", _i), ("work_off", _ll)]
+                ("rows_pad", _i), ("work_off", _ll), ("trans", _i), ("dgrad_noflip", _i)]
 
 
 class SnBwdLayer(C.Structure):
     _fields_ = [("dwt", _vp), ("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("dw", _vp), ("rows", _i), ("cols", _i),
-                ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i)]
+                ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i), ("trans", _i)]
 
 
 _lib = None

@@ -157,7 +157,7 @@ class _Holder:
 class LayerRT:
     """Runtime record of one weight-bearing layer inside a bank."""
     __slots__ = ("module", "index", "param", "kind", "rows", "cols", "Cin", "RS", "apply_sn", "rows_pad", "want_fwd", "want_dgrad",
-                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank")
+                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank", "trans", "noflip")
 
 
 class _Slot:
@@ -202,10 +202,12 @@ class WeightBank:
             r.rows, r.cols, r.Cin, r.RS = m._sg_rows, m._sg_cols, m._sg_cin, m._sg_rs
             r.apply_sn = 1 if m._sg_sn else 0
             r.rows_pad = getattr(m, "_sg_rows_pad", 0) or r.rows
+            r.trans = 1 if getattr(m, "_sg_trans", False) else 0
+            r.noflip = 1 if getattr(m, "_sg_dgrad_noflip", False) else 0
             r.want_fwd = r.kind == "conv"
             r.want_dgrad = r.kind == "conv"
             r.want_f32 = r.kind in ("linear", "embedding")
-            r.natural_dwt = 0 if r.kind == "conv" else 1
+            r.natural_dwt = (2 if getattr(m, "_sg_trans", False) else 0) if r.kind == "conv" else 1
             r.fwd_off = r.dgrad_off = r.f32_off = -1
             if r.want_fwd:
                 r.fwd_off = img_elems
@@ -269,6 +271,7 @@ class WeightBank:
             d.apply_sn = r.apply_sn
             d.rows_pad = r.rows_pad
             d.work_off = r.work_off
+            d.trans, d.dgrad_noflip = r.trans, r.noflip
         dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
         ent = (arr, dev_tab)
         slot.desc_cache[flags] = ent
@@ -349,6 +352,7 @@ class WeightBank:
                     d.rows, d.cols, d.Cin, d.RS = r.rows, r.cols, r.Cin, r.RS
                     d.natural = r.natural_dwt
                     d.apply_sn = r.apply_sn
+                    d.trans = r.trans
                 ent = [arr, None, None]
                 slot.bwd_cache[key] = ent
             arr = ent[0]

@@ -13,6 +13,14 @@
 
 #define SN_SPLITS 8
 
+// element (o, k) of the weight viewed as the [rows][cols] matrix spectral norm works on. Conv2d / Linear / Embedding:
+// natural layout (dim 0 = rows). ConvTranspose2d (torch uses dim=1): weight is [Cin][Cout][R][S], rows = Cout.
+template <class LAYER> __device__ __forceinline__ long long sn_widx(const LAYER& l, int o, int k) {
+  if (!l.trans) return (long long)o * l.cols + k;
+  const int c = k / l.RS, rs = k - c * l.RS;
+  return ((long long)c * l.rows + o) * l.RS + rs;
+}
+
 // grid (col tiles, SN_SPLITS, layers)
 __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* work) {
   const sg_sn_layer l = L[blockIdx.z];
@@ -22,7 +30,7 @@ __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* wor
   const int per = (l.rows + SN_SPLITS - 1) / SN_SPLITS;
   int o0 = blockIdx.y * per, o1 = o0 + per; if (o1 > l.rows) o1 = l.rows;
   float acc = 0.f;
-  for (int o = o0; o < o1; o++) acc += l.w[(long long)o * l.cols + k] * l.u[o];
+  for (int o = o0; o < o1; o++) acc += l.w[sn_widx(l, o, k)] * l.u[o];
   work[l.work_off + (long long)blockIdx.y * l.cols + k] = acc;
 }
 // grid (layers): v = normalize(sum of partials)
@@ -50,9 +58,8 @@ __global__ __launch_bounds__(256) void k_sn_wv(const sg_sn_layer* L, float* work
   const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (o >= l.rows) return;
   const int lane = threadIdx.x & 63;
-  const float* wr = l.w + (long long)o * l.cols;
   float acc = 0.f;
-  for (int k = lane; k < l.cols; k += 64) acc += wr[k] * l.v[k];
+  for (int k = lane; k < l.cols; k += 64) acc += l.w[sn_widx(l, o, k)] * l.v[k];
   acc = wave_sum(acc);
   if (lane == 0) work[l.work_off + (long long)SN_SPLITS * l.cols + o] = acc;
 }
@@ -91,9 +98,9 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack(const sg_
     const int c = k / l.RS, rs = k - c * l.RS;
     float val = 0.f;
     if (o < l.rows) {
-      val = l.w[i] / sig;
+      val = l.w[sn_widx(l, o, k)] / sig;
       if (l.w_f32) l.w_f32[i] = val;
-      if (l.w_dgrad) ((T*)l.w_dgrad)[((long long)c * l.RS + (l.RS - 1 - rs)) * l.rows + o] = from_f<T>(val);
+      if (l.w_dgrad) ((T*)l.w_dgrad)[((long long)c * l.RS + (l.dgrad_noflip ? rs : (l.RS - 1 - rs))) * l.rows + o] = from_f<T>(val);
     }
     if (l.w_fwd) ((T*)l.w_fwd)[((long long)o * l.RS + rs) * l.Cin + c] = from_f<T>(val);
   }
@@ -133,8 +140,9 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
 // ---- backward: dW = (dWt - <dWt, W/sigma> u v^T) / sigma --------------------------------------------------
 #define SNB_BLOCKS 64
 __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int o, int k) {
-  if (l.natural) return (long long)o * l.cols + k;
+  if (l.natural == 1) return (long long)o * l.cols + k;
   const int c = k / l.RS, rs = k - c * l.RS;
+  if (l.natural == 2) return ((long long)c * l.RS + rs) * l.rows + o;   // [Cin][R][S][Cout]: weight gradient of a transposed conv
   return ((long long)o * l.RS + rs) * l.Cin + c;
 }
 // grid (SNB_BLOCKS, layers): block partials of <dWt, W>
@@ -146,7 +154,7 @@ __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float
   float acc = 0.f;
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
     const int o = (int)(i / l.cols), k = (int)(i % l.cols);
-    acc += l.dwt[snb_src_index(l, o, k)] * l.w[i];
+    acc += l.dwt[snb_src_index(l, o, k)] * l.w[sn_widx(l, o, k)];
   }
   acc = block_sum_256(acc, sm);
   if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
@@ -167,7 +175,7 @@ __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, con
     const int o = (int)(i / l.cols), k = (int)(i % l.cols);
     float g = l.dwt[snb_src_index(l, o, k)];
     if (l.apply_sn) g = (g - coef * l.u[o] * l.v[k]) * inv;
-    l.dw[i] += g;
+    l.dw[sn_widx(l, o, k)] += g;
   }
 }
 extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s) {

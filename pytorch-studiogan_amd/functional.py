@@ -216,7 +216,11 @@ class ConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.stride != 1:
-                raise NotImplementedError("data gradient of strided convolution goes through ConvTransposeFn")
+                # strided convolution: gather form of the transposed convolution with the UNflipped [Cin][r][s][Cout] image
+                assert not (pool or cfg.in_upsample), "upsample / pooling fusion is stride-1 only"
+                dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
+                                mask=x if cfg.in_relu else None, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
+        if ctx.needs_input_grad[0] and cfg.stride == 1:
             pf = L.PIX_UPSAMPLE if pool else 0
             ef = L.EPI_POOL if cfg.in_upsample else 0
             # dy has rows_pad channels, the dgrad image has K = R*S*rows: read the first `rows` channels at pitch rows_pad
@@ -232,6 +236,43 @@ class ConvFn(torch.autograd.Function):
             L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())
         dres = dy if ctx.has_res else None
         return dx, None, None, dres, None, None, None
+
+
+class ConvTransposeFn(torch.autograd.Function):
+    """nn.ConvTranspose2d (reference src/utils/ops.py:176-184,207-216; DCGAN generator, src/models/deep_conv.py:21).
+    forward = transposed gather on the engine; data gradient = the ordinary strided convolution of dy; weight gradient =
+    the convolution weight-gradient kernel with the roles of x and dy exchanged (result lands as [Cin][R][S][Cout])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rt, slot, cfg):
+        bank = rt.bank()
+        x = _c(x)
+        N, H, W, Cin = x.shape
+        assert Cin == rt.Cin
+        Ho = (H - 1) * cfg.stride - 2 * cfg.pad_h + cfg.R
+        Wo = (W - 1) * cfg.stride - 2 * cfg.pad_w + cfg.S
+        y = conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0, bias=bias,
+                       transposed_out_hw=(Ho, Wo))
+        ctx.save_for_backward(x)
+        ctx.rt, ctx.slot, ctx.cfg, ctx.bias = rt, slot, cfg, bias
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        rt, slot, cfg = ctx.rt, ctx.slot, ctx.cfg
+        bank = rt.bank()
+        dy = _c(dy)
+        N, H, W, Cin = x.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w)
+        if ctx.needs_input_grad[1]:
+            conv2d_wgrad_raw(dy, x, bank.dwt(slot, rt), rt.rows, Cin, cfg.R, cfg.S, H, W, cfg.stride, cfg.pad_h, cfg.pad_w)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            g = ensure_grad(ctx.bias)
+            L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, dy.shape[0] * dy.shape[1] * dy.shape[2], rt.rows, L.ptr(g), 1.0, L.stream())
+        return dx, None, None, None, None, None
 
 
 class LinearFn(torch.autograd.Function):
@@ -442,6 +483,26 @@ class AddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         return dy, dy
+
+
+class ReluFn(torch.autograd.Function):
+    """standalone ReLU (only where no neighbouring launch can absorb it): y = x * (x > 0)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.call("sg_relu_mask", L.dt(x), L.ptr(x), L.ptr(x), L.ptr(y), x.numel(), L.stream())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = _c(dy)
+        dx = torch.empty_like(x)
+        L.call("sg_relu_mask", L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream())
+        return dx
 
 
 class AddReluFn(torch.autograd.Function):

@@ -103,6 +103,7 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
             raise NotImplementedError
         kh, kw = self.kernel_size
         self._sg_rows_pad = cout_pad
+        self._sg_dgrad_noflip = self.stride[0] != 1     # strided conv: data gradient is a transposed gather (unflipped image)
         self._sg_setup("conv", out_channels, in_channels * kh * kw, in_channels, kh * kw, sn)
 
     def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None):
@@ -119,6 +120,31 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         if self._sg_rows_pad and self._sg_rows_pad != self.out_channels:
             y = y[..., :self.out_channels]
         return to_nchw(y)
+
+
+class ConvTranspose2d(_WeightLayerMixin, nn.ConvTranspose2d):
+    """nn.ConvTranspose2d mirror (weight [Cin, Cout, kh, kw]; spectral norm over dim 1 like torch does)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=2, padding=0, dilation=1, groups=1, bias=True, sn=False):
+        nn.ConvTranspose2d.__init__(self, in_channels, out_channels, kernel_size, stride, padding, 0, groups, bias, dilation)
+        if self.dilation != (1, 1) or self.groups != 1 or self.output_padding != (0, 0):
+            raise NotImplementedError
+        kh, kw = self.kernel_size
+        self._sg_trans = True
+        self._sg_dgrad_noflip = True
+        self._sg_setup("conv", out_channels, in_channels * kh * kw, in_channels, kh * kw, sn)
+
+    def forward_nhwc(self, x, slot=None):
+        rt = self._sg_rt
+        slot = slot if slot is not None else rt.bank().current
+        kh, kw = self.kernel_size
+        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1])
+        return F.ConvTransposeFn.apply(x, self.master_weight, self.bias, rt, slot, cfg)
+
+    def forward(self, x, output_size=None):
+        slot = _standalone_slot(self, x)
+        _, bank = _root_and_bank(self)
+        return to_nchw(self.forward_nhwc(to_nhwc(x, bank.dtype), slot))
 
 
 class Linear(_WeightLayerMixin, nn.Linear):
@@ -242,6 +268,14 @@ def snconv2d(in_channels, out_channels, kernel_size, stride=1, padding=0, dilati
     return Conv2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, sn=True)
 
 
+def deconv2d(in_channels, out_channels, kernel_size, stride=2, padding=0, dilation=1, groups=1, bias=True):
+    return ConvTranspose2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, sn=False)
+
+
+def sndeconv2d(in_channels, out_channels, kernel_size, stride=2, padding=0, dilation=1, groups=1, bias=True):
+    return ConvTranspose2d(in_channels, out_channels, kernel_size, stride, padding, dilation, groups, bias, sn=True)
+
+
 def linear(in_features, out_features, bias=True):
     return Linear(in_features, out_features, bias, sn=False)
 
@@ -302,6 +336,8 @@ class Modules:
 
     def __init__(self, apply_g_sn=False, apply_d_sn=False, g_cond_mtd="W/O", backbone="big_resnet", g_act_fn="ReLU", d_act_fn="ReLU"):
         self.g_conv2d = snconv2d if apply_g_sn else conv2d
+        self.g_deconv2d = sndeconv2d if apply_g_sn else deconv2d
+        self.d_deconv2d = sndeconv2d if apply_d_sn else deconv2d
         self.g_linear = snlinear if apply_g_sn else linear
         self.g_embedding = sn_embedding if apply_g_sn else embedding
         self.d_conv2d = snconv2d if apply_d_sn else conv2d

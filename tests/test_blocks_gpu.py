@@ -1,4 +1,4 @@
-"""GPU: whole-network forward/backward of the BigGAN G and D against the CPU oracle with NON-initial parameters
+"""GPU: whole-network forward/backward of every backbone's G and D against the CPU oracle with NON-initial parameters
 (attention gate sigma != 0, random biases) -- exercises every backward path including the ones that are dead at
 initialisation (attention branch, gradient w.r.t. the input image, the identity-skip block)."""
 import pytest
@@ -30,10 +30,14 @@ def _perturb(P, seed):
             P[k] = 1 + 0.2 * torch.randn(P[k].shape, generator=g)
 
 
+NAMES = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"]
+
+
 @pytest.mark.parametrize("mixed", [False, True])
-def test_discriminator_fwd_bwd(sg, mixed):
+@pytest.mark.parametrize("name", NAMES)
+def test_discriminator_fwd_bwd(sg, name, mixed):
     dev = torch.device("cuda:0")
-    fix, meta = load_golden("biggan32")
+    fix, meta = load_golden(name)
     y = meta["yaml"]
     ocfg = MG.oracle_cfg(y)
     P, B = _split(sub(fix, "D_init/"))
@@ -43,11 +47,11 @@ def test_discriminator_fwd_bwd(sg, mixed):
     D.train()
     x = fix["in/real0"].clone()
     lab = fix["in/rl0"]
-    gadv = torch.tensor([0.3, -1.0, 0.7, 0.5])
+    gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1])[:x.shape[0]]
     # oracle
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     xo = x.clone().requires_grad_(True)
-    adv_o, h_o = O.biggan_discriminator(xo, lab, leaves, B, ocfg)
+    adv_o, h_o = O.model_fns(ocfg)[1](xo, lab, leaves, B)
     (adv_o * gadv).sum().backward()
     # HIP path
     xd = x.to(dev).requires_grad_(True)
@@ -75,10 +79,11 @@ def test_discriminator_fwd_bwd(sg, mixed):
 
 @pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("bn_mode", ["track", "untrack", "eval"])
-def test_generator_fwd_bwd(sg, mixed, bn_mode):
+@pytest.mark.parametrize("name", NAMES)
+def test_generator_fwd_bwd(sg, name, mixed, bn_mode):
     from studiogan_amd import worker as W
     dev = torch.device("cuda:0")
-    fix, meta = load_golden("biggan32")
+    fix, meta = load_golden(name)
     y = meta["yaml"]
     ocfg = MG.oracle_cfg(y)
     P, B = _split(sub(fix, "G_init/"))
@@ -97,9 +102,9 @@ def test_generator_fwd_bwd(sg, mixed, bn_mode):
         G.train()
         G.apply(W.track_bn_statistics if bn_mode == "track" else W.untrack_bn_statistics)
     z, lab = fix["in/z0"], fix["in/fl0"]
-    gimg = torch.randn(4, 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    gimg = torch.randn(z.shape[0], 3, 32, 32, generator=torch.Generator().manual_seed(11))
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    img_o = O.biggan_generator(z, lab, leaves, B, ocfg, bn_mode=bn_mode)
+    img_o = O.model_fns(ocfg)[0](z, lab, leaves, B, bn_mode=bn_mode)
     (img_o * gimg).sum().backward()
     for p in G.parameters():
         p.grad = None

@@ -91,14 +91,15 @@ def test_module_names_and_sn_state():
     assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-4)
 
 
-def test_golden_state_dict_keys_match_backbone():
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"])
+def test_golden_state_dict_keys_match_backbone(name):
     from util import load_golden, sub
     from test_model_gpu import build_from_yaml
-    fix, meta = load_golden("biggan32")
+    fix, meta = load_golden(name)
     G, D = build_from_yaml(meta["yaml"], False, torch.device("cpu"))
     assert set(G.state_dict().keys()) == set(sub(fix, "G_init/").keys())
     assert set(D.state_dict().keys()) == set(sub(fix, "D_init/").keys())
     G.load_state_dict(sub(fix, "G_init/"), strict=True)
     D.load_state_dict(sub(fix, "D_init/"), strict=True)
     with pytest.raises(RuntimeError):
-        G(torch.randn(2, 40), torch.zeros(2, dtype=torch.long))  # CPU tensors: no fallback on the product path
+        G(torch.randn(2, G.z_dim), torch.zeros(2, dtype=torch.long))  # CPU tensors: no fallback on the product path

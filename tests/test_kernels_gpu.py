@@ -113,11 +113,50 @@ def test_conv_fwd_dgrad_wgrad(sg, dtype, case):
         dx = F.conv2d_raw(gyd, w_dg.data_ptr(), Cout, Cin, R, S, 1, R - 1 - ph, S - 1 - pw)
         torch.cuda.synchronize()
         check(f"conv dgrad {case}", nchw(dx.float().cpu()), xr.grad, tol)
+    else:
+        # strided convolution: data gradient = transposed gather over the UNflipped [Cin][R][S][Cout] image
+        w_dg = w.permute(1, 2, 3, 0).contiguous().to(d)
+        dx = F.conv2d_raw(gyd, w_dg.data_ptr(), Cout, Cin, R, S, stride, ph, pw, L.PIX_TRANSPOSED, transposed_out_hw=(H, W))
+        torch.cuda.synchronize()
+        check(f"conv strided dgrad {case}", nchw(dx.float().cpu()), xr.grad, tol)
     for no_tr in ([0, 1] if dtype == torch.bfloat16 else [0]):
         dw = torch.zeros((Cout, R, S, Cin), dtype=torch.float32, device=d)
         F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, S, Ho, Wo, stride, ph, pw, no_tr=no_tr)
         torch.cuda.synchronize()
         check(f"conv wgrad {case} no_tr={no_tr}", dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("case", [(2, 16, 24, 4, 4, 4, 2, 1), (3, 64, 32, 8, 8, 4, 2, 1), (2, 8, 8, 5, 6, 3, 1, 1), (1, 12, 20, 3, 3, 5, 3, 2)])
+def test_conv_transpose(sg, dtype, case):
+    """nn.ConvTranspose2d forward / data gradient / weight gradient (reference utils/ops.py:176-184; DCGAN generator
+    models/deep_conv.py:21) against F.conv_transpose2d in fp64."""
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, W, R, stride, pad = case
+    d = dev()
+    x = rnd((N, Cin, H, W), dtype, 21)
+    w = rnd((Cin, Cout, R, R), dtype, 22, 0.2)              # torch's ConvTranspose2d weight layout
+    bias = rnd((Cout,), torch.float32, 23)
+    tol = 2e-4 if dtype == torch.float32 else 4e-3
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yref = TF.conv_transpose2d(xr, wr, bias.double(), stride=stride, padding=pad)
+    Ho, Wo = yref.shape[2], yref.shape[3]
+    w_fwd = w.permute(1, 2, 3, 0).contiguous().to(d)        # [Cout][R][S][Cin], unflipped
+    xd = nhwc(x).to(d)
+    y = F.conv2d_raw(xd, w_fwd.data_ptr(), Cin, Cout, R, R, stride, pad, pad, L.PIX_TRANSPOSED, bias=bias.to(d), transposed_out_hw=(Ho, Wo))
+    torch.cuda.synchronize()
+    check(f"deconv fwd {case}", nchw(y.float().cpu()), yref, tol)
+    gy = rnd(tuple(yref.shape), dtype, 24)
+    yref.backward(gy.double())
+    gyd = nhwc(gy).to(d)
+    w_dg = w.permute(0, 2, 3, 1).contiguous().to(d)         # [Cin][R][S][Cout]
+    dx = F.conv2d_raw(gyd, w_dg.data_ptr(), Cout, Cin, R, R, stride, pad, pad)
+    torch.cuda.synchronize()
+    check(f"deconv dgrad {case}", nchw(dx.float().cpu()), xr.grad, tol)
+    dw = torch.zeros((Cin, R, R, Cout), dtype=torch.float32, device=d)   # roles of x and dy exchanged
+    F.conv2d_wgrad_raw(gyd, xd, dw.data_ptr(), Cout, Cin, R, R, H, W, stride, pad, pad)
+    torch.cuda.synchronize()
+    check(f"deconv wgrad {case}", dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
 
 
 @pytest.mark.parametrize("dtype", DT)

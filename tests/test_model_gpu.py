@@ -6,7 +6,7 @@ import copy
 import pytest
 import torch
 
-from util import check, load_golden, sub, Collector
+from util import check, load_golden, sub, Collector, hyper, absmax
 
 pytestmark = pytest.mark.gpu
 
@@ -30,7 +30,7 @@ def build_from_yaml(y, mixed, device):
 
 
 @pytest.mark.parametrize("mixed", [False, True])
-@pytest.mark.parametrize("name", ["biggan32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"])
 def test_training_step_vs_golden(sg, name, mixed):
     from studiogan_amd.worker import Worker
     dev = torch.device("cuda:0")
@@ -40,15 +40,15 @@ def test_training_step_vs_golden(sg, name, mixed):
     # the reference's state_dict loads with strict=True (reference src/utils/ckpt.py:38)
     G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
     D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
-    opt = y["OPTIMIZATION"]
-    w = Worker(G, D, y["MODEL"]["z_dim"], y["DATA"]["num_classes"], meta["batch"], y["LOSS"]["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"],
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"],
                opt["beta2"], d_updates_per_step=1, apply_g_ema=True, g_ema_decay=0.9, g_ema_start=0)
     ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
     exp = sub(fix, "exp/")
     t1 = 2e-4 if not mixed else 4e-2   # first-forward quantities
     t2 = 1e-3 if not mixed else 8e-2   # gradients / state after SN- and BN-state dependent steps
     C = Collector()
-    gmax = lambda pre: max(float(v.abs().max()) for k, v in exp.items() if k.startswith(pre))
+    gmax = lambda pre: max(absmax(v) for k, v in exp.items() if k.startswith(pre))
     dmax, gmx = gmax("D_grad0/"), gmax("G_grad/")
     for i in range(n_d):
         w.train_discriminator(0, [(ins[f"real{i}"], ins[f"rl{i}"])], [(ins[f"z{i}"], ins[f"fl{i}"])])

@@ -25,8 +25,9 @@ def _run_restatement(name):
     return fix, exp
 
 
-def test_restatement_matches_golden_biggan32():
-    fix, exp = _run_restatement("biggan32")
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"])
+def test_restatement_matches_golden(name):
+    fix, exp = _run_restatement(name)
     gold = sub(fix, "exp/")
     assert set(gold.keys()) == set(exp.keys())
     for k in sorted(gold.keys()):
@@ -34,14 +35,18 @@ def test_restatement_matches_golden_biggan32():
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
-def test_golden_regenerates_from_reference(tmp_path, monkeypatch):
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "dcgan32"])
+def test_golden_regenerates_from_reference(name):
     """The committed fixture is exactly what the reference produces today (guards against stale fixtures)."""
     from oracle import ref_import as R
-    fix, meta = load_golden("biggan32")
-    c = MG.CONFIGS["biggan32"]
+    fix, meta = load_golden(name)
+    c = MG.CONFIGS[name]
     cfgs = R.load_cfgs(c["yaml"])
     torch.manual_seed(c["seed"])
     Gen, Dis = R.build_models(cfgs)
+    if c.get("compact"):
+        Gen.load_state_dict(MG.formula_state(meta["G_spec"], c["seed"]), strict=True)
+        Dis.load_state_dict(MG.formula_state(meta["D_spec"], c["seed"] + 1), strict=True)
     ocfg = MG.oracle_cfg(c["yaml"])
     ins = MG.synth_inputs(c["seed"] + 1, c["n_d"], c["batch"], ocfg["z_dim"], ocfg["num_classes"], ocfg["img_size"])
     exp = MG.run_reference(cfgs, Gen, Dis, ins, c["n_d"])

@@ -8,8 +8,35 @@ import torch
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+class Sampled:
+    """Expected value of a LARGE tensor in a compact fixture (oracle/make_golden.py compact_entries): evenly spaced
+    samples plus [sum, l2] of the whole tensor."""
+
+    def __init__(self, values, norms):
+        self.values, self.norms = values, norms
+
+    def pick(self, a):
+        from oracle.make_golden import sample_index
+        flat = a.detach().reshape(-1)
+        return flat[sample_index(flat.numel()).to(flat.device)]
+
+    def absmax(self):
+        return float(self.values.abs().max())
+
+
+def absmax(v):
+    return v.absmax() if isinstance(v, Sampled) else float(v.abs().max())
+
+
+def _pair(a, b):
+    if isinstance(b, Sampled):
+        return b.pick(a), b.values
+    return a, b
+
+
 def rel_err(a, b):
     """max |a-b| relative to the range of the expected tensor b (the tolerance unit of SURVEY.md §8c)."""
+    a, b = _pair(a, b)
     a = a.detach().double().cpu().reshape(-1)
     b = b.detach().double().cpu().reshape(-1)
     assert a.shape == b.shape, f"shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
@@ -30,8 +57,25 @@ def check(name, a, b, tol, report=None):
 def load_golden(name):
     z = np.load(os.path.join(GOLDEN, name + ".npz"))
     meta = json.load(open(os.path.join(GOLDEN, name + ".json")))
-    fix = {k: torch.from_numpy(z[k]) for k in z.files}
+    fix = {k: torch.from_numpy(z[k]) for k in z.files if not k.startswith(("exps/", "expn/"))}
+    if meta.get("compact"):
+        # compact fixture: the initial state is a formula (numpy RandomState keyed by tensor name), large expected tensors are samples
+        from oracle.make_golden import formula_state
+        for k, v in formula_state(meta["G_spec"], meta["seed"]).items():
+            fix["G_init/" + k] = v
+        for k, v in formula_state(meta["D_spec"], meta["seed"] + 1).items():
+            fix["D_init/" + k] = v
+        for k in z.files:
+            if k.startswith("exps/"):
+                fix["exp/" + k[5:]] = Sampled(torch.from_numpy(z[k]), torch.from_numpy(z["expn/" + k[5:]]))
     return fix, meta
+
+
+def hyper(y):
+    """hyper-parameters of a fixture's yaml with the reference's defaults filled in (reference src/config.py:128,232-247)."""
+    M, O, Ls = y.get("MODEL", {}), y.get("OPTIMIZATION", {}), y.get("LOSS", {})
+    return dict(z_dim=M.get("z_dim", 128), adv_loss=Ls.get("adv_loss", "vanilla"), g_lr=O.get("g_lr", 0.0002), d_lr=O.get("d_lr", 0.0002),
+                beta1=O.get("beta1", 0.5), beta2=O.get("beta2", 0.999))
 
 
 def sub(fix, prefix):
@@ -54,6 +98,13 @@ class Collector:
         convolution feeding a batch norm) from being judged against their own rounding noise.
         l2=True: err = ||a-b||_2 / max(||b||_2, floor*sqrt(n)) -- the robust metric for bf16 gradients, where a few
         ReLU units flipping under 2^-9 relative rounding produce sparse O(1) element errors."""
+        if isinstance(b, Sampled):
+            # whole-tensor l2 norm first (catches errors between the sample points), then the samples
+            na, nb = float(a.detach().double().norm()), float(b.norms[1])
+            en = abs(na - nb) / max(nb, floor * (a.numel() ** 0.5), 1e-30)
+            self.rows.append((name + "#norm", en, tol))
+            print(f"{name + '#norm':52s} nrerr={en:.3e} tol={tol:.1e} {'ok' if en <= tol else 'FAIL'}")
+        a, b = _pair(a, b)
         a = a.detach().double().cpu().reshape(-1)
         b = b.detach().double().cpu().reshape(-1)
         assert a.shape == b.shape, f"{name}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
