@@ -48,6 +48,8 @@ def test_training_step_vs_golden(sg, name, mixed):
     t1 = 2e-4 if not mixed else 4e-2   # first-forward quantities
     t2 = 1e-3 if not mixed else 8e-2   # gradients / state after SN- and BN-state dependent steps
     C = Collector()
+    wide = bool(meta.get("compact"))   # full DCGAN widths: ~1e6 ReLU units per layer, a handful within fp32 rounding of 0 -> l2 metric
+    l2 = mixed or wide
     gmax = lambda pre: max(absmax(v) for k, v in exp.items() if k.startswith(pre))
     dmax, gmx = gmax("D_grad0/"), gmax("G_grad/")
     for i in range(n_d):
@@ -60,7 +62,7 @@ def test_training_step_vs_golden(sg, name, mixed):
             # gradients are still in the arena (the optimizer does not clear them); tensors that are analytically
             # zero are judged against 1e-3 of the network's gradient scale instead of their own rounding noise
             for k, p in D.named_parameters():
-                C.check("D_grad0/" + k, p.grad, exp["D_grad0/" + k], t2 if not mixed else 0.25, floor=(1e-2 if mixed else 1e-3) * dmax, l2=mixed)
+                C.check("D_grad0/" + k, p.grad, exp["D_grad0/" + k], (3e-3 if wide else t2) if not mixed else (0.4 if wide else 0.25), floor=1e-2 * dmax, l2=l2)
     ema_before = {k: v.detach().clone() for k, v in w.Gen_ema.named_parameters()}
     w.train_generator(0, [(ins[f"z{n_d}"], ins[f"fl{n_d}"])])
     C.check("fake_g", w.last_g[0], exp["fake_g"], t2)
@@ -69,15 +71,25 @@ def test_training_step_vs_golden(sg, name, mixed):
     # weights by 1e-6, see DESIGN.md "conditioning of the step test"); tight gradient parity is asserted on
     # single forward/backward passes in test_blocks_gpu.py instead.
     tg = 2e-2 if not mixed else 0.35
+    if wide:
+        # full-width DCGAN: measured on the oracle alone, the +-0.3 lr differences Adam makes out of rounding noise in D move
+        # these gradients by 4-10 % (test_training_step_stagewise_vs_oracle holds the same update to 1e-2 after a re-sync)
+        tg = 0.15 if not mixed else 0.6
     for k, p in G.named_parameters():
-        C.check("G_grad/" + k, p.grad, exp["G_grad/" + k], tg, floor=(1e-2 if mixed else 1e-3) * gmx, l2=mixed)
+        C.check("G_grad/" + k, p.grad, exp["G_grad/" + k], tg, floor=1e-2 * gmx, l2=l2)
     # final state: Adam moves every element by about +-lr per step whatever the gradient magnitude, so elements whose
     # gradient is ~0 may legitimately land one lr-kick apart -> floor the scale at 100 * lr
+    # ... and a parameter whose gradient is analytically 0 (conv bias in front of a BN) gets a +-lr kick of random sign
+    # per update from the normalised rounding noise: only |delta| <= 2 lr per update can be asserted for those.
     lr_floor = 100 * max(opt["g_lr"], opt["d_lr"])
+
+    def zero_grad_kick(fam, k, fam_max, lr, n_upd):
+        g = exp.get(fam + k)
+        return 2.2 * lr * n_upd if (g is not None and absmax(g) < 1e-4 * fam_max) else None
     for k, v in list(G.named_parameters()) + [(k, b) for k, b in G.named_buffers() if "_ones" not in k]:
-        C.check("G_final/" + k, v, exp["G_final/" + k], 4 * t2, floor=lr_floor)
+        C.check("G_final/" + k, v, exp["G_final/" + k], (3 if wide else 1) * 4 * t2, floor=lr_floor, abs_tol=zero_grad_kick("G_grad/", k, gmx, opt["g_lr"], 1))
     for k, v in list(D.named_parameters()) + list(D.named_buffers()):
-        C.check("D_final/" + k, v, exp["D_final/" + k], 4 * t2, floor=lr_floor)
+        C.check("D_final/" + k, v, exp["D_final/" + k], 4 * t2, floor=lr_floor, abs_tol=zero_grad_kick("D_grad0/", k, dmax, opt["d_lr"], n_d))
     # EMA generator: p_ema = lerp(p, p_ema, 0.9) after the step (utils/ema.py:27-35)
     for k, p in w.Gen_ema.named_parameters():
         ref = dict(G.named_parameters())[k].detach().lerp(ema_before[k], 0.9)
@@ -101,56 +113,79 @@ def test_state_dict_roundtrip_and_deepcopy(sg):
     check("deepcopy forward", a, b, 1e-6)
 
 
-@pytest.mark.parametrize("mixed", [False])
-def test_training_step_stagewise_vs_oracle(sg, mixed):
-    """Same step as above, with the CPU oracle executed side by side and compared after EVERY update (localises a
-    mismatch to the update that introduced it)."""
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"])
+def test_training_step_stagewise_vs_oracle(sg, name):
+    """Same step, fp32, with the CPU oracle executed side by side and compared after EVERY update; after each update
+    the oracle's parameters and buffers are RE-SYNCHRONISED from the HIP path, so every update is judged on identical
+    inputs. (Without that, Adam turns the rounding noise of elements with |g| ~ eps into +-lr-sized parameter
+    differences, and the next update's gradients amplify them through ReLU flips: measured on the ORACLE ALONE for
+    dcgan32, a 6e-5 relative perturbation of D's weights moves the generator gradient by 4-10 %, see DESIGN.md
+    "conditioning of the step test".)"""
     from studiogan_amd.worker import Worker
     from oracle import make_golden as MG
     from oracle import restate as O
     dev = torch.device("cuda:0")
-    fix, meta = load_golden("biggan32")
+    fix, meta = load_golden(name)
     y, n_d = meta["yaml"], meta["n_d"]
     ocfg = MG.oracle_cfg(y)
     isb = lambda k: any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))
     GI, DI = sub(fix, "G_init/"), sub(fix, "D_init/")
     GP, GB = {k: v.clone() for k, v in GI.items() if not isb(k)}, {k: v.clone() for k, v in GI.items() if isb(k)}
     DP, DB = {k: v.clone() for k, v in DI.items() if not isb(k)}, {k: v.clone() for k, v in DI.items() if isb(k)}
-    opt = y["OPTIMIZATION"]
+    opt = hyper(y)
+    kind = opt["adv_loss"]
     gen_fn, dis_fn = O.model_fns(ocfg)
     g_opt, d_opt = O.AdamState(GP, opt["g_lr"], opt["beta1"], opt["beta2"]), O.AdamState(DP, opt["d_lr"], opt["beta1"], opt["beta2"])
-    G, D = build_from_yaml(y, mixed, dev)
+    G, D = build_from_yaml(y, False, dev)
     G.load_state_dict({k: v.to(dev) for k, v in GI.items()}, strict=True)
     D.load_state_dict({k: v.to(dev) for k, v in DI.items()}, strict=True)
-    w = Worker(G, D, y["MODEL"]["z_dim"], y["DATA"]["num_classes"], meta["batch"], y["LOSS"]["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"],
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], kind, opt["g_lr"], opt["d_lr"], opt["beta1"],
                opt["beta2"], d_updates_per_step=1, apply_g_ema=False)
     ins = sub(fix, "in/")
     insd = {k: v.to(dev) for k, v in ins.items()}
     C = Collector()
+    wide = bool(meta.get("compact"))
     t = 5e-4
+    tg = 1e-2 if wide else 5e-4        # wide: l2 metric (a handful of ~1e6 ReLU units per layer sit within fp32 rounding of 0)
+
+    def resync(mod, P, Bf):
+        for k, p in mod.named_parameters():
+            P[k].copy_(p.detach().cpu())
+        for k, b in mod.named_buffers():
+            if k in Bf:
+                Bf[k].copy_(b.detach().cpu())
     for i in range(n_d):
-        out = O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [ins[f"real{i}"]], [ins[f"rl{i}"]], [ins[f"z{i}"]], [ins[f"fl{i}"]], "hinge", record=True)
+        out = O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [ins[f"real{i}"]], [ins[f"rl{i}"]], [ins[f"z{i}"]], [ins[f"fl{i}"]], kind, record=True)
         w.train_discriminator(0, [(insd[f"real{i}"], insd[f"rl{i}"])], [(insd[f"z{i}"], insd[f"fl{i}"])])
         C.check(f"[D{i}] fake", w.last_d[0], out["fake"], t)
         C.check(f"[D{i}] adv_r", w.last_d[1], out["adv_r"], t)
         C.check(f"[D{i}] adv_f", w.last_d[2], out["adv_f"], t)
         gm = max(float(v.abs().max()) for v in out["grads"].values())
         for k, p in D.named_parameters():
-            C.check(f"[D{i}] grad {k}", p.grad, out["grads"][k], t, floor=1e-3 * gm)
-        for k, p in D.named_parameters():
-            C.check(f"[D{i}] param {k}", p, DP[k], t, floor=0.05)
+            C.check(f"[D{i}] grad {k}", p.grad, out["grads"][k], tg, floor=1e-2 * gm, l2=wide)
+        for k, p in D.named_parameters():   # analytically-zero gradients get a +-lr kick of random sign from Adam: bound only
+            C.check(f"[D{i}] param|kick {k}", p, DP[k], 0, abs_tol=2.2 * opt["d_lr"])
+            if float(out["grads"][k].abs().max()) >= 1e-4 * gm:
+                C.check(f"[D{i}] param {k}", p, DP[k], t, floor=0.05, l2=True)
         for k, b in D.named_buffers():
             C.check(f"[D{i}] buf {k}", b, DB[k], t)
         for k, b in G.named_buffers():
             if "_ones" not in k:
                 C.check(f"[D{i}] Gbuf {k}", b, GB[k], t)
-    out = O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [ins[f"z{n_d}"]], [ins[f"fl{n_d}"]], "hinge", record=True)
+        resync(D, DP, DB)
+        resync(G, GP, GB)
+    out = O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [ins[f"z{n_d}"]], [ins[f"fl{n_d}"]], kind, record=True)
     w.train_generator(0, [(insd[f"z{n_d}"], insd[f"fl{n_d}"])])
     C.check("[G] fake", w.last_g[0], out["fake"], t)
     C.check("[G] adv_f", w.last_g[1], out["adv_f"], t)
     gm = max(float(v.abs().max()) for v in out["grads"].values())
     for k, p in G.named_parameters():
-        C.check(f"[G] grad {k}", p.grad, out["grads"][k], 2e-2, floor=1e-3 * gm)  # ReLU-kink conditioning, see above
+        # through every ReLU of D and G: one unit within rounding distance of 0 moves these by ~1e-2 of the maximum at this batch size
+        C.check(f"[G] grad {k}", p.grad, out["grads"][k], 1e-2 if wide else 2e-2, floor=1e-2 * gm, l2=wide)
+    for k, p in G.named_parameters():
+        C.check(f"[G] param|kick {k}", p, GP[k], 0, abs_tol=2.2 * opt["g_lr"])
+        if float(out["grads"][k].abs().max()) >= 1e-4 * gm:
+            C.check(f"[G] param {k}", p, GP[k], t, floor=0.05, l2=True)
     for k, b in D.named_buffers():
         C.check(f"[G] Dbuf {k}", b, DB[k], t)
     C.finish()

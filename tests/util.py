@@ -93,11 +93,13 @@ class Collector:
     def __init__(self):
         self.rows = []
 
-    def check(self, name, a, b, tol, floor=0.0, l2=False):
+    def check(self, name, a, b, tol, floor=0.0, l2=False, abs_tol=None):
         """err = max|a-b| / max(max|b|, floor): `floor` keeps tensors that are analytically ~0 (e.g. the bias of a
         convolution feeding a batch norm) from being judged against their own rounding noise.
-        l2=True: err = ||a-b||_2 / max(||b||_2, floor*sqrt(n)) -- the robust metric for bf16 gradients, where a few
-        ReLU units flipping under 2^-9 relative rounding produce sparse O(1) element errors."""
+        l2=True: err = ||a-b||_2 / max(||b||_2, floor*sqrt(n)) -- the robust metric where a few ReLU units whose
+        pre-activation sits within rounding distance of 0 flip and produce sparse O(1) element errors (bf16 gradients;
+        fp32 gradients of the full-width networks).  abs_tol: pass on max|a-b| <= abs_tol instead.
+        Both metrics are always printed."""
         if isinstance(b, Sampled):
             # whole-tensor l2 norm first (catches errors between the sample points), then the samples
             na, nb = float(a.detach().double().norm()), float(b.norms[1])
@@ -108,15 +110,16 @@ class Collector:
         a = a.detach().double().cpu().reshape(-1)
         b = b.detach().double().cpu().reshape(-1)
         assert a.shape == b.shape, f"{name}: shape mismatch {tuple(a.shape)} vs {tuple(b.shape)}"
-        finite = bool(torch.isfinite(a).all())
-        if not finite:
-            e = float("inf")
-        elif l2:
-            e = float((a - b).norm() / max(float(b.norm()), floor * (a.numel() ** 0.5), 1e-30))
+        if not bool(torch.isfinite(a).all()):
+            e = e2 = em = float("inf")
         else:
-            e = float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+            e2 = float((a - b).norm() / max(float(b.norm()), floor * (a.numel() ** 0.5), 1e-30))
+            em = float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+            e = e2 if l2 else em
+            if abs_tol is not None:
+                e, tol = float((a - b).abs().max()), abs_tol
         self.rows.append((name, e, tol))
-        print(f"{name:52s} {'l2' if l2 else 'mx'}err={e:.3e} tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
+        print(f"{name:52s} mx={em:.3e} l2={e2:.3e} [{'abs' if abs_tol is not None else 'l2' if l2 else 'mx'}] tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
         return e
 
     def finish(self):
