@@ -159,6 +159,19 @@ int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, l
                     const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu,
                     const double* chan, double count, int use_batch_stats, sg_stream_t s);
 
+/* second-order backward of BN's data gradient (WGAN-GP double backward; reference utils/losses.py:268-275,301-316 reach
+ * it through torch autograd). u = dL/d(dx). Per-channel gain only. sums[N][C][5] fp32 (caller zeroes) ->
+ * chan[C][5] fp64 = {sum u, sum u*xhat, sum dy', sum dy'*xhat, sum u*dy'} -> g_dy = dL/d(dy), g_x = dL/dx (either may be
+ * NULL), dgain += dL/dgain from this rank's chan_local and the all-reduced chan. */
+int sg_bn_bwd2_reduce(int dtype, const void* x, const void* dy, const void* u, int N, long long HW, int C, const float* mean,
+                      const float* invstd, const float* gain, const float* bias, int relu, float* sums, sg_stream_t s);
+int sg_bn_bwd2_finalize(const float* sums, int N, int C, double* chan, sg_stream_t s);
+int sg_bn_bwd2_dgain(const double* chan_local, const double* chan, double count, const float* invstd, int C,
+                     int use_batch_stats, float* dgain, sg_stream_t s);
+int sg_bn_bwd2_apply(int dtype, const void* x, const void* dy, const void* u, void* g_dy, void* g_x, int N, long long HW, int C,
+                     const float* mean, const float* invstd, const float* gain, const float* bias, int relu, const double* chan,
+                     double count, int use_batch_stats, sg_stream_t s);
+
 /* ---- spectral norm (torch.nn.utils.spectral_norm, eps 1e-6, one power iteration per forward) -------------- */
 typedef struct {
   const float* w;     /* weight_orig viewed as [rows][cols] (OIHW flattened; [num_embeddings][dim] for embeddings) */
@@ -204,6 +217,14 @@ int sg_pd_head_bwd(const float* h, const float* w1, const float* emb, const floa
  * mean-reduced loss written to d_real / d_fake */
 int sg_loss_d(int kind, const float* real, const float* fake, int B, float* loss, float* d_real, float* d_fake, sg_stream_t s);
 int sg_loss_g(int kind, const float* fake, int B, float* loss, float* d_fake, sg_stream_t s);
+
+/* WGAN-GP (reference utils/losses.py:301-316): interpolates[b] = alpha[b]*real[b] + (1-alpha[b])*fake[b] over rows of n
+ * floats; penalty = mean_b (||grads[b]||_2 - 1)^2 with norms[B] kept for the backward; dgrads = gout * d penalty / d grads.
+ * sg_masked_sum_hw: out[b][c] = sum_hw t[b,hw,c] * (x[b,hw,c] > 0)  (adjoint of sg_relu_sum_hw_bwd in the second-order pass) */
+int sg_interp_rows(const float* real, const float* fake, const float* alpha, float* out, int B, long long n, sg_stream_t s);
+int sg_gp_fwd(const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s);
+int sg_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s);
+int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B, int HW, int C, sg_stream_t s);
 
 /* ---- optimizer / EMA over flat arenas -------------------------------------------------------------------- */
 /* torch.optim.Adam (no amsgrad, no weight decay unless wd != 0) on a flat fp32 arena, fused with the EMA of

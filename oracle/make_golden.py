@@ -51,6 +51,21 @@ CONFIGS = {
               "LOSS": {"adv_loss": "vanilla"},
               "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.0002, "d_lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "d_updates_per_step": 2}},
         batch=4, n_d=2, seed=777),
+    # WGAN-GP (C5 family: configs/CIFAR10/WGAN-GP.yaml at width 8): wasserstein + gradient penalty (double backward through a
+    # discriminator with batch norm), unconditional, no spectral norm
+    "wgangp32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "resnet", "z_dim": 32, "g_conv_dim": 8, "d_conv_dim": 8},
+              "LOSS": {"adv_loss": "wasserstein", "apply_gp": True, "gp_lambda": 10.0},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.0002, "d_lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=555),
+    # the same penalty through a spectrally normalised projection discriminator with self-attention-free ResNet blocks
+    "sngp32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 32, "g_conv_dim": 8, "d_conv_dim": 8},
+              "LOSS": {"adv_loss": "hinge", "apply_gp": True, "gp_lambda": 10.0},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.0002, "d_lr": 0.0002, "beta1": 0.5, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=556),
     # DCGAN exactly as configs/CIFAR10/DCGAN.yaml (C1): widths are hard-coded in models/deep_conv.py (6.7 M parameters),
     # so the fixture is COMPACT: formula-generated initial state + samples/norms of the large expected tensors
     "dcgan32": dict(
@@ -135,8 +150,17 @@ def synth_inputs(seed, n_d, batch, z_dim, num_classes, img_size):
     return ins
 
 
-def run_reference(cfgs, Gen, Dis, ins, n_d):
+GP_SEED = 100000   # host-RNG seed (+ update index) in front of each gradient-penalty alpha draw (utils/losses.py:303)
+
+
+def gp_alpha(seed, i, batch):
+    torch.manual_seed(seed + GP_SEED + i)
+    return torch.rand(batch, 1)
+
+
+def run_reference(cfgs, Gen, Dis, ins, n_d, seed=0):
     misc = importlib.import_module("utils.misc")
+    ref_losses = importlib.import_module("utils.losses")
     cfgs.define_losses()
     cfgs.define_optimizer(Gen, Dis)
     g_opt, d_opt = cfgs.OPTIMIZATION.g_optimizer, cfgs.OPTIMIZATION.d_optimizer
@@ -151,6 +175,12 @@ def run_reference(cfgs, Gen, Dis, ins, n_d):
         rd = Dis(ins[f"real{i}"], ins[f"rl{i}"])
         fd = Dis(fake, ins[f"fl{i}"])
         loss = cfgs.LOSS.d_loss(rd["adv_output"], fd["adv_output"], DDP=False)
+        if cfgs.LOSS.apply_gp:   # src/worker.py:369-375
+            torch.manual_seed(seed + GP_SEED + i)
+            gp = ref_losses.cal_grad_penalty(real_images=ins[f"real{i}"], real_labels=ins[f"rl{i}"], fake_images=fake, discriminator=Dis, device="cpu")
+            loss = loss + cfgs.LOSS.gp_lambda * gp
+            if i == 0:
+                exp["gp0"] = gp.detach().clone()
         loss.backward()
         if i == 0:
             exp["fake0"], exp["adv_r0"], exp["adv_f0"] = fake.detach().clone(), rd["adv_output"].detach().clone(), fd["adv_output"].detach().clone()
@@ -179,18 +209,21 @@ def run_reference(cfgs, Gen, Dis, ins, n_d):
     return exp
 
 
-def run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d):
+def run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d, seed=0):
     """Same step through oracle/restate.py (this is also what the GPU tests execute as the checker)."""
     opt = y.get("OPTIMIZATION", {})
     g_lr, d_lr = opt.get("g_lr", 0.0002), opt.get("d_lr", 0.0002)
     b1, b2 = opt.get("beta1", 0.5), opt.get("beta2", 0.999)
     kind = y.get("LOSS", {}).get("adv_loss", "vanilla")
+    lam = y.get("LOSS", {}).get("gp_lambda", 10.0) if y.get("LOSS", {}).get("apply_gp", False) else None
     gen_fn, dis_fn = O.model_fns(ocfg)
     g_opt, d_opt = O.AdamState(GP, g_lr, b1, b2), O.AdamState(DP, d_lr, b1, b2)
     exp = {}
     for i in range(n_d):
         out = O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [ins[f"real{i}"]], [ins[f"rl{i}"]], [ins[f"z{i}"]], [ins[f"fl{i}"]], kind,
-                         record=(i == 0))
+                         record=(i == 0), gp_lambda=lam, gp_alpha=[gp_alpha(seed, i, ins[f"z{i}"].shape[0])] if lam is not None else None)
+        if i == 0 and lam is not None:
+            exp["gp0"] = out["gp"]
         if i == 0:
             exp["fake0"], exp["adv_r0"], exp["adv_f0"] = out["fake"], out["adv_r"], out["adv_f"]
             exp["d_loss0"] = torch.tensor(out["loss"])
@@ -239,8 +272,8 @@ def main():
                 fix["D_init/" + k] = v.clone()
         for k, v in ins.items():
             fix["in/" + k] = v
-        exp_ref = run_reference(cfgs, Gen, Dis, ins, c["n_d"])
-        exp_res = run_restatement(ocfg, y, GP, GB, DP, DB, ins, c["n_d"])
+        exp_ref = run_reference(cfgs, Gen, Dis, ins, c["n_d"], c["seed"])
+        exp_res = run_restatement(ocfg, y, GP, GB, DP, DB, ins, c["n_d"], c["seed"])
         worst = {}
         for k, v in exp_ref.items():
             fam = k.split("/")[0]

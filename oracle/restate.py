@@ -301,6 +301,17 @@ def g_loss(kind, fake):
     raise ValueError(kind)
 
 
+def grad_penalty(dis_fn, real, real_labels, fake, P, B, alpha):
+    """utils/losses.py:301-316 with alpha [B,1] given (the reference draws it with torch.rand(batch_size, 1) on the host
+    RNG, :303): penalty = mean_b (||d sum(D(x_b)) / d x_b||_2 - 1)^2 at x = alpha*real + (1-alpha)*fake."""
+    a = alpha.view(-1, 1, 1, 1)
+    x = (a * real + (1 - a) * fake).detach().requires_grad_(True)
+    adv, _ = dis_fn(x, real_labels, P, B)
+    g = torch.autograd.grad(outputs=adv, inputs=x, grad_outputs=torch.ones_like(adv), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    g = g.view(g.size(0), -1)
+    return ((g.norm(2, dim=1) - 1) ** 2).mean() + x[:, 0, 0, 0].mean() * 0
+
+
 # ---------------------------------------------------------------------------------------------------------
 # optimizer / EMA (config.py:541-563 torch.optim.Adam eps=1e-6; utils/ema.py:27-40)
 # ---------------------------------------------------------------------------------------------------------
@@ -350,7 +361,8 @@ def _leaves(P):
     return {k: v.detach().clone().requires_grad_(True) for k, v in P.items()}
 
 
-def d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, real, real_labels, z, fake_labels, loss_kind="hinge", record=False):
+def d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, real, real_labels, z, fake_labels, loss_kind="hinge", record=False, gp_lambda=None,
+             gp_alpha=None):
     """One discriminator update on pre-drawn (z, fake_labels, real) micro-batches (lists of length acml).
     G runs in train mode without BN-stat tracking and without a graph (worker.py:216-225)."""
     acml = len(z)
@@ -361,7 +373,12 @@ def d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, real, real_labels, z, fake_l
             fake = gen_fn(z[i], fake_labels[i], GP, GB, bn_mode="untrack")
         adv_r, _ = dis_fn(real[i], real_labels[i], leaves, DB)
         adv_f, _ = dis_fn(fake, fake_labels[i], leaves, DB)
-        loss = d_loss(loss_kind, adv_r, adv_f) / acml
+        loss = d_loss(loss_kind, adv_r, adv_f)
+        if gp_lambda is not None:   # worker.py:369-375
+            gp = grad_penalty(dis_fn, real[i], real_labels[i], fake, leaves, DB, gp_alpha[i])
+            loss = loss + gp_lambda * gp
+            out["gp"] = gp.detach()
+        loss = loss / acml
         loss.backward()
         out["loss"] += float(loss.detach())
         if record and i == 0:

@@ -98,6 +98,14 @@ _PROTOS = {
     "sg_bn_bwd_reduce": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "sg_bn_bwd_finalize": [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sg_bn_bwd_apply": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _i, _vp],
+    "sg_bn_bwd2_reduce": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
+    "sg_bn_bwd2_finalize": [_vp, _i, _i, _vp, _vp],
+    "sg_bn_bwd2_dgain": [_vp, _vp, C.c_double, _vp, _i, _i, _vp, _vp],
+    "sg_bn_bwd2_apply": [_i, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, _i, _vp],
+    "sg_interp_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "sg_gp_fwd": [_vp, _i, _ll, _vp, _vp, _vp],
+    "sg_gp_bwd": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "sg_masked_sum_hw": [_i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sg_sn_forward": [_i, _vp, C.POINTER(SnLayer), _i, _f, _vp, _ll, _vp],
     "sg_sn_backward": [_vp, C.POINTER(SnBwdLayer), _i, _vp, _ll, _vp],
     "sg_embedding_fwd": [_vp, _vp, _vp, _i, _i, _i, _vp],

@@ -470,3 +470,72 @@ extern "C" int sg_relu_mask(int dtype, const void* dy, const void* x, void* dx, 
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- WGAN-GP pieces (reference src/utils/losses.py:268-275,301-316) -----------------------------------------------
+// out[b,c] = sum_hw t[b,hw,c] * (x[b,hw,c] > 0): adjoint of sg_relu_sum_hw_bwd w.r.t. dh (second-order pass)
+template <typename T> __global__ void k_masked_sum_hw(const T* t, const T* x, float* out, int B, int HW, int C) {
+  long long total = (long long)B * C;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    int b = (int)(i / C), c = (int)(i % C);
+    const long long base = (long long)b * HW * C + c;
+    float acc = 0.f;
+    for (int k = 0; k < HW; k++) acc += (to_f<T>(x[base + (long long)k * C]) > 0.f) ? to_f<T>(t[base + (long long)k * C]) : 0.f;
+    out[i] = acc;
+  }
+}
+extern "C" int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B, int HW, int C, sg_stream_t s) {
+  SG_CHECK(t && x && out, "sg_masked_sum_hw: null");
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_masked_sum_hw<T>, dim3(nblk((long long)B * C, 256)), dim3(256), 0, (hipStream_t)s, (const T*)t, (const T*)x, out, B, HW, C));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// interpolates[b,:] = alpha[b] * real[b,:] + (1 - alpha[b]) * fake[b,:]      (losses.py:303-308)
+__global__ void k_interp_rows(const float* real, const float* fake, const float* alpha, float* out, long long n, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float a = alpha[i / n];
+    out[i] = a * real[i] + (1.f - a) * fake[i];
+  }
+}
+extern "C" int sg_interp_rows(const float* real, const float* fake, const float* alpha, float* out, int B, long long n, sg_stream_t s) {
+  SG_CHECK(real && fake && alpha && out && B > 0 && n > 0, "sg_interp_rows: bad args");
+  hipLaunchKernelGGL(k_interp_rows, dim3(nblk((long long)B * n, 256)), dim3(256), 0, (hipStream_t)s, real, fake, alpha, out, n, (long long)B * n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// norms[b] = ||grads[b,:]||_2 (one block per sample); penalty = mean_b (norms[b] - 1)^2     (losses.py:313-315)
+__global__ __launch_bounds__(256) void k_gp_norms(const float* grads, long long n, float* norms) {
+  __shared__ float sm[4];
+  const float* p = grads + (long long)blockIdx.x * n;
+  float acc = 0.f;
+  for (long long i = threadIdx.x; i < n; i += 256) acc += p[i] * p[i];
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(acc);
+}
+__global__ __launch_bounds__(256) void k_gp_loss(const float* norms, int B, float* loss) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  for (int b = threadIdx.x; b < B; b += 256) { const float d = norms[b] - 1.f; acc += d * d; }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss[0] = acc / (float)B;
+}
+extern "C" int sg_gp_fwd(const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s) {
+  SG_CHECK(grads && norms && loss && B > 0 && n > 0, "sg_gp_fwd: bad args");
+  hipLaunchKernelGGL(k_gp_norms, dim3(B), dim3(256), 0, (hipStream_t)s, grads, n, norms);
+  hipLaunchKernelGGL(k_gp_loss, dim3(1), dim3(256), 0, (hipStream_t)s, norms, B, loss);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// d penalty / d grads[b,:] = gout * (2/B) (1 - 1/norms[b]) grads[b,:]
+__global__ void k_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, long long total) {
+  const float go = gout[0] * 2.f / (float)B;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const float nb = norms[i / n];
+    dgrads[i] = go * (1.f - 1.f / nb) * grads[i];
+  }
+}
+extern "C" int sg_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s) {
+  SG_CHECK(grads && norms && gout && dgrads && B > 0 && n > 0, "sg_gp_bwd: bad args");
+  hipLaunchKernelGGL(k_gp_bwd, dim3(nblk((long long)B * n, 256)), dim3(256), 0, (hipStream_t)s, grads, norms, gout, dgrads, B, n, (long long)B * n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

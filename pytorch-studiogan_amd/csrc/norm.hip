@@ -276,3 +276,114 @@ extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* d
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- second-order backward (WGAN-GP: gradient of the gradient penalty through BN's data gradient) -------------------
+// First order (per channel, gain g_c, r = invstd, N = count, g = dy' after the ReLU mask):
+//     dx = g_c r ( g - mean(g) - xhat mean(g xhat) )
+// Given u = dL/d(dx), with  ub = mean(u), a = mean(u xhat), gb = mean(g), c = mean(g xhat), m = mean(u g):
+//     dL/d(dy) = mask * g_c r ( u - ub - xhat a )
+//     dL/dx    = g_c r^2 ( -c (u - ub) - a (g - gb) + xhat (3 a c - m + ub gb) )
+//     dL/dg_c  = r N ( m - ub gb - a c )                       (reference: torch autograd through F.batch_norm's backward,
+//                                                               reached from utils/losses.py:268-275,301-316)
+// stage 1: sums[n][c][5] = {sum u, sum u xhat, sum g, sum g xhat, sum u g}; caller zeroes sums
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd2_reduce(const T* x, const T* dy, const T* u, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int relu, float* sums, long long rpb) {
+  __shared__ float sm[5][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  const int n = blockIdx.z;
+  long long r0 = blockIdx.y * rpb, r1 = r0 + rpb; if (r1 > HW) r1 = HW;
+  float s[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c];
+    const float ga = gain ? gain[c] : 1.f;
+    const float bi = bias ? bias[c] : 0.f;
+    const long long base = (long long)n * HW * C + c;
+    for (long long r = r0 + ry; r < r1; r += 4) {
+      const float xh = (to_f<T>(x[base + r * C]) - mu) * is;
+      float g = to_f<T>(dy[base + r * C]);
+      if (relu && !(xh * ga + bi > 0.f)) g = 0.f;
+      const float uu = to_f<T>(u[base + r * C]);
+      s[0] += uu; s[1] += uu * xh; s[2] += g; s[3] += g * xh; s[4] += uu * g;
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < 5; k++) sm[k][ry][cx] = s[k];
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    float* o = sums + ((long long)n * C + c) * 5;
+#pragma unroll
+    for (int k = 0; k < 5; k++) unsafeAtomicAdd(o + k, sm[k][0][cx] + sm[k][1][cx] + sm[k][2][cx] + sm[k][3][cx]);
+  }
+}
+extern "C" int sg_bn_bwd2_reduce(int dtype, const void* x, const void* dy, const void* u, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int relu, float* sums, sg_stream_t s) {
+  SG_CHECK(x && dy && u && mean && invstd && sums, "sg_bn_bwd2_reduce: null");
+  SG_CHECK(N <= 65535, "sg_bn_bwd2_reduce: batch too large for grid.z");
+  int ct = (C + 63) / 64;
+  long long want = 2048 / ((long long)ct * N); if (want < 1) want = 1;
+  long long rpb = (HW + want - 1) / want; if (rpb < 16) rpb = 16;
+  int gy = (int)((HW + rpb - 1) / rpb);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd2_reduce<T>, dim3(ct, gy, N), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (const T*)u, HW, C, mean, invstd, gain, bias, relu, sums, rpb));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// stage 2: chan[c][5] (fp64) = sum over n
+__global__ void k_bn_bwd2_finalize(const float* sums, int N, int C, double* chan) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (int n = 0; n < N; n++)
+    for (int k = 0; k < 5; k++) a[k] += (double)sums[((long long)n * C + c) * 5 + k];
+  for (int k = 0; k < 5; k++) chan[5 * c + k] = a[k];
+}
+extern "C" int sg_bn_bwd2_finalize(const float* sums, int N, int C, double* chan, sg_stream_t s) {
+  SG_CHECK(sums && chan, "sg_bn_bwd2_finalize: null");
+  hipLaunchKernelGGL(k_bn_bwd2_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, sums, N, C, chan);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// gain gradient from this rank's own sums (chan_local) and the statistics of the whole (possibly cross-rank) batch (chan)
+__global__ void k_bn_bwd2_dgain(const double* chan_local, const double* chan, double count, const float* invstd, int C, int use_batch, float* dgain) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const double r = invstd[c];
+  double v;
+  if (use_batch) {
+    const double gb = chan[5 * c + 2] / count, cc = chan[5 * c + 3] / count;
+    v = r * (chan_local[5 * c + 4] - gb * chan_local[5 * c + 0] - cc * chan_local[5 * c + 1]);
+  } else v = r * chan_local[5 * c + 4];
+  dgain[c] += (float)v;
+}
+extern "C" int sg_bn_bwd2_dgain(const double* chan_local, const double* chan, double count, const float* invstd, int C, int use_batch_stats, float* dgain, sg_stream_t s) {
+  SG_CHECK(chan_local && chan && invstd && dgain && count > 0, "sg_bn_bwd2_dgain: bad args");
+  hipLaunchKernelGGL(k_bn_bwd2_dgain, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, chan_local, chan, count, invstd, C, use_batch_stats, dgain);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// stage 3: elementwise; g_dy and/or g_x may be null
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd2_apply(const T* x, const T* dy, const T* u, T* g_dy, T* g_x, long long total, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int relu, const double* chan, double count, int use_batch) {
+  const float invc = (float)(1.0 / count);
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C);
+    const float is = invstd[c];
+    const float xh = (to_f<T>(x[i]) - mean[c]) * is;
+    const float ga = gain ? gain[c] : 1.f;
+    const float bi = bias ? bias[c] : 0.f;
+    const bool on = !(relu && !(xh * ga + bi > 0.f));
+    const float g = on ? to_f<T>(dy[i]) : 0.f;
+    const float uu = to_f<T>(u[i]);
+    float ub = 0.f, a = 0.f, gb = 0.f, cc = 0.f, m = 0.f;
+    if (use_batch) {
+      ub = (float)chan[5 * c] * invc; a = (float)chan[5 * c + 1] * invc; gb = (float)chan[5 * c + 2] * invc;
+      cc = (float)chan[5 * c + 3] * invc; m = (float)chan[5 * c + 4] * invc;
+    }
+    if (g_dy) g_dy[i] = from_f<T>(on ? ga * is * (uu - ub - xh * a) : 0.f);
+    if (g_x) g_x[i] = from_f<T>(use_batch ? ga * is * is * (-cc * (uu - ub) - a * (g - gb) + xh * (3.f * a * cc - m + ub * gb)) : 0.f);
+  }
+}
+extern "C" int sg_bn_bwd2_apply(int dtype, const void* x, const void* dy, const void* u, void* g_dy, void* g_x, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int relu, const double* chan, double count, int use_batch_stats, sg_stream_t s) {
+  SG_CHECK(x && dy && u && mean && invstd && chan && count > 0 && (g_dy || g_x), "sg_bn_bwd2_apply: bad args");
+  const long long total = (long long)N * HW * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_bn_bwd2_apply<T>, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (const T*)u, (T*)g_dy, (T*)g_x, total, C, mean, invstd, gain, bias, relu, chan, count, use_batch_stats));
+  SG_LAUNCH_CHECK();
+  return 0;
+}

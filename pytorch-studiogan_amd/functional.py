@@ -11,6 +11,27 @@ from . import _lib as L
 from .bank import ensure_grad
 
 
+def _first_order_only(name):
+    """Functions without a differentiable backward refuse create_graph=True instead of silently cutting the graph."""
+    if torch.is_grad_enabled():
+        raise NotImplementedError(name + ": second-order gradients (create_graph=True) are implemented for the discriminator's "
+                                         "conv / BN / pooling / head path only (WGAN-GP)")
+
+
+def _param_grad_wanted(*params):
+    """Inside a backward: does the running graph task actually want the gradient of any of these leaves? (ctx.needs_input_grad
+    is static; autograd.grad(inputs=...) -- the gradient penalty -- only wants the image gradient.)"""
+    for p in params:
+        if p is None or not torch.is_tensor(p) or not p.requires_grad:
+            continue
+        try:
+            if torch._C._will_engine_execute_node(torch.autograd.graph.get_gradient_edge(p).node):
+                return True
+        except Exception:
+            return True
+    return False
+
+
 def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
@@ -112,6 +133,8 @@ class NchwToNhwcFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        if torch.is_grad_enabled():        # create_graph=True (WGAN-GP): stay on differentiable ops
+            return NhwcToNchwFn.apply(dy, False), None
         dy = _c(dy)
         N, H, W, Cc = dy.shape
         dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dy.device)
@@ -136,6 +159,7 @@ class NhwcToNchwFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only("NhwcToNchwFn")
         dy = _c(dy.float())
         N, Cc, H, W = dy.shape
         y = ctx.saved_tensors[0] if ctx.apply_tanh else None
@@ -155,6 +179,7 @@ class ConvertFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only("ConvertFn")
         dy = _c(dy)
         dx = torch.empty(dy.shape, dtype=ctx.src, device=dy.device)
         L.call("sg_convert", L.dt(dy), L.dt(ctx.src), L.ptr(dy), L.ptr(dx), dy.numel(), L.stream())
@@ -170,6 +195,65 @@ class ConvCfg:
     def __init__(self, R, S, stride=1, pad_h=0, pad_w=0, in_relu=False, in_upsample=False, out_pool=False):
         self.R, self.S, self.stride, self.pad_h, self.pad_w = R, S, stride, pad_h, pad_w
         self.in_relu, self.in_upsample, self.out_pool = in_relu, in_upsample, out_pool
+
+
+def _conv_dgrad(dy, x, rt, slot, cfg):
+    """data gradient of ConvFn's fused launch: dx = relu-mask(x) * F^T(dy), F = pool?(conv(up?(.))) * (0.25 if pool)."""
+    bank = rt.bank()
+    N, Hs, Ws, Cin = x.shape
+    up = 2 if cfg.in_upsample else 1
+    Hin, Win = Hs * up, Ws * up
+    pool = cfg.out_pool
+    if cfg.stride != 1:
+        # strided convolution: gather form of the transposed convolution with the UNflipped [Cin][r][s][Cout] image
+        assert not (pool or cfg.in_upsample), "upsample / pooling fusion is stride-1 only"
+        return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
+                          mask=x if cfg.in_relu else None, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
+    pf = L.PIX_UPSAMPLE if pool else 0
+    ef = L.EPI_POOL if cfg.in_upsample else 0
+    # dy has rows_pad channels, the dgrad image has K = R*S*rows: read the first `rows` channels at pitch rows_pad
+    return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
+                      mask=x if cfg.in_relu else None, alpha=0.25 if pool else 1.0, ldx=dy.shape[3])
+
+
+class ConvDgradFn(torch.autograd.Function):
+    """The data gradient of ConvFn as a differentiable op (second-order pass of the gradient penalty, reference
+    utils/losses.py:301-316). dx = M * F_W^T(dy) is linear in dy and in the weight image, so with t = M * ddx:
+        d/d(dy) = F_W(t)           -- the forward launch again, without bias / residual / ReLU-on-load
+        d/dW    = wgrad(t, dy)     -- the forward's weight-gradient launch with x := t, accumulated into the bank's scratch
+    (M, the ReLU mask of the saved input, is piecewise constant)."""
+
+    @staticmethod
+    def forward(ctx, dy, x, weight, rt, slot, cfg):
+        dy = _c(dy)
+        assert rt.rows_pad == rt.rows, "padded output channels are not supported on the second-order path"
+        ctx.save_for_backward(dy, x)
+        ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
+        return _conv_dgrad(dy, x, rt, slot, cfg)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        dy, x = ctx.saved_tensors
+        rt, slot, cfg = ctx.rt, ctx.slot, ctx.cfg
+        bank = rt.bank()
+        t = _c(ddx)
+        if cfg.in_relu:
+            m = torch.empty_like(t)
+            L.call("sg_relu_mask", L.dt(t), L.ptr(t), L.ptr(x), L.ptr(m), t.numel(), L.stream())
+            t = m
+        N, Hs, Ws, Cin = x.shape
+        up = 2 if cfg.in_upsample else 1
+        Ho = (Hs * up + 2 * cfg.pad_h - cfg.R) // cfg.stride + 1
+        Wo = (Ws * up + 2 * cfg.pad_w - cfg.S) // cfg.stride + 1
+        pool = cfg.out_pool
+        g_dy = None
+        if ctx.needs_input_grad[0]:
+            g_dy = conv2d_raw(t, bank.w_fwd(slot, rt), Cin, rt.rows, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w,
+                              L.PIX_UPSAMPLE if cfg.in_upsample else 0, L.EPI_POOL if pool else 0, alpha=0.25 if pool else 1.0)
+        if ctx.needs_input_grad[2]:
+            conv2d_wgrad_raw(t, dy, bank.dwt(slot, rt), Cin, rt.rows, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w,
+                             L.PIX_UPSAMPLE if cfg.in_upsample else 0, L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0)
+        return g_dy, None, None, None, None, None
 
 
 class ConvFn(torch.autograd.Function):
@@ -197,6 +281,7 @@ class ConvFn(torch.autograd.Function):
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
         ctx.bias = bias
+        ctx.weight = weight      # the master parameter: only handed on to ConvDgradFn so the second-order graph reaches it
         ctx.has_res = res is not None
         return y
 
@@ -205,6 +290,13 @@ class ConvFn(torch.autograd.Function):
         (x,) = ctx.saved_tensors
         rt, slot, cfg = ctx.rt, ctx.slot, ctx.cfg
         bank = rt.bank()
+        if torch.is_grad_enabled():
+            # create_graph=True (gradient penalty): the data gradient must itself be differentiable; parameter gradients
+            # of this first pass are not (the reference only ever takes it w.r.t. the input image, losses.py:268-275)
+            if _param_grad_wanted(ctx.weight, ctx.bias):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP path)")
+            dx = ConvDgradFn.apply(dy, x, ctx.weight, rt, slot, cfg) if ctx.needs_input_grad[0] else None
+            return dx, None, None, (dy if ctx.has_res else None), None, None, None
         dy = _c(dy)
         N, Hs, Ws, Cin = x.shape
         up = 2 if cfg.in_upsample else 1
@@ -215,17 +307,7 @@ class ConvFn(torch.autograd.Function):
         scale = 0.25 if pool else 1.0
         dx = None
         if ctx.needs_input_grad[0]:
-            if cfg.stride != 1:
-                # strided convolution: gather form of the transposed convolution with the UNflipped [Cin][r][s][Cout] image
-                assert not (pool or cfg.in_upsample), "upsample / pooling fusion is stride-1 only"
-                dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
-                                mask=x if cfg.in_relu else None, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
-        if ctx.needs_input_grad[0] and cfg.stride == 1:
-            pf = L.PIX_UPSAMPLE if pool else 0
-            ef = L.EPI_POOL if cfg.in_upsample else 0
-            # dy has rows_pad channels, the dgrad image has K = R*S*rows: read the first `rows` channels at pitch rows_pad
-            dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
-                            mask=x if cfg.in_relu else None, alpha=scale, ldx=dy.shape[3])
+            dx = _conv_dgrad(dy, x, rt, slot, cfg)
         if ctx.needs_input_grad[1]:
             xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
             gf = L.PIX_UPSAMPLE if pool else 0
@@ -259,6 +341,7 @@ class ConvTransposeFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only("ConvTransposeFn")
         (x,) = ctx.saved_tensors
         rt, slot, cfg = ctx.rt, ctx.slot, ctx.cfg
         bank = rt.bank()
@@ -294,6 +377,7 @@ class LinearFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only("LinearFn")
         (x,) = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
         bank = rt.bank()
@@ -330,6 +414,7 @@ class EmbeddingFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _first_order_only("EmbeddingFn")
         (idx,) = ctx.saved_tensors
         w = ctx.weight
         if ctx.needs_input_grad[0]:
@@ -355,6 +440,7 @@ class SNEmbeddingFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dout):
+        _first_order_only("SNEmbeddingFn")
         (idx,) = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
         if ctx.needs_input_grad[0]:
@@ -426,6 +512,11 @@ class BNFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, gain, bias, mean, invstd = ctx.saved_tensors
         cfg, gsn = ctx.cfg, ctx.gsn
+        if torch.is_grad_enabled():
+            if gsn or _param_grad_wanted(gain, bias):
+                raise NotImplementedError("create_graph=True is supported for the input gradient of per-channel BN only (WGAN-GP path)")
+            dx = BNBwdFn.apply(dy, x, gain, bias, mean, invstd, cfg, ctx.count) if ctx.needs_input_grad[0] else None
+            return dx, None, None, None, None, None
         dy = _c(dy)
         N, H, W, Cc = x.shape
         HW = H * W
@@ -447,6 +538,60 @@ class BNFn(torch.autograd.Function):
         return dx, dgain, dbias, None, None, None
 
 
+class BNBwdFn(torch.autograd.Function):
+    """BN's data gradient dx(dy, x, gain) as a differentiable op (statistics are functions of x): the second-order pass
+    of the gradient penalty through a discriminator that uses batch norm (WGAN-GP.yaml: no SN => BN in D). Formulas and
+    kernels: csrc/norm.hip "second-order backward"."""
+
+    @staticmethod
+    def forward(ctx, dy, x, gain, bias, mean, invstd, cfg, count):
+        dy = _c(dy)
+        N, H, W, Cc = x.shape
+        dev = x.device
+        sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
+        L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), 0,
+               1 if cfg.relu else 0, L.ptr(sums), L.stream())
+        chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+        L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), 0, None, None, L.ptr(chan), L.stream())
+        if cfg.batch_stats and _world(cfg.group) > 1:
+            dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+        dx = torch.empty_like(x)
+        L.call("sg_bn_bwd_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
+               0, 1 if cfg.relu else 0, L.ptr(chan), count, 1 if cfg.batch_stats else 0, L.stream())
+        ctx.save_for_backward(dy, x, gain, bias, mean, invstd)
+        ctx.cfg, ctx.count = cfg, count
+        return dx
+
+    @staticmethod
+    def backward(ctx, u):
+        dy, x, gain, bias, mean, invstd = ctx.saved_tensors
+        cfg = ctx.cfg
+        u = _c(u)
+        N, H, W, Cc = x.shape
+        dev = x.device
+        relu = 1 if cfg.relu else 0
+        sums = torch.zeros((N, Cc, 5), dtype=torch.float32, device=dev)
+        L.call("sg_bn_bwd2_reduce", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(u), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), relu,
+               L.ptr(sums), L.stream())
+        chan_local = torch.empty(5 * Cc, dtype=torch.float64, device=dev)
+        L.call("sg_bn_bwd2_finalize", L.ptr(sums), N, Cc, L.ptr(chan_local), L.stream())
+        chan = chan_local
+        if cfg.batch_stats and _world(cfg.group) > 1:
+            chan = chan_local.clone()
+            dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+        use_batch = 1 if cfg.batch_stats else 0
+        g_dy = torch.empty_like(x) if ctx.needs_input_grad[0] else None
+        g_x = torch.empty_like(x) if ctx.needs_input_grad[1] else None
+        if g_dy is not None or g_x is not None:
+            L.call("sg_bn_bwd2_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(u), L.ptr(g_dy), L.ptr(g_x), N, H * W, Cc, L.ptr(mean), L.ptr(invstd),
+                   L.ptr(gain), L.ptr(bias), relu, L.ptr(chan), ctx.count, use_batch, L.stream())
+        dgain = None
+        if gain is not None and ctx.needs_input_grad[2]:
+            dgain = torch.zeros_like(gain)
+            L.call("sg_bn_bwd2_dgain", L.ptr(chan_local), L.ptr(chan), ctx.count, L.ptr(invstd), Cc, use_batch, L.ptr(dgain), L.stream())
+        return g_dy, g_x, dgain, None, None, None, None, None
+
+
 # ---------------------------------------------------------------------------------------------------------
 # small elementwise ops of the D blocks
 # ---------------------------------------------------------------------------------------------------------
@@ -462,11 +607,34 @@ class AvgPool2Fn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        dy = _c(dy)
+        if torch.is_grad_enabled():
+            return AvgPool2BwdFn.apply(dy, ctx.shape)
+        return _avgpool2_bwd(dy, ctx.shape)
+
+
+def _avgpool2_bwd(dy, shape):
+    dy = _c(dy)
+    N, H, W, Cc = shape
+    dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    L.call("sg_avgpool2_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, H, W, Cc, L.stream())
+    return dx
+
+
+class AvgPool2BwdFn(torch.autograd.Function):
+    """0.25 * broadcast of the pooled gradient; its adjoint is the pooling itself (second-order pass)."""
+
+    @staticmethod
+    def forward(ctx, dy, shape):
+        ctx.shape = shape
+        return _avgpool2_bwd(dy, shape)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        ddx = _c(ddx)
         N, H, W, Cc = ctx.shape
-        dx = torch.empty((N, H, W, Cc), dtype=dy.dtype, device=dy.device)
-        L.call("sg_avgpool2_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, H, W, Cc, L.stream())
-        return dx
+        g = torch.empty((N, H // 2, W // 2, Cc), dtype=ddx.dtype, device=ddx.device)
+        L.call("sg_avgpool2_fwd", L.dt(ddx), L.ptr(ddx), L.ptr(g), N, H, W, Cc, L.stream())
+        return g, None
 
 
 class AddFn(torch.autograd.Function):
@@ -485,6 +653,27 @@ class AddFn(torch.autograd.Function):
         return dy, dy
 
 
+def _mask(dy, x):
+    dy = _c(dy)
+    dx = torch.empty_like(x)
+    L.call("sg_relu_mask", L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream())
+    return dx
+
+
+class MaskFn(torch.autograd.Function):
+    """dy * (x > 0) as a differentiable op of dy (x's mask is piecewise constant): the ReLU backward inside a create_graph pass."""
+
+    @staticmethod
+    def forward(ctx, dy, x):
+        ctx.save_for_backward(x)
+        return _mask(dy, x)
+
+    @staticmethod
+    def backward(ctx, dd):
+        (x,) = ctx.saved_tensors
+        return _mask(dd, x), None
+
+
 class ReluFn(torch.autograd.Function):
     """standalone ReLU (only where no neighbouring launch can absorb it): y = x * (x > 0)."""
 
@@ -499,10 +688,7 @@ class ReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dy = _c(dy)
-        dx = torch.empty_like(x)
-        L.call("sg_relu_mask", L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream())
-        return dx
+        return MaskFn.apply(dy, x) if torch.is_grad_enabled() else _mask(dy, x)
 
 
 class AddReluFn(torch.autograd.Function):
@@ -520,11 +706,9 @@ class AddReluFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        dy = _c(dy)
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x)
-            L.call("sg_relu_mask", L.dt(x), L.ptr(dy), L.ptr(x), L.ptr(dx), x.numel(), L.stream())
+            dx = MaskFn.apply(dy, x) if torch.is_grad_enabled() else _mask(dy, x)
         return dy, dx
 
 
@@ -563,6 +747,7 @@ class AttnCoreFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, do):
+        _first_order_only("AttnCoreFn")
         theta, phi, g, idx_phi, idx_g, P = ctx.saved_tensors
         B, H, W, Dp, Cg = ctx.dims
         HW, HW4 = H * W, (H // 2) * (W // 2)
@@ -606,6 +791,7 @@ class AttnOutFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
+        _first_order_only("AttnOutFn")
         o, sigma = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
         bank = rt.bank()
@@ -641,11 +827,31 @@ class ReluSumFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dh):
         (x,) = ctx.saved_tensors
+        return ReluSumBwdFn.apply(dh, x) if torch.is_grad_enabled() else _relu_sum_bwd(dh, x)
+
+
+def _relu_sum_bwd(dh, x):
+    B, H, W, Cc = x.shape
+    dh = _c(dh.float())
+    dx = torch.empty_like(x)
+    L.call("sg_relu_sum_hw_bwd", L.dt(x), L.ptr(x), L.ptr(dh), L.ptr(dx), B, H * W, Cc, L.stream())
+    return dx
+
+
+class ReluSumBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dh, x):
+        ctx.save_for_backward(x)
+        return _relu_sum_bwd(dh, x)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (x,) = ctx.saved_tensors
+        ddx = _c(ddx)
         B, H, W, Cc = x.shape
-        dh = _c(dh.float())
-        dx = torch.empty_like(x)
-        L.call("sg_relu_sum_hw_bwd", L.dt(x), L.ptr(x), L.ptr(dh), L.ptr(dx), B, H * W, Cc, L.stream())
-        return dx
+        g = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        L.call("sg_masked_sum_hw", L.dt(x), L.ptr(ddx), L.ptr(x), L.ptr(g), B, H * W, Cc, L.stream())
+        return g, None
 
 
 class PDHeadFn(torch.autograd.Function):
@@ -667,6 +873,7 @@ class PDHeadFn(torch.autograd.Function):
         ctx.save_for_backward(h, emb, labels if rt_emb is not None else None)
         ctx.rts = (rt_lin, rt_emb, slot)
         ctx.b1 = b1
+        ctx.w1, ctx.emb_w = w1, emb_w    # master parameters, handed on to PDHeadBwdFn in a create_graph pass
         return adv
 
     @staticmethod
@@ -674,6 +881,11 @@ class PDHeadFn(torch.autograd.Function):
         h, emb, labels = ctx.saved_tensors
         rt_lin, rt_emb, slot = ctx.rts
         bank = rt_lin.bank()
+        if torch.is_grad_enabled():
+            if _param_grad_wanted(ctx.w1, ctx.emb_w, ctx.b1):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP path)")
+            dh = PDHeadBwdFn.apply(dadv, ctx.w1, ctx.emb_w, emb, labels, rt_lin, rt_emb, slot) if ctx.needs_input_grad[0] else None
+            return dh, None, None, None, None, None, None, None
         B, Cc = h.shape
         dadv = _c(dadv.float())
         dh = torch.empty_like(h)
@@ -685,6 +897,81 @@ class PDHeadFn(torch.autograd.Function):
         if emb is not None and ctx.needs_input_grad[3]:
             L.call("sg_embedding_bwd", L.ptr(demb), L.ptr(labels), bank.dwt(slot, rt_emb), B, Cc, rt_emb.rows, L.stream())
         return dh, None, None, None, None, None, None, None
+
+
+class PDHeadBwdFn(torch.autograd.Function):
+    """dh[b] = dadv[b] * (w1 + emb[y_b]) as a differentiable op of (dadv, w1, embedding): the same two head kernels with
+    the roles h := ddh (second-order pass of the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, dadv, w1, emb_w, emb, labels, rt_lin, rt_emb, slot):
+        bank = rt_lin.bank()
+        dadv = _c(dadv.float())
+        B = dadv.numel()
+        Cc = rt_lin.cols
+        dev = dadv.device
+        dh = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+        scratch = torch.zeros(Cc + 1, dtype=torch.float32, device=dev)
+        hz = torch.zeros((B, Cc), dtype=torch.float32, device=dev)
+        demb = torch.empty((B, Cc), dtype=torch.float32, device=dev) if emb is not None else None
+        L.call("sg_pd_head_bwd", L.ptr(hz), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(dh), L.ptr(scratch), None, L.ptr(demb), B, Cc, L.stream())
+        ctx.save_for_backward(dadv, emb, labels)
+        ctx.rts = (rt_lin, rt_emb, slot)
+        return dh
+
+    @staticmethod
+    def backward(ctx, ddh):
+        dadv, emb, labels = ctx.saved_tensors
+        rt_lin, rt_emb, slot = ctx.rts
+        bank = rt_lin.bank()
+        ddh = _c(ddh.float())
+        B, Cc = ddh.shape
+        dev = ddh.device
+        g_dadv = None
+        if ctx.needs_input_grad[0]:
+            g_dadv = torch.empty(B, dtype=torch.float32, device=dev)
+            L.call("sg_pd_head_fwd", L.ptr(ddh), bank.w_f32(slot, rt_lin), None, L.ptr(emb), L.ptr(g_dadv), B, Cc, L.stream())
+        if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
+            dw1 = bank.dwt(slot, rt_lin) if ctx.needs_input_grad[1] else L.ptr(torch.zeros(Cc, dtype=torch.float32, device=dev))
+            demb = torch.empty((B, Cc), dtype=torch.float32, device=dev) if emb is not None else None
+            scratch = torch.empty((B, Cc), dtype=torch.float32, device=dev)
+            L.call("sg_pd_head_bwd", L.ptr(ddh), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(scratch), dw1, None, L.ptr(demb), B, Cc, L.stream())
+            if emb is not None and ctx.needs_input_grad[2]:
+                L.call("sg_embedding_bwd", L.ptr(demb), L.ptr(labels), bank.dwt(slot, rt_emb), B, Cc, rt_emb.rows, L.stream())
+        return g_dadv, None, None, None, None, None, None, None
+
+
+class GradPenaltyFn(torch.autograd.Function):
+    """mean_b (||grads[b]||_2 - 1)^2  (reference utils/losses.py:313-315)."""
+
+    @staticmethod
+    def forward(ctx, grads):
+        grads = _c(grads.float())
+        B = grads.shape[0]
+        n = grads.numel() // B
+        norms = torch.empty(B, dtype=torch.float32, device=grads.device)
+        loss = torch.empty(1, dtype=torch.float32, device=grads.device)
+        L.call("sg_gp_fwd", L.ptr(grads), B, n, L.ptr(norms), L.ptr(loss), L.stream())
+        ctx.save_for_backward(grads, norms)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        grads, norms = ctx.saved_tensors
+        B = grads.shape[0]
+        g = _c(gout.float().reshape(1))
+        d = torch.empty_like(grads)
+        L.call("sg_gp_bwd", L.ptr(grads), L.ptr(norms), L.ptr(g), L.ptr(d), B, grads.numel() // B, L.stream())
+        return d
+
+
+def interpolate_rows(real, fake, alpha):
+    """alpha[b] * real[b] + (1 - alpha[b]) * fake[b]  (reference utils/losses.py:303-308); fp32 NCHW in and out."""
+    real, fake, alpha = _c(real.float()), _c(fake.float()), _c(alpha.float().reshape(-1))
+    out = torch.empty_like(real)
+    B = real.shape[0]
+    L.call("sg_interp_rows", L.ptr(real), L.ptr(fake), L.ptr(alpha), L.ptr(out), B, real.numel() // B, L.stream())
+    return out
 
 
 _LOSS_KIND = {"hinge": 0, "wasserstein": 1, "vanilla": 2}

@@ -1,5 +1,8 @@
 """Adversarial losses with the reference's names and call signature (reference src/utils/losses.py:197-239,
 wired by src/config.py:411-433 as cfgs.LOSS.{d_loss,g_loss}); forward + gradient in one small kernel each."""
+import torch
+from torch import autograd
+
 from . import functional as F
 
 
@@ -29,3 +32,22 @@ def g_vanilla(d_logit_fake, DDP=False):
 
 G_LOSSES = {"vanilla": g_vanilla, "hinge": g_hinge, "wasserstein": g_wasserstein}
 D_LOSSES = {"vanilla": d_vanilla, "hinge": d_hinge, "wasserstein": d_wasserstein}
+
+
+def cal_deriv(inputs, outputs, device):
+    """reference src/utils/losses.py:268-275: d(sum outputs)/d(inputs) with a graph for the second-order pass."""
+    grads = autograd.grad(outputs=outputs, inputs=inputs, grad_outputs=torch.ones(outputs.size(), device=outputs.device),
+                          create_graph=True, retain_graph=True, only_inputs=True)[0]
+    return grads
+
+
+def cal_grad_penalty(real_images, real_labels, fake_images, discriminator, device):
+    """WGAN-GP gradient penalty, reference src/utils/losses.py:301-316 (alpha is drawn on the host RNG like the reference
+    does, so identical seeds give identical interpolates). The discriminator's backward runs once more as differentiable
+    ops (functional.ConvDgradFn / BNBwdFn / ...), and penalty.backward() then walks the second-order graph."""
+    batch_size = real_images.shape[0]
+    alpha = torch.rand(batch_size, 1).to(real_images.device)
+    interpolates = F.interpolate_rows(real_images, fake_images.detach(), alpha).requires_grad_(True)
+    fake_dict = discriminator(interpolates, real_labels, eval=False)
+    grads = cal_deriv(inputs=interpolates, outputs=fake_dict["adv_output"], device=device)
+    return F.GradPenaltyFn.apply(grads)

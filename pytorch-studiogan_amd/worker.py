@@ -65,8 +65,9 @@ def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
 class Worker:
     def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
-                 group=None):
+                 group=None, apply_gp=False, gp_lambda=10.0):
         self.Gen, self.Dis = Gen, Dis
+        self.apply_gp, self.gp_lambda = apply_gp, gp_lambda
         self.z_dim, self.num_classes, self.batch_size = z_dim, num_classes, batch_size
         self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
         self.n_d, self.n_g, self.acml = d_updates_per_step, g_updates_per_step, acml_steps
@@ -99,6 +100,11 @@ class Worker:
                 fake_dict = self.Dis(fake_images, fake_labels)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
                 dis_acml_loss = self.d_loss(real_dict["adv_output"], fake_dict["adv_output"], DDP=self.group is not None)
+                if self.apply_gp:   # src/worker.py:369-375
+                    gp_loss = sg_losses.cal_grad_penalty(real_images=real_images, real_labels=real_labels, fake_images=fake_images,
+                                                         discriminator=self.Dis, device=self.device)
+                    self.last_gp = gp_loss.detach()
+                    dis_acml_loss = dis_acml_loss + self.gp_lambda * gp_loss
                 dis_acml_loss = dis_acml_loss / self.acml
                 dis_acml_loss.backward()
             self.d_optimizer.step(group=self.group)

@@ -133,3 +133,46 @@ def test_generator_fwd_bwd(sg, name, mixed, bn_mode):
         if "_ones" not in k:
             C.check("G buf " + k, b, B[k], t)
     C.finish()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "resgan32", "sngan32", "dcgan32", "sndcgan32"])
+def test_gradient_penalty_double_backward(sg, name, mixed):
+    """WGAN-GP penalty (reference utils/losses.py:301-316) and its gradient w.r.t. every discriminator parameter -- the
+    double backward through conv (stride 1 / 2, fused ReLU / pooling), batch norm with batch statistics, pooling, the
+    projection head and spectral norm -- against torch autograd's own double backward over the CPU oracle."""
+    from studiogan_amd import losses as SL
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 5)
+    _, D = build_from_yaml(y, mixed, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    real, lab = fix["in/real0"].clone(), fix["in/rl0"]
+    fake = fix["in/real1"].flip(0).clone() * 0.7
+    alpha = MG.gp_alpha(meta["seed"], 0, real.shape[0])
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    gp_o = O.grad_penalty(O.model_fns(ocfg)[1], real, lab, fake, leaves, B, alpha)
+    gp_o.backward()
+    for p in D.parameters():
+        p.grad = None
+    torch.manual_seed(meta["seed"] + MG.GP_SEED)
+    gp = SL.cal_grad_penalty(real.to(dev), lab.to(dev), fake.to(dev), D, dev)
+    gp.backward()
+    torch.cuda.synchronize()
+    C = Collector()
+    wide = bool(meta.get("compact"))
+    t = 5e-4 if not mixed else 5e-2
+    tg = (6e-3 if wide else 1e-3) if not mixed else 0.3
+    l2 = mixed or wide
+    C.check("penalty", gp, gp_o, t)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, p in D.named_parameters():
+        go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        C.check("gp grad " + k, p.grad if p.grad is not None else torch.zeros_like(p), go, tg, floor=(5e-2 if mixed else 1e-2) * gmax, l2=l2)
+    for k, b in D.named_buffers():
+        C.check("D buf " + k, b, B[k], t)
+    C.finish()

@@ -21,11 +21,11 @@ def _run_restatement(name):
     bnames = lambda d: {k: v.clone() for k, v in d.items() if any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))}
     GP, GB, DP, DB = pnames(GI), bnames(GI), pnames(DI), bnames(DI)
     ins = sub(fix, "in/")
-    exp = MG.run_restatement(ocfg, y, GP, GB, DP, DB, ins, meta["n_d"])
+    exp = MG.run_restatement(ocfg, y, GP, GB, DP, DB, ins, meta["n_d"], meta["seed"])
     return fix, exp
 
 
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32"])
 def test_restatement_matches_golden(name):
     fix, exp = _run_restatement(name)
     gold = sub(fix, "exp/")
@@ -35,7 +35,7 @@ def test_restatement_matches_golden(name):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "dcgan32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "dcgan32", "wgangp32"])
 def test_golden_regenerates_from_reference(name):
     """The committed fixture is exactly what the reference produces today (guards against stale fixtures)."""
     from oracle import ref_import as R
@@ -49,7 +49,7 @@ def test_golden_regenerates_from_reference(name):
         Dis.load_state_dict(MG.formula_state(meta["D_spec"], c["seed"] + 1), strict=True)
     ocfg = MG.oracle_cfg(c["yaml"])
     ins = MG.synth_inputs(c["seed"] + 1, c["n_d"], c["batch"], ocfg["z_dim"], ocfg["num_classes"], ocfg["img_size"])
-    exp = MG.run_reference(cfgs, Gen, Dis, ins, c["n_d"])
+    exp = MG.run_reference(cfgs, Gen, Dis, ins, c["n_d"], c["seed"])
     for k in ("fake0", "adv_r0", "d_loss0", "g_loss"):
         check("ref:" + k, exp[k], fix["exp/" + k], 1e-6)
 

@@ -75,7 +75,7 @@ def hyper(y):
     """hyper-parameters of a fixture's yaml with the reference's defaults filled in (reference src/config.py:128,232-247)."""
     M, O, Ls = y.get("MODEL", {}), y.get("OPTIMIZATION", {}), y.get("LOSS", {})
     return dict(z_dim=M.get("z_dim", 128), adv_loss=Ls.get("adv_loss", "vanilla"), g_lr=O.get("g_lr", 0.0002), d_lr=O.get("d_lr", 0.0002),
-                beta1=O.get("beta1", 0.5), beta2=O.get("beta2", 0.999))
+                beta1=O.get("beta1", 0.5), beta2=O.get("beta2", 0.999), apply_gp=Ls.get("apply_gp", False), gp_lambda=Ls.get("gp_lambda", 10.0))
 
 
 def sub(fix, prefix):
