@@ -114,7 +114,7 @@ int sg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H,
 /* T NHWC -> fp32 NCHW, optional tanh */
 int sg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int lds, int apply_tanh, sg_stream_t s);
 /* d_pre(NHWC,T) = d_out(NCHW fp32) * (1 - y^2), y = NCHW fp32 tanh output (apply_tanh=0: plain layout change) */
-int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int apply_tanh, sg_stream_t s);
+int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int ldo, int apply_tanh, sg_stream_t s);
 int sg_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, sg_stream_t s);
 int sg_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, sg_stream_t s);
 /* 2x2 max pooling over a column slice [c0, c0+C) of a [N,H,W,ldx] tensor; idx gets the argmax (0..3) */
@@ -189,6 +189,8 @@ typedef struct {
   long long work_off; /* this layer's slice of work[]: needs 8*cols + rows floats */
   int trans;          /* 1: ConvTranspose2d weight [Cin][Cout][R][S] (spectral norm over dim 1, rows = Cout) */
   int dgrad_noflip;   /* 1: w_dgrad = [Cin][r][s][Cout] without the spatial flip (strided / transposed convolutions) */
+  int Cin_pad;        /* >= Cin (0 = Cin): channel pitch of w_fwd ([Cout][R][S][Cin_pad], zero filled) -- thin inputs (RGB) are
+                         carried as 8-channel tensors so the 16-byte loaders apply; w_dgrad is [Cin][R][S][max(rows,rows_pad)] */
 } sg_sn_layer;
 /* runs all layers of a network in 4 batched launches. `layers` is a DEVICE array of n descriptors;
  * work[] is a device scratch; each layer owns the slice [work_off, work_off + 8*cols + rows) */
@@ -200,6 +202,7 @@ typedef struct {
   const float* u; const float* v; const float* sigma; /* snapshot of that forward */
   float* dw;          /* grad of weight_orig, accumulated (+=), natural OIHW layout */
   int rows, cols, Cin, RS, natural, apply_sn, trans;
+  int Cin_pad;        /* channel pitch of dwt when natural == 0 (0 = Cin) */
 } sg_sn_bwd_layer;
 int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s);
 

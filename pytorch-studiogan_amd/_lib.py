@@ -45,12 +45,12 @@ class GemmDesc(C.Structure):
 class SnLayer(C.Structure):
     _fields_ = [("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("u_snap", _vp), ("v_snap", _vp), ("w_fwd", _vp), ("w_dgrad", _vp),
                 ("w_f32", _vp), ("rows", _i), ("cols", _i), ("Cin", _i), ("RS", _i), ("do_power_iter", _i), ("apply_sn", _i),
-                ("rows_pad", _i), ("work_off", _ll), ("trans", _i), ("dgrad_noflip", _i)]
+                ("rows_pad", _i), ("work_off", _ll), ("trans", _i), ("dgrad_noflip", _i), ("Cin_pad", _i)]
 
 
 class SnBwdLayer(C.Structure):
     _fields_ = [("dwt", _vp), ("w", _vp), ("u", _vp), ("v", _vp), ("sigma", _vp), ("dw", _vp), ("rows", _i), ("cols", _i),
-                ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i), ("trans", _i)]
+                ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i), ("trans", _i), ("Cin_pad", _i)]
 
 
 _lib = None
@@ -78,7 +78,7 @@ _PROTOS = {
     "sg_gemm": [C.POINTER(GemmDesc), _vp],
     "sg_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_nhwc_to_nchw": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
-    "sg_nchw_grad_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_nchw_grad_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sg_avgpool2_fwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_avgpool2_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_maxpool2_fwd": [_i, _vp, _i, _vp, _i, _vp, _i, _i, _i, _i, _vp],

@@ -103,6 +103,7 @@ class Generator(nn.Module):
         self.activation = MODULES.g_act_fn
         self.conv2d5 = MODULES.g_conv2d(in_channels=self.out_dims[-1], out_channels=3, kernel_size=3, stride=1, padding=1)
         self.tanh = nn.Tanh()
+        self.conv2d5._sg_rows_pad = 8     # RGB rows are written as 8-channel pixels (16-byte stores / loads around the image boundary)
         ops.init_weights(self.modules, g_init)
         ops.adopt(self, _dtype(mixed_precision))
 
@@ -134,7 +135,7 @@ class Generator(nn.Module):
                     counter += 1
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
-        return F.NhwcToNchwFn.apply(act, True)
+        return F.NhwcToNchwFn.apply(act, True, 3)
 
 
 class DiscOptBlock(nn.Module):
@@ -149,6 +150,10 @@ class DiscOptBlock(nn.Module):
             self.bn1 = MODULES.d_bn(in_features=out_channels)
         self.activation = MODULES.d_act_fn
         self.average_pooling = nn.AvgPool2d(2)
+        # the RGB image travels as an 8-channel NHWC tensor (zero-filled) when no batch norm touches it: 16-byte loaders everywhere
+        self.cpad = 8 if (apply_d_sn and in_channels < 8) else 0
+        if self.cpad:
+            self.conv2d1._sg_cin_pad = self.conv2d0._sg_cin_pad = self.cpad
 
     def forward_nhwc(self, x, slot):
         h = self.conv2d1.forward_nhwc(x, slot)
@@ -259,7 +264,7 @@ class Discriminator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, x))
-        h = ops.to_nhwc(x, dtype)
+        h = ops.to_nhwc(x, dtype, self.blocks[0][0].cpad)
         for blocklist in self.blocks:
             for block in blocklist:
                 h = block.forward_nhwc(h, slot)

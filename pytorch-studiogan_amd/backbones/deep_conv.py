@@ -64,6 +64,7 @@ class Generator(nn.Module):
         self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])
         self.conv4 = MODULES.g_conv2d(in_channels=self.out_dims[-1], out_channels=3, kernel_size=3, stride=1, padding=1)
         self.tanh = nn.Tanh()
+        self.conv4._sg_rows_pad = 8
         ops.init_weights(self.modules, g_init)
         ops.adopt(self, _dtype(mixed_precision))
 
@@ -83,7 +84,7 @@ class Generator(nn.Module):
                 else:
                     act = block.forward_nhwc(act, affines, slot)
         act = self.conv4.forward_nhwc(act, slot)
-        return F.NhwcToNchwFn.apply(act, True)
+        return F.NhwcToNchwFn.apply(act, True, 3)
 
 
 class DiscBlock(nn.Module):
@@ -137,6 +138,7 @@ class Discriminator(nn.Module):
         self.linear1 = MODULES.d_linear(in_features=512, out_features=1, bias=True)
         if self.d_cond_mtd == "PD":
             self.embedding = MODULES.d_embedding(num_classes, 512)
+        self.blocks[0][0].conv0._sg_cin_pad = 8     # RGB image as an 8-channel NHWC tensor (zero-filled)
         if d_init:
             ops.init_weights(self.modules, d_init)
         ops.adopt(self, _dtype(mixed_precision))
@@ -145,7 +147,7 @@ class Discriminator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, x))
-        h = ops.to_nhwc(x, dtype)
+        h = ops.to_nhwc(x, dtype, 8)
         pending_relu = False       # with SN the block's trailing ReLU rides on the next stride-1 conv's load
         for blocklist in self.blocks:
             for block in blocklist:

@@ -84,6 +84,7 @@ class Generator(nn.Module):
         self.activation = MODULES.g_act_fn
         self.conv2d5 = MODULES.g_conv2d(in_channels=self.out_dims[-1], out_channels=3, kernel_size=3, stride=1, padding=1)
         self.tanh = nn.Tanh()
+        self.conv2d5._sg_rows_pad = 8
         ops.init_weights(self.modules, g_init)
         ops.adopt(self, _dtype(mixed_precision))
 
@@ -104,4 +105,4 @@ class Generator(nn.Module):
                     act = block.forward_nhwc(act, affines, slot)
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
-        return F.NhwcToNchwFn.apply(act, True)
+        return F.NhwcToNchwFn.apply(act, True, 3)

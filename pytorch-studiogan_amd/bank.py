@@ -157,7 +157,7 @@ class _Holder:
 class LayerRT:
     """Runtime record of one weight-bearing layer inside a bank."""
     __slots__ = ("module", "index", "param", "kind", "rows", "cols", "Cin", "RS", "apply_sn", "rows_pad", "want_fwd", "want_dgrad",
-                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank", "trans", "noflip")
+                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank", "trans", "noflip", "cin_pad")
 
 
 class _Slot:
@@ -204,6 +204,8 @@ class WeightBank:
             r.rows_pad = getattr(m, "_sg_rows_pad", 0) or r.rows
             r.trans = 1 if getattr(m, "_sg_trans", False) else 0
             r.noflip = 1 if getattr(m, "_sg_dgrad_noflip", False) else 0
+            r.cin_pad = getattr(m, "_sg_cin_pad", 0) or r.Cin
+            assert r.cin_pad == r.Cin or (r.kind == "conv" and not r.trans), "input-channel padding is for plain convolutions"
             r.want_fwd = r.kind == "conv"
             r.want_dgrad = r.kind == "conv"
             r.want_f32 = r.kind in ("linear", "embedding")
@@ -211,15 +213,15 @@ class WeightBank:
             r.fwd_off = r.dgrad_off = r.f32_off = -1
             if r.want_fwd:
                 r.fwd_off = img_elems
-                img_elems += _align(r.rows_pad * r.cols, 16)
+                img_elems += _align(r.rows_pad * r.RS * r.cin_pad, 16)
             if r.want_dgrad:
                 r.dgrad_off = img_elems
-                img_elems += _align(r.rows * r.cols, 16)
+                img_elems += _align(r.rows_pad * r.RS * r.cin_pad, 16)   # [cin_pad][RS][rows_pad], zero outside [Cin][RS][rows]
             if r.want_f32:
                 r.f32_off = f32_elems
                 f32_elems += _align(r.rows * r.cols)
             r.dwt_off = dwt_elems
-            dwt_elems += _align(r.rows_pad * r.cols)
+            dwt_elems += _align(r.rows_pad * r.RS * r.cin_pad)
             r.uv_off = uv_elems
             uv_elems += _align(r.rows) + _align(r.cols)
             r.work_off = work
@@ -272,6 +274,7 @@ class WeightBank:
             d.rows_pad = r.rows_pad
             d.work_off = r.work_off
             d.trans, d.dgrad_noflip = r.trans, r.noflip
+            d.Cin_pad = r.cin_pad
         dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
         ent = (arr, dev_tab)
         slot.desc_cache[flags] = ent
@@ -327,7 +330,7 @@ class WeightBank:
 
     def dwt_tensor(self, slot, r):
         self.dwt(slot, r)
-        return slot.dwt[r.dwt_off:r.dwt_off + r.rows_pad * r.cols].view(r.rows_pad, r.cols)
+        return slot.dwt[r.dwt_off:r.dwt_off + r.rows_pad * r.RS * r.cin_pad].view(r.rows_pad, r.RS * r.cin_pad)
 
     # -- backward of the normalisation, batched ----------------------------------------------------------------
     def flush(self):
@@ -353,6 +356,7 @@ class WeightBank:
                     d.natural = r.natural_dwt
                     d.apply_sn = r.apply_sn
                     d.trans = r.trans
+                    d.Cin_pad = r.cin_pad
                 ent = [arr, None, None]
                 slot.bwd_cache[key] = ent
             arr = ent[0]

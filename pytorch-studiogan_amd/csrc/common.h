@@ -40,6 +40,31 @@ template <> struct ET<bf16_t> { static constexpr int VEC = 8, BK = 32; };
 __device__ __forceinline__ u32x4 zero16() { u32x4 z = {0u, 0u, 0u, 0u}; return z; }
 
 // ReLU on a packed 16-byte vector
+// 16-byte vector <-> fp32 lanes (4 floats or 8 bf16)
+template <typename T> __device__ __forceinline__ void unpack16(u32x4 v, float* o);
+template <> __device__ __forceinline__ void unpack16<float>(u32x4 v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) o[i] = __uint_as_float(v[i]);
+}
+template <> __device__ __forceinline__ void unpack16<bf16_t>(u32x4 v, float* o) {
+#pragma unroll
+  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
+}
+template <typename T> __device__ __forceinline__ u32x4 pack16(const float* o);
+template <> __device__ __forceinline__ u32x4 pack16<float>(const float* o) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = __float_as_uint(o[i]);
+  return v;
+}
+template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* o) {
+  u32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; i++) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
+  return v;
+}
+
+
 template <typename T> __device__ __forceinline__ u32x4 relu16(u32x4 v);
 template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) {
 #pragma unroll

@@ -49,7 +49,8 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   const bool disabled = mode && mode[0] == '0';
   const bool force = mode && mode[0] == 'f';
   if (disabled || d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
-  if (d->C % 8 || d->ldx % 8 || d->C < 64 || d->R * d->S > 32 || J < 256) return false;
+  if (d->C % 8 || d->ldx % 8 || d->R * d->S > 32 || J < 256) return false;
+  if (d->C < 64 && d->C != 8 && d->C != 16 && d->C != 32) return false;   // thin inputs: a k-tile of 8 chunks must cover whole taps
   if (!aligned16(d->x) || !aligned16(d->w)) return false;
   const int tj = (J + 255) / 256;
   const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile spills with hipcc 7.2: left out)
@@ -71,7 +72,12 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   int rc = 0;
   if (best == 192) rc = sg_launch_conv_v2<192, 4, 2>(p, e, st);
   else if (best == 128) rc = sg_launch_conv_v2<128, 4, 2>(p, e, st);
-  else rc = sg_launch_conv_v2<96, 8, 1>(p, e, st);
+  else {
+    // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)
+    const char* b5 = getenv("SG_CONV_BJ512");
+    if (J >= 512 * 256 && !(b5 && b5[0] == '0')) rc = sg_launch_conv_v2<96, 8, 1, 512>(p, e, st);
+    else rc = sg_launch_conv_v2<96, 8, 1>(p, e, st);
+  }
   return rc == 0;
 }
 

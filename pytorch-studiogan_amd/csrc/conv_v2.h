@@ -30,9 +30,8 @@ struct ConvV2Params {
 typedef __attribute__((address_space(1))) const void* sg_gptr_t;
 typedef __attribute__((address_space(3))) void* sg_lptr_t;
 
-template <int BI, int WJ, int WI>
+template <int BI, int WJ, int WI, int BJ>
 __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
-  constexpr int BJ = 256;
   constexpr int QB = BJ * 128, PB = BI * 128, BUF = QB + PB;
   constexpr int NQ = BJ / 64;                 // Q DMA instructions per wave per k-tile (8 rows each, 8 waves)
   constexpr int NPI = (BI / 8 + 7) / 8;       // P DMA instructions per wave per k-tile (upper bound)
@@ -90,6 +89,7 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
   }
   // position of this lane inside K: tap (r,s) and chunk-in-tap c8; q = global chunk index
   int tap = 0, tr = 0, ts = 0, c8 = lc, q = lc;
+  while (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }
 
   auto issue = [&](int buf) {
     char* qd = smem + buf * BUF;
@@ -116,7 +116,7 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
     }
     // advance to the next k-tile: 8 chunks further
     q += 8; c8 += 8;
-    if (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }
+    while (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }   // one step when C >= 64; up to 8 for thin inputs
   };
 
   f32x16 acc[TI][TJ];
@@ -182,15 +182,15 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
     }
 }
 
-template <int BI, int WJ, int WI>
+template <int BI, int WJ, int WI, int BJ = 256>
 static inline int sg_launch_conv_v2(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  constexpr int BUF = (256 + BI) * 128;
+  constexpr int BUF = (BJ + BI) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
     attr_done = true;
   }
-  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + 255) / 256;
-  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI>), dim3(tilesI * tilesJ), dim3(512), 2 * BUF, st, p, e, tilesI, tilesJ);
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
+  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ>), dim3(tilesI * tilesJ), dim3(512), 2 * BUF, st, p, e, tilesI, tilesJ);
   return 0;
 }

@@ -47,19 +47,19 @@ extern "C" int sg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, in
   SG_LAUNCH_CHECK();
   return 0;
 }
-template <typename T> __global__ void k_nchw_grad_to_nhwc(const float* dy, const float* y, T* dst, int N, int C, int HW, int do_tanh) {
+template <typename T> __global__ void k_nchw_grad_to_nhwc(const float* dy, const float* y, T* dst, int N, int C, int HW, int ldo, int do_tanh) {
   long long total = (long long)N * HW * C;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
     int hw = (int)(i % HW); long long t = i / HW; int c = (int)(t % C); int n = (int)(t / C);
     float g = dy[i];
     if (do_tanh) { float yy = y[i]; g *= (1.f - yy * yy); }
-    dst[((long long)n * HW + hw) * C + c] = from_f<T>(g);
+    dst[((long long)n * HW + hw) * ldo + c] = from_f<T>(g);
   }
 }
-extern "C" int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int apply_tanh, sg_stream_t s) {
-  SG_CHECK(dy && dst && (y || !apply_tanh), "sg_nchw_grad_to_nhwc: null");
+extern "C" int sg_nchw_grad_to_nhwc(int dtype, const float* dy, const float* y, void* dst, int N, int C, int H, int W, int ldo, int apply_tanh, sg_stream_t s) {
+  SG_CHECK(dy && dst && (y || !apply_tanh) && ldo >= C, "sg_nchw_grad_to_nhwc: bad args");
   long long total = (long long)N * C * H * W;
-  DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_grad_to_nhwc<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, dy, y, (T*)dst, N, C, H * W, apply_tanh));
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_grad_to_nhwc<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, dy, y, (T*)dst, N, C, H * W, ldo, apply_tanh));
   SG_LAUNCH_CHECK();
   return 0;
 }
@@ -265,8 +265,47 @@ template <typename T> __global__ __launch_bounds__(256) void k_colsum(const T* x
   __syncthreads();
   if (ry == 0 && c < C) unsafeAtomicAdd(out + c, alpha * (sm[0][cx] + sm[1][cx] + sm[2][cx] + sm[3][cx]));
 }
+// Streaming variant (no mask): a thread owns one 16-byte channel vector and walks rows; lanes combined through LDS.
+template <typename T> __global__ __launch_bounds__(256) void k_colsum_stream(const T* x, int ldx, long long rows, int C, float* out, float alpha, long long rpb) {
+  constexpr int V = ET<T>::VEC;
+  extern __shared__ float cs_sm[];                      // [lanes_p][C]
+  const int CV = C / V;
+  const int lanes_p = blockDim.x / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  long long r0 = blockIdx.x * rpb, r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) acc[e] = 0.f;
+  for (long long r = r0 + pl; r < r1; r += lanes_p) {
+    float xv[V];
+    unpack16<T>(*(const u32x4*)(x + r * ldx + cv * V), xv);
+#pragma unroll
+    for (int e = 0; e < V; e++) acc[e] += xv[e];
+  }
+#pragma unroll
+  for (int e = 0; e < V; e++) cs_sm[pl * C + cv * V + e] = acc[e];
+  __syncthreads();
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    float a = 0.f;
+    for (int l = 0; l < lanes_p; l++) a += cs_sm[l * C + i];
+    unsafeAtomicAdd(out + i, alpha * a);
+  }
+}
 extern "C" int sg_colsum(int dtype, const void* x, int ldx, const void* mask, int ldm, long long rows, int C, float* out, float alpha, sg_stream_t s) {
   SG_CHECK(x && out && rows > 0 && C > 0, "sg_colsum: bad args");
+  bool done = false;
+  DISPATCH_T(dtype, {
+    constexpr int V = ET<T>::VEC;
+    const int CV = C / V;
+    if (!mask && C % V == 0 && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && CV <= 256 && rows >= 2048) {
+      const int lanes_p = 256 / CV;
+      long long rpb = (rows + 1023) / 1024; if (rpb < 8ll * lanes_p) rpb = 8ll * lanes_p;
+      const int gx = (int)((rows + rpb - 1) / rpb);
+      hipLaunchKernelGGL(k_colsum_stream<T>, dim3(gx), dim3(CV * lanes_p), (size_t)lanes_p * C * sizeof(float), (hipStream_t)s, (const T*)x, ldx, rows, C, out, alpha, rpb);
+      done = true;
+    }
+  });
+  if (done) { SG_LAUNCH_CHECK(); return 0; }
   int ct = (C + 63) / 64;
   long long want = 2048 / ct; if (want < 1) want = 1;
   long long rpb = (rows + want - 1) / want; if (rpb < 64) rpb = 64;

@@ -11,29 +11,6 @@
   else if ((dtype) == SG_DTYPE_BF16) { typedef bf16_t T; __VA_ARGS__; } \
   else { sg_set_error("bad dtype"); return -1; }
 
-template <typename T> __device__ __forceinline__ void unpack16(u32x4 v, float* o);
-template <> __device__ __forceinline__ void unpack16<float>(u32x4 v, float* o) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) o[i] = __uint_as_float(v[i]);
-}
-template <> __device__ __forceinline__ void unpack16<bf16_t>(u32x4 v, float* o) {
-#pragma unroll
-  for (int i = 0; i < 4; i++) { o[2 * i] = __uint_as_float(v[i] << 16); o[2 * i + 1] = __uint_as_float(v[i] & 0xffff0000u); }
-}
-template <typename T> __device__ __forceinline__ u32x4 pack16(const float* o);
-template <> __device__ __forceinline__ u32x4 pack16<float>(const float* o) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = __float_as_uint(o[i]);
-  return v;
-}
-template <> __device__ __forceinline__ u32x4 pack16<bf16_t>(const float* o) {
-  u32x4 v;
-#pragma unroll
-  for (int i = 0; i < 4; i++) v[i] = (uint32_t)f2bf(o[2 * i]) | ((uint32_t)f2bf(o[2 * i + 1]) << 16);
-  return v;
-}
-
 // ---- statistics ------------------------------------------------------------------------------------------
 template <typename T> __global__ __launch_bounds__(256) void k_bn_partial(const T* x, int ldx, long long rows, int C, double* partial, long long rpb) {
   __shared__ double sm[2][4][64];
@@ -54,8 +31,58 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_partial(const 
     atomicAdd(partial + 2 * c + 1, sm[1][0][cx] + sm[1][1][cx] + sm[1][2][cx] + sm[1][3][cx]);
   }
 }
+// Streaming variant: a thread owns one 16-byte channel vector and walks pixels (16-byte loads instead of 2-byte ones);
+// fp32 partials are flushed into fp64 every 32 pixels, lanes of a block are combined through LDS, one fp64 atomic per
+// channel and block.
+template <typename T> __global__ __launch_bounds__(256) void k_bn_partial_stream(const T* x, int ldx, long long rows, int C, double* partial, long long rpb) {
+  constexpr int V = ET<T>::VEC;
+  extern __shared__ double smd[];                       // [lanes_p][C][2]
+  const int CV = C / V;
+  const int lanes_p = blockDim.x / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  long long r0 = blockIdx.x * rpb, r1 = r0 + rpb; if (r1 > rows) r1 = rows;
+  double d1[V], d2[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) { d1[e] = 0.0; d2[e] = 0.0; }
+  for (long long rb = r0 + pl; rb < r1; rb += 32ll * lanes_p) {
+    float s1[V], s2[V];
+#pragma unroll
+    for (int e = 0; e < V; e++) { s1[e] = 0.f; s2[e] = 0.f; }
+    for (int k = 0; k < 32; k++) {
+      const long long r = rb + (long long)k * lanes_p;
+      if (r >= r1) break;
+      float xv[V];
+      unpack16<T>(*(const u32x4*)(x + r * ldx + cv * V), xv);
+#pragma unroll
+      for (int e = 0; e < V; e++) { s1[e] += xv[e]; s2[e] += xv[e] * xv[e]; }
+    }
+#pragma unroll
+    for (int e = 0; e < V; e++) { d1[e] += (double)s1[e]; d2[e] += (double)s2[e]; }
+  }
+#pragma unroll
+  for (int e = 0; e < V; e++) { smd[((long long)pl * C + cv * V + e) * 2] = d1[e]; smd[((long long)pl * C + cv * V + e) * 2 + 1] = d2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    double a = 0.0;
+    for (int l = 0; l < lanes_p; l++) a += smd[(long long)l * C * 2 + i];
+    atomicAdd(partial + i, a);
+  }
+}
 extern "C" int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_stream_t s) {
   SG_CHECK(x && partial && rows > 0 && C > 0, "sg_bn_partial_stats: bad args");
+  bool done = false;
+  DISPATCH_T(dtype, {
+    constexpr int V = ET<T>::VEC;
+    const int CV = C / V;
+    if (C % V == 0 && ldx % V == 0 && ((uintptr_t)x & 15) == 0 && CV <= 128 && rows >= 4096) {
+      const int lanes_p = 256 / CV;
+      long long rpb = (rows + 1023) / 1024; if (rpb < 32ll * lanes_p) rpb = 32ll * lanes_p;
+      const int gx = (int)((rows + rpb - 1) / rpb);
+      hipLaunchKernelGGL(k_bn_partial_stream<T>, dim3(gx), dim3(CV * lanes_p), (size_t)lanes_p * C * 2 * sizeof(double), (hipStream_t)s, (const T*)x, ldx, rows, C, partial, rpb);
+      done = true;
+    }
+  });
+  if (done) { SG_LAUNCH_CHECK(); return 0; }
   int ct = (C + 63) / 64;
   long long want = 2048 / ct; if (want < 1) want = 1;
   long long rpb = (rows + want - 1) / want; if (rpb < 64) rpb = 64;
@@ -207,9 +234,64 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_reduce(con
     unsafeAtomicAdd(o + 1, sm[1][0][cx] + sm[1][1][cx] + sm[1][2][cx] + sm[1][3][cx]);
   }
 }
+// Streaming variant of stage 1 (16-byte loads; thread = one channel vector of one sample; LDS combine; float atomics)
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_reduce_stream(const T* x, const T* dy, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, float* sums, int ppb) {
+  constexpr int V = ET<T>::VEC;
+  extern __shared__ float smf[];                        // [lanes_p][C][2]
+  const int CV = C / V;
+  const int n = blockIdx.y;
+  const int lanes_p = blockDim.x / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  float mu[V], is[V], ga[V], bi[V], s1[V], s2[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    const int c = cv * V + e;
+    mu[e] = mean[c]; is[e] = invstd[c];
+    ga[e] = gain ? gain[(long long)n * gsn + c] : 1.f;
+    bi[e] = bias ? bias[(long long)n * gsn + c] : 0.f;
+    s1[e] = 0.f; s2[e] = 0.f;
+  }
+  const long long p0 = (long long)blockIdx.x * ppb;
+  long long p1 = p0 + ppb; if (p1 > HW) p1 = HW;
+  const long long base = (long long)n * HW * C + cv * V;
+  for (long long pix = p0 + pl; pix < p1; pix += lanes_p) {
+    float xv[V], gv[V];
+    unpack16<T>(*(const u32x4*)(x + base + pix * C), xv);
+    unpack16<T>(*(const u32x4*)(dy + base + pix * C), gv);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float xh = (xv[e] - mu[e]) * is[e];
+      float g = gv[e];
+      if (relu && !(xh * ga[e] + bi[e] > 0.f)) g = 0.f;
+      s1[e] += g; s2[e] += g * xh;
+    }
+  }
+#pragma unroll
+  for (int e = 0; e < V; e++) { smf[((long long)pl * C + cv * V + e) * 2] = s1[e]; smf[((long long)pl * C + cv * V + e) * 2 + 1] = s2[e]; }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += blockDim.x) {
+    float a = 0.f;
+    for (int l = 0; l < lanes_p; l++) a += smf[(long long)l * C * 2 + i];
+    unsafeAtomicAdd(sums + (long long)n * C * 2 + i, a);
+  }
+}
 extern "C" int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, float* sums, sg_stream_t s) {
   SG_CHECK(x && dy && mean && invstd && sums, "sg_bn_bwd_reduce: null");
   SG_CHECK(N <= 65535, "sg_bn_bwd_reduce: batch too large for grid.z");
+  bool done = false;
+  DISPATCH_T(dtype, {
+    constexpr int V = ET<T>::VEC;
+    const int CV = C / V;
+    if (vec_ok<T>(x, dy, C) && CV <= 256 && HW >= 64) {
+      const int lanes_p = 256 / CV;
+      long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
+      long long ppb = (HW + chunks - 1) / chunks; if (ppb < 8 * lanes_p) ppb = 8 * lanes_p;
+      const int gx = (int)((HW + ppb - 1) / ppb);
+      hipLaunchKernelGGL(k_bn_bwd_reduce_stream<T>, dim3(gx, N), dim3(CV * lanes_p), (size_t)lanes_p * C * 2 * sizeof(float), (hipStream_t)s, (const T*)x, (const T*)dy, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, sums, (int)ppb);
+      done = true;
+    }
+  });
+  if (done) { SG_LAUNCH_CHECK(); return 0; }
   int ct = (C + 63) / 64;
   long long want = 2048 / ((long long)ct * N); if (want < 1) want = 1;
   long long rpb = (HW + want - 1) / want; if (rpb < 16) rpb = 16;
@@ -267,10 +349,55 @@ template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_bwd
     if (VECP) *(u32x4*)(dx + pix * C + c0) = pack16<T>(xv); else dx[pix * C + c0] = from_f<T>(xv[0]);
   }
 }
+// Streaming variant (same ownership as k_bn_apply_stream): a thread keeps the 6 per-channel coefficients of its 16-byte
+// channel vector in registers; the loop body is 2 loads -> ~6 flops per element -> 1 store.
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stream(const T* x, const T* dy, T* dx, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch, int ppb) {
+  constexpr int V = ET<T>::VEC;
+  const int CV = C / V;
+  const int n = blockIdx.y;
+  const int lanes_p = blockDim.x / CV;
+  const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
+  const float invc = (float)(1.0 / count);
+  float mu[V], is[V], ga[V], bi[V], k0[V], k1[V];
+#pragma unroll
+  for (int e = 0; e < V; e++) {
+    const int c = cv * V + e;
+    mu[e] = mean[c]; is[e] = invstd[c];
+    ga[e] = gain ? gain[(long long)n * gsn + c] : 1.f;
+    bi[e] = bias ? bias[(long long)n * gsn + c] : 0.f;
+    k0[e] = use_batch ? (float)chan[2 * c] : 0.f;
+    k1[e] = use_batch ? (float)chan[2 * c + 1] : 0.f;
+  }
+  const long long p0 = (long long)blockIdx.x * ppb;
+  long long p1 = p0 + ppb; if (p1 > HW) p1 = HW;
+  const long long base = (long long)n * HW * C + cv * V;
+  for (long long pix = p0 + pl; pix < p1; pix += lanes_p) {
+    float xv[V], gv[V];
+    unpack16<T>(*(const u32x4*)(x + base + pix * C), xv);
+    unpack16<T>(*(const u32x4*)(dy + base + pix * C), gv);
+#pragma unroll
+    for (int e = 0; e < V; e++) {
+      const float xh = (xv[e] - mu[e]) * is[e];
+      float g = gv[e];
+      if (relu && !(xh * ga[e] + bi[e] > 0.f)) g = 0.f;
+      float d = ga[e] * g;
+      if (use_batch) d -= (k0[e] + xh * k1[e]) * invc;     // same evaluation order as k_bn_bwd_apply
+      xv[e] = d * is[e];
+    }
+    *(u32x4*)(dx + base + pix * C) = pack16<T>(xv);
+  }
+}
 extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, const double* chan, double count, int use_batch_stats, sg_stream_t s) {
   SG_CHECK(x && dy && dx && mean && invstd && chan && count > 0, "sg_bn_bwd_apply: bad args");
   DISPATCH_T(dtype, {
-    if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0)) hipLaunchKernelGGL((k_bn_bwd_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
+    const int CV = C / ET<T>::VEC;
+    if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0) && CV <= 256 && N <= 65535 && HW >= 64) {
+      const int lanes_p = 256 / CV;
+      long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
+      long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
+      const int gx = (int)((HW + ppb - 1) / ppb);
+      hipLaunchKernelGGL(k_bn_bwd_apply_stream<T>, dim3(gx, N), dim3(CV * lanes_p), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, (int)ppb);
+    } else if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0)) hipLaunchKernelGGL((k_bn_bwd_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
     else hipLaunchKernelGGL((k_bn_bwd_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
   });
   SG_LAUNCH_CHECK();

@@ -100,15 +100,88 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack(const sg_
     if (o < l.rows) {
       val = l.w[sn_widx(l, o, k)] / sig;
       if (l.w_f32) l.w_f32[i] = val;
-      if (l.w_dgrad) ((T*)l.w_dgrad)[((long long)c * l.RS + (l.dgrad_noflip ? rs : (l.RS - 1 - rs))) * l.rows + o] = from_f<T>(val);
+      if (l.w_dgrad) ((T*)l.w_dgrad)[((long long)c * l.RS + (l.dgrad_noflip ? rs : (l.RS - 1 - rs))) * rows_out + o] = from_f<T>(val);
     }
-    if (l.w_fwd) ((T*)l.w_fwd)[((long long)o * l.RS + rs) * l.Cin + c] = from_f<T>(val);
+    if (l.w_fwd) ((T*)l.w_fwd)[((long long)o * l.RS + rs) * (l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin) + c] = from_f<T>(val);
+  }
+}
+
+// Tiled replacement of k_sn_pack (its scattered 2-byte stores ran at ~1/15 of HBM speed):
+//  * k_sn_pack_rows: one block per weight row -> fp32 natural copy and the forward image [o][rs][c]; the [c][rs] -> [rs][c]
+//    shuffle of the row goes through LDS so both the read and the write are contiguous.
+//  * k_sn_pack_dgrad: 64(o) x 128(k) tiles transposed through LDS -> data-gradient image [c][rs'][o], 128-byte rows of o.
+template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(const sg_sn_layer* L) {
+  extern __shared__ __attribute__((aligned(16))) char sn_raw[];
+  T* row = (T*)sn_raw;
+  const sg_sn_layer l = L[blockIdx.y];
+  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;
+  const float sig = l.sigma[0];
+  for (int o = blockIdx.x; o < rows_out; o += gridDim.x) {
+    for (int k = threadIdx.x; k < l.cols; k += 256) {
+      float val = 0.f;
+      if (o < l.rows) {
+        val = l.w[sn_widx(l, o, k)] / sig;
+        if (l.w_f32) l.w_f32[(long long)o * l.cols + k] = val;
+      }
+      row[k] = from_f<T>(val);
+    }
+    __syncthreads();
+    if (l.w_fwd) {
+      const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin, colsp = l.RS * cp;
+      T* dst = (T*)l.w_fwd + (long long)o * colsp;
+      for (int j = threadIdx.x; j < colsp; j += 256) {
+        const int rs = j / cp, c = j - rs * cp;
+        dst[j] = c < l.Cin ? row[c * l.RS + rs] : from_f<T>(0.f);
+      }
+    }
+    __syncthreads();
+  }
+}
+template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(const sg_sn_layer* L) {
+  __shared__ T tile[64][130];
+  const sg_sn_layer l = L[blockIdx.z];
+  if (!l.w_dgrad) return;
+  const int o0 = blockIdx.y * 64, k0 = blockIdx.x * 128;
+  if (o0 >= l.rows || k0 >= l.cols) return;
+  const float sig = l.sigma[0];
+  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;    // pitch of the image; columns >= rows stay zero
+  {
+    const int kk = threadIdx.x & 127, k = k0 + kk;
+    for (int p = 0; p < 32; p++) {
+      const int oo = p * 2 + (threadIdx.x >> 7), o = o0 + oo;
+      float val = 0.f;
+      if (o < l.rows && k < l.cols) val = l.w[sn_widx(l, o, k)] / sig;
+      tile[oo][kk] = from_f<T>(val);
+    }
+  }
+  __syncthreads();
+  {
+    const int oo = threadIdx.x & 63, o = o0 + oo;
+    for (int p = 0; p < 32; p++) {
+      const int kk = p * 4 + (threadIdx.x >> 6), k = k0 + kk;
+      if (k < l.cols && o < l.rows) {
+        const int c = k / l.RS, rs = k - c * l.RS;
+        ((T*)l.w_dgrad)[((long long)c * l.RS + (l.dgrad_noflip ? rs : (l.RS - 1 - rs))) * rows_out + o] = tile[oo][kk];
+      }
+    }
+  }
+}
+template <typename T> static void sn_pack_launch(const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, int max_rows_out, int max_rows, int max_cols, long long max_elems, hipStream_t st) {
+  bool any_dg = false;
+  for (int i = 0; i < n; i++) if (layers_host[i].w_dgrad) any_dg = true;
+  if ((size_t)max_cols * sizeof(T) <= 60 * 1024) {
+    int gx = max_rows_out; if (gx > 2048) gx = 2048;
+    hipLaunchKernelGGL(k_sn_pack_rows<T>, dim3(gx, n), dim3(256), (size_t)max_cols * sizeof(T), st, layers_dev);
+    if (any_dg) hipLaunchKernelGGL(k_sn_pack_dgrad<T>, dim3((max_cols + 127) / 128, (max_rows + 63) / 64, n), dim3(256), 0, st, layers_dev);
+  } else {
+    long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+    hipLaunchKernelGGL(k_sn_pack<T>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
   }
 }
 
 extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s) {
   SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_forward: bad args");
-  int max_rows = 1, max_cols = 1; long long max_elems = 1; bool any_sn = false, any_pi = false;
+  int max_rows = 1, max_cols = 1, max_rows_out = 1; long long max_elems = 1; bool any_sn = false, any_pi = false;
   for (int i = 0; i < n; i++) {
     const sg_sn_layer& l = layers_host[i];
     SG_CHECK(l.w && l.sigma && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_forward: bad layer");
@@ -119,7 +192,9 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
     }
     if (l.rows > max_rows) max_rows = l.rows;
     if (l.cols > max_cols) max_cols = l.cols;
-    const long long e = (long long)(l.rows_pad > l.rows ? l.rows_pad : l.rows) * l.cols;
+    const int ro = l.rows_pad > l.rows ? l.rows_pad : l.rows;
+    if (ro > max_rows_out) max_rows_out = ro;
+    const long long e = (long long)ro * l.cols;
     if (e > max_elems) max_elems = e;
   }
   hipStream_t st = (hipStream_t)s;
@@ -129,9 +204,8 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
   }
   if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, n), dim3(256), 0, st, layers_dev, work);
   hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
-  long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
-  if (dtype == SG_DTYPE_F32) hipLaunchKernelGGL(k_sn_pack<float>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
-  else if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_sn_pack<bf16_t>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
+  if (dtype == SG_DTYPE_F32) sn_pack_launch<float>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
+  else if (dtype == SG_DTYPE_BF16) sn_pack_launch<bf16_t>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
   else { sg_set_error("sg_sn_forward: bad dtype"); return -1; }
   SG_LAUNCH_CHECK();
   return 0;
@@ -143,7 +217,7 @@ __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int
   if (l.natural == 1) return (long long)o * l.cols + k;
   const int c = k / l.RS, rs = k - c * l.RS;
   if (l.natural == 2) return ((long long)c * l.RS + rs) * l.rows + o;   // [Cin][R][S][Cout]: weight gradient of a transposed conv
-  return ((long long)o * l.RS + rs) * l.Cin + c;
+  return ((long long)o * l.RS + rs) * (l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin) + c;
 }
 // grid (SNB_BLOCKS, layers): block partials of <dWt, W>
 __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float* work) {

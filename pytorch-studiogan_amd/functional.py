@@ -121,38 +121,45 @@ def gemm_raw(dtype, p, p_form, ldp, q, q_form, ldq, out, ldo, I, J, K, batch=1, 
 # layout at the reference's NCHW fp32 boundary
 # ---------------------------------------------------------------------------------------------------------
 class NchwToNhwcFn(torch.autograd.Function):
-    """fp32 NCHW -> compute-dtype NHWC (D input image; G's linear0 output)."""
+    """fp32 NCHW -> compute-dtype NHWC (D input image; G's linear0 output). cpad > C: the NHWC tensor gets cpad channels, the extra
+    ones zero (RGB images travel as 8-channel tensors so every convolution uses the 16-byte loaders)."""
 
     @staticmethod
-    def forward(ctx, x, dtype):
+    def forward(ctx, x, dtype, cpad=0):
         x = _c(x)
         N, Cc, H, W = x.shape
-        y = torch.empty((N, H, W, Cc), dtype=dtype, device=x.device)
-        L.call("sg_nchw_to_nhwc", L.dt(dtype), L.ptr(x), L.ptr(y), N, Cc, H, W, Cc, L.stream())
+        ld = max(cpad, Cc)
+        y = (torch.zeros if ld > Cc else torch.empty)((N, H, W, ld), dtype=dtype, device=x.device)
+        L.call("sg_nchw_to_nhwc", L.dt(dtype), L.ptr(x), L.ptr(y), N, Cc, H, W, ld, L.stream())
+        ctx.channels = Cc
         return y
 
     @staticmethod
     def backward(ctx, dy):
         if torch.is_grad_enabled():        # create_graph=True (WGAN-GP): stay on differentiable ops
-            return NhwcToNchwFn.apply(dy, False), None
+            return NhwcToNchwFn.apply(dy, False, ctx.channels), None, None
         dy = _c(dy)
-        N, H, W, Cc = dy.shape
+        N, H, W, ld = dy.shape
+        Cc = ctx.channels
         dx = torch.empty((N, Cc, H, W), dtype=torch.float32, device=dy.device)
-        L.call("sg_nhwc_to_nchw", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Cc, H, W, Cc, 0, L.stream())
-        return dx, None
+        L.call("sg_nhwc_to_nchw", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Cc, H, W, ld, 0, L.stream())
+        return dx, None, None
 
 
 class NhwcToNchwFn(torch.autograd.Function):
-    """compute-dtype NHWC -> fp32 NCHW with optional tanh (G output image)."""
+    """compute-dtype NHWC -> fp32 NCHW with optional tanh (G output image). channels < x.shape[3]: only the first `channels`
+    are real (the last convolution of G writes 8-channel rows)."""
 
     @staticmethod
-    def forward(ctx, x, apply_tanh):
+    def forward(ctx, x, apply_tanh, channels=0):
         x = _c(x)
-        N, H, W, Cc = x.shape
+        N, H, W, ld = x.shape
+        Cc = channels or ld
         y = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
-        L.call("sg_nhwc_to_nchw", L.dt(x), L.ptr(x), L.ptr(y), N, Cc, H, W, Cc, 1 if apply_tanh else 0, L.stream())
+        L.call("sg_nhwc_to_nchw", L.dt(x), L.ptr(x), L.ptr(y), N, Cc, H, W, ld, 1 if apply_tanh else 0, L.stream())
         ctx.apply_tanh = apply_tanh
         ctx.in_dtype = x.dtype
+        ctx.ld = ld
         if apply_tanh:
             ctx.save_for_backward(y)
         return y
@@ -163,9 +170,10 @@ class NhwcToNchwFn(torch.autograd.Function):
         dy = _c(dy.float())
         N, Cc, H, W = dy.shape
         y = ctx.saved_tensors[0] if ctx.apply_tanh else None
-        dx = torch.empty((N, H, W, Cc), dtype=ctx.in_dtype, device=dy.device)
-        L.call("sg_nchw_grad_to_nhwc", L.dt(ctx.in_dtype), L.ptr(dy), L.ptr(y), L.ptr(dx), N, Cc, H, W, 1 if ctx.apply_tanh else 0, L.stream())
-        return dx, None
+        ld = ctx.ld
+        dx = (torch.zeros if ld > Cc else torch.empty)((N, H, W, ld), dtype=ctx.in_dtype, device=dy.device)
+        L.call("sg_nchw_grad_to_nhwc", L.dt(ctx.in_dtype), L.ptr(dy), L.ptr(y), L.ptr(dx), N, Cc, H, W, ld, 1 if ctx.apply_tanh else 0, L.stream())
+        return dx, None, None
 
 
 class ConvertFn(torch.autograd.Function):
@@ -207,12 +215,13 @@ def _conv_dgrad(dy, x, rt, slot, cfg):
     if cfg.stride != 1:
         # strided convolution: gather form of the transposed convolution with the UNflipped [Cin][r][s][Cout] image
         assert not (pool or cfg.in_upsample), "upsample / pooling fusion is stride-1 only"
-        return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
+        return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows_pad, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
                           mask=x if cfg.in_relu else None, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
     pf = L.PIX_UPSAMPLE if pool else 0
     ef = L.EPI_POOL if cfg.in_upsample else 0
-    # dy has rows_pad channels, the dgrad image has K = R*S*rows: read the first `rows` channels at pitch rows_pad
-    return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
+    # dy has rows_pad channels and the dgrad image is [cin_pad][R][S][rows_pad] (zero outside the real weights): the padded
+    # channels ride along so the 16-byte loaders apply; dx comes out with cin_pad channels like x
+    return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows_pad, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
                       mask=x if cfg.in_relu else None, alpha=0.25 if pool else 1.0, ldx=dy.shape[3])
 
 
@@ -270,13 +279,16 @@ class ConvFn(torch.autograd.Function):
         bank = rt.bank()
         x = _c(x)
         N, Hs, Ws, Cin = x.shape
-        assert Cin == rt.Cin, f"conv input channels {Cin} != {rt.Cin}"
-        assert bias is None or rt.rows_pad == rt.rows
+        assert Cin == rt.cin_pad, f"conv input channels {Cin} != {rt.cin_pad}"
         pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
         ef = L.EPI_POOL if cfg.out_pool else 0
         if res is not None:
             res = _c(res)
-        y = conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, pf, ef, bias=bias, res=res,
+        bias_k = bias
+        if bias is not None and rt.rows_pad != rt.rows:      # padded output channels: the epilogue reads rows_pad bias entries
+            bias_k = torch.zeros(rt.rows_pad, dtype=torch.float32, device=x.device)
+            bias_k[:rt.rows].copy_(bias.detach())
+        y = conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, pf, ef, bias=bias_k, res=res,
                        alpha=0.25 if cfg.out_pool else 1.0)
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg

@@ -20,10 +20,12 @@ COMPUTE_DTYPE = torch.float32  # default compute dtype of standalone modules (ba
 # ---------------------------------------------------------------------------------------------------------
 # helpers
 # ---------------------------------------------------------------------------------------------------------
-def to_nhwc(x, dtype):
-    """logical NCHW tensor -> internal NHWC tensor of the compute dtype."""
+def to_nhwc(x, dtype, cpad=0):
+    """logical NCHW tensor -> internal NHWC tensor of the compute dtype (cpad: zero-pad the channels, see NchwToNhwcFn)."""
     if x.dim() != 4:
         raise RuntimeError("expected a 4-D NCHW tensor")
+    if cpad > x.shape[1]:
+        return F.NchwToNhwcFn.apply(x.float(), dtype, cpad)
     if x.dtype == dtype and x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] > 1 and x.is_contiguous() and x.shape[2] * x.shape[3] > 1):
         return x.permute(0, 2, 3, 1)
     if x.dtype == torch.float32 and x.is_contiguous():
@@ -116,7 +118,7 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
     def forward(self, x):
         slot = _standalone_slot(self, x)
         _, bank = _root_and_bank(self)
-        y = self.forward_nhwc(to_nhwc(x, bank.dtype), slot)
+        y = self.forward_nhwc(to_nhwc(x, bank.dtype, getattr(self, "_sg_cin_pad", 0)), slot)
         if self._sg_rows_pad and self._sg_rows_pad != self.out_channels:
             y = y[..., :self.out_channels]
         return to_nchw(y)

@@ -16,12 +16,27 @@ def short(name):
     return name[:110]
 
 
+def csv_rows(path):
+    import csv
+    agg = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            n = r["Kernel_Name"]
+            t = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+            a = agg.setdefault(n, [0, 0, 1 << 62, 0])
+            a[0] += 1; a[1] += t; a[2] = min(a[2], t); a[3] = max(a[3], t)
+    return [(short(n), a[0], a[1], a[2], a[3]) for n, a in agg.items()]
+
+
 def main():
-    db = sqlite3.connect(sys.argv[1])
     top = int(sys.argv[sys.argv.index("--top") + 1]) if "--top" in sys.argv else 40
-    q = """select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start)
-           from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name"""
-    rows = [(short(n), c, t, mn, mx) for n, c, t, mn, mx in db.execute(q)]
+    if sys.argv[1].endswith(".csv"):
+        rows = csv_rows(sys.argv[1])
+    else:
+        db = sqlite3.connect(sys.argv[1])
+        q = """select s.kernel_name, count(*), sum(d.end - d.start), min(d.end - d.start), max(d.end - d.start)
+               from rocpd_kernel_dispatch d join rocpd_info_kernel_symbol s on d.kernel_id = s.id group by s.kernel_name"""
+        rows = [(short(n), c, t, mn, mx) for n, c, t, mn, mx in db.execute(q)]
     agg = {}
     for n, c, t, mn, mx in rows:
         a = agg.setdefault(n, [0, 0, 1 << 62, 0])
