@@ -70,13 +70,17 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags;
   p.I = I; p.J = J; p.K = K; p.cpt = d->C / 8; p.ntap = d->R * d->S;
   int rc = 0;
-  if (best == 192) rc = sg_launch_conv_v2<192, 4, 2>(p, e, st);
-  else if (best == 128) rc = sg_launch_conv_v2<128, 4, 2>(p, e, st);
+  // piece placement (conv_v2.h SCHED): spreading the DMA pieces over the MFMA sub-steps pays on the 96-wide tiles (10 pieces per
+  // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %). SG_CONV_SCHED=0/1 forces one for A/B runs.
+  static const int sched_env = [] { const char* v = getenv("SG_CONV_SCHED"); return v ? atoi(v) : -1; }();
+  const bool s1 = sched_env >= 0 ? sched_env == 1 : (best == 96);
+  if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st);
+  else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 0>(p, e, st);
   else {
     // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)
     const char* b5 = getenv("SG_CONV_BJ512");
-    if (J >= 512 * 256 && !(b5 && b5[0] == '0')) rc = sg_launch_conv_v2<96, 8, 1, 512>(p, e, st);
-    else rc = sg_launch_conv_v2<96, 8, 1>(p, e, st);
+    if (J >= 512 * 256 && !(b5 && b5[0] == '0')) rc = s1 ? sg_launch_conv_v2<96, 8, 1, 512, 1>(p, e, st) : sg_launch_conv_v2<96, 8, 1, 512, 0>(p, e, st);
+    else rc = s1 ? sg_launch_conv_v2<96, 8, 1, 256, 1>(p, e, st) : sg_launch_conv_v2<96, 8, 1, 256, 0>(p, e, st);
   }
   return rc == 0;
 }

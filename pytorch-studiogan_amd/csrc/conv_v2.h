@@ -30,13 +30,18 @@ struct ConvV2Params {
 typedef __attribute__((address_space(1))) const void* sg_gptr_t;
 typedef __attribute__((address_space(3))) void* sg_lptr_t;
 
-template <int BI, int WJ, int WI, int BJ>
-__global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+// SCHED 0: all DMA pieces of the next k-tile are issued in front of the current tile's MFMAs.
+// SCHED 1: the pieces are spread over the four 16-deep MFMA sub-steps (a wave issues in order: a DMA piece costs ~100 issue
+//          cycles that would otherwise sit in front of the matrix pipe for BOTH lock-stepped waves of a SIMD at once).
+template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU>
+__global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int NW = WJ * WI;                  // waves per workgroup (8, or 4 for the two-workgroups-per-CU variant)
   constexpr int QB = BJ * 128, PB = BI * 128, BUF = QB + PB;
-  constexpr int NQ = BJ / 64;                 // Q DMA instructions per wave per k-tile (8 rows each, 8 waves)
-  constexpr int NPI = (BI / 8 + 7) / 8;       // P DMA instructions per wave per k-tile (upper bound)
+  constexpr int NQ = BJ / 8 / NW;             // Q DMA instructions per wave per k-tile (8 rows each)
+  constexpr int NPI = (BI / 8 + NW - 1) / NW; // P DMA instructions per wave per k-tile (upper bound)
   constexpr int TJ = BJ / WJ / 32, TI = BI / WI / 32;
-  static_assert(WJ * WI == 8, "8 waves");
+  static_assert(NW == 8 || NW == 4, "4 or 8 waves");
+  static_assert(BJ % (8 * NW) == 0, "pixel tile / DMA groups");
   static_assert(BJ % (WJ * 32) == 0 && BI % (WI * 32) == 0, "tile/wave mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -52,12 +57,12 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
 
   // ---- per-lane DMA state ------------------------------------------------------------------------------
   const int sub = lane >> 3;                                        // row within the 8-row DMA group
-  const int lc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical chunk this lane fetches (same for all its rows)
+  const int lc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical chunk this lane fetches (same for all its rows: NW is a multiple of 2)
   const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0;
   unsigned qbase[NQ]; unsigned qmask[NQ]; int qpar[NQ];
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
-    const int row = j0 + 8 * (wave + 8 * i) + sub;
+    const int row = j0 + 8 * (wave + NW * i) + sub;
     int n, ho, wo;
     if (p.flags & SG_PIX_QUAD) {
       const int q = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
@@ -82,7 +87,7 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
   unsigned pbase[NPI]; bool pok[NPI];
 #pragma unroll
   for (int i = 0; i < NPI; i++) {
-    const int g = wave + 8 * i;                 // DMA group index inside the P tile
+    const int g = wave + NW * i;                // DMA group index inside the P tile
     const int row = i0 + 8 * g + sub;
     pok[i] = (g < BI / 8) && (row < p.I);
     pbase[i] = (unsigned)row * (unsigned)p.K;
@@ -91,32 +96,51 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
   int tap = 0, tr = 0, ts = 0, c8 = lc, q = lc;
   while (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }
 
-  auto issue = [&](int buf) {
+  // one k-tile's DMA = NQ + NPI pieces per wave; piece(buf, i) issues piece i, advance() steps the lane's K position
+  auto piece = [&](int buf, int i) {
     char* qd = smem + buf * BUF;
     char* pd = qd + QB;
     const bool tap_ok = tap < p.ntap;
-    const int dr = tr - p.pad_h, ds = ts - p.pad_w;
-    const unsigned coff = (unsigned)c8 * 8u;
-#pragma unroll
-    for (int i = 0; i < NQ; i++) {
+    if (i < NQ) {
+      const int dr = tr - p.pad_h, ds = ts - p.pad_w;
       int dh = dr, dw = ds;
       if (up) { dh = ((qpar[i] & 1) + dr) >> 1; dw = ((qpar[i] >> 1) + ds) >> 1; }
-      const unsigned off = qbase[i] + (unsigned)((dh * p.Ws + dw) * p.ldx) + coff;
+      unsigned off = qbase[i] + (unsigned)((dh * p.Ws + dw) * p.ldx) + (unsigned)c8 * 8u;
+      asm volatile("" : "+v"(off));             // keep the address arithmetic unconditional: a select, not a branch, per piece
       const bool ok = tap_ok && ((qmask[i] >> tap) & 1u);
       const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
-      __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(qd + (wave + 8 * i) * 1024), 16, 0, 0);
-    }
-#pragma unroll
-    for (int i = 0; i < NPI; i++) {
-      if (wave + 8 * i < BI / 8) {              // wave-uniform
-        const bool ok = pok[i] && tap_ok;
-        const bf16_t* src = ok ? (p.w + pbase[i] + (unsigned)q * 8u) : (const bf16_t*)sg_zero_page;
-        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(pd + (wave + 8 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(qd + (wave + NW * i) * 1024), 16, 0, 0);
+    } else {
+      const int j = i - NQ;
+      if (NW * (j + 1) <= BI / 8 || wave + NW * j < BI / 8) {     // compile-time true for full groups, else wave-uniform
+        const bool ok = pok[j] && tap_ok;
+        unsigned woff = pbase[j] + (unsigned)q * 8u;
+        asm volatile("" : "+v"(woff));
+        const bf16_t* src = ok ? (p.w + woff) : (const bf16_t*)sg_zero_page;
+        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, 0, 0);
       }
     }
-    // advance to the next k-tile: 8 chunks further
-    q += 8; c8 += 8;
-    while (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }   // one step when C >= 64; up to 8 for thin inputs
+  };
+  // next k-tile: 8 chunks further. C >= 64: at most one tap boundary, done with selects (no branch in the k-loop);
+  // thin inputs (C = 8/16/32, a uniform property of the launch): 8/cpt whole taps per k-tile
+  auto advance = [&]() {
+    q += 8;
+    if (p.cpt >= 8) {
+      c8 += 8;
+      const bool w = c8 >= p.cpt;
+      c8 -= w ? p.cpt : 0;
+      tap += w ? 1 : 0; ts += w ? 1 : 0;
+      const bool w2 = ts == p.S;
+      ts = w2 ? 0 : ts; tr += w2 ? 1 : 0;
+    } else {
+      tap += 8 / p.cpt;
+      tr = tap / p.S; ts = tap - tr * p.S;
+    }
+  };
+  auto issue = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < NQ + NPI; i++) piece(buf, i);
+    advance();
   };
 
   f32x16 acc[TI][TJ];
@@ -130,13 +154,14 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
   const int wj = wave % WJ, wi = wave / WJ;
   const int wj0 = wj * (BJ / WJ), wi0 = wi * (BI / WI);
   const int frow = lane & 31, fhi = lane >> 5;
-  const bool relu = (p.flags & SG_PIX_RELU) != 0;
 
   const int nk = (p.K / 8 + 7) / 8;   // k-tiles of 8 chunks
   issue(0);
   __syncthreads();
+  constexpr int NP = NQ + NPI, PPS = (NP + 3) / 4;     // pieces per MFMA sub-step when spread (SCHED 1)
   for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) issue((kt + 1) & 1);
+    const bool more = kt + 1 < nk;
+    if (SCHED == 0 && more) issue((kt + 1) & 1);
     const char* qs = smem + (kt & 1) * BUF;
     const char* ps = qs + QB;
 #pragma unroll
@@ -154,8 +179,12 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
         const int row = wj0 + b * 32 + frow;
         const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
         u32x4 v = *(const u32x4*)(qs + row * 128 + ch * 16);
-        if (relu) v = relu16<bf16_t>(v);
+        if (RELU) v = relu16<bf16_t>(v);
         qf[b] = __builtin_bit_cast(bf16x8_t, v);
+      }
+      if (SCHED == 1 && more) {
+#pragma unroll
+        for (int i = ks * PPS; i < (ks + 1) * PPS && i < NP; i++) piece((kt + 1) & 1, i);
       }
 #pragma unroll
       for (int a = 0; a < TI; a++)
@@ -163,6 +192,7 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
         for (int b = 0; b < TJ; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
     }
+    if (SCHED == 1 && more) advance();
     __syncthreads();
   }
 
@@ -182,15 +212,20 @@ __global__ __launch_bounds__(512) void sg_conv_v2_kernel(ConvV2Params p, Epilogu
     }
 }
 
-template <int BI, int WJ, int WI, int BJ = 256>
-static inline int sg_launch_conv_v2(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU>
+static inline int sg_launch_conv_v2r(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BUF = (BJ + BI) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ>), dim3(tilesI * tilesJ), dim3(512), 2 * BUF, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), 2 * BUF, st, p, e, tilesI, tilesJ);
   return 0;
+}
+template <int BI, int WJ, int WI, int BJ = 256, int SCHED = 0>
+static inline int sg_launch_conv_v2(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  if (p.flags & SG_PIX_RELU) return sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, true>(p, e, st);
+  return sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, false>(p, e, st);
 }

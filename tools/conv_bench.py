@@ -43,7 +43,7 @@ def main():
     print(f"{'shape':34s} {'GFLOP':>8s} | {'fwd ms':>8s} {'TF':>7s} | {'dgrad ms':>8s} {'TF':>7s} | {'wgrad ms':>8s} {'TF':>7s}")
     tot = [0.0, 0.0, 0.0, 0.0]
     for (Cin, Cout, H, R, fl) in SHAPES:
-        if args.only and args.only not in f"{Cin}-{Cout}-{H}":
+        if args.only and not any(o == f"{Cin}-{Cout}-{H}" or (o in f"{Cin}-{Cout}-{H}-{fl}" and "-" not in o.replace(f"{Cin}-{Cout}-{H}", "")) for o in args.only.split(",")):
             continue
         up, relu, pool = "up" in fl, "relu" in fl, "pool" in fl
         Hs = H // 2 if up else H
