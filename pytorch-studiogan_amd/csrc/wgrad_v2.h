@@ -41,6 +41,33 @@ __device__ __forceinline__ bf16x8_t sg_frag_tr_swz(const char* img, int col0, in
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
+// The same fragment through inline asm. hipcc treats the transpose-read builtin as an LDS access that may alias the LDS-DMA in
+// flight and puts `s_waitcnt vmcnt(0)` in front of it -- i.e. it drains the NEXT tile's prefetch right after issuing it, which
+// serialised copy and compute in this kernel. The asm form is invisible to that analysis; the data dependence on the read is
+// re-created by routing the registers through sg_lgkm_wait<N>() (an `s_waitcnt lgkmcnt(N)` that "modifies" them) before use.
+typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+struct WgFrags { u32x2 v[8]; };               // {pf0, pf1, qf0, qf1} x {pixels 0..3 | 4..7 of the lane's 8}
+__device__ __forceinline__ void sg_frag_tr_issue(const char* img, int col0, int ks, u32x2& lo, u32x2& hi) {
+  const int l = threadIdx.x & 63;
+  const int g16 = l >> 4, t = l & 15;
+  const int prow = ks * 16 + 8 * (g16 >> 1) + (t >> 2);
+  const int col16 = col0 + 16 * (g16 & 1);
+  const int slot = ((col16 >> 3) + ((t & 3) >> 1)) ^ (4 * (t >> 2));
+  const unsigned a = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)(img + prow * 256 + slot * 16 + 8 * (t & 1));
+  asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(lo) : "v"(a));
+  asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=&v"(hi) : "v"(a));
+}
+template <int N> __device__ __forceinline__ void sg_lgkm_wait(WgFrags& f) {
+  asm volatile("s_waitcnt lgkmcnt(%8)"
+               : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]), "+v"(f.v[6]), "+v"(f.v[7])
+               : "n"(N));
+}
+__device__ __forceinline__ bf16x8_t sg_frag_join(u32x2 lo, u32x2 hi) {
+  u32x4 r = {lo[0], lo[1], hi[0], hi[1]};
+  return __builtin_bit_cast(bf16x8_t, r);
+}
+
+template <bool XRELU>
 __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   constexpr int IMG = 64 * 256;              // one [64][128] bf16 image
   constexpr int BUF = 3 * IMG;               // P sub-image 0, P sub-image 1, Q
@@ -91,13 +118,15 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
         int hh = ho + pr[h], ww = wo + ps[h];
         const bool ok = inb & pv[h] & ((unsigned)hh < (unsigned)p.Hin) & ((unsigned)ww < (unsigned)p.Win);
         if (p.x_up) { hh >>= 1; ww >>= 1; }
-        const unsigned off = ((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + pc[h];
+        unsigned off = ((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + pc[h];
+        asm volatile("" : "+v"(off));            // unconditional address arithmetic: a select per piece, no branch
         const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
         __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + h * IMG + pg * 1024), 16, 0, 0);
       }
       {
         const int hg = p.g_up ? (ho >> 1) : ho, wg = p.g_up ? (wo >> 1) : wo;
-        const unsigned off = ((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol;
+        unsigned off = ((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol;
+        asm volatile("" : "+v"(off));
         const bf16_t* src = (inb & qv) ? (p.dy + off) : (const bf16_t*)sg_zero_page;
         __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + 2 * IMG + pg * 1024), 16, 0, 0);
       }
@@ -121,20 +150,32 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     const char* base = smem + (kt & 1) * BUF;
     const char* pimg = base + (wi >> 1) * IMG;
     const char* qimg = base + 2 * IMG;
+    // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks; lgkmcnt(8) = "everything but those 8 reads"
+    WgFrags fr[2];
+    auto load = [&](int ks, WgFrags& f) {
+      sg_frag_tr_issue(pimg, 64 * (wi & 1), ks, f.v[0], f.v[1]);
+      sg_frag_tr_issue(pimg, 64 * (wi & 1) + 32, ks, f.v[2], f.v[3]);
+      sg_frag_tr_issue(qimg, 64 * wj, ks, f.v[4], f.v[5]);
+      sg_frag_tr_issue(qimg, 64 * wj + 32, ks, f.v[6], f.v[7]);
+    };
+    load(0, fr[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
+      if (ks < 3) { load(ks + 1, fr[(ks + 1) & 1]); sg_lgkm_wait<8>(fr[ks & 1]); }
+      else sg_lgkm_wait<0>(fr[ks & 1]);
+      WgFrags& f = fr[ks & 1];
       bf16x8_t pf[2], qf[2];
 #pragma unroll
       for (int a = 0; a < 2; a++) {
-        pf[a] = sg_frag_tr_swz(pimg, 64 * (wi & 1) + 32 * a, ks);
-        if (p.x_relu) {
+        pf[a] = sg_frag_join(f.v[2 * a], f.v[2 * a + 1]);
+        if (XRELU) {
           u32x4 v = __builtin_bit_cast(u32x4, pf[a]);
           v = relu16<bf16_t>(v);
           pf[a] = __builtin_bit_cast(bf16x8_t, v);
         }
       }
 #pragma unroll
-      for (int b = 0; b < 2; b++) qf[b] = sg_frag_tr_swz(qimg, 64 * wj + 32 * b, ks);
+      for (int b = 0; b < 2; b++) qf[b] = sg_frag_join(f.v[4 + 2 * b], f.v[5 + 2 * b]);
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
@@ -160,14 +201,18 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     }
 }
 
-static inline int sg_launch_wgrad_v2(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
+template <bool XRELU>
+static inline int sg_launch_wgrad_v2r(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
   constexpr int LDS = 2 * 3 * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel<XRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + 255) / 256, tilesJ = (p.J + 127) / 128;
-  hipLaunchKernelGGL(sg_wgrad_v2_kernel, dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL(sg_wgrad_v2_kernel<XRELU>, dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
   return 0;
+}
+static inline int sg_launch_wgrad_v2(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
+  return p.x_relu ? sg_launch_wgrad_v2r<true>(p, e, splits, st) : sg_launch_wgrad_v2r<false>(p, e, splits, st);
 }
