@@ -229,6 +229,16 @@ int sg_gp_fwd(const float* grads, int B, long long n, float* norms, float* loss,
 int sg_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s);
 int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B, int HW, int C, sg_stream_t s);
 
+/* ---- fused self-attention scores (reference utils/ops.py:83-103: softmax(theta . maxpool(phi)^T) and its backward), bf16 only.
+ * theta [B][HW][Dp], phi [B][HW4][Dp] (pooled), g [B][HW4][Cg] (pooled), dO [B][HW][Cg]; Dp <= 32, Dp % 8 == 0.
+ *   sg_attn_probs_fwd: P [B][HW][HW4] bf16 = row softmax of the scores, lse [B][HW] = row log-sum-exp (scores stay in registers)
+ *   sg_attn_ds_bwd:    dS [B][HW][HW4] bf16 = P * (dP - sum_k P dP), dP = dO . g^T, P recomputed from theta / phi / lse
+ * sg_attn_fused_ok returns 1 when the shape is supported (HW % 128 == 0, HW4 % 256 == 0, HW4 <= 2048, Cg <= 128). */
+int sg_attn_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
+int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, float* lse, int B, int HW, int HW4, int Dp, sg_stream_t s);
+int sg_attn_ds_bwd(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, void* dS,
+                   int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
+
 /* ---- optimizer / EMA over flat arenas -------------------------------------------------------------------- */
 /* torch.optim.Adam (no amsgrad, no weight decay unless wd != 0) on a flat fp32 arena, fused with the EMA of
  * the generator copy (ema may be NULL): p_ema = p_new.lerp(p_ema, decay) (reference utils/ema.py:27-35) */

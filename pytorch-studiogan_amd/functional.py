@@ -744,37 +744,48 @@ class AttnCoreFn(torch.autograd.Function):
         idx_g = torch.empty((B, HW4, Cg), dtype=torch.uint8, device=dev)
         L.call("sg_maxpool2_fwd", sd, L.ptr(phi_full), Dp, L.ptr(phi), Dp, L.ptr(idx_phi), B, H, W, Dp, L.stream())
         L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
-        S = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
-        # S[q][k] = theta_q . phi_k
-        gemm_raw(sd, phi, 0, Dp, theta, 0, Dp, S, HW4, HW4, HW, Dp, batch=B, p_bs=HW4 * Dp, q_bs=HW * Dp, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+        fused = T == torch.bfloat16 and L.lib().sg_attn_fused_ok(B, HW, HW4, Dp, Cg) == 1
         P = torch.empty((B, HW, HW4), dtype=T, device=dev)
-        L.call("sg_softmax_rows", sd, L.ptr(S), L.ptr(P), B * HW, HW4, L.stream())
-        del S
+        lse = None
+        if fused:
+            # scores stay in registers: one pass writes the bf16 probabilities (csrc/attn.hip)
+            lse = torch.empty((B, HW), dtype=torch.float32, device=dev)
+            L.call("sg_attn_probs_fwd", L.ptr(theta), L.ptr(phi), L.ptr(P), L.ptr(lse), B, HW, HW4, Dp, L.stream())
+        else:
+            S = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
+            # S[q][k] = theta_q . phi_k
+            gemm_raw(sd, phi, 0, Dp, theta, 0, Dp, S, HW4, HW4, HW, Dp, batch=B, p_bs=HW4 * Dp, q_bs=HW * Dp, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+            L.call("sg_softmax_rows", sd, L.ptr(S), L.ptr(P), B * HW, HW4, L.stream())
+            del S
         o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
         # o[q][c] = sum_k P[q][k] g[k][c]
         gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
-        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P)
+        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse)
         ctx.dims = (B, H, W, Dp, Cg)
         return o
 
     @staticmethod
     def backward(ctx, do):
         _first_order_only("AttnCoreFn")
-        theta, phi, g, idx_phi, idx_g, P = ctx.saved_tensors
+        theta, phi, g, idx_phi, idx_g, P, lse = ctx.saved_tensors
         B, H, W, Dp, Cg = ctx.dims
         HW, HW4 = H * W, (H // 2) * (W // 2)
         do = _c(do)
         dev, T = do.device, do.dtype
         sd = L.dt(T)
-        # dP[q][k] = sum_c do[q][c] g[k][c]
-        dP = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
-        gemm_raw(sd, g, 0, Cg, do, 0, Cg, dP, HW4, HW4, HW, Cg, batch=B, p_bs=HW4 * Cg, q_bs=HW * Cg, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
         # dg[k][c] = sum_q P[q][k] do[q][c]
         dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
         gemm_raw(sd, do, 1, Cg, P, 1, HW4, dg, Cg, Cg, HW4, HW, batch=B, p_bs=HW * Cg, q_bs=HW * HW4, out_bs=HW4 * Cg)
         dS = torch.empty((B, HW, HW4), dtype=T, device=dev)
-        L.call("sg_softmax_rows_bwd", sd, L.ptr(P), L.ptr(dP), L.ptr(dS), B * HW, HW4, L.stream())
-        del dP
+        if lse is not None:
+            # dS = P * (dP - sum_k P dP) with P and dP = dO . g^T recomputed in registers: no fp32 dP, no re-read of P (csrc/attn.hip)
+            L.call("sg_attn_ds_bwd", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(lse), L.ptr(dS), B, HW, HW4, Dp, Cg, L.stream())
+        else:
+            # dP[q][k] = sum_c do[q][c] g[k][c]
+            dP = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
+            gemm_raw(sd, g, 0, Cg, do, 0, Cg, dP, HW4, HW4, HW, Cg, batch=B, p_bs=HW4 * Cg, q_bs=HW * Cg, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+            L.call("sg_softmax_rows_bwd", sd, L.ptr(P), L.ptr(dP), L.ptr(dS), B * HW, HW4, L.stream())
+            del dP
         # dtheta[q][d] = sum_k dS[q][k] phi[k][d]
         dtheta = torch.empty((B, H, W, Dp), dtype=T, device=dev)
         gemm_raw(sd, phi, 1, Dp, dS, 0, HW4, dtheta, Dp, Dp, HW, HW4, batch=B, p_bs=HW4 * Dp, q_bs=HW * HW4, out_bs=HW * Dp)

@@ -310,14 +310,16 @@ def test_softmax_pool_misc(sg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-def test_attention_core(sg, dtype):
-    """AttnCoreFn = maxpool + QK^T + softmax + PV and its backward vs the reference formulation (utils/ops.py:83-100)."""
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 4, 16), (3, 32, 32, 24, 24, 96), (2, 32, 32, 16, 12, 48), (2, 64, 32, 32, 32, 40)])
+def test_attention_core(sg, dtype, shape):
+    """AttnCoreFn = maxpool + QK^T + softmax + PV and its backward vs the reference formulation (utils/ops.py:83-100).
+    The 32x32 / 64x32 shapes take the fused score kernels of csrc/attn.hip in bf16 (G: 24 -> 96 channels, D: 12(16) -> 48)."""
     from studiogan_amd import functional as F
     d = dev()
-    B, H, W, Dp, Dv, Cg = 2, 8, 8, 8, 4, 16
+    B, H, W, Dp, Dv, Cg = shape
     tol = 5e-4 if dtype == torch.float32 else 3e-2
-    th = rnd((B, Dp, H, W), dtype, 61); th[:, Dv:] = 0
-    ph = rnd((B, Dp, H, W), dtype, 62); ph[:, Dv:] = 0
+    th = rnd((B, Dp, H, W), dtype, 61, 0.5); th[:, Dv:] = 0
+    ph = rnd((B, Dp, H, W), dtype, 62, 0.5); ph[:, Dv:] = 0
     g = rnd((B, Cg, H, W), dtype, 63)
     thr, phr, gr = [t.double().requires_grad_(True) for t in (th, ph, g)]
     theta = thr.view(B, Dp, H * W)
