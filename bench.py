@@ -169,12 +169,20 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the product path has no CPU fallback)"
+    # SG_BENCH_ONE_DEVICE=1: plumbing check of the multi-rank path on a 1-GPU box (all ranks on cuda:0, gloo instead of RCCL);
+    # never a benchmark configuration
+    one_dev = os.environ.get("SG_BENCH_ONE_DEVICE") == "1"
+    if one_dev:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     group = None
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
+        if one_dev:
+            dist.init_process_group(backend="gloo", init_method="env://")
+        else:
+            dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         group = dist.group.WORLD
     assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
@@ -264,6 +272,15 @@ def main():
     conv_flop = prof[2] + prof[5]
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
+    # HBM bytes per conv launch: PMC counters need their own rocprofv3 passes, so the figure is the committed summary of
+    # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
+    traffic, traffic_src = None, None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc.json")))
+        if args.workload == "biggan128" and mixed and args.batch == 256:
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
+    except Exception:
+        pass
     out = {
         "metric": "images/sec (G+D step) BigGAN ImageNet-128 bs256",
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -272,8 +289,8 @@ def main():
         "config": {"workload": wl["desc"], "per_gpu_batch": args.batch, "global_batch": global_batch, "d_updates_per_step": wl["n_d"],
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": None,
-                     "kernel": "sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                     "kernel": "convolution engine: sg_conv_v2_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),

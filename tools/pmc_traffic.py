@@ -1,0 +1,49 @@
+"""Aggregate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes (separate runs of the same command, csv output) into HBM bytes per
+launch for the convolution-engine kernels (the `roofline.traffic` figure of bench.py).
+
+    python tools/pmc_traffic.py <fetch_counter_collection.csv> <write_counter_collection.csv> > profiles/<name>.json
+
+Units / corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports half of the
+bytes of a wide coalesced read stream (TCC_EA0_RDREQ tallied at 64 B for 128-B requests), so the read side is doubled."""
+import csv
+import json
+import re
+import sys
+
+CONV = re.compile(r"sg_conv_v2_kernel|sg_wgrad_v2_kernel|sg_gemm_kernel<.*ConvPix")
+
+
+def collect(path, counter):
+    per = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            k = re.sub(r"\(.*$", "", r["Kernel_Name"])
+            a = per.setdefault(k, [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return per
+
+
+def main():
+    fetch, write = collect(sys.argv[1], "FETCH_SIZE"), collect(sys.argv[2], "WRITE_SIZE")
+    rows, tot_n, tot_b = [], 0, 0.0
+    for k in sorted(set(fetch) | set(write)):
+        if not CONV.search(k):
+            continue
+        n = max(fetch.get(k, [0, 0])[0], write.get(k, [0, 0])[0])
+        rd = 2.0 * fetch.get(k, [0, 0.0])[1] * 1024.0
+        wr = write.get(k, [0, 0.0])[1] * 1024.0
+        rows.append({"kernel": k[:100], "launches": n, "read_GB": round(rd / 1e9, 3), "write_GB": round(wr / 1e9, 3),
+                     "bytes_per_launch": round((rd + wr) / max(n, 1))})
+        tot_n += n
+        tot_b += rd + wr
+    print(json.dumps({"kernel_family": "convolution engine (sg_conv_v2 / sg_wgrad_v2 / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
+                      "hbm_bytes_per_launch": round(tot_b / max(tot_n, 1)), "read_side_doubled": True,
+                      "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
+                      "per_kernel": rows}, indent=1))
+
+
+if __name__ == "__main__":
+    main()
