@@ -19,6 +19,69 @@ import torch.nn.functional as F
 
 
 # ---------------------------------------------------------------------------------------------------------
+# bf16 storage emulation. The HIP path's bf16 mode keeps activations, activation gradients and weight operand images in
+# bf16 and everything else (accumulators, statistics, master weights, heads, optimizer) in fp32. `Bf16Emu` rounds at the
+# same places so that bf16 parity can be asserted tightly (same ReLU masks up to rounding-boundary cases) instead of through
+# the mask-flip noise bound against the fp32 oracle. With the default `IDENT` every hook returns its argument unchanged: the
+# fp32 restatement is bit-for-bit what it was (make_golden.py re-checks that against the reference).
+#   q  : value written to HBM by a kernel epilogue (round forward; the incoming gradient is a stored bf16 tensor: round backward)
+#   qb : operand read by a kernel whose data gradient is written back in bf16 (identity forward, round backward)
+#   qw : weight operand image (round forward, fp32 weight gradient passes through)
+# ---------------------------------------------------------------------------------------------------------
+def _r(t):
+    return t.to(torch.bfloat16).to(torch.float32)
+
+
+class _RoundBoth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+class _RoundBwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return _r(g)
+
+
+class _RoundFwd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return _r(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class _Ident:
+    emulate = False
+    q = qb = qw = staticmethod(lambda t: t)
+
+
+class Bf16Emu:
+    emulate = True
+    q = staticmethod(_RoundBoth.apply)
+    qb = staticmethod(_RoundBwd.apply)
+    qw = staticmethod(_RoundFwd.apply)
+
+
+IDENT = _Ident()
+
+
+def emu_of(cfg):
+    return cfg.get("emu") or IDENT
+
+
+# ---------------------------------------------------------------------------------------------------------
 # spectral norm -- torch.nn.utils.spectral_norm (installed torch/nn/utils/spectral_norm.py:92-114) as applied by
 # utils/ops.py:195-224 with eps=1e-6, one power iteration per forward call while the module is in .train()
 # ---------------------------------------------------------------------------------------------------------
@@ -46,19 +109,21 @@ def weight_of(P, B, name, power_iterate=True, eps=1e-6, deconv=False):
     return w / sigma
 
 
-def conv(x, P, B, name, padding, sn_iter=True):
+def conv(x, P, B, name, padding, sn_iter=True, E=IDENT, qb_in=True):
+    """qb_in=False: the caller already placed the backward rounding (in front of a fused nearest-x2 upsample: the HIP data
+    gradient sums the 2x2 block in fp32 and rounds once)."""
     w = weight_of(P, B, name, sn_iter)
-    return F.conv2d(x, w, P.get(name + ".bias"), stride=1, padding=padding)
+    return F.conv2d(E.qb(x) if qb_in else x, E.qw(w), P.get(name + ".bias"), stride=1, padding=padding)
 
 
-def conv_strided(x, P, B, name, stride, padding, sn_iter=True):
-    return F.conv2d(x, weight_of(P, B, name, sn_iter), P.get(name + ".bias"), stride=stride, padding=padding)
+def conv_strided(x, P, B, name, stride, padding, sn_iter=True, E=IDENT):
+    return F.conv2d(E.qb(x), E.qw(weight_of(P, B, name, sn_iter)), P.get(name + ".bias"), stride=stride, padding=padding)
 
 
-def deconv(x, P, B, name, stride, padding, sn_iter=True):
+def deconv(x, P, B, name, stride, padding, sn_iter=True, E=IDENT):
     """nn.ConvTranspose2d (utils/ops.py:176-184); weight [Cin][Cout][kh][kw]. Spectral-norm variant (ops.py:207-216)
     normalises over dim 1."""
-    return F.conv_transpose2d(x, weight_of(P, B, name, sn_iter, deconv=True), P.get(name + ".bias"), stride=stride, padding=padding)
+    return F.conv_transpose2d(E.qb(x), E.qw(weight_of(P, B, name, sn_iter, deconv=True)), P.get(name + ".bias"), stride=stride, padding=padding)
 
 
 def linear(x, P, B, name, sn_iter=True):
@@ -91,15 +156,15 @@ def cond_batch_norm(x, y, P, B, name, bn_mode, sn_iter=True):
 # ---------------------------------------------------------------------------------------------------------
 # self attention (utils/ops.py:83-103)
 # ---------------------------------------------------------------------------------------------------------
-def self_attention(x, P, B, name, sn_iter=True):
+def self_attention(x, P, B, name, sn_iter=True, E=IDENT):
     n, ch, h, w = x.shape
-    theta = conv(x, P, B, name + ".conv1x1_theta", 0, sn_iter).view(n, ch // 8, h * w)
-    phi = F.max_pool2d(conv(x, P, B, name + ".conv1x1_phi", 0, sn_iter), 2, 2).view(n, ch // 8, h * w // 4)
-    attn = torch.softmax(torch.bmm(theta.permute(0, 2, 1), phi), dim=-1)
-    g = F.max_pool2d(conv(x, P, B, name + ".conv1x1_g", 0, sn_iter), 2, 2).view(n, ch // 2, h * w // 4)
-    attn_g = torch.bmm(g, attn.permute(0, 2, 1)).view(n, ch // 2, h, w)
-    attn_g = conv(attn_g, P, B, name + ".conv1x1_attn", 0, sn_iter)
-    return x + P[name + ".sigma"] * attn_g
+    theta = E.q(conv(x, P, B, name + ".conv1x1_theta", 0, sn_iter, E)).view(n, ch // 8, h * w)
+    phi = F.max_pool2d(E.q(conv(x, P, B, name + ".conv1x1_phi", 0, sn_iter, E)), 2, 2).view(n, ch // 8, h * w // 4)
+    attn = E.q(torch.softmax(E.qb(torch.bmm(theta.permute(0, 2, 1), phi)), dim=-1))
+    g = F.max_pool2d(E.q(conv(x, P, B, name + ".conv1x1_g", 0, sn_iter, E)), 2, 2).view(n, ch // 2, h * w // 4)
+    attn_g = E.q(torch.bmm(g, attn.permute(0, 2, 1))).view(n, ch // 2, h, w)
+    attn_g = conv(attn_g, P, B, name + ".conv1x1_attn", 0, sn_iter, E)
+    return E.q(x + P[name + ".sigma"] * attn_g)
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -126,24 +191,25 @@ def biggan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
         affines = [torch.cat([shared, item], 1) for item in zs[1:]]
     else:
         affines = list(zs[1:])
-    act = linear(zs[0], P, B, "linear0", sn_iter).view(-1, g_in[0], 4, 4)
+    E = emu_of(cfg)
+    act = E.q(linear(zs[0], P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
     bi = 0
     for index in range(nb):
         pre = f"blocks.{bi}.0"
         x0 = act
-        x = torch.relu(cond_batch_norm(act, affines[index], P, B, pre + ".bn1", bn_mode, sn_iter))
-        x = F.interpolate(x, scale_factor=2, mode="nearest")
-        x = conv(x, P, B, pre + ".conv2d1", 1, sn_iter)
-        x = torch.relu(cond_batch_norm(x, affines[index], P, B, pre + ".bn2", bn_mode, sn_iter))
-        x = conv(x, P, B, pre + ".conv2d2", 1, sn_iter)
-        x0 = conv(F.interpolate(x0, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter)
-        act = x + x0
+        x = E.q(torch.relu(cond_batch_norm(E.qb(act), affines[index], P, B, pre + ".bn1", bn_mode, sn_iter)))
+        x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
+        x = E.q(conv(x, P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
+        x = E.q(torch.relu(cond_batch_norm(E.qb(x), affines[index], P, B, pre + ".bn2", bn_mode, sn_iter)))
+        x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E))
+        x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
+        act = E.q(x + x0)
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
             bi += 1
-    act = torch.relu(batch_norm(act, P, B, "bn4", bn_mode))
-    return torch.tanh(conv(act, P, B, "conv2d5", 1, sn_iter))
+    act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
+    return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
 
 
 def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
@@ -152,20 +218,23 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
     shortcut branch of DiscBlock ALSO sees relu(x) -- restated explicitly here (r = relu(x))."""
     _, _, d_in, d_out, d_down = biggan_dims(cfg["img_size"], cfg["d_conv_dim"])
     sn = cfg["apply_d_sn"]
-    h = x
+    E = emu_of(cfg)
+    h = E.q(x)
     bi = 0
     for index in range(len(d_in)):
         pre = f"blocks.{bi}.0"
         if index == 0:
             x0 = h
-            y = conv(h, P, B, pre + ".conv2d1", 1, sn_iter)
+            y = E.q(conv(h, P, B, pre + ".conv2d1", 1, sn_iter, E))
             if not sn:
-                y = batch_norm(y, P, B, pre + ".bn1", bn_mode)
-            y = F.avg_pool2d(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter), 2)
-            x0 = F.avg_pool2d(x0, 2)
+                y = E.q(torch.relu(batch_norm(E.qb(y), P, B, pre + ".bn1", bn_mode)))
+                y = E.q(F.avg_pool2d(conv(y, P, B, pre + ".conv2d2", 1, sn_iter, E), 2))
+            else:
+                y = E.q(F.avg_pool2d(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E), 2))
+            x0 = E.q(F.avg_pool2d(E.qb(x0), 2))
             if not sn:
-                x0 = batch_norm(x0, P, B, pre + ".bn0", bn_mode)
-            h = y + conv(x0, P, B, pre + ".conv2d0", 0, sn_iter)
+                x0 = E.q(batch_norm(E.qb(x0), P, B, pre + ".bn0", bn_mode))
+            h = E.q(y + conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E))
         else:
             down, mismatch = d_down[index], d_in[index] != d_out[index]
             if sn:
@@ -174,24 +243,30 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
                 y = r
             else:
                 x0 = h
-                y = torch.relu(batch_norm(h, P, B, pre + ".bn1", bn_mode))
-            y = conv(y, P, B, pre + ".conv2d1", 1, sn_iter)
+                y = E.q(torch.relu(batch_norm(E.qb(h), P, B, pre + ".bn1", bn_mode)))
+            y = E.q(conv(y, P, B, pre + ".conv2d1", 1, sn_iter, E))
             if not sn:
-                y = batch_norm(y, P, B, pre + ".bn2", bn_mode)
-            y = conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter)
+                y = E.q(torch.relu(batch_norm(E.qb(y), P, B, pre + ".bn2", bn_mode)))
+                y = conv(y, P, B, pre + ".conv2d2", 1, sn_iter, E)
+            else:
+                y = conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E)
             if down:
                 y = F.avg_pool2d(y, 2)
+            y = E.q(y)
             if down or mismatch:
                 if not sn:
-                    x0 = batch_norm(x0, P, B, pre + ".bn0", bn_mode)
-                x0 = conv(x0, P, B, pre + ".conv2d0", 0, sn_iter)
+                    x0 = E.q(batch_norm(E.qb(x0), P, B, pre + ".bn0", bn_mode))
+                x0 = conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E)
                 if down:
                     x0 = F.avg_pool2d(x0, 2)
-            h = y + x0
+            else:
+                x0 = E.qb(x0)
+            h = E.q(y + x0)
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
-            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter)
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
             bi += 1
+    h = E.qb(h)
     h = torch.sum(torch.relu(h), dim=[2, 3])
     adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
     if cfg.get("d_cond_mtd", "W/O") == "PD":
@@ -210,25 +285,28 @@ def resnet_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
     cond = cfg.get("g_cond_mtd", "W/O") != "W/O"
     aff = F.one_hot(label, num_classes=cfg["num_classes"]).to(torch.float32) if cond else None
 
+    E = emu_of(cfg)
+
     def bn(x, name):
+        x = E.qb(x)
         return cond_batch_norm(x, aff, P, B, name, bn_mode, sn_iter) if cond else batch_norm(x, P, B, name, bn_mode)
 
-    act = linear(z, P, B, "linear0", sn_iter).view(-1, g_in[0], 4, 4)
+    act = E.q(linear(z, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
     bi = 0
     for index in range(len(g_in)):
         pre = f"blocks.{bi}.0"
         x0 = act
-        x = torch.relu(bn(act, pre + ".bn1"))
-        x = conv(F.interpolate(x, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d1", 1, sn_iter)
-        x = conv(torch.relu(bn(x, pre + ".bn2")), P, B, pre + ".conv2d2", 1, sn_iter)
-        x0 = conv(F.interpolate(x0, scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter)
-        act = x + x0
+        x = E.q(torch.relu(bn(act, pre + ".bn1")))
+        x = E.q(conv(F.interpolate(E.qb(x), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
+        x = E.q(conv(E.q(torch.relu(bn(x, pre + ".bn2"))), P, B, pre + ".conv2d2", 1, sn_iter, E))
+        x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
+        act = E.q(x + x0)
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
             bi += 1
-    act = torch.relu(batch_norm(act, P, B, "bn4", bn_mode))
-    return torch.tanh(conv(act, P, B, "conv2d5", 1, sn_iter))
+    act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
+    return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -238,42 +316,45 @@ def dcgan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
     """models/deep_conv.py:90-121 (Generator.forward), GenBlock.forward :32-39."""
     cond = cfg.get("g_cond_mtd", "W/O") != "W/O"
     aff = F.one_hot(label, num_classes=cfg["num_classes"]).to(torch.float32) if cond else None
-    act = linear(z, P, B, "linear0", sn_iter).view(-1, 512, 4, 4)
+    E = emu_of(cfg)
+    act = E.q(linear(z, P, B, "linear0", sn_iter)).view(-1, 512, 4, 4)
     bi = 0
     for index in range(3):
         pre = f"blocks.{bi}.0"
-        x = deconv(act, P, B, pre + ".deconv0", 2, 1, sn_iter)
+        x = E.qb(E.q(deconv(act, P, B, pre + ".deconv0", 2, 1, sn_iter, E)))
         x = cond_batch_norm(x, aff, P, B, pre + ".bn0", bn_mode, sn_iter) if cond else batch_norm(x, P, B, pre + ".bn0", bn_mode)
-        act = torch.relu(x)
+        act = E.q(torch.relu(x))
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter)
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
             bi += 1
-    return torch.tanh(conv(act, P, B, "conv4", 1, sn_iter))
+    return torch.tanh(E.q(conv(act, P, B, "conv4", 1, sn_iter, E)))
 
 
 def dcgan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
     """models/deep_conv.py:232-247,270-271 (Discriminator.forward), DiscBlock.forward :139-149."""
     sn = cfg["apply_d_sn"]
-    h = x
+    E = emu_of(cfg)
+    h = E.q(x)
     bi = 0
     for index in range(3):
         pre = f"blocks.{bi}.0"
-        h = conv(h, P, B, pre + ".conv0", 1, sn_iter)
+        h = E.q(conv(h, P, B, pre + ".conv0", 1, sn_iter, E))
         if not sn:
-            h = batch_norm(h, P, B, pre + ".bn0", bn_mode)
-        h = conv_strided(torch.relu(h), P, B, pre + ".conv1", 2, 1, sn_iter)
-        if not sn:
-            h = batch_norm(h, P, B, pre + ".bn1", bn_mode)
-        h = torch.relu(h)
+            h = E.q(torch.relu(batch_norm(E.qb(h), P, B, pre + ".bn0", bn_mode)))
+            h = E.q(conv_strided(h, P, B, pre + ".conv1", 2, 1, sn_iter, E))
+            h = E.q(torch.relu(batch_norm(E.qb(h), P, B, pre + ".bn1", bn_mode)))
+        else:
+            h = E.q(conv_strided(torch.relu(h), P, B, pre + ".conv1", 2, 1, sn_iter, E))
+            h = torch.relu(h)
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
-            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter)
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
             bi += 1
-    h = conv(h, P, B, "conv1", 1, sn_iter)
+    h = E.q(conv(h, P, B, "conv1", 1, sn_iter, E))
     if not sn:
-        h = batch_norm(h, P, B, "bn1", bn_mode)
-    h = torch.sum(torch.relu(h), dim=[2, 3])
+        h = E.q(batch_norm(E.qb(h), P, B, "bn1", bn_mode))
+    h = torch.sum(torch.relu(E.qb(h)), dim=[2, 3])
     adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
     if cfg.get("d_cond_mtd", "W/O") == "PD":
         adv = adv + torch.sum(F.embedding(label, weight_of(P, B, "embedding", sn_iter)) * h, 1)

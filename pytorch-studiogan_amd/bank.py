@@ -29,10 +29,10 @@ _ARENA_BY_ID = {}  # id(Parameter) -> (weakref to the Parameter, ParamArena, off
 def _register(p, arena, off):
     key = id(p)
 
-    def _gone(_ref, key=key):
-        ent = _ARENA_BY_ID.get(key)
+    def _gone(_ref, key=key, table=_ARENA_BY_ID):      # `table` bound here: module globals are None during interpreter shutdown
+        ent = table.get(key)
         if ent is not None and ent[0] is _ref:
-            del _ARENA_BY_ID[key]
+            del table[key]
     _ARENA_BY_ID[key] = (weakref.ref(p, _gone), arena, off)
 
 
