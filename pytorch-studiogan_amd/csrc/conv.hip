@@ -69,12 +69,17 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.Hin = d->Hs * up; p.Win = d->Ws * up; p.Ho = d->Ho; p.Wo = d->Wo;
   p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags;
   p.I = I; p.J = J; p.K = K; p.cpt = d->C / 8; p.ntap = d->R * d->S;
+  p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
   int rc = 0;
   // piece placement (conv_v2.h SCHED): spreading the DMA pieces over the MFMA sub-steps pays on the 96-wide tiles (10 pieces per
   // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %). SG_CONV_SCHED=0/1 forces one for A/B runs.
   static const int sched_env = [] { const char* v = getenv("SG_CONV_SCHED"); return v ? atoi(v) : -1; }();
   const bool s1 = sched_env >= 0 ? sched_env == 1 : (best == 96);
-  if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st);
+  if (best == 192 && sched_env >= 2) {      // ablation variants (tools/conv_bench.py only; results are wrong by construction)
+    rc = sched_env == 2 ? sg_launch_conv_v2<192, 4, 2, 256, 2>(p, e, st) : sched_env == 3 ? sg_launch_conv_v2<192, 4, 2, 256, 3>(p, e, st)
+       : sched_env == 4 ? sg_launch_conv_v2<192, 4, 2, 256, 4>(p, e, st) : sched_env == 5 ? sg_launch_conv_v2<192, 4, 2, 256, 5>(p, e, st)
+                                                                                          : sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st);
+  } else if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st);
   else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 0>(p, e, st);
   else {
     // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)

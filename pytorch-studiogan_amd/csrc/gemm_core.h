@@ -281,6 +281,11 @@ template <typename T> struct Epilogue {
 
   // lane owns (j, i0..i0+3)
   __device__ __forceinline__ void store(int j, int i0, float v[4], float a) const {
+    if (prep(j, i0, v, a)) write(j, i0, v);
+  }
+  // everything but the final store: pooling, scale, bias, mask, residual, ReLU. Returns false when this lane has nothing to
+  // write; j becomes the OUTPUT row (pooled index with SG_EPI_POOL). Every lane of the wave must call it (pool shuffles).
+  __device__ __forceinline__ bool prep(int& j, int i0, float v[4], float a) const {
     const int lane = threadIdx.x & 63;
     if (flags & SG_EPI_POOL) {
 #pragma unroll
@@ -288,11 +293,11 @@ template <typename T> struct Epilogue {
         v[e] += __shfl_xor(v[e], 1, 64);
         v[e] += __shfl_xor(v[e], 2, 64);
       }
-      if (lane & 3) return;
+      if (lane & 3) return false;
       j >>= 2;
     }
     const int Jout = (flags & SG_EPI_POOL) ? (J >> 2) : J;
-    if (j >= Jout || i0 >= I) return;
+    if (j >= Jout || i0 >= I) return false;
     const int ne = (I - i0) < 4 ? (I - i0) : 4;
 #pragma unroll
     for (int e = 0; e < 4; e++) {
@@ -320,6 +325,10 @@ template <typename T> struct Epilogue {
 #pragma unroll
       for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
     }
+    return true;
+  }
+  __device__ __forceinline__ void write(int j, int i0, const float v[4]) const {
+    const int ne = (I - i0) < 4 ? (I - i0) : 4;
     if (flags & SG_EPI_ATOMIC) {
       float* o = (float*)out + (long long)j * ldo + i0;
 #pragma unroll
