@@ -53,7 +53,7 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   if (d->C < 64 && d->C != 8 && d->C != 16 && d->C != 32) return false;   // thin inputs: a k-tile of 8 chunks must cover whole taps
   if (!aligned16(d->x) || !aligned16(d->w)) return false;
   const int tj = (J + 255) / 256;
-  const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile spills with hipcc 7.2: left out)
+  const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile puts part of its 128 accumulator registers in scratch with hipcc 7.2: left out)
   int best = 0, best_tiles = 0;
   for (int c = 0; c < 3; c++) {
     if (I % cands[c]) continue;
@@ -72,15 +72,16 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
   int rc = 0;
   // piece placement (conv_v2.h SCHED): spreading the DMA pieces over the MFMA sub-steps pays on the 96-wide tiles (10 pieces per
-  // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %). SG_CONV_SCHED=0/1 forces one for A/B runs.
+  // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %); those use the fragment-prefetch form
+  // (SCHED 7, +1.5 %). SG_CONV_SCHED=0/1/7 forces one for A/B runs, 2..6 are the ablation variants.
   static const int sched_env = [] { const char* v = getenv("SG_CONV_SCHED"); return v ? atoi(v) : -1; }();
   const bool s1 = sched_env >= 0 ? sched_env == 1 : (best == 96);
   if (best == 192 && sched_env >= 2) {      // ablation variants (tools/conv_bench.py only; results are wrong by construction)
     rc = sched_env == 2 ? sg_launch_conv_v2<192, 4, 2, 256, 2>(p, e, st) : sched_env == 3 ? sg_launch_conv_v2<192, 4, 2, 256, 3>(p, e, st)
        : sched_env == 4 ? sg_launch_conv_v2<192, 4, 2, 256, 4>(p, e, st) : sched_env == 5 ? sg_launch_conv_v2<192, 4, 2, 256, 5>(p, e, st)
-                                                                                          : sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st);
-  } else if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st);
-  else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 0>(p, e, st);
+       : sched_env == 6 ? sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st);
+  } else if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : (sched_env == 0 ? sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st));
+  else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 7>(p, e, st);
   else {
     // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)
     const char* b5 = getenv("SG_CONV_BJ512");
@@ -141,7 +142,8 @@ static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
   if (d->C % 8 || d->ldx % 8 || d->Cout % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return false;
   const long long K = (long long)d->N * d->Ho * d->Wo;
   const int I = d->R * d->S * d->C;
-  if (!force && (I < 256 || d->Cout < 64 || K < 4096)) return false;
+  if (!force && (I < 64 || d->Cout < 64 || K < 4096)) return false;   // narrow I (1x1 convs, the 8-channel RGB stem) wastes part of the
+                                                                       // 256-row tile but still beats the generic kernel 3-4x
   return true;
 }
 

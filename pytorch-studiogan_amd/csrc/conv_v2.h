@@ -162,15 +162,46 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   const int wj0 = wj * (BJ / WJ), wi0 = wi * (BI / WI);
   const int frow = lane & 31, fhi = lane >> 5;
 
-  const int nk = (SCHED >= 5) ? 1 : (p.K / 8 + 7) / 8;   // k-tiles of 8 chunks (SCHED 5/6: ablation, one k-tile only)
+  const int nk = (SCHED == 5 || SCHED == 6) ? 1 : (p.K / 8 + 7) / 8;   // k-tiles of 8 chunks (SCHED 5/6: ablation, one k-tile only)
   issue(0);
   __syncthreads();
   constexpr int NP = NQ + NPI, PPS = (NP + 3) / 4;     // pieces per MFMA sub-step when spread (SCHED 1)
   for (int kt = 0; kt < nk; kt++) {
     const bool more = (SCHED == 2 || SCHED == 4) ? false : (kt + 1 < nk);     // SCHED 2/4: ablation, no DMA in the loop (wrong results)
-    if ((SCHED == 0 || SCHED == 3) && more) issue((kt + 1) & 1);
+    if ((SCHED == 0 || SCHED == 3 || SCHED == 7) && more) issue((kt + 1) & 1);
     const char* qs = smem + (kt & 1) * BUF;
     const char* ps = qs + QB;
+    if (SCHED == 7) {
+      // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks (register double buffering)
+      bf16x8_t pf[2][TI], qf[2][TJ];
+      auto load = [&](int ks, int slot) {
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          const int row = wi0 + a * 32 + frow;
+          const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+          u32x4 v = *(const u32x4*)(ps + row * 128 + ch * 16);
+          pf[slot][a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          const int row = wj0 + b * 32 + frow;
+          const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+          u32x4 v = *(const u32x4*)(qs + row * 128 + ch * 16);
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[slot][b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      };
+      load(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        if (ks < 3) load(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+      }
+    } else {
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
       bf16x8_t pf[TI], qf[TJ];
@@ -205,6 +236,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
 #pragma unroll
         for (int b = 0; b < TJ; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+    }
     }
     if (SCHED == 1 && more) advance();
     __syncthreads();
