@@ -77,7 +77,7 @@ def test_training_step_vs_golden(sg, name, mixed):
     # sits within rounding distance of 0 moves these gradients by ~1e-2 (measured on the ORACLE by perturbing D's
     # weights by 1e-6, see DESIGN.md "conditioning of the step test"); tight gradient parity is asserted on
     # single forward/backward passes in test_blocks_gpu.py instead.
-    tg = 2e-2 if not mixed else 0.35
+    tg = 2e-2 if not mixed else 0.45   # bf16 vs the fp32 golden chain: mask-flip noise of two D updates + the G pass (tight bf16 parity: test_bf16_vs_emulating_oracle)
     if wide:
         # full-width DCGAN: measured on the oracle alone, the +-0.3 lr differences Adam makes out of rounding noise in D move
         # these gradients by 4-10 % (test_training_step_stagewise_vs_oracle holds the same update to 1e-2 after a re-sync)
