@@ -239,6 +239,12 @@ int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, float* lse, i
 int sg_attn_ds_bwd(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, void* dS,
                    int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
 
+/* BigGAN-deep skips (reference models/big_resnet_deep_legacy.py:53-56,74-77,236-238): channel slice (+ nearest x up, up in {1,2})
+ * y [N][Hs*up][Ws*up][C] from x [N][Hs][Ws][ldx], its adjoint (dx gets all ldx channels, zeros beyond C), and a pitched channel copy */
+int sg_slice_up_fwd(int dtype, const void* x, void* y, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s);
+int sg_slice_up_bwd(int dtype, const void* dy, void* dx, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s);
+int sg_copy_channels(int dtype, const void* src, int ld_src, void* dst, int ld_dst, long long rows, int C, sg_stream_t s);
+
 /* ---- optimizer / EMA over flat arenas -------------------------------------------------------------------- */
 /* torch.optim.Adam (no amsgrad, no weight decay unless wd != 0) on a flat fp32 arena, fused with the EMA of
  * the generator copy (ema may be NULL): p_ema = p_new.lerp(p_ema, decay) (reference utils/ema.py:27-35) */

@@ -37,6 +37,15 @@ CONFIGS = {
               "LOSS": {"adv_loss": "hinge"},
               "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
         batch=4, n_d=2, seed=1234),
+    # BigGAN-deep (C4 family: configs/ImageNet/BigGAN-Deep-256.yaml at width 8): bottleneck blocks, depth 2, attention, SN both
+    "bigdeep32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "big_resnet_deep_legacy", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [2], "attn_d_loc": [1], "z_dim": 24, "g_shared_dim": 16, "g_conv_dim": 8, "d_conv_dim": 8,
+                        "g_depth": 2, "d_depth": 2},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=4242),
     # SNGAN on the ResNet backbone (C2 family: reference configs/CIFAR10/SNGAN.yaml at width 8): cBN on the one-hot label, PD, SN in D only
     "sngan32": dict(
         yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
@@ -134,7 +143,8 @@ def oracle_cfg(y):
     return dict(img_size=D["img_size"], num_classes=D["num_classes"], g_conv_dim=M.get("g_conv_dim", 64), d_conv_dim=M.get("d_conv_dim", 64),
                 z_dim=M.get("z_dim", 128), attn_g_loc=M.get("attn_g_loc", []), attn_d_loc=M.get("attn_d_loc", []), apply_attn=M.get("apply_attn", False),
                 g_cond_mtd=M.get("g_cond_mtd", "W/O"), d_cond_mtd=M.get("d_cond_mtd", "W/O"), apply_g_sn=M.get("apply_g_sn", False),
-                apply_d_sn=M.get("apply_d_sn", False), backbone=M.get("backbone", "resnet"), g_shared_dim=M.get("g_shared_dim", 0))
+                apply_d_sn=M.get("apply_d_sn", False), backbone=M.get("backbone", "resnet"), g_shared_dim=M.get("g_shared_dim", 0),
+                g_depth=M.get("g_depth", 1), d_depth=M.get("d_depth", 1))
 
 
 def synth_inputs(seed, n_d, batch, z_dim, num_classes, img_size):

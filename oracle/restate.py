@@ -276,6 +276,95 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
 
 
 # ---------------------------------------------------------------------------------------------------------
+# BigGAN-deep (models/big_resnet_deep_legacy.py): bottleneck blocks, channel-slice skip in G, channel-concat skip in D
+# ---------------------------------------------------------------------------------------------------------
+def biggan_deep_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet_deep_legacy.py:163-197 (Generator.forward), GenBlock.forward :52-78. One affine input
+    [shared(label), z] for every block (no z chunks); g_depth blocks per stage, the last one upsamples."""
+    g_in, g_out, _, _, _ = biggan_dims(cfg["img_size"], cfg["g_conv_dim"])
+    E = emu_of(cfg)
+    depth = cfg["g_depth"]
+    if cfg.get("g_cond_mtd", "cBN") != "W/O":
+        affine = torch.cat([F.embedding(label, P["shared.weight"]), z], 1)
+    else:
+        affine = z
+    act = E.q(linear(affine, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
+    bi = 0
+    for index in range(len(g_in)):
+        for gi in range(depth):
+            pre = f"blocks.{bi}.0"
+            cin = g_in[index]
+            cout = cin if gi == 0 else g_out[index]
+            up = gi == depth - 1
+            x0 = act[:, :cout] if cin != cout else act
+            x = E.q(torch.relu(cond_batch_norm(E.qb(act), affine, P, B, pre + ".bn1", bn_mode, sn_iter)))
+            x = E.q(conv(x, P, B, pre + ".conv2d1", 0, sn_iter, E))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn2", bn_mode, sn_iter)))
+            if up:
+                x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
+            x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E, qb_in=not up))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn3", bn_mode, sn_iter)))
+            x = E.q(conv(x, P, B, pre + ".conv2d3", 1, sn_iter, E))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn4", bn_mode, sn_iter)))
+            x = conv(x, P, B, pre + ".conv2d4", 0, sn_iter, E)
+            if up:
+                x0 = E.q(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"))
+            act = E.q(x + x0)
+            bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
+            bi += 1
+    act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
+    return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
+
+
+def biggan_deep_dims(img_size, ch):
+    d_in = {32: [4, 4, 4], 64: [1, 2, 4, 8], 128: [1, 2, 4, 8, 16], 256: [1, 2, 4, 8, 8, 16]}[img_size]
+    d_out = {32: [4, 4, 4], 64: [2, 4, 8, 16], 128: [2, 4, 8, 16, 16], 256: [2, 4, 8, 8, 16, 16]}[img_size]
+    d_down = {32: [True, True, False, False], 64: [True] * 4 + [False], 128: [True] * 5 + [False], 256: [True] * 6 + [False]}[img_size]
+    return [c * ch for c in d_in], [c * ch for c in d_out], d_down
+
+
+def biggan_deep_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet_deep_legacy.py:323-330,354-355 (Discriminator.forward), DiscBlock.forward :222-240.
+    nn.ReLU(inplace=True) on the block input also rewrites the skip tensor (same storage): x0 = relu(x)."""
+    d_in, d_out, d_down = biggan_deep_dims(cfg["img_size"], cfg["d_conv_dim"])
+    E = emu_of(cfg)
+    depth = cfg["d_depth"]
+    h = E.q(conv(E.q(x), P, B, "input_conv", 1, sn_iter, E))
+    bi = 0
+    for index in range(len(d_in)):
+        for di in range(depth):
+            pre = f"blocks.{bi}.0"
+            cin = d_in[index] if di == 0 else d_out[index]
+            cout = d_out[index]
+            down = d_down[index] and di == 0
+            r = torch.relu(h)
+            x0 = r
+            y = E.q(conv(r, P, B, pre + ".conv2d1", 0, sn_iter, E))
+            y = E.q(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E))
+            y = E.q(conv(torch.relu(y), P, B, pre + ".conv2d3", 1, sn_iter, E))
+            y = torch.relu(y)
+            if down:
+                y = F.avg_pool2d(y, 2)
+            y = conv(y, P, B, pre + ".conv2d4", 0, sn_iter, E)
+            if down:
+                x0 = E.q(F.avg_pool2d(E.qb(x0), 2))
+            if cin != cout:
+                x0 = torch.cat([x0, E.q(conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E))], 1)
+            h = E.q(y + x0)
+            bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
+            bi += 1
+    h = torch.sum(torch.relu(E.qb(h)), dim=[2, 3])
+    adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
+    if cfg.get("d_cond_mtd", "W/O") == "PD":
+        adv = adv + torch.sum(F.embedding(label, weight_of(P, B, "embedding", sn_iter)) * h, 1)
+    return adv, h
+
+
+# ---------------------------------------------------------------------------------------------------------
 # SNGAN-style ResNet generator (models/resnet.py:15-158); its discriminator is line-for-line models/big_resnet.py's
 # ---------------------------------------------------------------------------------------------------------
 def resnet_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
@@ -498,6 +587,13 @@ def model_fns(cfg):
 
         def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
             return biggan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
+        return gen_fn, dis_fn
+    if bb == "big_resnet_deep_legacy":
+        def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_deep_generator(z, y, P, B, cfg, bn_mode, sn_iter)
+
+        def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_deep_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
         return gen_fn, dis_fn
     if bb == "resnet":
         def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):

@@ -105,6 +105,9 @@ _PROTOS = {
     "sg_attn_fused_ok": [_i, _i, _i, _i, _i],
     "sg_attn_probs_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_attn_ds_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_slice_up_fwd": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_slice_up_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_copy_channels": [_i, _vp, _i, _vp, _i, _ll, _i, _vp],
     "sg_interp_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
     "sg_gp_fwd": [_vp, _i, _ll, _vp, _vp, _vp],
     "sg_gp_bwd": [_vp, _vp, _vp, _vp, _i, _ll, _vp],

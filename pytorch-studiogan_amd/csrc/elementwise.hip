@@ -578,3 +578,57 @@ extern "C" int sg_gp_bwd(const float* grads, const float* norms, const float* go
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- BigGAN-deep skip connections (reference src/models/big_resnet_deep_legacy.py:53-56,74-77,236-238) ------------------------
+// y[n][h][w][c] = x[n][h/up][w/up][c] for c < C: the generator's channel-slice (+ nearest x2) skip
+template <typename T> __global__ void k_slice_up_fwd(const T* x, T* y, int Hs, int Ws, int ldx, int C, int up, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); long long t = i / C;
+    const int w = (int)(t % (Ws * up)); t /= (Ws * up);
+    const int h = (int)(t % (Hs * up)); const int n = (int)(t / (Hs * up));
+    y[i] = x[(((long long)n * Hs + h / up) * Ws + w / up) * ldx + c];
+  }
+}
+extern "C" int sg_slice_up_fwd(int dtype, const void* x, void* y, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s) {
+  SG_CHECK(x && y && C > 0 && C <= ldx && (up == 1 || up == 2), "sg_slice_up_fwd: bad args");
+  const long long total = (long long)N * Hs * up * Ws * up * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_slice_up_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, Hs, Ws, ldx, C, up, total));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// dx[n][hs][ws][c] = sum over the up x up block of dy (c < C), 0 for the channels the slice dropped
+template <typename T> __global__ void k_slice_up_bwd(const T* dy, T* dx, int Hs, int Ws, int ldx, int C, int up, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ldx); long long t = i / ldx;
+    const int ws = (int)(t % Ws); t /= Ws;
+    const int hs = (int)(t % Hs); const int n = (int)(t / Hs);
+    float acc = 0.f;
+    if (c < C) {
+      for (int a = 0; a < up; a++)
+        for (int b = 0; b < up; b++)
+          acc += to_f<T>(dy[(((long long)n * Hs * up + hs * up + a) * (Ws * up) + ws * up + b) * C + c]);
+    }
+    dx[i] = from_f<T>(acc);
+  }
+}
+extern "C" int sg_slice_up_bwd(int dtype, const void* dy, void* dx, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s) {
+  SG_CHECK(dy && dx && C > 0 && C <= ldx && (up == 1 || up == 2), "sg_slice_up_bwd: bad args");
+  const long long total = (long long)N * Hs * Ws * ldx;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_slice_up_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (T*)dx, Hs, Ws, ldx, C, up, total));
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// dst[r][0..C) = src[r][0..C) with independent row pitches (channel-concat skip of the discriminator)
+template <typename T> __global__ void k_copy_channels(const T* src, int lds, T* dst, int ldd, int C, long long total) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C); const long long r = i / C;
+    dst[r * ldd + c] = src[r * lds + c];
+  }
+}
+extern "C" int sg_copy_channels(int dtype, const void* src, int ld_src, void* dst, int ld_dst, long long rows, int C, sg_stream_t s) {
+  SG_CHECK(src && dst && rows > 0 && C > 0 && C <= ld_src && C <= ld_dst, "sg_copy_channels: bad args");
+  const long long total = rows * C;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_copy_channels<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)src, ld_src, (T*)dst, ld_dst, C, total));
+  SG_LAUNCH_CHECK();
+  return 0;
+}

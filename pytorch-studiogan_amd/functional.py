@@ -40,7 +40,7 @@ def _c(t):
 # raw launch helpers (also used directly by the kernel-level tests)
 # ---------------------------------------------------------------------------------------------------------
 def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None,
-               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0):
+               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0, x_coff=0):
     """x: [N,Hs,Ws,ldx] NHWC; returns [N,Ho',Wo',Cout]. w_ptr -> [Cout][R*S*Cin] in x.dtype."""
     N, Hs, Ws = x.shape[0], x.shape[1], x.shape[2]
     ldx = x.shape[3] if ldx is None else ldx
@@ -63,7 +63,7 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
     d.R, d.S, d.stride, d.pad_h, d.pad_w = R, S, stride, pad_h, pad_w
     d.pix_flags, d.epi_flags = pix_flags, epi_flags
     d.alpha, d.beta = alpha, beta
-    d.x, d.w = L.ptr(x), w_ptr
+    d.x, d.w = L.ptr(x) + x_coff * x.element_size(), w_ptr     # x_coff: read a channel slice of a wider tensor (pitch ldx)
     d.bias = L.ptr(bias)
     d.res = L.ptr(res)
     d.mask = L.ptr(mask)
@@ -77,7 +77,7 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
 
 
 def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, pad_w=0, x_flags=0, g_flags=0, alpha=1.0,
-                     alpha_ptr=None, splits=0, no_tr=0, ldg=None):
+                     alpha_ptr=None, splits=0, no_tr=0, ldg=None, dy_coff=0):
     d = L.ConvWgradDesc()
     d.dtype = L.dt(x)
     d.N = x.shape[0]
@@ -86,7 +86,7 @@ def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, 
     d.Ho, d.Wo = Ho, Wo
     d.R, d.S, d.stride, d.pad_h, d.pad_w = R, S, stride, pad_h, pad_w
     d.alpha = alpha
-    d.x, d.dy, d.dw = L.ptr(x), L.ptr(dy), dw_ptr
+    d.x, d.dy, d.dw = L.ptr(x), L.ptr(dy) + dy_coff * dy.element_size(), dw_ptr
     d.alpha_ptr = L.ptr(alpha_ptr)
     d.splits, d.no_tr = splits, no_tr
     sp, wf = L.C.c_int(0), L.C.c_longlong(0)
@@ -330,6 +330,68 @@ class ConvFn(torch.autograd.Function):
             L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())
         dres = dy if ctx.has_res else None
         return dx, None, None, dres, None, None, None
+
+
+class SliceUpFn(torch.autograd.Function):
+    """y = nearest_up(x[..., :C]) (up in {1, 2}): the channel-slice skip of a BigGAN-deep generator block
+    (reference src/models/big_resnet_deep_legacy.py:53-56,74-75)."""
+
+    @staticmethod
+    def forward(ctx, x, C, up):
+        x = _c(x)
+        N, Hs, Ws, ld = x.shape
+        y = torch.empty((N, Hs * up, Ws * up, C), dtype=x.dtype, device=x.device)
+        L.call("sg_slice_up_fwd", L.dt(x), L.ptr(x), L.ptr(y), N, Hs, Ws, ld, C, up, L.stream())
+        ctx.dims = (N, Hs, Ws, ld, C, up)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        _first_order_only("SliceUpFn")
+        N, Hs, Ws, ld, C, up = ctx.dims
+        dy = _c(dy)
+        dx = torch.empty((N, Hs, Ws, ld), dtype=dy.dtype, device=dy.device)
+        L.call("sg_slice_up_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Hs, Ws, ld, C, up, L.stream())
+        return dx, None, None
+
+
+class CatConvFn(torch.autograd.Function):
+    """out = cat([x, conv1x1(x) + bias], channel): the learnable channel-concat skip of a BigGAN-deep discriminator block
+    (reference src/models/big_resnet_deep_legacy.py:236-238). The convolution writes straight into its channel slice; the
+    backward reads the gradient slices in place (data gradient = one launch with the copied slice as its residual)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, rt, slot):
+        bank = rt.bank()
+        x = _c(x)
+        N, H, W, Cin = x.shape
+        Cc = rt.rows
+        out = torch.empty((N, H, W, Cin + Cc), dtype=x.dtype, device=x.device)
+        L.call("sg_copy_channels", L.dt(x), L.ptr(x), Cin, L.ptr(out), Cin + Cc, N * H * W, Cin, L.stream())
+        conv2d_raw(x, bank.w_fwd(slot, rt), Cin, Cc, 1, 1, bias=bias, out=out, out_coff=Cin)
+        ctx.save_for_backward(x)
+        ctx.rt, ctx.slot, ctx.bias = rt, slot, bias
+        return out
+
+    @staticmethod
+    def backward(ctx, dy):
+        _first_order_only("CatConvFn")
+        (x,) = ctx.saved_tensors
+        rt, slot = ctx.rt, ctx.slot
+        bank = rt.bank()
+        dy = _c(dy)
+        N, H, W, Cin = x.shape
+        Cc = rt.rows
+        ld = Cin + Cc
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = conv2d_raw(dy, bank.w_dgrad(slot, rt), Cc, Cin, 1, 1, res=dy, ldx=ld, x_coff=Cin)
+        if ctx.needs_input_grad[1]:
+            conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, Cc, 1, 1, H, W, ldg=ld, dy_coff=Cin)
+        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            g = ensure_grad(ctx.bias)
+            L.call("sg_colsum", L.dt(dy), L.ptr(dy) + Cin * dy.element_size(), ld, None, 0, N * H * W, Cc, L.ptr(g), 1.0, L.stream())
+        return dx, None, None, None, None
 
 
 class ConvTransposeFn(torch.autograd.Function):

@@ -24,18 +24,21 @@ def build_from_yaml(y, mixed, device):
     MOD = ops.Modules(apply_g_sn=M.get("apply_g_sn", False), apply_d_sn=M.get("apply_d_sn", False), g_cond_mtd=M.get("g_cond_mtd", "W/O"),
                       backbone=M.get("backbone", "resnet"))
     G = bb.Generator(M.get("z_dim", 128), M.get("g_shared_dim", "N/A"), D["img_size"], M.get("g_conv_dim", 64), M.get("apply_attn", False),
-                     M.get("attn_g_loc", ["N/A"]), M.get("g_cond_mtd", "W/O"), D["num_classes"], "ortho", "N/A", mixed, MOD, _MODEL)
+                     M.get("attn_g_loc", ["N/A"]), M.get("g_cond_mtd", "W/O"), D["num_classes"], "ortho", M.get("g_depth", "N/A"), mixed, MOD, _MODEL)
     Dm = bb.Discriminator(D["img_size"], M.get("d_conv_dim", 64), M.get("apply_d_sn", False), M.get("apply_attn", False), M.get("attn_d_loc", ["N/A"]),
-                          M.get("d_cond_mtd", "W/O"), "W/O", "N/A", False, D["num_classes"], "ortho", "N/A", mixed, MOD, _MODEL)
+                          M.get("d_cond_mtd", "W/O"), "W/O", "N/A", False, D["num_classes"], "ortho", M.get("d_depth", "N/A"), mixed, MOD, _MODEL)
     return G.to(device), Dm.to(device)
 
 
-ALL = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32"]
+ALL = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32", "bigdeep32"]
 
 
 @pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("name", ALL)
 def test_training_step_vs_golden(sg, name, mixed):
+    if mixed and name == "bigdeep32":
+        pytest.skip("48 ReLU layers at width 8: bf16 vs the fp32 golden chain is noise (30-60 %); bf16 parity of this network is "
+                    "asserted by test_bf16_vs_emulating_oracle, the fp32 chain by the non-mixed variant")
     from studiogan_amd.worker import Worker
     dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
