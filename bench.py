@@ -229,6 +229,34 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    # ---- north-star target figure: the BigGAN-128 (BigGAN-256.yaml) D FORWARD conv stack at batch 256 -----------
+    # 21.673 GFLOP/img whole forward, 21.170 GFLOP/img conv-only; conv-only time = hipEvent brackets of the conv launches.
+    dfwd = None
+    if args.workload == "biggan128" and rank == 0:
+        x, y = real[0]
+        with torch.no_grad():
+            for _ in range(2):
+                D(x, y)
+            torch.cuda.synchronize()
+            L.call("sg_prof_enable", 1)
+            it = 10
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(it):
+                D(x, y)
+            e1.record()
+            torch.cuda.synchronize()
+        pd = (ctypes.c_double * 9)()
+        L.call("sg_prof_collect", pd, 3)
+        L.call("sg_prof_enable", 0)
+        fwd_ms = e0.elapsed_time(e1) / it
+        conv_only_ms = pd[1] / it
+        pk = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
+        dfwd = {"what": "BigGAN-128 D forward at batch %d (SN power iteration + weight packing included in forward_ms)" % args.batch,
+                "forward_ms": round(fwd_ms, 3), "forward_tflops": round(21.673 * args.batch / fwd_ms, 1),
+                "conv_stack_ms": round(conv_only_ms, 3), "conv_launches": int(pd[0] / it),
+                "conv_stack_tflops": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
+                "conv_stack_frac_of_peak": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None, "peak_tflops": pk}
     # ---- second metric: FID-50k feature extraction (reference src/metrics/features.py:17-65) ------------------------
     fid = None
     if args.fid_samples > 0 and args.workload == "biggan128":
@@ -296,6 +324,8 @@ def main():
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),
                      "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
     }
+    if dfwd is not None:
+        out["d_forward_stack"] = dfwd
     if fid is not None:
         out["fid_extract"] = fid
     if wl["gflop"]:

@@ -50,7 +50,6 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   const bool force = mode && mode[0] == 'f';
   if (disabled || d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
   if (d->C % 8 || d->ldx % 8 || d->R * d->S > 32 || J < 256) return false;
-  if (d->C < 64 && d->C != 8 && d->C != 16 && d->C != 32) return false;   // thin inputs: a k-tile of 8 chunks must cover whole taps
   if (!aligned16(d->x) || !aligned16(d->w)) return false;
   const int tj = (J + 255) / 256;
   const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile puts part of its 128 accumulator registers in scratch with hipcc 7.2: left out)
@@ -73,14 +72,18 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   int rc = 0;
   // piece placement (conv_v2.h SCHED): spreading the DMA pieces over the MFMA sub-steps pays on the 96-wide tiles (10 pieces per
   // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %); those use the fragment-prefetch form
-  // (SCHED 7, +1.5 %). SG_CONV_SCHED=0/1/7 forces one for A/B runs, 2..6 are the ablation variants.
+  // (SCHED 7, +1.5 %). SG_CONV_SCHED=0/1/7 forces one for A/B runs; 2..6 are the ablation variants of a -DSG_ABLATION build
+  // (no DMA / no fragment reads / neither / one k-tile / one k-tile without epilogue: how DESIGN.md's loop breakdown was measured).
   static const int sched_env = [] { const char* v = getenv("SG_CONV_SCHED"); return v ? atoi(v) : -1; }();
   const bool s1 = sched_env >= 0 ? sched_env == 1 : (best == 96);
-  if (best == 192 && sched_env >= 2) {      // ablation variants (tools/conv_bench.py only; results are wrong by construction)
+#ifdef SG_ABLATION
+  if (best == 192 && sched_env >= 2 && sched_env <= 6) {      // ablation variants (tools/conv_bench.py only; results are wrong by construction)
     rc = sched_env == 2 ? sg_launch_conv_v2<192, 4, 2, 256, 2>(p, e, st) : sched_env == 3 ? sg_launch_conv_v2<192, 4, 2, 256, 3>(p, e, st)
        : sched_env == 4 ? sg_launch_conv_v2<192, 4, 2, 256, 4>(p, e, st) : sched_env == 5 ? sg_launch_conv_v2<192, 4, 2, 256, 5>(p, e, st)
-       : sched_env == 6 ? sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st);
-  } else if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : (sched_env == 0 ? sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st));
+       : sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st);
+  } else
+#endif
+  if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : (sched_env == 0 ? sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st));
   else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 7>(p, e, st);
   else {
     // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)

@@ -100,8 +100,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
     pbase[i] = (unsigned)row * (unsigned)p.K;
   }
   // position of this lane inside K: tap (r,s) and chunk-in-tap c8; q = global chunk index
-  int tap = 0, tr = 0, ts = 0, c8 = lc, q = lc;
-  while (c8 >= p.cpt) { c8 -= p.cpt; tap++; ts++; if (ts == p.S) { ts = 0; tr++; } }
+  int q = lc, tap = lc / p.cpt, c8 = lc - tap * p.cpt, tr = tap / p.S, ts = tap - tr * p.S;
 
   // one k-tile's DMA = NQ + NPI pieces per wave; piece(buf, i) issues piece i, advance() steps the lane's K position
   auto piece = [&](int buf, int i) {
@@ -139,8 +138,8 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
       tap += w ? 1 : 0; ts += w ? 1 : 0;
       const bool w2 = ts == p.S;
       ts = w2 ? 0 : ts; tr += w2 ? 1 : 0;
-    } else {
-      tap += 8 / p.cpt;
+    } else {                          // thin / odd channel counts (any C % 8 == 0): recompute the position from the chunk index
+      tap = q / p.cpt; c8 = q - tap * p.cpt;
       tr = tap / p.S; ts = tap - tr * p.S;
     }
   };

@@ -226,9 +226,19 @@ __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float
   if (!l.apply_sn) return;
   const long long total = (long long)l.rows * l.cols;
   float acc = 0.f;
-  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
-    const int o = (int)(i / l.cols), k = (int)(i % l.cols);
-    acc += l.dwt[snb_src_index(l, o, k)] * l.w[sn_widx(l, o, k)];
+  const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
+  if (l.natural == 0 && cp == l.Cin) {
+    // walk dwt in ITS order ([o][rs][c], contiguous reads of the big scratch) and gather w ([o][c][rs], L2-friendly 9-float strides)
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
+      const int o = (int)(i / l.cols), j = (int)(i % l.cols);
+      const int rs = j / l.Cin, c = j - rs * l.Cin;
+      acc += l.dwt[i] * l.w[sn_widx(l, o, c * l.RS + rs)];
+    }
+  } else {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
+      const int o = (int)(i / l.cols), k = (int)(i % l.cols);
+      acc += l.dwt[snb_src_index(l, o, k)] * l.w[sn_widx(l, o, k)];
+    }
   }
   acc = block_sum_256(acc, sm);
   if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
