@@ -22,6 +22,9 @@ CASES = [
     (2, 192, 384, 16, 1, False, False, False),
     (3, 72, 96, 12, 3, False, False, False),      # cpt = 9: k-tiles straddle taps; J not a multiple of 256
     (2, 96, 288, 16, 3, True, False, False),
+    (2, 24, 96, 16, 3, False, False, False),      # thin / odd chunk counts (cpt = 3, 5, 6): position recomputed from the chunk index
+    (2, 40, 128, 16, 3, True, False, False),
+    (2, 48, 96, 16, 3, True, True, False),
 ]
 
 
