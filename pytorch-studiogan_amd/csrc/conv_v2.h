@@ -55,6 +55,13 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   }
   const int tI = bid % tilesI, tJ = bid / tilesI;
   const int i0 = tI * BI, j0 = tJ * BJ;
+  // bias of this cout tile: fetched once per workgroup into its own LDS region (behind the operand buffers), visible after the
+  // first barrier. The per-fragment scalar loads of the generic epilogue cost ~1 ms on the 96 -> 96 @128^2 layer (24 dependent
+  // load groups per lane, every one exposing an L2 round trip).
+  float* sbias = (float*)(smem + 2 * BUF);
+  if (epi.bias) {
+    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+  }
 
   // ---- per-lane DMA state ------------------------------------------------------------------------------
   const int sub = lane >> 3;                                        // row within the 8-row DMA group
@@ -274,6 +281,28 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
     return;
   }
   __syncthreads();                             // every wave is done reading the operand buffers
+  // ReLU-mask / residual operand of the epilogue: its tile is fetched with the SAME coalesced 16-byte pattern as the output store,
+  // into the output staging area; a lane then finds the four values it needs at the very LDS location it is going to overwrite
+  // with its result (each (row, 4-channel group) location belongs to exactly one lane, so the update is in place).
+  // The generic form reads 8 bytes per lane from 32 different rows per instruction, 24 dependent groups per lane.
+  const int rows_out = pool ? BJ / 4 : BJ;
+  const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
+  constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
+  const bool pre_mask = epi.mask && (epi.ldm & 7) == 0 && ((((uintptr_t)epi.mask) & 15) == 0);
+  const bool pre_res = !pre_mask && epi.res && !(epi.flags & SG_EPI_RES_F32) && (epi.ldr & 7) == 0 && ((((uintptr_t)epi.res) & 15) == 0);
+  if (pre_mask || pre_res) {
+    const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
+    const int ld = pre_mask ? epi.ldm : epi.ldr;
+    for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int jg = jbase + r;
+      u32x4 t = {0u, 0u, 0u, 0u};
+      if (jg < Jout) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
+      *(u32x4*)(smem + r * CP + c * 16) = t;
+    }
+    __syncthreads();
+  }
+  const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
 #pragma unroll
   for (int ta = 0; ta < TI; ta++)
 #pragma unroll
@@ -283,20 +312,64 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
       for (int g4 = 0; g4 < 4; g4++) {
         const int il = wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
         float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
-        int j = j0 + jl;
-        if (epi.prep(j, i0 + il, v, al)) {
+        // same operation order as Epilogue::prep (pool, scale, bias, mask, residual, ReLU), operands from LDS
+        if (pool) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v[e] += __shfl_xor(v[e], 1, 64);
+            v[e] += __shfl_xor(v[e], 2, 64);
+          }
+        }
+        const int jo = pool ? (jl >> 2) : jl;
+        const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
+        if (act) {
+          char* loc = smem + jo * CP + il * 2;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= al;
+          if (epi.bias) {
+            const f32x4 b = *(const f32x4*)(sbias + il);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += b[e];
+          }
+          if (epi.mask) {
+            if (pre_mask) {
+              const u32x2 m = *(const u32x2*)loc;
+#pragma unroll
+              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
+            } else {
+              const bf16_t* m = epi.mask + (long long)(jbase + jo) * epi.ldm + i0 + il;
+#pragma unroll
+              for (int e = 0; e < 4; e++) if (!(bf2f(m[e]) > 0.f)) v[e] = 0.f;
+            }
+          }
+          if (epi.res) {
+            if (pre_res) {
+              const u32x2 r = *(const u32x2*)loc;
+#pragma unroll
+              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
+            } else if (epi.flags & SG_EPI_RES_F32) {
+              const float* r = (const float*)epi.res + (long long)(jbase + jo) * epi.ldr + i0 + il;
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[e] += epi.beta * r[e];
+            } else {
+              const bf16_t* r = (const bf16_t*)epi.res + (long long)(jbase + jo) * epi.ldr + i0 + il;
+#pragma unroll
+              for (int e = 0; e < 4; e++) v[e] += epi.beta * bf2f(r[e]);
+            }
+          }
+          if (relu_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+          }
           u32x2 t;
           t[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
           t[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
-          *(u32x2*)(smem + (pool ? (jl >> 2) : jl) * CP + il * 2) = t;
+          *(u32x2*)loc = t;
         }
       }
     }
   {
     __syncthreads();
-    const int rows_out = pool ? BJ / 4 : BJ;
-    const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
-    constexpr int CPR = BI / 8;                // 16-byte chunks per output row
     bf16_t* o = (bf16_t*)epi.out;
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;
@@ -311,11 +384,11 @@ static inline int sg_launch_conv_v2r(const ConvV2Params& p, const Epilogue<bf16_
   constexpr int BUF = (BJ + BI) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + BI * 4) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), 2 * BUF, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), 2 * BUF + BI * 4, st, p, e, tilesI, tilesJ);
   return 0;
 }
 template <int BI, int WJ, int WI, int BJ = 256, int SCHED = 0>

@@ -36,6 +36,7 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--fp32", action="store_true")
     ap.add_argument("--only", default="")
+    ap.add_argument("--bias", action="store_true", help="forward with a bias vector (as every layer of the networks has)")
     args = ap.parse_args()
     dt = torch.float32 if args.fp32 else torch.bfloat16
     dev = torch.device("cuda:0")
@@ -57,7 +58,8 @@ def main():
         pf = (L.PIX_UPSAMPLE if up else 0) | (L.PIX_RELU if relu else 0)
         ef = L.EPI_POOL if pool else 0
         flop = 2.0 * N * H * H * Cout * R * R * Cin
-        f = timeit(lambda: F.conv2d_raw(x, w.data_ptr(), Cin, Cout, R, R, 1, pad, pad, pf, ef, alpha=0.25 if pool else 1.0))
+        bias = torch.randn(Cout, device=dev) if args.bias else None
+        f = timeit(lambda: F.conv2d_raw(x, w.data_ptr(), Cin, Cout, R, R, 1, pad, pad, pf, ef, bias=bias, alpha=0.25 if pool else 1.0))
         d = timeit(lambda: F.conv2d_raw(gy, wd.data_ptr(), Cout, Cin, R, R, 1, pad, pad, L.PIX_UPSAMPLE if pool else 0, L.EPI_POOL if up else 0,
                                         mask=x if relu else None, alpha=0.25 if pool else 1.0))
         g = timeit(lambda: F.conv2d_wgrad_raw(x, gy, dw.data_ptr(), Cin, Cout, R, R, H, H, 1, pad, pad, pf, L.PIX_UPSAMPLE if pool else 0))
