@@ -25,6 +25,15 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   return (bf16_t)(u >> 16);
 }
 
+// two floats -> packed bf16 pair with the gfx950 hardware conversion (v_cvt_pk_bf16_f32, round-to-nearest-even: the same value as
+// f2bf for every finite input; 1 instruction per pair instead of ~12)
+typedef __bf16 sg_bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float sg_f32x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack2bf(float a, float b) {
+  sg_f32x2_t v = {a, b};
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, sg_bf16x2_t));
+}
+
 template <typename T> __device__ __forceinline__ float to_f(T v);
 template <> __device__ __forceinline__ float to_f<float>(float v) { return v; }
 template <> __device__ __forceinline__ float to_f<bf16_t>(bf16_t v) { return bf2f(v); }

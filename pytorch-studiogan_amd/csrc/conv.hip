@@ -49,8 +49,16 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   const bool disabled = mode && mode[0] == '0';
   const bool force = mode && mode[0] == 'f';
   if (disabled || d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
-  if (d->C % 8 || d->ldx % 8 || d->R * d->S > 32 || J < 256) return false;
+  if (d->C % 8 || d->ldx % 8 || d->R * d->S > 25 || J < 256) return false;
+  // descriptor extents: offsets with bit 31 (activations) / bit 30 (weights) set must be out of range
+  const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2, wbytes = (long long)I * K * 2;
+  if (xbytes >= (1ll << 31) || wbytes >= (1ll << 30)) return false;
   if (!aligned16(d->x) || !aligned16(d->w)) return false;
+  // the kernel's only epilogue: bf16 rows, 16-byte stores; its ReLU-mask OR residual tile (bf16) is pre-staged with 16-byte loads
+  if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
+  if (e.mask && e.res) return false;
+  if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
+  if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   const int tj = (J + 255) / 256;
   const int cands[3] = {192, 128, 96};   // (a 256-wide cout tile puts part of its 128 accumulator registers in scratch with hipcc 7.2: left out)
   int best = 0, best_tiles = 0;
@@ -69,27 +77,17 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags;
   p.I = I; p.J = J; p.K = K; p.cpt = d->C / 8; p.ntap = d->R * d->S;
   p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
+  p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   int rc = 0;
-  // piece placement (conv_v2.h SCHED): spreading the DMA pieces over the MFMA sub-steps pays on the 96-wide tiles (10 pieces per
-  // 24 MFMAs per wave: +13 % measured), not on the 192/128-wide ones (7 per 24: -3..7 %); those use the fragment-prefetch form
-  // (SCHED 7, +1.5 %). SG_CONV_SCHED=0/1/7 forces one for A/B runs; 2..6 are the ablation variants of a -DSG_ABLATION build
-  // (no DMA / no fragment reads / neither / one k-tile / one k-tile without epilogue: how DESIGN.md's loop breakdown was measured).
-  static const int sched_env = [] { const char* v = getenv("SG_CONV_SCHED"); return v ? atoi(v) : -1; }();
-  const bool s1 = sched_env >= 0 ? sched_env == 1 : (best == 96);
-#ifdef SG_ABLATION
-  if (best == 192 && sched_env >= 2 && sched_env <= 6) {      // ablation variants (tools/conv_bench.py only; results are wrong by construction)
-    rc = sched_env == 2 ? sg_launch_conv_v2<192, 4, 2, 256, 2>(p, e, st) : sched_env == 3 ? sg_launch_conv_v2<192, 4, 2, 256, 3>(p, e, st)
-       : sched_env == 4 ? sg_launch_conv_v2<192, 4, 2, 256, 4>(p, e, st) : sched_env == 5 ? sg_launch_conv_v2<192, 4, 2, 256, 5>(p, e, st)
-       : sg_launch_conv_v2<192, 4, 2, 256, 6>(p, e, st);
-  } else
-#endif
-  if (best == 192) rc = s1 ? sg_launch_conv_v2<192, 4, 2, 256, 1>(p, e, st) : (sched_env == 0 ? sg_launch_conv_v2<192, 4, 2, 256, 0>(p, e, st) : sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st));
-  else if (best == 128) rc = s1 ? sg_launch_conv_v2<128, 4, 2, 256, 1>(p, e, st) : sg_launch_conv_v2<128, 4, 2, 256, 7>(p, e, st);
+  // piece placement (conv_v2.h SCHED): the 96-wide tiles spread their DMA pieces over the MFMA sub-steps (SCHED 1), the 192/128-wide
+  // ones issue them in front and prefetch fragments across sub-steps (SCHED 7); SCHED 2..6 are the ablation variants of a
+  // -DSG_ABLATION build (no DMA / no fragment reads / neither / one k-tile / one k-tile without epilogue).
+  if (best == 192) rc = sg_launch_conv_v2<192, 4, 2, 256, 7>(p, e, st);
+  else if (best == 128) rc = sg_launch_conv_v2<128, 4, 2, 256, 7>(p, e, st);
   else {
     // 96 output channels: a 512-pixel tile gives every wave a 64 x 96 block (24 MFMAs per 20 fragment reads instead of 12 per 16)
-    const char* b5 = getenv("SG_CONV_BJ512");
-    if (J >= 512 * 256 && !(b5 && b5[0] == '0')) rc = s1 ? sg_launch_conv_v2<96, 8, 1, 512, 1>(p, e, st) : sg_launch_conv_v2<96, 8, 1, 512, 0>(p, e, st);
-    else rc = s1 ? sg_launch_conv_v2<96, 8, 1, 256, 1>(p, e, st) : sg_launch_conv_v2<96, 8, 1, 256, 0>(p, e, st);
+    if (J >= 512 * 256) rc = sg_launch_conv_v2<96, 8, 1, 512, 1>(p, e, st);
+    else rc = sg_launch_conv_v2<96, 8, 1, 256, 1>(p, e, st);
   }
   return rc == 0;
 }
@@ -145,6 +143,8 @@ static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
   if (d->C % 8 || d->ldx % 8 || d->Cout % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return false;
   const long long K = (long long)d->N * d->Ho * d->Wo;
   const int I = d->R * d->S * d->C;
+  // buffer-descriptor DMA: bit 31 of a byte offset must be out of range
+  if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return false;
   if (!force && (I < 64 || d->Cout < 64 || K < 4096)) return false;   // narrow I (1x1 convs, the 8-channel RGB stem) wastes part of the
                                                                        // 256-row tile but still beats the generic kernel 3-4x
   return true;
@@ -217,6 +217,8 @@ template <> bool wgrad_v2_launch<bf16_t>(const sg_conv_wgrad_desc* d, const Epil
   p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
   p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
   p.I = I; p.J = J; p.K = K;
+  p.xbytes = (unsigned)((((long long)d->N * d->xHs * d->xWs - 1) * d->ldx + d->C) * 2);
+  p.gbytes = (unsigned)((((long long)d->N * d->gHs * d->gWs - 1) * d->ldg + d->Cout) * 2);
   int klen = K;
   if (splits > 1) { klen = (K + splits - 1) / splits; klen = ((klen + 63) / 64) * 64; splits = (K + klen - 1) / klen; }
   p.klen = klen;

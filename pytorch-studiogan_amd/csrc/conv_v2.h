@@ -7,14 +7,16 @@
 //     The LDS image is lane-linear, so the bank-conflict swizzle is applied to the SOURCE address: lane (row, slot)
 //     fetches logical 16-byte chunk  slot ^ ((row >> 1) & 7); fragment reads apply the same involution
 //     (guide §5.4 rule 21). Conflict-free for the 16-lane service groups of ds_read_b128.
-//   * convolution halo / k-tail / row-tail: the lane's source pointer is redirected to a 16-byte zero page
+//   * the DMA goes through buffer descriptors (buffer_load_dwordx4 ... offen lds): a 32-bit byte offset per lane, no 64-bit
+//     address arithmetic; convolution halo / k-tail / row-tail lanes set bit 31 of their offset, which is out of range of the
+//     descriptor, and the hardware writes zeros to LDS for them (tools/probes/oob_lds_probe.hip). A DMA piece is 3-5 VALU
+//     instructions + s_add m0 + the load (the pointer-select form it replaces compiled to ~40 instructions and 4 branches per
+//     piece: ~300 of the 400 instructions of a k-tile, all in front of the 24 MFMAs)
 //   * the (tap, channel-chunk) position of a lane is advanced incrementally (no division in the k-loop); the
 //     per-row halo test is a precomputed bit mask
 //   * next k-tile's DMA is issued before the current tile's MFMAs; one barrier per k-tile.
 #pragma once
 #include "gemm_core.h"
-
-__device__ u32x4 sg_zero_page[4];
 
 struct ConvV2Params {
   const bf16_t* x; const bf16_t* w;
@@ -24,7 +26,8 @@ struct ConvV2Params {
   int flags;
   int I, J, K;
   int cpt;    // 16-byte chunks per tap = C / 8
-  int ntap;   // R * S
+  int ntap;   // R * S (<= 25)
+  unsigned xbytes, wbytes;   // extents of the two descriptors (< 2^31 / < 2^30: bits 31 / 30 of an offset mean "out of range")
   int wshift, hshift;   // log2(Wo), log2(Ho) or -1
 };
 
@@ -34,7 +37,7 @@ typedef __attribute__((address_space(3))) void* sg_lptr_t;
 // SCHED 0: all DMA pieces of the next k-tile are issued in front of the current tile's MFMAs.
 // SCHED 1: the pieces are spread over the four 16-deep MFMA sub-steps (a wave issues in order: a DMA piece costs ~100 issue
 //          cycles that would otherwise sit in front of the matrix pipe for BOTH lock-stepped waves of a SIMD at once).
-template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU>
+template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU, bool UP>
 __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   constexpr int NW = WJ * WI;                  // waves per workgroup (8, or 4 for the two-workgroups-per-CU variant)
   constexpr int QB = BJ * 128, PB = BI * 128, BUF = QB + PB;
@@ -46,7 +49,8 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   static_assert(BJ % (WJ * 32) == 0 && BI % (WI * 32) == 0, "tile/wave mismatch");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);     // provably uniform: LDS-DMA destinations (M0) stay in SGPRs
   const int nt = tilesI * tilesJ;
   int bid = blockIdx.x;
   {
@@ -64,10 +68,14 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   }
 
   // ---- per-lane DMA state ------------------------------------------------------------------------------
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
   const int sub = lane >> 3;                                        // row within the 8-row DMA group
   const int lc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical chunk this lane fetches (same for all its rows: NW is a multiple of 2)
-  const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0;
-  unsigned qbase[NQ]; unsigned qmask[NQ]; int qpar[NQ];
+  const unsigned ldx2 = 2u * (unsigned)p.ldx;                       // pixel pitch in bytes
+  unsigned qoff[NQ];      // byte offset of the row's centre pixel (source resolution)
+  unsigned qinv[NQ];      // bit t set = tap t of this row is outside the image (or the row is outside the problem); bits >= ntap set
+  bool qph[NQ], qpw[NQ];  // upsample-on-load: parity of the output pixel
 #pragma unroll
   for (int i = 0; i < NQ; i++) {
     const int row = j0 + 8 * (wave + NW * i) + sub;
@@ -93,49 +101,56 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
           if (hok && (unsigned)(wo - p.pad_w + ss) < (unsigned)p.Win) m |= 1u << t;
       }
     }
-    qmask[i] = m;
-    qpar[i] = up ? ((ho & 1) | ((wo & 1) << 1)) : 0;
-    const int hs = up ? (ho >> 1) : ho, ws = up ? (wo >> 1) : wo;
-    qbase[i] = ((unsigned)(n * p.Hs + hs) * (unsigned)p.Ws + (unsigned)ws) * (unsigned)p.ldx;
+    qinv[i] = ~m;
+    qph[i] = UP && (ho & 1); qpw[i] = UP && (wo & 1);
+    const int hs = UP ? (ho >> 1) : ho, ws = UP ? (wo >> 1) : wo;
+    qoff[i] = ((unsigned)(n * p.Hs + hs) * (unsigned)p.Ws + (unsigned)ws) * ldx2;
   }
-  unsigned pbase[NPI]; bool pok[NPI];
+  unsigned poff[NPI];     // byte offset of the weight row; 0x40000000 = row outside the problem
 #pragma unroll
   for (int i = 0; i < NPI; i++) {
     const int g = wave + NW * i;                // DMA group index inside the P tile
     const int row = i0 + 8 * g + sub;
-    pok[i] = (g < BI / 8) && (row < p.I);
-    pbase[i] = (unsigned)row * (unsigned)p.K;
+    poff[i] = ((g < BI / 8) && (row < p.I)) ? (unsigned)row * (unsigned)p.K * 2u : 0x40000000u;
   }
   // position of this lane inside K: tap (r,s) and chunk-in-tap c8; q = global chunk index
   int q = lc, tap = lc / p.cpt, c8 = lc - tap * p.cpt, tr = tap / p.S, ts = tap - tr * p.S;
+
+  // per k-tile, per lane: the byte displacement of the lane's (tap, chunk) from the centre pixel. With upsample-on-load the
+  // displacement depends on the parity of the output pixel: two row terms and two column terms, selected per piece.
+  unsigned kd0 = 0, kdh1 = 0, kdw1 = 0, kw = 0;
+  auto position = [&]() {
+    const int dr = tr - p.pad_h, ds = ts - p.pad_w;
+    if (UP) {
+      const unsigned rowb = (unsigned)p.Ws * ldx2;
+      kd0 = (unsigned)(dr >> 1) * rowb + (unsigned)(ds >> 1) * ldx2 + (unsigned)c8 * 16u;                  // even row, even column
+      kdh1 = ((unsigned)((dr + 1) >> 1) - (unsigned)(dr >> 1)) * rowb;                                     // extra for an odd output row
+      kdw1 = ((unsigned)((ds + 1) >> 1) - (unsigned)(ds >> 1)) * ldx2;                                     // extra for an odd output column
+    } else {
+      kd0 = (unsigned)(dr * p.Ws + ds) * ldx2 + (unsigned)c8 * 16u;
+    }
+    kw = (tap < p.ntap) ? (unsigned)q * 16u : 0x40000000u;
+  };
+  position();
 
   // one k-tile's DMA = NQ + NPI pieces per wave; piece(buf, i) issues piece i, advance() steps the lane's K position
   auto piece = [&](int buf, int i) {
     char* qd = smem + buf * BUF;
     char* pd = qd + QB;
-    const bool tap_ok = tap < p.ntap;
     if (i < NQ) {
-      const int dr = tr - p.pad_h, ds = ts - p.pad_w;
-      int dh = dr, dw = ds;
-      if (up) { dh = ((qpar[i] & 1) + dr) >> 1; dw = ((qpar[i] >> 1) + ds) >> 1; }
-      unsigned off = qbase[i] + (unsigned)((dh * p.Ws + dw) * p.ldx) + (unsigned)c8 * 8u;
-      asm volatile("" : "+v"(off));             // keep the address arithmetic unconditional: a select, not a branch, per piece
-      const bool ok = tap_ok && ((qmask[i] >> tap) & 1u);
-      const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
-      __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(qd + (wave + NW * i) * 1024), 16, 0, 0);
+      unsigned off = qoff[i] + kd0;
+      if (UP) off += (qph[i] ? kdh1 : 0u) + (qpw[i] ? kdw1 : 0u);
+      off |= ((qinv[i] >> tap) & 1u) << 31;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(qd + (wave + NW * i) * 1024), 16, (int)off, 0, 0, 0);
     } else {
       const int j = i - NQ;
       if (NW * (j + 1) <= BI / 8 || wave + NW * j < BI / 8) {     // compile-time true for full groups, else wave-uniform
-        const bool ok = pok[j] && tap_ok;
-        unsigned woff = pbase[j] + (unsigned)q * 8u;
-        asm volatile("" : "+v"(woff));
-        const bf16_t* src = ok ? (p.w + woff) : (const bf16_t*)sg_zero_page;
-        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, (int)(poff[j] + kw), 0, 0, 0);
       }
     }
   };
   // next k-tile: 8 chunks further. C >= 64: at most one tap boundary, done with selects (no branch in the k-loop);
-  // thin inputs (C = 8/16/32, a uniform property of the launch): 8/cpt whole taps per k-tile
+  // thin / odd channel counts (any C % 8 == 0): the position is recomputed from the chunk index
   auto advance = [&]() {
     q += 8;
     if (p.cpt >= 8) {
@@ -145,10 +160,11 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
       tap += w ? 1 : 0; ts += w ? 1 : 0;
       const bool w2 = ts == p.S;
       ts = w2 ? 0 : ts; tr += w2 ? 1 : 0;
-    } else {                          // thin / odd channel counts (any C % 8 == 0): recompute the position from the chunk index
+    } else {
       tap = q / p.cpt; c8 = q - tap * p.cpt;
       tr = tap / p.S; ts = tap - tr * p.S;
     }
+    position();
   };
   auto issue = [&](int buf) {
 #pragma unroll
@@ -261,25 +277,11 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   }
   // bf16 output tile: staged through LDS (the operand buffers are dead now) so that the global stores are 16 bytes per lane with
   // consecutive lanes on consecutive addresses of a row. The direct form (8 bytes per lane, 32 different rows per instruction)
-  // ran at ~1.4 TB/s and cost 17 us per 256 x 192 tile -- 27 % of a 192->192 @64^2 convolution.
+  // ran at ~1.4 TB/s and cost 17 us per 256 x 192 tile -- 27 % of a 192->192 @64^2 convolution. The launcher only admits
+  // problems this path can store (bf16 output, 16-byte aligned rows, whole cout tiles): there is no second epilogue in the kernel
+  // (the generic one was 19 k of the kernel's 21 k instructions -- fetched by every workgroup of a short-K layer).
   const bool pool = (epi.flags & SG_EPI_POOL) != 0;
-  const bool stage = !(epi.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) && (epi.ldo & 7) == 0 && ((((uintptr_t)epi.out) & 15) == 0) && (i0 + BI <= epi.I);
   constexpr int CP = BI * 2 + 16;              // LDS row pitch of the staged tile (bytes)
-  if (!stage) {
-#pragma unroll
-    for (int ta = 0; ta < TI; ta++)
-#pragma unroll
-      for (int tb = 0; tb < TJ; tb++) {
-        const int j = j0 + wj0 + tb * 32 + (lane & 31);
-#pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-          const int ii = i0 + wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
-          float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
-          epi.store(j, ii, v, al);
-        }
-      }
-    return;
-  }
   __syncthreads();                             // every wave is done reading the operand buffers
   // ReLU-mask / residual operand of the epilogue: its tile is fetched with the SAME coalesced 16-byte pattern as the output store,
   // into the output staging area; a lane then finds the four values it needs at the very LDS location it is going to overwrite
@@ -288,8 +290,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   const int rows_out = pool ? BJ / 4 : BJ;
   const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
   constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
-  const bool pre_mask = epi.mask && (epi.ldm & 7) == 0 && ((((uintptr_t)epi.mask) & 15) == 0);
-  const bool pre_res = !pre_mask && epi.res && !(epi.flags & SG_EPI_RES_F32) && (epi.ldr & 7) == 0 && ((((uintptr_t)epi.res) & 15) == 0);
+  const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // at most one of them (launcher), bf16, 16-byte aligned rows
   if (pre_mask || pre_res) {
     const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
     const int ld = pre_mask ? epi.ldm : epi.ldr;
@@ -331,39 +332,23 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += b[e];
           }
-          if (epi.mask) {
-            if (pre_mask) {
-              const u32x2 m = *(const u32x2*)loc;
+          if (pre_mask) {
+            const u32x2 m = *(const u32x2*)loc;
 #pragma unroll
-              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
-            } else {
-              const bf16_t* m = epi.mask + (long long)(jbase + jo) * epi.ldm + i0 + il;
-#pragma unroll
-              for (int e = 0; e < 4; e++) if (!(bf2f(m[e]) > 0.f)) v[e] = 0.f;
-            }
+            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
           }
-          if (epi.res) {
-            if (pre_res) {
-              const u32x2 r = *(const u32x2*)loc;
+          if (pre_res) {
+            const u32x2 r = *(const u32x2*)loc;
 #pragma unroll
-              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
-            } else if (epi.flags & SG_EPI_RES_F32) {
-              const float* r = (const float*)epi.res + (long long)(jbase + jo) * epi.ldr + i0 + il;
-#pragma unroll
-              for (int e = 0; e < 4; e++) v[e] += epi.beta * r[e];
-            } else {
-              const bf16_t* r = (const bf16_t*)epi.res + (long long)(jbase + jo) * epi.ldr + i0 + il;
-#pragma unroll
-              for (int e = 0; e < 4; e++) v[e] += epi.beta * bf2f(r[e]);
-            }
+            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
           }
           if (relu_out) {
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
           }
           u32x2 t;
-          t[0] = (uint32_t)f2bf(v[0]) | ((uint32_t)f2bf(v[1]) << 16);
-          t[1] = (uint32_t)f2bf(v[2]) | ((uint32_t)f2bf(v[3]) << 16);
+          t[0] = pack2bf(v[0], v[1]);
+          t[1] = pack2bf(v[2], v[3]);
           *(u32x2*)loc = t;
         }
       }
@@ -379,20 +364,21 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
   }
 }
 
-template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU>
+template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU, bool UP>
 static inline int sg_launch_conv_v2r(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BUF = (BJ + BI) * 128;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + BI * 4) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 2 * BUF + BI * 4) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), 2 * BUF + BI * 4, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v2_kernel<BI, WJ, WI, BJ, SCHED, RELU, UP>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), 2 * BUF + BI * 4, st, p, e, tilesI, tilesJ);
   return 0;
 }
 template <int BI, int WJ, int WI, int BJ = 256, int SCHED = 0>
 static inline int sg_launch_conv_v2(const ConvV2Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  if (p.flags & SG_PIX_RELU) return sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, true>(p, e, st);
-  return sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, false>(p, e, st);
+  const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0;
+  if (p.flags & SG_PIX_RELU) return up ? sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, true, true>(p, e, st) : sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, true, false>(p, e, st);
+  return up ? sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, false, true>(p, e, st) : sg_launch_conv_v2r<BI, WJ, WI, BJ, SCHED, false, false>(p, e, st);
 }

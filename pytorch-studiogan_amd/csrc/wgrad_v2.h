@@ -10,7 +10,7 @@
 //     lane-linear DMA image this is done on the SOURCE side: lane (pixel p, slot s) fetches channel chunk s ^ 4*(p&3)
 //     and the fragment read applies the same involution (conflict-free, MI355X_MICROARCH.md §LDS)
 //   * a lane's (tap, channel) is fixed for the whole k-loop; per k-tile it decomposes TWO pixel indices (shifts) and
-//     derives six source addresses; halo / tails go to the zero page
+//     derives six source byte offsets into two buffer descriptors; halo / tails set bit 31 (out of range: the DMA writes zeros)
 #pragma once
 #include "gemm_core.h"
 #include "conv_v2.h"
@@ -22,6 +22,7 @@ struct WgradV2Params {
   int Ho, Wo, wshift, hshift;
   int R, S, pad_h, pad_w;
   int I, J, K, klen;
+  unsigned xbytes, gbytes;   // descriptor extents (< 2^31)
 };
 
 __device__ __forceinline__ bf16x8_t sg_frag_tr_swz(const char* img, int col0, int ks) {
@@ -72,7 +73,10 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
   constexpr int IMG = 64 * 256;              // one [64][128] bf16 image
   constexpr int BUF = 3 * IMG;               // P sub-image 0, P sub-image 1, Q
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rsg = __builtin_amdgcn_make_buffer_rsrc((void*)p.dy, 0, (int)p.gbytes, 0x00020000);
   const int nt = tilesI * tilesJ;
   int bid = blockIdx.x;
   {
@@ -118,17 +122,15 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
         int hh = ho + pr[h], ww = wo + ps[h];
         const bool ok = inb & pv[h] & ((unsigned)hh < (unsigned)p.Hin) & ((unsigned)ww < (unsigned)p.Win);
         if (p.x_up) { hh >>= 1; ww >>= 1; }
-        unsigned off = ((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + pc[h];
-        asm volatile("" : "+v"(off));            // unconditional address arithmetic: a select per piece, no branch
-        const bf16_t* src = ok ? (p.x + off) : (const bf16_t*)sg_zero_page;
-        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + h * IMG + pg * 1024), 16, 0, 0);
+        unsigned off = (((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + pc[h]) * 2u;
+        off = ok ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(base + h * IMG + pg * 1024), 16, (int)off, 0, 0, 0);
       }
       {
         const int hg = p.g_up ? (ho >> 1) : ho, wg = p.g_up ? (wo >> 1) : wo;
-        unsigned off = ((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol;
-        asm volatile("" : "+v"(off));
-        const bf16_t* src = (inb & qv) ? (p.dy + off) : (const bf16_t*)sg_zero_page;
-        __builtin_amdgcn_global_load_lds((sg_gptr_t)src, (sg_lptr_t)(base + 2 * IMG + pg * 1024), 16, 0, 0);
+        unsigned off = (((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol) * 2u;
+        off = (inb & qv) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + 2 * IMG + pg * 1024), 16, (int)off, 0, 0, 0);
       }
     }
   };
