@@ -5,6 +5,7 @@
 #include "gemm_core.h"
 #include "conv_v2.h"
 #include "wgrad_v2.h"
+#include "conv_v3.h"
 #include "../../include/sgamd.h"
 
 static inline int ilog2_exact(int v) {
@@ -92,6 +93,55 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   return rc == 0;
 }
 
+// halo kernel (conv_v3.h) for 3x3 / stride 1 / pad 1 with >= 64 input channels; returns false when the problem is not eligible.
+// SG_CONV_V3=0 disables it, =force skips the tile-count heuristic (tests), =all also takes the shapes the default table leaves to v2.
+template <typename T> static bool conv_fwd_v3_try(const sg_conv_fwd_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool conv_fwd_v3_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
+  const char* mode = getenv("SG_CONV_V3");
+  if (mode && mode[0] == '0') return false;
+  const bool force = mode && mode[0] == 'f';
+  if (d->stride != 1 || (pflags & SG_PIX_TRANSPOSED) || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return false;
+  if (d->C < 64 || d->C % 8 || d->ldx % 8 || !aligned16(d->x) || !aligned16(d->w)) return false;
+  const bool up = (pflags & SG_PIX_UPSAMPLE) != 0, quad = (pflags & SG_PIX_QUAD) != 0;
+  if (d->Ho != d->Hs * (up ? 2 : 1) || d->Wo != d->Ws * (up ? 2 : 1)) return false;
+  const int wshift = ilog2_exact(d->Wo), hshift = ilog2_exact(d->Ho);
+  if (wshift < 0 || hshift < 0 || d->Ws < 8 || d->Hs < 2) return false;
+  const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2, wbytes = (long long)I * K * 2;
+  if (xbytes >= (1ll << 31) || wbytes >= (1ll << 30)) return false;
+  if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
+  if (e.mask && e.res) return false;
+  if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
+  if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
+  const int tj = (J + 255) / 256;
+  const int cands[3] = {192, 128, 96};
+  int best = 0, best_tiles = 0;
+  for (int c = 0; c < 3; c++) {
+    if (I % cands[c]) continue;
+    const int tiles = (I / cands[c]) * tj;
+    if (tiles >= 512) { best = cands[c]; best_tiles = tiles; break; }
+    if (tiles > best_tiles) { best = cands[c]; best_tiles = tiles; }
+  }
+  if (!best || (best_tiles < 160 && !force)) return false;
+  const int BJ = (best == 96 && J >= 512 * 256) ? 512 : 256;
+  if ((quad || up) && (BJ % (2 * d->Wo))) return false;     // the tile must cover whole (pairs of) image rows
+  if (J % d->Wo) return false;
+  ConvV3Params p;
+  p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;
+  p.W = d->Ws; p.wlog = ilog2_exact(d->Ws); p.C = d->C; p.ldx = d->ldx;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = wshift; p.hshift = hshift; p.flags = pflags;
+  p.I = I; p.J = J; p.K = K; p.nslice = (d->C + 63) / 64;
+  p.npix_src = d->N * d->Hs * d->Ws;
+  p.npx = (up ? BJ / 4 : BJ) + 2 * d->Ws + 16;
+  p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
+  p.zero_off = 0; p.bias_off = 0;
+  int rc;
+  if (best == 192) rc = sg_launch_conv_v3<192, 4, 2, 256>(p, e, st);
+  else if (best == 128) rc = sg_launch_conv_v3<128, 4, 2, 256>(p, e, st);
+  else if (BJ == 512) rc = sg_launch_conv_v3<96, 8, 1, 512>(p, e, st);
+  else rc = sg_launch_conv_v3<96, 8, 1, 256>(p, e, st);
+  return rc == 0;
+}
+
 template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream_t st) {
   const int K = d->R * d->S * d->C;
   const int I = d->Cout;
@@ -114,7 +164,8 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
-  if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}
+  if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) {}
+  else if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
   else conv_fwd_launch<T, false>(d, e, I, J, K, pflags, st);
   sg_prof_end(st, prof);

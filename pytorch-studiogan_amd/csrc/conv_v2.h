@@ -34,6 +34,102 @@ struct ConvV2Params {
 typedef __attribute__((address_space(1))) const void* sg_gptr_t;
 typedef __attribute__((address_space(3))) void* sg_lptr_t;
 
+// ---- the epilogue shared by conv_v2 / conv_v3 -------------------------------------------------------------------------
+// acc[TI][TJ]: 32x32 accumulator blocks of this wave (block (a,b) = couts wi0+32a.., pixels wj0+32b..); smem: the (dead) operand
+// buffers, reused as the output staging area; sbias: BI floats in LDS (valid when epi.bias).
+template <int BI, int BJ, int NW, int TI, int TJ>
+__device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* smem, const float* sbias, const Epilogue<bf16_t>& epi,
+                                                 int i0, int j0, int wi0, int wj0, float al) {
+  const int tid = threadIdx.x, lane = tid & 63;
+  // bf16 output tile: staged through LDS (the operand buffers are dead now) so that the global stores are 16 bytes per lane with
+  // consecutive lanes on consecutive addresses of a row. The direct form (8 bytes per lane, 32 different rows per instruction)
+  // ran at ~1.4 TB/s and cost 17 us per 256 x 192 tile -- 27 % of a 192->192 @64^2 convolution. The launcher only admits
+  // problems this path can store (bf16 output, 16-byte aligned rows, whole cout tiles): there is no second epilogue in the kernel
+  // (the generic one was 19 k of the kernel's 21 k instructions -- fetched by every workgroup of a short-K layer).
+  const bool pool = (epi.flags & SG_EPI_POOL) != 0;
+  constexpr int CP = BI * 2 + 16;              // LDS row pitch of the staged tile (bytes)
+  __syncthreads();                             // every wave is done reading the operand buffers
+  // ReLU-mask / residual operand of the epilogue: its tile is fetched with the SAME coalesced 16-byte pattern as the output store,
+  // into the output staging area; a lane then finds the four values it needs at the very LDS location it is going to overwrite
+  // with its result (each (row, 4-channel group) location belongs to exactly one lane, so the update is in place).
+  // The generic form reads 8 bytes per lane from 32 different rows per instruction, 24 dependent groups per lane.
+  const int rows_out = pool ? BJ / 4 : BJ;
+  const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
+  constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
+  const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // at most one of them (launcher), bf16, 16-byte aligned rows
+  if (pre_mask || pre_res) {
+    const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
+    const int ld = pre_mask ? epi.ldm : epi.ldr;
+    for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int jg = jbase + r;
+      u32x4 t = {0u, 0u, 0u, 0u};
+      if (jg < Jout) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
+      *(u32x4*)(smem + r * CP + c * 16) = t;
+    }
+    __syncthreads();
+  }
+  const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
+#pragma unroll
+  for (int ta = 0; ta < TI; ta++)
+#pragma unroll
+    for (int tb = 0; tb < TJ; tb++) {
+      const int jl = wj0 + tb * 32 + (lane & 31);
+#pragma unroll
+      for (int g4 = 0; g4 < 4; g4++) {
+        const int il = wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
+        float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
+        // same operation order as Epilogue::prep (pool, scale, bias, mask, residual, ReLU), operands from LDS
+        if (pool) {
+#pragma unroll
+          for (int e = 0; e < 4; e++) {
+            v[e] += __shfl_xor(v[e], 1, 64);
+            v[e] += __shfl_xor(v[e], 2, 64);
+          }
+        }
+        const int jo = pool ? (jl >> 2) : jl;
+        const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
+        if (act) {
+          char* loc = smem + jo * CP + il * 2;
+#pragma unroll
+          for (int e = 0; e < 4; e++) v[e] *= al;
+          if (epi.bias) {
+            const f32x4 b = *(const f32x4*)(sbias + il);
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] += b[e];
+          }
+          if (pre_mask) {
+            const u32x2 m = *(const u32x2*)loc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
+          }
+          if (pre_res) {
+            const u32x2 r = *(const u32x2*)loc;
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
+          }
+          if (relu_out) {
+#pragma unroll
+            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+          }
+          u32x2 t;
+          t[0] = pack2bf(v[0], v[1]);
+          t[1] = pack2bf(v[2], v[3]);
+          *(u32x2*)loc = t;
+        }
+      }
+    }
+  {
+    __syncthreads();
+    bf16_t* o = (bf16_t*)epi.out;
+    for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
+      const int r = idx / CPR, c = idx - r * CPR;
+      const int jg = jbase + r;
+      if (jg < Jout) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
+    }
+  }
+}
+
 // SCHED 0: all DMA pieces of the next k-tile are issued in front of the current tile's MFMAs.
 // SCHED 1: the pieces are spread over the four 16-deep MFMA sub-steps (a wave issues in order: a DMA piece costs ~100 issue
 //          cycles that would otherwise sit in front of the matrix pipe for BOTH lock-stepped waves of a SIMD at once).
@@ -275,93 +371,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
     if (t == 1234.5f) *(float*)epi.out = t;
     return;
   }
-  // bf16 output tile: staged through LDS (the operand buffers are dead now) so that the global stores are 16 bytes per lane with
-  // consecutive lanes on consecutive addresses of a row. The direct form (8 bytes per lane, 32 different rows per instruction)
-  // ran at ~1.4 TB/s and cost 17 us per 256 x 192 tile -- 27 % of a 192->192 @64^2 convolution. The launcher only admits
-  // problems this path can store (bf16 output, 16-byte aligned rows, whole cout tiles): there is no second epilogue in the kernel
-  // (the generic one was 19 k of the kernel's 21 k instructions -- fetched by every workgroup of a short-K layer).
-  const bool pool = (epi.flags & SG_EPI_POOL) != 0;
-  constexpr int CP = BI * 2 + 16;              // LDS row pitch of the staged tile (bytes)
-  __syncthreads();                             // every wave is done reading the operand buffers
-  // ReLU-mask / residual operand of the epilogue: its tile is fetched with the SAME coalesced 16-byte pattern as the output store,
-  // into the output staging area; a lane then finds the four values it needs at the very LDS location it is going to overwrite
-  // with its result (each (row, 4-channel group) location belongs to exactly one lane, so the update is in place).
-  // The generic form reads 8 bytes per lane from 32 different rows per instruction, 24 dependent groups per lane.
-  const int rows_out = pool ? BJ / 4 : BJ;
-  const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
-  constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
-  const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // at most one of them (launcher), bf16, 16-byte aligned rows
-  if (pre_mask || pre_res) {
-    const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
-    const int ld = pre_mask ? epi.ldm : epi.ldr;
-    for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
-      const int r = idx / CPR, c = idx - r * CPR;
-      const int jg = jbase + r;
-      u32x4 t = {0u, 0u, 0u, 0u};
-      if (jg < Jout) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
-      *(u32x4*)(smem + r * CP + c * 16) = t;
-    }
-    __syncthreads();
-  }
-  const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
-#pragma unroll
-  for (int ta = 0; ta < TI; ta++)
-#pragma unroll
-    for (int tb = 0; tb < TJ; tb++) {
-      const int jl = wj0 + tb * 32 + (lane & 31);
-#pragma unroll
-      for (int g4 = 0; g4 < 4; g4++) {
-        const int il = wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
-        float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
-        // same operation order as Epilogue::prep (pool, scale, bias, mask, residual, ReLU), operands from LDS
-        if (pool) {
-#pragma unroll
-          for (int e = 0; e < 4; e++) {
-            v[e] += __shfl_xor(v[e], 1, 64);
-            v[e] += __shfl_xor(v[e], 2, 64);
-          }
-        }
-        const int jo = pool ? (jl >> 2) : jl;
-        const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
-        if (act) {
-          char* loc = smem + jo * CP + il * 2;
-#pragma unroll
-          for (int e = 0; e < 4; e++) v[e] *= al;
-          if (epi.bias) {
-            const f32x4 b = *(const f32x4*)(sbias + il);
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] += b[e];
-          }
-          if (pre_mask) {
-            const u32x2 m = *(const u32x2*)loc;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
-          }
-          if (pre_res) {
-            const u32x2 r = *(const u32x2*)loc;
-#pragma unroll
-            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
-          }
-          if (relu_out) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-          }
-          u32x2 t;
-          t[0] = pack2bf(v[0], v[1]);
-          t[1] = pack2bf(v[2], v[3]);
-          *(u32x2*)loc = t;
-        }
-      }
-    }
-  {
-    __syncthreads();
-    bf16_t* o = (bf16_t*)epi.out;
-    for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
-      const int r = idx / CPR, c = idx - r * CPR;
-      const int jg = jbase + r;
-      if (jg < Jout) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
-    }
-  }
+  sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, wi0, wj0, al);
 }
 
 template <int BI, int WJ, int WI, int BJ, int SCHED, bool RELU, bool UP>

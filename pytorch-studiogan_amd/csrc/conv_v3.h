@@ -1,0 +1,264 @@
+// conv_v3.h -- "halo" forward / data-gradient kernel for 3x3 stride-1 pad-1 convolutions (bf16, >= 64 input channels).
+//
+// conv_v2.h stages one im2col k-tile per step: for a 3x3 filter every input pixel of the tile travels L2 -> LDS nine times
+// (once per tap), and with two LDS buffers only ONE k-tile of DMA is ever in flight -- the k-loop runs at
+// (bytes in flight) / (memory latency), ~40 KB/us per CU, far below what the MFMAs could consume on the <= 192-channel layers.
+// Here the pixel operand is staged ONCE per 64-channel slice as a PATCH: the tile's pixels plus one image row (+1 pixel) of
+// halo on either side, in raster order, [pixel][64 channels] = 128-byte rows with the same source-side XOR swizzle as conv_v2.
+// The nine taps then read their MFMA fragments from the same patch at SHIFTED row indices (row + (tr-1)*W + (ts-1)); pixels
+// outside the image are redirected to a zero line. Only the weight tile (BI x 64) is streamed per tap. L2 -> LDS bytes per
+// (tile, slice): patch (BJ + 2W + 16) * 128 + 9 * BI * 128   instead of   9 * (BJ + BI) * 128   (1.9x fewer on 192 -> 192 @64^2,
+// 3.3x fewer on 96 -> 96 @128^2), and the next slice's patch is in flight during all nine taps of the current one.
+//
+//   * raster row order: patch row of tile pixel p, tap (tr,ts) = (p - j0) + W + 8 + (tr-1)*W + (ts-1)
+//   * quad row order (2x2 pooling epilogue): same patch (the tile still covers BJ/W whole image rows), per-lane row base
+//   * nearest x2 upsample on load: the patch holds SOURCE pixels (4x fewer); row = base + ((ph+tr-1)>>1)*Ws + ((pw+ts-1)>>1)
+//   * fragment addresses: (row << 7) | ((chunk ^ (row >> 1 & 7)) << 4): any 16 rows with distinct residues mod 16 are
+//     conflict-free for ds_read_b128, so every shift is as good as the unshifted read
+//   * epilogue: sg_conv_epilogue (conv_v2.h)
+#pragma once
+#include "conv_v2.h"
+
+struct ConvV3Params {
+  const bf16_t* x; const bf16_t* w;
+  int W;                  // source image width (Ws): power of two >= 8; patch halo = one source row + 8 pixels either side
+  int wlog;               // log2(W)
+  int C, ldx;
+  int Ho, Wo, wshift, hshift;
+  int flags;
+  int I, J, K;
+  int nslice;             // ceil(C / 64)
+  int npix_src;           // N * Hs * Ws
+  int npx;                // patch pixels = BJ(/4 with upsample) + 2 W + 16
+  unsigned xbytes, wbytes;
+  int zero_off, bias_off; // LDS byte offsets of the zero line / bias vector (behind the output staging area)
+};
+
+template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2>
+__global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int NW = WJ * WI;
+  constexpr int PB = BI * 128;                 // one weight tile (BI couts x 64 channels)
+  constexpr int NPI = (BI / 8 + NW - 1) / NW;  // weight DMA pieces per wave per tap (upper bound)
+  constexpr int TJ = BJ / WJ / 32, TI = BI / WI / 32;
+  static_assert(NW == 8, "8 waves");
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = tilesI * tilesJ;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tI = bid % tilesI, tJ = bid / tilesI;
+  const int i0 = tI * BI, j0 = tJ * BJ;
+  const int patch_bytes = p.npx * 128;
+  char* const pbufs = smem + (PB2 ? 2 : 1) * patch_bytes;      // the two weight buffers sit behind the patch buffer(s)
+  float* sbias = (float*)(smem + p.bias_off);
+  if (epi.bias) {
+    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+  }
+  if (tid < 32) ((unsigned*)(smem + p.zero_off))[tid] = 0u;
+
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+  const int sub = lane >> 3;
+  const int lc = (lane & 7) ^ ((4 * wave + (lane >> 4)) & 7);       // logical 16-byte chunk this lane fetches (DMA group g: key = 4g + sub/2)
+  const unsigned ldx2 = 2u * (unsigned)p.ldx;
+
+  // ---- patch DMA: groups of 8 consecutive source pixels, group g = wave + 8 i ----------------------------------------------
+  const int P0 = (UP ? (j0 >> 2) : j0) - p.W - 8;                    // raster index of patch row 0
+  const int ngroups = p.npx >> 3;
+  const int npw = (ngroups - wave + NW - 1) / NW;                    // groups of this wave (wave-uniform)
+  const int pix0 = P0 + 8 * wave + sub;                              // this lane's pixel in group i = 0
+  const unsigned poff0 = (unsigned)pix0 * ldx2 + (unsigned)lc * 16u;
+  const unsigned pstep = 8u * NW * ldx2;
+  // slice s: channel chunk lc of the slice exists when s*64 + lc*8 < C
+  auto patch_piece = [&](int buf, int s, int i) {
+    const int pix = pix0 + 8 * NW * i;
+    unsigned off = poff0 + (unsigned)i * pstep + (unsigned)s * 128u;
+    const bool ok = ((unsigned)pix < (unsigned)p.npix_src) && (s * 64 + lc * 8 < p.C);
+    off = ok ? off : 0x80000000u;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + buf * patch_bytes + (wave + NW * i) * 1024), 16, (int)off, 0, 0, 0);
+  };
+
+  // ---- weight DMA: BI rows x 64 channels of tap t, slice s ------------------------------------------------------------------
+  unsigned woff[NPI];
+#pragma unroll
+  for (int i = 0; i < NPI; i++) {
+    const int g = wave + NW * i;
+    const int row = i0 + 8 * g + sub;
+    woff[i] = ((g < BI / 8) && (row < p.I)) ? (unsigned)row * (unsigned)p.K * 2u : 0x40000000u;
+  }
+  auto weight_tile = [&](int buf, int s, int t) {
+    const unsigned kw = (s * 64 + lc * 8 < p.C) ? (unsigned)((t * p.C + s * 64 + lc * 8) * 2) : 0x40000000u;
+    char* pd = pbufs + buf * PB;
+#pragma unroll
+    for (int j = 0; j < NPI; j++) {
+      if (NW * (j + 1) <= BI / 8 || wave + NW * j < BI / 8)
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, (int)(woff[j] + kw), 0, 0, 0);
+    }
+  };
+
+  // ---- fragment rows of this lane ---------------------------------------------------------------------------------------------
+  const int wj = wave % WJ, wi = wave / WJ;
+  const int wj0 = wj * (BJ / WJ), wi0 = wi * (BI / WI);
+  const int frow = lane & 31, fhi = lane >> 5;
+  int rb[TJ];             // patch row of the centre pixel
+  unsigned qinv[TJ];      // bit t set = tap t reads outside the image (or the row is outside the problem)
+  int rs0[TJ], rs2[TJ], cs0[TJ], cs2[TJ];   // row / column displacement of taps tr = 0, 2 and ts = 0, 2 (tr = ts = 1: none)
+#pragma unroll
+  for (int b = 0; b < TJ; b++) {
+    const int row = j0 + wj0 + b * 32 + frow;
+    int n, ho, wo;
+    if (p.flags & SG_PIX_QUAD) {
+      const int q = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
+      const int wq = q & ((p.Wo >> 1) - 1);
+      const int t = q >> (p.wshift - 1);
+      const int hq = t & ((p.Ho >> 1) - 1);
+      n = t >> (p.hshift - 1);
+      ho = 2 * hq + dy; wo = 2 * wq + dx;
+    } else {
+      wo = row & (p.Wo - 1); const int t = row >> p.wshift; ho = t & (p.Ho - 1); n = t >> p.hshift;
+    }
+    unsigned m = 0;
+    if (row < p.J) {
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++)
+          if ((unsigned)(ho - 1 + rr) < (unsigned)p.Ho && (unsigned)(wo - 1 + ss) < (unsigned)p.Wo) m |= 1u << (rr * 3 + ss);
+    }
+    qinv[b] = ~m;
+    if (UP) {
+      const int Hs = p.Ho >> 1;
+      const int spc = ((n * Hs + (ho >> 1)) << p.wlog) + (wo >> 1);
+      rb[b] = spc - P0;
+      rs0[b] = (ho & 1) ? 0 : -p.W; rs2[b] = (ho & 1) ? p.W : 0;
+      cs0[b] = (wo & 1) ? 0 : -1;  cs2[b] = (wo & 1) ? 1 : 0;
+    } else {
+      rb[b] = (((n << p.hshift) + ho) << p.wshift) + wo - P0;
+      rs0[b] = -p.W; rs2[b] = p.W; cs0[b] = -1; cs2[b] = 1;
+    }
+  }
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; a++)
+#pragma unroll
+    for (int b = 0; b < TJ; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // ---- prologue: patch of slice 0 and the weights of (slice 0, tap 0) ------------------------------------------------------------
+  for (int i = 0; i < npw; i++) patch_piece(0, 0, i);
+  weight_tile(0, 0, 0);
+  __syncthreads();
+
+  const int nslice = p.nslice;
+  const int ppt = (npw + 8) / 9;                   // patch pieces of the next slice issued per tap (PB2)
+  int step = 0;
+  for (int s = 0; s < nslice; s++) {
+    const char* patch = smem + (PB2 ? (s & 1) : 0) * patch_bytes;
+    const bool next_slice = s + 1 < nslice;
+#pragma unroll
+    for (int t = 0; t < 9; t++, step++) {
+      // prefetch: weights of the next (slice, tap); a share of the next slice's patch
+      if (t < 8) weight_tile((step + 1) & 1, s, t + 1);
+      else if (next_slice) weight_tile((step + 1) & 1, s + 1, 0);
+      if (PB2 && next_slice) {
+        const int hi = ((t + 1) * ppt < npw) ? (t + 1) * ppt : npw;
+        for (int i = t * ppt; i < hi; i++) patch_piece((s + 1) & 1, s + 1, i);
+      }
+      const char* ps = pbufs + (step & 1) * PB;
+      // fragment base addresses of this tap
+      const int tr = t / 3, ts = t % 3;            // compile-time after unrolling
+      unsigned qa[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        int row = rb[b];
+        if (tr == 0) row += rs0[b];
+        if (tr == 2) row += rs2[b];
+        if (ts == 0) row += cs0[b];
+        if (ts == 2) row += cs2[b];
+        unsigned a = ((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1)) & 7) << 4);
+        a = ((qinv[b] >> t) & 1u) ? (unsigned)(p.zero_off - (PB2 ? (s & 1) : 0) * patch_bytes) : a;
+        qa[b] = a;
+      }
+      bf16x8_t pf[2][TI], qf[2][TJ];
+      auto load = [&](int ks, int slot) {
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          const int row = wi0 + a * 32 + frow;
+          const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+          u32x4 v = *(const u32x4*)(ps + row * 128 + ch * 16);
+          pf[slot][a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          u32x4 v = *(const u32x4*)(patch + (qa[b] ^ (unsigned)(ks * 32)));
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[slot][b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      };
+      load(0, 0);
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) {
+        if (ks < 3) load(ks + 1, (ks + 1) & 1);
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();
+    }
+    if (!PB2 && next_slice) {                      // single patch buffer: the next slice's patch cannot overlap the taps
+      for (int i = 0; i < npw; i++) patch_piece(0, s + 1, i);
+      __syncthreads();
+    }
+  }
+
+  float al = epi.alpha;
+  if (epi.alpha_ptr) al *= *epi.alpha_ptr;
+  sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, wi0, wj0, al);
+}
+
+template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2>
+static inline int sg_launch_conv_v3r(ConvV3Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const int patch_bytes = p.npx * 128;
+  int body = (PB2 ? 2 : 1) * patch_bytes + 2 * BI * 128;
+  const int stage = BJ * (BI * 2 + 16);
+  if (stage > body) body = stage;
+  p.zero_off = body; p.bias_off = body + 128;
+  const int lds = body + 128 + BI * 4;
+  if (lds > 160 * 1024) return -1;
+  static int attr_lds = 0;
+  if (lds > attr_lds) {
+    if (hipFuncSetAttribute((const void*)sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+    attr_lds = 160 * 1024;
+  }
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
+  hipLaunchKernelGGL((sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), lds, st, p, e, tilesI, tilesJ);
+  return 0;
+}
+// LDS need of a configuration (bytes), or -1 when it does not fit
+static inline int sg_conv_v3_lds(int BI, int BJ, int npx, bool pb2) {
+  int body = (pb2 ? 2 : 1) * npx * 128 + 2 * BI * 128;
+  const int stage = BJ * (BI * 2 + 16);
+  if (stage > body) body = stage;
+  const int lds = body + 128 + BI * 4;
+  return lds <= 160 * 1024 ? lds : -1;
+}
+template <int BI, int WJ, int WI, int BJ>
+static inline int sg_launch_conv_v3(const ConvV3Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, relu = (p.flags & SG_PIX_RELU) != 0;
+  const bool pb2 = p.nslice > 1 && sg_conv_v3_lds(BI, BJ, p.npx, true) > 0;
+  if (!pb2 && sg_conv_v3_lds(BI, BJ, p.npx, false) < 0) return -1;
+#define SG_V3_CASE(R_, U_, P_) if (relu == R_ && up == U_ && pb2 == P_) return sg_launch_conv_v3r<BI, WJ, WI, BJ, R_, U_, P_>(p, e, st);
+  SG_V3_CASE(false, false, false) SG_V3_CASE(false, false, true) SG_V3_CASE(false, true, false) SG_V3_CASE(false, true, true)
+  SG_V3_CASE(true, false, false) SG_V3_CASE(true, false, true) SG_V3_CASE(true, true, false) SG_V3_CASE(true, true, true)
+#undef SG_V3_CASE
+  return -1;
+}

@@ -71,6 +71,63 @@ def test_conv_v2_matches_reference_and_v1(sg, case):
         check(f"conv v2 dgrad {case}", nchw(dx.float().cpu()), xr.grad, 4e-3)
 
 
+V3_CASES = [
+    # N, Cin, Cout, H(in), relu, up, pool      -- 3x3, pad 1 (csrc/conv_v3.h: halo kernel)
+    (2, 64, 192, 16, False, False, False),      # raster rows, one slice
+    (2, 192, 192, 16, True, False, True),       # quad rows (pooling epilogue), three slices, ReLU on load
+    (2, 96, 96, 16, False, False, False),       # C = 96: second slice half empty
+    (1, 128, 128, 16, True, True, False),       # nearest x2 upsample on load
+    (2, 128, 96, 8, False, True, True),         # upsample + pooling
+    (8, 64, 96, 8, False, False, False),        # 8x8 images: a tile spans four images
+    (5, 64, 96, 8, True, False, False),         # J = 320: partial last tile
+    (3, 72, 96, 16, False, False, False),       # C = 72
+    (5, 64, 128, 16, True, False, False),       # 128-wide cout tile
+    (8, 96, 96, 128, True, False, True),        # the 512-pixel tile configuration (J = 131072), as D's first block
+]
+
+
+@pytest.mark.parametrize("case", V3_CASES)
+def test_conv_v3_matches_reference_and_v2(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cin, H, H), dt, 91)
+    w = rnd((Cout, Cin, 3, 3), dt, 92, 0.1)
+    bias = rnd((Cout,), torch.float32, 93)
+    Ho = H * (2 if up else 1)
+    Hy = Ho // 2 if pool else Ho
+    res = rnd((N, Cout, Hy, Hy), dt, 94)
+    big = N * Ho * Ho > 65536
+    sel = [0, N - 1] if big else list(range(N))      # big case: CPU fp64 reference for the first and the last image only
+    yref = _conv_ref(x[sel], w, 1, 1, relu, up, pool, bias, res[sel])
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    ef = L.EPI_POOL if pool else 0
+    outs = {}
+    for name, v3, v2 in (("v3", "force", "force"), ("v2", "0", "force")):
+        os.environ["SG_CONV_V3"], os.environ["SG_CONV_V2"] = v3, v2
+        y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, bias=bias.to(d), res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        outs[name] = y.float().cpu()
+    check(f"conv v3 {case}", nchw(outs["v3"])[sel], yref, 4e-3)
+    check(f"conv v3 vs v2 {case}", outs["v3"], outs["v2"], 4e-3)
+    # data gradient through the same kernel (flipped weights; ReLU mask / pooled-gradient broadcast / pooling-sum epilogues)
+    if Cin % 96 == 0 or Cin % 128 == 0:
+        xr, wr = x[sel].double().requires_grad_(True), w.double()
+        y2 = _conv_ref(xr, wr, 1, 1, relu, up, pool, None, None)
+        gy = rnd((N,) + tuple(y2.shape[1:]), dt, 95)
+        y2.backward(gy[sel].double())
+        wdg = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(d)
+        os.environ["SG_CONV_V3"], os.environ["SG_CONV_V2"] = "force", "force"
+        dx = F.conv2d_raw(nhwc(gy).to(d), wdg.data_ptr(), Cout, Cin, 3, 3, 1, 1, 1, L.PIX_UPSAMPLE if pool else 0,
+                          L.EPI_POOL if up else 0, mask=xd if relu else None, alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        check(f"conv v3 dgrad {case}", nchw(dx.float().cpu())[sel], xr.grad, 4e-3)
+    os.environ.pop("SG_CONV_V3", None)
+    os.environ.pop("SG_CONV_V2", None)
+
+
 WG_CASES = [
     # N, Cin, Cout, H, R, relu, up, pool
     (2, 64, 96, 16, 3, False, False, False),
