@@ -81,12 +81,16 @@ template <> __device__ __forceinline__ u32x4 relu16<float>(u32x4 v) {
   return v;
 }
 template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) {
+  // bf16 ReLU == signed 16-bit max with 0 (sign bit set -> 0, everything else unchanged): one v_pk_max_i16 per dword. The
+  // mask/select form it replaces compiled to ~6 VALU per dword, ~190 VALU per 24-MFMA tap of the halo kernel.
+  typedef short s16x2_t __attribute__((ext_vector_type(2)));
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    uint32_t x = v[i];
-    uint32_t lo = (x & 0x00008000u) ? 0u : (x & 0x0000ffffu);
-    uint32_t hi = (x & 0x80000000u) ? 0u : (x & 0xffff0000u);
-    v[i] = lo | hi;
+    const uint32_t x = v[i];       // (bit_cast straight from the vector element miscompiles with hipcc 7.2: go through a scalar)
+    s16x2_t a = __builtin_bit_cast(s16x2_t, x);
+    const s16x2_t z = {0, 0};
+    a = __builtin_elementwise_max(a, z);
+    v[i] = __builtin_bit_cast(uint32_t, a);
   }
   return v;
 }

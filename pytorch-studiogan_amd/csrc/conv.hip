@@ -6,6 +6,7 @@
 #include "conv_v2.h"
 #include "wgrad_v2.h"
 #include "conv_v3.h"
+#include "conv_sk.h"
 #include "../../include/sgamd.h"
 
 static inline int ilog2_exact(int v) {
@@ -105,7 +106,7 @@ template <> bool conv_fwd_v3_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   const bool up = (pflags & SG_PIX_UPSAMPLE) != 0, quad = (pflags & SG_PIX_QUAD) != 0;
   if (d->Ho != d->Hs * (up ? 2 : 1) || d->Wo != d->Ws * (up ? 2 : 1)) return false;
   const int wshift = ilog2_exact(d->Wo), hshift = ilog2_exact(d->Ho);
-  if (wshift < 0 || hshift < 0 || d->Ws < 8 || d->Hs < 2) return false;
+  if (wshift < 0 || hshift < 0 || d->Ws < 4 || d->Hs < 2) return false;
   const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2, wbytes = (long long)I * K * 2;
   if (xbytes >= (1ll << 31) || wbytes >= (1ll << 30)) return false;
   if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
@@ -121,8 +122,9 @@ template <> bool conv_fwd_v3_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
     if (tiles >= 512) { best = cands[c]; best_tiles = tiles; break; }
     if (tiles > best_tiles) { best = cands[c]; best_tiles = tiles; }
   }
+  if (I <= 32 && I % 8 == 0 && (J >= 512 * 256 || force)) { best = 32; best_tiles = (J + 511) / 512; }   // narrow outputs (G's RGB layer, 8 padded couts): HBM-bound, one cout tile
   if (!best || (best_tiles < 160 && !force)) return false;
-  const int BJ = (best == 96 && J >= 512 * 256) ? 512 : 256;
+  const int BJ = (best == 32 || (best == 96 && J >= 512 * 256)) ? 512 : 256;
   if ((quad || up) && (BJ % (2 * d->Wo))) return false;     // the tile must cover whole (pairs of) image rows
   if (J % d->Wo) return false;
   ConvV3Params p;
@@ -137,9 +139,42 @@ template <> bool conv_fwd_v3_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   int rc;
   if (best == 192) rc = sg_launch_conv_v3<192, 4, 2, 256>(p, e, st);
   else if (best == 128) rc = sg_launch_conv_v3<128, 4, 2, 256>(p, e, st);
+  else if (best == 32) rc = sg_launch_conv_v3<32, 8, 1, 512>(p, e, st);
   else if (BJ == 512) rc = sg_launch_conv_v3<96, 8, 1, 512>(p, e, st);
   else rc = sg_launch_conv_v3<96, 8, 1, 256>(p, e, st);
   return rc == 0;
+}
+
+// small-K streaming kernel (conv_sk.h): 1x1 convolutions with <= 192 input channels and the 3x3 stem over 8 padded channels.
+// SG_CONV_SK=0 disables it, =force skips the problem-size heuristic (tests).
+template <typename T> static bool conv_fwd_sk_try(const sg_conv_fwd_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool conv_fwd_sk_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
+  const char* mode = getenv("SG_CONV_SK");
+  if (mode && mode[0] == '0') return false;
+  const bool force = mode && mode[0] == 'f';
+  if (d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
+  const bool up = (pflags & SG_PIX_UPSAMPLE) != 0;
+  const bool one = d->R == 1 && d->S == 1 && d->pad_h == 0 && d->pad_w == 0 && d->C <= 192;
+  const bool stem = d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 && d->C == 8 && !up;
+  if (!one && !stem) return false;
+  if (d->C % 8 || d->ldx % 8 || I % 8 || I > 384 || !aligned16(d->x) || !aligned16(d->w)) return false;
+  if (d->Ho != d->Hs * (up ? 2 : 1) || d->Wo != d->Ws * (up ? 2 : 1)) return false;
+  const int wshift = ilog2_exact(d->Wo), hshift = ilog2_exact(d->Ho);
+  if (wshift < 1 || hshift < 1) return false;
+  const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2;
+  if (xbytes >= (1ll << 31) || J >= (1 << 30)) return false;
+  if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
+  if (e.mask && e.res) return false;
+  if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
+  if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
+  if (J < 16384 && !force) return false;
+  ConvSkParams p;
+  p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;
+  p.C = d->C; p.ldx = d->ldx; p.Hs = d->Hs; p.Ws = d->Ws;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = wshift; p.hshift = hshift;
+  p.mode3 = stem ? 1 : 0; p.flags = pflags;
+  p.I = I; p.J = J; p.K = K; p.xbytes = (unsigned)xbytes; p.nrb = 0;
+  return sg_launch_conv_sk(p, e, st) == 0;
 }
 
 template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream_t st) {
@@ -164,7 +199,8 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
-  if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) {}
+  if (w_vec && x_vec && conv_fwd_sk_try<T>(d, e, I, J, K, pflags, st)) {}
+  else if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
   else conv_fwd_launch<T, false>(d, e, I, J, K, pflags, st);

@@ -57,6 +57,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
   const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
   constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
   const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // at most one of them (launcher), bf16, 16-byte aligned rows
+  const int ncr = ((epi.I - i0 < BI ? epi.I - i0 : BI) + 7) >> 3;             // 16-byte chunks of an output row that exist (cout tail tile)
   if (pre_mask || pre_res) {
     const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
     const int ld = pre_mask ? epi.ldm : epi.ldr;
@@ -64,7 +65,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
       u32x4 t = {0u, 0u, 0u, 0u};
-      if (jg < Jout) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
+      if (jg < Jout && c < ncr) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
       *(u32x4*)(smem + r * CP + c * 16) = t;
     }
     __syncthreads();
@@ -125,7 +126,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
-      if (jg < Jout) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
+      if (jg < Jout && c < ncr) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
     }
   }
 }
@@ -289,6 +290,9 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
     if ((SCHED == 0 || SCHED == 3 || SCHED == 7) && more) issue((kt + 1) & 1);
     const char* qs = smem + (kt & 1) * BUF;
     const char* ps = qs + QB;
+    // 16-deep sub-steps of this k-tile that hold data (wave-uniform; < 4 only in the last tile when K % 64 != 0)
+    const int krem = p.K - kt * 64;
+    const int nks = krem >= 64 ? 4 : ((krem + 15) >> 4);
     if (SCHED == 7) {
       // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks (register double buffering)
       bf16x8_t pf[2][TI], qf[2][TJ];
@@ -312,12 +316,14 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
       load(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        if (ks < 3) load(ks + 1, (ks + 1) & 1);
+        if (ks < 3 && ks + 1 < nks) load(ks + 1, (ks + 1) & 1);
+        if (ks < nks) {
 #pragma unroll
-        for (int a = 0; a < TI; a++)
+          for (int a = 0; a < TI; a++)
 #pragma unroll
-          for (int b = 0; b < TJ; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TJ; b++)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+        }
       }
     } else {
 #pragma unroll
@@ -349,11 +355,13 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
 #pragma unroll
         for (int i = ks * PPS; i < (ks + 1) * PPS && i < NP; i++) piece((kt + 1) & 1, i);
       }
+      if (ks < nks) {
 #pragma unroll
-      for (int a = 0; a < TI; a++)
+        for (int a = 0; a < TI; a++)
 #pragma unroll
-        for (int b = 0; b < TJ; b++)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
     }
     }
     if (SCHED == 1 && more) advance();

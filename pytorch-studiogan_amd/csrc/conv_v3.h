@@ -21,7 +21,7 @@
 
 struct ConvV3Params {
   const bf16_t* x; const bf16_t* w;
-  int W;                  // source image width (Ws): power of two >= 8; patch halo = one source row + 8 pixels either side
+  int W;                  // source image width (Ws): power of two >= 4; patch halo = one source row + 8 pixels either side
   int wlog;               // log2(W)
   int C, ldx;
   int Ho, Wo, wshift, hshift;
@@ -162,6 +162,10 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
   for (int s = 0; s < nslice; s++) {
     const char* patch = smem + (PB2 ? (s & 1) : 0) * patch_bytes;
     const bool next_slice = s + 1 < nslice;
+    // 16-channel sub-steps of this slice that hold data (wave-uniform): a 96-channel layer's second slice is half empty, and
+    // running its zero half cost 25 % of the layer's MFMAs and fragment reads
+    const int crem = p.C - s * 64;
+    const int nks = crem >= 64 ? 4 : ((crem + 15) >> 4);
 #pragma unroll
     for (int t = 0; t < 9; t++, step++) {
       // prefetch: weights of the next (slice, tap); a share of the next slice's patch
@@ -205,12 +209,14 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
       load(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        if (ks < 3) load(ks + 1, (ks + 1) & 1);
+        if (ks < 3 && ks + 1 < nks) load(ks + 1, (ks + 1) & 1);
+        if (ks < nks) {
 #pragma unroll
-        for (int a = 0; a < TI; a++)
+          for (int a = 0; a < TI; a++)
 #pragma unroll
-          for (int b = 0; b < TJ; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+            for (int b = 0; b < TJ; b++)
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+        }
       }
       __syncthreads();
     }

@@ -83,6 +83,9 @@ V3_CASES = [
     (3, 72, 96, 16, False, False, False),       # C = 72
     (5, 64, 128, 16, True, False, False),       # 128-wide cout tile
     (8, 96, 96, 128, True, False, True),        # the 512-pixel tile configuration (J = 131072), as D's first block
+    (16, 64, 96, 4, True, False, False),        # 4x4 images (D's last blocks): a 256-pixel tile spans 16 images
+    (8, 128, 96, 4, False, True, False),        # 4x4 source, upsampled to 8x8
+    (2, 96, 8, 32, False, False, False),        # narrow cout tile (G's RGB layer: 3 couts padded to 8), cout-tail guard of the epilogue
 ]
 
 
@@ -126,6 +129,80 @@ def test_conv_v3_matches_reference_and_v2(sg, case):
         check(f"conv v3 dgrad {case}", nchw(dx.float().cpu())[sel], xr.grad, 4e-3)
     os.environ.pop("SG_CONV_V3", None)
     os.environ.pop("SG_CONV_V2", None)
+
+
+SK_CASES = [
+    # N, Cin, Cout, H(in), R, relu, up, pool      -- csrc/conv_sk.h: 1x1 with <= 192 channels and the 3x3 stem over 8 padded channels
+    (2, 8, 96, 32, 3, False, False, False),      # the RGB stem (chunk = tap), halo zeros
+    (3, 8, 96, 16, 3, False, False, True),       # stem-shaped with the pooling epilogue (quad rows); J = 768: partial wave strides
+    (2, 8, 96, 16, 1, False, False, False),      # D's first skip: K = 8
+    (2, 96, 16, 16, 1, False, False, False),     # attention theta / phi (12 couts padded to 16): cout tile 32 with a tail
+    (2, 96, 48, 16, 1, True, False, False),      # attention g; ReLU on load
+    (2, 48, 96, 16, 1, False, False, False),     # attention o: K = 48
+    (2, 96, 192, 16, 1, False, False, True),     # D skip: 1x1 + pooling, two passes of 96 couts
+    (2, 192, 96, 8, 1, False, True, False),      # G skip: nearest x2 upsample on load, K = 192
+    (2, 192, 384, 16, 1, True, False, False),    # two cout tiles of 192 (three passes of 64), K = 192
+    (5, 24, 192, 16, 1, False, False, False),    # K = 24 (zero-padded k tail), J = 1280
+    (1, 64, 128, 16, 1, False, True, True),      # 128 couts (two passes of 64), upsample + pooling
+]
+
+
+@pytest.mark.parametrize("case", SK_CASES)
+def test_conv_sk_matches_reference_and_v2(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, R, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    pad = R // 2
+    x = rnd((N, Cin, H, H), dt, 61)
+    w = rnd((Cout, Cin, R, R), dt, 62, 0.1)
+    bias = rnd((Cout,), torch.float32, 63)
+    Ho = H * (2 if up else 1)
+    Hy = Ho // 2 if pool else Ho
+    res = rnd((N, Cout, Hy, Hy), dt, 64)
+    msk = rnd((N, Cout, Hy, Hy), dt, 65)
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    ef = L.EPI_POOL if pool else 0
+    al = 0.25 if pool else 1.0
+    for what in ("res", "mask", "plain"):
+        kw = dict(bias=bias.to(d)) if what != "mask" else {}
+        if what == "res":
+            kw["res"] = nhwc(res).to(d)
+        if what == "mask":
+            kw["mask"] = nhwc(msk).to(d)
+        outs = {}
+        for name, sk in (("sk", "force"), ("old", "0")):
+            os.environ["SG_CONV_SK"] = sk
+            y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, R, R, 1, pad, pad, pf, ef, alpha=al, **kw)
+            torch.cuda.synchronize()
+            outs[name] = y.float().cpu()
+        os.environ.pop("SG_CONV_SK", None)
+        yref = _conv_ref(x, w, 1, pad, relu, up, pool, bias if what != "mask" else None, res if what == "res" else None)
+        if what == "mask":
+            yref = yref * (msk.double() > 0)
+        check(f"conv sk {what} {case}", nchw(outs["sk"]), yref, 4e-3)
+        check(f"conv sk vs tile kernels {what} {case}", outs["sk"], outs["old"], 4e-3)
+
+
+def test_conv_sk_full_size_stem_and_skip(sg):
+    """BigGAN-128 D's stem (8 -> 96, 3x3 @128^2) and first skip (1x1 + pool) at batch 32: every wave runs several row blocks
+    (software pipeline, out-of-range tail fetches); compared with the tile kernels on the whole tensor."""
+    from studiogan_amd import functional as F, _lib as L
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    for (N, Cin, Cout, H, R, pool) in ((32, 8, 96, 128, 3, False), (32, 96, 192, 64, 1, True), (7, 96, 48, 64, 1, False)):
+        x = rnd((N, H, H, Cin), dt, 51).to(d)
+        w = rnd((Cout, R, R, Cin), dt, 52, 0.1).to(d)
+        bias = rnd((Cout,), torch.float32, 53).to(d)
+        outs = {}
+        for name, sk in (("sk", "force"), ("old", "0")):
+            os.environ["SG_CONV_SK"] = sk
+            y = F.conv2d_raw(x, w.data_ptr(), Cin, Cout, R, R, 1, R // 2, R // 2, 0, L.EPI_POOL if pool else 0, bias=bias, alpha=0.25 if pool else 1.0)
+            torch.cuda.synchronize()
+            outs[name] = y.float().cpu()
+        os.environ.pop("SG_CONV_SK", None)
+        check(f"conv sk full size {(N, Cin, Cout, H, R, pool)}", outs["sk"], outs["old"], 4e-3)
 
 
 WG_CASES = [
