@@ -306,7 +306,7 @@ def main():
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc.json")))
         if args.workload == "biggan128" and mixed and args.batch == 256:
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic_pmc_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
     except Exception:
         pass
     out = {
@@ -318,7 +318,7 @@ def main():
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine: sg_conv_v2_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "kernel": "convolution engine: sg_conv_v3_kernel (3x3 halo) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),

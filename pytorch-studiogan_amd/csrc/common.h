@@ -95,6 +95,14 @@ template <> __device__ __forceinline__ u32x4 relu16<bf16_t>(u32x4 v) {
   return v;
 }
 
+// sum over the 4 lanes of a quad (lanes 4q..4q+3), result in every lane: two v_add_f32_dpp (quad_perm), no LDS crossbar round trip.
+// Same values as v += shfl_xor(v,1); v += shfl_xor(v,2) (the additions commute), which compiled to two dependent ds_bpermute.
+__device__ __forceinline__ float quad_sum(float v) {
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, true));   // quad_perm [1,0,3,2]
+  v += __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, true));   // quad_perm [2,3,0,1]
+  return v;
+}
+
 // wave-level sum (64 lanes)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

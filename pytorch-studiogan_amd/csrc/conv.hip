@@ -136,6 +136,12 @@ template <> bool conv_fwd_v3_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.npx = (up ? BJ / 4 : BJ) + 2 * d->Ws + 16;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.zero_off = 0; p.bias_off = 0;
+  {   // DMA piece placement (conv_v3.h): SG_V3_SCHED=0 / 1 overrides the default
+    static int sched = -1;
+    if (sched < 0) { const char* e2 = getenv("SG_V3_SCHED"); sched = e2 ? (e2[0] - '0') : 1; }
+    p.sched = sched;
+  }
+  if (((p.npx >> 3) + 7) / 8 >= 19) return false;           // would need more than 2 patch pieces per tap and wave (never with <= 160 KB of LDS)
   int rc;
   if (best == 192) rc = sg_launch_conv_v3<192, 4, 2, 256>(p, e, st);
   else if (best == 128) rc = sg_launch_conv_v3<128, 4, 2, 256>(p, e, st);

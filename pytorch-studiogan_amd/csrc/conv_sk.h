@@ -31,15 +31,14 @@ struct ConvSkParams {
 };
 
 // TI x 32 couts per accumulator pass, NP passes over the same pixel fragments (cout tile = TI * NP * 32)
-template <int TI, int NP, int TJ, int KS>
-__global__ __launch_bounds__(256) void sg_conv_sk_kernel(ConvSkParams p, Epilogue<bf16_t> epi) {
-  constexpr int NW = 4;
+template <int TI, int NP, int TJ, int KS, int NW>
+__global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epilogue<bf16_t> epi) {
   constexpr int BI = TI * NP * 32;
   constexpr int NCH = 2 * KS;              // 16-byte k-chunks
   constexpr int WP = KS * 32 + 16;         // weight row pitch in LDS
-  constexpr int CP = BI * 2 + 16;          // staging row pitch
+  constexpr int CP = TI * 64 + 16;         // staging row pitch: the couts of ONE pass (the passes stage and store one after the other)
   constexpr int ROWS = 32 * TJ;
-  constexpr int CPR = BI / 8;              // 16-byte chunks per output row of the tile
+  constexpr int CPR = TI * 4;              // 16-byte chunks per output row of a pass
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const wsm = smem;
   float* const sbias = (float*)(smem + BI * WP);
@@ -133,23 +132,9 @@ __global__ __launch_bounds__(256) void sg_conv_sk_kernel(ConvSkParams p, Epilogu
           t = __builtin_elementwise_max(t, floor2);
           q[b][ks][e] = __builtin_bit_cast(uint32_t, t);
         }
-    // ---- wave-private epilogue -------------------------------------------------------------------------------------------------
     const int r0 = rb * ROWS;
     const int rows_out = pool ? rows_out_full / 4 : rows_out_full;
     const int jbase = pool ? (r0 >> 2) : r0;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous block's staging reads are done (LDS is in order per wave)
-    if (pre_mask || pre_res) {
-      const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
-      const int ld = pre_mask ? epi.ldm : epi.ldr;
-      for (int idx = lane; idx < rows_out * CPR; idx += 64) {
-        const int r = idx / CPR, c = idx - r * CPR;
-        const int jg = jbase + r;
-        u32x4 t = {0u, 0u, 0u, 0u};
-        if (jg < Jout && c < ncr) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
-        *(u32x4*)(stg + r * CP + c * 16) = t;
-      }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    }
 #pragma unroll
     for (int ps = 0; ps < NP; ps++) {
       f32x16 acc[TI][TJ];
@@ -175,62 +160,75 @@ __global__ __launch_bounds__(256) void sg_conv_sk_kernel(ConvSkParams p, Epilogu
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
+      // ---- wave-private epilogue of this pass (couts i0 + ps*TI*32 ..) ---------------------------------------------------------
+      const int ic0 = ps * TI * 32;                    // first cout of the pass inside the tile
+      const int ncp = ncr - ps * CPR;                  // 16-byte chunks of this pass that exist (cout tail)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous staging reads are done (LDS is in order per wave)
+      if (pre_mask || pre_res) {
+        const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
+        const int ld = pre_mask ? epi.ldm : epi.ldr;
+        for (int idx = lane; idx < rows_out * CPR; idx += 64) {
+          const int r = idx / CPR, c = idx - r * CPR;
+          const int jg = jbase + r;
+          u32x4 t = {0u, 0u, 0u, 0u};
+          if (jg < Jout && c < ncp) t = *(const u32x4*)(src + (long long)jg * ld + i0 + ic0 + c * 8);
+          *(u32x4*)(stg + r * CP + c * 16) = t;
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      }
 #pragma unroll
-    for (int ta = 0; ta < TI; ta++)
+      for (int ta = 0; ta < TI; ta++)
 #pragma unroll
-      for (int tb = 0; tb < TJ; tb++) {
-        const int jl = tb * 32 + (lane & 31);
+        for (int tb = 0; tb < TJ; tb++) {
+          const int jl = tb * 32 + (lane & 31);
 #pragma unroll
-        for (int g4 = 0; g4 < 4; g4++) {
-          const int il = (ps * TI + ta) * 32 + 8 * g4 + 4 * (lane >> 5);
-          float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
-          if (pool) {
+          for (int g4 = 0; g4 < 4; g4++) {
+            const int il = ta * 32 + 8 * g4 + 4 * (lane >> 5);       // cout inside the pass
+            float v[4] = {acc[ta][tb][4 * g4 + 0], acc[ta][tb][4 * g4 + 1], acc[ta][tb][4 * g4 + 2], acc[ta][tb][4 * g4 + 3]};
+            if (pool) {
 #pragma unroll
-            for (int e = 0; e < 4; e++) {
-              v[e] += __shfl_xor(v[e], 1, 64);
-              v[e] += __shfl_xor(v[e], 2, 64);
+              for (int e = 0; e < 4; e++) v[e] = quad_sum(v[e]);
             }
-          }
-          const int jo = pool ? (jl >> 2) : jl;
-          const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
-          if (act) {
-            char* loc = stg + jo * CP + il * 2;
+            const int jo = pool ? (jl >> 2) : jl;
+            const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
+            if (act) {
+              char* loc = stg + jo * CP + il * 2;
 #pragma unroll
-            for (int e = 0; e < 4; e++) v[e] *= al;
-            {
-              const f32x4 bv = *(const f32x4*)(sbias + il);
+              for (int e = 0; e < 4; e++) v[e] *= al;
+              {
+                const f32x4 bv = *(const f32x4*)(sbias + ic0 + il);
 #pragma unroll
-              for (int e = 0; e < 4; e++) v[e] += bv[e];
+                for (int e = 0; e < 4; e++) v[e] += bv[e];
+              }
+              if (pre_mask) {
+                const u32x2 m = *(const u32x2*)loc;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
+              }
+              if (pre_res) {
+                const u32x2 r = *(const u32x2*)loc;
+#pragma unroll
+                for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
+              }
+              if (relu_out) {
+#pragma unroll
+                for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
+              }
+              u32x2 t;
+              t[0] = pack2bf(v[0], v[1]);
+              t[1] = pack2bf(v[2], v[3]);
+              *(u32x2*)loc = t;
             }
-            if (pre_mask) {
-              const u32x2 m = *(const u32x2*)loc;
-#pragma unroll
-              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }
-            }
-            if (pre_res) {
-              const u32x2 r = *(const u32x2*)loc;
-#pragma unroll
-              for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((r[e >> 1] >> (16 * (e & 1))) & 0xffffu); v[e] += epi.beta * bf2f(h); }
-            }
-            if (relu_out) {
-#pragma unroll
-              for (int e = 0; e < 4; e++) v[e] = fmaxf(v[e], 0.f);
-            }
-            u32x2 t;
-            t[0] = pack2bf(v[0], v[1]);
-            t[1] = pack2bf(v[2], v[3]);
-            *(u32x2*)loc = t;
           }
         }
-      }
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    {
-      bf16_t* o = (bf16_t*)epi.out;
-      for (int idx = lane; idx < rows_out * CPR; idx += 64) {
-        const int r = idx / CPR, c = idx - r * CPR;
-        const int jg = jbase + r;
-        if (jg < Jout && c < ncr) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(stg + r * CP + c * 16);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      {
+        bf16_t* o = (bf16_t*)epi.out;
+        for (int idx = lane; idx < rows_out * CPR; idx += 64) {
+          const int r = idx / CPR, c = idx - r * CPR;
+          const int jg = jbase + r;
+          if (jg < Jout && c < ncp) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + ic0 + c * 8) = *(const u32x4*)(stg + r * CP + c * 16);
+        }
       }
     }
   };
@@ -254,22 +252,24 @@ __global__ __launch_bounds__(256) void sg_conv_sk_kernel(ConvSkParams p, Epilogu
 
 template <int TI, int NP, int TJ, int KS>
 static inline int sg_launch_conv_sk_t(ConvSkParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  constexpr int BI = TI * NP * 32, WP = KS * 32 + 16, CP = BI * 2 + 16, ROWS = 32 * TJ;
-  constexpr int lds = BI * WP + BI * 4 + 4 * ROWS * CP;
+  constexpr int BI = TI * NP * 32, WP = KS * 32 + 16, CP = TI * 64 + 16, ROWS = 32 * TJ;
+  // 8 waves per CU (2 per SIMD: the register budget): two 4-wave workgroups when their LDS fits twice, else one 8-wave workgroup
+  // sharing one copy of the weights
+  constexpr int lds4 = BI * WP + BI * 4 + 4 * ROWS * CP;
+  constexpr int NW = (2 * lds4 <= 160 * 1024) ? 4 : 8;
+  constexpr int lds = BI * WP + BI * 4 + NW * ROWS * CP;
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_sk_kernel<TI, NP, TJ, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_sk_kernel<TI, NP, TJ, KS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
     attr_done = true;
   }
   p.nrb = (p.J + ROWS - 1) / ROWS;
   const int tilesI = (p.I + BI - 1) / BI;
-  int per_cu = (160 * 1024) / lds;                        // workgroups a CU can hold: LDS, and 2 waves per SIMD by registers
-  if (per_cu > 2) per_cu = 2;
-  int gx = (p.nrb + 3) / 4;
-  const int cap = (256 * per_cu + tilesI - 1) / tilesI;
+  int gx = (p.nrb + NW - 1) / NW;
+  const int cap = (256 * (8 / NW) + tilesI - 1) / tilesI;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL((sg_conv_sk_kernel<TI, NP, TJ, KS>), dim3(gx, tilesI), dim3(256), lds, st, p, e);
+  hipLaunchKernelGGL((sg_conv_sk_kernel<TI, NP, TJ, KS, NW>), dim3(gx, tilesI), dim3(64 * NW), lds, st, p, e);
   return 0;
 }
 

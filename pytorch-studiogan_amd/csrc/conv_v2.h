@@ -83,10 +83,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
         // same operation order as Epilogue::prep (pool, scale, bias, mask, residual, ReLU), operands from LDS
         if (pool) {
 #pragma unroll
-          for (int e = 0; e < 4; e++) {
-            v[e] += __shfl_xor(v[e], 1, 64);
-            v[e] += __shfl_xor(v[e], 2, 64);
-          }
+          for (int e = 0; e < 4; e++) v[e] = quad_sum(v[e]);
         }
         const int jo = pool ? (jl >> 2) : jl;
         const bool act = (!pool || (lane & 3) == 0) && (jbase + jo < Jout);
@@ -316,8 +313,8 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
       load(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        if (ks < 3 && ks + 1 < nks) load(ks + 1, (ks + 1) & 1);
-        if (ks < nks) {
+        if (ks < 3 && __builtin_expect(ks + 1 < nks, 1)) load(ks + 1, (ks + 1) & 1);
+        if (__builtin_expect(ks < nks, 1)) {
 #pragma unroll
           for (int a = 0; a < TI; a++)
 #pragma unroll
@@ -355,7 +352,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
 #pragma unroll
         for (int i = ks * PPS; i < (ks + 1) * PPS && i < NP; i++) piece((kt + 1) & 1, i);
       }
-      if (ks < nks) {
+      if (__builtin_expect(ks < nks, 1)) {
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll

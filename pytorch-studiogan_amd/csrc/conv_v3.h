@@ -32,10 +32,15 @@ struct ConvV3Params {
   int npx;                // patch pixels = BJ(/4 with upsample) + 2 W + 16
   unsigned xbytes, wbytes;
   int zero_off, bias_off; // LDS byte offsets of the zero line / bias vector (behind the output staging area)
+  int sched;              // 0: next tap's DMA pieces issued in front of the tap's MFMAs; 1: interleaved with the first sub-step's MFMAs
 };
 
-template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2>
+// W3: three weight buffers (PB2 only). The weights of tap t+1 are then complete and visible one barrier EARLIER than they are
+// needed, so the first fragments of tap t+1 are requested before the barrier that ends tap t: the matrix pipe does not drain at
+// every tap boundary while all eight waves sit behind the barrier and then queue for the LDS at once.
+template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2, bool W3 = false>
 __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  static_assert(!W3 || PB2, "W3 needs the double patch buffer");
   constexpr int NW = WJ * WI;
   constexpr int PB = BI * 128;                 // one weight tile (BI couts x 64 channels)
   constexpr int NPI = (BI / 8 + NW - 1) / NW;  // weight DMA pieces per wave per tap (upper bound)
@@ -91,14 +96,15 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
     const int row = i0 + 8 * g + sub;
     woff[i] = ((g < BI / 8) && (row < p.I)) ? (unsigned)row * (unsigned)p.K * 2u : 0x40000000u;
   }
-  auto weight_tile = [&](int buf, int s, int t) {
+  auto weight_piece = [&](int buf, int s, int t, int j) {
     const unsigned kw = (s * 64 + lc * 8 < p.C) ? (unsigned)((t * p.C + s * 64 + lc * 8) * 2) : 0x40000000u;
     char* pd = pbufs + buf * PB;
+    if (NW * (j + 1) <= BI / 8 || wave + NW * j < BI / 8)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, (int)(woff[j] + kw), 0, 0, 0);
+  };
+  auto weight_tile = [&](int buf, int s, int t) {
 #pragma unroll
-    for (int j = 0; j < NPI; j++) {
-      if (NW * (j + 1) <= BI / 8 || wave + NW * j < BI / 8)
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pd + (wave + NW * j) * 1024), 16, (int)(woff[j] + kw), 0, 0, 0);
-    }
+    for (int j = 0; j < NPI; j++) weight_piece(buf, s, t, j);
   };
 
   // ---- fragment rows of this lane ---------------------------------------------------------------------------------------------
@@ -151,6 +157,97 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
+  if constexpr (W3) {
+    // ---- three weight buffers: buffer of step (9 s + t) = t % 3; DMA runs two taps ahead; fragments one sub-step ahead ACROSS taps --
+    for (int i = 0; i < npw; i++) patch_piece(0, 0, i);
+    weight_tile(0, 0, 0);
+    weight_tile(1, 0, 1);
+    __syncthreads();
+    const int nslice = p.nslice;
+    const int ppt8 = (npw + 7) >> 3;                 // patch pieces of the next slice per tap, taps 0..7 (<= 2: launcher)
+    bf16x8_t pf[2][TI], qf[2][TJ];
+    unsigned qa[TJ];                                 // fragment byte offsets (from smem) of the tap whose sub-step 0 is loaded next
+    auto make_qa = [&](int t, int poff) {            // t: compile-time tap; poff: byte offset of the slice's patch buffer
+      const int tr = t / 3, ts = t % 3;
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        int row = rb[b];
+        if (tr == 0) row += rs0[b];
+        if (tr == 2) row += rs2[b];
+        if (ts == 0) row += cs0[b];
+        if (ts == 2) row += cs2[b];
+        unsigned a = (unsigned)poff + (((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1)) & 7) << 4));
+        a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
+        qa[b] = a;
+      }
+    };
+    auto load = [&](int ks, int slot, const char* ps) {
+#pragma unroll
+      for (int a = 0; a < TI; a++) {
+        const int row = wi0 + a * 32 + frow;
+        const int ch = (ks * 2 + fhi) ^ ((row >> 1) & 7);
+        u32x4 v = *(const u32x4*)(ps + row * 128 + ch * 16);
+        pf[slot][a] = __builtin_bit_cast(bf16x8_t, v);
+      }
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+        if (RELU) v = relu16<bf16_t>(v);
+        qf[slot][b] = __builtin_bit_cast(bf16x8_t, v);
+      }
+    };
+    make_qa(0, 0);
+    load(0, 0, pbufs);
+    for (int s = 0; s < nslice; s++) {
+      const bool next_slice = s + 1 < nslice;
+      const int crem = p.C - s * 64;
+      const int nks = crem >= 64 ? 4 : ((crem + 15) >> 4);
+      const int poff_cur = (s & 1) * patch_bytes, poff_nxt = ((s + 1) & 1) * patch_bytes;
+#pragma unroll
+      for (int t = 0; t < 9; t++) {
+        const char* ps = pbufs + (t % 3) * PB;
+        const int phi = ((t + 1) * ppt8 < npw) ? (t + 1) * ppt8 : npw;
+        auto dma_piece = [&](int k) {
+          if (k < NPI) {
+            if (t + 2 < 9) weight_piece((t + 2) % 3, s, t + 2, k);
+            else if (next_slice) weight_piece((t + 2) % 3, s + 1, t + 2 - 9, k);
+          } else if (t < 8 && next_slice) {
+            const int i = t * ppt8 + (k - NPI);
+            if (i < phi) patch_piece((s + 1) & 1, s + 1, i);
+          }
+        };
+        if (p.sched == 0) {
+#pragma unroll
+          for (int k = 0; k < NPI + 2; k++) dma_piece(k);
+        }
+#pragma unroll
+        for (int ks = 0; ks < 4; ks++) {
+          if (ks < 3 && __builtin_expect(ks + 1 < nks, 1)) load(ks + 1, (ks + 1) & 1, ps);
+          if (__builtin_expect(ks < nks, 1)) {
+#pragma unroll
+            for (int a = 0; a < TI; a++)
+#pragma unroll
+              for (int b = 0; b < TJ; b++) {
+                acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+                if (ks == 0 && a * TJ + b < NPI + 2 && p.sched != 0) {
+                  __builtin_amdgcn_sched_barrier(0);
+                  dma_piece(a * TJ + b);
+                  __builtin_amdgcn_sched_barrier(0);
+                }
+              }
+            if (ks == 0 && p.sched != 0) {
+#pragma unroll
+              for (int k = TI * TJ; k < NPI + 2; k++) dma_piece(k);
+            }
+          }
+        }
+        // sub-step 0 of the next tap (its weights were complete at the PREVIOUS barrier; the patch of the next slice at barrier 7)
+        if (t < 8) { make_qa(t + 1, poff_cur); load(0, 0, pbufs + ((t + 1) % 3) * PB); }
+        else if (next_slice) { make_qa(0, poff_nxt); load(0, 0, pbufs); }
+        __syncthreads();
+      }
+    }
+  } else {
   // ---- prologue: patch of slice 0 and the weights of (slice 0, tap 0) ------------------------------------------------------------
   for (int i = 0; i < npw; i++) patch_piece(0, 0, i);
   weight_tile(0, 0, 0);
@@ -168,12 +265,23 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
     const int nks = crem >= 64 ? 4 : ((crem + 15) >> 4);
 #pragma unroll
     for (int t = 0; t < 9; t++, step++) {
-      // prefetch: weights of the next (slice, tap); a share of the next slice's patch
-      if (t < 8) weight_tile((step + 1) & 1, s, t + 1);
-      else if (next_slice) weight_tile((step + 1) & 1, s + 1, 0);
-      if (PB2 && next_slice) {
-        const int hi = ((t + 1) * ppt < npw) ? (t + 1) * ppt : npw;
-        for (int i = t * ppt; i < hi; i++) patch_piece((s + 1) & 1, s + 1, i);
+      // prefetch: weights of the next (slice, tap); a share (<= 2 pieces: launcher) of the next slice's patch. DMA piece k of this
+      // tap: k < NPI = weight piece k, k = NPI, NPI + 1 = patch pieces. A piece costs 60-180 issue cycles; issued in front of the
+      // tap (sched 0) both lock-stepped waves of a SIMD pay them with the matrix pipe idle, so sched 1 puts one piece behind each
+      // of the first sub-step's MFMAs, where the pipe is busy anyway.
+      const int phi = ((t + 1) * ppt < npw) ? (t + 1) * ppt : npw;
+      auto dma_piece = [&](int k) {
+        if (k < NPI) {
+          if (t < 8) weight_piece((step + 1) & 1, s, t + 1, k);
+          else if (next_slice) weight_piece((step + 1) & 1, s + 1, 0, k);
+        } else if (PB2 && next_slice) {
+          const int i = t * ppt + (k - NPI);
+          if (i < phi) patch_piece((s + 1) & 1, s + 1, i);
+        }
+      };
+      if (p.sched == 0) {
+#pragma unroll
+        for (int k = 0; k < NPI + 2; k++) dma_piece(k);
       }
       const char* ps = pbufs + (step & 1) * PB;
       // fragment base addresses of this tap
@@ -209,15 +317,31 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
       load(0, 0);
 #pragma unroll
       for (int ks = 0; ks < 4; ks++) {
-        if (ks < 3 && ks + 1 < nks) load(ks + 1, (ks + 1) & 1);
-        if (ks < nks) {
+        if (ks < 3 && __builtin_expect(ks + 1 < nks, 1)) load(ks + 1, (ks + 1) & 1);
+        if (__builtin_expect(ks < nks, 1)) {
 #pragma unroll
           for (int a = 0; a < TI; a++)
 #pragma unroll
-            for (int b = 0; b < TJ; b++)
+            for (int b = 0; b < TJ; b++) {
               acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks & 1][a], qf[ks & 1][b], acc[a][b], 0, 0, 0);
+              if (ks == 0 && a * TJ + b < NPI + 2 && (p.sched == 1 || p.sched == 2)) {
+                __builtin_amdgcn_sched_barrier(0);
+                dma_piece(a * TJ + b);
+                __builtin_amdgcn_sched_barrier(0);
+              }
+            }
+          if (ks == 0 && (p.sched == 1 || p.sched == 2)) {   // fewer MFMAs in a sub-step than pieces: the rest behind the sub-step
+#pragma unroll
+            for (int k = TI * TJ; k < NPI + 2; k++) dma_piece(k);
+          }
         }
       }
+#ifdef SG_ABLATION
+      if (p.sched >= 2) {   // ablation (wrong results): barrier without waiting for this tap's DMA -- how much of a tap is DMA latency?
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        continue;
+      }
+#endif
       __syncthreads();
     }
     if (!PB2 && next_slice) {                      // single patch buffer: the next slice's patch cannot overlap the taps
@@ -226,15 +350,17 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
     }
   }
 
+  }   // !W3
+
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
   sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, wi0, wj0, al);
 }
 
-template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2>
+template <int BI, int WJ, int WI, int BJ, bool RELU, bool UP, bool PB2, bool W3 = false>
 static inline int sg_launch_conv_v3r(ConvV3Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const int patch_bytes = p.npx * 128;
-  int body = (PB2 ? 2 : 1) * patch_bytes + 2 * BI * 128;
+  int body = (PB2 ? 2 : 1) * patch_bytes + (W3 ? 3 : 2) * BI * 128;
   const int stage = BJ * (BI * 2 + 16);
   if (stage > body) body = stage;
   p.zero_off = body; p.bias_off = body + 128;
@@ -242,16 +368,16 @@ static inline int sg_launch_conv_v3r(ConvV3Params p, const Epilogue<bf16_t>& e, 
   if (lds > 160 * 1024) return -1;
   static int attr_lds = 0;
   if (lds > attr_lds) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2, W3>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess) return -1;
     attr_lds = 160 * 1024;
   }
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), lds, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v3_kernel<BI, WJ, WI, BJ, RELU, UP, PB2, W3>), dim3(tilesI * tilesJ), dim3(64 * WJ * WI), lds, st, p, e, tilesI, tilesJ);
   return 0;
 }
 // LDS need of a configuration (bytes), or -1 when it does not fit
-static inline int sg_conv_v3_lds(int BI, int BJ, int npx, bool pb2) {
-  int body = (pb2 ? 2 : 1) * npx * 128 + 2 * BI * 128;
+static inline int sg_conv_v3_lds(int BI, int BJ, int npx, bool pb2, bool w3 = false) {
+  int body = (pb2 ? 2 : 1) * npx * 128 + (w3 ? 3 : 2) * BI * 128;
   const int stage = BJ * (BI * 2 + 16);
   if (stage > body) body = stage;
   const int lds = body + 128 + BI * 4;
@@ -262,6 +388,14 @@ static inline int sg_launch_conv_v3(const ConvV3Params& p, const Epilogue<bf16_t
   const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, relu = (p.flags & SG_PIX_RELU) != 0;
   const bool pb2 = p.nslice > 1 && sg_conv_v3_lds(BI, BJ, p.npx, true) > 0;
   if (!pb2 && sg_conv_v3_lds(BI, BJ, p.npx, false) < 0) return -1;
+  if constexpr (BJ == 256 && (BI == 192 || BI == 128)) {      // the deep-layer configurations: three weight buffers when they fit
+    static int w3_mode = -1;
+    if (w3_mode < 0) { const char* e3 = getenv("SG_V3_W3"); w3_mode = (e3 && e3[0] == '0') ? 0 : 1; }
+    if (w3_mode && pb2 && sg_conv_v3_lds(BI, BJ, p.npx, true, true) > 0 && (((p.npx >> 3) + 7) / 8 + 7) / 8 <= 2) {
+      if (relu) return up ? sg_launch_conv_v3r<BI, WJ, WI, BJ, true, true, true, true>(p, e, st) : sg_launch_conv_v3r<BI, WJ, WI, BJ, true, false, true, true>(p, e, st);
+      return up ? sg_launch_conv_v3r<BI, WJ, WI, BJ, false, true, true, true>(p, e, st) : sg_launch_conv_v3r<BI, WJ, WI, BJ, false, false, true, true>(p, e, st);
+    }
+  }
 #define SG_V3_CASE(R_, U_, P_) if (relu == R_ && up == U_ && pb2 == P_) return sg_launch_conv_v3r<BI, WJ, WI, BJ, R_, U_, P_>(p, e, st);
   SG_V3_CASE(false, false, false) SG_V3_CASE(false, false, true) SG_V3_CASE(false, true, false) SG_V3_CASE(false, true, true)
   SG_V3_CASE(true, false, false) SG_V3_CASE(true, false, true) SG_V3_CASE(true, true, false) SG_V3_CASE(true, true, true)

@@ -289,10 +289,7 @@ template <typename T> struct Epilogue {
     const int lane = threadIdx.x & 63;
     if (flags & SG_EPI_POOL) {
 #pragma unroll
-      for (int e = 0; e < 4; e++) {
-        v[e] += __shfl_xor(v[e], 1, 64);
-        v[e] += __shfl_xor(v[e], 2, 64);
-      }
+      for (int e = 0; e < 4; e++) v[e] = quad_sum(v[e]);
       if (lane & 3) return false;
       j >>= 2;
     }

@@ -83,6 +83,9 @@ V3_CASES = [
     (3, 72, 96, 16, False, False, False),       # C = 72
     (5, 64, 128, 16, True, False, False),       # 128-wide cout tile
     (8, 96, 96, 128, True, False, True),        # the 512-pixel tile configuration (J = 131072), as D's first block
+    (2, 384, 192, 8, True, False, False),       # six slices through the three-weight-buffer loop (cross-tap fragment prefetch)
+    (2, 160, 128, 16, False, False, True),      # 128-wide tile, last slice half empty (nks = 2), pooling
+    (1, 192, 384, 16, False, True, False),      # two cout tiles, upsample on load, three weight buffers
     (16, 64, 96, 4, True, False, False),        # 4x4 images (D's last blocks): a 256-pixel tile spans 16 images
     (8, 128, 96, 4, False, True, False),        # 4x4 source, upsampled to 8x8
     (2, 96, 8, 32, False, False, False),        # narrow cout tile (G's RGB layer: 3 couts padded to 8), cout-tail guard of the epilogue
