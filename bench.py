@@ -304,7 +304,7 @@ def main():
     # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc.json")))
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc_v2.json")))
         if args.workload == "biggan128" and mixed and args.batch == 256:
             traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic_pmc_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
     except Exception:
