@@ -263,6 +263,10 @@ int sg_pool2d(int dtype, const void* x, void* y, int N, int H, int W, int C, int
 int sg_global_avgpool(int dtype, const void* x, float* y, int N, int HW, int C, sg_stream_t s);
 /* hits[n] = 1 iff the true class is within the top k of scores[n][0..ncls) with sklearn's tie rule (higher index wins a tie) */
 int sg_topk_hits(const float* scores, int ld, int ncls, const int64_t* labels, int k, int N, uint8_t* hits, sg_stream_t s);
+/* top-k training of G (reference src/worker.py:565-566 torch.topk(adv_output, k).values): vals/idx = the k largest of x[0..n),
+ * descending, lower index first among equals; scatter = its gradient (dx[idx[r]] = g[r], 0 elsewhere) */
+int sg_topk_select(const float* x, int n, int k, float* vals, int* idx, sg_stream_t s);
+int sg_topk_scatter(const float* g, const int* idx, int k, float* dx, int n, sg_stream_t s);
 /* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
 int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
 

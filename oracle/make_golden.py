@@ -46,6 +46,15 @@ CONFIGS = {
               "LOSS": {"adv_loss": "hinge"},
               "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
         batch=4, n_d=2, seed=4242),
+    # StudioGAN's own BigGAN-deep variant (models/big_resnet_deep_studiogan.py): learned 1x1 skips, optblock, narrow 32x32 stem
+    "bigdeepsg32": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "big_resnet_deep_studiogan", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [2], "attn_d_loc": [1], "z_dim": 24, "g_shared_dim": 16, "g_conv_dim": 8, "d_conv_dim": 8,
+                        "g_depth": 2, "d_depth": 2},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=2424),
     # SNGAN on the ResNet backbone (C2 family: reference configs/CIFAR10/SNGAN.yaml at width 8): cBN on the one-hot label, PD, SN in D only
     "sngan32": dict(
         yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},

@@ -365,6 +365,96 @@ def biggan_deep_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True
 
 
 # ---------------------------------------------------------------------------------------------------------
+# StudioGAN's BigGAN-deep variant (models/big_resnet_deep_studiogan.py): learned 1x1 skips, pool in front of the last ReLU of D
+# ---------------------------------------------------------------------------------------------------------
+def biggan_deep_sg_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet_deep_studiogan.py:143-176 (Generator.forward), GenBlock.forward :57-79: as the legacy generator, but the
+    skip is conv2d0 (1x1) over the (upsampled) block input."""
+    g_in, g_out, _, _, _ = biggan_dims(cfg["img_size"], cfg["g_conv_dim"])
+    E = emu_of(cfg)
+    depth = cfg["g_depth"]
+    if cfg.get("g_cond_mtd", "cBN") != "W/O":
+        affine = torch.cat([F.embedding(label, P["shared.weight"]), z], 1)
+    else:
+        affine = z
+    act = E.q(linear(affine, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
+    bi = 0
+    for index in range(len(g_in)):
+        for gi in range(depth):
+            pre = f"blocks.{bi}.0"
+            up = gi == depth - 1
+            x0 = act
+            x = E.q(torch.relu(cond_batch_norm(E.qb(act), affine, P, B, pre + ".bn1", bn_mode, sn_iter)))
+            x = E.q(conv(x, P, B, pre + ".conv2d1", 0, sn_iter, E))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn2", bn_mode, sn_iter)))
+            if up:
+                x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
+            x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E, qb_in=not up))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn3", bn_mode, sn_iter)))
+            x = E.q(conv(x, P, B, pre + ".conv2d3", 1, sn_iter, E))
+            x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn4", bn_mode, sn_iter)))
+            x = E.q(conv(x, P, B, pre + ".conv2d4", 0, sn_iter, E))
+            if up:
+                x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
+            else:
+                x0 = conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E)
+            act = E.q(x + x0)
+            bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
+            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
+            bi += 1
+    act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
+    return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
+
+
+def biggan_deep_sg_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
+    """models/big_resnet_deep_studiogan.py:323-330,354-355 (Discriminator.forward), DiscBlock.forward :232-250: the average
+    pool precedes the last ReLU + conv1x1; the skip is conv2d0 over all output channels, pooled after the conv except in the
+    first block (`optblock`: pool, then conv). nn.ReLU(inplace=True) on the block input rewrites the skip tensor: x0 = relu(x).
+    32x32: the stem is d_conv_dim wide (:259)."""
+    d_in, d_out, d_down = biggan_deep_dims(cfg["img_size"], cfg["d_conv_dim"])
+    if cfg["img_size"] == 32:
+        d_in = [cfg["d_conv_dim"]] + d_in[1:]
+    E = emu_of(cfg)
+    depth = cfg["d_depth"]
+    h = E.q(conv(E.q(x), P, B, "input_conv", 1, sn_iter, E))
+    bi = 0
+    for index in range(len(d_in)):
+        for di in range(depth):
+            pre = f"blocks.{bi}.0"
+            cin = d_in[index] if di == 0 else d_out[index]
+            cout = d_out[index]
+            down = d_down[index] and di == 0
+            opt = index == 0 and di == 0
+            r = torch.relu(h)
+            x0 = r
+            y = E.q(conv(r, P, B, pre + ".conv2d1", 0, sn_iter, E))
+            y = E.q(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E))
+            y = conv(torch.relu(y), P, B, pre + ".conv2d3", 1, sn_iter, E)
+            if down:
+                y = F.avg_pool2d(y, 2)
+            y = E.q(y)
+            y = conv(torch.relu(y), P, B, pre + ".conv2d4", 0, sn_iter, E)
+            if opt:
+                x0 = E.q(conv(E.q(F.avg_pool2d(E.qb(x0), 2)), P, B, pre + ".conv2d0", 0, sn_iter, E))
+            elif down or cin != cout:
+                x0 = conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E)
+                if down:
+                    x0 = F.avg_pool2d(x0, 2)
+                x0 = E.q(x0)
+            h = E.q(y + x0)
+            bi += 1
+        if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
+            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
+            bi += 1
+    h = torch.sum(torch.relu(E.qb(h)), dim=[2, 3])
+    adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))
+    if cfg.get("d_cond_mtd", "W/O") == "PD":
+        adv = adv + torch.sum(F.embedding(label, weight_of(P, B, "embedding", sn_iter)) * h, 1)
+    return adv, h
+
+
+# ---------------------------------------------------------------------------------------------------------
 # SNGAN-style ResNet generator (models/resnet.py:15-158); its discriminator is line-for-line models/big_resnet.py's
 # ---------------------------------------------------------------------------------------------------------
 def resnet_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
@@ -594,6 +684,13 @@ def model_fns(cfg):
 
         def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
             return biggan_deep_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
+        return gen_fn, dis_fn
+    if bb == "big_resnet_deep_studiogan":
+        def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_deep_sg_generator(z, y, P, B, cfg, bn_mode, sn_iter)
+
+        def dis_fn(x, y, P, B, bn_mode="track", sn_iter=True):
+            return biggan_deep_sg_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
         return gen_fn, dis_fn
     if bb == "resnet":
         def gen_fn(z, y, P, B, bn_mode="track", sn_iter=True):

@@ -129,6 +129,8 @@ _PROTOS = {
     "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_topk_hits": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "sg_topk_select": [_vp, _i, _i, _vp, _vp, _vp],
+    "sg_topk_scatter": [_vp, _vp, _i, _vp, _i, _vp],
 }
 
 

@@ -52,6 +52,8 @@ class GenBlock(nn.Module):
 
 
 class Generator(nn.Module):
+    BLOCK = GenBlock       # big_resnet_deep_studiogan.py swaps in its own block (learned 1x1 skip)
+
     def __init__(self, z_dim, g_shared_dim, img_size, g_conv_dim, apply_attn, attn_g_loc, g_cond_mtd, num_classes, g_init, g_depth,
                  mixed_precision, MODULES, MODEL):
         super().__init__()
@@ -88,9 +90,9 @@ class Generator(nn.Module):
         self.linear0 = MODULES.g_linear(in_features=self.affine_input_dim, out_features=self.in_dims[0] * self.bottom * self.bottom, bias=True)
         blocks = []
         for index in range(self.num_blocks):
-            blocks += [[GenBlock(in_channels=self.in_dims[index], out_channels=self.in_dims[index] if g_index == 0 else self.out_dims[index],
-                                 g_cond_mtd=g_cond_mtd, affine_input_dim=self.affine_input_dim, upsample=True if g_index == (g_depth - 1) else False,
-                                 MODULES=MODULES)] for g_index in range(g_depth)]
+            blocks += [[self.BLOCK(in_channels=self.in_dims[index], out_channels=self.in_dims[index] if g_index == 0 else self.out_dims[index],
+                                   g_cond_mtd=g_cond_mtd, affine_input_dim=self.affine_input_dim, upsample=True if g_index == (g_depth - 1) else False,
+                                   MODULES=MODULES)] for g_index in range(g_depth)]
             if index + 1 in attn_g_loc and apply_attn:
                 blocks += [[ops.SelfAttention(self.out_dims[index], is_generator=True, MODULES=MODULES)]]
         self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])
@@ -155,11 +157,17 @@ class DiscBlock(nn.Module):
 
 
 class Discriminator(nn.Module):
+    IN32_FIRST = 4         # width multiple of the 32x32 stem (big_resnet_deep_studiogan.py: 1)
+
+    @staticmethod
+    def make_block(index, d_index, in_channels, out_channels, MODULES, downsample):
+        return DiscBlock(in_channels=in_channels, out_channels=out_channels, MODULES=MODULES, downsample=downsample)
+
     def __init__(self, img_size, d_conv_dim, apply_d_sn, apply_attn, attn_d_loc, d_cond_mtd, aux_cls_type, d_embed_dim, normalize_d_embed,
                  num_classes, d_init, d_depth, mixed_precision, MODULES, MODEL):
         super().__init__()
         d_in_dims_collection = {
-            "32": [d_conv_dim * 4, d_conv_dim * 4, d_conv_dim * 4],
+            "32": [d_conv_dim * self.IN32_FIRST, d_conv_dim * 4, d_conv_dim * 4],
             "64": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8],
             "128": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 16],
             "256": [d_conv_dim, d_conv_dim * 2, d_conv_dim * 4, d_conv_dim * 8, d_conv_dim * 8, d_conv_dim * 16],
@@ -196,8 +204,8 @@ class Discriminator(nn.Module):
         self.input_conv._sg_cin_pad = 8      # RGB image as an 8-channel NHWC tensor (zero-filled)
         blocks = []
         for index in range(len(self.in_dims)):
-            blocks += [[DiscBlock(in_channels=self.in_dims[index] if d_index == 0 else self.out_dims[index], out_channels=self.out_dims[index],
-                                  MODULES=MODULES, downsample=True if down[index] and d_index == 0 else False)] for d_index in range(d_depth)]
+            blocks += [[self.make_block(index, d_index, self.in_dims[index] if d_index == 0 else self.out_dims[index], self.out_dims[index],
+                                        MODULES, True if down[index] and d_index == 0 else False)] for d_index in range(d_depth)]
             if (index + 1) in attn_d_loc and apply_attn:
                 blocks += [[ops.SelfAttention(self.out_dims[index], is_generator=False, MODULES=MODULES)]]
         self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])

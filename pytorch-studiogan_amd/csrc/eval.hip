@@ -151,3 +151,36 @@ extern "C" int sg_topk_hits(const float* scores, int ld, int ncls, const int64_t
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- top-k training of the generator (reference src/worker.py:565-566: torch.topk(adv_output, k).values; losses.py:364-366) ------
+// vals[r] / idx[r] = the r-th largest of x[0..n) (descending; among equal values the lower index first). Rank by counting:
+// n <= a few thousand logits, one workgroup. The set of selected logits is what the loss depends on (a mean over them).
+__global__ __launch_bounds__(256) void k_topk_select(const float* x, int n, int k, float* vals, int* idx) {
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = x[i];
+    int rank = 0;
+    for (int j = 0; j < n; j++) {
+      const float u = x[j];
+      rank += (u > v) || (u == v && j < i);
+    }
+    if (rank < k) { vals[rank] = v; idx[rank] = i; }
+  }
+}
+extern "C" int sg_topk_select(const float* x, int n, int k, float* vals, int* idx, sg_stream_t s) {
+  SG_CHECK(x && vals && idx && n > 0 && k > 0 && k <= n, "sg_topk_select: bad args");
+  hipLaunchKernelGGL(k_topk_select, dim3(1), dim3(256), 0, (hipStream_t)s, x, n, k, vals, idx);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// dx[i] = g[r] if i == idx[r] else 0
+__global__ __launch_bounds__(256) void k_topk_scatter(const float* g, const int* idx, int k, float* dx, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dx[i] = 0.f;
+  __syncthreads();
+  for (int r = threadIdx.x; r < k; r += 256) dx[idx[r]] = g[r];
+}
+extern "C" int sg_topk_scatter(const float* g, const int* idx, int k, float* dx, int n, sg_stream_t s) {
+  SG_CHECK(g && idx && dx && n > 0 && k > 0 && k <= n, "sg_topk_scatter: bad args");
+  hipLaunchKernelGGL(k_topk_scatter, dim3(1), dim3(256), 0, (hipStream_t)s, g, idx, k, dx, n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1059,6 +1059,29 @@ def interpolate_rows(real, fake, alpha):
     return out
 
 
+class TopkFn(torch.autograd.Function):
+    """torch.topk(logits, k).values on a [B] vector (reference src/worker.py:565-566); backward scatters to the selected logits."""
+
+    @staticmethod
+    def forward(ctx, x, k):
+        x = _c(x.float().reshape(-1))
+        n = x.numel()
+        vals = torch.empty(k, dtype=torch.float32, device=x.device)
+        idx = torch.empty(k, dtype=torch.int32, device=x.device)
+        L.call("sg_topk_select", L.ptr(x), n, k, L.ptr(vals), L.ptr(idx), L.stream())
+        ctx.save_for_backward(idx)
+        ctx.n = n
+        return vals
+
+    @staticmethod
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _c(g.float())
+        dx = torch.empty(ctx.n, dtype=torch.float32, device=g.device)
+        L.call("sg_topk_scatter", L.ptr(g), L.ptr(idx), idx.numel(), L.ptr(dx), ctx.n, L.stream())
+        return dx, None
+
+
 _LOSS_KIND = {"hinge": 0, "wasserstein": 1, "vanilla": 2}
 
 

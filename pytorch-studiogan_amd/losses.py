@@ -51,3 +51,14 @@ def cal_grad_penalty(real_images, real_labels, fake_images, discriminator, devic
     fake_dict = discriminator(interpolates, real_labels, eval=False)
     grads = cal_deriv(inputs=interpolates, outputs=fake_dict["adv_output"], device=device)
     return F.GradPenaltyFn.apply(grads)
+
+
+def adjust_k(current_k, topk_gamma, inf_k):
+    """reference src/utils/losses.py:364-366."""
+    current_k = max(current_k * topk_gamma, inf_k)
+    return current_k
+
+
+def topk_values(d_logit_fake, k):
+    """torch.topk(d_logit_fake, k).values of reference src/worker.py:565-566 (one small kernel each way)."""
+    return F.TopkFn.apply(d_logit_fake, int(k))

@@ -65,8 +65,11 @@ def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
 class Worker:
     def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
-                 group=None, apply_gp=False, gp_lambda=10.0):
+                 group=None, apply_gp=False, gp_lambda=10.0, apply_topk=False, topk_gamma=0.99, topk_nu=0.5):
         self.Gen, self.Dis = Gen, Dis
+        # top-k training of the generator (reference src/worker.py:117-121,565-566; k decays by topk_gamma per epoch down to nu * batch)
+        self.apply_topk, self.topk_gamma, self.topk_nu = apply_topk, topk_gamma, topk_nu
+        self.topk = batch_size
         self.apply_gp, self.gp_lambda = apply_gp, gp_lambda
         self.z_dim, self.num_classes, self.batch_size = z_dim, num_classes, batch_size
         self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
@@ -126,12 +129,19 @@ class Worker:
                 fake_images = self.Gen(zs, fake_labels)
                 fake_dict = self.Dis(fake_images, fake_labels)
                 self.last_g = (fake_images.detach(), fake_dict["adv_output"].detach())
+                if self.apply_topk:      # src/worker.py:565-566
+                    fake_dict["adv_output"] = sg_losses.topk_values(fake_dict["adv_output"], int(self.topk))
                 gen_acml_loss = self.g_loss(fake_dict["adv_output"], DDP=self.group is not None)
                 gen_acml_loss = gen_acml_loss / self.acml
                 gen_acml_loss.backward()
             # Adam and the EMA of the generator copy (src/worker.py:630-634,675-676) in one launch
             self.g_optimizer.step(ema=self.ema, iteration=current_step, group=self.group)
         return gen_acml_loss
+
+    def adjust_topk(self):
+        """once per epoch (reference src/loader.py: `worker.topk = losses.adjust_k(...)` under LOSS.apply_topk)."""
+        self.topk = sg_losses.adjust_k(current_k=self.topk, topk_gamma=self.topk_gamma, inf_k=int(self.batch_size * self.topk_nu))
+        return self.topk
 
     # -- src/loader.py:392-405 ------------------------------------------------------------------------------------
     def step(self, current_step, real_batches, injected_d=None, injected_g=None):

@@ -30,7 +30,7 @@ def _perturb(P, seed):
             P[k] = 1 + 0.2 * torch.randn(P[k].shape, generator=g)
 
 
-NAMES = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32"]
+NAMES = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32", "bigdeepsg32"]
 
 
 @pytest.mark.parametrize("mixed", [False, True])
@@ -124,15 +124,19 @@ def test_generator_fwd_bwd(sg, name, mixed, bn_mode):
     wide = bool(meta.get("compact"))
     if wide and not mixed:
         tg = 6e-3
-    if mixed and name == "bigdeep32":
+    if mixed and name in ("bigdeep32", "bigdeepsg32"):
         # 48 cBN+ReLU layers at a width-8 bottleneck: against the FP32 oracle the bf16 mask-flip noise compounds to 30-60 % --
         # only a sanity bound here; the bf16 parity of this network is asserted against the emulating oracle (4-10 %)
         t, tg = 0.15, 0.9
     l2 = mixed or wide
     C.check(f"G img [{bn_mode}]", img, img_o, t)
     gmax = max(float(v.grad.abs().max()) for v in leaves.values())
+    deep_bf16 = mixed and name in ("bigdeep32", "bigdeepsg32")
     for k, p in G.named_parameters():
-        C.check("G grad " + k, p.grad, leaves[k].grad, tg, floor=1e-2 * gmax, l2=l2)  # 1e-2: bias gradients in front of a BN are analytically 0 (pure cancellation noise)
+        # single scalars (the attention gate sigma: one dot product of cancelling terms) have no averaging over the mask-flip noise of
+        # the deep bf16 nets against the FP32 oracle (measured 1.6 on bigdeepsg32; 2e-2 against the emulating oracle): finite-ness only
+        tk = 4.0 if (deep_bf16 and p.numel() < 16) else tg
+        C.check("G grad " + k, p.grad, leaves[k].grad, tk, floor=1e-2 * gmax, l2=l2)  # 1e-2: bias gradients in front of a BN are analytically 0 (pure cancellation noise)
     for k, b in G.named_buffers():
         if "_ones" not in k:
             C.check("G buf " + k, b, B[k], t)
@@ -205,7 +209,7 @@ def test_bf16_vs_emulating_oracle(sg, name, which):
     for p in net.parameters():
         p.grad = None
     C = Collector()
-    tg = 0.15 if (meta.get("compact") or name == "bigdeep32") else 8e-2     # bigdeep32: 48 ReLU layers deep
+    tg = 0.15 if (meta.get("compact") or name in ("bigdeep32", "bigdeepsg32")) else 8e-2     # bigdeep32: 48 ReLU layers deep
     if which == "D":
         x, lab = fix["in/real0"].clone(), fix["in/rl0"]
         gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1])[:x.shape[0]]

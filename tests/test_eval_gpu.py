@@ -84,3 +84,36 @@ def test_feature_loop_with_generator(sg):
     assert torch.isfinite(feats).all() and abs(float(probs.sum(1).mean()) - 1) < 1e-4
     mu, sigma = mom.finalize()
     check("loop moments", torch.from_numpy(mu), feats.double().mean(0).cpu(), 1e-5)
+
+
+def test_topk_training_select_and_scatter(sg):
+    """Top-k generator training (reference src/worker.py:565-566: torch.topk(adv_output, k).values, then the loss over them):
+    the selected VALUES are bit-exact against torch.topk on the host (ties included), the gradient lands on the selected
+    logits only, and k follows losses.adjust_k (reference src/utils/losses.py:364-366)."""
+    from studiogan_amd import losses as SL
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(9)
+    for n, k in ((256, 256), (256, 128), (64, 7), (1000, 333)):
+        x = torch.randn(n, generator=g)
+        x[n // 3] = x[n // 2]                                   # a tie
+        xd = x.to(dev).requires_grad_(True)
+        v = SL.topk_values(xd, k)
+        ref = torch.topk(x, k).values
+        assert torch.equal(v.detach().cpu(), ref), "top-k values must be bit-exact"
+        w = torch.randn(k, generator=g)
+        (v * w.to(dev)).sum().backward()
+        xr = x.clone().requires_grad_(True)
+        (torch.topk(xr, k).values * w).sum().backward()
+        # with a tie straddling the cut torch may pick either index; the kernel takes the lower one: compare as multisets per value
+        gd, gr = xd.grad.cpu(), xr.grad
+        assert int((gd != 0).sum()) <= k and abs(float(gd.sum() - gr.sum())) < 1e-4
+        keep = x != x[n // 2]
+        assert torch.equal(gd[keep], gr[keep]), "gradient scatter"
+    # hinge generator loss over the k best fakes == reference formula
+    x = torch.randn(32, generator=g)
+    loss = SL.g_hinge(SL.topk_values(x.to(dev), 10))
+    assert abs(float(loss) - float(-torch.mean(torch.topk(x, 10).values))) < 1e-6
+    k = 256
+    for _ in range(200):
+        k = SL.adjust_k(current_k=k, topk_gamma=0.99, inf_k=int(256 * 0.5))
+    assert k == 128

@@ -91,7 +91,7 @@ def test_module_names_and_sn_state():
     assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32", "bigdeepsg32"])
 def test_golden_state_dict_keys_match_backbone(name):
     from util import load_golden, sub
     from test_model_gpu import build_from_yaml

@@ -30,13 +30,13 @@ def build_from_yaml(y, mixed, device):
     return G.to(device), Dm.to(device)
 
 
-ALL = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32", "bigdeep32"]
+ALL = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32", "bigdeep32", "bigdeepsg32"]
 
 
 @pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("name", ALL)
 def test_training_step_vs_golden(sg, name, mixed):
-    if mixed and name == "bigdeep32":
+    if mixed and name in ("bigdeep32", "bigdeepsg32"):
         pytest.skip("48 ReLU layers at width 8: bf16 vs the fp32 golden chain is noise (30-60 %); bf16 parity of this network is "
                     "asserted by test_bf16_vs_emulating_oracle, the fp32 chain by the non-mixed variant")
     from studiogan_amd.worker import Worker
