@@ -225,8 +225,10 @@ int sg_loss_g(int kind, const float* fake, int B, float* loss, float* d_fake, sg
  * floats; penalty = mean_b (||grads[b]||_2 - 1)^2 with norms[B] kept for the backward; dgrads = gout * d penalty / d grads.
  * sg_masked_sum_hw: out[b][c] = sum_hw t[b,hw,c] * (x[b,hw,c] > 0)  (adjoint of sg_relu_sum_hw_bwd in the second-order pass) */
 int sg_interp_rows(const float* real, const float* fake, const float* alpha, float* out, int B, long long n, sg_stream_t s);
-int sg_gp_fwd(const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s);
-int sg_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s);
+/* kind 0: mean_b (||g_b|| - 1)^2 (WGAN-GP / DRA, losses.py:301-335); 1: 0.5 mean_b ||g_b||^2 (R1, :355-361); 2: max_b ||g_b||^2
+ * (maxGP, :338-352). norms: B + 1 floats (row norms; slot B = arg-max row of kind 2) */
+int sg_gp_fwd(int kind, const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s);
+int sg_gp_bwd(int kind, const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s);
 int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B, int HW, int C, sg_stream_t s);
 
 /* ---- fused self-attention scores (reference utils/ops.py:83-103: softmax(theta . maxpool(phi)^T) and its backward), bf16 only.

@@ -572,6 +572,26 @@ def grad_penalty(dis_fn, real, real_labels, fake, P, B, alpha):
     return ((g.norm(2, dim=1) - 1) ** 2).mean() + x[:, 0, 0, 0].mean() * 0
 
 
+def maxgrad_penalty(dis_fn, real, real_labels, fake, P, B, alpha):
+    """utils/losses.py:338-352: the interpolates of grad_penalty, penalty = max_b ||grad_b||^2."""
+    a = alpha.view(-1, 1, 1, 1)
+    x = (a * real + (1 - a) * fake).detach().requires_grad_(True)
+    adv, _ = dis_fn(x, real_labels, P, B)
+    g = torch.autograd.grad(outputs=adv, inputs=x, grad_outputs=torch.ones_like(adv), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    g = g.view(g.size(0), -1)
+    return torch.max(g.norm(2, dim=1) ** 2) + x[:, 0, 0, 0].mean() * 0
+
+
+def r1_reg(dis_fn, real, real_labels, P, B):
+    """utils/losses.py:355-361 on the real batch (src/worker.py:260-261,410-412): 0.5 mean_b ||d sum(D(x)) / d x_b||^2.
+    Returns (penalty, adv) -- the reference takes the gradient through the SAME forward that feeds the adversarial loss."""
+    x = real.detach().requires_grad_(True)
+    adv, _ = dis_fn(x, real_labels, P, B)
+    g = torch.autograd.grad(outputs=adv.sum(), inputs=x, grad_outputs=torch.ones([]), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    r1 = 0.5 * g.pow(2).contiguous().view(real.shape[0], -1).sum(1).mean(0) + x[:, 0, 0, 0].mean() * 0
+    return r1, adv
+
+
 # ---------------------------------------------------------------------------------------------------------
 # optimizer / EMA (config.py:541-563 torch.optim.Adam eps=1e-6; utils/ema.py:27-40)
 # ---------------------------------------------------------------------------------------------------------

@@ -109,8 +109,8 @@ _PROTOS = {
     "sg_slice_up_bwd": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sg_copy_channels": [_i, _vp, _i, _vp, _i, _ll, _i, _vp],
     "sg_interp_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
-    "sg_gp_fwd": [_vp, _i, _ll, _vp, _vp, _vp],
-    "sg_gp_bwd": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "sg_gp_fwd": [_i, _vp, _i, _ll, _vp, _vp, _vp],
+    "sg_gp_bwd": [_i, _vp, _vp, _vp, _vp, _i, _ll, _vp],
     "sg_masked_sum_hw": [_i, _vp, _vp, _vp, _i, _i, _i, _vp],
     "sg_sn_forward": [_i, _vp, C.POINTER(SnLayer), _i, _f, _vp, _ll, _vp],
     "sg_sn_backward": [_vp, C.POINTER(SnBwdLayer), _i, _vp, _ll, _vp],

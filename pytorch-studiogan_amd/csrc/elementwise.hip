@@ -550,31 +550,50 @@ __global__ __launch_bounds__(256) void k_gp_norms(const float* grads, long long 
   acc = block_sum_256(acc, sm);
   if (threadIdx.x == 0) norms[blockIdx.x] = sqrtf(acc);
 }
-__global__ __launch_bounds__(256) void k_gp_loss(const float* norms, int B, float* loss) {
+// kind 0: WGAN-GP  mean_b (||g_b|| - 1)^2   (reference utils/losses.py:301-316; DRA :319-335 is the same functional)
+// kind 1: R1       0.5 mean_b ||g_b||^2      (:355-361)
+// kind 2: maxGP    max_b ||g_b||^2           (:338-352); norms[B] receives the (first) arg-max row for the backward pass
+__global__ __launch_bounds__(256) void k_gp_loss(int kind, float* norms, int B, float* loss) {
   __shared__ float sm[4];
+  if (kind == 2) {
+    if (threadIdx.x == 0) {
+      float best = -1.f; int bi = 0;
+      for (int b = 0; b < B; b++) { const float v = norms[b] * norms[b]; if (v > best) { best = v; bi = b; } }
+      loss[0] = best; norms[B] = (float)bi;
+    }
+    return;
+  }
   float acc = 0.f;
-  for (int b = threadIdx.x; b < B; b += 256) { const float d = norms[b] - 1.f; acc += d * d; }
+  for (int b = threadIdx.x; b < B; b += 256) {
+    if (kind == 0) { const float d = norms[b] - 1.f; acc += d * d; }
+    else acc += 0.5f * norms[b] * norms[b];
+  }
   acc = block_sum_256(acc, sm);
   if (threadIdx.x == 0) loss[0] = acc / (float)B;
 }
-extern "C" int sg_gp_fwd(const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s) {
-  SG_CHECK(grads && norms && loss && B > 0 && n > 0, "sg_gp_fwd: bad args");
+extern "C" int sg_gp_fwd(int kind, const float* grads, int B, long long n, float* norms, float* loss, sg_stream_t s) {
+  SG_CHECK(grads && norms && loss && B > 0 && n > 0 && kind >= 0 && kind <= 2, "sg_gp_fwd: bad args");
   hipLaunchKernelGGL(k_gp_norms, dim3(B), dim3(256), 0, (hipStream_t)s, grads, n, norms);
-  hipLaunchKernelGGL(k_gp_loss, dim3(1), dim3(256), 0, (hipStream_t)s, norms, B, loss);
+  hipLaunchKernelGGL(k_gp_loss, dim3(1), dim3(256), 0, (hipStream_t)s, kind, norms, B, loss);
   SG_LAUNCH_CHECK();
   return 0;
 }
-// d penalty / d grads[b,:] = gout * (2/B) (1 - 1/norms[b]) grads[b,:]
-__global__ void k_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, long long total) {
-  const float go = gout[0] * 2.f / (float)B;
+// d penalty / d grads[b,:] = gout * { (2/B) (1 - 1/norms[b]) | 1/B | 2 [b == argmax] } grads[b,:]
+__global__ void k_gp_bwd(int kind, const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, long long total) {
+  const float go = gout[0];
+  const int bmax = kind == 2 ? (int)norms[B] : -1;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
-    const float nb = norms[i / n];
-    dgrads[i] = go * (1.f - 1.f / nb) * grads[i];
+    const int b = (int)(i / n);
+    float f;
+    if (kind == 0) f = go * 2.f / (float)B * (1.f - 1.f / norms[b]);
+    else if (kind == 1) f = go / (float)B;
+    else f = (b == bmax) ? 2.f * go : 0.f;
+    dgrads[i] = f * grads[i];
   }
 }
-extern "C" int sg_gp_bwd(const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s) {
-  SG_CHECK(grads && norms && gout && dgrads && B > 0 && n > 0, "sg_gp_bwd: bad args");
-  hipLaunchKernelGGL(k_gp_bwd, dim3(nblk((long long)B * n, 256)), dim3(256), 0, (hipStream_t)s, grads, norms, gout, dgrads, B, n, (long long)B * n);
+extern "C" int sg_gp_bwd(int kind, const float* grads, const float* norms, const float* gout, float* dgrads, int B, long long n, sg_stream_t s) {
+  SG_CHECK(grads && norms && gout && dgrads && B > 0 && n > 0 && kind >= 0 && kind <= 2, "sg_gp_bwd: bad args");
+  hipLaunchKernelGGL(k_gp_bwd, dim3(nblk((long long)B * n, 256)), dim3(256), 0, (hipStream_t)s, kind, grads, norms, gout, dgrads, B, n, (long long)B * n);
   SG_LAUNCH_CHECK();
   return 0;
 }

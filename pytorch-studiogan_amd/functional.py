@@ -1027,17 +1027,19 @@ class PDHeadBwdFn(torch.autograd.Function):
 
 
 class GradPenaltyFn(torch.autograd.Function):
-    """mean_b (||grads[b]||_2 - 1)^2  (reference utils/losses.py:313-315)."""
+    """kind 0: mean_b (||grads[b]||_2 - 1)^2 (reference utils/losses.py:313-315, :332-334); 1: 0.5 mean_b ||grads[b]||^2 (R1,
+    :358-360); 2: max_b ||grads[b]||^2 (maxGP, :350-351)."""
 
     @staticmethod
-    def forward(ctx, grads):
+    def forward(ctx, grads, kind=0):
         grads = _c(grads.float())
         B = grads.shape[0]
         n = grads.numel() // B
-        norms = torch.empty(B, dtype=torch.float32, device=grads.device)
+        norms = torch.empty(B + 1, dtype=torch.float32, device=grads.device)
         loss = torch.empty(1, dtype=torch.float32, device=grads.device)
-        L.call("sg_gp_fwd", L.ptr(grads), B, n, L.ptr(norms), L.ptr(loss), L.stream())
+        L.call("sg_gp_fwd", kind, L.ptr(grads), B, n, L.ptr(norms), L.ptr(loss), L.stream())
         ctx.save_for_backward(grads, norms)
+        ctx.kind = kind
         return loss[0]
 
     @staticmethod
@@ -1046,8 +1048,8 @@ class GradPenaltyFn(torch.autograd.Function):
         B = grads.shape[0]
         g = _c(gout.float().reshape(1))
         d = torch.empty_like(grads)
-        L.call("sg_gp_bwd", L.ptr(grads), L.ptr(norms), L.ptr(g), L.ptr(d), B, grads.numel() // B, L.stream())
-        return d
+        L.call("sg_gp_bwd", ctx.kind, L.ptr(grads), L.ptr(norms), L.ptr(g), L.ptr(d), B, grads.numel() // B, L.stream())
+        return d, None
 
 
 def interpolate_rows(real, fake, alpha):

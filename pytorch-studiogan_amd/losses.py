@@ -53,6 +53,24 @@ def cal_grad_penalty(real_images, real_labels, fake_images, discriminator, devic
     return F.GradPenaltyFn.apply(grads)
 
 
+def cal_maxgrad_penalty(real_images, real_labels, fake_images, discriminator, device):
+    """max-gradient penalty of Lipschitz GANs, reference src/utils/losses.py:338-352: same interpolates and double backward as
+    cal_grad_penalty, penalty = max_b ||grad_b||^2."""
+    batch_size = real_images.shape[0]
+    alpha = torch.rand(batch_size, 1).to(real_images.device)
+    interpolates = F.interpolate_rows(real_images, fake_images.detach(), alpha).requires_grad_(True)
+    fake_dict = discriminator(interpolates, real_labels, eval=False)
+    grads = cal_deriv(inputs=interpolates, outputs=fake_dict["adv_output"], device=device)
+    return F.GradPenaltyFn.apply(grads, 2)
+
+
+def cal_r1_reg(adv_output, images, device):
+    """R1 regulariser, reference src/utils/losses.py:355-361: 0.5 * mean_b ||d sum(D(x)) / d x_b||^2 on the REAL batch; `images`
+    must have requires_grad=True before the discriminator forward that produced `adv_output` (src/worker.py:260-261)."""
+    grad_dout = cal_deriv(inputs=images, outputs=adv_output, device=device)
+    return F.GradPenaltyFn.apply(grad_dout, 1)
+
+
 def adjust_k(current_k, topk_gamma, inf_k):
     """reference src/utils/losses.py:364-366."""
     current_k = max(current_k * topk_gamma, inf_k)

@@ -65,8 +65,10 @@ def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
 class Worker:
     def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
-                 group=None, apply_gp=False, gp_lambda=10.0, apply_topk=False, topk_gamma=0.99, topk_nu=0.5):
+                 group=None, apply_gp=False, gp_lambda=10.0, apply_topk=False, topk_gamma=0.99, topk_nu=0.5,
+                 apply_r1_reg=False, r1_lambda=10.0, apply_maxgp=False, maxgp_lambda=1.0):
         self.Gen, self.Dis = Gen, Dis
+        self.apply_r1_reg, self.r1_lambda, self.apply_maxgp, self.maxgp_lambda = apply_r1_reg, r1_lambda, apply_maxgp, maxgp_lambda
         # top-k training of the generator (reference src/worker.py:117-121,565-566; k decays by topk_gamma per epoch down to nu * batch)
         self.apply_topk, self.topk_gamma, self.topk_nu = apply_topk, topk_gamma, topk_nu
         self.topk = batch_size
@@ -99,6 +101,8 @@ class Worker:
                 zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
                 k += 1
                 fake_images = self.Gen(zs, fake_labels)
+                if self.apply_r1_reg:    # src/worker.py:260-261
+                    real_images = real_images.detach().requires_grad_(True)
                 real_dict = self.Dis(real_images, real_labels)
                 fake_dict = self.Dis(fake_images, fake_labels)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
@@ -108,6 +112,13 @@ class Worker:
                                                          discriminator=self.Dis, device=self.device)
                     self.last_gp = gp_loss.detach()
                     dis_acml_loss = dis_acml_loss + self.gp_lambda * gp_loss
+                if self.apply_maxgp:     # src/worker.py:386-392
+                    mg = sg_losses.cal_maxgrad_penalty(real_images=real_images.detach(), real_labels=real_labels, fake_images=fake_images,
+                                                       discriminator=self.Dis, device=self.device)
+                    dis_acml_loss = dis_acml_loss + self.maxgp_lambda * mg
+                if self.apply_r1_reg:    # src/worker.py:410-412
+                    self.r1_penalty = sg_losses.cal_r1_reg(adv_output=real_dict["adv_output"], images=real_images, device=self.device)
+                    dis_acml_loss = dis_acml_loss + self.r1_lambda * self.r1_penalty
                 dis_acml_loss = dis_acml_loss / self.acml
                 dis_acml_loss.backward()
             self.d_optimizer.step(group=self.group)

@@ -186,6 +186,52 @@ def test_gradient_penalty_double_backward(sg, name, mixed):
     C.finish()
 
 
+@pytest.mark.parametrize("kind", ["r1", "maxgp"])
+@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "sngan32"])
+def test_r1_and_maxgp_double_backward(sg, name, kind):
+    """R1 (reference utils/losses.py:355-361, taken through the SAME real-batch forward that feeds the adversarial loss,
+    src/worker.py:260-261,410-412) and the max-gradient penalty (:338-352): value and gradient w.r.t. every discriminator
+    parameter against torch autograd's double backward over the CPU oracle (fp32)."""
+    from studiogan_amd import losses as SL
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 6)
+    _, D = build_from_yaml(y, False, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    real, lab = fix["in/real0"].clone(), fix["in/rl0"]
+    fake = fix["in/real1"].flip(0).clone() * 0.7
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    dis = O.model_fns(ocfg)[1]
+    for p in D.parameters():
+        p.grad = None
+    if kind == "r1":
+        r_o, adv_o = O.r1_reg(dis, real, lab, leaves, B)
+        (10.0 * r_o + torch.mean(torch.relu(1.0 - adv_o))).backward()        # hinge on the real half + lambda * R1, one backward
+        xr = real.to(dev).requires_grad_(True)
+        out = D(xr, lab.to(dev))
+        r = SL.cal_r1_reg(adv_output=out["adv_output"], images=xr, device=dev)
+        (10.0 * r + SL.d_hinge(out["adv_output"], torch.full_like(out["adv_output"].detach(), -5.0))).backward()   # fake half: relu(1 - 5) = 0
+    else:
+        alpha = MG.gp_alpha(meta["seed"], 0, real.shape[0])
+        r_o = O.maxgrad_penalty(dis, real, lab, fake, leaves, B, alpha)
+        r_o.backward()
+        torch.manual_seed(meta["seed"] + MG.GP_SEED)
+        r = SL.cal_maxgrad_penalty(real.to(dev), lab.to(dev), fake.to(dev), D, dev)
+        r.backward()
+    torch.cuda.synchronize()
+    C = Collector()
+    C.check(kind + " penalty", r, r_o, 5e-4)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, p in D.named_parameters():
+        go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        C.check(kind + " grad " + k, p.grad if p.grad is not None else torch.zeros_like(p), go, 1e-3, floor=1e-2 * gmax)
+    C.finish()
+
+
 @pytest.mark.parametrize("which", ["D", "G"])
 @pytest.mark.parametrize("name", NAMES)
 def test_bf16_vs_emulating_oracle(sg, name, which):
