@@ -174,7 +174,14 @@ template <> bool conv_fwd_sk_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
   if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   if (J < 16384 && !force) return false;
+  // output / mask / residual go through buffer descriptors too (32-bit offsets, bit 31 = "no access")
+  const bool pooled = (e.flags & SG_EPI_POOL) != 0;
+  const long long jout = pooled ? (J >> 2) : J;
+  const long long obytes = ((jout - 1) * e.ldo + I) * 2;
+  const long long sbytes = e.mask ? ((jout - 1) * e.ldm + I) * 2 : (e.res ? ((jout - 1) * e.ldr + I) * 2 : 16);
+  if (obytes >= (1ll << 31) || sbytes >= (1ll << 31)) return false;
   ConvSkParams p;
+  p.obytes = (unsigned)obytes; p.sbytes = (unsigned)sbytes;
   p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;
   p.C = d->C; p.ldx = d->ldx; p.Hs = d->Hs; p.Ws = d->Ws;
   p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = wshift; p.hshift = hshift;

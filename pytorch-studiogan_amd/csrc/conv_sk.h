@@ -27,11 +27,12 @@ struct ConvSkParams {
   int flags;                   // SG_PIX_RELU | SG_PIX_UPSAMPLE | SG_PIX_QUAD
   int I, J, K;
   unsigned xbytes;
+  unsigned obytes, sbytes;     // extents of the output tensor and of the mask / residual tensor (< 2^31: bit 31 of an offset = skip)
   int nrb;                     // row blocks of 32 * TJ pixels
 };
 
 // TI x 32 couts per accumulator pass, NP passes over the same pixel fragments (cout tile = TI * NP * 32)
-template <int TI, int NP, int TJ, int KS, int NW>
+template <int TI, int NP, int TJ, int KS, int NW, bool POOL>
 __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epilogue<bf16_t> epi) {
   constexpr int BI = TI * NP * 32;
   constexpr int NCH = 2 * KS;              // 16-byte k-chunks
@@ -58,6 +59,9 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
   __syncthreads();
 
   const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rso = __builtin_amdgcn_make_buffer_rsrc(epi.out, 0, (int)p.obytes, 0x00020000);
+  const auto rss = __builtin_amdgcn_make_buffer_rsrc((void*)(epi.mask ? (const void*)epi.mask : epi.res), 0, (int)p.sbytes, 0x00020000);
+  constexpr int NIT = ((POOL ? ROWS / 4 : ROWS) * CPR + 63) / 64;      // 16-byte pieces of a staged pass tile per lane
   const int frow = lane & 31, fhi = lane >> 5;
   const unsigned ldx2 = 2u * (unsigned)p.ldx;
   const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, quad = (p.flags & SG_PIX_QUAD) != 0;
@@ -100,19 +104,28 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
       const bool rok = row < p.J;
       const int hs = up ? (ho >> 1) : ho, ws = up ? (wo >> 1) : wo;
       const unsigned pixoff = ((unsigned)(n * p.Hs + hs) * (unsigned)p.Ws + (unsigned)ws) * ldx2;
+      if constexpr (KS == 6) {       // the only sub-step count the stem (K = 72) maps to: tap displacement + halo test per chunk
 #pragma unroll
-      for (int ks = 0; ks < KS; ks++) {
-        const bool ok = rok && cok[ks] && (unsigned)(ho + ctr[ks] - 1) < (unsigned)p.Ho && (unsigned)(wo + cts[ks] - 1) < (unsigned)p.Wo;
-        unsigned off = pixoff + cdelta[ks];
-        off = ok ? off : 0x80000000u;
-        q[b][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0));
+        for (int ks = 0; ks < KS; ks++) {
+          const bool ok = rok && cok[ks] && (unsigned)(ho + ctr[ks] - 1) < (unsigned)p.Ho && (unsigned)(wo + cts[ks] - 1) < (unsigned)p.Wo;
+          unsigned off = pixoff + cdelta[ks];
+          off = ok ? off : 0x80000000u;
+          q[b][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0));
+        }
+      } else {                       // 1x1 only: chunk c of the pixel's own row (the offsets fold into the instruction's immediate)
+        const unsigned base = rok ? pixoff + (unsigned)fhi * 16u : 0x80000000u;
+#pragma unroll
+        for (int ks = 0; ks < KS; ks++) {
+          const unsigned off = ((2 * ks + fhi) * 8 < p.C) ? base + (unsigned)ks * 32u : 0x80000000u;
+          q[b][ks] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rsx, (int)off, 0, 0));
+        }
       }
     }
   };
 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
-  const bool pool = (epi.flags & SG_EPI_POOL) != 0;
+  constexpr bool pool = POOL;
   const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
   const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;
   const int Jout = pool ? (epi.J >> 2) : epi.J;
@@ -133,7 +146,7 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
           q[b][ks][e] = __builtin_bit_cast(uint32_t, t);
         }
     const int r0 = rb * ROWS;
-    const int rows_out = pool ? rows_out_full / 4 : rows_out_full;
+    constexpr int rows_out = pool ? rows_out_full / 4 : rows_out_full;
     const int jbase = pool ? (r0 >> 2) : r0;
 #pragma unroll
     for (int ps = 0; ps < NP; ps++) {
@@ -164,15 +177,27 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
       const int ic0 = ps * TI * 32;                    // first cout of the pass inside the tile
       const int ncp = ncr - ps * CPR;                  // 16-byte chunks of this pass that exist (cout tail)
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // the previous staging reads are done (LDS is in order per wave)
+      // The tile copies below are straight-line code with a compile-time number of buffer instructions (lanes with nothing to do
+      // carry an out-of-range offset: loads return zeros, stores are dropped). vmcnt is one in-order counter for loads AND stores:
+      // only with an exact count can the wait in front of the next block's MFMAs leave this block's stores in flight (a
+      // data-dependent loop made it drain them -- a full HBM write round trip per 32-pixel row block).
       if (pre_mask || pre_res) {
-        const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
         const int ld = pre_mask ? epi.ldm : epi.ldr;
-        for (int idx = lane; idx < rows_out * CPR; idx += 64) {
+        u32x4 pre[NIT];
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {          // all loads first, one wait
+          const int idx = lane + 64 * it;
           const int r = idx / CPR, c = idx - r * CPR;
           const int jg = jbase + r;
-          u32x4 t = {0u, 0u, 0u, 0u};
-          if (jg < Jout && c < ncp) t = *(const u32x4*)(src + (long long)jg * ld + i0 + ic0 + c * 8);
-          *(u32x4*)(stg + r * CP + c * 16) = t;
+          const bool ok = idx < rows_out * CPR && jg < Jout && c < ncp;
+          const unsigned off = ok ? ((unsigned)jg * (unsigned)ld + (unsigned)(i0 + ic0 + c * 8)) * 2u : 0x80000000u;
+          pre[it] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rss, (int)off, 0, 0));
+        }
+#pragma unroll
+        for (int it = 0; it < NIT; it++) {
+          const int idx = lane + 64 * it;
+          const int r = idx / CPR, c = idx - r * CPR;
+          if (idx < rows_out * CPR) *(u32x4*)(stg + r * CP + c * 16) = pre[it];
         }
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       }
@@ -222,13 +247,16 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
           }
         }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      {
-        bf16_t* o = (bf16_t*)epi.out;
-        for (int idx = lane; idx < rows_out * CPR; idx += 64) {
-          const int r = idx / CPR, c = idx - r * CPR;
-          const int jg = jbase + r;
-          if (jg < Jout && c < ncp) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + ic0 + c * 8) = *(const u32x4*)(stg + r * CP + c * 16);
-        }
+#pragma unroll
+      for (int it = 0; it < NIT; it++) {
+        const int idx = lane + 64 * it;
+        const int r = idx / CPR, c = idx - r * CPR;
+        const int jg = jbase + r;
+        const bool ok = idx < rows_out * CPR && jg < Jout && c < ncp;
+        const unsigned off = ok ? ((unsigned)jg * (unsigned)epi.ldo + (unsigned)(i0 + ic0 + c * 8)) * 2u : 0x80000000u;
+        const int rr = idx < rows_out * CPR ? r : 0;          // (rows past the tile: any valid staging address; the store is dropped)
+        const u32x4 v = *(const u32x4*)(stg + rr * CP + c * 16);
+        __builtin_amdgcn_raw_buffer_store_b128(v, rso, (int)off, 0, 0);
       }
     }
   };
@@ -238,6 +266,14 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
   u32x4 qa[TJ][KS], qb[TJ][KS];
   if (rb >= p.nrb) return;
   fetch(rb, qa);
+  // as many (dropped: out-of-range) stores as one row block issues, so that the loop is entered with the same vmcnt history it has
+  // on its back edge -- otherwise the compiler's merged state assumes "no stores in flight" and the first wait of every other
+  // iteration drains them
+#pragma unroll
+  for (int it = 0; it < NP * NIT; it++) {
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    __builtin_amdgcn_raw_buffer_store_b128(z, rso, (int)(0x80000000u + 16u * it), 0, 0);     // (distinct offsets: identical stores get merged)
+  }
   while (true) {
     fetch(rb + stride, qb);
     compute_store(rb, qa);
@@ -250,8 +286,8 @@ __global__ __launch_bounds__(64 * NW) void sg_conv_sk_kernel(ConvSkParams p, Epi
   }
 }
 
-template <int TI, int NP, int TJ, int KS>
-static inline int sg_launch_conv_sk_t(ConvSkParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
+template <int TI, int NP, int TJ, int KS, bool POOL>
+static inline int sg_launch_conv_sk_tp(ConvSkParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BI = TI * NP * 32, WP = KS * 32 + 16, CP = TI * 64 + 16, ROWS = 32 * TJ;
   // 8 waves per CU (2 per SIMD: the register budget): two 4-wave workgroups when their LDS fits twice, else one 8-wave workgroup
   // sharing one copy of the weights
@@ -261,7 +297,7 @@ static inline int sg_launch_conv_sk_t(ConvSkParams p, const Epilogue<bf16_t>& e,
   static_assert(lds <= 160 * 1024, "LDS");
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_sk_kernel<TI, NP, TJ, KS, NW>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_sk_kernel<TI, NP, TJ, KS, NW, POOL>, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return -1;
     attr_done = true;
   }
   p.nrb = (p.J + ROWS - 1) / ROWS;
@@ -269,8 +305,12 @@ static inline int sg_launch_conv_sk_t(ConvSkParams p, const Epilogue<bf16_t>& e,
   int gx = (p.nrb + NW - 1) / NW;
   const int cap = (256 * (8 / NW) + tilesI - 1) / tilesI;
   if (gx > cap) gx = cap;
-  hipLaunchKernelGGL((sg_conv_sk_kernel<TI, NP, TJ, KS, NW>), dim3(gx, tilesI), dim3(64 * NW), lds, st, p, e);
+  hipLaunchKernelGGL((sg_conv_sk_kernel<TI, NP, TJ, KS, NW, POOL>), dim3(gx, tilesI), dim3(64 * NW), lds, st, p, e);
   return 0;
+}
+template <int TI, int NP, int TJ, int KS>
+static inline int sg_launch_conv_sk_t(const ConvSkParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  return (e.flags & SG_EPI_POOL) ? sg_launch_conv_sk_tp<TI, NP, TJ, KS, true>(p, e, st) : sg_launch_conv_sk_tp<TI, NP, TJ, KS, false>(p, e, st);
 }
 
 // cout tile 32 / 64 / 96 (one pass) or 128 / 192 (two passes of 64 / 96); KS in {1,3,6,12} (K <= 16/48/96/192); TJ = 2 (64-pixel
@@ -281,9 +321,9 @@ static inline int sg_launch_conv_sk(const ConvSkParams& p, const Epilogue<bf16_t
 #define SG_SK_CASE(T_, TI_, NP_, KS_, TJ_) if (ti == T_ && ks == KS_) return sg_launch_conv_sk_t<TI_, NP_, TJ_, KS_>(p, e, st);
   SG_SK_CASE(1, 1, 1, 1, 2) SG_SK_CASE(1, 1, 1, 3, 2) SG_SK_CASE(1, 1, 1, 6, 2) SG_SK_CASE(1, 1, 1, 12, 1)
   SG_SK_CASE(2, 2, 1, 1, 2) SG_SK_CASE(2, 2, 1, 3, 2) SG_SK_CASE(2, 2, 1, 6, 1) SG_SK_CASE(2, 2, 1, 12, 1)
-  SG_SK_CASE(3, 3, 1, 1, 2) SG_SK_CASE(3, 3, 1, 3, 1) SG_SK_CASE(3, 3, 1, 6, 1) SG_SK_CASE(3, 3, 1, 12, 1)
+  SG_SK_CASE(3, 3, 1, 1, 1) SG_SK_CASE(3, 3, 1, 3, 1) SG_SK_CASE(3, 3, 1, 6, 1) SG_SK_CASE(3, 3, 1, 12, 1)
   SG_SK_CASE(4, 2, 2, 1, 2) SG_SK_CASE(4, 2, 2, 3, 2) SG_SK_CASE(4, 2, 2, 6, 1) SG_SK_CASE(4, 2, 2, 12, 1)
-  SG_SK_CASE(6, 3, 2, 1, 2) SG_SK_CASE(6, 3, 2, 3, 1) SG_SK_CASE(6, 3, 2, 6, 1) SG_SK_CASE(6, 2, 3, 12, 1)
+  SG_SK_CASE(6, 3, 2, 1, 1) SG_SK_CASE(6, 3, 2, 3, 1) SG_SK_CASE(6, 3, 2, 6, 1) SG_SK_CASE(6, 2, 3, 12, 1)
 #undef SG_SK_CASE
   return -1;
 }
