@@ -251,7 +251,7 @@ static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
 }
 
 static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, int& BJ, int& splits, bool v2 = false) {
-  if (v2) { BI = 256; BJ = 128; bk = 64; }
+  if (v2) { BI = 256; BJ = sg_wgrad_v2_bj(I, J, K); bk = 64; }
   else if (I <= 32) { BI = 32; BJ = 256; }
   else if (J <= 32) { BI = 256; BJ = 32; }
   else if (J % 128 != 0 && (J % 96 == 0 || (J < 128 && J > 64))) { BI = 256; BJ = 96; }

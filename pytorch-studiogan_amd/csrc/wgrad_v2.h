@@ -47,7 +47,7 @@ __device__ __forceinline__ bf16x8_t sg_frag_tr_swz(const char* img, int col0, in
 // serialised copy and compute in this kernel. The asm form is invisible to that analysis; the data dependence on the read is
 // re-created by routing the registers through sg_lgkm_wait<N>() (an `s_waitcnt lgkmcnt(N)` that "modifies" them) before use.
 typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-struct WgFrags { u32x2 v[8]; };               // {pf0, pf1, qf0, qf1} x {pixels 0..3 | 4..7 of the lane's 8}
+template <int NF> struct WgFrags { u32x2 v[2 * NF]; };   // NF fragments (2 of P, TJ of Q) x {pixels 0..3 | 4..7 of the lane's 8}
 __device__ __forceinline__ void sg_frag_tr_issue(const char* img, int col0, int ks, u32x2& lo, u32x2& hi) {
   const int l = threadIdx.x & 63;
   const int g16 = l >> 4, t = l & 15;
@@ -58,9 +58,15 @@ __device__ __forceinline__ void sg_frag_tr_issue(const char* img, int col0, int 
   asm volatile("ds_read_b64_tr_b16 %0, %1" : "=&v"(lo) : "v"(a));
   asm volatile("ds_read_b64_tr_b16 %0, %1 offset:1024" : "=&v"(hi) : "v"(a));
 }
-template <int N> __device__ __forceinline__ void sg_lgkm_wait(WgFrags& f) {
+template <int N> __device__ __forceinline__ void sg_lgkm_wait(WgFrags<4>& f) {
   asm volatile("s_waitcnt lgkmcnt(%8)"
                : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]), "+v"(f.v[6]), "+v"(f.v[7])
+               : "n"(N));
+}
+template <int N> __device__ __forceinline__ void sg_lgkm_wait(WgFrags<6>& f) {
+  asm volatile("s_waitcnt lgkmcnt(%12)"
+               : "+v"(f.v[0]), "+v"(f.v[1]), "+v"(f.v[2]), "+v"(f.v[3]), "+v"(f.v[4]), "+v"(f.v[5]), "+v"(f.v[6]), "+v"(f.v[7]),
+                 "+v"(f.v[8]), "+v"(f.v[9]), "+v"(f.v[10]), "+v"(f.v[11])
                : "n"(N));
 }
 __device__ __forceinline__ bf16x8_t sg_frag_join(u32x2 lo, u32x2 hi) {
@@ -68,10 +74,14 @@ __device__ __forceinline__ bf16x8_t sg_frag_join(u32x2 lo, u32x2 hi) {
   return __builtin_bit_cast(bf16x8_t, r);
 }
 
-template <bool XRELU>
+// BJ = 128 (4 x 2 waves of 64 x 64) or 256 (64 x 128 per wave: 8 MFMAs per 12 transpose reads instead of 4 per 8, and a third
+// fewer DMA pieces per MFMA; for Cout % 256 == 0)
+template <bool XRELU, int BJ>
 __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   constexpr int IMG = 64 * 256;              // one [64][128] bf16 image
-  constexpr int BUF = 3 * IMG;               // P sub-image 0, P sub-image 1, Q
+  constexpr int NQI = BJ / 128;              // Q images (128 couts each)
+  constexpr int TJ = BJ / 2 / 32;            // 32-wide cout blocks per wave
+  constexpr int BUF = (2 + NQI) * IMG;       // P sub-image 0, P sub-image 1, Q image(s)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -84,7 +94,7 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   const int tI = bid % tilesI, tJ = bid / tilesI;
-  const int i0 = tI * 256, j0 = tJ * 128;
+  const int i0 = tI * 256, j0 = tJ * BJ;
   const int k_begin = blockIdx.y * p.klen;
   const int k_end = (k_begin + p.klen < p.K) ? (k_begin + p.klen) : p.K;
   if (epi.split_stride) epi.out = (float*)epi.out + (long long)blockIdx.y * epi.split_stride;
@@ -102,8 +112,9 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     pr[h] = tap / p.S - p.pad_h;
     ps[h] = tap % p.S - p.pad_w;
   }
-  const int qcol = j0 + 8 * lc;
-  const bool qv = qcol < p.J;
+  int qcol[NQI]; bool qv[NQI];
+#pragma unroll
+  for (int h = 0; h < NQI; h++) { qcol[h] = j0 + 128 * h + 8 * lc; qv[h] = qcol[h] < p.J; }
 
   auto issue = [&](int buf, int kt) {
     char* base = smem + buf * BUF;
@@ -128,18 +139,22 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
       }
       {
         const int hg = p.g_up ? (ho >> 1) : ho, wg = p.g_up ? (wo >> 1) : wo;
-        unsigned off = (((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg + (unsigned)qcol) * 2u;
-        off = (inb & qv) ? off : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + 2 * IMG + pg * 1024), 16, (int)off, 0, 0, 0);
+        const unsigned pixb = ((unsigned)(n * p.gHs + hg) * (unsigned)p.gWs + (unsigned)wg) * (unsigned)p.ldg;
+#pragma unroll
+        for (int h = 0; h < NQI; h++) {
+          unsigned off = (pixb + (unsigned)qcol[h]) * 2u;
+          off = (inb & qv[h]) ? off : 0x80000000u;
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + (2 + h) * IMG + pg * 1024), 16, (int)off, 0, 0, 0);
+        }
       }
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[2][TJ];
 #pragma unroll
   for (int a = 0; a < 2; a++)
 #pragma unroll
-    for (int b = 0; b < 2; b++)
+    for (int b = 0; b < TJ; b++)
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
@@ -151,22 +166,26 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
     const char* base = smem + (kt & 1) * BUF;
     const char* pimg = base + (wi >> 1) * IMG;
-    const char* qimg = base + 2 * IMG;
-    // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks; lgkmcnt(8) = "everything but those 8 reads"
-    WgFrags fr[2];
-    auto load = [&](int ks, WgFrags& f) {
+    const char* qbase = base + 2 * IMG;
+    // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks; lgkmcnt(NR) = "everything but those NR reads"
+    constexpr int NF = 2 + TJ, NR = 2 * NF;
+    WgFrags<NF> fr[2];
+    auto load = [&](int ks, WgFrags<NF>& f) {
       sg_frag_tr_issue(pimg, 64 * (wi & 1), ks, f.v[0], f.v[1]);
       sg_frag_tr_issue(pimg, 64 * (wi & 1) + 32, ks, f.v[2], f.v[3]);
-      sg_frag_tr_issue(qimg, 64 * wj, ks, f.v[4], f.v[5]);
-      sg_frag_tr_issue(qimg, 64 * wj + 32, ks, f.v[6], f.v[7]);
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        const int col = (BJ / 2) * wj + 32 * b;                       // cout inside the tile
+        sg_frag_tr_issue(qbase + (col >> 7) * IMG, col & 127, ks, f.v[4 + 2 * b], f.v[5 + 2 * b]);
+      }
     };
     load(0, fr[0]);
 #pragma unroll
     for (int ks = 0; ks < 4; ks++) {
-      if (ks < 3) { load(ks + 1, fr[(ks + 1) & 1]); sg_lgkm_wait<8>(fr[ks & 1]); }
+      if (ks < 3) { load(ks + 1, fr[(ks + 1) & 1]); sg_lgkm_wait<NR>(fr[ks & 1]); }
       else sg_lgkm_wait<0>(fr[ks & 1]);
-      WgFrags& f = fr[ks & 1];
-      bf16x8_t pf[2], qf[2];
+      WgFrags<NF>& f = fr[ks & 1];
+      bf16x8_t pf[2], qf[TJ];
 #pragma unroll
       for (int a = 0; a < 2; a++) {
         pf[a] = sg_frag_join(f.v[2 * a], f.v[2 * a + 1]);
@@ -177,11 +196,11 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
         }
       }
 #pragma unroll
-      for (int b = 0; b < 2; b++) qf[b] = sg_frag_join(f.v[4 + 2 * b], f.v[5 + 2 * b]);
+      for (int b = 0; b < TJ; b++) qf[b] = sg_frag_join(f.v[4 + 2 * b], f.v[5 + 2 * b]);
 #pragma unroll
       for (int a = 0; a < 2; a++)
 #pragma unroll
-        for (int b = 0; b < 2; b++)
+        for (int b = 0; b < TJ; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
     }
     __syncthreads();
@@ -192,8 +211,8 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
 #pragma unroll
   for (int ta = 0; ta < 2; ta++)
 #pragma unroll
-    for (int tb = 0; tb < 2; tb++) {
-      const int j = j0 + 64 * wj + tb * 32 + (lane & 31);
+    for (int tb = 0; tb < TJ; tb++) {
+      const int j = j0 + (BJ / 2) * wj + tb * 32 + (lane & 31);
 #pragma unroll
       for (int g4 = 0; g4 < 4; g4++) {
         const int ii = i0 + 64 * wi + ta * 32 + 8 * g4 + 4 * (lane >> 5);
@@ -203,18 +222,34 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     }
 }
 
-template <bool XRELU>
+template <bool XRELU, int BJ>
 static inline int sg_launch_wgrad_v2r(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
-  constexpr int LDS = 2 * 3 * 64 * 256;
+  constexpr int LDS = 2 * (2 + BJ / 128) * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel<XRELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel<XRELU, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     attr_done = true;
   }
-  const int tilesI = (p.I + 255) / 256, tilesJ = (p.J + 127) / 128;
-  hipLaunchKernelGGL(sg_wgrad_v2_kernel<XRELU>, dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
+  const int tilesI = (p.I + 255) / 256, tilesJ = (p.J + BJ - 1) / BJ;
+  hipLaunchKernelGGL((sg_wgrad_v2_kernel<XRELU, BJ>), dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
   return 0;
 }
+// cout tile of the plan (the launcher and wgrad_plan must agree): 256 when the couts fill it AND every workgroup still gets a long
+// k-loop. Measured (tools/conv_bench.py, MI355X): 1536 -> 1536 @8^2 +17 %, 768 -> 768 @16^2 +12 %, 1536 -> 768 @16^2 +7 % (85-205
+// k-tiles per workgroup), but 768 -> 1536 @8^2 -13 %, 1x1 -19 %, the 4x4 layers -8 % (11-52 k-tiles: the 256 KB partial tile and the
+// prologue are not amortised). SG_WGRAD_BJ256=0 / force: never / whenever Cout % 256 == 0.
+static inline int sg_wgrad_v2_bj(int I, int J, int K) {
+  const char* e = getenv("SG_WGRAD_BJ256");      // (read per call: the tests switch it)
+  const int mode = !e ? 1 : (e[0] == '0' ? 0 : (e[0] == 'f' ? 2 : 1));
+  if (!mode || J % 256) return 128;
+  if (mode == 2) return 256;
+  const int tiles = ((I + 255) / 256) * (J / 256);
+  int splits = (768 + tiles - 1) / tiles;
+  if (splits < 1) splits = 1;
+  return (K / splits / 64 >= 80) ? 256 : 128;
+}
 static inline int sg_launch_wgrad_v2(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
-  return p.x_relu ? sg_launch_wgrad_v2r<true>(p, e, splits, st) : sg_launch_wgrad_v2r<false>(p, e, splits, st);
+  if (sg_wgrad_v2_bj(p.I, p.J, p.K) == 256)
+    return p.x_relu ? sg_launch_wgrad_v2r<true, 256>(p, e, splits, st) : sg_launch_wgrad_v2r<false, 256>(p, e, splits, st);
+  return p.x_relu ? sg_launch_wgrad_v2r<true, 128>(p, e, splits, st) : sg_launch_wgrad_v2r<false, 128>(p, e, splits, st);
 }

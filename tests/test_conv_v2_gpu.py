@@ -216,6 +216,9 @@ WG_CASES = [
     (1, 128, 128, 16, 3, True, True, True),
     (2, 192, 384, 16, 1, False, False, False),
     (3, 72, 200, 8, 3, True, False, False),       # partial I tile (648 rows), partial J tile, k tail
+    (2, 64, 256, 16, 3, True, False, False),      # 256-wide cout tile (64 x 128 per wave), ReLU on load
+    (2, 192, 512, 8, 1, False, False, False),     # two 256-wide cout tiles, 1x1
+    (2, 96, 256, 16, 3, False, True, True),       # 256-wide tile with upsample-on-load and the pooled-gradient broadcast
 ]
 
 
@@ -237,6 +240,7 @@ def test_wgrad_v2_matches_reference_and_v1(sg, case):
     xf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
     gf = L.PIX_UPSAMPLE if pool else 0
     outs = {}
+    os.environ["SG_WGRAD_BJ256"] = "force"        # the 256-wide cout tile whenever Cout % 256 == 0 (test-sized problems are below its heuristic)
     for mode in ("force", "0"):
         os.environ["SG_CONV_V2"] = mode
         for splits in (0, 3):
@@ -246,4 +250,5 @@ def test_wgrad_v2_matches_reference_and_v1(sg, case):
             outs[(mode, splits)] = dw.cpu()
             check(f"wgrad {mode} splits={splits} {case}", dw.cpu().permute(0, 3, 1, 2), wr.grad, 2e-3)
     os.environ.pop("SG_CONV_V2", None)
+    os.environ.pop("SG_WGRAD_BJ256", None)
     check(f"wgrad v2 vs v1 {case}", outs[("force", 0)], outs[("0", 0)], 1e-4)
