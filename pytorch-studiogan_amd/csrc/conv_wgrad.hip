@@ -1,0 +1,145 @@
+// conv_wgrad.hip -- convolution weight gradient (sg_conv2d_wgrad, sg_conv2d_wgrad_plan): wgrad_v2.h for the hot bf16 shapes,
+// gemm_core.h's ConvPixMC x ConvPixMC contraction otherwise; deterministic two-stage split-K.
+// Replaces autograd's convolution_backward (weight part) on the StudioGAN hot path (reference src/utils/ops.py:165-173,195-204).
+#include "conv_common.h"
+#include "wgrad_v2.h"
+
+// tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)
+static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
+  const char* mode = getenv("SG_CONV_V2");
+  if (mode && mode[0] == '0') return false;
+  const bool force = mode && mode[0] == 'f';
+  if (d->dtype != SG_DTYPE_BF16 || d->stride != 1 || d->no_tr) return false;
+  if ((d->x_flags | d->g_flags) & SG_PIX_TRANSPOSED) return false;
+  if (ilog2_exact(d->Ho) < 0 || ilog2_exact(d->Wo) < 0) return false;
+  if (d->C % 8 || d->ldx % 8 || d->Cout % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return false;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  const int I = d->R * d->S * d->C;
+  // buffer-descriptor DMA: bit 31 of a byte offset must be out of range
+  if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return false;
+  if (!force && (I < 64 || d->Cout < 64 || K < 4096)) return false;   // narrow I (1x1 convs, the 8-channel RGB stem) wastes part of the
+                                                                       // 256-row tile but still beats the generic kernel 3-4x
+  return true;
+}
+
+static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, int& BJ, int& splits, bool v2 = false) {
+  if (v2) { BI = 256; BJ = sg_wgrad_v2_bj(I, J, K); bk = 64; }
+  else if (I <= 32) { BI = 32; BJ = 256; }
+  else if (J <= 32) { BI = 256; BJ = 32; }
+  else if (J % 128 != 0 && (J % 96 == 0 || (J < 128 && J > 64))) { BI = 256; BJ = 96; }
+  else { BI = 128; BJ = 128; }
+  const int tiles = ((I + BI - 1) / BI) * ((J + BJ - 1) / BJ);
+  splits = want_splits;
+  if (splits <= 0) {
+    splits = (768 + tiles - 1) / tiles;          // ~3 workgroups per CU
+    int maxs = K / (bk * 16); if (maxs < 1) maxs = 1;
+    if (splits > maxs) splits = maxs;
+    if (splits > 512) splits = 512;
+  }
+  if (splits > 1) {  // what sg_launch_gemm will really use after rounding klen up to a multiple of bk
+    int klen = (K + splits - 1) / splits; klen = ((klen + bk - 1) / bk) * bk;
+    splits = (K + klen - 1) / klen;
+  }
+}
+
+extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, long long* work_floats) {
+  SG_CHECK(d && splits && work_floats, "sg_conv2d_wgrad_plan: null");
+  const int I = d->R * d->S * d->C, J = d->Cout;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  int BI, BJ, sp;
+  wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp, wgrad_v2_ok(d));
+  *splits = sp;
+  *work_floats = sp > 1 ? (long long)sp * I * J : 0;
+  return 0;
+}
+
+// out[i] += sum_s partial[s][i]   (fixed summation order: deterministic weight gradients)
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* partial, float* out, int splits, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) {
+    float acc = 0.f;
+    for (int s = 0; s < splits; s++) acc += partial[(long long)s * n + i];
+    out[i] += acc;
+  }
+}
+
+template <typename T, bool TR, bool FAST>
+static void conv_wgrad_launch(const sg_conv_wgrad_desc* d, const Epilogue<T>& e, int I, int J, int K, int BI, int BJ, int splits, hipStream_t st) {
+  typedef ConvPixMC<T, FAST> LM;
+  LM lp;
+  fill_geom<T>(lp.g, d->x, d->N, d->xHs, d->xWs, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w,
+               d->x_flags & ~SG_PIX_QUAD);
+  lp.rows = I; lp.K = K;
+  LM lq;
+  fill_geom<T>(lq.g, d->dy, d->N, d->gHs, d->gWs, d->Cout, d->ldg, d->Ho, d->Wo, 1, 1, 1, 0, 0, d->g_flags & ~SG_PIX_QUAD);
+  lq.rows = J; lq.K = K;
+  if (BI == 32) sg_launch_gemm<T, LM, LM, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else if (BJ == 32) sg_launch_gemm<T, LM, LM, 256, 32, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else if (BJ == 96) sg_launch_gemm<T, LM, LM, 256, 96, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
+  else sg_launch_gemm<T, LM, LM, 128, 128, 2, 2, TR>(lp, lq, e, I, J, K, splits, 1, st);
+}
+
+template <typename T> static bool wgrad_v2_launch(const sg_conv_wgrad_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool wgrad_v2_launch<bf16_t>(const sg_conv_wgrad_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int splits, hipStream_t st) {
+  WgradV2Params p;
+  p.x = (const bf16_t*)d->x; p.dy = (const bf16_t*)d->dy;
+  p.xHs = d->xHs; p.xWs = d->xWs; p.C = d->C; p.ldx = d->ldx;
+  p.x_up = (d->x_flags & SG_PIX_UPSAMPLE) ? 1 : 0; p.x_relu = (d->x_flags & SG_PIX_RELU) ? 1 : 0;
+  p.Hin = d->xHs * (p.x_up ? 2 : 1); p.Win = d->xWs * (p.x_up ? 2 : 1);
+  p.gHs = d->gHs; p.gWs = d->gWs; p.Cout = d->Cout; p.ldg = d->ldg; p.g_up = (d->g_flags & SG_PIX_UPSAMPLE) ? 1 : 0;
+  p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
+  p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w;
+  p.I = I; p.J = J; p.K = K;
+  p.xbytes = (unsigned)((((long long)d->N * d->xHs * d->xWs - 1) * d->ldx + d->C) * 2);
+  p.gbytes = (unsigned)((((long long)d->N * d->gHs * d->gWs - 1) * d->ldg + d->Cout) * 2);
+  int klen = K;
+  if (splits > 1) { klen = (K + splits - 1) / splits; klen = ((klen + 63) / 64) * 64; splits = (K + klen - 1) / klen; }
+  p.klen = klen;
+  return sg_launch_wgrad_v2(p, e, splits, st) == 0;
+}
+
+template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc* d, hipStream_t st) {
+  const int I = d->R * d->S * d->C;
+  const int J = d->Cout;
+  const long long Kll = (long long)d->N * d->Ho * d->Wo;
+  SG_CHECK(Kll < (1ll << 31), "sg_conv2d_wgrad: too many pixels");
+  SG_CHECK((long long)d->N * d->xHs * d->xWs * d->ldx < (1ll << 31) && (long long)d->N * d->gHs * d->gWs * d->ldg < (1ll << 31),
+           "sg_conv2d_wgrad: tensor too large for 32-bit element offsets");
+  const int K = (int)Kll;
+  int BI, BJ, splits;
+  const bool v2 = wgrad_v2_ok(d);
+  wgrad_plan(I, J, K, ET<T>::BK, d->splits, BI, BJ, splits, v2);
+  const long long n = (long long)I * J;
+  const bool two_stage = splits > 1 && d->work && d->work_floats >= (long long)splits * n;
+  Epilogue<T> e;
+  e.out = d->dw; e.out_bstride = 0; e.ldo = I; e.bias = nullptr; e.res = nullptr; e.res_bstride = 0; e.ldr = 0; e.beta = 0.f;
+  e.mask = nullptr; e.mask_bstride = 0; e.ldm = 0; e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.split_stride = 0;
+  e.flags = SG_EPI_OUT_F32; e.I = I; e.J = J;
+  if (splits == 1) { e.res = d->dw; e.ldr = I; e.beta = 1.f; e.flags |= SG_EPI_RES_F32; }   // single writer: dw += tile, no atomics
+  else if (two_stage) { e.out = d->work; e.split_stride = n; }                                 // partial tiles, reduced below
+  else e.flags |= SG_EPI_ATOMIC;                                                               // no workspace: fp32 atomics
+  const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
+  const bool fast = (d->C % ET<T>::VEC == 0) && (d->ldx % ET<T>::VEC == 0) && aligned16(d->x) &&
+                    (d->Cout % ET<T>::VEC == 0) && (d->ldg % ET<T>::VEC == 0) && aligned16(d->dy);
+  if (v2 && wgrad_v2_launch<T>(d, e, I, J, K, splits, st)) {}
+  else if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
+  else conv_wgrad_launch<T, TR, false>(d, e, I, J, K, BI, BJ, splits, st);
+  if (two_stage) {
+    long long blocks = (n + 255) / 256; if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, splits, n);
+  }
+  sg_prof_end(st, prof);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int sg_conv2d_wgrad(const sg_conv_wgrad_desc* d, sg_stream_t stream) {
+  SG_CHECK(d && d->x && d->dy && d->dw, "sg_conv2d_wgrad: null pointer");
+  SG_CHECK(d->N > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0, "sg_conv2d_wgrad: bad shape");
+  if (d->dtype == SG_DTYPE_F32) return conv_wgrad_t<float, true>(d, (hipStream_t)stream);
+  if (d->dtype == SG_DTYPE_BF16) {
+    if (d->no_tr) return conv_wgrad_t<bf16_t, false>(d, (hipStream_t)stream);
+    return conv_wgrad_t<bf16_t, true>(d, (hipStream_t)stream);
+  }
+  sg_set_error("sg_conv2d_wgrad: bad dtype");
+  return -1;
+}
