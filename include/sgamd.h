@@ -254,6 +254,13 @@ int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long l
                 float eps, float wd, int step, float ema_decay, float grad_scale, sg_stream_t s);
 int sg_ema_lerp(const float* src, float* ema, long long n, float decay, sg_stream_t s);
 
+/* LeCam regulariser (reference src/utils/losses.py:262-265): loss = mean relu(real - ema_fake)^2 + mean relu(ema_real - fake)^2 and its
+ * gradient w.r.t. the two logit vectors */
+int sg_lecam(const float* real, const float* fake, int B, float ema_real, float ema_fake, float* loss, float* d_real, float* d_fake, sg_stream_t s);
+/* uint8 input path (reference src/data_util.py:92-94): [N][H][W][3] uint8 (+ optional per-image horizontal-flip flags) ->
+ * T [N][H][W][cpad] = (x/255 - 0.5)/0.5, zero-filled channels */
+int sg_u8_to_nhwc(int dtype, const uint8_t* x, const uint8_t* flip, void* y, int N, int H, int W, int cpad, sg_stream_t s);
+
 /* ---- evaluation path -------------------------------------------------------------------------------------- */
 /* fp32 NCHW [-1,1] -> uint8 quantise (trunc((x+1)/2*255+0.5), clamp) -> bilinear (align_corners=False) resize to
  * OHxOW -> clip(0,255) -> (x/255-0.5)/0.5 -> T NHWC.  quant_out (optional) receives the uint8 NCHW image. */

@@ -582,6 +582,30 @@ def maxgrad_penalty(dis_fn, real, real_labels, fake, P, B, alpha):
     return torch.max(g.norm(2, dim=1) ** 2) + x[:, 0, 0, 0].mean() * 0
 
 
+def dra_penalty(dis_fn, real, real_labels, P, B, alpha, noise):
+    """utils/losses.py:319-335 with the host draws given (alpha = torch.rand(B,1,1,1), noise = torch.rand(real.size()), :321,325):
+    the gradient-penalty functional at real + alpha * 0.5 * real.std() * noise."""
+    x = (real + alpha * (0.5 * real.std() * noise)).detach().requires_grad_(True)
+    adv, _ = dis_fn(x, real_labels, P, B)
+    g = torch.autograd.grad(outputs=adv, inputs=x, grad_outputs=torch.ones_like(adv), create_graph=True, retain_graph=True, only_inputs=True)[0]
+    g = g.view(g.size(0), -1)
+    return ((g.norm(2, dim=1) - 1) ** 2).mean() + x[:, 0, 0, 0].mean() * 0
+
+
+def lecam_reg(d_logit_real, d_logit_fake, ema_d_real, ema_d_fake):
+    """utils/losses.py:262-265 (ema.D_real / ema.D_fake: utils/ops.py:106-133)."""
+    return torch.mean(F.relu(d_logit_real - ema_d_fake).pow(2)) + torch.mean(F.relu(ema_d_real - d_logit_fake).pow(2))
+
+
+def uint8_to_normalized(x_u8_nhwc, flip=None):
+    """data_util.py:92-94,141: ToTensor (HWC uint8 -> CHW float / 255) + Normalize(0.5, 0.5) (+ horizontal flip) -> fp32 NCHW."""
+    x = x_u8_nhwc.permute(0, 3, 1, 2).to(torch.float32).div(255.0)
+    x = (x - 0.5) / 0.5
+    if flip is not None:
+        x = torch.where(flip.view(-1, 1, 1, 1).bool(), x.flip(3), x)
+    return x
+
+
 def r1_reg(dis_fn, real, real_labels, P, B):
     """utils/losses.py:355-361 on the real batch (src/worker.py:260-261,410-412): 0.5 mean_b ||d sum(D(x)) / d x_b||^2.
     Returns (penalty, adv) -- the reference takes the gradient through the SAME forward that feeds the adversarial loss."""

@@ -130,6 +130,8 @@ _PROTOS = {
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_topk_hits": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
     "sg_topk_select": [_vp, _i, _i, _vp, _vp, _vp],
+    "sg_lecam": [_vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
+    "sg_u8_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_topk_scatter": [_vp, _vp, _i, _vp, _i, _vp],
 }
 

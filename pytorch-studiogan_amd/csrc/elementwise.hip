@@ -651,3 +651,53 @@ extern "C" int sg_copy_channels(int dtype, const void* src, int ld_src, void* ds
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- LeCam regulariser (reference src/utils/losses.py:262-265; anchors = LeCamEMA.D_fake / D_real, src/utils/ops.py:106-133) ------
+// loss = mean relu(real - ema_fake)^2 + mean relu(ema_real - fake)^2, with its gradient w.r.t. the logits
+__global__ __launch_bounds__(256) void k_lecam(const float* real, const float* fake, int B, float ema_real, float ema_fake, float* loss,
+                                               float* d_real, float* d_fake) {
+  __shared__ float sm[4];
+  float acc = 0.f;
+  const float inv = 1.f / (float)B;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const float a = fmaxf(real[b] - ema_fake, 0.f), c = fmaxf(ema_real - fake[b], 0.f);
+    acc += a * a + c * c;
+    d_real[b] = 2.f * a * inv;
+    d_fake[b] = -2.f * c * inv;
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss[0] = acc * inv;
+}
+extern "C" int sg_lecam(const float* real, const float* fake, int B, float ema_real, float ema_fake, float* loss, float* d_real, float* d_fake,
+                        sg_stream_t s) {
+  SG_CHECK(real && fake && loss && d_real && d_fake && B > 0, "sg_lecam: bad args");
+  hipLaunchKernelGGL(k_lecam, dim3(1), dim3(256), 0, (hipStream_t)s, real, fake, B, ema_real, ema_fake, loss, d_real, d_fake);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- uint8 input path (reference src/data_util.py:92-94,141: ToTensor + Normalize(0.5, 0.5) of the HDF5 / in-memory uint8 images,
+// optional horizontal flip): [N][H][W][3] uint8 -> T [N][H][W][cpad] = (x / 255 - 0.5) / 0.5, zero-filled channels, the layout the
+// discriminator's stem reads. Same fp32 operations as the host transform, so the result equals converting its fp32 output.
+template <typename T> __global__ void k_u8_to_nhwc(const uint8_t* x, const uint8_t* flip, T* y, int H, int W, int cpad, long long npix) {
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < npix; i += (long long)gridDim.x * blockDim.x) {
+    const int w = (int)(i % W);
+    const long long nh = i / W;
+    const long long n = nh / H;
+    const int ws = (flip && flip[n]) ? (W - 1 - w) : w;
+    const uint8_t* p = x + (nh * W + ws) * 3;
+    T* o = y + i * cpad;
+    for (int c = 0; c < cpad; c++) {
+      float v = 0.f;
+      if (c < 3) v = __fdiv_rn(__fsub_rn(__fdiv_rn((float)p[c], 255.f), 0.5f), 0.5f);
+      o[c] = from_f<T>(v);
+    }
+  }
+}
+extern "C" int sg_u8_to_nhwc(int dtype, const uint8_t* x, const uint8_t* flip, void* y, int N, int H, int W, int cpad, sg_stream_t s) {
+  SG_CHECK(x && y && N > 0 && H > 0 && W > 0 && cpad >= 3, "sg_u8_to_nhwc: bad args");
+  const long long npix = (long long)N * H * W;
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_u8_to_nhwc<T>, dim3(nblk(npix, 256)), dim3(256), 0, (hipStream_t)s, x, flip, (T*)y, H, W, cpad, npix));
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1061,6 +1061,37 @@ def interpolate_rows(real, fake, alpha):
     return out
 
 
+class LeCamFn(torch.autograd.Function):
+    """mean relu(real - ema_fake)^2 + mean relu(ema_real - fake)^2 (reference src/utils/losses.py:262-265)."""
+
+    @staticmethod
+    def forward(ctx, real, fake, ema_real, ema_fake):
+        real, fake = _c(real.float().reshape(-1)), _c(fake.float().reshape(-1))
+        B = real.numel()
+        loss = torch.empty(1, dtype=torch.float32, device=real.device)
+        dr, df = torch.empty_like(real), torch.empty_like(fake)
+        L.call("sg_lecam", L.ptr(real), L.ptr(fake), B, float(ema_real), float(ema_fake), L.ptr(loss), L.ptr(dr), L.ptr(df), L.stream())
+        ctx.save_for_backward(dr, df)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        dr, df = ctx.saved_tensors
+        return dr * g, df * g, None, None
+
+
+def u8_to_nhwc(x, dtype, cpad=8, flip=None):
+    """uint8 [N,H,W,3] (HDF5 / in-memory dataset layout, reference src/data_util.py:102-142) -> normalised NHWC tensor of the compute
+    dtype with `cpad` channels: ToTensor + Normalize(0.5, 0.5) (+ per-image horizontal flip) in one kernel, no fp32 NCHW image."""
+    x = _c(x)
+    assert x.dtype == torch.uint8 and x.dim() == 4 and x.shape[3] == 3, "expected uint8 [N,H,W,3]"
+    N, H, W, _ = x.shape
+    y = torch.empty((N, H, W, cpad), dtype=dtype, device=x.device)
+    fl = None if flip is None else _c(flip.to(torch.uint8))
+    L.call("sg_u8_to_nhwc", L.dt(y), L.ptr(x), L.ptr(fl), L.ptr(y), N, H, W, cpad, L.stream())
+    return y
+
+
 class TopkFn(torch.autograd.Function):
     """torch.topk(logits, k).values on a [B] vector (reference src/worker.py:565-566); backward scatters to the selected logits."""
 

@@ -4,6 +4,7 @@ import torch
 from torch import autograd
 
 from . import functional as F
+from . import _lib as L
 
 
 def d_hinge(d_logit_real, d_logit_fake, DDP=False):
@@ -62,6 +63,33 @@ def cal_maxgrad_penalty(real_images, real_labels, fake_images, discriminator, de
     fake_dict = discriminator(interpolates, real_labels, eval=False)
     grads = cal_deriv(inputs=interpolates, outputs=fake_dict["adv_output"], device=device)
     return F.GradPenaltyFn.apply(grads, 2)
+
+
+def cal_dra_penalty(real_images, real_labels, discriminator, device):
+    """DRAGAN penalty, reference src/utils/losses.py:319-335: the WGAN-GP functional at real + alpha * 0.5 * std(real) * U(0,1)
+    (alpha and U drawn on the host RNG like the reference: identical seeds give identical perturbations)."""
+    batch_size = real_images.shape[0]
+    alpha = torch.rand(batch_size, 1, 1, 1)
+    noise = torch.rand(real_images.size())
+    real = real_images.detach().float().contiguous()
+    n = real.numel()
+    stats = torch.zeros(2, dtype=torch.float32, device=real.device)
+    ones = torch.ones_like(real)
+    L.call("sg_dot", L.dt(real), L.ptr(real), L.ptr(real), n, L.ptr(stats), 1.0, None, L.stream())
+    L.call("sg_dot", L.dt(real), L.ptr(real), L.ptr(ones), n, L.ptr(stats) + 4, 1.0, None, L.stream())
+    sq, sm = (float(v) for v in stats.cpu())
+    std = max((sq - sm * sm / n) / (n - 1), 0.0) ** 0.5          # torch.Tensor.std(): unbiased, over all elements
+    interpolates = (alpha * noise).to(real.device).contiguous()
+    L.call("sg_axpby", L.dt(real), L.ptr(real), L.ptr(interpolates), n, 1.0, 0.5 * std, L.stream())   # y = 1 * real + (0.5 std) * y
+    interpolates.requires_grad_(True)
+    fake_dict = discriminator(interpolates, real_labels, eval=False)
+    grads = cal_deriv(inputs=interpolates, outputs=fake_dict["adv_output"], device=device)
+    return F.GradPenaltyFn.apply(grads, 0)
+
+
+def lecam_reg(d_logit_real, d_logit_fake, ema):
+    """reference src/utils/losses.py:262-265 (ema: ops.LeCamEMA)."""
+    return F.LeCamFn.apply(d_logit_real, d_logit_fake, float(ema.D_real), float(ema.D_fake))
 
 
 def cal_r1_reg(adv_output, images, device):

@@ -24,6 +24,8 @@ def to_nhwc(x, dtype, cpad=0):
     """logical NCHW tensor -> internal NHWC tensor of the compute dtype (cpad: zero-pad the channels, see NchwToNhwcFn)."""
     if x.dim() != 4:
         raise RuntimeError("expected a 4-D NCHW tensor")
+    if x.dtype == torch.uint8:      # the dataset's own format: uint8 [N,H,W,3] (reference src/data_util.py:102-142), normalised on the device
+        return F.u8_to_nhwc(x, dtype, max(cpad, 3))
     if cpad > x.shape[1]:
         return F.NchwToNhwcFn.apply(x.float(), dtype, cpad)
     if x.dtype == dtype and x.is_contiguous(memory_format=torch.channels_last) and not (x.shape[1] > 1 and x.is_contiguous() and x.shape[2] * x.shape[3] > 1):
@@ -257,6 +259,25 @@ class SelfAttention(nn.Module):
     def forward(self, x):
         _, bank = _root_and_bank(self.conv1x1_theta)
         return to_nchw(self.forward_nhwc(to_nhwc(x, bank.dtype)))
+
+
+class LeCamEMA(object):
+    """reference src/utils/ops.py:106-133 (host-side scalar EMAs of the discriminator's mean logits / losses)."""
+
+    def __init__(self, init=7777, decay=0.9, start_iter=0):
+        self.G_loss = init
+        self.D_loss_real = init
+        self.D_loss_fake = init
+        self.D_real = init
+        self.D_fake = init
+        self.decay = decay
+        self.start_itr = start_iter
+
+    def update(self, cur, mode, itr):
+        decay = 0.0 if itr < self.start_itr else self.decay
+        if mode not in ("G_loss", "D_loss_real", "D_loss_fake", "D_real", "D_fake"):
+            raise ValueError(mode)
+        setattr(self, mode, getattr(self, mode) * decay + cur * (1 - decay))
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -66,8 +66,12 @@ class Worker:
     def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
                  group=None, apply_gp=False, gp_lambda=10.0, apply_topk=False, topk_gamma=0.99, topk_nu=0.5,
-                 apply_r1_reg=False, r1_lambda=10.0, apply_maxgp=False, maxgp_lambda=1.0):
+                 apply_r1_reg=False, r1_lambda=10.0, apply_maxgp=False, maxgp_lambda=1.0, apply_dra=False, dra_lambda=10.0,
+                 apply_lecam=False, lecam_lambda=0.3, lecam_ema_start_iter=1000, lecam_ema_decay=0.99):
         self.Gen, self.Dis = Gen, Dis
+        self.apply_dra, self.dra_lambda = apply_dra, dra_lambda
+        self.apply_lecam, self.lecam_lambda, self.lecam_ema_start_iter = apply_lecam, lecam_lambda, lecam_ema_start_iter
+        self.lecam_ema = ops.LeCamEMA(decay=lecam_ema_decay, start_iter=lecam_ema_start_iter) if apply_lecam else None   # src/worker.py:139-140
         self.apply_r1_reg, self.r1_lambda, self.apply_maxgp, self.maxgp_lambda = apply_r1_reg, r1_lambda, apply_maxgp, maxgp_lambda
         # top-k training of the generator (reference src/worker.py:117-121,565-566; k decays by topk_gamma per epoch down to nu * batch)
         self.apply_topk, self.topk_gamma, self.topk_nu = apply_topk, topk_gamma, topk_nu
@@ -112,6 +116,14 @@ class Worker:
                                                          discriminator=self.Dis, device=self.device)
                     self.last_gp = gp_loss.detach()
                     dis_acml_loss = dis_acml_loss + self.gp_lambda * gp_loss
+                if self.apply_dra:       # src/worker.py:378-383
+                    dra = sg_losses.cal_dra_penalty(real_images=real_images.detach(), real_labels=real_labels, discriminator=self.Dis, device=self.device)
+                    dis_acml_loss = dis_acml_loss + self.dra_lambda * dra
+                if self.apply_lecam:     # src/worker.py:395-407 (single process: no gather)
+                    self.lecam_ema.update(float(real_dict["adv_output"].detach().mean()), "D_real", current_step)
+                    self.lecam_ema.update(float(fake_dict["adv_output"].detach().mean()), "D_fake", current_step)
+                    if current_step > self.lecam_ema_start_iter:
+                        dis_acml_loss = dis_acml_loss + self.lecam_lambda * sg_losses.lecam_reg(real_dict["adv_output"], fake_dict["adv_output"], self.lecam_ema)
                 if self.apply_maxgp:     # src/worker.py:386-392
                     mg = sg_losses.cal_maxgrad_penalty(real_images=real_images.detach(), real_labels=real_labels, fake_images=fake_images,
                                                        discriminator=self.Dis, device=self.device)

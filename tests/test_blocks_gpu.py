@@ -232,6 +232,72 @@ def test_r1_and_maxgp_double_backward(sg, name, kind):
     C.finish()
 
 
+def test_dra_penalty_lecam_and_uint8_input(sg):
+    """DRAGAN penalty (reference utils/losses.py:319-335), LeCam regulariser (:262-265 + utils/ops.py:106-133) and
+    the uint8 dataset format as discriminator input (data_util.py:92-94,102-142), against the CPU oracle."""
+    from studiogan_amd import losses as SL, ops, functional as F
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("sngp32")
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 8)
+    _, D = build_from_yaml(y, False, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    real, lab = fix["in/real0"].clone(), fix["in/rl0"]
+    dis = O.model_fns(ocfg)[1]
+    C = Collector()
+    # -- DRA: same host draws on both sides (torch.rand(B,1,1,1) then torch.rand(real.size()), losses.py:321,325)
+    torch.manual_seed(77)
+    alpha, noise = torch.rand(real.shape[0], 1, 1, 1), torch.rand(real.size())
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    d_o = O.dra_penalty(dis, real, lab, leaves, B, alpha, noise)
+    d_o.backward()
+    for p in D.parameters():
+        p.grad = None
+    torch.manual_seed(77)
+    d = SL.cal_dra_penalty(real.to(dev), lab.to(dev), D, dev)
+    d.backward()
+    torch.cuda.synchronize()
+    C.check("dra penalty", d, d_o, 5e-4)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, p in D.named_parameters():
+        go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        C.check("dra grad " + k, p.grad if p.grad is not None else torch.zeros_like(p), go, 1e-3, floor=1e-2 * gmax)
+    # -- LeCam: value and gradient w.r.t. the logits; the EMA class follows the reference's update rule
+    g = torch.Generator().manual_seed(3)
+    lr_, lf_ = torch.randn(37, generator=g), torch.randn(37, generator=g)
+    ema = ops.LeCamEMA(init=0.0, decay=0.9, start_iter=2)
+    ema.update(0.5, "D_real", 0); ema.update(-0.25, "D_fake", 0)          # itr < start_iter: decay 0 -> takes the value
+    ema.update(1.0, "D_real", 5); ema.update(0.0, "D_fake", 5)
+    assert abs(ema.D_real - (0.5 * 0.9 + 0.1)) < 1e-12 and abs(ema.D_fake - (-0.25 * 0.9)) < 1e-12
+    ro, fo = lr_.clone().requires_grad_(True), lf_.clone().requires_grad_(True)
+    l_o = O.lecam_reg(ro, fo, ema.D_real, ema.D_fake)
+    l_o.backward()
+    rd, fd = lr_.to(dev).requires_grad_(True), lf_.to(dev).requires_grad_(True)
+    l = SL.lecam_reg(rd, fd, ema)
+    l.backward()
+    C.check("lecam", l, l_o, 1e-6)
+    C.check("lecam d_real", rd.grad, ro.grad, 1e-6)
+    C.check("lecam d_fake", fd.grad, fo.grad, 1e-6)
+    # -- uint8 input: bit-identical to converting the host-normalised fp32 image, with and without flips; D accepts it directly
+    xu = torch.randint(0, 256, (4, 32, 32, 3), generator=g, dtype=torch.uint8)
+    flip = torch.tensor([1, 0, 0, 1], dtype=torch.uint8)
+    for fl in (None, flip):
+        xn = O.uint8_to_normalized(xu, fl)
+        for dt in (torch.float32, torch.bfloat16):
+            a = F.u8_to_nhwc(xu.to(dev), dt, 8, None if fl is None else fl.to(dev))
+            b = ops.to_nhwc(xn.to(dev), dt, 8)
+            assert torch.equal(a.cpu(), b.cpu()), f"uint8 input path must be bit-exact ({dt}, flip={fl is not None})"
+    D.eval()      # no power iteration between the two forwards
+    with torch.no_grad():
+        o1 = D(xu.to(dev), lab.to(dev))["adv_output"]
+        o2 = D(O.uint8_to_normalized(xu).to(dev), lab.to(dev))["adv_output"]
+    C.check("D(uint8) == D(normalised fp32)", o1, o2, 1e-6)
+    C.finish()
+
+
 @pytest.mark.parametrize("which", ["D", "G"])
 @pytest.mark.parametrize("name", NAMES)
 def test_bf16_vs_emulating_oracle(sg, name, which):
