@@ -262,12 +262,11 @@ def main():
     if args.fid_samples > 0 and args.workload == "biggan128":
         from studiogan_amd import metrics as M
         from studiogan_amd.worker import make_GAN_untrainable
-        from oracle.inception import random_state_dict     # seeded random Inception weights (the real ones need network access)
         make_GAN_untrainable(G, w.Gen_ema, D)
         per_rank = (args.fid_samples + world - 1) // world
         fid = {}
         for name, idt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-            model = M.LoadEvalModel(device=device, state_dict=random_state_dict(0), dtype=idt)
+            model = M.LoadEvalModel(device=device, state_dict=M.synthetic_state_dict(0), dtype=idt)   # seeded random Inception weights (the real ones need network access)
             M.generate_images_and_stack_features(w.Gen_ema, model, 2 * args.batch, args.batch, wl["z_dim"], wl["classes"], device=device)  # warm-up
             barrier()
             mom = M.FeatureMoments(2048, device)

@@ -56,6 +56,25 @@ def _spec():
 SPEC = _spec()
 
 
+def synthetic_state_dict(seed=0):
+    """Seeded random weights under torchvision's inception_v3 state_dict names (94 BasicConv2d + fc), for throughput measurements
+    when the pretrained FID weights (reference src/metrics/inception_net.py:13,130, downloaded at run time) are not available.
+    Same values as the test oracle's generator for the same seed (same draw order), without importing it."""
+    g = torch.Generator().manual_seed(seed)
+    sd = {}
+    for name, (_, cin, cout, kh, kw, _, _, _) in SPEC.items():
+        fan = cin * kh * kw
+        sd[name + ".conv.weight"] = torch.randn(cout, cin, kh, kw, generator=g) * math.sqrt(2.0 / fan)
+        sd[name + ".bn.weight"] = 1.0 + 0.1 * torch.randn(cout, generator=g)
+        sd[name + ".bn.bias"] = 0.1 * torch.randn(cout, generator=g)
+        sd[name + ".bn.running_mean"] = 0.1 * torch.randn(cout, generator=g)
+        sd[name + ".bn.running_var"] = 0.5 + torch.rand(cout, generator=g)
+        sd[name + ".bn.num_batches_tracked"] = torch.tensor(0)
+    sd["fc.weight"] = torch.randn(1008, 2048, generator=g) * math.sqrt(1.0 / 2048)
+    sd["fc.bias"] = 0.01 * torch.randn(1008, generator=g)
+    return sd
+
+
 class InceptionV3:
     """FID InceptionV3 (torchvision structure + the reference's FID patches, src/metrics/inception_net.py:135-249),
     inference only, BN folded into the convolutions at load time. `state_dict` uses torchvision's key names, i.e. the

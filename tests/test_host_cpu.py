@@ -103,3 +103,30 @@ def test_golden_state_dict_keys_match_backbone(name):
     D.load_state_dict(sub(fix, "D_init/"), strict=True)
     with pytest.raises(RuntimeError):
         G(torch.randn(2, G.z_dim), torch.zeros(2, dtype=torch.long))  # CPU tensors: no fallback on the product path
+
+
+def test_synthetic_inception_weights_match_oracle_generator():
+    """bench.py's FID leg takes its seeded random Inception weights from the product package (the oracle is test infrastructure and is
+    not imported by anything that is measured); both generators must produce the same tensors for the same seed."""
+    from studiogan_amd import metrics as M
+    from oracle import inception as OI
+    a, b = M.synthetic_state_dict(3), OI.random_state_dict(3)
+    assert list(a.keys()) == list(b.keys())
+    assert all(torch.equal(a[k], b[k]) for k in a)
+
+
+def test_loss_schedule_helpers():
+    """reference src/utils/losses.py:364-366 (adjust_k) and src/utils/ops.py:106-133 (LeCamEMA)."""
+    from studiogan_amd import losses as SL, ops
+    k = 64
+    for _ in range(500):
+        k = SL.adjust_k(current_k=k, topk_gamma=0.99, inf_k=int(64 * 0.5))
+    assert k == 32
+    e = ops.LeCamEMA(decay=0.9, start_iter=10)
+    assert e.D_real == 7777
+    e.update(2.0, "D_real", 3)            # before start_iter: decay 0
+    assert e.D_real == 2.0
+    e.update(4.0, "D_real", 10)
+    assert abs(e.D_real - (2.0 * 0.9 + 4.0 * 0.1)) < 1e-12
+    with pytest.raises(ValueError):
+        e.update(1.0, "nope", 0)
