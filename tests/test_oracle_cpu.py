@@ -103,3 +103,48 @@ def test_inception_oracle_structure_and_kats():
     imgs = torch.tensor([[[[-1.0, 1.0], [0.0, 0.00392]]]]).repeat(1, 3, 1, 1)
     _, q = OI.quantize_resize_normalize(imgs, size=4)
     assert q[0, 0].tolist() == [[0, 255], [128, 128]]                         # uint8 truncation of (x+1)/2*255+0.5
+
+
+def test_regulariser_restatements_match_reference_fixture():
+    """tests/golden/regularisers.npz holds the outputs of the REAL reference functions (utils/losses.py cal_maxgrad_penalty,
+    cal_dra_penalty, cal_r1_reg, lecam_reg, adjust_k; utils/ops.py LeCamEMA; the ToTensor + Normalize input transform) on a seeded SN +
+    projection discriminator -- produced by oracle/make_golden_regularisers.py, which also asserts bit-identity at generation time.
+    Here the restatements (the checker of the GPU tests) are re-run on the stored inputs."""
+    fix, meta = load_golden("regularisers")
+    ocfg = MG.oracle_cfg(meta["yaml"])
+    dis_fn = O.model_fns(ocfg)[1]
+    DP, DB = sub(fix, "D_P/"), sub(fix, "D_B/")
+    real, fake, lab = fix["in/real"], fix["in/fake"], fix["in/lab"]
+
+    def run(name, fn):
+        leaves = {k: v.clone().requires_grad_(True) for k, v in DP.items()}
+        out = fn(leaves, {k: v.clone() for k, v in DB.items()})
+        gs = torch.autograd.grad(out, list(leaves.values()), allow_unused=True)
+        check(name, out.detach(), fix["exp/" + name], 1e-6)
+        gmax = max(float(fix[f"exp/{name}_grad/" + k].abs().max()) for k in leaves)
+        for k, g in zip(leaves, gs):
+            ref = fix[f"exp/{name}_grad/" + k]
+            g = torch.zeros_like(ref) if g is None else g
+            assert float((g - ref).abs().max()) <= 1e-5 * gmax, f"{name} grad {k}"
+
+    run("maxgp", lambda P, B: O.maxgrad_penalty(dis_fn, real, lab, fake, P, B, fix["in/maxgp_alpha"]))
+    run("dra", lambda P, B: O.dra_penalty(dis_fn, real, lab, P, B, fix["in/dra_alpha"], fix["in/dra_noise"]))
+    run("r1", lambda P, B: O.r1_reg(dis_fn, real, lab, P, B)[0])
+    # LeCam with the EMA values the reference's LeCamEMA reached after the recorded update sequence; the product-side EMA class too
+    from studiogan_amd import ops, losses as SL
+    ema = ops.LeCamEMA(decay=0.9, start_iter=2)
+    for cur, mode, itr in meta["lecam_updates"]:
+        ema.update(cur, mode, itr)
+    assert [ema.D_real, ema.D_fake] == [float(v) for v in fix["exp/lecam_ema"]]
+    a, b = fix["in/lecam_real"].clone().requires_grad_(True), fix["in/lecam_fake"].clone().requires_grad_(True)
+    lo = O.lecam_reg(a, b, ema.D_real, ema.D_fake)
+    lo.backward()
+    assert torch.equal(lo.detach(), fix["exp/lecam"]) and torch.equal(a.grad, fix["exp/lecam_dreal"]) and torch.equal(b.grad, fix["exp/lecam_dfake"])
+    # top-k schedule and the uint8 input transform
+    k, ks = 64, []
+    for _ in range(100):
+        k = SL.adjust_k(current_k=k, topk_gamma=0.99, inf_k=int(64 * 0.5))
+        ks.append(k)
+    assert ks == [float(v) for v in fix["exp/adjust_k"]]
+    assert torch.equal(torch.topk(fix["in/topk_x"], 10).values, fix["exp/topk_10"])
+    assert torch.equal(O.uint8_to_normalized(fix["in/u8"]), fix["exp/u8_norm"])
