@@ -1,6 +1,7 @@
 """Adversarial losses with the reference's names and call signature (reference src/utils/losses.py:197-239,
 wired by src/config.py:411-433 as cfgs.LOSS.{d_loss,g_loss}); forward + gradient in one small kernel each."""
 import torch
+import torch.distributed as dist
 from torch import autograd
 
 from . import functional as F
@@ -29,6 +30,37 @@ def d_vanilla(d_logit_real, d_logit_fake, DDP=False):
 
 def g_vanilla(d_logit_fake, DDP=False):
     return F.GLossFn.apply(d_logit_fake, 2)
+
+
+class GatherLayer(autograd.Function):
+    """All-gather with a backward pass, reference src/utils/losses.py:19-37 (used under DDP by the LeCam regulariser,
+    src/worker.py:396-399, and the contrastive heads): forward returns the rank-ordered concatenation of every rank's tensor
+    (== torch.cat(reference GatherLayer.apply(x), dim=0)) from ONE collective into one buffer; backward hands each rank the slice of
+    the upstream gradient that belongs to its own samples, exactly like the reference (no reduction across ranks)."""
+
+    @staticmethod
+    def forward(ctx, x, group=None):
+        world, ctx.rank, ctx.n = dist.get_world_size(group), dist.get_rank(group), x.shape[0]
+        x = x.contiguous()
+        out = torch.empty((world * ctx.n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        try:
+            dist.all_gather_into_tensor(out, x, group=group)
+        except (RuntimeError, NotImplementedError):      # a backend without the flat collective
+            parts = [torch.empty_like(x) for _ in range(world)]
+            dist.all_gather(parts, x, group=group)
+            out = torch.cat(parts, dim=0)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[ctx.rank * ctx.n:(ctx.rank + 1) * ctx.n].clone(), None
+
+
+def gather_logits(x, group=None):
+    """Logits of the global batch under data parallelism (identity in a single process)."""
+    if group is None or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return x
+    return GatherLayer.apply(x, group)
 
 
 G_LOSSES = {"vanilla": g_vanilla, "hinge": g_hinge, "wasserstein": g_wasserstein}

@@ -119,11 +119,13 @@ class Worker:
                 if self.apply_dra:       # src/worker.py:378-383
                     dra = sg_losses.cal_dra_penalty(real_images=real_images.detach(), real_labels=real_labels, discriminator=self.Dis, device=self.device)
                     dis_acml_loss = dis_acml_loss + self.dra_lambda * dra
-                if self.apply_lecam:     # src/worker.py:395-407 (single process: no gather)
-                    self.lecam_ema.update(float(real_dict["adv_output"].detach().mean()), "D_real", current_step)
-                    self.lecam_ema.update(float(fake_dict["adv_output"].detach().mean()), "D_fake", current_step)
+                if self.apply_lecam:     # src/worker.py:395-407: under data parallelism over the logits of the GLOBAL batch
+                    real_adv = sg_losses.gather_logits(real_dict["adv_output"], self.group)
+                    fake_adv = sg_losses.gather_logits(fake_dict["adv_output"], self.group)
+                    self.lecam_ema.update(float(real_adv.detach().mean()), "D_real", current_step)
+                    self.lecam_ema.update(float(fake_adv.detach().mean()), "D_fake", current_step)
                     if current_step > self.lecam_ema_start_iter:
-                        dis_acml_loss = dis_acml_loss + self.lecam_lambda * sg_losses.lecam_reg(real_dict["adv_output"], fake_dict["adv_output"], self.lecam_ema)
+                        dis_acml_loss = dis_acml_loss + self.lecam_lambda * sg_losses.lecam_reg(real_adv, fake_adv, self.lecam_ema)
                 if self.apply_maxgp:     # src/worker.py:386-392
                     mg = sg_losses.cal_maxgrad_penalty(real_images=real_images.detach(), real_labels=real_labels, fake_images=fake_images,
                                                        discriminator=self.Dis, device=self.device)

@@ -140,3 +140,29 @@ def _grad_avg_job(rank, world):
 def test_gradient_average_equals_full_batch_gloo():
     out = _spawn(_grad_avg_job)
     assert max(out.values()) < 1e-6
+
+
+def _gather_job(rank, world):
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import losses as SL
+    g = torch.Generator().manual_seed(7)
+    full = torch.randn(world * 3, 5, generator=g)
+    w = torch.randn(world * 3, 5, generator=g)
+    x = full[rank * 3:(rank + 1) * 3].clone().requires_grad_(True)
+    out = SL.gather_logits(x, dist.group.WORLD)
+    (out * w).sum().backward()
+    return out.detach().clone(), x.grad.clone(), full, w
+
+
+def test_gather_layer_forward_concat_and_local_gradient():
+    """GatherLayer (reference src/utils/losses.py:19-37): every rank sees the rank-ordered concatenation; the gradient of a rank's own
+    tensor is its slice of the upstream gradient (no cross-rank reduction), and a single process is the identity."""
+    res = _spawn(_gather_job, world=2)
+    for rank in (0, 1):
+        out, gx, full, w = res[rank]
+        assert torch.equal(out, full)
+        assert torch.equal(gx, w[rank * 3:(rank + 1) * 3])
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import losses as SL
+    t = torch.randn(4)
+    assert SL.gather_logits(t, None) is t
