@@ -1,0 +1,53 @@
+"""Pin the host-side metric formulas of the product (pytorch-studiogan_amd/metrics.py: frechet_inception_distance, calculate_kl_div)
+and of the oracle (oracle/inception.py: frechet_distance) against the REAL reference functions (reference src/metrics/fid.py:34-62,
+src/metrics/ins.py:28-42) run here on CPU; writes tests/golden/metrics_host.npz (inputs + the reference's outputs).
+
+    python oracle/make_golden_metrics.py      (authoring container only: imports /root/reference through oracle/ref_import.py)
+
+TEST INFRASTRUCTURE ONLY.
+"""
+import importlib
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from oracle import ref_import as RI      # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "metrics_host")
+
+
+def main():
+    RI._prepare()
+    fid = importlib.import_module("metrics.fid")
+    ins = importlib.import_module("metrics.ins")
+    rs = np.random.RandomState(20260922)
+    fix = {}
+    # FID between two Gaussians' sample moments (64-d), and a near-singular pair (rank-deficient covariance: the eps branch of fid.py:50-54)
+    a = rs.randn(400, 64)
+    b = rs.randn(400, 64) * 1.3 + 0.2
+    c = np.concatenate([rs.randn(30, 64)] * 2)         # 60 samples, rank <= 29
+    for tag, x in (("a", a), ("b", b), ("c", c)):
+        fix[f"in/mu_{tag}"], fix[f"in/sigma_{tag}"] = x.mean(0), np.cov(x, rowvar=False)
+    fix["exp/fid_ab"] = np.float64(fid.frechet_inception_distance(fix["in/mu_a"], fix["in/sigma_a"], fix["in/mu_b"], fix["in/sigma_b"]))
+    fix["exp/fid_ac"] = np.float64(fid.frechet_inception_distance(fix["in/mu_a"], fix["in/sigma_a"], fix["in/mu_c"], fix["in/sigma_c"]))
+    fix["exp/fid_aa"] = np.float64(fid.frechet_inception_distance(fix["in/mu_a"], fix["in/sigma_a"], fix["in/mu_a"], fix["in/sigma_a"]))
+    # Inception score of softmax rows, 1 and 5 splits (ins.py:28-42)
+    p = torch.softmax(3.0 * torch.randn(250, 1008, generator=torch.Generator().manual_seed(5)), 1)
+    fix["in/probs"] = p.numpy()
+    for splits in (1, 5):
+        m, s = ins.calculate_kl_div(p, splits)
+        fix[f"exp/is_mean_{splits}"], fix[f"exp/is_std_{splits}"] = np.float64(m), np.float64(s)
+    np.savez_compressed(OUT + ".npz", **fix)
+    json.dump({"note": "reference src/metrics/fid.py frechet_inception_distance and src/metrics/ins.py calculate_kl_div run on CPU by "
+                       "oracle/make_golden_metrics.py"}, open(OUT + ".json", "w"), indent=1)
+    print({k: float(v) for k, v in fix.items() if k.startswith("exp/")})
+    print("wrote", OUT + ".npz", os.path.getsize(OUT + ".npz") // 1024, "KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -148,3 +148,25 @@ def test_regulariser_restatements_match_reference_fixture():
     assert ks == [float(v) for v in fix["exp/adjust_k"]]
     assert torch.equal(torch.topk(fix["in/topk_x"], 10).values, fix["exp/topk_10"])
     assert torch.equal(O.uint8_to_normalized(fix["in/u8"]), fix["exp/u8_norm"])
+
+
+def test_metric_host_formulas_match_reference_fixture():
+    """FID (reference src/metrics/fid.py:34-62, incl. the near-singular eps branch) and the Inception score (src/metrics/ins.py:28-42):
+    the product's host-side functions and the oracle's FID against outputs of the REAL reference functions
+    (oracle/make_golden_metrics.py -> tests/golden/metrics_host.npz)."""
+    import numpy as np
+    from studiogan_amd import metrics as M
+    from oracle import inception as OI
+    fix, _ = load_golden("metrics_host")
+    g = lambda k: fix[k].numpy()
+    for pair in ("ab", "ac", "aa"):
+        x, y = pair
+        ref = float(fix["exp/fid_" + pair])
+        ours = float(M.frechet_inception_distance(g("in/mu_" + x), g("in/sigma_" + x), g("in/mu_" + y), g("in/sigma_" + y)))
+        orc = float(OI.frechet_distance(g("in/mu_" + x), g("in/sigma_" + x), g("in/mu_" + y), g("in/sigma_" + y)))
+        assert abs(ours - ref) <= 1e-9 * max(1.0, abs(ref)), (pair, ours, ref)
+        assert abs(orc - ref) <= 1e-6 * max(1.0, abs(ref)), (pair, orc, ref)
+    p = fix["in/probs"]
+    for splits in (1, 5):
+        m, s = M.calculate_kl_div(p, splits)
+        assert abs(float(m) - float(fix[f"exp/is_mean_{splits}"])) < 1e-6 and (splits == 1 or abs(float(s) - float(fix[f"exp/is_std_{splits}"])) < 1e-6)
