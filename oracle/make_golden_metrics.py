@@ -42,10 +42,31 @@ def main():
     for splits in (1, 5):
         m, s = ins.calculate_kl_div(p, splits)
         fix[f"exp/is_mean_{splits}"], fix[f"exp/is_std_{splits}"] = np.float64(m), np.float64(s)
+    # Evaluation pre-processing (src/metrics/preparation.py:103-108 -> utils/ops.py:251-263 quantize_images + resize_images with the
+    # "legacy" resizer of utils/resize.py:68-69,83-93). torchvision is absent here: ToTensor is applied by its definition for a float
+    # HWC ndarray (transpose to CHW, no scaling -- only uint8 input is divided by 255).
+    rops = importlib.import_module("utils.ops")
+    rres = importlib.import_module("utils.resize")
+    from oracle import inception as OI
+    x = torch.rand(3, 3, 32, 32, generator=torch.Generator().manual_seed(9)) * 2.4 - 1.2          # incl. values outside [-1, 1]
+    q = rops.quantize_images(x)
+    resizer = rres.build_resizer("legacy", "InceptionV3_tf", 299)
+    to_tensor = lambda a: torch.from_numpy(np.ascontiguousarray(a.transpose((2, 0, 1))))
+    mean = torch.Tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1)
+    std = torch.Tensor([0.5, 0.5, 0.5]).view(1, 3, 1, 1)
+    r = rops.resize_images(q, resizer, to_tensor, mean, std, device="cpu")
+    ro, qo = OI.quantize_resize_normalize(x, quantize=True)
+    assert np.array_equal(q, qo), "uint8 quantisation"
+    assert torch.equal(r, ro), "legacy resize + normalise"
+    flat = r.reshape(-1)
+    idx = (torch.arange(4096, dtype=torch.int64) * flat.numel()) // 4096
+    fix["in/pre_x"], fix["exp/pre_q"] = x.numpy(), q
+    fix["exp/pre_samples"], fix["exp/pre_norms"] = flat[idx].numpy(), np.array([float(flat.double().sum()), float(flat.double().norm())])
+    print("eval pre-processing: oracle bit-identical to the reference (uint8 image and the 299x299 normalised tensor)")
     np.savez_compressed(OUT + ".npz", **fix)
     json.dump({"note": "reference src/metrics/fid.py frechet_inception_distance and src/metrics/ins.py calculate_kl_div run on CPU by "
                        "oracle/make_golden_metrics.py"}, open(OUT + ".json", "w"), indent=1)
-    print({k: float(v) for k, v in fix.items() if k.startswith("exp/")})
+    print({k: float(v) for k, v in fix.items() if k.startswith("exp/") and np.ndim(v) == 0})
     print("wrote", OUT + ".npz", os.path.getsize(OUT + ".npz") // 1024, "KiB")
 
 

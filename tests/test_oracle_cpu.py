@@ -170,3 +170,13 @@ def test_metric_host_formulas_match_reference_fixture():
     for splits in (1, 5):
         m, s = M.calculate_kl_div(p, splits)
         assert abs(float(m) - float(fix[f"exp/is_mean_{splits}"])) < 1e-6 and (splits == 1 or abs(float(s) - float(fix[f"exp/is_std_{splits}"])) < 1e-6)
+    # evaluation pre-processing: uint8 quantisation bit-exact, legacy bilinear resize + normalisation sampled + norms
+    import numpy as np
+    x = fix["in/pre_x"]
+    r, q = OI.quantize_resize_normalize(x, quantize=True)
+    assert np.array_equal(q, fix["exp/pre_q"].numpy())
+    flat = r.reshape(-1)
+    idx = (torch.arange(4096, dtype=torch.int64) * flat.numel()) // 4096
+    assert torch.equal(flat[idx], fix["exp/pre_samples"])
+    n = fix["exp/pre_norms"]
+    assert abs(float(flat.double().sum()) - float(n[0])) <= 1e-9 * abs(float(n[0])) and abs(float(flat.double().norm()) - float(n[1])) <= 1e-12 * float(n[1])
