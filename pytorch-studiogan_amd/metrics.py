@@ -324,3 +324,39 @@ def top_k_accuracy(probs, labels, k, c0=1, ncls=1000):
     hits = torch.empty(probs.shape[0], dtype=torch.uint8, device=probs.device)
     L.call("sg_topk_hits", L.ptr(probs) + 4 * c0, probs.shape[1], ncls, L.ptr(lab), k, probs.shape[0], L.ptr(hits), L.stream())
     return float(hits.float().mean().item())
+
+
+def load_ImageNet_label_dict(label_table_path):
+    """reference src/utils/misc.py:582-595 (TF-Inception branch): `folder -> line index` of the reference's
+    `src/utils/tf_imagenet_folder_label_pairs.txt` (1000 lines `n02119789 1 kit_fox`; the file stays in the StudioGAN checkout -- pass
+    its path)."""
+    d, label = {}, 0
+    with open(label_table_path, "r") as f:
+        for line in f:
+            if not line.strip():
+                continue
+            d[line.split(" ")[0]] = label
+            label += 1
+    return d
+
+
+def convert_labels(labels, class_to_idx, folder_label_dict):
+    """loader label -> folder name -> TF-Inception class index (reference src/metrics/ins.py:48-49,68-70)."""
+    loader_label_folder_dict = {v: k for k, v in class_to_idx.items()}
+    return [folder_label_dict[loader_label_folder_dict[int(l)]] for l in labels]
+
+
+def eval_features(probs, labels, num_features, split, is_acc, class_to_idx=None, folder_label_dict=None, topk_fn=None):
+    """reference src/metrics/ins.py:45-79 for the TF-Inception backbone on ImageNet: IS over the first num_features rows; top-1 / top-5 of
+    the remapped labels against probs[:, 1:1001] (the reference passes `[i + 1 for i in converted]` with that slice to sklearn, which
+    maps label i + 1 to column i: the same decision as testing 0-based class i here). The accuracy itself runs on the device
+    (`top_k_accuracy`: sklearn's tie rule, bit-exact)."""
+    topk_fn = topk_fn or top_k_accuracy
+    probs, labels = probs[:num_features], labels[:num_features]
+    m_scores, m_std = calculate_kl_div(probs, splits=split)
+    top1, top5 = "N/A", "N/A"
+    if is_acc:
+        converted = convert_labels(labels, class_to_idx, folder_label_dict)
+        top1 = topk_fn(probs, converted, 1, 1, 1000)
+        top5 = topk_fn(probs, converted, 5, 1, 1000)
+    return m_scores, m_std, top1, top5

@@ -180,3 +180,49 @@ def test_metric_host_formulas_match_reference_fixture():
     assert torch.equal(flat[idx], fix["exp/pre_samples"])
     n = fix["exp/pre_norms"]
     assert abs(float(flat.double().sum()) - float(n[0])) <= 1e-9 * abs(float(n[0])) and abs(float(flat.double().norm()) - float(n[1])) <= 1e-12 * float(n[1])
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_is_accuracy_label_remap_matches_reference():
+    """IS top-1/top-5 label handling (reference src/metrics/ins.py:45-79 + src/utils/misc.py:582-595, TF-Inception on ImageNet): the
+    product's host logic (label table, loader-label -> folder -> TF index, the [:, 1:1001] slice) against the reference's own
+    eval_features on the same synthetic probabilities (the device top-k kernel is replaced by a CPU stand-in with sklearn's tie rule,
+    which tests/test_eval_gpu.py checks bit-exactly against the kernel)."""
+    import importlib
+    import types
+    import numpy as np
+    from oracle import ref_import as RI
+    from studiogan_amd import metrics as M
+    RI._prepare()
+    ins = importlib.import_module("metrics.ins")
+    table = "/root/reference/src/utils/tf_imagenet_folder_label_pairs.txt"
+    d = M.load_ImageNet_label_dict(table)
+    assert len(d) == 1000 and d["n02119789"] == 0 and d["n02100735"] == 1
+    folders = sorted(d.keys())                                   # ImageFolder sorts class folders alphabetically
+    class_to_idx = {f: i for i, f in enumerate(folders)}
+    g = torch.Generator().manual_seed(12)
+    n = 3000
+    labels = torch.cat([torch.arange(1000), torch.randint(0, 1000, (n - 1000,), generator=g)]).tolist()   # every class present (sklearn needs it)
+    logits = torch.randn(n, 1008, generator=g)
+    for i, l in enumerate(labels):                               # make ~half of the samples right
+        if i % 2 == 0:
+            logits[i, 1 + d[folders[l]]] += 4.0
+    probs = torch.softmax(logits, 1)
+    loader = types.SimpleNamespace(dataset=types.SimpleNamespace(data_name="ImageNet", data=types.SimpleNamespace(class_to_idx=class_to_idx)))
+    cwd = os.getcwd()
+    os.chdir("/root/reference")
+    try:
+        ref = ins.eval_features(probs, labels, loader, n, 1, True, is_torch_backbone=False)
+    finally:
+        os.chdir(cwd)
+
+    def cpu_topk(p, lab, k, c0, ncls):      # sklearn's rule: stable ascending argsort reversed -> the higher class index wins a tie
+        s = p[:, c0:c0 + ncls].numpy()
+        t = np.asarray(lab)
+        st = s[np.arange(len(t)), t][:, None]
+        beat = (s > st).sum(1) + ((s == st) & (np.arange(ncls)[None, :] > t[:, None])).sum(1)
+        return float((beat < k).mean())
+    ours = M.eval_features(probs, labels, n, 1, True, class_to_idx=class_to_idx, folder_label_dict=d, topk_fn=cpu_topk)
+    assert abs(float(ours[0]) - float(ref[0])) < 1e-6
+    assert abs(ours[2] - ref[2]) < 1e-12 and abs(ours[3] - ref[3]) < 1e-12, (ours, ref)
+    assert 0.2 < ours[2] < 0.7 and ours[3] >= ours[2]
