@@ -226,3 +226,36 @@ def test_is_accuracy_label_remap_matches_reference():
     assert abs(float(ours[0]) - float(ref[0])) < 1e-6
     assert abs(ours[2] - ref[2]) < 1e-12 and abs(ours[3] - ref[3]) < 1e-12, (ours, ref)
     assert 0.2 < ours[2] < 0.7 and ours[3] >= ours[2]
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_ema_restatement_matches_reference_class():
+    """oracle.ema_update against the reference's Ema (src/utils/ema.py:11-40) on a small network with batch-norm buffers: before
+    start_iter (decay 0 -> copy), after it (lerp), and the integer buffer (copied, never lerped)."""
+    import importlib
+    import torch.nn as nn
+    from oracle import ref_import as RI
+    RI._prepare()
+    ref_ema = importlib.import_module("utils.ema")
+
+    def net(seed):
+        torch.manual_seed(seed)
+        m = nn.Sequential(nn.Conv2d(3, 4, 3), nn.BatchNorm2d(4), nn.Conv2d(4, 2, 1))
+        m.train()
+        m(torch.randn(5, 3, 6, 6))          # moves running stats and num_batches_tracked
+        return m
+    src, tgt = net(1), net(2)
+    e = ref_ema.Ema(src, tgt, decay=0.9, start_iter=3)       # copies src into tgt
+    oP = {k: v.detach().clone() for k, v in tgt.named_parameters()}
+    oB = {k: v.detach().clone() for k, v in tgt.named_buffers()}
+    for it in (0, 2, 3, 7):
+        with torch.no_grad():                                # the source trains on
+            for p in src.parameters():
+                p.add_(0.1 * torch.randn_like(p))
+        src(torch.randn(5, 3, 6, 6))
+        e.update(it)
+        O.ema_update(dict(src.named_parameters()), dict(src.named_buffers()), oP, oB, it, decay=0.9, start_iter=3)
+        for k, v in tgt.named_parameters():
+            assert torch.equal(v, oP[k]), (it, k)
+        for k, v in tgt.named_buffers():
+            assert torch.equal(v, oB[k]), (it, k)
