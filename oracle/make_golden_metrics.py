@@ -63,6 +63,13 @@ def main():
     fix["in/pre_x"], fix["exp/pre_q"] = x.numpy(), q
     fix["exp/pre_samples"], fix["exp/pre_norms"] = flat[idx].numpy(), np.array([float(flat.double().sum()), float(flat.double().norm())])
     print("eval pre-processing: oracle bit-identical to the reference (uint8 image and the 299x299 normalised tensor)")
+    # FID moments of generated features: the reference truncates the (over-generated) stack to num_generate BEFORE np.mean / np.cov
+    # (src/metrics/fid.py:64-69,96-98); 37 rows = 5 batches of 8 minus nothing, num_generate = 30 is not a multiple of the batch
+    ff = torch.randn(37, 32, generator=torch.Generator().manual_seed(12)) * 1.7 + 0.3
+    mu, sigma = fid.calculate_moments(data_loader="N/A", eval_model=None, num_generate=30, batch_size=8, quantize=True, world_size=1, DDP=False,
+                                      disable_tqdm=True, fake_feats=ff)
+    fix["in/mom_feats"], fix["in/mom_num_generate"] = ff.numpy(), np.int64(30)
+    fix["exp/mom_mu"], fix["exp/mom_sigma"] = mu.astype(np.float64), sigma.astype(np.float64)
     np.savez_compressed(OUT + ".npz", **fix)
     json.dump({"note": "reference src/metrics/fid.py frechet_inception_distance and src/metrics/ins.py calculate_kl_div run on CPU by "
                        "oracle/make_golden_metrics.py"}, open(OUT + ".json", "w"), indent=1)

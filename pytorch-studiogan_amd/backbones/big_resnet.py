@@ -28,9 +28,8 @@ def _need_graph(module, *inputs):
     for t in inputs:
         if torch.is_tensor(t) and t.requires_grad:
             return True
-    for p in module.parameters():
-        return p.requires_grad
-    return False
+    # any trainable parameter (freezeD, reference src/utils/misc.py:199-216, freezes only the FIRST blocks)
+    return any(p.requires_grad for p in module.parameters())
 
 
 class GenBlock(nn.Module):

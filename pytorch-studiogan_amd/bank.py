@@ -161,6 +161,9 @@ class LayerRT:
 
 
 class _Slot:
+    """One set of per-forward weight-side buffers (operand images, u / v / sigma snapshots, dL/dW_sn scratch). `begin_forward` hands
+    out a HANDLE per forward: a second _Slot object that shares this one's attribute dict. Every autograd node of that forward keeps
+    the handle alive through ctx.slot, so "the handle is gone" == "no backward of that forward can come any more"."""
     pass
 
 
@@ -229,24 +232,52 @@ class WeightBank:
             m._sg_rt = r
             self.layers.append(r)
         self.work = torch.zeros(max(work, 64 * len(layers)) + 64, device=dev, dtype=torch.float32)
+        self._sizes = (img_elems, f32_elems, dwt_elems, uv_elems)
         self.slots = []
         for s in range(nslots):
-            sl = _Slot()
-            sl.index = s
-            sl.img = torch.zeros(max(img_elems, 16), device=dev, dtype=compute_dtype)
-            sl.f32 = torch.zeros(max(f32_elems, 4), device=dev, dtype=torch.float32)
-            sl.dwt = torch.zeros(max(dwt_elems, 4), device=dev, dtype=torch.float32) if s > 0 else None
-            sl.uv = torch.zeros(max(uv_elems, 4), device=dev, dtype=torch.float32)
-            sl.sigma = torch.ones(len(layers), device=dev, dtype=torch.float32)
-            sl.dwt_zeroed = False
-            sl.pending = []
-            sl.desc_cache = {}
-            sl.bwd_cache = {}
-            self.slots.append(sl)
+            self.slots.append(self._new_slot(s))
         self._ring = 0
         self.current = self.slots[0]
         self._cb_queued = False
         self.es = es
+
+    MAX_SLOTS = 12
+
+    def _new_slot(self, s):
+        img_elems, f32_elems, dwt_elems, uv_elems = self._sizes
+        dev = self.device
+        sl = _Slot()
+        sl.index = s
+        sl.img = torch.zeros(max(img_elems, 16), device=dev, dtype=self.dtype)
+        sl.f32 = torch.zeros(max(f32_elems, 4), device=dev, dtype=torch.float32)
+        sl.dwt = torch.zeros(max(dwt_elems, 4), device=dev, dtype=torch.float32) if s > 0 else None
+        sl.uv = torch.zeros(max(uv_elems, 4), device=dev, dtype=torch.float32)
+        sl.sigma = torch.ones(len(self.layers), device=dev, dtype=torch.float32)
+        sl.dwt_zeroed = False
+        sl.pending = []
+        sl.desc_cache = {}
+        sl.bwd_cache = {}
+        sl.live = None          # weakref to the handle of the forward that currently owns the slot
+        return sl
+
+    def _free_graph_slot(self):
+        """Next graph slot (ring order) whose previous forward can no longer run a backward. A D step with several penalties
+        (apply_gp + apply_dra / apply_maxgp, bCR / zCR) keeps more forwards waiting for ONE backward than the initial ring holds:
+        the ring grows (288 GB of HBM) instead of silently recycling a slot whose sigma / u / v / operand images are still needed."""
+        n = len(self.slots) - 1
+        for k in range(1, n + 1):
+            idx = (self._ring + k - 1) % n + 1
+            sl = self.slots[idx]
+            if sl.live is None or sl.live() is None:
+                self._ring = idx
+                return sl
+        if len(self.slots) >= self.MAX_SLOTS:
+            raise RuntimeError(f"{len(self.slots) - 1} forwards of this network are waiting for their backward; refusing to overwrite the "
+                               "spectral-norm state of the oldest one (raise WeightBank.MAX_SLOTS if this is intended)")
+        sl = self._new_slot(len(self.slots))
+        self.slots.append(sl)
+        self._ring = sl.index
+        return sl
 
     # -- forward ------------------------------------------------------------------------------------------
     def _desc(self, slot, flags):
@@ -287,10 +318,12 @@ class WeightBank:
     def begin_forward(self, need_graph):
         """One spectral-norm power iteration + weight image emission for every layer; returns the slot."""
         if need_graph:
-            self._ring = self._ring % (self.nslots - 1) + 1
-            slot = self.slots[self._ring]
-            slot.dwt_zeroed = False
-            slot.pending = []
+            phys = self._free_graph_slot()
+            phys.dwt_zeroed = False
+            phys.pending = []
+            slot = _Slot()
+            slot.__dict__ = phys.__dict__          # handle: same attributes, its lifetime = the lifetime of this forward's graph
+            phys.live = weakref.ref(slot)
         else:
             slot = self.slots[0]
         flags = tuple(bool(r.module().training) for r in self.layers)

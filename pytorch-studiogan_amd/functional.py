@@ -975,7 +975,8 @@ class PDHeadFn(torch.autograd.Function):
         dadv = _c(dadv.float())
         dh = torch.empty_like(h)
         train_w = ctx.needs_input_grad[1]
-        dw1 = bank.dwt(slot, rt_lin) if train_w else L.ptr(torch.zeros(Cc, dtype=torch.float32, device=h.device))
+        dw1_dummy = None if train_w else torch.zeros(Cc, dtype=torch.float32, device=h.device)   # kept alive until after the launch
+        dw1 = bank.dwt(slot, rt_lin) if train_w else L.ptr(dw1_dummy)
         db1 = L.ptr(ensure_grad(ctx.b1)) if (ctx.b1 is not None and train_w) else None
         demb = torch.empty_like(emb) if emb is not None else None
         L.call("sg_pd_head_bwd", L.ptr(h), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(dh), dw1, db1, L.ptr(demb), B, Cc, L.stream())
@@ -1017,7 +1018,8 @@ class PDHeadBwdFn(torch.autograd.Function):
             g_dadv = torch.empty(B, dtype=torch.float32, device=dev)
             L.call("sg_pd_head_fwd", L.ptr(ddh), bank.w_f32(slot, rt_lin), None, L.ptr(emb), L.ptr(g_dadv), B, Cc, L.stream())
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw1 = bank.dwt(slot, rt_lin) if ctx.needs_input_grad[1] else L.ptr(torch.zeros(Cc, dtype=torch.float32, device=dev))
+            dw1_dummy = None if ctx.needs_input_grad[1] else torch.zeros(Cc, dtype=torch.float32, device=dev)   # kept alive until after the launch
+            dw1 = bank.dwt(slot, rt_lin) if ctx.needs_input_grad[1] else L.ptr(dw1_dummy)
             demb = torch.empty((B, Cc), dtype=torch.float32, device=dev) if emb is not None else None
             scratch = torch.empty((B, Cc), dtype=torch.float32, device=dev)
             L.call("sg_pd_head_bwd", L.ptr(ddh), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(scratch), dw1, None, L.ptr(demb), B, Cc, L.stream())

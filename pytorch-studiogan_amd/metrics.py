@@ -228,18 +228,29 @@ def softmax_rows(logits):
 def generate_images_and_stack_features(generator, eval_model, num_generate, batch_size, z_dim, num_classes, quantize=True, world_size=1,
                                        DDP=False, device="cuda", moments=None):
     """reference src/metrics/features.py:17-65. Returns (features [n,2048], probs [n,1008], labels list).
-    moments: optional `FeatureMoments` accumulator that receives every feature batch on the device."""
+    moments: optional `FeatureMoments` accumulator fed on the device. It receives exactly the rows the reference keeps
+    (`fake_feats[:num_generate]` of the rank-major gathered stack, src/metrics/fid.py:68-69): the over-generated tail --
+    ceil(num_generate / batch) batches, `num_batches // world_size + 1` per rank under DDP -- is NOT accumulated."""
     from .worker import sample_zy
     num_batches = int(math.ceil(float(num_generate) / float(batch_size)))
+    rank = 0
     if DDP:
         num_batches = num_batches // world_size + 1
+        if world_size > 1:
+            import torch.distributed as dist
+            rank = dist.get_rank()
+    # rows of this rank sit at [rank * per_rank, (rank + 1) * per_rank) of the gathered stack; the first num_generate survive
+    per_rank = num_batches * batch_size
+    keep = max(0, min(per_rank, num_generate - rank * per_rank))
     feats, probs, labels = [], [], []
-    for _ in range(num_batches):
+    for b in range(num_batches):
         zs, ys = sample_zy(batch_size, z_dim, num_classes, device)
         fake = generator(zs, ys, eval=True)
         f, logit = eval_model.get_outputs(fake, quantize=quantize)
         if moments is not None:
-            moments.add(f)
+            take = max(0, min(batch_size, keep - b * batch_size))
+            if take:
+                moments.add(f[:take])
         feats.append(f)
         probs.append(softmax_rows(logit))
         labels.append(ys)

@@ -29,6 +29,44 @@ def pipelined_allreduce(flat, ranges, group=None):
         yield lo, hi
 
 
+def _fingerprint(flat):
+    """[sum, sum of squares, weighted sum] of a flat fp32 buffer in fp64: equal on two ranks iff (for all practical purposes) the buffers are."""
+    d = flat.double()
+    w = torch.arange(1, d.numel() + 1, dtype=torch.float64, device=d.device) / d.numel()
+    return torch.stack([d.sum(), (d * d).sum(), (d * w).sum()])
+
+
+def assert_replicas_identical(flat, group=None, what="buffer"):
+    """Raise if `flat` differs across the ranks of `group` (one tiny MIN/MAX all-reduce pair)."""
+    fp = _fingerprint(flat)
+    lo, hi = fp.clone(), fp.clone()
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+    if not bool(torch.equal(lo, hi)):
+        raise RuntimeError(f"data-parallel replicas disagree: {what} differ across ranks. Without DistributedDataParallel nothing "
+                           "broadcasts the initial weights -- call studiogan_amd.optim.sync_replicas(module, group) after building "
+                           "each network (INTEGRATION.md §5), or seed every rank identically before construction.")
+
+
+@torch.no_grad()
+def sync_replicas(module, group=None, src=0):
+    """What DistributedDataParallel's constructor does for the reference (src/models/model.py:171-180): every rank takes rank
+    `src`'s parameters AND buffers (spectral-norm u / v, BN running statistics). Two broadcasts: the flat parameter arena and the
+    flat buffer arena; integer buffers (num_batches_tracked) one by one."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return module
+    a = _arena_for(list(module.parameters()))
+    root = src if group is None else dist.get_global_rank(group, src)
+    dist.broadcast(a.data, src=root, group=group)
+    b = get_buffer_arena(module)
+    if b.numel:
+        dist.broadcast(b.data, src=root, group=group)
+    for _, buf in module.named_buffers():
+        if buf is not None and buf.dtype != torch.float32:
+            dist.broadcast(buf, src=root, group=group)
+    return module
+
+
 def _arena_for(params):
     ents = [arena_of(p) for p in params]
     if any(e is None for e in ents) or len({id(e[0]) for e in ents}) != 1 or not ents[0][0].intact():
@@ -47,6 +85,7 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._t = 0
         self.comm_chunks = comm_chunks
+        self._replicas_checked = False
 
     def _state(self):
         params = self.param_groups[0]["params"]
@@ -63,6 +102,41 @@ class FusedAdam(torch.optim.Optimizer):
                             v[o_new:o_new + p.numel()] = self._v[o_old:o_old + p.numel()]
             self._arena, self._m, self._v = a, m, v
         return a
+
+    # -- checkpoint layout of torch.optim.Adam (reference src/utils/ckpt.py saves optimizer.state_dict() and restores it with
+    #    load_state_dict): state[i] = {step, exp_avg, exp_avg_sq} per parameter. The moments live in two flat arenas here, so
+    #    state_dict() emits per-parameter copies of the arena slices and load_state_dict() copies them back.
+    def state_dict(self):
+        a = self._state()
+        step = torch.tensor(float(self._t), dtype=torch.float32)
+        for p, o in zip(a.params, a.offsets):
+            n = p.numel()
+            self.state[p] = {"step": step.clone(), "exp_avg": self._m[o:o + n].view(p.shape).clone(),
+                             "exp_avg_sq": self._v[o:o + n].view(p.shape).clone()}
+        try:
+            return super().state_dict()
+        finally:
+            self.state.clear()          # the arenas stay the single source of truth
+
+    def load_state_dict(self, state_dict):
+        a = self._state()
+        super().load_state_dict(state_dict)      # torch's own validation / device + dtype casting of the per-parameter tensors
+        steps = set()
+        with torch.no_grad():
+            for p, o in zip(a.params, a.offsets):
+                st = self.state.get(p)
+                n = p.numel()
+                if not st:                       # a parameter torch.optim.Adam never stepped (no gradient yet): zero moments
+                    self._m[o:o + n].zero_()
+                    self._v[o:o + n].zero_()
+                    continue
+                self._m[o:o + n].copy_(st["exp_avg"].reshape(-1))
+                self._v[o:o + n].copy_(st["exp_avg_sq"].reshape(-1))
+                steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise RuntimeError(f"FusedAdam keeps one step count per network; the checkpoint holds {sorted(steps)}")
+        self._t = steps.pop() if steps else 0
+        self.state.clear()
 
     def zero_grad(self, set_to_none=False):
         a = self._state()
@@ -89,6 +163,11 @@ class FusedAdam(torch.optim.Optimizer):
         world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
         n = a.numel
         st = L.stream()
+        if world > 1 and not self._replicas_checked:
+            # DDP's constructor broadcast is gone with DDP (reference src/models/model.py:171-180): replicas that start from
+            # different weights would silently never converge to one model. Checked once, on the first exchange.
+            assert_replicas_identical(a.data, group, "parameters of the network handed to FusedAdam")
+            self._replicas_checked = True
         if world > 1:
             # pipelined all-reduce(sum) -> Adam(grad/world): chunk i+1 is on the wire while chunk i is being applied
             for lo, hi in pipelined_allreduce(a.grad, chunk_ranges(n, self.comm_chunks), group):

@@ -10,7 +10,7 @@ import torch
 
 from . import losses as sg_losses
 from . import ops
-from .optim import FusedAdam, Ema
+from .optim import FusedAdam, Ema, sync_replicas
 
 
 def toggle_grad(model, grad):
@@ -81,6 +81,10 @@ class Worker:
         self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
         self.n_d, self.n_g, self.acml = d_updates_per_step, g_updates_per_step, acml_steps
         self.device = next(Gen.parameters()).device
+        if group is not None:
+            # what DDP's constructor broadcast does for the reference (src/models/model.py:171-180, seeds differ per rank: src/loader.py:99)
+            sync_replicas(Gen, group)
+            sync_replicas(Dis, group)
         self.g_optimizer = FusedAdam(Gen.parameters(), lr=g_lr, betas=(beta1, beta2), eps=1e-6)
         self.d_optimizer = FusedAdam(Dis.parameters(), lr=d_lr, betas=(beta1, beta2), eps=1e-6)
         self.Gen_ema, self.ema = None, None
@@ -135,6 +139,7 @@ class Worker:
                     dis_acml_loss = dis_acml_loss + self.r1_lambda * self.r1_penalty
                 dis_acml_loss = dis_acml_loss / self.acml
                 dis_acml_loss.backward()
+                dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
             self.d_optimizer.step(group=self.group)
         return dis_acml_loss
 
@@ -159,6 +164,7 @@ class Worker:
                 gen_acml_loss = self.g_loss(fake_dict["adv_output"], DDP=self.group is not None)
                 gen_acml_loss = gen_acml_loss / self.acml
                 gen_acml_loss.backward()
+                gen_acml_loss = gen_acml_loss.detach()
             # Adam and the EMA of the generator copy (src/worker.py:630-634,675-676) in one launch
             self.g_optimizer.step(ema=self.ema, iteration=current_step, group=self.group)
         return gen_acml_loss

@@ -83,7 +83,24 @@ def test_feature_loop_with_generator(sg):
     assert feats.shape == (12, 2048) and probs.shape == (12, 1008) and len(labels) == 12
     assert torch.isfinite(feats).all() and abs(float(probs.sum(1).mean()) - 1) < 1e-4
     mu, sigma = mom.finalize()
-    check("loop moments", torch.from_numpy(mu), feats.double().mean(0).cpu(), 1e-5)
+    # the reference's rule (src/metrics/fid.py:68-69,96-97): moments over the first num_generate = 10 rows of the 12 generated
+    assert mom.n == 10
+    kept = feats[:10].double().cpu().numpy()
+    check("loop moments mean (first num_generate rows)", torch.from_numpy(mu), torch.from_numpy(kept.mean(0)), 1e-5)
+    check("loop moments cov (first num_generate rows)", torch.from_numpy(sigma), torch.from_numpy(np.cov(kept, rowvar=False)), 1e-4)
+
+
+def test_moments_truncation_vs_reference_fixture(sg):
+    """M.calculate_moments(feats, num_generate) against the REAL reference's calculate_moments(fake_feats=...) output for a stack whose
+    length is not num_generate (tests/golden/metrics_host.npz, written by oracle/make_golden_metrics.py)."""
+    import os
+    from studiogan_amd import metrics as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_host.npz"))
+    dev = torch.device("cuda:0")
+    f = torch.from_numpy(z["in/mom_feats"]).to(dev)
+    mu, sigma = M.calculate_moments(f, int(z["in/mom_num_generate"]))
+    check("mu vs reference calculate_moments", torch.from_numpy(mu), torch.from_numpy(z["exp/mom_mu"]), 1e-6)
+    check("sigma vs reference calculate_moments", torch.from_numpy(sigma), torch.from_numpy(z["exp/mom_sigma"]), 1e-5)
 
 
 def test_topk_training_select_and_scatter(sg):

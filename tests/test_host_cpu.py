@@ -130,3 +130,78 @@ def test_loss_schedule_helpers():
     assert abs(e.D_real - (2.0 * 0.9 + 4.0 * 0.1)) < 1e-12
     with pytest.raises(ValueError):
         e.update(1.0, "nope", 0)
+
+
+def test_fused_adam_checkpoint_layout_roundtrip():
+    """FusedAdam.state_dict()/load_state_dict() interchange with torch.optim.Adam's checkpoint layout (the reference saves
+    optimizer.state_dict() and restores it with load_state_dict, src/utils/ckpt.py): exp_avg / exp_avg_sq / step survive both ways."""
+    from studiogan_amd.optim import FusedAdam
+    torch.manual_seed(0)
+    net = nn.Sequential(nn.Linear(5, 7), nn.Linear(7, 3))
+    ref = copy.deepcopy(net)
+    ropt = torch.optim.Adam(ref.parameters(), lr=2e-4, betas=(0.0, 0.999), eps=1e-6)
+    for _ in range(3):
+        ropt.zero_grad()
+        ref(torch.randn(4, 5)).square().sum().backward()
+        ropt.step()
+    sd = ropt.state_dict()
+    opt = FusedAdam(net.parameters(), lr=1e-3, betas=(0.5, 0.9), eps=1e-6)
+    opt.load_state_dict(copy.deepcopy(sd))
+    assert opt._t == 3
+    g = opt.param_groups[0]
+    assert g["lr"] == 2e-4 and tuple(g["betas"]) == (0.0, 0.999)
+    a = opt._arena
+    for p, o, q in zip(a.params, a.offsets, ref.parameters()):
+        st = ropt.state[q]
+        assert torch.equal(opt._m[o:o + p.numel()].view(p.shape), st["exp_avg"])
+        assert torch.equal(opt._v[o:o + p.numel()].view(p.shape), st["exp_avg_sq"])
+    out = opt.state_dict()
+    assert out["param_groups"][0]["params"] == sd["param_groups"][0]["params"]
+    assert set(out["state"].keys()) == set(sd["state"].keys())
+    for i in sd["state"]:
+        for k in ("exp_avg", "exp_avg_sq"):
+            assert torch.equal(out["state"][i][k], sd["state"][i][k])
+        assert float(out["state"][i]["step"]) == float(sd["state"][i]["step"]) == 3.0
+    # and torch.optim.Adam accepts what FusedAdam wrote (a StudioGAN checkpoint written by this package resumes on the reference)
+    ropt2 = torch.optim.Adam(copy.deepcopy(ref).parameters(), lr=1.0)
+    ropt2.load_state_dict(out)
+    assert len(opt.state) == 0, "the flat arenas stay the single source of truth"
+
+
+def test_weight_bank_ring_never_recycles_a_live_slot():
+    """begin_forward hands out one handle per forward; a slot whose handle is still referenced (a forward waiting for its backward)
+    is never re-used -- the ring grows instead, and refuses beyond MAX_SLOTS (D steps with several penalties)."""
+    import weakref
+    from studiogan_amd import bank as B
+
+    class FakeBank(B.WeightBank):
+        def __init__(self, n):
+            self.slots = [self._new_slot(i) for i in range(n)]
+            self._ring = 0
+
+        def _new_slot(self, s):
+            sl = B._Slot()
+            sl.index, sl.live = s, None
+            return sl
+
+        def take(self):
+            phys = self._free_graph_slot()
+            h = B._Slot()
+            h.__dict__ = phys.__dict__
+            phys.live = weakref.ref(h)
+            return h
+    fb = FakeBank(4)
+    a, b, c = fb.take(), fb.take(), fb.take()
+    assert [a.index, b.index, c.index] == [1, 2, 3]
+    d = fb.take()                                   # all three graph slots are waiting for a backward: the ring grows
+    assert d.index == 4 and len(fb.slots) == 5
+    del b                                           # that forward's graph is gone
+    e = fb.take()
+    assert e.index == 2
+    del a, c, d, e
+    assert fb.take().index in (1, 3, 4)
+    held = [fb.take() for _ in range(B.WeightBank.MAX_SLOTS - 1)]
+    assert len(fb.slots) == B.WeightBank.MAX_SLOTS
+    with pytest.raises(RuntimeError):
+        fb.take()
+    del held

@@ -410,6 +410,35 @@ def test_adam_ema_and_lerp(sg):
     assert torch.equal(ed2.cpu(), pd2.cpu()), "EMA with decay 0 must be a hard copy"
 
 
+def test_fused_adam_resumes_from_torch_adam_checkpoint(sg):
+    """A torch.optim.Adam checkpoint (what the reference's ckpt.py writes) loaded into FusedAdam: the NEXT step equals torch's next
+    step -- moments and bias-correction step count are restored, not restarted."""
+    import copy
+    from studiogan_amd.optim import FusedAdam
+    d = dev()
+    torch.manual_seed(3)
+    ref = torch.nn.Sequential(torch.nn.Linear(33, 65), torch.nn.Linear(65, 9))
+    ropt = torch.optim.Adam(ref.parameters(), lr=2e-4, betas=(0.5, 0.999), eps=1e-6)
+    for _ in range(4):
+        ropt.zero_grad()
+        ref(torch.randn(16, 33)).square().sum().backward()
+        ropt.step()
+    net = copy.deepcopy(ref).to(d)
+    opt = FusedAdam(net.parameters(), lr=1.0, betas=(0.9, 0.9), eps=1e-6)
+    opt.load_state_dict(copy.deepcopy(ropt.state_dict()))
+    x = torch.randn(16, 33)
+    ropt.zero_grad(); ref(x).square().sum().backward(); ropt.step()
+    opt.zero_grad(); net(x.to(d)).square().sum().backward(); opt.step()
+    torch.cuda.synchronize()
+    for (k, a), b in zip(net.named_parameters(), ref.parameters()):
+        check("resumed step " + k, a.detach().cpu(), b.detach(), 2e-6)
+    sd = opt.state_dict()
+    for i, q in enumerate(ref.parameters()):
+        check(f"exp_avg[{i}]", sd["state"][i]["exp_avg"].cpu(), ropt.state[q]["exp_avg"], 1e-5)
+        check(f"exp_avg_sq[{i}]", sd["state"][i]["exp_avg_sq"].cpu(), ropt.state[q]["exp_avg_sq"], 1e-5)
+        assert float(sd["state"][i]["step"]) == 5.0
+
+
 def test_quantize_bit_exact_and_resize(sg):
     """uint8 quantisation (utils/ops.py:251-255) must be bit-exact; the legacy bilinear resize (utils/resize.py:87-91)
     within fp32 tolerance."""

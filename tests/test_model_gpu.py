@@ -125,6 +125,54 @@ def test_state_dict_roundtrip_and_deepcopy(sg):
     check("deepcopy forward", a, b, 1e-6)
 
 
+def test_many_forwards_before_one_backward_and_freezeD(sg):
+    """Five discriminator forwards feed ONE backward (gradient-penalty style D steps, bCR / zCR): every forward keeps its own
+    spectral-norm state until its backward has run (the weight-bank ring grows instead of recycling a live slot), so the summed
+    gradient equals the sum of five separate single-forward backwards run from the same u / v state. Then freezeD: the first
+    blocks frozen, real images without grad -- the forward must still take a graph slot."""
+    from studiogan_amd.bank import get_bank
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("sngan32")
+    _, D = build_from_yaml(meta["yaml"], False, dev)
+    init = {k: v.to(dev) for k, v in sub(fix, "D_init/").items()}
+    D.load_state_dict(init, strict=True)
+    D.train()
+    xs = [(fix[f"in/real{i % 2}"] * (1.0 - 0.1 * i)).to(dev) for i in range(5)]
+    lab = fix["in/rl0"].to(dev)
+    # reference run: one forward + backward at a time; u / v advance by one power iteration per forward either way
+    total = None
+    for x in xs:
+        for p in D.parameters():
+            p.grad = None
+        D(x, lab)["adv_output"].sum().backward()
+        g = {k: p.grad.detach().clone() for k, p in D.named_parameters()}
+        total = g if total is None else {k: total[k] + g[k] for k in g}
+    D.load_state_dict(init, strict=True)
+    for p in D.parameters():
+        p.grad = None
+    outs = [D(x, lab)["adv_output"].sum() for x in xs]          # five graphs alive at once
+    bank = get_bank(D, D.compute_dtype)
+    assert len(bank.slots) - 1 >= 5, "five live forwards need five graph slots"
+    sum(outs).backward()
+    torch.cuda.synchronize()
+    C = Collector()
+    gm = max(float(v.abs().max()) for v in total.values())
+    for k, p in D.named_parameters():
+        C.check("5-forward grad " + k, p.grad, total[k], 2e-5, floor=1e-2 * gm)
+    # freezeD (reference src/utils/misc.py:199-216): first block frozen, input without grad
+    for k, p in D.named_parameters():
+        p.requires_grad = not k.startswith("blocks.0.")
+        p.grad = None
+    D(xs[0], lab)["adv_output"].sum().backward()
+    torch.cuda.synchronize()
+    for k, p in D.named_parameters():
+        if k.startswith("blocks.0."):
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0
+        elif "bias" not in k:
+            assert p.grad is not None and float(p.grad.abs().max()) > 0.0, k
+    C.finish()
+
+
 @pytest.mark.parametrize("name", ALL)
 def test_training_step_stagewise_vs_oracle(sg, name):
     """Same step, fp32, with the CPU oracle executed side by side and compared after EVERY update; after each update
