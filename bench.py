@@ -218,10 +218,17 @@ def main():
         sys.stderr.write(f"[bench] warmup {args.warmup} step(s): {time.perf_counter() - tw:.2f}s\n")
     L.call("sg_prof_enable", 1)
     t0 = time.perf_counter()
+    last = None
     for i in range(args.steps):
-        w.step(args.warmup + i, real)
+        last = w.step(args.warmup + i, real)
     barrier()
     elapsed = time.perf_counter() - t0
+    # the step must have produced numbers: finite losses of the last timed step (read AFTER the timed region: a host sync)
+    d_last, g_last = (float(last[0]), float(last[1])) if last is not None else (float("nan"), float("nan"))
+    import math
+    assert math.isfinite(d_last) and math.isfinite(g_last), f"non-finite losses after the timed steps: D {d_last} G {g_last}"
+    fake_chk = w.last_g[0]
+    assert bool(torch.isfinite(fake_chk).all()) and float(fake_chk.abs().max()) <= 1.0, "generator images of the last step are not finite / not in [-1, 1]"
     prof = (ctypes.c_double * 9)()
     L.call("sg_prof_collect", prof, 3)
     L.call("sg_prof_enable", 0)
@@ -313,6 +320,7 @@ def main():
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if mixed else "f32", "data": "synthetic",
+        "last_step_losses": {"d_loss": round(d_last, 5), "g_loss": round(g_last, 5)},
         "config": {"workload": wl["desc"], "per_gpu_batch": args.batch, "global_batch": global_batch, "d_updates_per_step": wl["n_d"],
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
@@ -320,6 +328,7 @@ def main():
                      "kernel": "convolution engine: sg_conv_v3_kernel (3x3 halo) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
+                     "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),
                      "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
     }

@@ -99,14 +99,47 @@ CONFIGS = {
               "LOSS": {"adv_loss": "hinge"},
               "OPTIMIZATION": {"batch_size": 8, "d_updates_per_step": 2}},
         batch=8, n_d=2, seed=100, compact=True),
+    # ---- FULL-WIDTH fixtures: the configurations bench.py measures, at their real channel widths / resolutions, so that the kernels the
+    # benchmark dispatches (halo conv_v3, streaming conv_sk, conv_v2, wgrad_v2, fused attention at HW = 4096) are the ones under test.
+    # C3 = configs/ImageNet/BigGAN-256.yaml verbatim (ch 96, 128^2, z 120, shared 128, 1000 classes, attention G@64^2 / D@64^2), batch 4
+    "biggan128w": dict(
+        yaml={"DATA": {"name": "ImageNet", "img_size": 128, "num_classes": 1000},
+              "MODEL": {"backbone": "big_resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [4], "attn_d_loc": [1], "z_dim": 120, "g_shared_dim": 128, "g_conv_dim": 96, "d_conv_dim": 96},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 4, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=4, n_d=2, seed=31, compact=True, sample=512),
+    # C2 = configs/CIFAR10/SNGAN.yaml verbatim (resnet, ch 64: G 256 channels, D 128), batch 16
+    "sngan32w": dict(
+        yaml={"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+              "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 16, "d_updates_per_step": 2}},
+        batch=16, n_d=2, seed=32, compact=True, sample=512),
+    # C5 = configs/CIFAR10/WGAN-GP.yaml at img_size 128 (resnet ch 64, unconditional, no SN => batch norm in D, wasserstein + GP), batch 2
+    "wgangp128w": dict(
+        yaml={"DATA": {"name": "ImageNet", "img_size": 128, "num_classes": 1000},
+              "MODEL": {"backbone": "resnet"},
+              "LOSS": {"adv_loss": "wasserstein", "apply_gp": True, "gp_lambda": 10.0},
+              "OPTIMIZATION": {"batch_size": 2, "d_updates_per_step": 2}},
+        batch=2, n_d=2, seed=33, compact=True, sample=512),
+    # C4 family = configs/ImageNet/BigGAN-Deep-2048.yaml model section verbatim (big_resnet_deep_legacy, ch 128, depth 2, 128^2), batch 2
+    "bigdeep128w": dict(
+        yaml={"DATA": {"name": "ImageNet", "img_size": 128, "num_classes": 1000},
+              "MODEL": {"backbone": "big_resnet_deep_legacy", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [4], "attn_d_loc": [1], "z_dim": 128, "g_shared_dim": 128, "g_conv_dim": 128, "d_conv_dim": 128,
+                        "g_depth": 2, "d_depth": 2},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 2, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=2, n_d=2, seed=34, compact=True, sample=512),
 }
 
 SAMPLE = 2048          # compact fixtures: tensors above FULL_MAX elements keep SAMPLE evenly spaced values + [sum, l2]
 FULL_MAX = 8192
 
 
-def sample_index(numel):
-    return (torch.arange(SAMPLE, dtype=torch.int64) * numel) // SAMPLE
+def sample_index(numel, n=SAMPLE):
+    return (torch.arange(n, dtype=torch.int64) * numel) // n
 
 
 def formula_state(spec, seed):
@@ -138,12 +171,12 @@ def formula_state(spec, seed):
     return out
 
 
-def compact_entries(key, v):
+def compact_entries(key, v, sample=SAMPLE):
     """fixture entries for one expected tensor of a compact fixture."""
-    if v.numel() <= FULL_MAX:
+    if v.numel() <= min(FULL_MAX, 4 * sample):
         return {"exp/" + key: v}
     flat = v.reshape(-1)
-    return {"exps/" + key: flat[sample_index(flat.numel())].clone(),
+    return {"exps/" + key: flat[sample_index(flat.numel(), sample)].clone(),
             "expn/" + key: torch.tensor([float(flat.double().sum()), float(flat.double().norm())], dtype=torch.float64)}
 
 
@@ -275,6 +308,8 @@ def main():
         meta = {"yaml": y, "batch": c["batch"], "n_d": c["n_d"], "seed": c["seed"]}
         if compact:
             meta["compact"] = True
+            if c.get("sample"):
+                meta["sample"] = c["sample"]
             meta["G_spec"] = {k: list(v.shape) for k, v in Gen.state_dict().items()}
             meta["D_spec"] = {k: list(v.shape) for k, v in Dis.state_dict().items()}
             Gen.load_state_dict(formula_state(meta["G_spec"], c["seed"]), strict=True)
@@ -300,7 +335,7 @@ def main():
             err = float((a - b).abs().max() / (a.abs().max() + 1e-12))
             worst[fam] = max(worst.get(fam, 0.0), err)
             if compact:
-                fix.update(compact_entries(k, v))
+                fix.update(compact_entries(k, v, c.get("sample", SAMPLE)))
             else:
                 fix["exp/" + k] = v
         print(name, "restatement vs reference, max relative-to-range error per family:")

@@ -36,6 +36,10 @@ NAMES = ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32",
 @pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("name", NAMES)
 def test_discriminator_fwd_bwd(sg, name, mixed):
+    discriminator_fwd_bwd(name, mixed)
+
+
+def discriminator_fwd_bwd(name, mixed):
     dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
     y = meta["yaml"]
@@ -47,7 +51,7 @@ def test_discriminator_fwd_bwd(sg, name, mixed):
     D.train()
     x = fix["in/real0"].clone()
     lab = fix["in/rl0"]
-    gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1])[:x.shape[0]]
+    gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1]).repeat((x.shape[0] + 7) // 8)[:x.shape[0]]
     # oracle
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     xo = x.clone().requires_grad_(True)
@@ -85,6 +89,10 @@ def test_discriminator_fwd_bwd(sg, name, mixed):
 @pytest.mark.parametrize("bn_mode", ["track", "untrack", "eval"])
 @pytest.mark.parametrize("name", NAMES)
 def test_generator_fwd_bwd(sg, name, mixed, bn_mode):
+    generator_fwd_bwd(name, mixed, bn_mode)
+
+
+def generator_fwd_bwd(name, mixed, bn_mode):
     from studiogan_amd import worker as W
     dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
@@ -106,7 +114,8 @@ def test_generator_fwd_bwd(sg, name, mixed, bn_mode):
         G.train()
         G.apply(W.track_bn_statistics if bn_mode == "track" else W.untrack_bn_statistics)
     z, lab = fix["in/z0"], fix["in/fl0"]
-    gimg = torch.randn(z.shape[0], 3, 32, 32, generator=torch.Generator().manual_seed(11))
+    S = y["DATA"]["img_size"]
+    gimg = torch.randn(z.shape[0], 3, S, S, generator=torch.Generator().manual_seed(11))
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
     img_o = O.model_fns(ocfg)[0](z, lab, leaves, B, bn_mode=bn_mode)
     (img_o * gimg).sum().backward()
@@ -301,6 +310,10 @@ def test_dra_penalty_lecam_and_uint8_input(sg):
 @pytest.mark.parametrize("which", ["D", "G"])
 @pytest.mark.parametrize("name", NAMES)
 def test_bf16_vs_emulating_oracle(sg, name, which):
+    bf16_vs_emulating_oracle(name, which)
+
+
+def bf16_vs_emulating_oracle(name, which, report=None):
     """bf16 mode against the oracle run with `Bf16Emu` (oracle/restate.py): the same bf16 rounding at the same storage points
     (activations, activation gradients, weight images), fp32 everywhere else. Per operator the model is exact to 3e-5
     (conv / BN forward + backward) and 8e-3 (attention backward) -- tools/diag_bf16.py, measured on MI355X; over a whole
@@ -324,7 +337,7 @@ def test_bf16_vs_emulating_oracle(sg, name, which):
     tg = 0.15 if (meta.get("compact") or name in ("bigdeep32", "bigdeepsg32")) else 8e-2     # bigdeep32: 48 ReLU layers deep
     if which == "D":
         x, lab = fix["in/real0"].clone(), fix["in/rl0"]
-        gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1])[:x.shape[0]]
+        gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1]).repeat((x.shape[0] + 7) // 8)[:x.shape[0]]
         xo = x.clone().requires_grad_(True)
         adv_o, h_o = O.model_fns(ocfg)[1](xo, lab, leaves, B)
         (adv_o * gadv).sum().backward()
@@ -337,7 +350,8 @@ def test_bf16_vs_emulating_oracle(sg, name, which):
         C.check("D dx", xd.grad, xo.grad, tg, l2=True)
     else:
         z, lab = fix["in/z0"], fix["in/fl0"]
-        gimg = torch.randn(z.shape[0], 3, 32, 32, generator=torch.Generator().manual_seed(11))
+        S = y["DATA"]["img_size"]
+        gimg = torch.randn(z.shape[0], 3, S, S, generator=torch.Generator().manual_seed(11))
         img_o = O.model_fns(ocfg)[0](z, lab, leaves, B, bn_mode="track")
         (img_o * gimg).sum().backward()
         img = G(z.to(dev), lab.to(dev))
@@ -348,4 +362,6 @@ def test_bf16_vs_emulating_oracle(sg, name, which):
     for k, p in net.named_parameters():
         # the attention gate is ONE scalar summing dy * conv(o) over every pixel: judged on the network's gradient scale
         C.check(which + " grad " + k, p.grad, leaves[k].grad, tg, floor=(1.0 if k.endswith("sigma") else 1e-2) * gmax, l2=True)
+    if report is not None:
+        report.extend(C.rows)
     C.finish()

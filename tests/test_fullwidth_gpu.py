@@ -1,0 +1,77 @@
+"""GPU: parity of the BENCHMARKED configurations at their real channel widths and resolutions (tests/golden/*w: BigGAN-128 ch 96 =
+configs/ImageNet/BigGAN-256.yaml, SNGAN-32 ch 64, WGAN-GP ResNet-128, BigGAN-deep-128 ch 128), with the tile-count / problem-size
+heuristics of the dispatchers switched off (SG_CONV_V3 / SG_CONV_V2 / SG_CONV_SK = force, SG_WGRAD_BJ256 = force) so that the
+kernels bench.py runs at batch 256 -- halo conv_v3 (incl. the 96x512 tile), streaming conv_sk, conv_v2, wgrad_v2 (both cout tiles),
+fused attention at HW = 4096 -- are the kernels under test at the fixtures' small batch.
+
+Three comparisons per fixture (the width-8 fixtures get the same three in test_model_gpu.py / test_blocks_gpu.py):
+  * one full training step against the golden vectors written by the REAL reference (fp32 and bf16),
+  * the same step in fp32 against the CPU oracle, re-synchronised after every update (tight per-update bound),
+  * bf16 forward / backward of D and G against the bf16-emulating oracle (forward <= 2e-2; gradient relative-L2 reported).
+The measured errors are written to gpurun_out/fullwidth_parity.txt when that directory is writable."""
+import os
+
+import pytest
+import torch
+
+from test_model_gpu import step_vs_golden, stagewise_vs_oracle
+from test_blocks_gpu import bf16_vs_emulating_oracle, discriminator_fwd_bwd, generator_fwd_bwd
+
+pytestmark = pytest.mark.gpu
+
+WIDE = ["biggan128w", "sngan32w", "wgangp128w", "bigdeep128w"]
+
+
+@pytest.fixture
+def forced(monkeypatch):
+    for k in ("SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_WGRAD_BJ256", "SG_WGRAD_V3"):
+        monkeypatch.setenv(k, "force")
+
+
+def _dump(tag, rows):
+    d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "fullwidth_parity.txt"), "a") as f:
+            worst = {}
+            for n, e, t in rows:
+                fam = n.split(" ")[0] + " " + (n.split(" ")[1] if " " in n else "")
+                fam = fam.split(".")[0]
+                if e > worst.get(fam, (0, 0))[0]:
+                    worst[fam] = (e, t)
+            for fam, (e, t) in sorted(worst.items()):
+                f.write(f"{tag:40s} {fam:40s} worst err {e:.3e} (tol {t:.1e})\n")
+    except OSError:
+        pass
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("name", WIDE)
+def test_fullwidth_step_vs_golden(sg, forced, name, mixed):
+    step_vs_golden(name, mixed)
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_fullwidth_step_stagewise_vs_oracle(sg, forced, name):
+    rows = []
+    try:
+        stagewise_vs_oracle(name, t=1e-3, report=rows)
+    finally:
+        _dump("stagewise fp32 " + name, rows)
+
+
+@pytest.mark.parametrize("which", ["D", "G"])
+@pytest.mark.parametrize("name", WIDE)
+def test_fullwidth_bf16_vs_emulating_oracle(sg, forced, name, which):
+    rows = []
+    try:
+        bf16_vs_emulating_oracle(name, which, report=rows)
+    finally:
+        _dump(f"bf16-emu {which} " + name, rows)
+
+
+@pytest.mark.parametrize("mixed", [False, True])
+@pytest.mark.parametrize("name", WIDE)
+def test_fullwidth_networks_fwd_bwd(sg, forced, name, mixed):
+    discriminator_fwd_bwd(name, mixed)
+    generator_fwd_bwd(name, mixed, "track")

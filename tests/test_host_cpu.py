@@ -91,7 +91,7 @@ def test_module_names_and_sn_state():
     assert torch.allclose(w @ w.t(), torch.eye(16), atol=1e-4)
 
 
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32", "bigdeepsg32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "bigdeep32", "bigdeepsg32", "sngan32w", "wgangp128w"])
 def test_golden_state_dict_keys_match_backbone(name):
     from util import load_golden, sub
     from test_model_gpu import build_from_yaml
@@ -205,3 +205,100 @@ def test_weight_bank_ring_never_recycles_a_live_slot():
     with pytest.raises(RuntimeError):
         fb.take()
     del held
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+@pytest.mark.parametrize("name", ["biggan32", "sngan32"])
+def test_boundary_through_the_references_own_loader(name):
+    """The drop-in boundary driven by the REFERENCE's code: the mirrors registered as `models.<backbone>`,
+    `config.define_modules` resolving its factories from studiogan_amd.ops, then the unmodified
+    reference src/models/model.py:19-155 load_generator_discriminator, config.define_optimizer (src/config.py:497-563),
+    utils.ema.Ema, utils.misc.make_GAN_untrainable / toggle_grad (freezeD) and strict state_dict interchange with the reference's own
+    modules. Construction, .to(), deepcopy, EMA and state handling are pure host logic and run on CPU; a forward would need the GPU."""
+    import importlib
+    import logging
+    import sys
+    from oracle import ref_import as R
+    from oracle import make_golden as MG
+    from studiogan_amd import ops as sg_ops
+    from studiogan_amd.optim import FusedAdam
+    R._prepare()
+    import config                                   # reference src/config.py
+    y = copy.deepcopy(MG.CONFIGS[name]["yaml"])
+    y["MODEL"].update(apply_g_ema=True, g_ema_decay=0.9, g_ema_start=0)
+    backbone = y["MODEL"]["backbone"]
+    run = {"mixed_precision": False, "distributed_data_parallel": False, "synchronized_bn": False}
+    # the reference's own build of the same configuration (its utils.ops): the contract to match
+    cfgs_ref = R.load_cfgs(y)
+    cfgs_ref.update_cfgs(run, super="RUN")
+    torch.manual_seed(0)
+    Gr, Dr = R.build_models(cfgs_ref)
+    saved_ops, saved_mod = config.ops, sys.modules.get("models." + backbone)
+    try:
+        config.ops = sg_ops                          # INTEGRATION.md §3: `import studiogan_amd.ops as ops` in src/config.py
+        sys.modules["models." + backbone] = importlib.import_module("studiogan_amd.backbones." + backbone)     # §2: register under the existing name
+        cfgs = R.load_cfgs(y)
+        cfgs.update_cfgs(run, super="RUN")
+        cfgs.define_modules()
+        assert cfgs.MODULES.d_conv2d is sg_ops.snconv2d and cfgs.MODULES.g_bn is sg_ops.ConditionalBatchNorm2d
+        model = importlib.import_module("models.model")
+        Gen, _, _, Dis, Gen_ema, _, _, ema = model.load_generator_discriminator(
+            cfgs.DATA, cfgs.OPTIMIZATION, cfgs.MODEL, cfgs.STYLEGAN, cfgs.MODULES, cfgs.RUN, "cpu", logging.getLogger("boundary-test"))
+    finally:
+        config.ops = saved_ops
+        if saved_mod is not None:
+            sys.modules["models." + backbone] = saved_mod
+        else:
+            sys.modules.pop("models." + backbone, None)
+    assert type(Gen).__module__.startswith("studiogan_amd.") and type(Dis).__module__.startswith("studiogan_amd.")
+    # EMA twin: the reference's deepcopy + its Ema class on the mirror (utils/ema.py:11-40)
+    assert type(ema).__module__ == "utils.ema" and Gen_ema is not Gen
+    p0, e0 = next(Gen.parameters()), next(Gen_ema.parameters())
+    assert torch.equal(p0, e0) and p0.data_ptr() != e0.data_ptr()
+    with torch.no_grad():
+        p0.add_(1.0)
+    ema.update(5)
+    assert torch.allclose(e0, p0 - 1.0 + 0.1, atol=1e-6)                    # lerp(p, p_ema, 0.9)
+    # same parameter / buffer names and shapes as the reference's modules; strict interchange both ways (src/utils/ckpt.py:38)
+    for mine, ref in ((Gen, Gr), (Dis, Dr)):
+        a, b = mine.state_dict(), ref.state_dict()
+        assert list(a.keys()) == list(b.keys())
+        assert all(a[k].shape == b[k].shape and a[k].dtype == b[k].dtype for k in a)
+        mine.load_state_dict(b, strict=True)
+        ref.load_state_dict(mine.state_dict(), strict=True)
+        assert [k for k, _ in mine.named_parameters()] == [k for k, _ in ref.named_parameters()]
+    misc = importlib.import_module("utils.misc")
+    assert misc.count_parameters(Gen) == misc.count_parameters(Gr) and misc.count_parameters(Dis) == misc.count_parameters(Dr)
+    assert Gen.in_dims == Gr.in_dims and Dis.in_dims == Dr.in_dims          # misc.py:199 reads .in_dims for freezeD
+    # the driver's mode / freeze helpers (misc.py:190-216,239-267,356-364)
+    misc.make_GAN_untrainable(Gen, Gen_ema, Dis)
+    for m in Dis.modules():
+        if isinstance(m, (nn.Conv2d, nn.Linear, nn.Embedding)):
+            assert m.training, "SN layers keep iterating in eval mode (misc.py:254-262)"
+    for m in Gen.modules():
+        if isinstance(m, nn.modules.batchnorm._BatchNorm):
+            assert not m.training
+    misc.make_GAN_trainable(Gen, Gen_ema, Dis)
+    misc.toggle_grad(Dis, grad=True, num_freeze_layers=1, is_stylegan=False)
+    frozen = {k for k, p in Dis.named_parameters() if not p.requires_grad}
+    frozen_ref = None
+    misc.toggle_grad(Dr, grad=True, num_freeze_layers=1, is_stylegan=False)
+    frozen_ref = {k for k, p in Dr.named_parameters() if not p.requires_grad}
+    assert frozen == frozen_ref and frozen and all(k.startswith("blocks.0.") for k in frozen)
+    misc.toggle_grad(Dis, grad=True, num_freeze_layers=-1, is_stylegan=False)
+    # optimizer seam (src/config.py:541-563): torch.optim.Adam(eps=1e-6) as the reference builds it, and FusedAdam in its place
+    cfgs.define_optimizer(Gen, Dis)
+    go = cfgs.OPTIMIZATION.g_optimizer
+    assert isinstance(go, torch.optim.Adam) and go.param_groups[0]["eps"] == 1e-6
+    fo = FusedAdam(Gen.parameters(), lr=go.param_groups[0]["lr"], betas=go.param_groups[0]["betas"], eps=1e-6)
+    fo.load_state_dict(go.state_dict())
+    assert fo.param_groups[0]["lr"] == cfgs.OPTIMIZATION.g_lr
+    # losses seam (src/config.py:411-433): same names, same (…, DDP=…) signature
+    from studiogan_amd import losses as sg_losses
+    ref_losses = importlib.import_module("utils.losses")
+    for fn in ("d_hinge", "g_hinge", "d_vanilla", "g_vanilla", "d_wasserstein", "g_wasserstein", "cal_grad_penalty", "cal_deriv", "cal_r1_reg",
+               "cal_maxgrad_penalty", "cal_dra_penalty", "lecam_reg", "adjust_k"):
+        assert hasattr(sg_losses, fn) and hasattr(ref_losses, fn), fn
+    # the product path has no CPU fallback: a forward on CPU raises instead of silently computing something else
+    with pytest.raises(RuntimeError):
+        Gen(torch.randn(2, cfgs.MODEL.z_dim), torch.zeros(2, dtype=torch.long))

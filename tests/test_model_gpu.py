@@ -39,6 +39,10 @@ def test_training_step_vs_golden(sg, name, mixed):
     if mixed and name in ("bigdeep32", "bigdeepsg32"):
         pytest.skip("48 ReLU layers at width 8: bf16 vs the fp32 golden chain is noise (30-60 %); bf16 parity of this network is "
                     "asserted by test_bf16_vs_emulating_oracle, the fp32 chain by the non-mixed variant")
+    step_vs_golden(name, mixed)
+
+
+def step_vs_golden(name, mixed):
     from studiogan_amd.worker import Worker
     dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
@@ -175,6 +179,10 @@ def test_many_forwards_before_one_backward_and_freezeD(sg):
 
 @pytest.mark.parametrize("name", ALL)
 def test_training_step_stagewise_vs_oracle(sg, name):
+    stagewise_vs_oracle(name)
+
+
+def stagewise_vs_oracle(name, t=5e-4, report=None):
     """Same step, fp32, with the CPU oracle executed side by side and compared after EVERY update; after each update
     the oracle's parameters and buffers are RE-SYNCHRONISED from the HIP path, so every update is judged on identical
     inputs. (Without that, Adam turns the rounding noise of elements with |g| ~ eps into +-lr-sized parameter
@@ -206,7 +214,6 @@ def test_training_step_stagewise_vs_oracle(sg, name):
     C = Collector()
     wide = bool(meta.get("compact"))
     lam = opt["gp_lambda"] if opt["apply_gp"] else None
-    t = 5e-4
     tg = 1e-2 if wide else 5e-4        # wide: l2 metric (a handful of ~1e6 ReLU units per layer sit within fp32 rounding of 0)
 
     def resync(mod, P, Bf):
@@ -253,4 +260,6 @@ def test_training_step_stagewise_vs_oracle(sg, name):
             C.check(f"[G] param {k}", p, GP[k], t, floor=0.05, l2=True)
     for k, b in D.named_buffers():
         C.check(f"[G] Dbuf {k}", b, DB[k], t)
+    if report is not None:
+        report.extend(C.rows)
     C.finish()

@@ -25,7 +25,8 @@ def _run_restatement(name):
     return fix, exp
 
 
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32", "bigdeep32", "bigdeepsg32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "resgan32", "dcgan32", "sndcgan32", "wgangp32", "sngp32", "bigdeep32", "bigdeepsg32",
+                                  "biggan128w", "sngan32w"])      # (wgangp128w / bigdeep128w: bit-identity asserted when oracle/make_golden.py wrote them)
 def test_restatement_matches_golden(name):
     fix, exp = _run_restatement(name)
     gold = sub(fix, "exp/")
@@ -35,7 +36,7 @@ def test_restatement_matches_golden(name):
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
-@pytest.mark.parametrize("name", ["biggan32", "sngan32", "dcgan32", "wgangp32", "bigdeep32", "bigdeepsg32"])
+@pytest.mark.parametrize("name", ["biggan32", "sngan32", "dcgan32", "wgangp32", "bigdeep32", "bigdeepsg32", "biggan128w"])
 def test_golden_regenerates_from_reference(name):
     """The committed fixture is exactly what the reference produces today (guards against stale fixtures)."""
     from oracle import ref_import as R

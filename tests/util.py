@@ -18,7 +18,7 @@ class Sampled:
     def pick(self, a):
         from oracle.make_golden import sample_index
         flat = a.detach().reshape(-1)
-        return flat[sample_index(flat.numel()).to(flat.device)]
+        return flat[sample_index(flat.numel(), self.values.numel()).to(flat.device)]
 
     def absmax(self):
         return float(self.values.abs().max())
