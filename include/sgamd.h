@@ -38,6 +38,7 @@ typedef void* sg_stream_t; /* hipStream_t */
 
 #define SG_DTYPE_F32 0
 #define SG_DTYPE_BF16 1
+#define SG_DTYPE_F64 2 /* collectives only */
 
 /* activation-view flags (pix_flags / x_flags / g_flags) */
 #define SG_PIX_RELU 1
@@ -142,6 +143,20 @@ int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C
  * (unbiased variance, momentum) -- torch.nn.functional.batch_norm training semantics */
 int sg_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, sg_stream_t s);
+/* ---- data-parallel exchanges over RCCL (one process per GPU; replaces DistributedDataParallel's bucketed gradient all-reduce and
+ * SyncBatchNorm's statistics exchange, reference src/models/model.py:157-180). librccl is bound at run time (dlopen). ----------- */
+typedef void* sg_comm_t; /* ncclComm_t */
+/* rank 0: 128-byte RCCL unique id, to be handed to every rank by the host (any out-of-band channel) */
+int sg_comm_unique_id(void* out128);
+int sg_comm_init_rank(const void* id128, int nranks, int rank, sg_comm_t* comm);
+int sg_comm_size(sg_comm_t comm, int* nranks);
+int sg_comm_destroy(sg_comm_t comm);
+/* in-place sum of a flat device buffer over the ranks of comm, enqueued on s; dtype SG_DTYPE_F32 (gradient arena) or SG_DTYPE_F64 (BN terms) */
+int sg_allreduce_flat(sg_comm_t comm, void* buf, long long count, int dtype, sg_stream_t s);
+/* sync-BN statistics in one call: local partial sums -> all-reduce over comm (NULL = single rank) -> mean / invstd (+ running
+ * statistics when running_mean != NULL), count = rows * nranks; partial = fp64 scratch [2*C] */
+int sg_bn_stats_sync(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_comm_t comm, float eps, float momentum,
+                     float* mean, float* invstd, float* running_mean, float* running_var, sg_stream_t s);
 /* eval mode: mean/invstd from running stats */
 int sg_bn_from_running(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, sg_stream_t s);
 /* y = relu?( (x-mean)*invstd * gain + bias ), gain/bias either per-channel [C] (stride_n = 0) or per-sample [N][C] */

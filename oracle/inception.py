@@ -2,13 +2,15 @@
 
 TEST INFRASTRUCTURE ONLY (see oracle/restate.py header).
 
-PARITY UNPINNED for pretrained weights: the reference builds torchvision.models.inception_v3 (torchvision is neither
-vendored in /root/reference nor installed here; the docker pin is torch 1.13 / torchvision 0.14) and downloads
-`pt_inception-2015-12-05-6726825d.pth` at run time (inception_net.py:13,130) -- unavailable offline. This file restates
-the published torchvision structure (BasicConv2d = Conv2d(bias=False) -> BatchNorm2d(eps=1e-3) -> ReLU; Inception A/B/C/D/E)
-with the FID patches of inception_net.py:135-249 (average pools with count_include_pad=False in A, C, E_1; max pool in
-E_2; fc 2048 -> 1008), keyed by torchvision's state_dict names so the real FID weights would load. Weights here are
-seeded random; what the tests pin is therefore structure + arithmetic, not FID values.
+Pin: the reference's OWN code (fid_inception_v3, FIDInceptionA / C / E_1 / E_2.forward, InceptionV3.__init__ / forward) runs on CPU
+with oracle/tv_stub.py standing in for the absent torchvision and this file's seeded weights as the "downloaded" checkpoint;
+tests/test_oracle_cpu.py::test_inception_oracle_pinned_to_the_references_own_code asserts bit-identity block by block and end to end
+at 299 x 299. PARITY UNPINNED only for the VALUES of the pretrained checkpoint: the reference downloads
+`pt_inception-2015-12-05-6726825d.pth` at run time (inception_net.py:13,130) -- unavailable offline -- and torchvision itself (docker pin
+torch 1.13 / torchvision 0.14) is restated from its published structure (BasicConv2d = Conv2d(bias=False) -> BatchNorm2d(eps=1e-3) ->
+ReLU; Inception A/B/C/D/E), not executed. This file restates that structure with the FID patches of inception_net.py:135-249 (average
+pools with count_include_pad=False in A, C, E_1; max pool in E_2; fc 2048 -> 1008), keyed by torchvision's state_dict names so the
+real FID weights load.
 """
 import math
 

@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgamd.so")
 CSRC = os.path.join(_HERE, "csrc")
 
-F32, BF16 = 0, 1
+F32, BF16, F64 = 0, 1, 2
 PIX_RELU, PIX_UPSAMPLE, PIX_QUAD, PIX_TRANSPOSED = 1, 2, 4, 8
 EPI_OUT_F32, EPI_ATOMIC, EPI_POOL, EPI_RELU, EPI_RES_F32 = 1, 2, 4, 8, 16
 
@@ -93,6 +93,12 @@ _PROTOS = {
     "sg_colsum": [_i, _vp, _i, _vp, _i, _ll, _i, _vp, _f, _vp],
     "sg_bn_partial_stats": [_i, _vp, _i, _ll, _i, _vp, _vp],
     "sg_bn_finalize": [_vp, C.c_double, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_comm_unique_id": [_vp],
+    "sg_comm_init_rank": [_vp, _i, _i, C.POINTER(_vp)],
+    "sg_comm_size": [_vp, C.POINTER(_i)],
+    "sg_comm_destroy": [_vp],
+    "sg_allreduce_flat": [_vp, _vp, _ll, _i, _vp],
+    "sg_bn_stats_sync": [_i, _vp, _i, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sg_bn_from_running": [_vp, _vp, _i, _f, _vp, _vp, _vp],
     "sg_bn_apply": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "sg_bn_bwd_reduce": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],

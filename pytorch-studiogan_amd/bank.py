@@ -168,7 +168,8 @@ class _Slot:
 
 
 class WeightBank:
-    SN_SPLITS = 8
+    SN_SPLITS = 16          # row groups of csrc/sn.hip k_sn_wtu (same constant there)
+    SNB_BLOCKS = 512        # block partials of csrc/sn.hip k_snb_dot
 
     def __init__(self, root, compute_dtype, nslots=4, eps=1e-6):
         self.root_ref = weakref.ref(root)
@@ -231,7 +232,7 @@ class WeightBank:
             work += self.SN_SPLITS * r.cols + r.rows
             m._sg_rt = r
             self.layers.append(r)
-        self.work = torch.zeros(max(work, 64 * len(layers)) + 64, device=dev, dtype=torch.float32)
+        self.work = torch.zeros(max(work, self.SNB_BLOCKS * len(layers)) + 64, device=dev, dtype=torch.float32)
         self._sizes = (img_elems, f32_elems, dwt_elems, uv_elems)
         self.slots = []
         for s in range(nslots):

@@ -300,25 +300,38 @@ extern "C" int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N,
   SG_LAUNCH_CHECK();
   return 0;
 }
-__global__ void k_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gsn, float* dgain, float* dbias, double* chan) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// grid (C / 64), block (64 channels x 16 sample groups): the per-sample partial sums of sg_bn_bwd_reduce -> per-channel fp64 terms of
+// the batch-statistics gradient, plus the (conditional) gain / bias gradients. One thread per channel walking all N samples (the
+// first version) was a 256-long dependent chain per launch: 226 us average in the r01 trace for a few KB of data.
+__global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gsn, float* dgain, float* dbias, double* chan) {
+  __shared__ double sa0[16][64], sa1[16][64];
+  __shared__ float sg0[16][64], sg1[16][64];
+  const int cl = threadIdx.x & 63, grp = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
   double a0 = 0.0, a1 = 0.0; float g0 = 0.f, g1 = 0.f;
-  for (int n = 0; n < N; n++) {
-    const float s1 = sums[((long long)n * C + c) * 2], s2 = sums[((long long)n * C + c) * 2 + 1];
-    const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
-    a0 += (double)ga * s1; a1 += (double)ga * s2;
-    if (gsn) {
-      if (dgain) dgain[(long long)n * C + c] += s2;
-      if (dbias) dbias[(long long)n * C + c] += s1;
-    } else { g0 += s1; g1 += s2; }
+  if (c < C) {
+    for (int n = grp; n < N; n += 16) {
+      const float s1 = sums[((long long)n * C + c) * 2], s2 = sums[((long long)n * C + c) * 2 + 1];
+      const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
+      a0 += (double)ga * s1; a1 += (double)ga * s2;
+      if (gsn) {
+        if (dgain) dgain[(long long)n * C + c] += s2;
+        if (dbias) dbias[(long long)n * C + c] += s1;
+      } else { g0 += s1; g1 += s2; }
+    }
   }
-  if (!gsn) { if (dgain) dgain[c] += g1; if (dbias) dbias[c] += g0; }
-  chan[2 * c] = a0; chan[2 * c + 1] = a1;
+  sa0[grp][cl] = a0; sa1[grp][cl] = a1; sg0[grp][cl] = g0; sg1[grp][cl] = g1;
+  __syncthreads();
+  if (grp == 0 && c < C) {
+    a0 = 0.0; a1 = 0.0; g0 = 0.f; g1 = 0.f;
+    for (int g = 0; g < 16; g++) { a0 += sa0[g][cl]; a1 += sa1[g][cl]; g0 += sg0[g][cl]; g1 += sg1[g][cl]; }   // fixed order: deterministic
+    if (!gsn) { if (dgain) dgain[c] += g1; if (dbias) dbias[c] += g0; }
+    chan[2 * c] = a0; chan[2 * c + 1] = a1;
+  }
 }
 extern "C" int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gb_stride_n, float* dgain, float* dbias, double* chan, sg_stream_t s) {
   SG_CHECK(sums && chan, "sg_bn_bwd_finalize: null");
-  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, sums, N, C, gain, gb_stride_n, dgain, dbias, chan);
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3((C + 63) / 64), dim3(1024), 0, (hipStream_t)s, sums, N, C, gain, gb_stride_n, dgain, dbias, chan);
   SG_LAUNCH_CHECK();
   return 0;
 }

@@ -8,6 +8,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import comm as _comm
 from .bank import ensure_grad
 
 
@@ -539,6 +540,16 @@ def _world(group):
     return 1
 
 
+def _allreduce_sum(t, group):
+    """sum over the data-parallel ranks: the C ABI's RCCL entry point when a native communicator serves the group (comm.enable),
+    torch.distributed otherwise."""
+    nc = _comm.native_for(group)
+    if nc is not None:
+        nc.allreduce_(t)
+    else:
+        dist.all_reduce(t, group=None if group is True else group)
+
+
 class BNFn(torch.autograd.Function):
     """y = relu?( (x - mean) * invstd * gain + bias ) with batch or running statistics.
 
@@ -556,15 +567,23 @@ class BNFn(torch.autograd.Function):
         invstd = torch.empty(Cc, dtype=torch.float32, device=dev)
         count = float(N * HW)
         if cfg.batch_stats:
-            partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
-            L.call("sg_bn_partial_stats", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), L.stream())
             ws = _world(cfg.group)
-            if ws > 1:
-                dist.all_reduce(partial, group=None if cfg.group is True else cfg.group)
-                count *= ws
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
-            L.call("sg_bn_finalize", L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
+            nc = _comm.native_for(cfg.group) if ws > 1 else None
+            if nc is not None:
+                # sync-BN statistics in ONE C-ABI call: partial sums -> RCCL all-reduce -> mean / invstd / running stats, same stream
+                partial = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+                L.call("sg_bn_stats_sync", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), nc.handle, cfg.eps, cfg.momentum, L.ptr(mean),
+                       L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
+                count *= ws
+            else:
+                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                L.call("sg_bn_partial_stats", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), L.stream())
+                if ws > 1:
+                    dist.all_reduce(partial, group=None if cfg.group is True else cfg.group)
+                    count *= ws
+                L.call("sg_bn_finalize", L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
         else:
             L.call("sg_bn_from_running", L.ptr(running_mean), L.ptr(running_var), Cc, cfg.eps, L.ptr(mean), L.ptr(invstd), L.stream())
         gsn = 0
@@ -605,7 +624,7 @@ class BNFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.batch_stats and _world(cfg.group) > 1:
-                dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+                _allreduce_sum(chan, cfg.group)
             dx = torch.empty_like(x)
             L.call("sg_bn_bwd_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
                    gsn, 1 if cfg.relu else 0, L.ptr(chan), ctx.count, 1 if cfg.batch_stats else 0, L.stream())
@@ -628,7 +647,7 @@ class BNBwdFn(torch.autograd.Function):
         chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), 0, None, None, L.ptr(chan), L.stream())
         if cfg.batch_stats and _world(cfg.group) > 1:
-            dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+            _allreduce_sum(chan, cfg.group)
         dx = torch.empty_like(x)
         L.call("sg_bn_bwd_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
                0, 1 if cfg.relu else 0, L.ptr(chan), count, 1 if cfg.batch_stats else 0, L.stream())
@@ -652,7 +671,7 @@ class BNBwdFn(torch.autograd.Function):
         chan = chan_local
         if cfg.batch_stats and _world(cfg.group) > 1:
             chan = chan_local.clone()
-            dist.all_reduce(chan, group=None if cfg.group is True else cfg.group)
+            _allreduce_sum(chan, cfg.group)
         use_batch = 1 if cfg.batch_stats else 0
         g_dy = torch.empty_like(x) if ctx.needs_input_grad[0] else None
         g_x = torch.empty_like(x) if ctx.needs_input_grad[1] else None

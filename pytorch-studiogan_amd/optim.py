@@ -9,6 +9,7 @@ import torch
 import torch.distributed as dist
 
 from . import _lib as L
+from . import comm as _comm
 from .bank import ParamArena, arena_of, get_buffer_arena
 
 
@@ -168,7 +169,27 @@ class FusedAdam(torch.optim.Optimizer):
             # different weights would silently never converge to one model. Checked once, on the first exchange.
             assert_replicas_identical(a.data, group, "parameters of the network handed to FusedAdam")
             self._replicas_checked = True
-        if world > 1:
+        nc = _comm.native_for(group) if world > 1 else None
+        if nc is not None:
+            # the same pipeline through the C ABI (sg_allreduce_flat): the reductions queue on the communicator's side stream behind
+            # an event that marks "gradients complete"; the Adam launch of chunk i waits for ITS reduction only
+            ranges = chunk_ranges(n, self.comm_chunks)
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            nc.stream.wait_event(ready)
+            done = []
+            for lo, hi in ranges:
+                nc.allreduce_(a.grad[lo:hi], stream=nc.stream.cuda_stream)
+                ev = torch.cuda.Event()
+                ev.record(nc.stream)
+                done.append(ev)
+            for (lo, hi), ev in zip(ranges, done):
+                main.wait_event(ev)
+                L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                       self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)
+        elif world > 1:
             # pipelined all-reduce(sum) -> Adam(grad/world): chunk i+1 is on the wire while chunk i is being applied
             for lo, hi in pipelined_allreduce(a.grad, chunk_ranges(n, self.comm_chunks), group):
                 L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,

@@ -1,0 +1,164 @@
+"""GPU: the world > 1 PRODUCT path on one device -- two ranks on cuda:0 over gloo (the collectives are torch.distributed's, the
+kernels around them are the real ones): G / D forward + backward with synchronised batch norm (functional.BNFn's all-reduces of the
+statistics and of the backward channel terms), FusedAdam.step(group=...) (replica check, pipelined all-reduce of the flat gradient
+arena, 1/world folded into the Adam launch), sync_replicas -- compared with the single-rank run over the full batch:
+  * after one D update and one G update both ranks hold BIT-IDENTICAL parameters and buffers,
+  * they equal the full-batch single-rank result (gradient average == full-batch gradient of the mean-reduced loss, sync-BN
+    statistics == full-batch statistics),
+  * replicas that start from different weights are caught (assert_replicas_identical) and repaired (sync_replicas).
+Plus the native RCCL entry points of the C ABI (sg_comm_*, sg_allreduce_flat, sg_bn_stats_sync) on a one-rank communicator."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _run(rank, world, port, name, desync, ret):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    if world > 1:
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        ret[rank] = _job(rank, world, name, desync)
+    finally:
+        if world > 1:
+            dist.destroy_process_group()
+
+
+def _job(rank, world, name, desync):
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import ops
+    from studiogan_amd.worker import Worker
+    from studiogan_amd.optim import sync_replicas
+    from util import load_golden, sub, hyper
+    from test_model_gpu import build_from_yaml
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    G, D = build_from_yaml(y, False, dev)
+    G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+    D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
+    group = dist.group.WORLD if world > 1 else None
+    caught = None
+    if desync and rank == 1:                       # what per-rank seeding does to an un-broadcast model (reference src/loader.py:99)
+        with torch.no_grad():
+            for p in D.parameters():
+                p.add_(0.01 * torch.randn_like(p))
+    if desync and world > 1:
+        from studiogan_amd.optim import assert_replicas_identical, _arena_for
+        try:
+            assert_replicas_identical(_arena_for(list(D.parameters())).data, group, "D")
+            caught = False
+        except RuntimeError:
+            caught = True
+    if world > 1:
+        for m in list(G.modules()) + list(D.modules()):
+            if isinstance(m, ops.BatchNorm2d):
+                m.sync_group = True
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"] // world, opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"],
+               opt["beta2"], d_updates_per_step=1, apply_g_ema=False, group=group)      # Worker.__init__ runs sync_replicas(G / D, group)
+    ins = sub(fix, "in/")
+    h = meta["batch"] // world
+    sl = slice(rank * h, (rank + 1) * h)
+    put = lambda k: ins[k][sl].to(dev)
+    w.train_discriminator(0, [(put("real0"), put("rl0"))], [(put("z0"), put("fl0"))])
+    d_grad = {k: p.grad.detach().cpu().clone() / world for k, p in D.named_parameters()}      # the arena holds the all-reduced SUM
+    w.train_generator(0, [(put("z1"), put("fl1"))])
+    torch.cuda.synchronize()
+    g_grad = {k: p.grad.detach().cpu().clone() / world for k, p in G.named_parameters()}
+    state = {"D/" + k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    state.update({"G/" + k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+    return {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught}
+
+
+def _spawn(world, name, desync=False):
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_run, args=(world, _free_port(), name, desync, ret), nprocs=world, join=True)
+    return dict(ret)
+
+
+@pytest.mark.parametrize("name", ["resgan32", "biggan32"])     # BN in G and D (no SN) / cBN in G + SN + attention + projection D
+def test_two_ranks_on_one_gpu_equal_the_full_batch_step(sg, name):
+    from util import Collector
+    full = _spawn(1, name)[0]
+    two = _spawn(2, name)
+    a, b = two[0], two[1]
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), f"replicas diverged: {k}"
+    C = Collector()
+    gm = max(float(v.abs().max()) for v in full["d_grad"].values())
+    for k, v in full["d_grad"].items():
+        C.check("D grad " + k, a["d_grad"][k], v, 2e-4, floor=1e-2 * gm)
+    gm = max(float(v.abs().max()) for v in full["g_grad"].values())
+    for k, v in full["g_grad"].items():
+        C.check("G grad " + k, a["g_grad"][k], v, 5e-3, floor=1e-2 * gm)      # through every ReLU of D after one D update (see DESIGN "conditioning")
+    for k, v in full["state"].items():
+        if v.dtype.is_floating_point:
+            C.check("state " + k, a["state"][k], v, 2e-3, floor=0.05)
+        else:
+            assert torch.equal(a["state"][k], v), k
+    C.finish()
+
+
+def test_desynchronised_replicas_are_caught_and_repaired(sg):
+    two = _spawn(2, "sngan32", desync=True)
+    assert two[0]["caught"] is True and two[1]["caught"] is True, "assert_replicas_identical must flag replicas that differ"
+    for k in two[0]["state"]:
+        assert torch.equal(two[0]["state"][k], two[1]["state"][k]), f"sync_replicas (Worker.__init__) must leave identical replicas: {k}"
+
+
+def test_native_rccl_entry_points_single_rank(sg):
+    """sg_comm_unique_id / sg_comm_init_rank / sg_allreduce_flat / sg_bn_stats_sync on a communicator of ONE rank (the 1-GPU box cannot
+    host two RCCL ranks on one device): the all-reduce is the identity, sg_bn_stats_sync equals partial_stats + finalize."""
+    from studiogan_amd import comm, _lib as L
+    dev = torch.device("cuda:0")
+    nc = comm.NativeComm()
+    assert nc.world == 1 and nc.handle
+    t = torch.randn(100003, device=dev)
+    ref = t.clone()
+    nc.allreduce_(t)
+    d = torch.randn(77, device=dev, dtype=torch.float64)
+    dref = d.clone()
+    nc.allreduce_(d)
+    torch.cuda.synchronize()
+    assert torch.equal(t, ref) and torch.equal(d, dref)
+    x = (torch.randn(6, 5, 7, 24, device=dev) * 1.5 + 0.2).to(torch.bfloat16)
+    Cc, rows = 24, 6 * 5 * 7
+    out = []
+    for native in (True, False):
+        mean, invstd = torch.empty(Cc, device=dev), torch.empty(Cc, device=dev)
+        rm, rv = torch.zeros(Cc, device=dev), torch.ones(Cc, device=dev)
+        if native:
+            partial = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
+            L.call("sg_bn_stats_sync", L.dt(x), x.data_ptr(), Cc, rows, Cc, partial.data_ptr(), nc.handle, 1e-4, 0.1, mean.data_ptr(), invstd.data_ptr(),
+                   rm.data_ptr(), rv.data_ptr(), L.stream())
+        else:
+            partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+            L.call("sg_bn_partial_stats", L.dt(x), x.data_ptr(), Cc, rows, Cc, partial.data_ptr(), L.stream())
+            L.call("sg_bn_finalize", partial.data_ptr(), float(rows), Cc, 1e-4, 0.1, mean.data_ptr(), invstd.data_ptr(), rm.data_ptr(), rv.data_ptr(), L.stream())
+        torch.cuda.synchronize()
+        out.append((mean.cpu(), invstd.cpu(), rm.cpu(), rv.cpu()))
+    for u, v in zip(*out):
+        assert torch.equal(u, v)
+    xf = x.float().reshape(-1, Cc).double().cpu()
+    assert torch.allclose(out[0][0].double(), xf.mean(0), atol=1e-5)
+    nc.close()

@@ -29,6 +29,24 @@ def test_inception_features_vs_oracle(sg, dtype, tol):
     check("softmax(logits)", p, torch.softmax(logit.cpu().double(), 1), 1e-5)
 
 
+def test_inception_features_at_full_input_size(sg):
+    """InceptionV3 at the real evaluation geometry: 32 images already at 299 x 299 (no resize in the way), fp32 <= 2e-4 against
+    the CPU oracle (itself bit-identical to the reference's inception_net.py, tests/test_oracle_cpu.py); bf16 reported with its bound."""
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    sd = OI.random_state_dict(1)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(32, 3, 299, 299, generator=g) * 2 - 1
+    feat_o, logit_o = OI.inception_forward(x, sd)
+    for dtype, tol in ((torch.float32, 2e-4), (torch.bfloat16, 6e-2)):
+        model = M.InceptionV3(sd, dev, dtype)
+        xn = x.to(dev).permute(0, 2, 3, 1).contiguous().to(dtype)
+        feat, logit = model.forward_nhwc(xn)
+        torch.cuda.synchronize()
+        check(f"299^2 B=32 pool3 features {dtype}", feat, feat_o, tol)
+        check(f"299^2 B=32 logits {dtype}", logit, logit_o, tol)
+
+
 def test_preprocess_bit_exact_quantisation(sg):
     from studiogan_amd import metrics as M
     dev = torch.device("cuda:0")

@@ -260,3 +260,51 @@ def test_ema_restatement_matches_reference_class():
             assert torch.equal(v, oP[k]), (it, k)
         for k, v in tgt.named_buffers():
             assert torch.equal(v, oB[k]), (it, k)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_inception_oracle_pinned_to_the_references_own_code():
+    """oracle/inception.py against the REFERENCE's code (src/metrics/inception_net.py): fid_inception_v3(), the FID-patched
+    FIDInceptionA / C / E_1 / E_2.forward (:135-249) and InceptionV3.__init__ / forward (:16-107) run unmodified on CPU with
+    oracle/tv_stub.py standing in for the absent torchvision (its published BasicConv2d / Inception A-E constructors) and the
+    oracle's seeded weights returned by the (patched) checkpoint download. Bit-identical block by block and end to end. What stays
+    unpinned: the values of the real FID checkpoint (not obtainable offline)."""
+    import importlib
+    from oracle import ref_import as R, tv_stub, inception as OI
+    R._prepare()
+    names = ("torchvision", "torchvision.models", "torchvision.models.inception", "torchvision.models.utils", "metrics.inception_net")
+    saved = {k: sys.modules.get(k) for k in names}
+    try:
+        tv, models, inc = tv_stub.as_modules()
+        sys.modules["torchvision"], sys.modules["torchvision.models"], sys.modules["torchvision.models.inception"] = tv, models, inc
+        sys.modules.pop("torchvision.models.utils", None)
+        sys.modules.pop("metrics.inception_net", None)
+        net = importlib.import_module("metrics.inception_net")
+        sd = OI.random_state_dict(5)
+        net.load_state_dict_from_url = lambda *a, **k: sd        # inception_net.py:130 downloads pt_inception-2015-12-05-6726825d.pth
+        ref = net.InceptionV3(resize_input=False, normalize_input=False).eval()      # metrics/preparation.py:53
+        g = torch.Generator().manual_seed(2)
+        with torch.no_grad():
+            # block level: the reference's patched forwards on their own inputs
+            _, inception = net.fid_inception_v3()
+            inception.eval()
+            for name, cin, hw, fn in (("Mixed_5b", 192, 12, lambda x, p: OI._blockA(x, sd, p)), ("Mixed_5d", 288, 12, lambda x, p: OI._blockA(x, sd, p)),
+                                      ("Mixed_6a", 288, 13, lambda x, p: OI._blockB(x, sd, p)), ("Mixed_6c", 768, 9, lambda x, p: OI._blockC(x, sd, p)),
+                                      ("Mixed_7a", 768, 9, lambda x, p: OI._blockD(x, sd, p)), ("Mixed_7b", 1280, 5, lambda x, p: OI._blockE(x, sd, p, "avg")),
+                                      ("Mixed_7c", 2048, 5, lambda x, p: OI._blockE(x, sd, p, "max"))):
+                x = torch.randn(2, cin, hw, hw, generator=g)
+                a, b = getattr(inception, name)(x), fn(x, name)
+                assert a.shape == b.shape and torch.equal(a, b), name
+            assert type(inception.Mixed_7b).__name__ == "FIDInceptionE_1" and type(inception.Mixed_7c).__name__ == "FIDInceptionE_2"
+            # end to end, at the real input size
+            x = torch.rand(2, 3, 299, 299, generator=g) * 2 - 1
+            f_ref, l_ref = ref(x)
+            f_o, l_o = OI.inception_forward(x, sd)
+        assert f_ref.shape == (2, 2048) and l_ref.shape == (2, 1008)
+        assert torch.equal(f_ref, f_o) and torch.equal(l_ref, l_o)
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                sys.modules.pop(k, None)
+            else:
+                sys.modules[k] = v
