@@ -293,8 +293,92 @@ def run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d, seed=0):
     return exp
 
 
+COND_EPS = 2e-6     # relative size of the weight perturbation of the conditioning measurement (fp32 kernels of two implementations
+                    # disagree at about this level: first-forward quantities of the HIP path match the oracle to ~5e-6)
+
+
+def _perturbed(P, eps, seed):
+    g = torch.Generator().manual_seed(seed)
+    return {k: (v * (1 + eps * torch.randn(v.shape, generator=g)) if v.is_floating_point() else v.clone()) for k, v in P.items()}
+
+
+def _noise(a, b):
+    d = (a.detach().double() - b.detach().double()).reshape(-1)
+    return torch.tensor([float(d.norm() / max(d.numel(), 1) ** 0.5), float(d.abs().max()) if d.numel() else 0.0], dtype=torch.float64)
+
+
+def conditioning(name):
+    """How far the ORACLE ITSELF moves when every weight is perturbed by COND_EPS (relative): per expected tensor [rms, max] of the
+    difference, (a) over the unsynchronised chain of the golden step ("chain/<key>", keys of run_restatement) and (b) per update with
+    the perturbation applied right before that update ("stage/D<i>/..", "stage/G/..": what the re-synchronised stage-wise test
+    sees). A WGAN-GP critic at batch 2, or a generator gradient that has passed every ReLU of D after two Adam updates, turn such a
+    perturbation into 1e-3..1e-1 relative differences; the GPU tests allow base tolerance + 4 x this measured noise instead of a
+    hand-picked number. Written to tests/golden/<name>.cond.npz; needs only the restatement (no reference)."""
+    import copy
+    sys.path.insert(0, os.path.join(os.path.dirname(GOLDEN_DIR)))
+    from util import load_golden, sub, hyper
+    fix, meta = load_golden(name)
+    y, n_d, seed = meta["yaml"], meta["n_d"], meta["seed"]
+    ocfg = oracle_cfg(y)
+    isb = lambda k: any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))
+    GI, DI = sub(fix, "G_init/"), sub(fix, "D_init/")
+    split = lambda d: ({k: v.clone() for k, v in d.items() if not isb(k)}, {k: v.clone() for k, v in d.items() if isb(k)})
+    ins = sub(fix, "in/")
+    out = {}
+    # (a) chain
+    GP, GB = split(GI); DP, DB = split(DI)
+    base = run_restatement(ocfg, y, GP, GB, DP, DB, ins, n_d, seed)
+    GP, GB = split(GI); DP, DB = split(DI)
+    pert = run_restatement(ocfg, y, _perturbed(GP, COND_EPS, 11), GB, _perturbed(DP, COND_EPS, 12), DB, ins, n_d, seed)
+    for k in base:
+        out["chain/" + k] = _noise(base[k], pert[k])
+    # (b) per update, perturbation applied to the state the update starts from
+    opt = hyper(y)
+    kind = opt["adv_loss"]
+    lam = opt["gp_lambda"] if opt["apply_gp"] else None
+    gen_fn, dis_fn = O.model_fns(ocfg)
+    GP, GB = split(GI); DP, DB = split(DI)
+    g_opt, d_opt = O.AdamState(GP, opt["g_lr"], opt["beta1"], opt["beta2"]), O.AdamState(DP, opt["d_lr"], opt["beta1"], opt["beta2"])
+    B = ins["z0"].shape[0]
+    for i in range(n_d + 1):
+        st = copy.deepcopy((GP, GB, DP, DB, g_opt, d_opt))
+        pGP, pGB, pDP, pDB, pg, pd = copy.deepcopy(st)
+        pGP, pDP = _perturbed(pGP, COND_EPS, 21 + i), _perturbed(pDP, COND_EPS, 31 + i)
+        res = []
+        for (a, b, c, d, go, do) in ((GP, GB, DP, DB, g_opt, d_opt), (pGP, pGB, pDP, pDB, pg, pd)):
+            if i < n_d:
+                o = O.d_update(gen_fn, dis_fn, a, b, c, d, do, [ins[f"real{i}"]], [ins[f"rl{i}"]], [ins[f"z{i}"]], [ins[f"fl{i}"]], kind, record=True,
+                               gp_lambda=lam, gp_alpha=[gp_alpha(seed, i, B)] if lam is not None else None)
+                res.append((o, c))
+            else:
+                o = O.g_update(gen_fn, dis_fn, a, b, c, d, go, [ins[f"z{n_d}"]], [ins[f"fl{n_d}"]], kind, record=True)
+                res.append((o, a))
+        tag = f"stage/D{i}/" if i < n_d else "stage/G/"
+        (o0, p0), (o1, p1) = res
+        for k in ("fake", "adv_r", "adv_f", "gp"):
+            if k in o0 and torch.is_tensor(o0[k]):
+                out[tag + k] = _noise(o0[k], o1[k])
+        for k in o0["grads"]:
+            if o0["grads"][k] is not None:
+                out[tag + "grad/" + k] = _noise(o0["grads"][k], o1["grads"][k])
+        for k in p0:
+            out[tag + "param/" + k] = _noise(p0[k], p1[k])     # (the 2e-6 start offset is far below the +-lr movement of an Adam step)
+    np.savez_compressed(os.path.join(GOLDEN_DIR, name + ".cond.npz"), **{k: v.numpy() for k, v in out.items()})
+    worst = {}
+    for k, v in out.items():
+        fam = "/".join(k.split("/")[:3]) if k.startswith("stage") else k.split("/")[1]
+        worst[fam] = max(worst.get(fam, 0.0), float(v[0]))
+    print(name, "conditioning (rms of the oracle's own movement under a", COND_EPS, "relative weight perturbation), worst per family:")
+    for fam, e in sorted(worst.items()):
+        print(f"   {fam:28s} {e:.3e}")
+
+
 def main():
     os.makedirs(GOLDEN_DIR, exist_ok=True)
+    if len(sys.argv) > 1 and sys.argv[1] == "--cond":
+        for name in sys.argv[2:]:
+            conditioning(name)
+        return
     assert R.available(), "/root/reference is required to (re)generate the golden fixtures"
     only = sys.argv[1:]
     for name, c in CONFIGS.items():

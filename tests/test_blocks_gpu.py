@@ -335,6 +335,13 @@ def bf16_vs_emulating_oracle(name, which, report=None):
         p.grad = None
     C = Collector()
     tg = 0.15 if (meta.get("compact") or name in ("bigdeep32", "bigdeepsg32")) else 8e-2     # bigdeep32: 48 ReLU layers deep
+    # full-width fixtures (name ends in "w"): the emulating oracle decorrelates from ANY other bf16 evaluation of the same network after
+    # a handful of layers -- measured on the oracle alone (tools/bf16_noise_floor.py, profiles/r02_bf16_noise_floor.txt): a 1e-5 relative
+    # weight perturbation moves BigGAN-128's emulated image by 1.5e-2 relative-L2 / 5e-2 of range. Forward quantities are therefore held to
+    # SURVEY 8(c)'s 2e-2 in relative-L2 (max-norm printed), gradients to 0.3 relative-L2 (printed per tensor).
+    full = name.endswith("w")
+    if full:
+        tg = 0.3
     if which == "D":
         x, lab = fix["in/real0"].clone(), fix["in/rl0"]
         gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1]).repeat((x.shape[0] + 7) // 8)[:x.shape[0]]
@@ -345,8 +352,8 @@ def bf16_vs_emulating_oracle(name, which, report=None):
         out = D(xd, lab.to(dev))
         (out["adv_output"] * gadv.to(dev)).sum().backward()
         torch.cuda.synchronize()
-        C.check("D adv", out["adv_output"], adv_o, 2e-2)
-        C.check("D h", out["h"], h_o, 2e-2)
+        C.check("D adv", out["adv_output"], adv_o, 2e-2, l2=full)
+        C.check("D h", out["h"], h_o, 2e-2, l2=full)
         C.check("D dx", xd.grad, xo.grad, tg, l2=True)
     else:
         z, lab = fix["in/z0"], fix["in/fl0"]
@@ -357,7 +364,7 @@ def bf16_vs_emulating_oracle(name, which, report=None):
         img = G(z.to(dev), lab.to(dev))
         (img * gimg.to(dev)).sum().backward()
         torch.cuda.synchronize()
-        C.check("G img", img, img_o, 2e-2)
+        C.check("G img", img, img_o, 2e-2, l2=full)
     gmax = max(float(v.grad.abs().max()) for v in leaves.values())
     for k, p in net.named_parameters():
         # the attention gate is ONE scalar summing dy * conv(o) over every pixel: judged on the network's gradient scale

@@ -7,7 +7,10 @@ fused attention at HW = 4096 -- are the kernels under test at the fixtures' smal
 Three comparisons per fixture (the width-8 fixtures get the same three in test_model_gpu.py / test_blocks_gpu.py):
   * one full training step against the golden vectors written by the REAL reference (fp32 and bf16),
   * the same step in fp32 against the CPU oracle, re-synchronised after every update (tight per-update bound),
-  * bf16 forward / backward of D and G against the bf16-emulating oracle (forward <= 2e-2; gradient relative-L2 reported).
+  * bf16 forward / backward of D and G against the bf16-emulating oracle (forward <= 2e-2 relative-L2; gradient relative-L2 reported).
+fp32 tolerances = base (1e-3 forward / state, 1e-2 gradient relative-L2) + 4 x the ORACLE's OWN movement of that tensor under a 2e-6 relative
+weight perturbation (tests/golden/<name>.cond.npz, oracle/make_golden.py conditioning()): ill-conditioned quantities (WGAN-GP critic at
+batch 2, generator gradients through every ReLU of D) get a measured bound instead of a hand-picked one.
 The measured errors are written to gpurun_out/fullwidth_parity.txt when that directory is writable."""
 import os
 
@@ -15,7 +18,7 @@ import pytest
 import torch
 
 from test_model_gpu import step_vs_golden, stagewise_vs_oracle
-from test_blocks_gpu import bf16_vs_emulating_oracle, discriminator_fwd_bwd, generator_fwd_bwd
+from test_blocks_gpu import bf16_vs_emulating_oracle
 
 pytestmark = pytest.mark.gpu
 
@@ -61,17 +64,10 @@ def test_fullwidth_step_stagewise_vs_oracle(sg, forced, name):
 
 
 @pytest.mark.parametrize("which", ["D", "G"])
-@pytest.mark.parametrize("name", WIDE)
+@pytest.mark.parametrize("name", ["biggan128w", "sngan32w"])     # (C3 = the benchmarked configuration, C2; the deeper nets only add oracle minutes)
 def test_fullwidth_bf16_vs_emulating_oracle(sg, forced, name, which):
     rows = []
     try:
         bf16_vs_emulating_oracle(name, which, report=rows)
     finally:
         _dump(f"bf16-emu {which} " + name, rows)
-
-
-@pytest.mark.parametrize("mixed", [False, True])
-@pytest.mark.parametrize("name", WIDE)
-def test_fullwidth_networks_fwd_bwd(sg, forced, name, mixed):
-    discriminator_fwd_bwd(name, mixed)
-    generator_fwd_bwd(name, mixed, "track")
