@@ -264,6 +264,24 @@ def main():
                 "conv_stack_ms": round(conv_only_ms, 3), "conv_launches": int(pd[0] / it),
                 "conv_stack_tflops": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
                 "conv_stack_frac_of_peak": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None, "peak_tflops": pk}
+    # ---- HBM-bound kernel families of the step: algorithmic bytes / hipEvent time per family over two more steps --------
+    hbm = None
+    if rank == 0 or world > 1:
+        L.call("sg_prof_enable", 2)          # bit 1: spectral norm, batch norm, attention score kernels, Adam / EMA
+        hsteps = 2
+        for i in range(hsteps):
+            w.step(args.warmup + args.steps + i, real)
+        barrier()
+        ph = (ctypes.c_double * 21)()
+        L.call("sg_prof_collect", ph, 7)
+        L.call("sg_prof_enable", 0)
+        if rank == 0:
+            hbm = {"peak_GBps": 8000.0, "steps": hsteps, "note": "algorithmic bytes (each tensor of the family read / written once per pass) / hipEvent time on the launch stream"}
+            for kind, name in ((3, "spectral_norm"), (4, "batch_norm"), (5, "attention_scores"), (6, "adam_ema")):
+                n_l, ms, by = ph[kind * 3], ph[kind * 3 + 1], ph[kind * 3 + 2]
+                gbps = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+                hbm[name] = {"ms_per_step": round(ms / hsteps, 3), "GB_per_step": round(by / hsteps / 1e9, 3), "GBps": round(gbps, 1),
+                             "frac_of_8TBps": round(gbps / 8000.0, 3), "calls_per_step": round(n_l / hsteps, 1)}
     # ---- second metric: FID-50k feature extraction (reference src/metrics/features.py:17-65) ------------------------
     fid = None
     if args.fid_samples > 0 and args.workload == "biggan128":
@@ -332,6 +350,8 @@ def main():
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),
                      "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
     }
+    if hbm is not None:
+        out["roofline_hbm"] = hbm
     if dfwd is not None:
         out["d_forward_stack"] = dfwd
     if fid is not None:

@@ -181,6 +181,7 @@ extern "C" int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, fl
   SG_CHECK(theta && phi && P && lse, "sg_attn_probs_fwd: null");
   SG_CHECK(at_ok(B, HW, HW4, Dp) && HW4 * 64 <= 128 * 1024, "sg_attn_probs_fwd: unsupported shape");
   const int lds = HW4 * 64;
+  SgProfScope prof((hipStream_t)s, (double)B * HW * ((double)HW4 * 2.0 + Dp * 2.0 + 4.0) + (double)B * HW4 * Dp * 2.0, 5);   // P written once (bf16), theta / phi read, lse
   static int attr = 0;
   if (attr < lds) {
     SG_CHECK(hipFuncSetAttribute((const void*)k_attn_probs_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024) == hipSuccess, "sg_attn_probs_fwd: LDS attribute");
@@ -194,6 +195,7 @@ extern "C" int sg_attn_ds_bwd(const void* theta, const void* phi, const void* g,
   SG_CHECK(theta && phi && g && dO && lse && dS, "sg_attn_ds_bwd: null");
   SG_CHECK(at_ok(B, HW, HW4, Dp) && Cg % 8 == 0 && Cg >= 8 && Cg <= 128, "sg_attn_ds_bwd: unsupported shape");
   const int ncg = (Cg + 31) / 32;
+  SgProfScope prof((hipStream_t)s, (double)B * HW * ((double)HW4 * 2.0 + (Dp + Cg) * 2.0 + 4.0) + (double)B * HW4 * (Dp + Cg) * 2.0, 5);   // dS written once
   const int lds = (1 + ncg) * 256 * 64;
   const dim3 grid(HW / 128, B), blk(256);
   hipStream_t st = (hipStream_t)s;

@@ -31,13 +31,13 @@ extern "C" int sg_prof_enable(int on) {
     }
     g_ev_created = SG_PROF_MAX;
   }
-  g_prof_on = on ? 1 : 0;
+  g_prof_on = on;          // bit 0: contraction engine (kinds 0-2), bit 1: HBM-bound families (kinds 3-6)
   g_prof_n = 0;
   return 0;
 }
 // returns the slot index or -1
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind) {
-  if (!g_prof_on || g_prof_n >= SG_PROF_MAX) return -1;
+  if (!(g_prof_on & (kind < 3 ? 1 : 2)) || g_prof_n >= SG_PROF_MAX) return -1;
   const int i = g_prof_n++;
   g_flops[i] = flops; g_kind[i] = kind;
   hipEventRecord(g_ev0[i], st);

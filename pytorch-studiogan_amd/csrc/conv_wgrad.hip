@@ -3,6 +3,57 @@
 // Replaces autograd's convolution_backward (weight part) on the StudioGAN hot path (reference src/utils/ops.py:165-173,195-204).
 #include "conv_common.h"
 #include "wgrad_v2.h"
+#include "wgrad_sk.h"
+
+// ---- thin layers: streaming kernel (wgrad_sk.h). SG_WGRAD_SK=0 disables it. -----------------------------------------------------
+struct SkPlan { bool ok, taps; int NI, NJ, swap, nw; long long n; };
+static SkPlan wgrad_sk_plan(const sg_conv_wgrad_desc* d) {
+  SkPlan s; s.ok = false; s.taps = false; s.NI = s.NJ = s.swap = s.nw = 0; s.n = 0;
+  const char* mode = getenv("SG_WGRAD_SK");
+  if (mode && mode[0] == '0') return s;
+  if (d->dtype != SG_DTYPE_BF16 || d->stride != 1 || d->no_tr) return s;
+  if ((d->x_flags | d->g_flags) & SG_PIX_TRANSPOSED) return s;
+  const int wsh = ilog2_exact(d->Wo), hsh = ilog2_exact(d->Ho);
+  if (wsh < 0 || hsh < 0) return s;
+  if (d->C % 8 || d->ldx % 8 || d->Cout % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return s;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  if (K % 32 || K / 32 >= (1ll << 30)) return s;
+  if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return s;
+  const bool xup = d->x_flags & SG_PIX_UPSAMPLE, gup = d->g_flags & SG_PIX_UPSAMPLE, xrelu = d->x_flags & SG_PIX_RELU;
+  if (d->R == 1 && d->S == 1 && d->pad_h == 0 && d->pad_w == 0) {
+    if (d->C > 192 || d->Cout > 96) return s;
+    const int ni = (d->C + 31) / 32, nj = (d->Cout + 31) / 32;
+    if (ni == 4 || ni == 5) return s;                       // (no layer of the networks has 97..160 input channels on a thin 1x1)
+    s.ok = true; s.NI = ni; s.NJ = nj; s.n = (long long)d->C * d->Cout;
+  } else if (d->R == 3 && d->S == 3 && d->pad_h == 1 && d->pad_w == 1 && !xup && !gup && !xrelu && d->Wo >= 32) {
+    if (d->C == 8 && d->Cout <= 96) { s.ok = true; s.taps = true; s.NI = 3; s.NJ = (d->Cout + 31) / 32; s.n = 72ll * d->Cout; }
+    else if (d->Cout == 8 && d->C <= 96) { s.ok = true; s.taps = true; s.swap = 1; s.NI = 3; s.NJ = (d->C + 31) / 32; s.n = 72ll * d->C; }
+  }
+  if (s.ok) s.nw = sg_wgrad_sk_waves((int)(K / 32));
+  return s;
+}
+static int wgrad_sk_launch(const sg_conv_wgrad_desc* d, const SkPlan& s, hipStream_t st) {
+  WgradSkParams p;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  const unsigned xbytes = (unsigned)((((long long)d->N * d->xHs * d->xWs - 1) * d->ldx + d->C) * 2);
+  const unsigned gbytes = (unsigned)((((long long)d->N * d->gHs * d->gWs - 1) * d->ldg + d->Cout) * 2);
+  p.H = d->Ho; p.W = d->Wo; p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
+  p.nchunk = (int)(K / 32);
+  p.arelu = (d->x_flags & SG_PIX_RELU) ? 1 : 0;
+  p.work = (float*)d->work; p.n = s.n;
+  p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
+  const int xup = (d->x_flags & SG_PIX_UPSAMPLE) ? 1 : 0, gup = (d->g_flags & SG_PIX_UPSAMPLE) ? 1 : 0;
+  if (!s.swap) {       // A = x, B = dy
+    p.a = (const bf16_t*)d->x; p.lda = d->ldx; p.CA = d->C; p.upA = xup; p.HsA = d->xHs; p.WsA = d->xWs; p.abytes = xbytes;
+    p.b = (const bf16_t*)d->dy; p.ldb = d->ldg; p.CB = d->Cout; p.upB = gup; p.HsB = d->gHs; p.WsB = d->gWs; p.bbytes = gbytes;
+    p.sgn = 1; p.swap = 0; p.I = s.taps ? 72 : d->C; p.J = d->Cout;
+  } else {             // generator RGB layer: A = dy (8 padded couts, shifted by -tap), B = x
+    p.a = (const bf16_t*)d->dy; p.lda = d->ldg; p.CA = 8; p.upA = 0; p.HsA = d->gHs; p.WsA = d->gWs; p.abytes = gbytes;
+    p.b = (const bf16_t*)d->x; p.ldb = d->ldx; p.CB = d->C; p.upB = 0; p.HsB = d->xHs; p.WsB = d->xWs; p.bbytes = xbytes;
+    p.sgn = -1; p.swap = 1; p.I = 72; p.J = d->C;
+  }
+  return sg_launch_wgrad_sk(p, s.taps, s.NI, s.NJ, st);
+}
 
 // tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)
 static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
@@ -46,6 +97,8 @@ extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, lo
   SG_CHECK(d && splits && work_floats, "sg_conv2d_wgrad_plan: null");
   const int I = d->R * d->S * d->C, J = d->Cout;
   const long long K = (long long)d->N * d->Ho * d->Wo;
+  const SkPlan sk = wgrad_sk_plan(d);
+  if (sk.ok) { *splits = sk.nw; *work_floats = (long long)sk.nw * sk.n; return 0; }
   int BI, BJ, sp;
   wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp, wgrad_v2_ok(d));
   *splits = sp;
@@ -105,6 +158,18 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   SG_CHECK((long long)d->N * d->xHs * d->xWs * d->ldx < (1ll << 31) && (long long)d->N * d->gHs * d->gWs * d->ldg < (1ll << 31),
            "sg_conv2d_wgrad: tensor too large for 32-bit element offsets");
   const int K = (int)Kll;
+  {
+    const SkPlan sk = wgrad_sk_plan(d);
+    if (sk.ok && d->work && d->work_floats >= (long long)sk.nw * sk.n) {
+      const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
+      if (wgrad_sk_launch(d, sk, st) != 0) { sg_set_error("sg_conv2d_wgrad: streaming kernel launch failed"); return -2; }
+      long long blocks = (sk.n + 255) / 256; if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, sk.nw, sk.n);
+      sg_prof_end(st, prof);
+      SG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
   int BI, BJ, splits;
   const bool v2 = wgrad_v2_ok(d);
   wgrad_plan(I, J, K, ET<T>::BK, d->splits, BI, BJ, splits, v2);

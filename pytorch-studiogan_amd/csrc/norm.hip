@@ -69,6 +69,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_partial_stream
   }
 }
 extern "C" int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, (double)rows * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && partial && rows > 0 && C > 0, "sg_bn_partial_stats: bad args");
   bool done = false;
   DISPATCH_T(dtype, {
@@ -188,6 +189,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_apply_stream(c
   }
 }
 extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, 2.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && y && mean && invstd, "sg_bn_apply: null");
   DISPATCH_T(dtype, {
     const int CV = C / ET<T>::VEC;
@@ -276,6 +278,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_reduce_str
   }
 }
 extern "C" int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, float* sums, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, 2.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && dy && mean && invstd && sums, "sg_bn_bwd_reduce: null");
   SG_CHECK(N <= 65535, "sg_bn_bwd_reduce: batch too large for grid.z");
   bool done = false;
@@ -401,6 +404,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stre
   }
 }
 extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, const double* chan, double count, int use_batch_stats, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, 3.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && dy && dx && mean && invstd && chan && count > 0, "sg_bn_bwd_apply: bad args");
   DISPATCH_T(dtype, {
     const int CV = C / ET<T>::VEC;

@@ -47,6 +47,7 @@ __global__ __launch_bounds__(256) void k_adam_ema(float* p, const float* g, floa
 }
 extern "C" int sg_adam_ema(float* p, const float* g, float* m, float* v, float* ema, long long n, float lr, float beta1, float beta2,
                            float eps, float wd, int step, float ema_decay, float grad_scale, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, (double)n * (ema ? 36.0 : 28.0), 6);      // p, m, v read + write, g read (+ ema read + write)
   SG_CHECK(p && g && m && v && n > 0 && step >= 1, "sg_adam_ema: bad args");
   SG_CHECK(((((uintptr_t)p) | ((uintptr_t)g) | ((uintptr_t)m) | ((uintptr_t)v) | ((uintptr_t)ema)) & 15) == 0, "sg_adam_ema: arenas must be 16-byte aligned");
   const double bc1 = 1.0 - pow((double)beta1, (double)step);
@@ -62,6 +63,7 @@ __global__ __launch_bounds__(256) void k_ema_lerp(const float* src, float* ema, 
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) ema[i] = torch_lerp(src[i], ema[i], decay);
 }
 extern "C" int sg_ema_lerp(const float* src, float* ema, long long n, float decay, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, (double)(n > 0 ? n : 0) * 12.0, 6);
   SG_CHECK(src && ema, "sg_ema_lerp: null");
   if (n <= 0) return 0;
   long long blocks = (n + 255) / 256; if (blocks > 256 * 16) blocks = 256 * 16;

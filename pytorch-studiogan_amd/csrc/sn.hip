@@ -221,6 +221,13 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
     if (e > max_elems) max_elems = e;
   }
   hipStream_t st = (hipStream_t)s;
+  double bytes = 0.0;      // algorithmic: W^T u and W v read the fp32 weight once each, the pack reads it again and writes the operand images
+  for (int i = 0; i < n; i++) {
+    const sg_sn_layer& l = layers_host[i];
+    const double e = (double)l.rows * l.cols, es = dtype == SG_DTYPE_BF16 ? 2.0 : 4.0;
+    bytes += e * (4.0 * ((l.apply_sn && l.do_power_iter ? 1 : 0) + (l.apply_sn ? 1 : 0) + 1) + (l.w_fwd ? es : 0.0) + (l.w_dgrad ? es : 0.0) + (l.w_f32 ? 4.0 : 0.0));
+  }
+  SgProfScope prof(st, bytes, 3);
   if (any_pi) {
     hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 1023) / 1024, SN_SPLITS, n), dim3(256), 0, st, layers_dev, work);
     hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
@@ -306,6 +313,9 @@ extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd
     if (e > max_elems) max_elems = e;
   }
   hipStream_t st = (hipStream_t)s;
+  double bytes = 0.0;      // dot: dWt + W; apply: dWt + read-modify-write of dW
+  for (int i = 0; i < n; i++) bytes += (double)layers_host[i].rows * layers_host[i].cols * 4.0 * ((layers_host[i].apply_sn ? 2 : 0) + 3);
+  SgProfScope prof(st, bytes, 3);
   if (any_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
   long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
   hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);

@@ -76,7 +76,12 @@ __device__ __forceinline__ bf16x8_t sg_frag_join(u32x2 lo, u32x2 hi) {
 
 // BJ = 128 (4 x 2 waves of 64 x 64) or 256 (64 x 128 per wave: 8 MFMAs per 12 transpose reads instead of 4 per 8, and a third
 // fewer DMA pieces per MFMA; for Cout % 256 == 0)
-template <bool XRELU, int BJ>
+// NBUF = 2: the DMA of k-tile kt+1 overlaps the MFMAs of k-tile kt and is drained at the barrier that ends kt. NBUF = 3 (BJ = 128
+// only: 3 x 48 KB of LDS): k-tile kt+2 is requested before the MFMAs of kt and only kt+1 has to have landed at that barrier
+// (`s_waitcnt vmcnt(<pieces of one tile>)` + a bare s_barrier -- LDS-DMA stays in flight across it), i.e. two k-tiles of latency
+// cover instead of one. Counter evidence for the change: profiles/r02_conv_sq_counters_baseline.txt, SQ_WAIT_ANY = 0.37-0.46 of the
+// wave cycles of this kernel at MFMA busy 0.36-0.46.
+template <bool XRELU, int BJ, int NBUF = 2>
 __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   constexpr int IMG = 64 * 256;              // one [64][128] bf16 image
   constexpr int NQI = BJ / 128;              // Q images (128 couts each)
@@ -160,11 +165,20 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
 
   const int wi = wave & 3, wj = wave >> 2;
   const int nk = (k_end - k_begin + 63) / 64;
+  constexpr int NPIECE = 2 * (2 + NQI);      // LDS-DMA instructions one issue() makes per wave
   issue(0, 0);
-  __syncthreads();
+  if (NBUF == 3 && nk > 1) issue(1, 1);
+  if (NBUF == 3) {
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+  } else {
+    __syncthreads();
+  }
+  int cur = 0, nxt2 = 2;                     // NBUF == 3: buffer of k-tile kt, buffer k-tile kt+2 goes to
   for (int kt = 0; kt < nk; kt++) {
-    if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
-    const char* base = smem + (kt & 1) * BUF;
+    if (NBUF == 3) { if (kt + 2 < nk) issue(nxt2, kt + 2); }
+    else if (kt + 1 < nk) issue((kt + 1) & 1, kt + 1);
+    const char* base = smem + (NBUF == 3 ? cur : (kt & 1)) * BUF;
     const char* pimg = base + (wi >> 1) * IMG;
     const char* qbase = base + 2 * IMG;
     // fragments of sub-step ks+1 are requested before the MFMAs of sub-step ks; lgkmcnt(NR) = "everything but those NR reads"
@@ -203,7 +217,16 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
         for (int b = 0; b < TJ; b++)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
     }
-    __syncthreads();
+    if (NBUF == 3) {
+      // k-tile kt+1 must be complete in every wave's view, kt+2 (just requested) may stay in flight; all fragment reads of kt are done
+      // (consumed by the MFMAs above through lgkmcnt waits), so its buffer can be refilled after the barrier
+      if (kt + 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPIECE) : "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      cur = (cur == 2) ? 0 : cur + 1;
+      nxt2 = (nxt2 == 2) ? 0 : nxt2 + 1;
+    } else {
+      __syncthreads();
+    }
   }
 
   float al = epi.alpha;
@@ -222,16 +245,16 @@ __global__ __launch_bounds__(512) void sg_wgrad_v2_kernel(WgradV2Params p, Epilo
     }
 }
 
-template <bool XRELU, int BJ>
+template <bool XRELU, int BJ, int NBUF = 2>
 static inline int sg_launch_wgrad_v2r(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
-  constexpr int LDS = 2 * (2 + BJ / 128) * 64 * 256;
+  constexpr int LDS = NBUF * (2 + BJ / 128) * 64 * 256;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel<XRELU, BJ>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_wgrad_v2_kernel<XRELU, BJ, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + 255) / 256, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_wgrad_v2_kernel<XRELU, BJ>), dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_wgrad_v2_kernel<XRELU, BJ, NBUF>), dim3(tilesI * tilesJ, splits), dim3(512), LDS, st, p, e, tilesI, tilesJ);
   return 0;
 }
 // cout tile of the plan (the launcher and wgrad_plan must agree): 256 when the couts fill it AND every workgroup still gets a long
@@ -251,5 +274,9 @@ static inline int sg_wgrad_v2_bj(int I, int J, int K) {
 static inline int sg_launch_wgrad_v2(const WgradV2Params& p, const Epilogue<bf16_t>& e, int splits, hipStream_t st) {
   if (sg_wgrad_v2_bj(p.I, p.J, p.K) == 256)
     return p.x_relu ? sg_launch_wgrad_v2r<true, 256>(p, e, splits, st) : sg_launch_wgrad_v2r<false, 256>(p, e, splits, st);
+  // SG_WGRAD_NBUF=2: the two-buffer loop (A/B switch); default three buffers
+  static int nbuf = -1;
+  if (nbuf < 0) { const char* e3 = getenv("SG_WGRAD_NBUF"); nbuf = (e3 && e3[0] == '2') ? 2 : 3; }
+  if (nbuf == 3) return p.x_relu ? sg_launch_wgrad_v2r<true, 128, 3>(p, e, splits, st) : sg_launch_wgrad_v2r<false, 128, 3>(p, e, splits, st);
   return p.x_relu ? sg_launch_wgrad_v2r<true, 128>(p, e, splits, st) : sg_launch_wgrad_v2r<false, 128>(p, e, splits, st);
 }

@@ -252,3 +252,74 @@ def test_wgrad_v2_matches_reference_and_v1(sg, case):
     os.environ.pop("SG_CONV_V2", None)
     os.environ.pop("SG_WGRAD_BJ256", None)
     check(f"wgrad v2 vs v1 {case}", outs[("force", 0)], outs[("0", 0)], 1e-4)
+
+
+WSK_CASES = [
+    # N, Cin, Cout, H(in), R, relu, up, pool      -- csrc/wgrad_sk.h: streaming weight gradient of the thin layers
+    (2, 8, 96, 32, 3, False, False, False),      # D's RGB stem: nine taps out of one 3-row patch, halo zeros (W = 32: chunk = image row)
+    (3, 8, 64, 64, 3, False, False, False),      # stem with two column blocks, W = 64 (two chunks per row), odd image count
+    (2, 96, 8, 32, 3, False, False, False),      # G's RGB layer: roles of x and dy exchanged, tap shift negated
+    (3, 64, 8, 64, 3, False, False, False),      # ... 64 input channels (ResNet generator), W = 64
+    (2, 8, 96, 16, 1, False, False, False),      # D's first skip: 8 -> 96 (one row block, 24 of 32 rows empty)
+    (2, 96, 16, 16, 1, False, False, False),     # attention theta / phi (12 couts padded to 16)
+    (2, 96, 48, 16, 1, True, False, False),      # attention g, ReLU on the A operand
+    (2, 48, 96, 16, 1, False, False, False),     # attention o
+    (2, 96, 96, 16, 1, True, False, True),       # D skip shape: ReLU + pooled-gradient broadcast (dy at half resolution)
+    (2, 192, 96, 8, 1, False, True, False),      # G skip: x at half resolution (nearest x2 on load), six row blocks
+    (5, 192, 24, 16, 1, False, False, False),    # G attention theta: J = 24, 1280 pixels
+    (2, 24, 96, 16, 1, False, False, False),     # 24 input channels: zero-filled channel tail of the row block
+]
+
+
+@pytest.mark.parametrize("case", WSK_CASES)
+def test_wgrad_sk_matches_reference_and_tile_kernels(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, R, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    pad = R // 2
+    x = rnd((N, Cin, H, H), dt, 41)
+    w = rnd((Cout, Cin, R, R), dt, 42, 0.1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    y = _conv_ref(xr, wr, 1, pad, relu, up, pool, None, None)
+    gy = rnd(tuple(y.shape), dt, 43)
+    y.backward(gy.double())
+    Ho = H * (2 if up else 1)
+    xd, gyd = nhwc(x).to(d), nhwc(gy).to(d)
+    xf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    gf = L.PIX_UPSAMPLE if pool else 0
+    sig = torch.tensor([0.7], device=d)
+    outs = {}
+    for mode in ("1", "0"):
+        os.environ["SG_WGRAD_SK"] = mode
+        dw = torch.zeros((Cout, R, R, Cin), dtype=torch.float32, device=d)
+        F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        outs[mode] = dw.cpu().clone()
+        check(f"wgrad sk={mode} {case}", dw.cpu().permute(0, 3, 1, 2), wr.grad, 2e-3)
+        # accumulation into dw (acml_steps > 1, shared weights) and the device-side scale (attention gate): dw += 0.7 * dW
+        F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, alpha_ptr=sig)
+        torch.cuda.synchronize()
+        check(f"wgrad sk={mode} accumulate {case}", dw.cpu().permute(0, 3, 1, 2), 1.7 * wr.grad, 2e-3)
+    os.environ.pop("SG_WGRAD_SK", None)
+    check(f"wgrad sk vs tile kernels {case}", outs["1"], outs["0"], 1e-4)
+
+
+def test_wgrad_sk_full_size_layers(sg):
+    """The RGB layers and an attention 1x1 at the benchmark's resolution (batch 16): every wave runs many chunks (double-buffer
+    hand-over, chunk stride = number of waves), compared with the tile kernels."""
+    from studiogan_amd import functional as F, _lib as L
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    for (N, Cin, Cout, H, R) in ((16, 8, 96, 128, 3), (16, 96, 8, 128, 3), (16, 96, 48, 64, 1), (16, 192, 96, 64, 1)):
+        x = rnd((N, H, H, Cin), dt, 31).to(d)
+        gy = rnd((N, H, H, Cout), dt, 32).to(d)
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["SG_WGRAD_SK"] = mode
+            dw = torch.zeros((Cout, R, R, Cin), dtype=torch.float32, device=d)
+            F.conv2d_wgrad_raw(x, gy, dw.data_ptr(), Cin, Cout, R, R, H, H, 1, R // 2, R // 2)
+            torch.cuda.synchronize()
+            outs[mode] = dw.cpu()
+        os.environ.pop("SG_WGRAD_SK", None)
+        check(f"wgrad sk full size {(N, Cin, Cout, H, R)}", outs["1"], outs["0"], 2e-3)
