@@ -293,6 +293,20 @@ int sg_topk_select(const float* x, int n, int k, float* vals, int* idx, sg_strea
 int sg_topk_scatter(const float* g, const int* idx, int k, float* dx, int n, sg_stream_t s);
 /* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
 int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
+/* ---- precision / recall / density / coverage (reference src/metrics/prdc.py:87-168) on squared distances. The cross term
+ * D[r][c] = |y_c|^2 - 2 x_r . y_c comes from sg_gemm (fp32, alpha = -2, bias = |y|^2) one row block at a time. */
+int sg_row_sqnorm(const float* f, int n, int C, float* sq, sg_stream_t s);
+/* out[r] = k-th smallest (1-based, k <= 16) of max(0, D[r][c] + row_add[r]) */
+int sg_kth_smallest_rows(const float* D, long long ld, int rows, int cols, int k, const float* row_add, float* out, sg_stream_t s);
+/* col_cnt[c] += #{r : d2 < r2_row[r]}; row_any[r] = any_c d2 < r2_col[c]; row_min[r] = min_c d2, with d2 = max(0, D[r][c] + row_add[r]) */
+int sg_prdc_rows(const float* D, long long ld, int rows, int cols, const float* row_add, const float* r2_row, const float* r2_col,
+                 int* col_cnt, uint8_t* row_any, float* row_min, sg_stream_t s);
+/* ---- tr sqrtm(S1 S2) of the Frechet distance (reference src/metrics/fid.py:34-62, scipy.linalg.sqrtm on the host) in fp64 on the device:
+ * Cholesky factors L1, L2, B = L2^T L1, singular values of B by one-sided Jacobi sweeps, sum of the row norms. [n][n] row-major doubles. */
+int sg_chol_lower(double* A, int n, int* flag, sg_stream_t s);          /* in place; *flag = 1 + first non-positive pivot, 0 if SPD */
+int sg_dgemm_tn(const double* A, const double* B, double* C, int n, sg_stream_t s);   /* C = A^T B */
+int sg_jacobi_sweep(double* M, int n, double* offd, sg_stream_t s);    /* n even; *offd = max |<r_p, r_q>| / (|r_p| |r_q|) met in the sweep */
+int sg_row_norm_sum(const double* M, int n, double* out, sg_stream_t s);
 
 #ifdef __cplusplus
 }

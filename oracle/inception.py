@@ -196,3 +196,23 @@ def frechet_distance(mu1, sigma1, mu2, sigma2):
     if np.iscomplexobj(covmean):
         covmean = covmean.real
     return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+
+
+def prdc(real, fake, nearest_k):
+    """reference src/metrics/prdc.py:87-168 restated in float64 torch (euclidean pairwise distances; manifold radius = the
+    (nearest_k + 1)-th smallest self-inclusive distance of a sample, i.e. get_kth_value(distances, k = nearest_k + 1)): returns
+    dict(precision, recall, density, coverage). Pinned against the reference's compute_prdc by oracle/make_golden_metrics.py."""
+    real, fake = real.double(), fake.double()
+
+    def radii(x):
+        d = torch.cdist(x, x)
+        return torch.kthvalue(d, nearest_k + 1, dim=1).values
+
+    rr, rf = radii(real), radii(fake)
+    d = torch.cdist(real, fake)
+    inside_real = d < rr.unsqueeze(1)
+    precision = inside_real.any(dim=0).double().mean()
+    recall = (d < rf.unsqueeze(0)).any(dim=1).double().mean()
+    density = (1.0 / float(nearest_k)) * inside_real.sum(dim=0).double().mean()
+    coverage = (d.min(dim=1).values < rr).double().mean()
+    return dict(precision=float(precision), recall=float(recall), density=float(density), coverage=float(coverage))

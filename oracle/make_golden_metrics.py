@@ -70,6 +70,17 @@ def main():
                                       disable_tqdm=True, fake_feats=ff)
     fix["in/mom_feats"], fix["in/mom_num_generate"] = ff.numpy(), np.int64(30)
     fix["exp/mom_mu"], fix["exp/mom_sigma"] = mu.astype(np.float64), sigma.astype(np.float64)
+    # PRDC (src/metrics/prdc.py:143-168): two overlapping Gaussian clouds, nearest_k = 5 (the reference's default)
+    prdc = importlib.import_module("metrics.prdc")
+    pr = torch.randn(300, 64, generator=torch.Generator().manual_seed(21)).numpy().astype(np.float64)
+    pf = (torch.randn(260, 64, generator=torch.Generator().manual_seed(22)) * 1.15 + 0.35).numpy().astype(np.float64)
+    m = prdc.compute_prdc(real_features=pr, fake_features=pf, nearest_k=5)
+    mo = OI.prdc(torch.from_numpy(pr), torch.from_numpy(pf), 5)
+    for k in ("precision", "recall", "density", "coverage"):
+        assert abs(float(m[k]) - mo[k]) < 1e-12, ("PRDC restatement", k, float(m[k]), mo[k])
+        fix["exp/prdc_" + k] = np.float64(m[k])
+    fix["in/prdc_real"], fix["in/prdc_fake"] = pr.astype(np.float32), pf.astype(np.float32)
+    print("PRDC: oracle restatement identical to the reference's compute_prdc:", {k: float(v) for k, v in m.items()})
     np.savez_compressed(OUT + ".npz", **fix)
     json.dump({"note": "reference src/metrics/fid.py frechet_inception_distance and src/metrics/ins.py calculate_kl_div run on CPU by "
                        "oracle/make_golden_metrics.py"}, open(OUT + ".json", "w"), indent=1)

@@ -135,6 +135,13 @@ _PROTOS = {
     "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_topk_hits": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "sg_chol_lower": [_vp, _i, _vp, _vp],
+    "sg_dgemm_tn": [_vp, _vp, _vp, _i, _vp],
+    "sg_jacobi_sweep": [_vp, _i, _vp, _vp],
+    "sg_row_norm_sum": [_vp, _i, _vp, _vp],
+    "sg_row_sqnorm": [_vp, _i, _i, _vp, _vp],
+    "sg_kth_smallest_rows": [_vp, _ll, _i, _i, _i, _vp, _vp, _vp],
+    "sg_prdc_rows": [_vp, _ll, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp],
     "sg_topk_select": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_lecam": [_vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
     "sg_u8_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],

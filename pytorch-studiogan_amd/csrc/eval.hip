@@ -184,3 +184,104 @@ extern "C" int sg_topk_scatter(const float* g, const int* idx, int k, float* dx,
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- precision / recall / density / coverage on the device (reference src/metrics/prdc.py:87-168: sklearn pairwise_distances with
+// n_jobs = 8 + numpy argpartition over 50k x 50k float64 matrices on the host) -------------------------------------------------------
+// The pairwise term -2 x.y + |y|^2 comes from the exact-fp32 MFMA GEMM (sg_gemm, alpha = -2, bias = |y|^2) in row blocks; the kernels
+// below add |x|^2 per row, clamp at 0 (sklearn clips its own cancellation noise the same way) and reduce every row on the fly, so no
+// distance matrix larger than one row block ever exists. All comparisons are on SQUARED distances (monotone in the distance).
+
+// sq[n] = sum_c f[n][c]^2 (fp32 features, fp64 accumulation)
+__global__ __launch_bounds__(256) void k_row_sqnorm(const float* f, int n, int C, float* sq) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const int lane = threadIdx.x & 63;
+  double acc = 0.0;
+  for (int c = lane; c < C; c += 64) { const double v = f[(long long)r * C + c]; acc += v * v; }
+  acc = wave_sum_d(acc);
+  if (lane == 0) sq[r] = (float)acc;
+}
+extern "C" int sg_row_sqnorm(const float* f, int n, int C, float* sq, sg_stream_t s) {
+  SG_CHECK(f && sq && n > 0 && C > 0, "sg_row_sqnorm: bad args");
+  hipLaunchKernelGGL(k_row_sqnorm, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)s, f, n, C, sq);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+#define SG_KTH_MAX 16
+// out[r] = k-th smallest (1-based) of max(0, D[r][c] + row_add[r]) over c < cols. One wave per row: every lane keeps its own k
+// smallest in a sorted register list, then k rounds of "global minimum, owner pops" merge the 64 lists.
+__global__ __launch_bounds__(256) void k_kth_smallest_rows(const float* D, long long ld, int rows, int cols, int k, const float* row_add, float* out) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float add = row_add ? row_add[r] : 0.f;
+  float best[SG_KTH_MAX];
+#pragma unroll
+  for (int i = 0; i < SG_KTH_MAX; i++) best[i] = INFINITY;
+  const float* row = D + (long long)r * ld;
+  for (int c = lane; c < cols; c += 64) {
+    float v = fmaxf(row[c] + add, 0.f);
+    if (v < best[SG_KTH_MAX - 1]) {
+#pragma unroll
+      for (int i = 0; i < SG_KTH_MAX; i++) {        // insertion into the ascending list (only the first k entries matter)
+        const float b = best[i];
+        const bool lt = v < b;
+        best[i] = lt ? v : b;
+        v = lt ? b : v;
+      }
+    }
+  }
+  float kth = INFINITY;
+  for (int round = 0; round < k; round++) {
+    const float mine = best[0];
+    const float m = -wave_max(-mine);
+    kth = m;
+    // exactly one lane holding the minimum pops it (lowest lane among equals)
+    const unsigned long long owners = __ballot(mine == m);
+    const int first = __ffsll((long long)owners) - 1;
+    if (lane == first) {
+#pragma unroll
+      for (int i = 0; i < SG_KTH_MAX - 1; i++) best[i] = best[i + 1];
+      best[SG_KTH_MAX - 1] = INFINITY;
+    }
+  }
+  if (lane == 0) out[r] = kth;
+}
+extern "C" int sg_kth_smallest_rows(const float* D, long long ld, int rows, int cols, int k, const float* row_add, float* out, sg_stream_t s) {
+  SG_CHECK(D && out && rows > 0 && cols > 0 && k > 0 && k <= SG_KTH_MAX && k <= cols, "sg_kth_smallest_rows: bad args (k <= 16)");
+  hipLaunchKernelGGL(k_kth_smallest_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, D, ld, rows, cols, k, row_add, out);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
+// One pass over a row block of the real-vs-fake squared distances d2[r][c] = max(0, D[r][c] + row_add[r]):
+//   col_cnt[c] += #{ r : d2 < r2_row[r] }      (precision / density: fake c inside the k-NN ball of real r)      integer atomics: deterministic
+//   row_any[r]  = any_c d2 < r2_col[c]         (recall: real r inside the ball of some fake c)
+//   row_min[r]  = min_c d2                     (coverage: compared with r2_row[r] by the caller)
+__global__ __launch_bounds__(256) void k_prdc_rows(const float* D, long long ld, int rows, int cols, const float* row_add, const float* r2_row, const float* r2_col,
+                                                   int* col_cnt, uint8_t* row_any, float* row_min) {
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int lane = threadIdx.x & 63;
+  const float add = row_add[r], rr = r2_row[r];
+  const float* row = D + (long long)r * ld;
+  float mn = INFINITY;
+  int any = 0;
+  for (int c = lane; c < cols; c += 64) {
+    const float v = fmaxf(row[c] + add, 0.f);
+    mn = fminf(mn, v);
+    any |= (v < r2_col[c]) ? 1 : 0;
+    if (v < rr) atomicAdd(col_cnt + c, 1);
+  }
+  mn = -wave_max(-mn);
+  const unsigned long long a = __ballot(any != 0);
+  if (lane == 0) { row_min[r] = mn; row_any[r] = a ? 1 : 0; }
+}
+extern "C" int sg_prdc_rows(const float* D, long long ld, int rows, int cols, const float* row_add, const float* r2_row, const float* r2_col,
+                            int* col_cnt, uint8_t* row_any, float* row_min, sg_stream_t s) {
+  SG_CHECK(D && row_add && r2_row && r2_col && col_cnt && row_any && row_min && rows > 0 && cols > 0, "sg_prdc_rows: bad args");
+  hipLaunchKernelGGL(k_prdc_rows, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)s, D, ld, rows, cols, row_add, r2_row, r2_col, col_cnt, row_any, row_min);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

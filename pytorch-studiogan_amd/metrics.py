@@ -314,6 +314,43 @@ def frechet_inception_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
     return diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean)
 
 
+def frechet_inception_distance_device(mu1, sigma1, mu2, sigma2, device=None, max_sweeps=40, tol=1e-12):
+    """The same distance with tr sqrtm(S1 S2) computed on the GPU in fp64 (csrc/linalg.hip): Cholesky factors, B = L2^T L1, one-sided
+    Jacobi sweeps until the rows of B are orthogonal to `tol`, sum of their norms (= sum of sqrt of the eigenvalues of S1 S2).
+    When a covariance is not positive definite (fewer samples than dimensions) the host formula above -- the reference's own route,
+    eps branch included -- is used instead. Returns a python float."""
+    dev = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+    mu1, mu2 = np.atleast_1d(np.asarray(mu1, dtype=np.float64)), np.atleast_1d(np.asarray(mu2, dtype=np.float64))
+    s1, s2 = np.atleast_2d(np.asarray(sigma1, dtype=np.float64)), np.atleast_2d(np.asarray(sigma2, dtype=np.float64))
+    n = s1.shape[0]
+    ne = n + (n & 1)                                    # the tournament pairs rows: pad an odd dimension with one zero row / column of B
+    L1 = torch.from_numpy(s1).to(dev).contiguous().clone()
+    L2 = torch.from_numpy(s2).to(dev).contiguous().clone()
+    flags = torch.zeros(2, dtype=torch.int32, device=dev)
+    L.call("sg_chol_lower", L.ptr(L1), n, L.ptr(flags), L.stream())
+    L.call("sg_chol_lower", L.ptr(L2), n, L.ptr(flags) + 4, L.stream())
+    if int(flags.abs().sum().item()) != 0:
+        return float(frechet_inception_distance(mu1, s1, mu2, s2))
+    B = torch.empty((n, n), dtype=torch.float64, device=dev)
+    L.call("sg_dgemm_tn", L.ptr(L2), L.ptr(L1), L.ptr(B), n, L.stream())
+    if ne != n:
+        Bp = torch.zeros((ne, ne), dtype=torch.float64, device=dev)
+        Bp[:n, :n] = B
+        B = Bp
+    offd = torch.zeros(1, dtype=torch.float64, device=dev)
+    for _ in range(max_sweeps):
+        L.call("sg_jacobi_sweep", L.ptr(B), ne, L.ptr(offd), L.stream())
+        if float(offd.item()) < tol:
+            break
+    else:
+        if float(offd.item()) > 1e-8:       # (the sum of the singular values is second-order accurate in this measure)
+            raise RuntimeError(f"one-sided Jacobi did not converge in {max_sweeps} sweeps (off-diagonal measure {float(offd.item()):.2e})")
+    nuc = torch.zeros(1, dtype=torch.float64, device=dev)
+    L.call("sg_row_norm_sum", L.ptr(B), ne, L.ptr(nuc), L.stream())
+    diff = mu1 - mu2
+    return float(diff.dot(diff) + np.trace(s1) + np.trace(s2) - 2.0 * float(nuc.item()))
+
+
 def calculate_kl_div(ps, splits):
     """reference src/metrics/ins.py:28-42 (device tensors in, numpy scalars out)."""
     scores = []
@@ -371,3 +408,63 @@ def eval_features(probs, labels, num_features, split, is_acc, class_to_idx=None,
         top1 = topk_fn(probs, converted, 1, 1, 1000)
         top5 = topk_fn(probs, converted, 5, 1, 1000)
     return m_scores, m_std, top1, top5
+
+
+# ---------------------------------------------------------------------------------------------------------
+# precision / recall / density / coverage on the device (reference src/metrics/prdc.py:87-168)
+# ---------------------------------------------------------------------------------------------------------
+def _sq_dist_block(xb, y, y_sq, out):
+    """out[r][c] = |y_c|^2 - 2 x_r . y_c for a row block xb of X (exact-fp32 MFMA GEMM; |x_r|^2 is added by the consumer kernels)."""
+    rows, C = xb.shape
+    F.gemm_raw(L.F32, y, 0, C, xb, 0, C, out, y.shape[0], y.shape[0], rows, C, bias=y_sq, alpha=-2.0)
+    return out
+
+
+def _kth_nn_sq(feats, k, block=4096):
+    """squared distance of every row to its k-th nearest neighbour, the row itself included (prdc.py:128-140 with k = nearest_k + 1)."""
+    n, C = feats.shape
+    sq = torch.empty(n, dtype=torch.float32, device=feats.device)
+    L.call("sg_row_sqnorm", L.ptr(feats), n, C, L.ptr(sq), L.stream())
+    out = torch.empty(n, dtype=torch.float32, device=feats.device)
+    buf = torch.empty((min(block, n), n), dtype=torch.float32, device=feats.device)
+    for r0 in range(0, n, block):
+        xb = feats[r0:r0 + block]
+        d = _sq_dist_block(xb, feats, sq, buf[:xb.shape[0]])
+        L.call("sg_kth_smallest_rows", L.ptr(d), n, xb.shape[0], n, k, L.ptr(sq[r0:r0 + block]), L.ptr(out[r0:r0 + block]), L.stream())
+    return out, sq
+
+
+@torch.no_grad()
+def compute_prdc(real_features, fake_features, nearest_k, block=4096):
+    """reference src/metrics/prdc.py:143-168 `compute_prdc`: dict(precision, recall, density, coverage). Features: [N, dim] tensors
+    (any float dtype / device; computed in fp32 on the GPU). Three blocked fp32 GEMMs + streaming row reductions replace
+    sklearn.metrics.pairwise_distances(n_jobs=8) + np.argpartition over N x N float64 matrices; decisions are taken on squared
+    distances (monotone), the manifold radii are the (nearest_k + 1)-th smallest self-inclusive distances exactly as in the reference."""
+    assert 1 <= nearest_k < 16, "nearest_k + 1 <= 16 neighbours are kept per lane"
+    dev = torch.device("cuda", torch.cuda.current_device()) if not (torch.is_tensor(real_features) and real_features.is_cuda) else real_features.device
+    real = torch.as_tensor(real_features).to(device=dev, dtype=torch.float32).contiguous()
+    fake = torch.as_tensor(fake_features).to(device=dev, dtype=torch.float32).contiguous()
+    nr, nf = real.shape[0], fake.shape[0]
+    r2_real, sq_real = _kth_nn_sq(real, nearest_k + 1, block)
+    r2_fake, sq_fake = _kth_nn_sq(fake, nearest_k + 1, block)
+    col_cnt = torch.zeros(nf, dtype=torch.int32, device=dev)
+    row_any = torch.empty(nr, dtype=torch.uint8, device=dev)
+    row_min = torch.empty(nr, dtype=torch.float32, device=dev)
+    buf = torch.empty((min(block, nr), nf), dtype=torch.float32, device=dev)
+    for r0 in range(0, nr, block):
+        xb = real[r0:r0 + block]
+        d = _sq_dist_block(xb, fake, sq_fake, buf[:xb.shape[0]])
+        L.call("sg_prdc_rows", L.ptr(d), nf, xb.shape[0], nf, L.ptr(sq_real[r0:r0 + block]), L.ptr(r2_real[r0:r0 + block]), L.ptr(r2_fake), L.ptr(col_cnt),
+               L.ptr(row_any[r0:r0 + block]), L.ptr(row_min[r0:r0 + block]), L.stream())
+    cnt = col_cnt.double()
+    precision = float((cnt > 0).double().mean())
+    recall = float(row_any.double().mean())
+    density = float(cnt.mean() / float(nearest_k))
+    coverage = float((row_min < r2_real).double().mean())
+    return dict(precision=precision, recall=recall, density=density, coverage=coverage)
+
+
+def calculate_pr_dc(real_feats, fake_feats, num_generate, nearest_k):
+    """reference src/metrics/prdc.py:66-84 with the features already extracted (the fake stack is truncated to num_generate first)."""
+    m = compute_prdc(real_feats, fake_feats[:num_generate], nearest_k)
+    return m["precision"], m["recall"], m["density"], m["coverage"]

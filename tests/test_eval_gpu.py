@@ -152,3 +152,54 @@ def test_topk_training_select_and_scatter(sg):
     for _ in range(200):
         k = SL.adjust_k(current_k=k, topk_gamma=0.99, inf_k=int(256 * 0.5))
     assert k == 128
+
+
+def test_prdc_on_device_vs_reference_fixture_and_oracle(sg):
+    """metrics.compute_prdc (blocked fp32 GEMM + streaming k-th-value / ball-membership kernels) against (a) the REAL reference's
+    compute_prdc output stored in tests/golden/metrics_host.npz (src/metrics/prdc.py:143-168; counts of strict inequalities: exact),
+    (b) the float64 oracle restatement at Inception-like scale (3000 x 2048 features, several row blocks, k = 5 and 3)."""
+    import os
+    from studiogan_amd import metrics as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_host.npz"))
+    dev = torch.device("cuda:0")
+    real, fake = torch.from_numpy(z["in/prdc_real"]), torch.from_numpy(z["in/prdc_fake"])
+    for block in (4096, 128):                      # one row block / several (ragged last block)
+        m = M.compute_prdc(real.to(dev), fake.to(dev), 5, block=block)
+        for k in ("precision", "recall", "density", "coverage"):
+            assert abs(m[k] - float(z["exp/prdc_" + k])) < 1e-12, (k, block, m[k], float(z["exp/prdc_" + k]))
+    g = torch.Generator().manual_seed(33)
+    base = torch.rand(1, 2048, generator=g)
+    real = torch.relu(torch.randn(3000, 2048, generator=g) * 0.5 + base)            # non-negative, Inception-pool-like magnitudes
+    fake = torch.relu(torch.randn(2500, 2048, generator=g) * 0.55 + base + 0.02)
+    for k in (5, 3):
+        mo = OI.prdc(real, fake, k)
+        m = M.compute_prdc(real.to(dev), fake.to(dev), k, block=1024)
+        p, r, d, c = M.calculate_pr_dc(real.to(dev), fake.to(dev), 2500, k)
+        assert (p, r, d, c) == (m["precision"], m["recall"], m["density"], m["coverage"])
+        for name in ("precision", "recall", "density", "coverage"):
+            # a decision flips only when a squared distance ties a radius within fp32 rounding: at most a few of 2500-3000 samples
+            assert abs(m[name] - mo[name]) <= 2e-3, (k, name, m[name], mo[name])
+
+
+def test_frechet_distance_on_device_vs_reference_and_scipy(sg):
+    """frechet_inception_distance_device (fp64 Cholesky + B = L2^T L1 + one-sided Jacobi, csrc/linalg.hip) against (a) the REAL
+    reference's frechet_inception_distance outputs of tests/golden/metrics_host.npz (src/metrics/fid.py:34-62, scipy sqrtm), including
+    the rank-deficient pair that must take the host route, (b) the scipy formula on random 384-dimensional covariances (odd size too),
+    (c) the known answer FID(x, x) = 0."""
+    import os
+    from studiogan_amd import metrics as M
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_host.npz"))
+    ab = M.frechet_inception_distance_device(z["in/mu_a"], z["in/sigma_a"], z["in/mu_b"], z["in/sigma_b"])
+    assert abs(ab - float(z["exp/fid_ab"])) <= 1e-9 * abs(float(z["exp/fid_ab"])), (ab, float(z["exp/fid_ab"]))
+    ac = M.frechet_inception_distance_device(z["in/mu_a"], z["in/sigma_a"], z["in/mu_c"], z["in/sigma_c"])      # sigma_c: rank <= 29 of 64 -> host route
+    assert abs(ac - float(z["exp/fid_ac"])) <= 1e-9 * abs(float(z["exp/fid_ac"])), (ac, float(z["exp/fid_ac"]))
+    aa = M.frechet_inception_distance_device(z["in/mu_a"], z["in/sigma_a"], z["in/mu_a"], z["in/sigma_a"])
+    assert abs(aa) < 1e-9
+    rs = np.random.RandomState(3)
+    for n in (384, 129):
+        xa = rs.randn(4 * n, n) @ (np.eye(n) + 0.2 * rs.randn(n, n))
+        xb = rs.randn(4 * n, n) * 1.2 + 0.1
+        m1, s1, m2, s2 = xa.mean(0), np.cov(xa, rowvar=False), xb.mean(0), np.cov(xb, rowvar=False)
+        ref = float(M.frechet_inception_distance(m1, s1, m2, s2))
+        got = M.frechet_inception_distance_device(m1, s1, m2, s2)
+        assert abs(got - ref) <= 1e-8 * abs(ref), (n, got, ref)

@@ -308,3 +308,14 @@ def test_inception_oracle_pinned_to_the_references_own_code():
                 sys.modules.pop(k, None)
             else:
                 sys.modules[k] = v
+
+
+def test_prdc_restatement_matches_reference_fixture():
+    """oracle/inception.py prdc() on the stored inputs against the REAL reference's compute_prdc outputs (tests/golden/metrics_host.npz,
+    written by oracle/make_golden_metrics.py, which also asserts the identity at generation time)."""
+    import numpy as np
+    from oracle import inception as OI
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "metrics_host.npz"))
+    m = OI.prdc(torch.from_numpy(z["in/prdc_real"]), torch.from_numpy(z["in/prdc_fake"]), 5)
+    for k in ("precision", "recall", "density", "coverage"):
+        assert abs(m[k] - float(z["exp/prdc_" + k])) < 1e-12, (k, m[k])
