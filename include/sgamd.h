@@ -293,6 +293,19 @@ int sg_topk_select(const float* x, int n, int k, float* vals, int* idx, sg_strea
 int sg_topk_scatter(const float* g, const int* idx, int k, float* dx, int n, sg_stream_t s);
 /* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
 int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
+/* ---- class-conditioning heads and losses (reference src/utils/losses.py:40-165,242-252; src/models/big_resnet.py:307-333,380-413).
+ * All fp32, [rows][cols] row-major; losses are means over rows and return the gradient of that mean in the same call. */
+int sg_row_normalize_fwd(const float* x, float* y, float* inv, int rows, int cols, float eps, sg_stream_t s);   /* F.normalize(dim=1) */
+int sg_row_normalize_bwd(const float* y, const float* inv, const float* dy, float* dx, int rows, int cols, sg_stream_t s);
+int sg_row_dot(const float* a, const float* b, float* p, int rows, int cols, sg_stream_t s);                    /* p[r] = <a[r], b[r]> */
+int sg_row_scale(const float* g, const float* x, float* out, int rows, int cols, int accumulate, sg_stream_t s); /* out[r] (+)= g[r] x[r] */
+/* kind 0: cross entropy (AC head), 1: Crammer-Singer multi-hinge (MH head): row_loss[rows], loss[1] = mean, dz = d loss / d z */
+int sg_class_loss(int kind, const float* z, const int64_t* label, int rows, int cols, float* row_loss, float* loss, float* dz, sg_stream_t s);
+/* kind 0: conditional contrastive loss (2C), 1: data-to-data cross entropy (D2D-CE) over S = cos(e_i, e_j) [B][B], p = cos(e_i, proxy_i) */
+int sg_contrastive_loss(int kind, const float* S, const float* p, const int64_t* label, int B, float temperature, float m_p,
+                        float* row_loss, float* loss, float* dS, float* dp, sg_stream_t s);
+int sg_gather_cols(const float* z, const int64_t* label, int rows, int cols, float* out, sg_stream_t s);       /* MD head: z[r][label[r]] */
+int sg_scatter_cols(const float* g, const int64_t* label, int rows, int cols, float* dz, sg_stream_t s);
 /* ---- precision / recall / density / coverage (reference src/metrics/prdc.py:87-168) on squared distances. The cross term
  * D[r][c] = |y_c|^2 - 2 x_r . y_c comes from sg_gemm (fp32, alpha = -2, bias = |y|^2) one row block at a time. */
 int sg_row_sqnorm(const float* f, int n, int C, float* sq, sg_stream_t s);

@@ -186,7 +186,8 @@ def oracle_cfg(y):
                 z_dim=M.get("z_dim", 128), attn_g_loc=M.get("attn_g_loc", []), attn_d_loc=M.get("attn_d_loc", []), apply_attn=M.get("apply_attn", False),
                 g_cond_mtd=M.get("g_cond_mtd", "W/O"), d_cond_mtd=M.get("d_cond_mtd", "W/O"), apply_g_sn=M.get("apply_g_sn", False),
                 apply_d_sn=M.get("apply_d_sn", False), backbone=M.get("backbone", "resnet"), g_shared_dim=M.get("g_shared_dim", 0),
-                g_depth=M.get("g_depth", 1), d_depth=M.get("d_depth", 1))
+                g_depth=M.get("g_depth", 1), d_depth=M.get("d_depth", 1), aux_cls_type=M.get("aux_cls_type", "W/O"),
+                normalize_d_embed=M.get("normalize_d_embed", False), d_embed_dim=M.get("d_embed_dim", "N/A"))
 
 
 def synth_inputs(seed, n_d, batch, z_dim, num_classes, img_size):

@@ -751,3 +751,109 @@ def model_fns(cfg):
             return dcgan_discriminator(x, y, P, B, cfg, bn_mode, sn_iter)
         return gen_fn, dis_fn
     raise NotImplementedError(bb)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# class-conditioning heads and losses (models/big_resnet.py:307-333,358-413; utils/losses.py:40-165,242-252)
+# ---------------------------------------------------------------------------------------------------------
+def d_heads(adv, h, label, P, B, cfg, adc_fake=False, sn_iter=True):
+    """Everything of Discriminator.forward after `adv_output = squeeze(linear1(h))` (big_resnet.py:363-413) except the projection term
+    (already in the trunk functions). Returns the dictionary the reference returns (the entries the losses read)."""
+    mtd, aux, nrm = cfg.get("d_cond_mtd", "W/O"), cfg.get("aux_cls_type", "W/O"), cfg.get("normalize_d_embed", False)
+    out = {"h": h, "adv_output": adv, "embed": None, "proxy": None, "cls_output": None, "label": label,
+           "mi_embed": None, "mi_proxy": None, "mi_cls_output": None}
+    if aux == "ADC":
+        label = label * 2 + 1 if adc_fake else label * 2
+        out["label"] = label
+    if mtd == "AC":
+        if nrm:
+            h = F.normalize(h, dim=1)          # (the weight normalisation loop of the reference is a no-op: it rebinds a local name)
+            out["h"] = h
+        out["cls_output"] = linear(h, P, B, "linear2", sn_iter)
+    elif mtd in ("2C", "D2DCE"):
+        embed = linear(h, P, B, "linear2", sn_iter)
+        proxy = F.embedding(label, weight_of(P, B, "embedding", sn_iter))
+        if nrm:
+            embed, proxy = F.normalize(embed, dim=1), F.normalize(proxy, dim=1)
+        out["embed"], out["proxy"] = embed, proxy
+    elif mtd == "MD":
+        out["adv_output"] = adv[torch.arange(label.shape[0]), label]
+    if aux == "TAC":
+        if mtd == "AC":
+            out["mi_cls_output"] = linear(h, P, B, "linear_mi", sn_iter)
+        elif mtd in ("2C", "D2DCE"):
+            mi_e = linear(h, P, B, "linear_mi", sn_iter)
+            mi_p = F.embedding(label, weight_of(P, B, "embedding_mi", sn_iter))
+            if nrm:
+                mi_e, mi_p = F.normalize(mi_e, dim=1), F.normalize(mi_p, dim=1)
+            out["mi_embed"], out["mi_proxy"] = mi_e, mi_p
+    return out
+
+
+def _cos_matrix(x, y):
+    return F.cosine_similarity(x.unsqueeze(1), y.unsqueeze(0), dim=-1)
+
+
+def _off_diag(M):
+    n = M.shape[0]
+    return M[~torch.eye(n, dtype=torch.bool)].view(n, n - 1)
+
+
+def cond_loss(mtd, out, temperature=1.0, m_p=1.0):
+    """utils/losses.py:40-47 (AC: cross entropy), :50-97 (2C), :100-165 (D2DCE) on a head dictionary."""
+    label = out["label"]
+    if mtd == "AC":
+        return F.cross_entropy(out["cls_output"], label)
+    embed, proxy = out["embed"], out["proxy"]
+    same = (label.view(-1, 1) == label.view(1, -1))
+    if mtd == "2C":
+        sim = torch.exp(_off_diag(_cos_matrix(embed, embed)) / temperature)
+        pos = _off_diag(same.long()) * sim
+        e2p = torch.exp(F.cosine_similarity(embed, proxy, dim=-1) / temperature)
+        num = e2p + pos.sum(dim=1)
+        den = torch.cat([e2p.unsqueeze(1), sim], dim=1).sum(dim=1)
+        return -torch.log(num / den).mean()
+    if mtd == "D2DCE":
+        sim = _off_diag((_cos_matrix(embed, embed) + m_p - 1) / temperature)
+        mx, _ = torch.max(sim, dim=1, keepdim=True)
+        sim = F.relu(sim) - mx.detach()
+        s2p = F.cosine_similarity(embed, proxy, dim=-1)
+        improved = _off_diag((~same).long()) * torch.exp(sim)
+        pos_attr = F.relu((m_p - s2p) / temperature)
+        neg_repul = torch.log(torch.exp(-pos_attr) + improved.sum(dim=1))
+        return (pos_attr + neg_repul).mean()
+    raise NotImplementedError(mtd)
+
+
+def crammer_singer(adv, label):
+    """utils/losses.py:242-252."""
+    n = adv.shape[1] - 1
+    mask = torch.ones_like(adv)
+    mask.scatter_(1, label.unsqueeze(-1), 0)
+    wrongs = torch.masked_select(adv, mask.bool()).reshape(adv.shape[0], n)
+    max_wrong = wrongs.max(1)[0].unsqueeze(-1)
+    target = adv.gather(1, label.unsqueeze(-1))
+    return torch.mean(F.relu(1 + max_wrong - target))
+
+
+def d_side_loss(dis_fn, P, B, cfg, real, real_labels, fake, fake_labels, loss_kind, hp):
+    """The discriminator-side loss of one micro-batch with class conditioning (src/worker.py:281-317): adversarial loss (or the multi-hinge
+    pair) + cond_lambda * conditioning loss on the real half (+ the TAC / ADC term on the fake half). hp: cond_lambda, temperature, m_p,
+    tac_dis_lambda. Returns (loss, real head dictionary, fake head dictionary)."""
+    mtd, aux = cfg.get("d_cond_mtd", "W/O"), cfg.get("aux_cls_type", "W/O")
+    adv_r, h_r = dis_fn(real, real_labels, P, B)
+    rd = d_heads(adv_r, h_r, real_labels, P, B, cfg, False)
+    adv_f, h_f = dis_fn(fake, fake_labels, P, B)
+    fd = d_heads(adv_f, h_f, fake_labels, P, B, cfg, aux == "ADC")
+    if loss_kind == "MH":
+        lossy = torch.full((fake.shape[0],), cfg["num_classes"], dtype=torch.long)
+        loss = crammer_singer(rd["adv_output"], rd["label"]) + crammer_singer(fd["adv_output"], lossy)
+    else:
+        loss = d_loss(loss_kind, rd["adv_output"], fd["adv_output"])
+    if mtd in ("AC", "2C", "D2DCE"):
+        loss = loss + hp["cond_lambda"] * cond_loss(mtd, rd, hp["temperature"], hp["m_p"])
+        if aux == "TAC":
+            loss = loss + hp["tac_dis_lambda"] * cond_loss(mtd, fd, hp["temperature"], hp["m_p"])     # (src/worker.py:311: the twin loss reads cls_output / embed / proxy)
+        elif aux == "ADC":
+            loss = loss + hp["cond_lambda"] * cond_loss(mtd, fd, hp["temperature"], hp["m_p"])
+    return loss, rd, fd

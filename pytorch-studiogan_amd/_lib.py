@@ -135,6 +135,14 @@ _PROTOS = {
     "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_topk_hits": [_vp, _i, _i, _vp, _i, _i, _vp, _vp],
+    "sg_row_normalize_fwd": [_vp, _vp, _vp, _i, _i, _f, _vp],
+    "sg_row_normalize_bwd": [_vp, _vp, _vp, _vp, _i, _i, _vp],
+    "sg_row_dot": [_vp, _vp, _vp, _i, _i, _vp],
+    "sg_row_scale": [_vp, _vp, _vp, _i, _i, _i, _vp],
+    "sg_class_loss": [_i, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "sg_contrastive_loss": [_i, _vp, _vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_gather_cols": [_vp, _vp, _i, _i, _vp, _vp],
+    "sg_scatter_cols": [_vp, _vp, _i, _i, _vp, _vp],
     "sg_chol_lower": [_vp, _i, _vp, _vp],
     "sg_dgemm_tn": [_vp, _vp, _vp, _i, _vp],
     "sg_jacobi_sweep": [_vp, _i, _vp, _vp],

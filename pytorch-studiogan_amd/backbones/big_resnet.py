@@ -16,6 +16,7 @@ import torch.nn as nn
 from .. import functional as F
 from .. import ops
 from ..bank import get_bank
+from .heads import build_heads, apply_heads
 
 
 def _dtype(mixed_precision):
@@ -238,8 +239,6 @@ class Discriminator(nn.Module):
         self.out_dims = d_out_dims_collection[str(img_size)]
         self.MODEL = MODEL
         down = d_down[str(img_size)]
-        if d_cond_mtd not in ("W/O", "PD") or aux_cls_type not in ("W/O", "N/A") or getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("only the unconditional and projection (PD) heads are on the benchmarked hot path (SURVEY.md §8f)")
 
         blocks = []
         for index in range(len(self.in_dims)):
@@ -252,9 +251,7 @@ class Discriminator(nn.Module):
                 blocks += [[ops.SelfAttention(self.out_dims[index], is_generator=False, MODULES=MODULES)]]
         self.blocks = nn.ModuleList([nn.ModuleList(block) for block in blocks])
         self.activation = MODULES.d_act_fn
-        self.linear1 = MODULES.d_linear(in_features=self.out_dims[-1], out_features=1, bias=True)
-        if self.d_cond_mtd == "PD":
-            self.embedding = MODULES.d_embedding(num_classes, self.out_dims[-1])
+        build_heads(self, MODULES, self.out_dims[-1], d_cond_mtd, aux_cls_type, d_embed_dim, num_classes, MODEL)
         if d_init:
             ops.init_weights(self.modules, d_init)
         ops.adopt(self, _dtype(mixed_precision))
@@ -268,11 +265,4 @@ class Discriminator(nn.Module):
             for block in blocklist:
                 h = block.forward_nhwc(h, slot)
         h = F.ReluSumFn.apply(h)
-        pd = self.d_cond_mtd == "PD"
-        adv_output = F.PDHeadFn.apply(h, self.linear1.master_weight, self.linear1.bias, self.embedding.master_weight if pd else None,
-                                      label if pd else None, self.linear1._sg_rt, self.embedding._sg_rt if pd else None, slot)
-        return {
-            "h": h, "adv_output": adv_output, "embed": None, "proxy": None, "cls_output": None, "label": label,
-            "mi_embed": None, "mi_proxy": None, "mi_cls_output": None,
-            "info_discrete_c_logits": None, "info_conti_mu": None, "info_conti_var": None
-        }
+        return apply_heads(self, h, label, slot, adc_fake)

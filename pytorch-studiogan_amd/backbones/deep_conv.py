@@ -12,6 +12,7 @@ import torch.nn.functional as TF
 from .. import functional as F
 from .. import ops
 from ..bank import get_bank
+from .heads import build_heads, apply_heads
 from .big_resnet import _dtype, _need_graph
 
 
@@ -123,8 +124,6 @@ class Discriminator(nn.Module):
         self.num_classes = num_classes
         self.mixed_precision = mixed_precision
         self.MODEL = MODEL
-        if d_cond_mtd not in ("W/O", "PD") or aux_cls_type not in ("W/O", "N/A") or getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("only the unconditional and projection (PD) heads are on the benchmarked hot path (SURVEY.md §8f)")
         blocks = []
         for index in range(len(self.in_dims)):
             blocks += [[DiscBlock(in_channels=self.in_dims[index], out_channels=self.out_dims[index], apply_d_sn=self.apply_d_sn, MODULES=MODULES)]]
@@ -135,9 +134,7 @@ class Discriminator(nn.Module):
         self.conv1 = MODULES.d_conv2d(in_channels=256, out_channels=512, kernel_size=3, stride=1, padding=1)
         if not self.apply_d_sn:
             self.bn1 = MODULES.d_bn(in_features=512)
-        self.linear1 = MODULES.d_linear(in_features=512, out_features=1, bias=True)
-        if self.d_cond_mtd == "PD":
-            self.embedding = MODULES.d_embedding(num_classes, 512)
+        build_heads(self, MODULES, 512, d_cond_mtd, aux_cls_type, d_embed_dim, num_classes, MODEL)
         self.blocks[0][0].conv0._sg_cin_pad = 8     # RGB image as an 8-channel NHWC tensor (zero-filled)
         if d_init:
             ops.init_weights(self.modules, d_init)
@@ -165,11 +162,4 @@ class Discriminator(nn.Module):
             h = self.conv1.forward_nhwc(h, slot)
             h = self.bn1.forward_nhwc(h)
             h = F.ReluSumFn.apply(h)
-        pd = self.d_cond_mtd == "PD"
-        adv_output = F.PDHeadFn.apply(h, self.linear1.master_weight, self.linear1.bias, self.embedding.master_weight if pd else None,
-                                      label if pd else None, self.linear1._sg_rt, self.embedding._sg_rt if pd else None, slot)
-        return {
-            "h": h, "adv_output": adv_output, "embed": None, "proxy": None, "cls_output": None, "label": label,
-            "mi_embed": None, "mi_proxy": None, "mi_cls_output": None,
-            "info_discrete_c_logits": None, "info_conti_mu": None, "info_conti_var": None
-        }
+        return apply_heads(self, h, label, slot, adc_fake)

@@ -140,3 +140,61 @@ def adjust_k(current_k, topk_gamma, inf_k):
 def topk_values(d_logit_fake, k):
     """torch.topk(d_logit_fake, k).values of reference src/worker.py:565-566 (one small kernel each way)."""
     return F.TopkFn.apply(d_logit_fake, int(k))
+
+
+# ---------------------------------------------------------------------------------------------------------
+# class-conditioning losses (reference src/utils/losses.py:40-165,242-252; chosen by src/worker.py:141-157)
+# ---------------------------------------------------------------------------------------------------------
+def _gather_cat(t, group, DDP):
+    """torch.cat(GatherLayer.apply(t), dim=0) of the reference under DDP; labels (no gradient) take a plain all-gather."""
+    if not DDP or not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return t
+    if t.is_floating_point():
+        return GatherLayer.apply(t, group)
+    parts = [torch.empty_like(t) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, t.contiguous(), group=group)
+    return torch.cat(parts, dim=0)
+
+
+class CrossEntropyLoss(torch.nn.Module):
+    """reference losses.py:40-47 (ACGAN / TAC / ADC auxiliary classifier): forward(cls_output, label, **_)."""
+
+    def forward(self, cls_output, label, **_):
+        return F.ClassLossFn.apply(cls_output, label, 0)
+
+
+class _EmbedProxyLoss(torch.nn.Module):
+    kind = 0
+
+    def __init__(self, num_classes, temperature, master_rank="cuda", DDP=False, m_p=0.0, group=None):
+        super().__init__()
+        self.num_classes, self.temperature, self.master_rank, self.DDP, self.m_p, self.group = num_classes, temperature, master_rank, DDP, m_p, group
+
+    def forward(self, embed, proxy, label, **_):
+        embed, proxy, label = (_gather_cat(t, self.group, self.DDP) for t in (embed, proxy, label))
+        en = F.RowNormalizeFn.apply(embed, 1e-8)           # torch.nn.CosineSimilarity(dim=-1, eps=1e-8): x.y / (|x| |y|)
+        pn = F.RowNormalizeFn.apply(proxy, 1e-8)
+        S = F.MatmulNTFn.apply(en, en)                     # cosine similarity of every pair of embeddings
+        p = F.RowDotFn.apply(en, pn)                       # ... of every embedding with the proxy of its own class
+        return F.ContrastiveLossFn.apply(S, p, label, self.kind, self.temperature, self.m_p)
+
+
+class ConditionalContrastiveLoss(_EmbedProxyLoss):
+    """ContraGAN's 2C loss, reference losses.py:50-97: ConditionalContrastiveLoss(num_classes, temperature, master_rank, DDP)."""
+    kind = 0
+
+    def __init__(self, num_classes, temperature, master_rank="cuda", DDP=False, group=None):
+        super().__init__(num_classes, temperature, master_rank, DDP, 0.0, group)
+
+
+class Data2DataCrossEntropyLoss(_EmbedProxyLoss):
+    """ReACGAN's D2D-CE loss, reference losses.py:100-165: Data2DataCrossEntropyLoss(num_classes, temperature, m_p, master_rank, DDP)."""
+    kind = 1
+
+    def __init__(self, num_classes, temperature, m_p, master_rank="cuda", DDP=False, group=None):
+        super().__init__(num_classes, temperature, master_rank, DDP, m_p, group)
+
+
+def crammer_singer_loss(adv_output, label, DDP=False, **_):
+    """multi-hinge criterion, reference losses.py:242-252: mean relu(1 + max_{c != label} adv[c] - adv[label])."""
+    return F.ClassLossFn.apply(adv_output, label, 1)

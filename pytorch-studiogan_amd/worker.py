@@ -67,7 +67,9 @@ class Worker:
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
                  group=None, apply_gp=False, gp_lambda=10.0, apply_topk=False, topk_gamma=0.99, topk_nu=0.5,
                  apply_r1_reg=False, r1_lambda=10.0, apply_maxgp=False, maxgp_lambda=1.0, apply_dra=False, dra_lambda=10.0,
-                 apply_lecam=False, lecam_lambda=0.3, lecam_ema_start_iter=1000, lecam_ema_decay=0.99):
+                 apply_lecam=False, lecam_lambda=0.3, lecam_ema_start_iter=1000, lecam_ema_decay=0.99,
+                 d_cond_mtd="W/O", aux_cls_type="W/O", cond_lambda=1.0, temperature=1.0, m_p=1.0, tac_dis_lambda=1.0, tac_gen_lambda=1.0,
+                 mh_lambda=1.0):
         self.Gen, self.Dis = Gen, Dis
         self.apply_dra, self.dra_lambda = apply_dra, dra_lambda
         self.apply_lecam, self.lecam_lambda, self.lecam_ema_start_iter = apply_lecam, lecam_lambda, lecam_ema_start_iter
@@ -78,7 +80,26 @@ class Worker:
         self.topk = batch_size
         self.apply_gp, self.gp_lambda = apply_gp, gp_lambda
         self.z_dim, self.num_classes, self.batch_size = z_dim, num_classes, batch_size
-        self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
+        # class conditioning of the discriminator (reference src/worker.py:123-157): classifier-based GANs get a conditioning loss on top of
+        # the adversarial one; the multi-hinge loss ("MH") replaces it
+        self.adv_loss, self.d_cond_mtd, self.aux_cls_type = adv_loss, d_cond_mtd, aux_cls_type
+        self.cond_lambda, self.tac_dis_lambda, self.tac_gen_lambda, self.mh_lambda = cond_lambda, tac_dis_lambda, tac_gen_lambda, mh_lambda
+        self.adc_fake = aux_cls_type == "ADC"
+        nc = num_classes * 2 if self.adc_fake else num_classes
+        DDP = group is not None
+        self.cond_loss = None
+        if d_cond_mtd == "AC":
+            self.cond_loss = sg_losses.CrossEntropyLoss()
+        elif d_cond_mtd == "2C":
+            self.cond_loss = sg_losses.ConditionalContrastiveLoss(num_classes=nc, temperature=temperature, master_rank="cuda", DDP=DDP, group=group)
+        elif d_cond_mtd == "D2DCE":
+            self.cond_loss = sg_losses.Data2DataCrossEntropyLoss(num_classes=nc, temperature=temperature, m_p=m_p, master_rank="cuda", DDP=DDP, group=group)
+        self.cond_loss_mi = copy.deepcopy(self.cond_loss) if aux_cls_type == "TAC" else None
+        if adv_loss == "MH":
+            self.d_loss = self.g_loss = sg_losses.crammer_singer_loss
+            self.lossy = torch.full((batch_size,), num_classes, dtype=torch.long, device=next(Gen.parameters()).device)
+        else:
+            self.d_loss, self.g_loss = sg_losses.D_LOSSES[adv_loss], sg_losses.G_LOSSES[adv_loss]
         self.n_d, self.n_g, self.acml = d_updates_per_step, g_updates_per_step, acml_steps
         self.device = next(Gen.parameters()).device
         if group is not None:
@@ -112,9 +133,23 @@ class Worker:
                 if self.apply_r1_reg:    # src/worker.py:260-261
                     real_images = real_images.detach().requires_grad_(True)
                 real_dict = self.Dis(real_images, real_labels)
-                fake_dict = self.Dis(fake_images, fake_labels)
+                fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
-                dis_acml_loss = self.d_loss(real_dict["adv_output"], fake_dict["adv_output"], DDP=self.group is not None)
+                if self.adv_loss == "MH":          # src/worker.py:300-302
+                    dis_acml_loss = self.d_loss(DDP=self.group is not None, **real_dict)
+                    dis_acml_loss = dis_acml_loss + self.d_loss(fake_dict["adv_output"], self.lossy, DDP=self.group is not None)
+                else:
+                    dis_acml_loss = self.d_loss(real_dict["adv_output"], fake_dict["adv_output"], DDP=self.group is not None)
+                if self.cond_loss is not None:     # src/worker.py:307-317
+                    real_cond_loss = self.cond_loss(**real_dict)
+                    self.last_cond = real_cond_loss.detach()
+                    dis_acml_loss = dis_acml_loss + self.cond_lambda * real_cond_loss
+                    if self.aux_cls_type == "TAC":
+                        # (the reference hands the WHOLE dictionary to the twin loss, whose forward picks cls_output / embed / proxy -- not the
+                        #  mi_* entries, src/worker.py:311 with src/utils/losses.py:45,78,139; mirrored as is)
+                        dis_acml_loss = dis_acml_loss + self.tac_dis_lambda * self.cond_loss_mi(**fake_dict)
+                    elif self.aux_cls_type == "ADC":
+                        dis_acml_loss = dis_acml_loss + self.cond_lambda * self.cond_loss(**fake_dict)
                 if self.apply_gp:   # src/worker.py:369-375
                     gp_loss = sg_losses.cal_grad_penalty(real_images=real_images, real_labels=real_labels, fake_images=fake_images,
                                                          discriminator=self.Dis, device=self.device)
@@ -161,7 +196,17 @@ class Worker:
                 self.last_g = (fake_images.detach(), fake_dict["adv_output"].detach())
                 if self.apply_topk:      # src/worker.py:565-566
                     fake_dict["adv_output"] = sg_losses.topk_values(fake_dict["adv_output"], int(self.topk))
-                gen_acml_loss = self.g_loss(fake_dict["adv_output"], DDP=self.group is not None)
+                if self.adv_loss == "MH":          # src/worker.py:569-572
+                    gen_acml_loss = self.mh_lambda * self.g_loss(DDP=self.group is not None, **fake_dict)
+                else:
+                    gen_acml_loss = self.g_loss(fake_dict["adv_output"], DDP=self.group is not None)
+                if self.cond_loss is not None:     # src/worker.py:575-585
+                    gen_acml_loss = gen_acml_loss + self.cond_lambda * self.cond_loss(**fake_dict)
+                    if self.aux_cls_type == "TAC":
+                        gen_acml_loss = gen_acml_loss - self.tac_gen_lambda * self.cond_loss_mi(**fake_dict)      # src/worker.py:579
+                    elif self.aux_cls_type == "ADC":
+                        adc_fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
+                        gen_acml_loss = gen_acml_loss - self.cond_lambda * self.cond_loss(**adc_fake_dict)
                 gen_acml_loss = gen_acml_loss / self.acml
                 gen_acml_loss.backward()
                 gen_acml_loss = gen_acml_loss.detach()

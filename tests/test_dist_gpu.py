@@ -111,9 +111,12 @@ def test_two_ranks_on_one_gpu_equal_the_full_batch_step(sg, name):
     gm = max(float(v.abs().max()) for v in full["g_grad"].values())
     for k, v in full["g_grad"].items():
         C.check("G grad " + k, a["g_grad"][k], v, 5e-3, floor=1e-2 * gm)      # through every ReLU of D after one D update (see DESIGN "conditioning")
+    from util import load_golden, hyper
+    lr = max(hyper(load_golden(name)[1]["yaml"])[k] for k in ("g_lr", "d_lr"))
     for k, v in full["state"].items():
         if v.dtype.is_floating_point:
-            C.check("state " + k, a["state"][k], v, 2e-3, floor=0.05)
+            # (an element whose gradient is rounding noise -- e.g. a conv bias in front of a BN -- moves by +-lr with either sign)
+            C.check("state " + k, a["state"][k], v, 2e-3, floor=0.05, abs_ok=2.2 * lr)
         else:
             assert torch.equal(a["state"][k], v), k
     C.finish()

@@ -26,7 +26,8 @@ def build_from_yaml(y, mixed, device):
     G = bb.Generator(M.get("z_dim", 128), M.get("g_shared_dim", "N/A"), D["img_size"], M.get("g_conv_dim", 64), M.get("apply_attn", False),
                      M.get("attn_g_loc", ["N/A"]), M.get("g_cond_mtd", "W/O"), D["num_classes"], "ortho", M.get("g_depth", "N/A"), mixed, MOD, _MODEL)
     Dm = bb.Discriminator(D["img_size"], M.get("d_conv_dim", 64), M.get("apply_d_sn", False), M.get("apply_attn", False), M.get("attn_d_loc", ["N/A"]),
-                          M.get("d_cond_mtd", "W/O"), "W/O", "N/A", False, D["num_classes"], "ortho", M.get("d_depth", "N/A"), mixed, MOD, _MODEL)
+                          M.get("d_cond_mtd", "W/O"), M.get("aux_cls_type", "W/O"), M.get("d_embed_dim", "N/A"), M.get("normalize_d_embed", False),
+                          D["num_classes"], "ortho", M.get("d_depth", "N/A"), mixed, MOD, _MODEL)
     return G.to(device), Dm.to(device)
 
 
@@ -115,11 +116,11 @@ def step_vs_golden(name, mixed):
         return 2.2 * lr * n_upd if (g is not None and absmax(g) < 1e-4 * fam_max) else None
     for k, v in list(G.named_parameters()) + [(k, b) for k, b in G.named_buffers() if "_ones" not in k]:
         C.check("G_final/" + k, v, exp["G_final/" + k], (3 if wide else 1) * 4 * t2, floor=lr_floor, abs_tol=zero_grad_kick("G_grad/", k, gmx, opt["g_lr"], 1),
-                noise=nz("G_final/" + k))
+                noise=nz("G_final/" + k), abs_ok=2.2 * opt["g_lr"] if v.is_floating_point() and k in dict(G.named_parameters()) else None)
     for k, v in list(D.named_parameters()) + list(D.named_buffers()):
         uv = wide and mixed and k.endswith(("weight_u", "weight_v"))     # unit vectors of a power iteration over bf16-noisy weights: L2, 0.5
         C.check("D_final/" + k, v, exp["D_final/" + k], 0.5 if uv else 4 * t2, floor=lr_floor, abs_tol=zero_grad_kick("D_grad0/", k, dmax, opt["d_lr"], n_d),
-                noise=nz("D_final/" + k), l2=uv)
+                noise=nz("D_final/" + k), l2=uv, abs_ok=2.2 * opt["d_lr"] * n_d if k in dict(D.named_parameters()) else None)
     # EMA generator: p_ema = lerp(p, p_ema, 0.9) after the step (utils/ema.py:27-35)
     for k, p in w.Gen_ema.named_parameters():
         ref = dict(G.named_parameters())[k].detach().lerp(ema_before[k], 0.9)

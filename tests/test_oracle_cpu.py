@@ -319,3 +319,25 @@ def test_prdc_restatement_matches_reference_fixture():
     m = OI.prdc(torch.from_numpy(z["in/prdc_real"]), torch.from_numpy(z["in/prdc_fake"]), 5)
     for k in ("precision", "recall", "density", "coverage"):
         assert abs(m[k] - float(z["exp/prdc_" + k])) < 1e-12, (k, m[k])
+
+
+def test_heads_restatement_matches_reference_fixture():
+    """oracle/restate.py d_heads / cond_loss / crammer_singer / d_side_loss on the stored states and inputs against the REAL reference's
+    outputs (tests/golden/heads.npz: big_resnet.Discriminator heads + utils/losses.py, combined as src/worker.py:281-317)."""
+    import json
+    import numpy as np
+    here = os.path.dirname(os.path.abspath(__file__))
+    meta = json.load(open(os.path.join(here, "golden", "heads.json")))
+    z = np.load(os.path.join(here, "golden", "heads.npz"))
+    for name, c in meta["cases"].items():
+        y = c["yaml"]
+        ocfg = dict(MG.oracle_cfg(y), num_classes=y["DATA"]["num_classes"])
+        P = {k[len(name) + 3:]: torch.from_numpy(z[k]).clone().requires_grad_(True) for k in z.files if k.startswith(name + "/P/")}
+        B = {k[len(name) + 3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(name + "/B/")}
+        get = lambda k: torch.from_numpy(z[name + "/in/" + k])
+        loss, rd, fd = O.d_side_loss(O.model_fns(ocfg)[1], P, B, ocfg, get("real"), get("rl"), get("fake"), get("fl"), c["adv_loss"], meta["hp"])
+        loss.backward()
+        assert abs(float(loss.detach()) - float(z[name + "/exp/loss"])) < 1e-5, name
+        for k, p in P.items():
+            g = p.grad if p.grad is not None else torch.zeros_like(p)
+            assert float((g - torch.from_numpy(z[name + "/grad/" + k])).abs().max()) < 1e-5, (name, k)

@@ -104,12 +104,14 @@ class Collector:
 
     NOISE_FACTOR = 4.0
 
-    def check(self, name, a, b, tol, floor=0.0, l2=False, abs_tol=None, noise=None):
+    def check(self, name, a, b, tol, floor=0.0, l2=False, abs_tol=None, noise=None, abs_ok=None):
         """err = max|a-b| / max(max|b|, floor): `floor` keeps tensors that are analytically ~0 (e.g. the bias of a
         convolution feeding a batch norm) from being judged against their own rounding noise.
         l2=True: err = ||a-b||_2 / max(||b||_2, floor*sqrt(n)) -- the robust metric where a few ReLU units whose
         pre-activation sits within rounding distance of 0 flip and produce sparse O(1) element errors (bf16 gradients;
         fp32 gradients of the full-width networks).  abs_tol: pass on max|a-b| <= abs_tol instead.
+        abs_ok: the comparison also passes when max|a-b| <= abs_ok whatever the relative error -- for parameters after Adam steps, where
+        an element whose gradient is rounding noise moves by +-lr with a sign that two correct implementations need not share.
         noise: [rms, max] of the ORACLE's own movement of this tensor under a 2e-6 relative weight perturbation
         (tests/golden/<name>.cond.npz, oracle/make_golden.py conditioning()): the tolerance becomes tol + NOISE_FACTOR * that movement
         expressed in the metric used -- a measured bound for ill-conditioned quantities instead of a hand-picked one.
@@ -140,6 +142,8 @@ class Collector:
                 tol = tol + self.NOISE_FACTOR * (n_rms * (a.numel() ** 0.5) / d2 if l2 else n_mx / dm)
             if abs_tol is not None:
                 e, tol = float((a - b).abs().max()), abs_tol + self.NOISE_FACTOR * n_mx
+            elif abs_ok is not None and float((a - b).abs().max()) <= abs_ok:
+                e = min(e, tol)
         self.rows.append((name, e, tol))
         print(f"{name:52s} mx={em:.3e} l2={e2:.3e} [{'abs' if abs_tol is not None else 'l2' if l2 else 'mx'}] tol={tol:.1e} {'ok' if e <= tol else 'FAIL'}")
         return e
