@@ -252,6 +252,14 @@ int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B,
  *   sg_attn_ds_bwd:    dS [B][HW][HW4] bf16 = P * (dP - sum_k P dP), dP = dO . g^T, P recomputed from theta / phi / lse
  * sg_attn_fused_ok returns 1 when the shape is supported (HW % 128 == 0, HW4 % 256 == 0, HW4 <= 2048, Cg <= 128). */
 int sg_attn_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
+/* fused forward of the attention core: O = softmax(theta phi^T) g per image in one launch (probabilities stored only when P != NULL) */
+int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
+int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
+/* fused backward of the attention core: dtheta, dphi, dg from theta / phi / g / dO / lse with P and dS recomputed on the fly (two launches:
+ * query side + key side); delta = fp32 scratch [B][HW] */
+int sg_attn_bwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
+int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, float* delta, void* dtheta, void* dphi, void* dg,
+                      int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
 int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, float* lse, int B, int HW, int HW4, int Dp, sg_stream_t s);
 int sg_attn_ds_bwd(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, void* dS,
                    int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);

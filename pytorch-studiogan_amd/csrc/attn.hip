@@ -117,6 +117,119 @@ __global__ __launch_bounds__(256) void k_attn_probs_fwd(const bf16_t* theta, con
   }
 }
 
+
+// ---- fused forward: O = softmax(theta phi^T) V without a trip of the probabilities through HBM for the product --------------------------
+// Same two passes over the keys as k_attn_probs_fwd (identical P: the bf16 probabilities are what the MFMA consumes, and what is stored
+// for the backward when STORE_P), plus in pass 2, per 32-key block, O^T[c][q] += V^T[c][k] P[k][q] on the MFMA: the probabilities go from
+// the score accumulators straight into the B operand. A lane owns keys {0-3, 8-11, 16-19, 24-27} + 4h of a block for its query; the
+// contraction index of the second product is simply taken in THAT order (slot (h, e) <-> key 4h + e, 8 + 4h + e - 4, ...), and the V^T
+// fragments are gathered in the same order by ds_read_b64_tr_b16 from the [key][32 channels] chunk image -- no cross-lane exchange.
+// LDS: phi of the whole image (HW4 * 64 B) + one 256-key chunk of V (NCG * 16 KiB).
+__device__ __forceinline__ at_bf16x8 at_vfrag(const char* img, int kbase, int lane) {
+  // V^T fragment: channel = lane & 31 of this 32-channel image, keys kbase .. kbase + 3 (elements 0-3) and kbase + 8 .. + 11 (elements 4-7);
+  // kbase is a multiple of 4, so the four rows one 16-lane group reads share their swizzle key
+  const int g16 = lane >> 4, t = lane & 15;
+  const int row = kbase + (t >> 2);
+  const int slot = (2 * (g16 & 1) + ((t & 3) >> 1)) ^ ((row >> 2) & 3);
+  const char* p = img + row * 64 + slot * 16 + 8 * (t & 1);
+  const int slot2 = (2 * (g16 & 1) + ((t & 3) >> 1)) ^ (((row + 8) >> 2) & 3);
+  const char* p2 = img + (row + 8) * 64 + slot2 * 16 + 8 * (t & 1);
+  s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p);
+  s16x4 b = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)p2);
+  s16x8 r;
+  r[0] = a[0]; r[1] = a[1]; r[2] = a[2]; r[3] = a[3];
+  r[4] = b[0]; r[5] = b[1]; r[6] = b[2]; r[7] = b[3];
+  return __builtin_bit_cast(at_bf16x8, r);
+}
+template <int NCG, bool STORE_P>
+__global__ __launch_bounds__(256) void k_attn_fwd_fused(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, bf16_t* P, float* lse, bf16_t* O,
+                                                        int HW, int HW4, int Dp, int Cg) {
+  constexpr int KC = 256;
+  extern __shared__ __attribute__((aligned(16))) char at_smem[];
+  char* kimg = at_smem;
+  char* vimg = at_smem + HW4 * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int h = lane >> 5;
+  at_stage<4>(kimg, phi + (long long)b * HW4 * Dp, HW4, Dp, 0, Dp, wave, lane);
+  const u32x4 q0 = at_gfrag(theta, (long long)b * HW + q, Dp, 8 * h, Dp);
+  const u32x4 q1 = at_gfrag(theta, (long long)b * HW + q, Dp, 16 + 8 * h, Dp);
+  const at_bf16x8 qf0 = __builtin_bit_cast(at_bf16x8, q0), qf1 = __builtin_bit_cast(at_bf16x8, q1);
+  __syncthreads();
+  const int nb = HW4 / 32;
+  float m = -3.0e38f, l = 0.f;
+  for (int kb = 0; kb < nb; kb++) {
+    at_f32x16 s;
+#pragma unroll
+    for (int r = 0; r < 16; r++) s[r] = 0.f;
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 0, lane), qf0, s, 0, 0, 0);
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 1, lane), qf1, s, 0, 0, 0);
+    float bm = s[0];
+#pragma unroll
+    for (int r = 1; r < 16; r++) bm = fmaxf(bm, s[r]);
+    const float mn = fmaxf(m, bm);
+    float acc = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; r++) acc += __expf(s[r] - mn);
+    l = l * __expf(m - mn) + acc;
+    m = mn;
+  }
+  {
+    const float mo = at_half_max(m);
+    l = at_half_sum(l * __expf(m - mo));
+    m = mo;
+  }
+  const float inv = 1.f / l;
+  if (h == 0) lse[(long long)b * HW + q] = m + __logf(l);
+  bf16_t* prow = STORE_P ? (P + ((long long)b * HW + q) * HW4 + 16 * h) : nullptr;
+  at_f32x16 o[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[cg][r] = 0.f;
+  for (int k0 = 0; k0 < HW4; k0 += KC) {
+    __syncthreads();                                             // previous V chunk fully consumed
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++) at_stage<4>(vimg + cg * KC * 64, g + ((long long)b * HW4 + k0) * Cg, KC, Cg, cg * 32, Cg, wave, lane);
+    __syncthreads();
+    for (int kc = 0; kc < KC / 32; kc++) {
+      const int kb = k0 / 32 + kc;
+      at_f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 0, lane), qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 1, lane), qf1, s, 0, 0, 0);
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) p[r] = __expf(s[r] - m) * inv;
+      if (STORE_P) at_store16(prow + kb * 32, p, h);
+      u32x4 pa, pb;                                               // regs 0-7 / 8-15 = contraction slots of the two k-steps
+#pragma unroll
+      for (int i = 0; i < 4; i++) { pa[i] = pack2bf(p[2 * i], p[2 * i + 1]); pb[i] = pack2bf(p[8 + 2 * i], p[8 + 2 * i + 1]); }
+      const at_bf16x8 pfa = __builtin_bit_cast(at_bf16x8, pa), pfb = __builtin_bit_cast(at_bf16x8, pb);
+#pragma unroll
+      for (int cg = 0; cg < NCG; cg++) {
+        const char* vi = vimg + cg * KC * 64;
+        o[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(vi, kc * 32 + 4 * h, lane), pfa, o[cg], 0, 0, 0);
+        o[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(vi, kc * 32 + 16 + 4 * h, lane), pfb, o[cg], 0, 0, 0);
+      }
+    }
+  }
+  // O^T tile: lane = (query, h) holds channels cg * 32 + 8 * (r >> 2) + 4 h + (r & 3): four consecutive channels per register group
+  bf16_t* orow = O + ((long long)b * HW + q) * Cg;
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int c0 = cg * 32 + 8 * g4 + 4 * h;
+      if (c0 < Cg) {
+        u32x2 v = {pack2bf(o[cg][4 * g4 + 0], o[cg][4 * g4 + 1]), pack2bf(o[cg][4 * g4 + 2], o[cg][4 * g4 + 3])};
+        *(u32x2*)(orow + c0) = v;
+      }
+    }
+}
+
 // grid (HW / 128, B), 256 threads. Keys in chunks of KC = 256: LDS = (1 + NCG) * 16 KiB.
 template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse, bf16_t* dS, int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
@@ -171,11 +284,233 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf
   }
 }
 
+
+// ---- fused backward, query side: delta, dS (registers only) and dtheta = dS phi ------------------------------------------------------------
+// k_attn_ds_bwd with the product that consumed dS moved inside: dtheta^T[d][q] += phi^T[d][k] dS[k][q] per 32-key block, dS going from the
+// score accumulators into the MFMA B operand (same key order trick as the fused forward); delta_q is also written out for the key side.
+template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse,
+                                                                        float* delta_out, bf16_t* dtheta, int HW, int HW4, int Dp, int Cg) {
+  constexpr int KC = 256;
+  extern __shared__ __attribute__((aligned(16))) char at_smem[];
+  char* kimg = at_smem;
+  char* vimg = at_smem + KC * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const long long qrow = (long long)b * HW + q;
+  const at_bf16x8 qf0 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 8 * h, Dp));
+  const at_bf16x8 qf1 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 16 + 8 * h, Dp));
+  at_bf16x8 df[NCG][2];
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) df[cg][t] = __builtin_bit_cast(at_bf16x8, at_gfrag(dO, qrow, Cg, cg * 32 + 16 * t + 8 * h, Cg));
+  float delta = 0.f;
+  const float ls = lse[qrow];
+  at_f32x16 dth;
+#pragma unroll
+  for (int r = 0; r < 16; r++) dth[r] = 0.f;
+  for (int pass = 0; pass < 2; pass++) {
+    for (int k0 = 0; k0 < HW4; k0 += KC) {
+      __syncthreads();
+      at_stage<4>(kimg, phi + ((long long)b * HW4 + k0) * Dp, KC, Dp, 0, Dp, wave, lane);
+#pragma unroll
+      for (int cg = 0; cg < NCG; cg++) at_stage<4>(vimg + cg * KC * 64, g + ((long long)b * HW4 + k0) * Cg, KC, Cg, cg * 32, Cg, wave, lane);
+      __syncthreads();
+      for (int kb = 0; kb < KC / 32; kb++) {
+        at_f32x16 s, dp;
+#pragma unroll
+        for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 0, lane), qf0, s, 0, 0, 0);
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 1, lane), qf1, s, 0, 0, 0);
+#pragma unroll
+        for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+          for (int t = 0; t < 2; t++)
+            dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(vimg + cg * KC * 64, kb, t, lane), df[cg][t], dp, 0, 0, 0);
+        if (pass == 0) {
+#pragma unroll
+          for (int r = 0; r < 16; r++) delta += __expf(s[r] - ls) * dp[r];
+        } else {
+          float o[16];
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[r] = __expf(s[r] - ls) * (dp[r] - delta);
+          u32x4 da, db;
+#pragma unroll
+          for (int i = 0; i < 4; i++) { da[i] = pack2bf(o[2 * i], o[2 * i + 1]); db[i] = pack2bf(o[8 + 2 * i], o[8 + 2 * i + 1]); }
+          dth = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(kimg, kb * 32 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, da), dth, 0, 0, 0);
+          dth = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(kimg, kb * 32 + 16 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, db), dth, 0, 0, 0);
+        }
+      }
+    }
+    if (pass == 0) delta = at_half_sum(delta);
+  }
+  if (h == 0) delta_out[qrow] = delta;
+  bf16_t* trow = dtheta + qrow * Dp;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; g4++) {
+    const int c0 = 8 * g4 + 4 * h;
+    if (c0 < Dp) {
+      u32x2 v = {pack2bf(dth[4 * g4 + 0], dth[4 * g4 + 1]), pack2bf(dth[4 * g4 + 2], dth[4 * g4 + 3])};
+      *(u32x2*)(trow + c0) = v;
+    }
+  }
+}
+
+// ---- fused backward, key side: dphi = dS^T theta, dg = P^T dO with P and dS recomputed per (32 queries x 32 keys) block ----------------------
+// One workgroup = 4 waves = 128 keys of one image; a lane owns ONE key (l & 31) and 16 of the 32 queries of a block (the transposed
+// orientation of the query-side kernels: scores = theta (rows) x phi (columns)). Query-side operands (theta, dO; lse, delta) are staged by
+// LDS-DMA in chunks of 256 queries; they feed the score / dP products as k-contiguous fragments and the two accumulating products as
+// transposed fragments of the same images. No P and no dS ever exist in HBM.
+template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_k(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse,
+                                                                        const float* delta, bf16_t* dphi, bf16_t* dg, int HW, int HW4, int Dp, int Cg) {
+  constexpr int QC = 256;
+  extern __shared__ __attribute__((aligned(16))) char at_smem[];
+  char* timg = at_smem;
+  char* oimg = at_smem + QC * 64;
+  float* st = (float*)(at_smem + (1 + NCG) * QC * 64);
+  float* dl = st + QC;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int key = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const long long krow = (long long)b * HW4 + key;
+  const at_bf16x8 kf0 = __builtin_bit_cast(at_bf16x8, at_gfrag(phi, krow, Dp, 8 * h, Dp));
+  const at_bf16x8 kf1 = __builtin_bit_cast(at_bf16x8, at_gfrag(phi, krow, Dp, 16 + 8 * h, Dp));
+  at_bf16x8 gf[NCG][2];
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int t = 0; t < 2; t++) gf[cg][t] = __builtin_bit_cast(at_bf16x8, at_gfrag(g, krow, Cg, cg * 32 + 16 * t + 8 * h, Cg));
+  at_f32x16 dph, dgt[NCG];
+#pragma unroll
+  for (int r = 0; r < 16; r++) dph[r] = 0.f;
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) dgt[cg][r] = 0.f;
+  for (int q0 = 0; q0 < HW; q0 += QC) {
+    __syncthreads();
+    at_stage<4>(timg, theta + ((long long)b * HW + q0) * Dp, QC, Dp, 0, Dp, wave, lane);
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++) at_stage<4>(oimg + cg * QC * 64, dO + ((long long)b * HW + q0) * Cg, QC, Cg, cg * 32, Cg, wave, lane);
+    if (tid < QC) { st[tid] = lse[(long long)b * HW + q0 + tid]; dl[tid] = delta[(long long)b * HW + q0 + tid]; }
+    __syncthreads();
+    for (int qb = 0; qb < QC / 32; qb++) {
+      at_f32x16 s, dp;
+#pragma unroll
+      for (int r = 0; r < 16; r++) { s[r] = 0.f; dp[r] = 0.f; }
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(timg, qb, 0, lane), kf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(timg, qb, 1, lane), kf1, s, 0, 0, 0);
+#pragma unroll
+      for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+        for (int t = 0; t < 2; t++)
+          dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(oimg + cg * QC * 64, qb, t, lane), gf[cg][t], dp, 0, 0, 0);
+      float pr[16], ds[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) {
+        const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // the query of accumulator register r
+        pr[r] = __expf(s[r] - st[qi]);
+        ds[r] = pr[r] * (dp[r] - dl[qi]);
+      }
+      u32x4 pa, pb, da, db;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        pa[i] = pack2bf(pr[2 * i], pr[2 * i + 1]); pb[i] = pack2bf(pr[8 + 2 * i], pr[8 + 2 * i + 1]);
+        da[i] = pack2bf(ds[2 * i], ds[2 * i + 1]); db[i] = pack2bf(ds[8 + 2 * i], ds[8 + 2 * i + 1]);
+      }
+#pragma unroll
+      for (int cg = 0; cg < NCG; cg++) {
+        const char* oi = oimg + cg * QC * 64;
+        dgt[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(oi, qb * 32 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, pa), dgt[cg], 0, 0, 0);
+        dgt[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(oi, qb * 32 + 16 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, pb), dgt[cg], 0, 0, 0);
+      }
+      dph = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(timg, qb * 32 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, da), dph, 0, 0, 0);
+      dph = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(timg, qb * 32 + 16 + 4 * h, lane), __builtin_bit_cast(at_bf16x8, db), dph, 0, 0, 0);
+    }
+  }
+  bf16_t* prow = dphi + krow * Dp;
+  bf16_t* grow = dg + krow * Cg;
+#pragma unroll
+  for (int g4 = 0; g4 < 4; g4++) {
+    const int c0 = 8 * g4 + 4 * h;
+    if (c0 < Dp) {
+      u32x2 v = {pack2bf(dph[4 * g4 + 0], dph[4 * g4 + 1]), pack2bf(dph[4 * g4 + 2], dph[4 * g4 + 3])};
+      *(u32x2*)(prow + c0) = v;
+    }
+  }
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int c0 = cg * 32 + 8 * g4 + 4 * h;
+      if (c0 < Cg) {
+        u32x2 v = {pack2bf(dgt[cg][4 * g4 + 0], dgt[cg][4 * g4 + 1]), pack2bf(dgt[cg][4 * g4 + 2], dgt[cg][4 * g4 + 3])};
+        *(u32x2*)(grow + c0) = v;
+      }
+    }
+}
+
 static bool at_ok(int B, int HW, int HW4, int Dp) {
   return B > 0 && B <= 65535 && HW % 128 == 0 && HW4 % 256 == 0 && Dp % 8 == 0 && Dp >= 8 && Dp <= 32;
 }
 extern "C" int sg_attn_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
   return (at_ok(B, HW, HW4, Dp) && HW4 * 64 <= 128 * 1024 && Cg % 8 == 0 && Cg <= 128) ? 1 : 0;
+}
+extern "C" int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
+  const int ncg = (Cg + 31) / 32;
+  return (at_ok(B, HW, HW4, Dp) && Cg % 8 == 0 && Cg >= 8 && Cg <= 128 && HW4 * 64 + ncg * 16384 <= 160 * 1024) ? 1 : 0;
+}
+// O = softmax(theta phi^T) g in one launch; P == NULL: the probabilities are not stored (no backward will ask for them)
+extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
+  SG_CHECK(theta && phi && g && lse && O, "sg_attn_fwd_fused: null");
+  SG_CHECK(sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_fwd_fused: unsupported shape");
+  const int ncg = (Cg + 31) / 32;
+  const int lds = HW4 * 64 + ncg * 16384;
+  SgProfScope prof((hipStream_t)s, (double)B * HW * ((P ? (double)HW4 * 2.0 : 0.0) + (Dp + Cg) * 2.0 + 4.0) + (double)B * HW4 * (Dp + Cg) * 2.0, 5);
+  const dim3 grid(HW / 128, B), blk(256);
+  hipStream_t st = (hipStream_t)s;
+#define ATF_LAUNCH(N, SP)                                                                                                                 \
+  {                                                                                                                                        \
+    static bool done = false;                                                                                                              \
+    if (!done) { SG_CHECK(hipFuncSetAttribute((const void*)k_attn_fwd_fused<N, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "sg_attn_fwd_fused: LDS attribute"); done = true; } \
+    hipLaunchKernelGGL((k_attn_fwd_fused<N, SP>), grid, blk, lds, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (bf16_t*)P, lse, (bf16_t*)O, HW, HW4, Dp, Cg); \
+  }
+  if (P) { if (ncg == 1) ATF_LAUNCH(1, true) else if (ncg == 2) ATF_LAUNCH(2, true) else if (ncg == 3) ATF_LAUNCH(3, true) else ATF_LAUNCH(4, true) }
+  else { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
+#undef ATF_LAUNCH
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// fused backward (no P, no dS in HBM): dtheta [B][HW][Dp], dphi [B][HW4][Dp], dg [B][HW4][Cg] (pooled keys / values), delta = fp32 scratch [B][HW]
+extern "C" int sg_attn_bwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
+  return (at_ok(B, HW, HW4, Dp) && HW % 256 == 0 && HW4 % 128 == 0 && Cg % 8 == 0 && Cg >= 8 && Cg <= 128) ? 1 : 0;
+}
+extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, float* delta, void* dtheta, void* dphi, void* dg,
+                                 int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
+  SG_CHECK(theta && phi && g && dO && lse && delta && dtheta && dphi && dg, "sg_attn_bwd_fused: null");
+  SG_CHECK(sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_bwd_fused: unsupported shape");
+  const int ncg = (Cg + 31) / 32;
+  const int lds_q = (1 + ncg) * 256 * 64, lds_k = (1 + ncg) * 256 * 64 + 2 * 256 * 4;
+  SgProfScope prof((hipStream_t)s, 2.0 * ((double)B * HW * ((Dp + Cg) * 2.0 + 8.0) + (double)B * HW4 * (Dp + Cg) * 2.0) + (double)B * (HW + HW4) * (Dp * 2.0) + (double)B * HW4 * Cg * 2.0, 5);
+  hipStream_t st = (hipStream_t)s;
+#define ATB_LAUNCH(N)                                                                                                                     \
+  {                                                                                                                                        \
+    static bool done = false;                                                                                                              \
+    if (!done) {                                                                                                                           \
+      SG_CHECK(hipFuncSetAttribute((const void*)k_attn_bwd_q<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_q) == hipSuccess, "sg_attn_bwd_fused: LDS attribute"); \
+      SG_CHECK(hipFuncSetAttribute((const void*)k_attn_bwd_k<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "sg_attn_bwd_fused: LDS attribute"); \
+      done = true;                                                                                                                         \
+    }                                                                                                                                      \
+    hipLaunchKernelGGL(k_attn_bwd_q<N>, dim3(HW / 128, B), dim3(256), lds_q, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, lse, delta, (bf16_t*)dtheta, HW, HW4, Dp, Cg); \
+    hipLaunchKernelGGL(k_attn_bwd_k<N>, dim3(HW4 / 128, B), dim3(256), lds_k, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, lse, (const float*)delta, (bf16_t*)dphi, (bf16_t*)dg, HW, HW4, Dp, Cg); \
+  }
+  if (ncg == 1) ATB_LAUNCH(1) else if (ncg == 2) ATB_LAUNCH(2) else if (ncg == 3) ATB_LAUNCH(3) else ATB_LAUNCH(4)
+#undef ATB_LAUNCH
+  SG_LAUNCH_CHECK();
+  return 0;
 }
 extern "C" int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, float* lse, int B, int HW, int HW4, int Dp, sg_stream_t s) {
   SG_CHECK(theta && phi && P && lse, "sg_attn_probs_fwd: null");

@@ -826,21 +826,32 @@ class AttnCoreFn(torch.autograd.Function):
         L.call("sg_maxpool2_fwd", sd, L.ptr(phi_full), Dp, L.ptr(phi), Dp, L.ptr(idx_phi), B, H, W, Dp, L.stream())
         L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
         fused = T == torch.bfloat16 and L.lib().sg_attn_fused_ok(B, HW, HW4, Dp, Cg) == 1
-        P = torch.empty((B, HW, HW4), dtype=T, device=dev)
+        fused_fwd = fused and L.lib().sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
         lse = None
-        if fused:
-            # scores stay in registers: one pass writes the bf16 probabilities (csrc/attn.hip)
+        if fused_fwd:
+            # one launch: scores, softmax and the product with the pooled values; the bf16 probabilities are written only when a backward
+            # can come (they feed dg = P^T dO), never for the no-grad generator forwards of the discriminator update
+            # ... nor when the backward recomputes them itself (sg_attn_bwd_fused: no P and no dS in HBM at all)
+            need_p = any(ctx.needs_input_grad) and L.lib().sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) != 1
+            P = torch.empty((B, HW, HW4), dtype=T, device=dev) if need_p else None
             lse = torch.empty((B, HW), dtype=torch.float32, device=dev)
-            L.call("sg_attn_probs_fwd", L.ptr(theta), L.ptr(phi), L.ptr(P), L.ptr(lse), B, HW, HW4, Dp, L.stream())
+            o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
+            L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P), L.ptr(lse), L.ptr(o), B, HW, HW4, Dp, Cg, L.stream())
         else:
-            S = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
-            # S[q][k] = theta_q . phi_k
-            gemm_raw(sd, phi, 0, Dp, theta, 0, Dp, S, HW4, HW4, HW, Dp, batch=B, p_bs=HW4 * Dp, q_bs=HW * Dp, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
-            L.call("sg_softmax_rows", sd, L.ptr(S), L.ptr(P), B * HW, HW4, L.stream())
-            del S
-        o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
-        # o[q][c] = sum_k P[q][k] g[k][c]
-        gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
+            P = torch.empty((B, HW, HW4), dtype=T, device=dev)
+            if fused:
+                # scores stay in registers: one pass writes the bf16 probabilities (csrc/attn.hip)
+                lse = torch.empty((B, HW), dtype=torch.float32, device=dev)
+                L.call("sg_attn_probs_fwd", L.ptr(theta), L.ptr(phi), L.ptr(P), L.ptr(lse), B, HW, HW4, Dp, L.stream())
+            else:
+                S = torch.empty((B, HW, HW4), dtype=torch.float32, device=dev)
+                # S[q][k] = theta_q . phi_k
+                gemm_raw(sd, phi, 0, Dp, theta, 0, Dp, S, HW4, HW4, HW, Dp, batch=B, p_bs=HW4 * Dp, q_bs=HW * Dp, out_bs=HW * HW4, epi_flags=L.EPI_OUT_F32)
+                L.call("sg_softmax_rows", sd, L.ptr(S), L.ptr(P), B * HW, HW4, L.stream())
+                del S
+            o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
+            # o[q][c] = sum_k P[q][k] g[k][c]
+            gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
         ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse)
         ctx.dims = (B, H, W, Dp, Cg)
         return o
@@ -854,6 +865,21 @@ class AttnCoreFn(torch.autograd.Function):
         do = _c(do)
         dev, T = do.device, do.dtype
         sd = L.dt(T)
+        if P is None:
+            # fused backward (csrc/attn.hip k_attn_bwd_q / k_attn_bwd_k): P, dP and dS are recomputed per tile in registers on both the
+            # query side (dtheta) and the key side (dphi, dg); only the row statistics (lse, delta) cross HBM
+            assert lse is not None
+            delta = torch.empty((B, HW), dtype=torch.float32, device=dev)
+            dtheta = torch.empty((B, H, W, Dp), dtype=T, device=dev)
+            dphi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
+            dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
+            L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi), L.ptr(dg),
+                   B, HW, HW4, Dp, Cg, L.stream())
+            dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
+            dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)
+            L.call("sg_maxpool2_bwd", sd, L.ptr(dphi), Dp, L.ptr(idx_phi), L.ptr(dphi_full), Dp, B, H, W, Dp, L.stream())
+            L.call("sg_maxpool2_bwd", sd, L.ptr(dg), Cg, L.ptr(idx_g), L.ptr(dg_full), Cg, B, H, W, Cg, L.stream())
+            return dtheta, dphi_full, dg_full
         # dg[k][c] = sum_q P[q][k] do[q][c]
         dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
         gemm_raw(sd, do, 1, Cg, P, 1, HW4, dg, Cg, Cg, HW4, HW, batch=B, p_bs=HW * Cg, q_bs=HW * HW4, out_bs=HW4 * Cg)

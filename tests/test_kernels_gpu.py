@@ -469,3 +469,79 @@ def test_no_cpu_fallback(sg):
     m = ops.snconv2d(4, 8, 3, 1, 1)
     with pytest.raises(RuntimeError):
         m(torch.randn(1, 4, 8, 8))
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32, 24, 96), (2, 32, 32, 16, 48), (2, 64, 32, 32, 40), (1, 64, 64, 16, 48)])
+def test_attention_fused_forward_matches_unfused_chain(sg, shape):
+    """sg_attn_fwd_fused (scores, softmax and P.V in one launch) against the chain it replaces (sg_attn_probs_fwd + batched GEMM) on the
+    same inputs: identical probabilities / log-sum-exp, the output to fp32-summation-order differences of bf16 products; and without
+    the probability store (no-grad forward)."""
+    from studiogan_amd import functional as F, _lib as L
+    d = dev()
+    B, H, W, Dp, Cg = shape
+    HW, HW4 = H * W, H * W // 4
+    T = torch.bfloat16
+    theta = rnd((B, HW, Dp), T, 71, 0.7).to(d)
+    phi = rnd((B, HW4, Dp), T, 72, 0.7).to(d)
+    g = rnd((B, HW4, Cg), T, 73).to(d)
+    assert L.lib().sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
+    P0 = torch.empty((B, HW, HW4), dtype=T, device=d)
+    lse0 = torch.empty((B, HW), dtype=torch.float32, device=d)
+    L.call("sg_attn_probs_fwd", L.ptr(theta), L.ptr(phi), L.ptr(P0), L.ptr(lse0), B, HW, HW4, Dp, L.stream())
+    o0 = torch.empty((B, HW, Cg), dtype=T, device=d)
+    F.gemm_raw(L.BF16, g, 1, Cg, P0, 0, HW4, o0, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
+    for store in (True, False):
+        P1 = torch.zeros((B, HW, HW4), dtype=T, device=d) if store else None
+        lse1 = torch.empty((B, HW), dtype=torch.float32, device=d)
+        o1 = torch.empty((B, HW, Cg), dtype=T, device=d)
+        L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P1), L.ptr(lse1), L.ptr(o1), B, HW, HW4, Dp, Cg, L.stream())
+        torch.cuda.synchronize()
+        if store:
+            assert torch.equal(P1, P0), "fused forward must store the same bf16 probabilities"
+        assert torch.equal(lse1, lse0)
+        check(f"fused attention output (store_p={store})", o1.float().cpu(), o0.float().cpu(), 8e-3)
+    # against fp64 softmax(theta phi^T) g
+    ref = torch.softmax(theta.double().cpu() @ phi.double().cpu().transpose(1, 2), -1) @ g.double().cpu()
+    check("fused attention vs fp64", o1.float().cpu(), ref, 3e-2)
+
+
+@pytest.mark.parametrize("shape", [(3, 32, 32, 24, 96), (2, 32, 32, 16, 48), (2, 64, 32, 32, 40), (1, 64, 64, 16, 48)])
+def test_attention_fused_backward_matches_unfused_chain(sg, shape):
+    """sg_attn_bwd_fused (query side: delta, dS in registers, dtheta; key side: P and dS recomputed in the transposed orientation, dphi, dg)
+    against the chain it replaces (stored P, sg_attn_ds_bwd + three batched GEMMs) and against fp64 autograd of softmax(theta phi^T) g."""
+    from studiogan_amd import functional as F, _lib as L
+    d = dev()
+    B, H, W, Dp, Cg = shape
+    HW, HW4 = H * W, H * W // 4
+    T = torch.bfloat16
+    theta = rnd((B, HW, Dp), T, 81, 0.7).to(d)
+    phi = rnd((B, HW4, Dp), T, 82, 0.7).to(d)
+    g = rnd((B, HW4, Cg), T, 83).to(d)
+    do = rnd((B, HW, Cg), T, 84).to(d)
+    assert L.lib().sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
+    P = torch.empty((B, HW, HW4), dtype=T, device=d)
+    lse = torch.empty((B, HW), dtype=torch.float32, device=d)
+    L.call("sg_attn_probs_fwd", L.ptr(theta), L.ptr(phi), L.ptr(P), L.ptr(lse), B, HW, HW4, Dp, L.stream())
+    sd = L.BF16
+    dg0 = torch.empty((B, HW4, Cg), dtype=T, device=d)
+    F.gemm_raw(sd, do, 1, Cg, P, 1, HW4, dg0, Cg, Cg, HW4, HW, batch=B, p_bs=HW * Cg, q_bs=HW * HW4, out_bs=HW4 * Cg)
+    dS = torch.empty((B, HW, HW4), dtype=T, device=d)
+    L.call("sg_attn_ds_bwd", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(lse), L.ptr(dS), B, HW, HW4, Dp, Cg, L.stream())
+    dth0 = torch.empty((B, HW, Dp), dtype=T, device=d)
+    F.gemm_raw(sd, phi, 1, Dp, dS, 0, HW4, dth0, Dp, Dp, HW, HW4, batch=B, p_bs=HW4 * Dp, q_bs=HW * HW4, out_bs=HW * Dp)
+    dph0 = torch.empty((B, HW4, Dp), dtype=T, device=d)
+    F.gemm_raw(sd, theta, 1, Dp, dS, 1, HW4, dph0, Dp, Dp, HW4, HW, batch=B, p_bs=HW * Dp, q_bs=HW * HW4, out_bs=HW4 * Dp)
+    delta = torch.empty((B, HW), dtype=torch.float32, device=d)
+    dth1, dph1, dg1 = torch.empty_like(dth0), torch.empty_like(dph0), torch.empty_like(dg0)
+    L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dth1), L.ptr(dph1), L.ptr(dg1),
+           B, HW, HW4, Dp, Cg, L.stream())
+    torch.cuda.synchronize()
+    check("fused bwd dtheta vs chain", dth1.float().cpu(), dth0.float().cpu(), 1e-2)
+    check("fused bwd dphi vs chain", dph1.float().cpu(), dph0.float().cpu(), 1e-2)
+    check("fused bwd dg vs chain", dg1.float().cpu(), dg0.float().cpu(), 1e-2)
+    tr, pr, gr = [t.double().cpu().requires_grad_(True) for t in (theta, phi, g)]
+    o = torch.softmax(tr @ pr.transpose(1, 2), -1) @ gr
+    o.backward(do.double().cpu())
+    check("fused bwd dtheta vs fp64", dth1.float().cpu(), tr.grad, 3e-2)
+    check("fused bwd dphi vs fp64", dph1.float().cpu(), pr.grad, 3e-2)
+    check("fused bwd dg vs fp64", dg1.float().cpu(), gr.grad, 3e-2)
