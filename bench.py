@@ -406,9 +406,10 @@ def main():
     # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
     traffic, traffic_src = None, None
     try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_conv_hbm_traffic_pmc_v2.json")))
+        tname = "r02_conv_hbm_traffic_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic_pmc.json")) else "r01_conv_hbm_traffic_pmc_v2.json"
+        tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         if args.workload == "biggan128" and mixed and args.batch == 256:
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], "profiles/r01_conv_hbm_traffic_pmc_v2.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
+            traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
     except Exception:
         pass
     out = {

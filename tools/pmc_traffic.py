@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_sk_kernel|sg_wgrad_v2_kernel|sg_gemm_kernel<.*ConvPix")
+CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_sk_kernel|sg_wgrad_v2_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
 
 
 def collect(path, counter):
@@ -37,11 +37,12 @@ def main():
         wr = write.get(k, [0, 0.0])[1] * 1024.0
         rows.append({"kernel": k[:100], "launches": n, "read_GB": round(rd / 1e9, 3), "write_GB": round(wr / 1e9, 3),
                      "bytes_per_launch": round((rd + wr) / max(n, 1))})
-        tot_n += n
+        if "k_splitk_reduce" not in k:      # the reduce belongs to the weight-gradient launch that precedes it
+            tot_n += n
         tot_b += rd + wr
     print(json.dumps({"kernel_family": "convolution engine (sg_conv_v3 / sg_conv_v2 / sg_conv_sk / sg_wgrad_v2 / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
                       "hbm_bytes_per_launch": round(tot_b / max(tot_n, 1)), "read_side_doubled": True,
-                      "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1",
+                      "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 --no-extras --fid-samples 0 --no-cpu-baseline; launches = sg_conv2d_fwd / sg_conv2d_wgrad calls (a weight-gradient launch includes its split-K reduce)",
                       "per_kernel": rows}, indent=1))
 
 
