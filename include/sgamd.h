@@ -291,6 +291,12 @@ int sg_quantize_resize_normalize(int dtype, const float* x, void* out, uint8_t* 
                                  int OH, int OW, int quantize, sg_stream_t s);
 /* generic pooling on NHWC: mode 0 max, 1 avg (count_include_pad), 2 avg excluding padding */
 int sg_pool2d(int dtype, const void* x, void* y, int N, int H, int W, int C, int k, int stride, int pad, int mode, int ldy, int c_off, sg_stream_t s);
+/* PIL resizers of reference src/utils/resize.py:39-78 ("clean": bicubic, "friendly": bilinear for InceptionV3_tf) on quantised images: Pillow's
+ * separable, support-scaled resampling (horizontal then vertical, double accumulation, float intermediate) with host-computed coefficient
+ * windows bounds[o] = {first, count}, kk[o][ksize]; tmp = fp32 scratch [N][C][H][OW]; out = NHWC, (v / 255 - 0.5) / 0.5 */
+int sg_pil_resize_normalize(int dtype, const float* x, void* out, float* tmp, int N, int C, int H, int W, int OH, int OW,
+                            const int* bounds_h, const double* kk_h, int ksize_h, const int* bounds_v, const double* kk_v, int ksize_v,
+                            int quantize, sg_stream_t s);
 /* global average pool [N,HW,C] -> fp32 [N,C] */
 int sg_global_avgpool(int dtype, const void* x, float* y, int N, int HW, int C, sg_stream_t s);
 /* hits[n] = 1 iff the true class is within the top k of scores[n][0..ncls) with sklearn's tie rule (higher index wins a tie) */
@@ -301,6 +307,10 @@ int sg_topk_select(const float* x, int n, int k, float* vals, int* idx, sg_strea
 int sg_topk_scatter(const float* g, const int* idx, int k, float* dx, int n, sg_stream_t s);
 /* sum_f[c] += sum_n f[n][c];  sum_ff[c1][c2] += sum_n f[n][c1] f[n][c2]  (fp64 accumulators; FID moments) */
 int sg_feat_moments_accumulate(const float* f, int n, int C, double* sum_f, double* sum_ff, sg_stream_t s);
+/* training "basket" out of a uint8 data set resident in HBM ([N][H][W][3], the HDF5 / in-memory layout of reference src/utils/hdf5.py:35-97):
+ * dst[b] = (optionally mirrored) src[idx[b]], lab_dst[b] = lab_src[idx[b]] (both label pointers NULL: images only) */
+int sg_gather_images_u8(const uint8_t* src, const int64_t* idx, const uint8_t* flip, uint8_t* dst, int B, int H, int W,
+                        const int64_t* lab_src, int64_t* lab_dst, sg_stream_t s);
 /* ---- class-conditioning heads and losses (reference src/utils/losses.py:40-165,242-252; src/models/big_resnet.py:307-333,380-413).
  * All fp32, [rows][cols] row-major; losses are means over rows and return the gradient of that mean in the same call. */
 int sg_row_normalize_fwd(const float* x, float* y, float* inv, int rows, int cols, float eps, sg_stream_t s);   /* F.normalize(dim=1) */

@@ -135,6 +135,7 @@ _PROTOS = {
     "sg_adam_ema": [_vp, _vp, _vp, _vp, _vp, _ll, _f, _f, _f, _f, _f, _i, _f, _f, _vp],
     "sg_ema_lerp": [_vp, _vp, _ll, _f, _vp],
     "sg_quantize_resize_normalize": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_pil_resize_normalize": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp, _vp, _i, _i, _vp],
     "sg_pool2d": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _vp],
     "sg_global_avgpool": [_i, _vp, _vp, _i, _i, _i, _vp],
     "sg_feat_moments_accumulate": [_vp, _i, _i, _vp, _vp, _vp],
@@ -157,6 +158,7 @@ _PROTOS = {
     "sg_topk_select": [_vp, _i, _i, _vp, _vp, _vp],
     "sg_lecam": [_vp, _vp, _i, _f, _f, _vp, _vp, _vp, _vp],
     "sg_u8_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sg_gather_images_u8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "sg_topk_scatter": [_vp, _vp, _i, _vp, _i, _vp],
 }
 

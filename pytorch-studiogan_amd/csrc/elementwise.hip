@@ -701,3 +701,33 @@ extern "C" int sg_u8_to_nhwc(int dtype, const uint8_t* x, const uint8_t* flip, v
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- the dataset resident in HBM: a training "basket" is one gather ------------------------------------------------------------------------
+// dst[b][h][w][c] = src[idx[b]][h][flip[b] ? W - 1 - w : w][c] for uint8 images [N][H][W][3] (the HDF5 / in-memory layout of reference
+// src/utils/hdf5.py:35-97, src/data_util.py:102-142); replaces the DataLoader's per-sample __getitem__ + RandomHorizontalFlip + collate +
+// host-to-device copy for a data set that fits the 288 GB of HBM (ImageNet-128 as uint8: 63 GB). labels gathered alongside.
+__global__ __launch_bounds__(256) void k_gather_images_u8(const uint8_t* src, const int64_t* idx, const uint8_t* flip, uint8_t* dst, int B, int H, int W,
+                                                          const int64_t* lab_src, int64_t* lab_dst) {
+  const long long npix = (long long)B * H * W;
+  for (long long p = blockIdx.x * 256ll + threadIdx.x; p < npix; p += (long long)gridDim.x * 256) {
+    const int w = (int)(p % W);
+    const long long t = p / W;
+    const int h = (int)(t % H);
+    const int b = (int)(t / H);
+    const long long n = idx[b];
+    const int ws = (flip && flip[b]) ? (W - 1 - w) : w;
+    const uint8_t* s = src + ((n * H + h) * W + ws) * 3;
+    uint8_t* d = dst + p * 3;
+    d[0] = s[0]; d[1] = s[1]; d[2] = s[2];
+    if (lab_dst && h == 0 && w == 0) lab_dst[b] = lab_src[n];
+  }
+}
+extern "C" int sg_gather_images_u8(const uint8_t* src, const int64_t* idx, const uint8_t* flip, uint8_t* dst, int B, int H, int W,
+                                   const int64_t* lab_src, int64_t* lab_dst, sg_stream_t s) {
+  SG_CHECK(src && idx && dst && B > 0 && H > 0 && W > 0, "sg_gather_images_u8: bad args");
+  SG_CHECK((lab_src == nullptr) == (lab_dst == nullptr), "sg_gather_images_u8: labels in and out go together");
+  const long long npix = (long long)B * H * W;
+  hipLaunchKernelGGL(k_gather_images_u8, dim3(nblk(npix, 256)), dim3(256), 0, (hipStream_t)s, src, idx, flip, dst, B, H, W, lab_src, lab_dst);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -285,3 +285,49 @@ extern "C" int sg_prdc_rows(const float* D, long long ld, int rows, int cols, co
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- PIL resizers ("clean" = bicubic, "friendly" = bilinear for InceptionV3_tf; reference src/utils/resize.py:39-78: Image.resize on mode 'F'
+// single-channel images). Pillow resamples separably -- horizontal pass, then vertical -- with per-output-pixel coefficient windows whose
+// support is scaled by the reduction factor (antialiasing); for 32-bit images it accumulates in double and stores float after each pass.
+// The coefficient tables (bounds[o] = {first source index, count}, kk[o][ksize] doubles, normalised) are computed on the host exactly as
+// Pillow's precompute_coeffs does (metrics.py pil_coeffs); the two kernels below only apply them.
+// pass 1: uint8-quantised NCHW fp32 input (quantisation of ops.quantize_images applied on load) -> tmp [N][C][H][OW] fp32
+__global__ __launch_bounds__(256) void k_pil_resample_h(const float* x, float* tmp, int N, int C, int H, int W, int OW, const int* bounds, const double* kk, int ksize, int quantize) {
+  const long long total = (long long)N * C * H * OW;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int ox = (int)(i % OW);
+    const long long row = i / OW;                      // (n, c, h)
+    const int x0 = bounds[2 * ox], cnt = bounds[2 * ox + 1];
+    const float* p = x + row * W + x0;
+    const double* k = kk + (long long)ox * ksize;
+    double ss = 0.0;
+    for (int j = 0; j < cnt; j++) { const float v = quantize ? quant_u8(p[j]) : truncf(p[j]); ss += (double)v * k[j]; }
+    tmp[i] = (float)ss;
+  }
+}
+// pass 2: tmp [N][C][H][OW] -> out [N][OH][OW][C] NHWC, normalised (v / 255 - 0.5) / 0.5 (no clipping: PIL's bicubic overshoot is kept,
+// unlike the legacy resizer)
+template <typename T> __global__ __launch_bounds__(256) void k_pil_resample_v(const float* tmp, T* out, int N, int C, int H, int OH, int OW, const int* bounds, const double* kk, int ksize) {
+  const long long total = (long long)N * OH * OW * C;
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+    const int c = (int)(i % C); long long t = i / C; const int ox = (int)(t % OW); t /= OW; const int oy = (int)(t % OH); const int n = (int)(t / OH);
+    const int y0 = bounds[2 * oy], cnt = bounds[2 * oy + 1];
+    const float* p = tmp + (((long long)n * C + c) * H + y0) * OW + ox;
+    const double* k = kk + (long long)oy * ksize;
+    double ss = 0.0;
+    for (int j = 0; j < cnt; j++) ss += (double)p[(long long)j * OW] * k[j];
+    float v = (float)ss;
+    v = (v / 255.0f - 0.5f) / 0.5f;
+    out[i] = from_f<T>(v);
+  }
+}
+extern "C" int sg_pil_resize_normalize(int dtype, const float* x, void* out, float* tmp, int N, int C, int H, int W, int OH, int OW,
+                                       const int* bounds_h, const double* kk_h, int ksize_h, const int* bounds_v, const double* kk_v, int ksize_v,
+                                       int quantize, sg_stream_t s) {
+  SG_CHECK(x && out && tmp && bounds_h && kk_h && bounds_v && kk_v && N > 0 && C > 0 && ksize_h > 0 && ksize_v > 0, "sg_pil_resize_normalize: bad args");
+  hipStream_t st = (hipStream_t)s;
+  hipLaunchKernelGGL(k_pil_resample_h, dim3(grid1d((long long)N * C * H * OW)), dim3(256), 0, st, x, tmp, N, C, H, W, OW, bounds_h, kk_h, ksize_h, quantize);
+  DISPATCH_T(dtype, hipLaunchKernelGGL(k_pil_resample_v<T>, dim3(grid1d((long long)N * OH * OW * C)), dim3(256), 0, st, (const float*)tmp, (T*)out, N, C, H, OH, OW, bounds_v, kk_v, ksize_v));
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -196,13 +196,70 @@ def preprocess(x, dtype, quantize=True, size=299, want_uint8=False):
     return (out, q) if want_uint8 else out
 
 
+_PIL_FILTERS = {"bilinear": (1.0, lambda x: np.where(np.abs(x) < 1.0, 1.0 - np.abs(x), 0.0)),
+                "bicubic": (2.0, None)}
+
+
+def _bicubic(x, a=-0.5):
+    x = np.abs(x)
+    return np.where(x < 1.0, ((a + 2.0) * x - (a + 3.0)) * x * x + 1.0, np.where(x < 2.0, (((x - 5.0) * x + 8.0) * x - 4.0) * a, 0.0))
+
+
+def pil_coeffs(in_size, out_size, filt):
+    """Pillow's precompute_coeffs (src/libImaging/Resample.c) for a full-image box: per output index the first source index, the number of
+    taps and the normalised double coefficients; the support is the filter's, scaled by in / out when reducing (antialiasing)."""
+    support, fn = _PIL_FILTERS[filt]
+    fn = fn or _bicubic
+    scale = float(in_size) / float(out_size)
+    filterscale = max(scale, 1.0)
+    support = support * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    kk = np.zeros((out_size, ksize), dtype=np.float64)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = (xx + 0.5) * scale
+        xmin = max(int(center - support + 0.5), 0)
+        xmax = min(int(center + support + 0.5), in_size) - xmin
+        w = fn((np.arange(xmax) + xmin - center + 0.5) * ss)
+        ww = w.sum()
+        if ww != 0.0:
+            w = w / ww
+        kk[xx, :xmax] = w
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+_PIL_CACHE = {}
+
+
+def preprocess_pil(x, dtype, filt, quantize=True, size=299):
+    """ops.quantize_images + resize_images with a PIL resizer (reference utils/resize.py:39-78: 'clean' = bicubic, 'friendly' = bilinear for
+    InceptionV3_tf) + normalise, on the device."""
+    x = x.float().contiguous()
+    N, Cc, H, W = x.shape
+    key = (H, W, size, filt, str(x.device))
+    if key not in _PIL_CACHE:
+        bh, kh, nh = pil_coeffs(W, size, filt)
+        bv, kv, nv = pil_coeffs(H, size, filt)
+        to = lambda a: torch.from_numpy(a).to(x.device).contiguous()
+        _PIL_CACHE[key] = (to(bh), to(kh), nh, to(bv), to(kv), nv)
+    bh, kh, nh, bv, kv, nv = _PIL_CACHE[key]
+    tmp = torch.empty((N, Cc, H, size), dtype=torch.float32, device=x.device)
+    out = torch.empty((N, size, size, Cc), dtype=dtype, device=x.device)
+    L.call("sg_pil_resize_normalize", L.dt(dtype), L.ptr(x), L.ptr(out), L.ptr(tmp), N, Cc, H, W, size, size, L.ptr(bh), L.ptr(kh), nh, L.ptr(bv), L.ptr(kv), nv,
+           1 if quantize else 0, L.stream())
+    return out
+
+
 class LoadEvalModel:
-    """reference src/metrics/preparation.py:43-122 for eval_backbone == "InceptionV3_tf", post_resizer == "legacy"."""
+    """reference src/metrics/preparation.py:43-122 for eval_backbone == "InceptionV3_tf" with the post-resizers "legacy" (torch bilinear),
+    "clean" (PIL bicubic) and "friendly" (PIL bilinear), reference src/utils/resize.py:49-69."""
 
     def __init__(self, eval_backbone="InceptionV3_tf", post_resizer="legacy", world_size=1, distributed_data_parallel=False, device="cuda",
                  state_dict=None, dtype=torch.float32):
-        if eval_backbone != "InceptionV3_tf" or post_resizer != "legacy":
-            raise NotImplementedError("only the InceptionV3_tf backbone with the legacy resizer is on the hot path (SURVEY §2)")
+        if eval_backbone != "InceptionV3_tf" or post_resizer not in ("legacy", "clean", "friendly"):
+            raise NotImplementedError("InceptionV3_tf with the legacy / clean / friendly resizers is on the hot path (SURVEY §2)")
         if state_dict is None:
             raise RuntimeError("pass the FID Inception state_dict (pt_inception-2015-12-05-6726825d.pth); there is no network access here")
         self.eval_backbone, self.post_resizer, self.device = eval_backbone, post_resizer, torch.device(device)
@@ -215,7 +272,9 @@ class LoadEvalModel:
 
     @torch.no_grad()
     def get_outputs(self, x, quantize=False):
-        return self.model.forward_nhwc(preprocess(x, self.dtype, quantize, self.res))
+        if self.post_resizer == "legacy":
+            return self.model.forward_nhwc(preprocess(x, self.dtype, quantize, self.res))
+        return self.model.forward_nhwc(preprocess_pil(x, self.dtype, "bicubic" if self.post_resizer == "clean" else "bilinear", quantize, self.res))
 
 
 def softmax_rows(logits):

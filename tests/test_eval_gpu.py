@@ -203,3 +203,61 @@ def test_frechet_distance_on_device_vs_reference_and_scipy(sg):
         ref = float(M.frechet_inception_distance(m1, s1, m2, s2))
         got = M.frechet_inception_distance_device(m1, s1, m2, s2)
         assert abs(got - ref) <= 1e-8 * abs(ref), (n, got, ref)
+
+
+def test_device_dataset_basket_is_bit_exact(sg):
+    """data.DeviceDataset (uint8 data set resident in HBM, reference storage format of utils/hdf5.py / data_util.py): gather + horizontal flip
+    bit-identical to numpy indexing, the basket split like torch.split (src/worker.py:194-208), every sample once per epoch, and the
+    discriminator consumes a uint8 micro-batch exactly like the host-normalised fp32 batch."""
+    from studiogan_amd.data import DeviceDataset
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(4)
+    imgs = torch.randint(0, 256, (50, 16, 16, 3), generator=g, dtype=torch.uint8)
+    labels = torch.randint(0, 10, (50,), generator=g)
+    ds = DeviceDataset(imgs.numpy(), labels.numpy(), device=dev, random_flip=True, seed=3)
+    idx = torch.tensor([7, 0, 49, 7, 13])
+    flip = torch.tensor([1, 0, 1, 0, 0], dtype=torch.uint8)
+    out, lab = ds.gather(idx, flip)
+    ref = imgs[idx].clone()
+    ref[flip.bool()] = ref[flip.bool()].flip(2)
+    assert torch.equal(out.cpu(), ref) and torch.equal(lab.cpu(), labels[idx])
+    seen = []
+    for _ in range(3):                                   # 3 baskets of 2 x 8 = 48 of 50 samples: one epoch, no repeats
+        xb, yb = ds.sample_data_basket(8, 2)
+        assert len(xb) == 2 and xb[0].shape == (8, 16, 16, 3) and xb[0].dtype == torch.uint8 and yb[1].shape == (8,)
+        for x, y in zip(xb, yb):
+            for i in range(8):
+                xi = x[i].cpu()
+                hit = [n for n in range(50) if (torch.equal(imgs[n], xi) or torch.equal(imgs[n].flip(1), xi)) and int(labels[n]) == int(y[i])]
+                assert hit, "a basket image must be a (possibly mirrored) data set image with its label"
+                seen.append(hit[0])
+    assert len(set(seen)) == 48 and ds.epoch == 1
+    ds.sample_data_basket(8, 2)
+    assert ds.epoch == 2                                  # the next basket does not fit the remaining 2 samples: new permutation
+
+
+@pytest.mark.parametrize("filt,resizer", [("bicubic", "clean"), ("bilinear", "friendly")])
+@pytest.mark.parametrize("src", [32, 128, 512])
+def test_pil_resizers_match_pillow(sg, filt, resizer, src):
+    """metrics.preprocess_pil against the reference's own resizer functions (src/utils/resize.py:68-78 build_resizer / make_resizer: PIL
+    Image.resize on mode 'F' channels) applied to the reference-quantised uint8 image, then (x / 255 - 0.5) / 0.5 as utils/ops.py:258-262:
+    up-sampling (32, 128 -> 299) and antialiased reduction (512 -> 299)."""
+    from PIL import Image
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(src)
+    x = torch.rand(2, 3, src, src, generator=g) * 2.2 - 1.1
+    _, q = OI.quantize_resize_normalize(x, quantize=True, size=8)            # q: the reference's uint8 quantisation (bit-exact, pinned elsewhere)
+    flt = {"bicubic": Image.BICUBIC, "bilinear": Image.BILINEAR}[filt]
+    ref = np.zeros((2, 299, 299, 3), dtype=np.float32)
+    for n in range(2):
+        for c in range(3):
+            img = Image.fromarray(q[n, c].astype(np.float32), mode="F").resize((299, 299), resample=flt)
+            ref[n, :, :, c] = np.asarray(img)
+    ref = (ref / 255.0 - 0.5) / 0.5
+    out = M.preprocess_pil(x.to(dev), torch.float32, filt, True, 299)
+    torch.cuda.synchronize()
+    check(f"PIL {filt} {src}->299", out.cpu(), torch.from_numpy(ref), 2e-6)
+    model = M.LoadEvalModel("InceptionV3_tf", resizer, 1, False, dev, state_dict=OI.random_state_dict(0), dtype=torch.bfloat16)
+    f, l = model.get_outputs(x.to(dev), quantize=True)
+    assert f.shape == (2, 2048) and bool(torch.isfinite(f).all())
