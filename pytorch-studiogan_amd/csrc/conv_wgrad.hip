@@ -4,6 +4,7 @@
 #include "conv_common.h"
 #include "wgrad_v2.h"
 #include "wgrad_sk.h"
+#include "wgrad_v3.h"
 
 // ---- thin layers: streaming kernel (wgrad_sk.h). SG_WGRAD_SK=0 disables it. -----------------------------------------------------
 struct SkPlan { bool ok, taps; int NI, NJ, swap, nw; long long n; };
@@ -55,6 +56,47 @@ static int wgrad_sk_launch(const sg_conv_wgrad_desc* d, const SkPlan& s, hipStre
   return sg_launch_wgrad_sk(p, s.taps, s.NI, s.NJ, st);
 }
 
+// ---- wide-image 3x3 layers: halo kernel (wgrad_v3.h). SG_WGRAD_V3=0 disables it. -----------------------------------------------------
+struct V3Plan { bool ok; int NB, nci, nco, splits, nchunk; long long n; };
+static V3Plan wgrad_v3_plan(const sg_conv_wgrad_desc* d) {
+  V3Plan s; s.ok = false; s.NB = s.nci = s.nco = s.splits = s.nchunk = 0; s.n = 0;
+  const char* mode = getenv("SG_WGRAD_V3");
+  if (mode && mode[0] == '0') return s;
+  const bool force = mode && mode[0] == 'f';                            // test hook: no lower bound on the problem size
+  if (d->dtype != SG_DTYPE_BF16 || d->stride != 1 || d->no_tr || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return s;
+  if ((d->x_flags | d->g_flags) & SG_PIX_TRANSPOSED) return s;
+  if (d->Wo != 32 && d->Wo % 64) return s;
+  if (d->Wo == 32 && (d->Ho & 1)) return s;
+  if (d->C % 32 || d->ldx % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return s;
+  if (d->Cout % 96 == 0) s.NB = 3; else if (d->Cout % 64 == 0) s.NB = 2; else return s;
+  const long long K = (long long)d->N * d->Ho * d->Wo;
+  if (K % 64 || (!force && K < 65536) || K >= (1ll << 31)) return s;
+  if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return s;
+  s.nci = d->C / 32; s.nco = d->Cout / (32 * s.NB); s.nchunk = (int)(K / 64);
+  s.n = 9ll * d->C * d->Cout;
+  const int tiles = s.nci * s.nco;
+  int sp = d->splits > 0 ? d->splits : (768 >= tiles ? 768 / tiles : 1);   // three workgroups per CU fit (registers, LDS): one full wave of 768
+  const int maxs = s.nchunk / 8 > 0 ? s.nchunk / 8 : 1;                // at least eight chunks per workgroup
+  if (sp > maxs) sp = maxs;
+  if (sp > 512) sp = 512;
+  s.splits = sp;
+  s.ok = true;
+  return s;
+}
+static int wgrad_v3_launch(const sg_conv_wgrad_desc* d, const V3Plan& s, hipStream_t st) {
+  WgradV3Params p;
+  p.x = (const bf16_t*)d->x; p.dy = (const bf16_t*)d->dy;
+  p.xHs = d->xHs; p.xWs = d->xWs; p.ldx = d->ldx; p.x_up = (d->x_flags & SG_PIX_UPSAMPLE) ? 1 : 0; p.x_relu = (d->x_flags & SG_PIX_RELU) ? 1 : 0;
+  p.gHs = d->gHs; p.gWs = d->gWs; p.ldg = d->ldg; p.g_up = (d->g_flags & SG_PIX_UPSAMPLE) ? 1 : 0;
+  p.N = d->N; p.H = d->Ho; p.W = d->Wo; p.C = d->C; p.Cout = d->Cout;
+  p.nci = s.nci; p.nco = s.nco; p.nchunk = s.nchunk; p.splits = s.splits;
+  p.xbytes = (unsigned)((((long long)d->N * d->xHs * d->xWs - 1) * d->ldx + d->C) * 2);
+  p.gbytes = (unsigned)((((long long)d->N * d->gHs * d->gWs - 1) * d->ldg + d->Cout) * 2);
+  p.out = d->work; p.split_stride = s.n;
+  p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
+  return sg_launch_wgrad_v3(p, s.NB, st);
+}
+
 // tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)
 static bool wgrad_v2_ok(const sg_conv_wgrad_desc* d) {
   const char* mode = getenv("SG_CONV_V2");
@@ -99,6 +141,8 @@ extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, lo
   const long long K = (long long)d->N * d->Ho * d->Wo;
   const SkPlan sk = wgrad_sk_plan(d);
   if (sk.ok) { *splits = sk.nw; *work_floats = (long long)sk.nw * sk.n; return 0; }
+  const V3Plan v3 = wgrad_v3_plan(d);
+  if (v3.ok) { *splits = v3.splits; *work_floats = (long long)v3.splits * v3.n; return 0; }
   int BI, BJ, sp;
   wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp, wgrad_v2_ok(d));
   *splits = sp;
@@ -183,6 +227,18 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
       if (wgrad_sk_launch(d, sk, st) != 0) { sg_set_error("sg_conv2d_wgrad: streaming kernel launch failed"); return -2; }
       long long blocks = (sk.n + 63) / 64; if (blocks > 8192) blocks = 8192;
       hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, sk.nw, sk.n);
+      sg_prof_end(st, prof);
+      SG_LAUNCH_CHECK();
+      return 0;
+    }
+  }
+  {
+    const V3Plan v3 = wgrad_v3_plan(d);
+    if (v3.ok && d->work && d->work_floats >= (long long)v3.splits * v3.n) {
+      const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
+      if (wgrad_v3_launch(d, v3, st) != 0) { sg_set_error("sg_conv2d_wgrad: halo kernel launch failed"); return -2; }
+      long long blocks = (v3.n + 63) / 64; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, v3.splits, v3.n);
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;

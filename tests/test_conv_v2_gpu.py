@@ -323,3 +323,73 @@ def test_wgrad_sk_full_size_layers(sg):
             outs[mode] = dw.cpu()
         os.environ.pop("SG_WGRAD_SK", None)
         check(f"wgrad sk full size {(N, Cin, Cout, H, R)}", outs["1"], outs["0"], 2e-3)
+
+
+WV3_CASES = [
+    # N, Cin, Cout, H(in), relu, up, pool      -- csrc/wgrad_v3.h: halo weight gradient of the wide-image 3x3 layers
+    (2, 96, 96, 32, True, False, False),        # W = 32: chunk = two image rows, three cout blocks, ReLU on load
+    (1, 32, 64, 64, False, False, False),       # W = 64: chunk = one row; one channel slice, two cout blocks (waves 2, 3 without extra tap)
+    (1, 96, 192, 64, True, False, True),        # D block conv2: pooled gradient (dy at half resolution), two cout tiles
+    (1, 192, 96, 32, True, True, False),        # G block conv1: ReLU + nearest x2 on load, six channel slices
+    (1, 64, 128, 128, False, False, False),     # W = 128: two chunks per row (halo columns come from the neighbouring chunk)
+    (3, 96, 96, 32, False, False, False),       # odd image count
+    (1, 128, 192, 32, True, True, True),        # upsample on x and pooled dy at once (W = 64 after the upsample)
+]
+
+
+@pytest.mark.parametrize("case", WV3_CASES)
+def test_wgrad_v3_matches_reference_and_v2(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, relu, up, pool = case
+    R, pad = 3, 1
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cin, H, H), dt, 61)
+    w = rnd((Cout, Cin, R, R), dt, 62, 0.1)
+    xr, wr = x.double(), w.double().requires_grad_(True)
+    y = _conv_ref(xr, wr, 1, pad, relu, up, pool, None, None)
+    gy = rnd(tuple(y.shape), dt, 63)
+    y.backward(gy.double())
+    Ho = H * (2 if up else 1)
+    xd, gyd = nhwc(x).to(d), nhwc(gy).to(d)
+    xf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    gf = L.PIX_UPSAMPLE if pool else 0
+    sig = torch.tensor([0.7], device=d)
+    outs = {}
+    for mode in ("force", "0"):
+        os.environ["SG_WGRAD_V3"] = mode
+        for splits in (0, 3):
+            dw = torch.zeros((Cout, R, R, Cin), dtype=torch.float32, device=d)
+            F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, splits=splits)
+            torch.cuda.synchronize()
+            outs[(mode, splits)] = dw.cpu().clone()
+            check(f"wgrad v3={mode} splits={splits} {case}", dw.cpu().permute(0, 3, 1, 2), wr.grad, 2e-3)
+        F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, alpha_ptr=sig, splits=3)
+        torch.cuda.synchronize()
+        check(f"wgrad v3={mode} accumulate {case}", dw.cpu().permute(0, 3, 1, 2), 1.7 * wr.grad, 2e-3)
+    os.environ.pop("SG_WGRAD_V3", None)
+    check(f"wgrad v3 vs v2 {case}", outs[("force", 0)], outs[("0", 0)], 1e-4)
+    check(f"wgrad v3 split counts {case}", outs[("force", 0)], outs[("force", 3)], 1e-4)
+
+
+def test_wgrad_v3_full_size_layers(sg):
+    """The 96 / 192 / 384-channel layers at the benchmark's resolutions (batch 16): every workgroup walks many chunks (double-buffer
+    hand-over, chunk stride = number of splits), XCD renumbering of the grid; compared with wgrad_v2."""
+    from studiogan_amd import functional as F, _lib as L
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    for (N, Cin, Cout, H, xf, gf) in ((16, 96, 96, 128, L.PIX_RELU, 0), (16, 192, 192, 64, L.PIX_RELU, L.PIX_UPSAMPLE), (16, 384, 384, 32, 0, 0),
+                                      (16, 192, 96, 128, L.PIX_RELU | L.PIX_UPSAMPLE, 0), (16, 64, 64, 32, L.PIX_RELU, 0)):
+        hx = H // 2 if xf & L.PIX_UPSAMPLE else H
+        hg = H // 2 if gf & L.PIX_UPSAMPLE else H
+        x = rnd((N, hx, hx, Cin), dt, 71).to(d)
+        gy = rnd((N, hg, hg, Cout), dt, 72).to(d)
+        outs = {}
+        for mode in ("1", "0"):
+            os.environ["SG_WGRAD_V3"] = mode
+            dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=d)
+            F.conv2d_wgrad_raw(x, gy, dw.data_ptr(), Cin, Cout, 3, 3, H, H, 1, 1, 1, xf, gf)
+            torch.cuda.synchronize()
+            outs[mode] = dw.cpu()
+        os.environ.pop("SG_WGRAD_V3", None)
+        check(f"wgrad v3 full size {(N, Cin, Cout, H, xf, gf)}", outs["1"], outs["0"], 2e-3)
