@@ -112,7 +112,7 @@ _PROTOS = {
     "sg_attn_fwd_fused_ok": [_i, _i, _i, _i, _i],
     "sg_attn_fwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_attn_bwd_fused_ok": [_i, _i, _i, _i, _i],
-    "sg_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
+    "sg_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_attn_probs_fwd": [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_attn_ds_bwd": [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_slice_up_fwd": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

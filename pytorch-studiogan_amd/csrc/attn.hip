@@ -230,6 +230,97 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(const bf16_t* theta, con
     }
 }
 
+// ---- fused forward when nothing stores P: max pass + one unnormalised pass ------------------------------------------------------------------
+// k_attn_fwd_fused<., false> was measured at 811 us on D's attention (B 256, 4096 queries x 1024 keys, 48 channels; session D trace):
+// 96 KiB of LDS = one workgroup = ONE wave per SIMD, so every MFMA -> exp -> pack -> MFMA chain ran exposed, and its first pass paid
+// 17 v_exp per 32 x 32 block only to get the row sums (v_exp is quarter rate: 16 of them cost as much as 8 MFMAs).
+// Here both passes walk the keys in 256-key chunks (LDS (1 + NCG) * 16 KiB: three workgroups per CU for NCG = 2), pass 1 keeps only the
+// running row maximum (16 v_max per block), pass 2 forms p = exp2(s log2e - m log2e) (one fma + one v_exp), accumulates the row sum and
+// O' = sum p V with the unnormalised bf16 p as the MFMA operand, and O = O' / l at the end (m is the true maximum, so no rescaling).
+template <int NCG>
+__global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O,
+                                                        int HW, int HW4, int Dp, int Cg) {
+  constexpr int KC = 256;
+  constexpr float LOG2E = 1.4426950408889634f;
+  extern __shared__ __attribute__((aligned(16))) char at_smem[];
+  char* kimg = at_smem;
+  char* vimg = at_smem + KC * 64;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int b = blockIdx.y;
+  const int q = blockIdx.x * 128 + wave * 32 + (lane & 31);
+  const int h = lane >> 5;
+  const long long qrow = (long long)b * HW + q;
+  const at_bf16x8 qf0 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 8 * h, Dp));
+  const at_bf16x8 qf1 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 16 + 8 * h, Dp));
+  float m = -3.0e38f;
+  for (int k0 = 0; k0 < HW4; k0 += KC) {
+    __syncthreads();
+    at_stage<4>(kimg, phi + ((long long)b * HW4 + k0) * Dp, KC, Dp, 0, Dp, wave, lane);
+    __syncthreads();
+#pragma unroll 2
+    for (int kb = 0; kb < KC / 32; kb++) {
+      at_f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 0, lane), qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 1, lane), qf1, s, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 16; r++) m = fmaxf(m, s[r]);
+    }
+  }
+  m = at_half_max(m);
+  const float m2 = m * LOG2E;
+  float l = 0.f;
+  at_f32x16 o[NCG];
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int r = 0; r < 16; r++) o[cg][r] = 0.f;
+  for (int k0 = 0; k0 < HW4; k0 += KC) {
+    __syncthreads();
+    at_stage<4>(kimg, phi + ((long long)b * HW4 + k0) * Dp, KC, Dp, 0, Dp, wave, lane);
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++) at_stage<4>(vimg + cg * KC * 64, g + ((long long)b * HW4 + k0) * Cg, KC, Cg, cg * 32, Cg, wave, lane);
+    __syncthreads();
+    for (int kc = 0; kc < KC / 32; kc++) {
+      at_f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; r++) s[r] = 0.f;
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kc, 0, lane), qf0, s, 0, 0, 0);
+      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kc, 1, lane), qf1, s, 0, 0, 0);
+      float p[16];
+#pragma unroll
+      for (int r = 0; r < 16; r++) { p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -m2)); l += p[r]; }
+      u32x4 pa, pb;                                               // regs 0-7 / 8-15 = contraction slots of the two k-steps
+#pragma unroll
+      for (int i = 0; i < 4; i++) { pa[i] = pack2bf(p[2 * i], p[2 * i + 1]); pb[i] = pack2bf(p[8 + 2 * i], p[8 + 2 * i + 1]); }
+      const at_bf16x8 pfa = __builtin_bit_cast(at_bf16x8, pa), pfb = __builtin_bit_cast(at_bf16x8, pb);
+#pragma unroll
+      for (int cg = 0; cg < NCG; cg++) {
+        const char* vi = vimg + cg * KC * 64;
+        o[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(vi, kc * 32 + 4 * h, lane), pfa, o[cg], 0, 0, 0);
+        o[cg] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_vfrag(vi, kc * 32 + 16 + 4 * h, lane), pfb, o[cg], 0, 0, 0);
+      }
+    }
+  }
+  l = at_half_sum(l);
+  // (the MFMA contracts over the key slots of BOTH lane halves, so o[] is already complete for the channels this lane holds; only the
+  // row sum and the row maximum are per half and need the exchange)
+  const float inv = 1.f / l;
+  if (h == 0) lse[qrow] = m + __logf(l);
+  bf16_t* orow = O + qrow * Cg;
+#pragma unroll
+  for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+    for (int g4 = 0; g4 < 4; g4++) {
+      const int c0 = cg * 32 + 8 * g4 + 4 * h;
+      if (c0 < Cg) {
+        u32x2 v = {pack2bf(o[cg][4 * g4 + 0] * inv, o[cg][4 * g4 + 1] * inv), pack2bf(o[cg][4 * g4 + 2] * inv, o[cg][4 * g4 + 3] * inv)};
+        *(u32x2*)(orow + c0) = v;
+      }
+    }
+}
+
 // grid (HW / 128, B), 256 threads. Keys in chunks of KC = 256: LDS = (1 + NCG) * 16 KiB.
 template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse, bf16_t* dS, int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
@@ -288,8 +379,10 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf
 // ---- fused backward, query side: delta, dS (registers only) and dtheta = dS phi ------------------------------------------------------------
 // k_attn_ds_bwd with the product that consumed dS moved inside: dtheta^T[d][q] += phi^T[d][k] dS[k][q] per 32-key block, dS going from the
 // score accumulators into the MFMA B operand (same key order trick as the fused forward); delta_q is also written out for the key side.
-template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse,
-                                                                        float* delta_out, bf16_t* dtheta, int HW, int HW4, int Dp, int Cg) {
+// With the forward output O at hand, delta_q = sum_k P_qk dP_qk = sum_c dO_qc O_qc (the row identity flash attention uses) is a dot product of
+// two rows the lane pair already touches, and the first of the two key passes (16 v_exp + 6 MFMAs per block just for delta) disappears.
+template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const bf16_t* Oin,
+                                                                        const float* lse, float* delta_out, bf16_t* dtheta, int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
   char* kimg = at_smem;
@@ -307,11 +400,24 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf1
 #pragma unroll
     for (int t = 0; t < 2; t++) df[cg][t] = __builtin_bit_cast(at_bf16x8, at_gfrag(dO, qrow, Cg, cg * 32 + 16 * t + 8 * h, Cg));
   float delta = 0.f;
-  const float ls = lse[qrow];
+  const float ls2 = lse[qrow] * 1.4426950408889634f;
+  if (Oin) {
+#pragma unroll
+    for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        const u32x4 ov = at_gfrag(Oin, qrow, Cg, cg * 32 + 16 * t + 8 * h, Cg);    // zero beyond Cg, like df
+        const u32x4 dv = __builtin_bit_cast(u32x4, df[cg][t]);
+#pragma unroll
+        for (int e = 0; e < 4; e++)
+          delta += __uint_as_float(ov[e] << 16) * __uint_as_float(dv[e] << 16) + __uint_as_float(ov[e] & 0xffff0000u) * __uint_as_float(dv[e] & 0xffff0000u);
+      }
+    delta = at_half_sum(delta);
+  }
   at_f32x16 dth;
 #pragma unroll
   for (int r = 0; r < 16; r++) dth[r] = 0.f;
-  for (int pass = 0; pass < 2; pass++) {
+  for (int pass = Oin ? 1 : 0; pass < 2; pass++) {
     for (int k0 = 0; k0 < HW4; k0 += KC) {
       __syncthreads();
       at_stage<4>(kimg, phi + ((long long)b * HW4 + k0) * Dp, KC, Dp, 0, Dp, wave, lane);
@@ -331,11 +437,11 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf1
             dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(vimg + cg * KC * 64, kb, t, lane), df[cg][t], dp, 0, 0, 0);
         if (pass == 0) {
 #pragma unroll
-          for (int r = 0; r < 16; r++) delta += __expf(s[r] - ls) * dp[r];
+          for (int r = 0; r < 16; r++) delta += __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], 1.4426950408889634f, -ls2)) * dp[r];
         } else {
           float o[16];
 #pragma unroll
-          for (int r = 0; r < 16; r++) o[r] = __expf(s[r] - ls) * (dp[r] - delta);
+          for (int r = 0; r < 16; r++) o[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], 1.4426950408889634f, -ls2)) * (dp[r] - delta);
           u32x4 da, db;
 #pragma unroll
           for (int i = 0; i < 4; i++) { da[i] = pack2bf(o[2 * i], o[2 * i + 1]); db[i] = pack2bf(o[8 + 2 * i], o[8 + 2 * i + 1]); }
@@ -395,7 +501,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_k(const bf1
     at_stage<4>(timg, theta + ((long long)b * HW + q0) * Dp, QC, Dp, 0, Dp, wave, lane);
 #pragma unroll
     for (int cg = 0; cg < NCG; cg++) at_stage<4>(oimg + cg * QC * 64, dO + ((long long)b * HW + q0) * Cg, QC, Cg, cg * 32, Cg, wave, lane);
-    if (tid < QC) { st[tid] = lse[(long long)b * HW + q0 + tid]; dl[tid] = delta[(long long)b * HW + q0 + tid]; }
+    if (tid < QC) { st[tid] = lse[(long long)b * HW + q0 + tid] * 1.4426950408889634f; dl[tid] = delta[(long long)b * HW + q0 + tid]; }
     __syncthreads();
     for (int qb = 0; qb < QC / 32; qb++) {
       at_f32x16 s, dp;
@@ -412,7 +518,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_k(const bf1
 #pragma unroll
       for (int r = 0; r < 16; r++) {
         const int qi = qb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;       // the query of accumulator register r
-        pr[r] = __expf(s[r] - st[qi]);
+        pr[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], 1.4426950408889634f, -st[qi]));
         ds[r] = pr[r] * (dp[r] - dl[qi]);
       }
       u32x4 pa, pb, da, db;
@@ -478,8 +584,17 @@ extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void*
     if (!done) { SG_CHECK(hipFuncSetAttribute((const void*)k_attn_fwd_fused<N, SP>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "sg_attn_fwd_fused: LDS attribute"); done = true; } \
     hipLaunchKernelGGL((k_attn_fwd_fused<N, SP>), grid, blk, lds, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (bf16_t*)P, lse, (bf16_t*)O, HW, HW4, Dp, Cg); \
   }
+#define ATL_LAUNCH(N)                                                                                                                     \
+  {                                                                                                                                        \
+    static bool done = false;                                                                                                              \
+    if (!done) { SG_CHECK(hipFuncSetAttribute((const void*)k_attn_fwd_flash<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "sg_attn_fwd_fused: LDS attribute"); done = true; } \
+    hipLaunchKernelGGL((k_attn_fwd_flash<N>), grid, blk, (1 + N) * 16384, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, lse, (bf16_t*)O, HW, HW4, Dp, Cg); \
+  }
+  static const bool two_pass = [] { const char* e = getenv("SG_ATTN_FLASH"); return e && e[0] == '0'; }();    // A/B switch: the first fused forward
   if (P) { if (ncg == 1) ATF_LAUNCH(1, true) else if (ncg == 2) ATF_LAUNCH(2, true) else if (ncg == 3) ATF_LAUNCH(3, true) else ATF_LAUNCH(4, true) }
-  else { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
+  else if (two_pass) { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
+  else { if (ncg == 1) ATL_LAUNCH(1) else if (ncg == 2) ATL_LAUNCH(2) else if (ncg == 3) ATL_LAUNCH(3) else ATL_LAUNCH(4) }
+#undef ATL_LAUNCH
 #undef ATF_LAUNCH
   SG_LAUNCH_CHECK();
   return 0;
@@ -488,8 +603,8 @@ extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void*
 extern "C" int sg_attn_bwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
   return (at_ok(B, HW, HW4, Dp) && HW % 256 == 0 && HW4 % 128 == 0 && Cg % 8 == 0 && Cg >= 8 && Cg <= 128) ? 1 : 0;
 }
-extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, float* delta, void* dtheta, void* dphi, void* dg,
-                                 int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
+extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const void* O, const float* lse, float* delta, void* dtheta, void* dphi,
+                                 void* dg, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
   SG_CHECK(theta && phi && g && dO && lse && delta && dtheta && dphi && dg, "sg_attn_bwd_fused: null");
   SG_CHECK(sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_bwd_fused: unsupported shape");
   const int ncg = (Cg + 31) / 32;
@@ -504,7 +619,7 @@ extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void*
       SG_CHECK(hipFuncSetAttribute((const void*)k_attn_bwd_k<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "sg_attn_bwd_fused: LDS attribute"); \
       done = true;                                                                                                                         \
     }                                                                                                                                      \
-    hipLaunchKernelGGL(k_attn_bwd_q<N>, dim3(HW / 128, B), dim3(256), lds_q, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, lse, delta, (bf16_t*)dtheta, HW, HW4, Dp, Cg); \
+    hipLaunchKernelGGL(k_attn_bwd_q<N>, dim3(HW / 128, B), dim3(256), lds_q, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, (const bf16_t*)O, lse, delta, (bf16_t*)dtheta, HW, HW4, Dp, Cg); \
     hipLaunchKernelGGL(k_attn_bwd_k<N>, dim3(HW4 / 128, B), dim3(256), lds_k, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, lse, (const float*)delta, (bf16_t*)dphi, (bf16_t*)dg, HW, HW4, Dp, Cg); \
   }
   if (ncg == 1) ATB_LAUNCH(1) else if (ncg == 2) ATB_LAUNCH(2) else if (ncg == 3) ATB_LAUNCH(3) else ATB_LAUNCH(4)

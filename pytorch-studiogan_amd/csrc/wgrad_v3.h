@@ -1,5 +1,6 @@
-// wgrad_v3.h -- "halo" weight gradient for the wide-image 3x3 layers (bf16, stride 1, pad 1, W >= 32): the layers whose activations stream
-// from HBM (96 / 192 / 384-channel blocks of BigGAN at 32^2 .. 128^2, the 64 .. 256-channel blocks of the ResNet GANs).
+// wgrad_v3.h -- "halo" weight gradient for the 3x3 layers (bf16, stride 1, pad 1, W >= 8): first written for the layers whose activations
+// stream from HBM (96 / 192 / 384-channel blocks of BigGAN at 32^2 .. 128^2, the 64 .. 256-channel blocks of the ResNet GANs), then
+// extended to the 16^2 and 8^2 layers (chunk = 4 / 8 whole image rows).
 //
 //   dW[co][tap][ci] (+)= alpha * sum_pix dy'[pix][co] * x'[pix + tap][ci]
 //
@@ -83,7 +84,7 @@ __device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, 
   if (extra) acc[2 * NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], xf, acc[2 * NB], 0, 0, 0);
 }
 
-// NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in pixels (64: one row segment, 32: two rows of a 32-wide image)
+// NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in pixels: 64 = one row segment, 32 / 16 / 8 = 2 / 4 / 8 whole rows of a 32 / 16 / 8-wide image
 template <int NB, int WC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_wgrad_v3_kernel(WgradV3Params p) {
   constexpr int RC = 64 / WC;                       // image rows per chunk
@@ -147,9 +148,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const unsigned sb = (unsigned)(uintptr_t)(__attribute__((address_space(3))) const char*)smem;
   // taps of this wave: 2w, 2w + 1 and 8; tap t = (dr, ds) is the patch pixel (row + dr, col + ds) of output pixel (row, col)
   const int t0 = 2 * wave, t1 = 2 * wave + 1;
-  const unsigned a0 = sb + (((t0 / 3) * PW + (t0 % 3)) + prow) * 64 + csub * 2;
-  const unsigned a1 = sb + (((t1 / 3) * PW + (t1 % 3)) + prow) * 64 + csub * 2;
-  const unsigned a2 = sb + ((2 * PW + 2) + prow) * 64 + csub * 2;
+  // (a 16-pixel k-step is part of one image row for WC >= 16 and two whole rows for WC = 8: the lane's pixel is (prow / WC, prow % WC) of it)
+  const int ppix = (prow / WC) * PW + (prow % WC);
+  const unsigned a0 = sb + (((t0 / 3) * PW + (t0 % 3)) + ppix) * 64 + csub * 2;
+  const unsigned a1 = sb + (((t1 / 3) * PW + (t1 % 3)) + ppix) * 64 + csub * 2;
+  const unsigned a2 = sb + ((2 * PW + 2) + ppix) * 64 + csub * 2;
   const unsigned b0 = sb + GOFF + prow * GPITCH + csub * 2;
   const bool extra = wave < NB;                                      // (tap 8, cout block `wave`)
   const unsigned bx = b0 + (extra ? wave : 0) * 64;
@@ -205,7 +208,13 @@ static inline int sg_launch_wgrad_v3_t(const WgradV3Params& p, hipStream_t st) {
   return 0;
 }
 static inline int sg_launch_wgrad_v3(const WgradV3Params& p, int NB, hipStream_t st) {
-  const bool w32 = p.W == 32;
-  if (NB == 3) return w32 ? sg_launch_wgrad_v3_t<3, 32>(p, st) : sg_launch_wgrad_v3_t<3, 64>(p, st);
-  return w32 ? sg_launch_wgrad_v3_t<2, 32>(p, st) : sg_launch_wgrad_v3_t<2, 64>(p, st);
+  const int wc = p.W >= 64 ? 64 : p.W;
+  if (NB == 3) {
+    switch (wc) { case 64: return sg_launch_wgrad_v3_t<3, 64>(p, st); case 32: return sg_launch_wgrad_v3_t<3, 32>(p, st);
+                  case 16: return sg_launch_wgrad_v3_t<3, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<3, 8>(p, st); }
+  } else {
+    switch (wc) { case 64: return sg_launch_wgrad_v3_t<2, 64>(p, st); case 32: return sg_launch_wgrad_v3_t<2, 32>(p, st);
+                  case 16: return sg_launch_wgrad_v3_t<2, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<2, 8>(p, st); }
+  }
+  return -1;
 }

@@ -852,14 +852,15 @@ class AttnCoreFn(torch.autograd.Function):
             o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
             # o[q][c] = sum_k P[q][k] g[k][c]
             gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
-        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse)
+        # the fused backward takes delta_q = dO_q . O_q from the output instead of a pass over the keys
+        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse, o if (P is None and any(ctx.needs_input_grad)) else None)
         ctx.dims = (B, H, W, Dp, Cg)
         return o
 
     @staticmethod
     def backward(ctx, do):
         _first_order_only("AttnCoreFn")
-        theta, phi, g, idx_phi, idx_g, P, lse = ctx.saved_tensors
+        theta, phi, g, idx_phi, idx_g, P, lse, o = ctx.saved_tensors
         B, H, W, Dp, Cg = ctx.dims
         HW, HW4 = H * W, (H // 2) * (W // 2)
         do = _c(do)
@@ -873,8 +874,8 @@ class AttnCoreFn(torch.autograd.Function):
             dtheta = torch.empty((B, H, W, Dp), dtype=T, device=dev)
             dphi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
             dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
-            L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi), L.ptr(dg),
-                   B, HW, HW4, Dp, Cg, L.stream())
+            L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(o), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi),
+                   L.ptr(dg), B, HW, HW4, Dp, Cg, L.stream())
             dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
             dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)
             L.call("sg_maxpool2_bwd", sd, L.ptr(dphi), Dp, L.ptr(idx_phi), L.ptr(dphi_full), Dp, B, H, W, Dp, L.stream())

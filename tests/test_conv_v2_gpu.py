@@ -334,6 +334,9 @@ WV3_CASES = [
     (1, 64, 128, 128, False, False, False),     # W = 128: two chunks per row (halo columns come from the neighbouring chunk)
     (3, 96, 96, 32, False, False, False),       # odd image count
     (1, 128, 192, 32, True, True, True),        # upsample on x and pooled dy at once (W = 64 after the upsample)
+    (4, 64, 96, 16, True, False, False),        # W = 16: chunk = four image rows
+    (4, 96, 64, 8, False, False, False),        # W = 8: chunk = a whole image, a k-step = two rows
+    (4, 64, 64, 8, True, True, True),           # W = 16 after the upsample, pooled dy at 8 x 8
 ]
 
 
@@ -379,7 +382,8 @@ def test_wgrad_v3_full_size_layers(sg):
     d = torch.device("cuda:0")
     dt = torch.bfloat16
     for (N, Cin, Cout, H, xf, gf) in ((16, 96, 96, 128, L.PIX_RELU, 0), (16, 192, 192, 64, L.PIX_RELU, L.PIX_UPSAMPLE), (16, 384, 384, 32, 0, 0),
-                                      (16, 192, 96, 128, L.PIX_RELU | L.PIX_UPSAMPLE, 0), (16, 64, 64, 32, L.PIX_RELU, 0)):
+                                      (16, 192, 96, 128, L.PIX_RELU | L.PIX_UPSAMPLE, 0), (16, 64, 64, 32, L.PIX_RELU, 0),
+                                      (64, 768, 768, 16, L.PIX_RELU, 0), (256, 768, 1536, 8, 0, 0)):
         hx = H // 2 if xf & L.PIX_UPSAMPLE else H
         hg = H // 2 if gf & L.PIX_UPSAMPLE else H
         x = rnd((N, hx, hx, Cin), dt, 71).to(d)
