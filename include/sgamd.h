@@ -254,12 +254,13 @@ int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B,
 int sg_attn_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
 /* fused forward of the attention core: O = softmax(theta phi^T) g per image in one launch (probabilities stored only when P != NULL) */
 int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
-int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
+int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, float* O32, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
 /* fused backward of the attention core: dtheta, dphi, dg from theta / phi / g / dO / lse with P and dS recomputed on the fly (two launches:
- * query side + key side); delta = fp32 scratch [B][HW]. O = the forward output [B][HW][Cg] (delta_q = dO_q . O_q, one key pass on the query
- * side) or NULL (delta from an extra pass over the keys) */
+ * query side + key side); delta = fp32 scratch [B][HW]. O32 = the unrounded fp32 copy of the forward output [B][HW][Cg] that
+ * sg_attn_fwd_fused writes on request (P == NULL path): delta_q = dO_q . O_q, one key pass on the query side; NULL: delta from an extra pass
+ * over the keys */
 int sg_attn_bwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
-int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const void* O, const float* lse, float* delta, void* dtheta, void* dphi,
+int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const float* O32, const float* lse, float* delta, void* dtheta, void* dphi,
                       void* dg, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
 int sg_attn_probs_fwd(const void* theta, const void* phi, void* P, float* lse, int B, int HW, int HW4, int Dp, sg_stream_t s);
 int sg_attn_ds_bwd(const void* theta, const void* phi, const void* g, const void* dO, const float* lse, void* dS,

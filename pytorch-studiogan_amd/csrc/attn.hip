@@ -238,7 +238,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(const bf16_t* theta, con
 // running row maximum (16 v_max per block), pass 2 forms p = exp2(s log2e - m log2e) (one fma + one v_exp), accumulates the row sum and
 // O' = sum p V with the unnormalised bf16 p as the MFMA operand, and O = O' / l at the end (m is the true maximum, so no rescaling).
 template <int NCG>
-__global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O,
+__global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O, float* O32,
                                                         int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
   constexpr float LOG2E = 1.4426950408889634f;
@@ -315,8 +315,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, con
     for (int g4 = 0; g4 < 4; g4++) {
       const int c0 = cg * 32 + 8 * g4 + 4 * h;
       if (c0 < Cg) {
-        u32x2 v = {pack2bf(o[cg][4 * g4 + 0] * inv, o[cg][4 * g4 + 1] * inv), pack2bf(o[cg][4 * g4 + 2] * inv, o[cg][4 * g4 + 3] * inv)};
+        const f32x4 f = {o[cg][4 * g4 + 0] * inv, o[cg][4 * g4 + 1] * inv, o[cg][4 * g4 + 2] * inv, o[cg][4 * g4 + 3] * inv};
+        u32x2 v = {pack2bf(f[0], f[1]), pack2bf(f[2], f[3])};
         *(u32x2*)(orow + c0) = v;
+        if (O32) *(f32x4*)(O32 + qrow * Cg + c0) = f;             // unrounded copy for the backward's delta_q = dO_q . O_q
       }
     }
 }
@@ -381,7 +383,10 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf
 // score accumulators into the MFMA B operand (same key order trick as the fused forward); delta_q is also written out for the key side.
 // With the forward output O at hand, delta_q = sum_k P_qk dP_qk = sum_c dO_qc O_qc (the row identity flash attention uses) is a dot product of
 // two rows the lane pair already touches, and the first of the two key passes (16 v_exp + 6 MFMAs per block just for delta) disappears.
-template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const bf16_t* Oin,
+// O comes as the UNROUNDED fp32 copy the forward keeps for this purpose: with the bf16 output the error of dtheta against fp64 grew from
+// ~2e-2 to 4.4e-2 on the near-uniform softmax of tests/test_kernels_gpu.py::test_attention_core (session F), because dS = P (dP - delta)
+// subtracts nearly equal numbers there.
+template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* Oin,
                                                                         const float* lse, float* delta_out, bf16_t* dtheta, int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
@@ -406,11 +411,13 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf1
     for (int cg = 0; cg < NCG; cg++)
 #pragma unroll
       for (int t = 0; t < 2; t++) {
-        const u32x4 ov = at_gfrag(Oin, qrow, Cg, cg * 32 + 16 * t + 8 * h, Cg);    // zero beyond Cg, like df
-        const u32x4 dv = __builtin_bit_cast(u32x4, df[cg][t]);
-#pragma unroll
-        for (int e = 0; e < 4; e++)
-          delta += __uint_as_float(ov[e] << 16) * __uint_as_float(dv[e] << 16) + __uint_as_float(ov[e] & 0xffff0000u) * __uint_as_float(dv[e] & 0xffff0000u);
+        const int c0 = cg * 32 + 16 * t + 8 * h;
+        if (c0 < Cg) {                                               // Cg % 8 == 0: groups of 8 channels are whole
+          const f32x4 oa = *(const f32x4*)(Oin + qrow * Cg + c0), ob = *(const f32x4*)(Oin + qrow * Cg + c0 + 4);
+          const u32x4 dv = __builtin_bit_cast(u32x4, df[cg][t]);
+          delta += oa[0] * __uint_as_float(dv[0] << 16) + oa[1] * __uint_as_float(dv[0] & 0xffff0000u) + oa[2] * __uint_as_float(dv[1] << 16) + oa[3] * __uint_as_float(dv[1] & 0xffff0000u)
+                 + ob[0] * __uint_as_float(dv[2] << 16) + ob[1] * __uint_as_float(dv[2] & 0xffff0000u) + ob[2] * __uint_as_float(dv[3] << 16) + ob[3] * __uint_as_float(dv[3] & 0xffff0000u);
+        }
       }
     delta = at_half_sum(delta);
   }
@@ -570,8 +577,9 @@ extern "C" int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
   return (at_ok(B, HW, HW4, Dp) && Cg % 8 == 0 && Cg >= 8 && Cg <= 128 && HW4 * 64 + ncg * 16384 <= 160 * 1024) ? 1 : 0;
 }
 // O = softmax(theta phi^T) g in one launch; P == NULL: the probabilities are not stored (no backward will ask for them)
-extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
+extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, float* O32, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
   SG_CHECK(theta && phi && g && lse && O, "sg_attn_fwd_fused: null");
+  SG_CHECK(!(P && O32), "sg_attn_fwd_fused: the fp32 copy of O belongs to the path that does not store P");
   SG_CHECK(sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_fwd_fused: unsupported shape");
   const int ncg = (Cg + 31) / 32;
   const int lds = HW4 * 64 + ncg * 16384;
@@ -588,11 +596,11 @@ extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void*
   {                                                                                                                                        \
     static bool done = false;                                                                                                              \
     if (!done) { SG_CHECK(hipFuncSetAttribute((const void*)k_attn_fwd_flash<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "sg_attn_fwd_fused: LDS attribute"); done = true; } \
-    hipLaunchKernelGGL((k_attn_fwd_flash<N>), grid, blk, (1 + N) * 16384, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, lse, (bf16_t*)O, HW, HW4, Dp, Cg); \
+    hipLaunchKernelGGL((k_attn_fwd_flash<N>), grid, blk, (1 + N) * 16384, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, lse, (bf16_t*)O, O32, HW, HW4, Dp, Cg); \
   }
   static const bool two_pass = [] { const char* e = getenv("SG_ATTN_FLASH"); return e && e[0] == '0'; }();    // A/B switch: the first fused forward
   if (P) { if (ncg == 1) ATF_LAUNCH(1, true) else if (ncg == 2) ATF_LAUNCH(2, true) else if (ncg == 3) ATF_LAUNCH(3, true) else ATF_LAUNCH(4, true) }
-  else if (two_pass) { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
+  else if (two_pass && !O32) { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
   else { if (ncg == 1) ATL_LAUNCH(1) else if (ncg == 2) ATL_LAUNCH(2) else if (ncg == 3) ATL_LAUNCH(3) else ATL_LAUNCH(4) }
 #undef ATL_LAUNCH
 #undef ATF_LAUNCH
@@ -603,7 +611,7 @@ extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void*
 extern "C" int sg_attn_bwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
   return (at_ok(B, HW, HW4, Dp) && HW % 256 == 0 && HW4 % 128 == 0 && Cg % 8 == 0 && Cg >= 8 && Cg <= 128) ? 1 : 0;
 }
-extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const void* O, const float* lse, float* delta, void* dtheta, void* dphi,
+extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void* g, const void* dO, const float* O32, const float* lse, float* delta, void* dtheta, void* dphi,
                                  void* dg, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
   SG_CHECK(theta && phi && g && dO && lse && delta && dtheta && dphi && dg, "sg_attn_bwd_fused: null");
   SG_CHECK(sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_bwd_fused: unsupported shape");
@@ -619,7 +627,7 @@ extern "C" int sg_attn_bwd_fused(const void* theta, const void* phi, const void*
       SG_CHECK(hipFuncSetAttribute((const void*)k_attn_bwd_k<N>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_k) == hipSuccess, "sg_attn_bwd_fused: LDS attribute"); \
       done = true;                                                                                                                         \
     }                                                                                                                                      \
-    hipLaunchKernelGGL(k_attn_bwd_q<N>, dim3(HW / 128, B), dim3(256), lds_q, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, (const bf16_t*)O, lse, delta, (bf16_t*)dtheta, HW, HW4, Dp, Cg); \
+    hipLaunchKernelGGL(k_attn_bwd_q<N>, dim3(HW / 128, B), dim3(256), lds_q, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, O32, lse, delta, (bf16_t*)dtheta, HW, HW4, Dp, Cg); \
     hipLaunchKernelGGL(k_attn_bwd_k<N>, dim3(HW4 / 128, B), dim3(256), lds_k, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, (const bf16_t*)dO, lse, (const float*)delta, (bf16_t*)dphi, (bf16_t*)dg, HW, HW4, Dp, Cg); \
   }
   if (ncg == 1) ATB_LAUNCH(1) else if (ncg == 2) ATB_LAUNCH(2) else if (ncg == 3) ATB_LAUNCH(3) else ATB_LAUNCH(4)

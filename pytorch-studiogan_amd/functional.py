@@ -827,7 +827,7 @@ class AttnCoreFn(torch.autograd.Function):
         L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
         fused = T == torch.bfloat16 and L.lib().sg_attn_fused_ok(B, HW, HW4, Dp, Cg) == 1
         fused_fwd = fused and L.lib().sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
-        lse = None
+        lse = o32 = None
         if fused_fwd:
             # one launch: scores, softmax and the product with the pooled values; the bf16 probabilities are written only when a backward
             # can come (they feed dg = P^T dO), never for the no-grad generator forwards of the discriminator update
@@ -836,7 +836,9 @@ class AttnCoreFn(torch.autograd.Function):
             P = torch.empty((B, HW, HW4), dtype=T, device=dev) if need_p else None
             lse = torch.empty((B, HW), dtype=torch.float32, device=dev)
             o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
-            L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P), L.ptr(lse), L.ptr(o), B, HW, HW4, Dp, Cg, L.stream())
+            # the fused backward takes delta_q = dO_q . O_q from an unrounded fp32 copy of the output instead of a pass over the keys
+            o32 = torch.empty((B, HW, Cg), dtype=torch.float32, device=dev) if (P is None and any(ctx.needs_input_grad)) else None
+            L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P), L.ptr(lse), L.ptr(o), L.ptr(o32), B, HW, HW4, Dp, Cg, L.stream())
         else:
             P = torch.empty((B, HW, HW4), dtype=T, device=dev)
             if fused:
@@ -852,15 +854,14 @@ class AttnCoreFn(torch.autograd.Function):
             o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
             # o[q][c] = sum_k P[q][k] g[k][c]
             gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
-        # the fused backward takes delta_q = dO_q . O_q from the output instead of a pass over the keys
-        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse, o if (P is None and any(ctx.needs_input_grad)) else None)
+        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse, o32)
         ctx.dims = (B, H, W, Dp, Cg)
         return o
 
     @staticmethod
     def backward(ctx, do):
         _first_order_only("AttnCoreFn")
-        theta, phi, g, idx_phi, idx_g, P, lse, o = ctx.saved_tensors
+        theta, phi, g, idx_phi, idx_g, P, lse, o32 = ctx.saved_tensors
         B, H, W, Dp, Cg = ctx.dims
         HW, HW4 = H * W, (H // 2) * (W // 2)
         do = _c(do)
@@ -874,7 +875,7 @@ class AttnCoreFn(torch.autograd.Function):
             dtheta = torch.empty((B, H, W, Dp), dtype=T, device=dev)
             dphi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
             dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
-            L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(o), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi),
+            L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(o32), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi),
                    L.ptr(dg), B, HW, HW4, Dp, Cg, L.stream())
             dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
             dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)

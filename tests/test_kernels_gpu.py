@@ -494,8 +494,11 @@ def test_attention_fused_forward_matches_unfused_chain(sg, shape):
         P1 = torch.zeros((B, HW, HW4), dtype=T, device=d) if store else None
         lse1 = torch.empty((B, HW), dtype=torch.float32, device=d)
         o1 = torch.empty((B, HW, Cg), dtype=T, device=d)
-        L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P1), L.ptr(lse1), L.ptr(o1), B, HW, HW4, Dp, Cg, L.stream())
+        o32 = None if store else torch.empty((B, HW, Cg), dtype=torch.float32, device=d)
+        L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(P1), L.ptr(lse1), L.ptr(o1), L.ptr(o32), B, HW, HW4, Dp, Cg, L.stream())
         torch.cuda.synchronize()
+        if o32 is not None:
+            assert torch.equal(o32.to(T), o1), "the fp32 copy of O must round to the bf16 output"
         if store:
             assert torch.equal(P1, P0), "fused forward must store the same bf16 probabilities"
             assert torch.equal(lse1, lse0)
@@ -536,11 +539,12 @@ def test_attention_fused_backward_matches_unfused_chain(sg, shape):
     tr, pr, gr = [t.double().cpu().requires_grad_(True) for t in (theta, phi, g)]
     o = torch.softmax(tr @ pr.transpose(1, 2), -1) @ gr
     o.backward(do.double().cpu())
-    # the forward output as the product path has it (bf16, from the fused forward): delta_q = dO_q . O_q
+    # the forward output as the product path keeps it for the backward (unrounded fp32 copy from the fused forward): delta_q = dO_q . O_q
     lse_f = torch.empty((B, HW), dtype=torch.float32, device=d)
     o_f = torch.empty((B, HW, Cg), dtype=T, device=d)
-    L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), None, L.ptr(lse_f), L.ptr(o_f), B, HW, HW4, Dp, Cg, L.stream())
-    for what, o_arg, lse_arg in (("delta from a key pass", None, lse), ("delta = dO . O", o_f, lse_f)):
+    o32 = torch.empty((B, HW, Cg), dtype=torch.float32, device=d)
+    L.call("sg_attn_fwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), None, L.ptr(lse_f), L.ptr(o_f), L.ptr(o32), B, HW, HW4, Dp, Cg, L.stream())
+    for what, o_arg, lse_arg in (("delta from a key pass", None, lse), ("delta = dO . O", o32, lse_f)):
         delta = torch.empty((B, HW), dtype=torch.float32, device=d)
         dth1, dph1, dg1 = torch.empty_like(dth0), torch.empty_like(dph0), torch.empty_like(dg0)
         L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(o_arg), L.ptr(lse_arg), L.ptr(delta), L.ptr(dth1), L.ptr(dph1),
@@ -553,4 +557,4 @@ def test_attention_fused_backward_matches_unfused_chain(sg, shape):
         check(f"fused bwd dphi vs fp64 ({what})", dph1.float().cpu(), pr.grad, 3e-2)
         check(f"fused bwd dg vs fp64 ({what})", dg1.float().cpu(), gr.grad, 3e-2)
         dref = (do.double().cpu() * o).sum(-1)
-        check(f"delta ({what})", delta.cpu().double(), dref, 2e-2)
+        check(f"delta ({what})", delta.cpu().double(), dref, 5e-3)
