@@ -1,6 +1,7 @@
 // conv_v3.hip -- dispatcher of the halo kernel (conv_v3.h): 3x3 / stride 1 / pad 1 forward and data gradient, bf16.
 #include "conv_common.h"
 #include "conv_v3.h"
+extern template int sg_conv_v3_dispatch<2>(int, int, const ConvV3Params&, const Epilogue<bf16_t>&, hipStream_t);   // conv_v3b.hip
 
 // halo kernel (conv_v3.h) for 3x3 / stride 1 / pad 1 with >= 64 input channels; returns false when the problem is not eligible.
 // SG_CONV_V3=0 disables it, =force skips the tile-count heuristic (tests), =all also takes the shapes the default table leaves to v2.
@@ -9,7 +10,7 @@ bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   if (mode && mode[0] == '0') return false;
   const bool force = mode && mode[0] == 'f';
   if (d->stride != 1 || (pflags & SG_PIX_TRANSPOSED) || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return false;
-  if (d->C < 64 || d->C % 8 || d->ldx % 8 || !aligned16(d->x) || !aligned16(d->w)) return false;
+  if (d->C < 64 || d->C % 32 || d->ldx % 8 || !aligned16(d->x) || !aligned16(d->w)) return false;   // slices of 64 channels, the last one whole or half
   const bool up = (pflags & SG_PIX_UPSAMPLE) != 0, quad = (pflags & SG_PIX_QUAD) != 0;
   if (d->Ho != d->Hs * (up ? 2 : 1) || d->Wo != d->Ws * (up ? 2 : 1)) return false;
   const int wshift = ilog2_exact(d->Wo), hshift = ilog2_exact(d->Ho);
@@ -44,19 +45,9 @@ bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   p.npix_src = d->N * d->Hs * d->Ws;
   p.npx = (up ? BJ / 4 : BJ) + 2 * d->Ws + 16;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
-  p.zero_off = 0; p.bias_off = 0;
-  {   // DMA piece placement (conv_v3.h): SG_V3_SCHED=0 / 1 overrides the default
-    static int sched = -1;
-    if (sched < 0) { const char* e2 = getenv("SG_V3_SCHED"); sched = e2 ? (e2[0] - '0') : 1; }
-    p.sched = sched;
-  }
+  p.zero_off = 0; p.bias_off = 0; p.dump_off = 0;
   if (((p.npx >> 3) + 7) / 8 >= 19) return false;           // would need more than 2 patch pieces per tap and wave (never with <= 160 KB of LDS)
-  int rc;
-  if (best == 192) rc = sg_launch_conv_v3<192, 4, 2, 256>(p, e, st);
-  else if (best == 128) rc = sg_launch_conv_v3<128, 4, 2, 256>(p, e, st);
-  else if (best == 32) rc = sg_launch_conv_v3<32, 8, 1, 512>(p, e, st);
-  else if (BJ == 512) rc = sg_launch_conv_v3<96, 8, 1, 512>(p, e, st);
-  else rc = sg_launch_conv_v3<96, 8, 1, 256>(p, e, st);
+  const int rc = (d->C % 64 == 0) ? sg_conv_v3_dispatch<4>(best, BJ, p, e, st) : sg_conv_v3_dispatch<2>(best, BJ, p, e, st);
   return rc == 0;
 }
-
+template int sg_conv_v3_dispatch<4>(int, int, const ConvV3Params&, const Epilogue<bf16_t>&, hipStream_t);
