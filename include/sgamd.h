@@ -90,8 +90,13 @@ typedef struct {
   int no_tr;                       /* 1 = use the gather fragment path instead of ds_read_b64_tr_b16 (test hook) */
   float* work; long long work_floats; /* optional scratch for the deterministic two-stage split-K (see sg_conv2d_wgrad_plan);
                                          without it k-splits fall back to fp32 atomics */
+  float* dbias;                    /* optional: dbias[co] += sum over the stored dy pixels of dy[.., co] (the bias gradient of the same layer),
+                                      computed from the dy fragments the weight-gradient kernel already holds. Only honoured when
+                                      sg_conv2d_wgrad_fuses_bias(d) == 1; otherwise the caller runs sg_colsum */
 } sg_conv_wgrad_desc;
 int sg_conv2d_wgrad(const sg_conv_wgrad_desc* d, sg_stream_t stream);
+/* 1 when sg_conv2d_wgrad will also produce d->dbias for this problem (halo kernel + workspace present) */
+int sg_conv2d_wgrad_fuses_bias(const sg_conv_wgrad_desc* d);
 /* the k-split count the launcher will use for this problem and the scratch floats its two-stage reduction wants */
 int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, long long* work_floats);
 

@@ -32,7 +32,7 @@ class ConvWgradDesc(C.Structure):
     _fields_ = [("dtype", _i), ("N", _i), ("xHs", _i), ("xWs", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("gHs", _i), ("gWs", _i),
                 ("Cout", _i), ("ldg", _i), ("g_flags", _i), ("Ho", _i), ("Wo", _i), ("R", _i), ("S", _i), ("stride", _i),
                 ("pad_h", _i), ("pad_w", _i), ("alpha", _f), ("x", _vp), ("dy", _vp), ("dw", _vp), ("alpha_ptr", _vp),
-                ("splits", _i), ("no_tr", _i), ("work", _vp), ("work_floats", _ll)]
+                ("splits", _i), ("no_tr", _i), ("work", _vp), ("work_floats", _ll), ("dbias", _vp)]
 
 
 class GemmDesc(C.Structure):
@@ -75,6 +75,7 @@ _PROTOS = {
     "sg_conv2d_fwd": [C.POINTER(ConvFwdDesc), _vp],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_conv2d_wgrad_plan": [C.POINTER(ConvWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
+    "sg_conv2d_wgrad_fuses_bias": [C.POINTER(ConvWgradDesc)],
     "sg_gemm": [C.POINTER(GemmDesc), _vp],
     "sg_nchw_to_nhwc": [_i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_nhwc_to_nchw": [_i, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],

@@ -57,9 +57,9 @@ static int wgrad_sk_launch(const sg_conv_wgrad_desc* d, const SkPlan& s, hipStre
 }
 
 // ---- wide-image 3x3 layers: halo kernel (wgrad_v3.h). SG_WGRAD_V3=0 disables it. -----------------------------------------------------
-struct V3Plan { bool ok; int NB, nci, nco, splits, nchunk; long long n; };
+struct V3Plan { bool ok; int NB, nci, nco, splits, nchunk; long long n, stride; };   // stride: floats per partial = n (+ Cout when the bias gradient rides along)
 static V3Plan wgrad_v3_plan(const sg_conv_wgrad_desc* d) {
-  V3Plan s; s.ok = false; s.NB = s.nci = s.nco = s.splits = s.nchunk = 0; s.n = 0;
+  V3Plan s; s.ok = false; s.NB = s.nci = s.nco = s.splits = s.nchunk = 0; s.n = 0; s.stride = 0;
   const char* mode = getenv("SG_WGRAD_V3");
   if (mode && mode[0] == '0') return s;
   const bool force = mode && mode[0] == 'f';                            // test hook: no lower bound on the problem size
@@ -74,6 +74,7 @@ static V3Plan wgrad_v3_plan(const sg_conv_wgrad_desc* d) {
   if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return s;
   s.nci = d->C / 32; s.nco = d->Cout / (32 * s.NB); s.nchunk = (int)(K / 64);
   s.n = 9ll * d->C * d->Cout;
+  s.stride = s.n + (d->dbias ? d->Cout : 0);
   const int tiles = s.nci * s.nco;
   int sp = d->splits > 0 ? d->splits : (768 >= tiles ? 768 / tiles : 1);   // three workgroups per CU fit (registers, LDS): one full wave of 768
   const int maxs = s.nchunk / 8 > 0 ? s.nchunk / 8 : 1;                // at least eight chunks per workgroup
@@ -92,7 +93,8 @@ static int wgrad_v3_launch(const sg_conv_wgrad_desc* d, const V3Plan& s, hipStre
   p.nci = s.nci; p.nco = s.nco; p.nchunk = s.nchunk; p.splits = s.splits;
   p.xbytes = (unsigned)((((long long)d->N * d->xHs * d->xWs - 1) * d->ldx + d->C) * 2);
   p.gbytes = (unsigned)((((long long)d->N * d->gHs * d->gWs - 1) * d->ldg + d->Cout) * 2);
-  p.out = d->work; p.split_stride = s.n;
+  p.out = d->work; p.split_stride = s.stride;
+  p.bias_off = d->dbias ? s.n : -1; p.bias_scale = p.g_up ? 0.25f : 1.f;
   p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
   return sg_launch_wgrad_v3(p, s.NB, st);
 }
@@ -135,6 +137,12 @@ static void wgrad_plan(int I, int J, int K, int bk, int want_splits, int& BI, in
   }
 }
 
+extern "C" int sg_conv2d_wgrad_fuses_bias(const sg_conv_wgrad_desc* d) {
+  if (!d || !d->dbias) return 0;
+  if (wgrad_sk_plan(d).ok) return 0;
+  return wgrad_v3_plan(d).ok ? 1 : 0;            // (the launcher also needs the workspace sg_conv2d_wgrad_plan asks for: the caller provides it)
+}
+
 extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, long long* work_floats) {
   SG_CHECK(d && splits && work_floats, "sg_conv2d_wgrad_plan: null");
   const int I = d->R * d->S * d->C, J = d->Cout;
@@ -142,7 +150,7 @@ extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, lo
   const SkPlan sk = wgrad_sk_plan(d);
   if (sk.ok) { *splits = sk.nw; *work_floats = (long long)sk.nw * sk.n; return 0; }
   const V3Plan v3 = wgrad_v3_plan(d);
-  if (v3.ok) { *splits = v3.splits; *work_floats = (long long)v3.splits * v3.n; return 0; }
+  if (v3.ok) { *splits = v3.splits; *work_floats = (long long)v3.splits * v3.stride; return 0; }
   int BI, BJ, sp;
   wgrad_plan(I, J, (int)K, d->dtype == SG_DTYPE_BF16 ? 32 : 16, d->splits, BI, BJ, sp, wgrad_v2_ok(d));
   *splits = sp;
@@ -154,25 +162,30 @@ extern "C" int sg_conv2d_wgrad_plan(const sg_conv_wgrad_desc* d, int* splits, lo
 // 256 threads = 64 outputs x 4 split phases: phase q sums the splits s = q, q + 4, ... with four loads in flight, the four phase sums are
 // combined in a fixed order through LDS. (One thread per output walking all splits -- the first version -- was a chain of up to 1024
 // dependent loads on 27-324 workgroups: 106 us average, 11 ms per training step in the r02 trace for a few hundred MB.)
-__global__ __launch_bounds__(256) void k_splitk_reduce(const float* partial, float* out, int splits, long long n) {
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* partial, float* out, int splits, long long n, long long stride = 0, float* out2 = nullptr, long long n2 = 0) {
   __shared__ float sm[4][64];
+  if (stride == 0) stride = n;                    // partial s at partial + s * stride; elements n .. n + n2 - 1 of a partial go to out2 (bias gradient)
+  const long long nt = n + n2;
   const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
-  for (long long i0 = blockIdx.x * 64ll; i0 < n; i0 += (long long)gridDim.x * 64) {
+  for (long long i0 = blockIdx.x * 64ll; i0 < nt; i0 += (long long)gridDim.x * 64) {
     const long long i = i0 + li;
     float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
-    if (i < n) {
+    if (i < nt) {
       int s = q;
       for (; s + 12 < splits; s += 16) {
-        a0 += partial[(long long)s * n + i];
-        a1 += partial[(long long)(s + 4) * n + i];
-        a2 += partial[(long long)(s + 8) * n + i];
-        a3 += partial[(long long)(s + 12) * n + i];
+        a0 += partial[(long long)s * stride + i];
+        a1 += partial[(long long)(s + 4) * stride + i];
+        a2 += partial[(long long)(s + 8) * stride + i];
+        a3 += partial[(long long)(s + 12) * stride + i];
       }
-      for (; s < splits; s += 4) a0 += partial[(long long)s * n + i];
+      for (; s < splits; s += 4) a0 += partial[(long long)s * stride + i];
     }
     sm[q][li] = (a0 + a1) + (a2 + a3);
     __syncthreads();
-    if (q == 0 && i < n) out[i] += (sm[0][li] + sm[1][li]) + (sm[2][li] + sm[3][li]);
+    if (q == 0 && i < nt) {
+      const float t = (sm[0][li] + sm[1][li]) + (sm[2][li] + sm[3][li]);
+      if (i < n) out[i] += t; else out2[i - n] += t;
+    }
     __syncthreads();
   }
 }
@@ -234,11 +247,12 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   }
   {
     const V3Plan v3 = wgrad_v3_plan(d);
-    if (v3.ok && d->work && d->work_floats >= (long long)v3.splits * v3.n) {
+    if (v3.ok && d->work && d->work_floats >= (long long)v3.splits * v3.stride) {
       const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
       if (wgrad_v3_launch(d, v3, st) != 0) { sg_set_error("sg_conv2d_wgrad: halo kernel launch failed"); return -2; }
-      long long blocks = (v3.n + 63) / 64; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, v3.splits, v3.n);
+      long long blocks = (v3.stride + 63) / 64; if (blocks > 8192) blocks = 8192;
+      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, v3.splits, v3.n, v3.stride, d->dbias,
+                         (long long)(d->dbias ? d->Cout : 0));
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;

@@ -31,7 +31,9 @@ struct WgradV3Params {
   int nchunk;                    // N * H * W / 64
   int splits;                    // workgroups per (ci slice, co tile); chunk c goes to split c % splits
   unsigned xbytes, gbytes;
-  float* out; long long split_stride;   // partial s at out + s * split_stride (split_stride == 0: single split accumulates into dw... not used)
+  float* out; long long split_stride;   // partial s at out + s * split_stride
+  long long bias_off;            // >= 0: the workgroups of channel slice 0 also write sum_pix dy[pix][co] * bias_scale to out[s * split_stride + bias_off + co]
+  float bias_scale;              // 0.25 when dy is the pooled gradient read four times (g_up), else 1
   float alpha; const float* alpha_ptr;
 };
 
@@ -42,7 +44,8 @@ template <int OFF> __device__ __forceinline__ void w3_tr_read(unsigned addr, u32
 typedef short w3_s16x2 __attribute__((ext_vector_type(2)));
 // one k-step (16 pixels) of a chunk: 2 NB + 1 MFMAs from 3 activation fragments (taps t0, t1, 8) and NB + 1 gradient fragments
 template <int NB, int WC, int KS>
-__device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, uint32_t relu_bound, bool extra) {
+__device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, uint32_t relu_bound, bool extra,
+                                         float* csum, bool do_csum) {
   constexpr int PW = WC + 2, GPITCH = NB * 64;
   constexpr int KX = ((KS * 16) / WC) * PW * 64 + ((KS * 16) % WC) * 64;       // patch byte offset of pixels KS * 16 .. of the chunk raster
   constexpr int KG = KS * 16 * GPITCH;
@@ -76,6 +79,16 @@ __device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, 
     bf[b] = __builtin_bit_cast(bf16x8_t, v);
   }
   { asm volatile("" : "+v"(xl), "+v"(xh)); u32x4 v = {xl[0], xl[1], xh[0], xh[1]}; xf = __builtin_bit_cast(bf16x8_t, v); }
+  if (do_csum) {       // bias gradient (one wave of the slice-0 workgroups): this lane's 8 pixels of cout b * 32 + (lane & 31)
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const u32x4 v = __builtin_bit_cast(u32x4, bf[b]);
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 4; q++) t += __uint_as_float(v[q] << 16) + __uint_as_float(v[q] & 0xffff0000u);
+      csum[b] += t;
+    }
+  }
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b], acc[b], 0, 0, 0);
@@ -164,6 +177,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
     for (int r = 0; r < 16; r++) acc[s][r] = 0.f;
 
+  // bias gradient: wave 3 (the wave without a seventh product for NB = 3) of the workgroups that own channel slice 0
+  const bool do_csum = p.bias_off >= 0 && cis == 0 && wave == 3;
+  float csum[NB];
+#pragma unroll
+  for (int b = 0; b < NB; b++) csum[b] = 0.f;
+
   int buf = 0;
   if (split < p.nchunk) issue(split, 0);
   for (int c = split; c < p.nchunk; c += p.splits) {
@@ -171,10 +190,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_s_barrier();                   // chunk c has landed everywhere; every wave is done with the other buffer
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
-    w3_kstep<NB, WC, 0>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra);
-    w3_kstep<NB, WC, 1>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra);
-    w3_kstep<NB, WC, 2>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra);
-    w3_kstep<NB, WC, 3>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra);
+    w3_kstep<NB, WC, 0>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra, csum, do_csum);
+    w3_kstep<NB, WC, 1>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra, csum, do_csum);
+    w3_kstep<NB, WC, 2>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra, csum, do_csum);
+    w3_kstep<NB, WC, 3>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, relu_bound, extra, csum, do_csum);
     buf ^= 1;
   }
 
@@ -193,6 +212,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
   for (int b = 0; b < NB; b++) { store(acc[b], t0, b); store(acc[NB + b], t1, b); }
   if (extra) store(acc[2 * NB], 8, wave);
+  if (do_csum) {
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      const float t = csum[b] + __shfl_xor(csum[b], 32, 64);        // the two k-halves of the wave hold different pixels of the same cout
+      if (lane < 32) out[p.bias_off + co0 + b * 32 + lane] = t * p.bias_scale;
+    }
+  }
 }
 
 template <int NB, int WC>

@@ -78,7 +78,9 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
 
 
 def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, pad_w=0, x_flags=0, g_flags=0, alpha=1.0,
-                     alpha_ptr=None, splits=0, no_tr=0, ldg=None, dy_coff=0):
+                     alpha_ptr=None, splits=0, no_tr=0, ldg=None, dy_coff=0, dbias=None):
+    """dw += alpha * wgrad(x, dy). dbias (fp32 [Cout], optional): asks the launch to add the bias gradient (column sums of the stored dy)
+    as well; returns True when it did (halo kernel), False when the caller still has to run sg_colsum."""
     d = L.ConvWgradDesc()
     d.dtype = L.dt(x)
     d.N = x.shape[0]
@@ -90,6 +92,12 @@ def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, 
     d.x, d.dy, d.dw = L.ptr(x), L.ptr(dy) + dy_coff * dy.element_size(), dw_ptr
     d.alpha_ptr = L.ptr(alpha_ptr)
     d.splits, d.no_tr = splits, no_tr
+    fused = False
+    if dbias is not None:
+        d.dbias = L.ptr(dbias)
+        fused = L.lib().sg_conv2d_wgrad_fuses_bias(L.C.byref(d)) == 1
+        if not fused:
+            d.dbias = None
     sp, wf = L.C.c_int(0), L.C.c_longlong(0)
     L.call("sg_conv2d_wgrad_plan", d, L.C.byref(sp), L.C.byref(wf))
     work = None
@@ -97,6 +105,7 @@ def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, 
         work = torch.empty(wf.value, dtype=torch.float32, device=x.device)   # scratch of the deterministic two-stage split-K
         d.splits, d.work, d.work_floats = sp.value, work.data_ptr(), wf.value
     L.call("sg_conv2d_wgrad", d, L.stream())
+    return fused
 
 
 def gemm_raw(dtype, p, p_form, ldp, q, q_form, ldq, out, ldo, I, J, K, batch=1, p_bs=0, q_bs=0, out_bs=0, bias=None, res=None,
@@ -321,11 +330,16 @@ class ConvFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(dy, x, rt, slot, cfg)
+        want_db = ctx.bias is not None and ctx.needs_input_grad[2]
+        db_done = False
         if ctx.needs_input_grad[1]:
             xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
             gf = L.PIX_UPSAMPLE if pool else 0
-            conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w, xf, gf, alpha=scale)
-        if ctx.bias is not None and ctx.needs_input_grad[2]:
+            # the halo weight-gradient kernel holds the dy fragments anyway: the bias gradient rides along (no separate pass over dy)
+            g = ensure_grad(ctx.bias) if (want_db and rt.rows_pad == rt.rows) else None
+            db_done = conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w, xf, gf,
+                                       alpha=scale, dbias=g)
+        if want_db and not db_done:
             g = ensure_grad(ctx.bias)
             rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
             L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())

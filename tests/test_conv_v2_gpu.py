@@ -370,6 +370,17 @@ def test_wgrad_v3_matches_reference_and_v2(sg, case):
         F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, alpha_ptr=sig, splits=3)
         torch.cuda.synchronize()
         check(f"wgrad v3={mode} accumulate {case}", dw.cpu().permute(0, 3, 1, 2), 1.7 * wr.grad, 2e-3)
+        # bias gradient riding along (column sums of the STORED dy -- the pooled one is read four times and scaled back), accumulating
+        db = torch.full((Cout,), 0.5, dtype=torch.float32, device=d)
+        dw2 = torch.zeros((Cout, R, R, Cin), dtype=torch.float32, device=d)
+        fused = F.conv2d_wgrad_raw(xd, gyd, dw2.data_ptr(), Cin, Cout, R, R, Ho, Ho, 1, pad, pad, xf, gf, alpha=0.25 if pool else 1.0, dbias=db)
+        torch.cuda.synchronize()
+        assert fused == (mode == "force")
+        if fused:
+            check(f"wgrad v3 fused bias gradient {case}", db.cpu().double(), 0.5 + gy.double().sum((0, 2, 3)), 2e-3)
+            check(f"wgrad v3 with bias: dw {case}", dw2.cpu(), outs[(mode, 0)], 1e-6)
+        else:
+            assert torch.equal(db.cpu(), torch.full((Cout,), 0.5))
     os.environ.pop("SG_WGRAD_V3", None)
     check(f"wgrad v3 vs v2 {case}", outs[("force", 0)], outs[("0", 0)], 1e-4)
     check(f"wgrad v3 split counts {case}", outs[("force", 0)], outs[("force", 3)], 1e-4)
