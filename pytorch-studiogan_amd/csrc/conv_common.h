@@ -29,3 +29,4 @@ static void fill_geom(PixGeom<T>& g, const void* x, int N, int Hs, int Ws, int C
 // the bf16 fast paths living in their own translation units; false = not eligible (the caller falls through to the next engine)
 bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);
 bool sg_conv_fwd_sk_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);
+bool sg_conv_fwd_v4_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);

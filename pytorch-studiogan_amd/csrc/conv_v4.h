@@ -1,0 +1,226 @@
+// conv_v4.h -- halo forward / data-gradient kernel for the SHORT-K 3x3 layers (bf16, stride 1, pad 1, C % 32 == 0): three small
+// independent workgroups per CU instead of one large one.
+//
+// conv_v3.h runs ONE 125-150 KB workgroup of 8 waves per CU. On the deep layers (K = 9 C >= 3456) a tile is hundreds of taps long and
+// its fixed costs vanish; on the 96-channel 128^2 layers a 512-pixel tile is 18 taps against a 100 KB patch prologue, a second patch
+// load between its two channel slices and a 98 KB staged epilogue, and with one workgroup per CU nothing overlaps them: 680-840 TFLOP/s
+// (profiles/r02_conv_layer_table_f.txt), 670 even with the loop's DMA removed (profiles/r01_conv_v3_ablation_dma.txt). wgrad_v3.h
+// fixed the same problem for the weight gradient by making workgroups small enough that three share a CU; this is the same move:
+//   * tile = 256 output pixels x 32 NB couts (NB = 3 or 2); 4 waves, wave w = pixels 64 w .. 64 w + 63 x all couts (2 x NB accumulators
+//     of 32 x 32 = 96 registers for NB = 3): <= 168 registers per lane;
+//   * the pixel operand is staged once per 32-CHANNEL slice as a raster patch ([tile + one image row + 8 pixels either side] x 64 B,
+//     chunk swizzle c ^ (row >> 2 & 3): any 16 consecutive rows are conflict-free for ds_read_b128), 33 KB at W = 128; the nine taps
+//     read it at shifted rows exactly like conv_v3.h; weights stream per tap: 32 NB x 64 B, two buffers;
+//   * operand LDS 46 KB, staged epilogue 53 KB -> three workgroups per CU (12 waves, 3 per SIMD, from different workgroups: one
+//     computes while another loads its patch or stores its tile). One barrier (4 waves) per tap = per 4 NB MFMAs of a wave.
+// Row bookkeeping (raster / quad order, nearest x2 upsample on load, image-border masks) is conv_v3.h's; epilogue: sg_conv_epilogue.
+#pragma once
+#include "conv_v2.h"
+
+struct ConvV4Params {
+  const bf16_t* x; const bf16_t* w;
+  int W, wlog;            // source image width (power of two >= 4)
+  int C, ldx;
+  int Ho, Wo, wshift, hshift;
+  int flags;
+  int I, J, K;
+  int nslice;             // C / 32
+  int npix_src;           // N * Hs * Ws
+  int npx;                // patch pixels (multiple of 16) >= BJ(/4 with upsample) + 2 W + 16
+  unsigned xbytes, wbytes;
+  int wgt_off, zero_off, bias_off;   // LDS byte offsets: weight buffers, zero line, bias vector
+};
+
+template <int NB, bool RELU, bool UP>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int BI = 32 * NB, BJ = 256, NW = 4, TI = NB, TJ = 2;
+  constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
+  constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = tilesI * tilesJ;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int tI = bid % tilesI, tJ = bid / tilesI;
+  const int i0 = tI * BI, j0 = tJ * BJ;
+  char* const pbufs = smem + p.wgt_off;
+  float* sbias = (float*)(smem + p.bias_off);
+  if (epi.bias) {
+    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+  }
+  if (tid < 32) ((unsigned*)(smem + p.zero_off))[tid] = 0u;
+
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+  // DMA piece = 1 KiB = 16 rows x 64 B, LDS linear in lane order: lane -> (row sub = lane >> 2, physical chunk lane & 3); the logical
+  // 16-byte chunk it fetches is the swizzle inverse: lc = (lane & 3) ^ (row >> 2 & 3), and row = 16 g + sub gives (sub >> 2) & 3.
+  const int sub = lane >> 2;
+  const int lc = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned ldx2 = 2u * (unsigned)p.ldx;
+
+  // ---- patch DMA: groups of 16 consecutive source pixels, group g = wave + 4 i ----------------------------------------------------
+  const int P0 = (UP ? (j0 >> 2) : j0) - p.W - 8;                    // raster index of patch row 0
+  const int ngroups = p.npx >> 4;
+  const int pix0 = P0 + 16 * wave + sub;
+  auto patch_slice = [&](int s) {
+    for (int g = wave; g < ngroups; g += NW) {
+      const int pix = pix0 + 16 * (g - wave);
+      unsigned off = (unsigned)pix * ldx2 + (unsigned)(s * 64 + lc * 16);
+      off = ((unsigned)pix < (unsigned)p.npix_src) ? off : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+  // ---- weight DMA: BI rows x 32 channels of (slice s, tap t) ----------------------------------------------------------------------
+  auto weight_tile = [&](int buf, int s, int t) {
+    for (int g = wave; g < NWP; g += NW) {
+      const int row = i0 + 16 * g + sub;
+      unsigned off = ((unsigned)row * (unsigned)p.K + (unsigned)(t * p.C + s * 32 + lc * 8)) * 2u;
+      off = (row < p.I) ? off : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment rows of this lane (conv_v3.h's bookkeeping) ------------------------------------------------------------------------
+  const int wj0 = wave * 64;
+  const int frow = lane & 31, fhi = lane >> 5;
+  int rb[TJ];             // patch row of the centre pixel
+  unsigned qinv[TJ];      // bit t set = tap t reads outside the image (or the row is outside the problem)
+  int rs0[TJ], rs2[TJ], cs0[TJ], cs2[TJ];
+#pragma unroll
+  for (int b = 0; b < TJ; b++) {
+    const int row = j0 + wj0 + b * 32 + frow;
+    int n, ho, wo;
+    if (p.flags & SG_PIX_QUAD) {
+      const int q = row >> 2, dy = (row >> 1) & 1, dx = row & 1;
+      const int wq = q & ((p.Wo >> 1) - 1);
+      const int t = q >> (p.wshift - 1);
+      const int hq = t & ((p.Ho >> 1) - 1);
+      n = t >> (p.hshift - 1);
+      ho = 2 * hq + dy; wo = 2 * wq + dx;
+    } else {
+      wo = row & (p.Wo - 1); const int t = row >> p.wshift; ho = t & (p.Ho - 1); n = t >> p.hshift;
+    }
+    unsigned m = 0;
+    if (row < p.J) {
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++)
+          if ((unsigned)(ho - 1 + rr) < (unsigned)p.Ho && (unsigned)(wo - 1 + ss) < (unsigned)p.Wo) m |= 1u << (rr * 3 + ss);
+    }
+    qinv[b] = ~m;
+    if (UP) {
+      const int Hs = p.Ho >> 1;
+      const int spc = ((n * Hs + (ho >> 1)) << p.wlog) + (wo >> 1);
+      rb[b] = spc - P0;
+      rs0[b] = (ho & 1) ? 0 : -p.W; rs2[b] = (ho & 1) ? p.W : 0;
+      cs0[b] = (wo & 1) ? 0 : -1;  cs2[b] = (wo & 1) ? 1 : 0;
+    } else {
+      rb[b] = (((n << p.hshift) + ho) << p.wshift) + wo - P0;
+      rs0[b] = -p.W; rs2[b] = p.W; cs0[b] = -1; cs2[b] = 1;
+    }
+  }
+  // weight fragment addresses: row = cout a * 32 + frow, chunk (ks * 2 + fhi) ^ (row >> 2 & 3); ks = 1 is the address ^ 32
+  unsigned wa[TI];
+#pragma unroll
+  for (int a = 0; a < TI; a++) {
+    const int row = a * 32 + frow;
+    wa[a] = (unsigned)(row * 64 + ((fhi ^ ((row >> 2) & 3)) << 4));
+  }
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; a++)
+#pragma unroll
+    for (int b = 0; b < TJ; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  const int nslice = p.nslice;
+  for (int s = 0; s < nslice; s++) {
+    // every wave is past the last tap of the previous slice (barrier below): the patch and weight buffer 0 may be overwritten
+    patch_slice(s);
+    weight_tile(0, s, 0);
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 9; t++) {
+      if (t < 8) weight_tile((t + 1) & 1, s, t + 1);            // next tap's weights land during this tap
+      const char* ps = pbufs + (t & 1) * PB;
+      const int tr = t / 3, ts = t % 3;                          // compile-time after unrolling
+      unsigned qa[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        int row = rb[b];
+        if (tr == 0) row += rs0[b];
+        if (tr == 2) row += rs2[b];
+        if (ts == 0) row += cs0[b];
+        if (ts == 2) row += cs2[b];
+        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
+        a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
+        qa[b] = a;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8_t pf[TI], qf[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          u32x4 v = *(const u32x4*)(ps + (wa[a] ^ (unsigned)(ks * 32)));
+          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+      __syncthreads();                                           // next tap's weights are complete; this tap's buffer is free
+    }
+  }
+
+  float al = epi.alpha;
+  if (epi.alpha_ptr) al *= *epi.alpha_ptr;
+  sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+}
+
+// LDS need (bytes) of a configuration
+static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off) {
+  const int BI = 32 * NB;
+  const int ops = npx * 64 + 2 * BI * 64;
+  const int stage = 256 * (BI * 2 + 16);
+  const int body = ops > stage ? ops : stage;
+  if (wgt_off) *wgt_off = npx * 64;
+  if (zero_off) *zero_off = body;
+  if (bias_off) *bias_off = body + 128;
+  return body + 128 + BI * 4;
+}
+template <int NB, bool RELU, bool UP>
+static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
+  if (lds > 64 * 1024) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  const int BI = 32 * NB;
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + 255) / 256;
+  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
+  return 0;
+}
+template <int NB>
+static inline int sg_launch_conv_v4(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, relu = (p.flags & SG_PIX_RELU) != 0;
+  if (relu) return up ? sg_launch_conv_v4r<NB, true, true>(p, e, st) : sg_launch_conv_v4r<NB, true, false>(p, e, st);
+  return up ? sg_launch_conv_v4r<NB, false, true>(p, e, st) : sg_launch_conv_v4r<NB, false, false>(p, e, st);
+}

@@ -111,6 +111,7 @@ def test_conv_v3_matches_reference_and_v2(sg, case):
     pf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
     ef = L.EPI_POOL if pool else 0
     outs = {}
+    os.environ["SG_CONV_V4"] = "0"                     # (conv_v4.h would take some of these shapes first)
     for name, v3, v2 in (("v3", "force", "force"), ("v2", "0", "force")):
         os.environ["SG_CONV_V3"], os.environ["SG_CONV_V2"] = v3, v2
         y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, bias=bias.to(d), res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
@@ -132,6 +133,67 @@ def test_conv_v3_matches_reference_and_v2(sg, case):
         check(f"conv v3 dgrad {case}", nchw(dx.float().cpu())[sel], xr.grad, 4e-3)
     os.environ.pop("SG_CONV_V3", None)
     os.environ.pop("SG_CONV_V2", None)
+    os.environ.pop("SG_CONV_V4", None)
+
+
+V4_CASES = [
+    # N, Cin, Cout, H(in), relu, up, pool      -- 3x3, pad 1 (csrc/conv_v4.h: small-workgroup halo kernel, 32-channel slices)
+    (2, 96, 96, 16, False, False, False),       # raster rows, three slices, one cout tile
+    (2, 96, 192, 16, True, False, True),        # quad rows (pooling epilogue), ReLU on load, two cout tiles
+    (1, 192, 96, 16, True, True, False),        # nearest x2 upsample on load (G block conv1), six slices
+    (2, 64, 128, 8, False, True, True),         # NB = 2 (64-wide cout tiles), upsample + pooling
+    (8, 32, 64, 8, False, False, False),        # 8x8 images: a tile spans four images; one slice
+    (5, 64, 96, 8, True, False, False),         # J = 320: partial last tile
+    (4, 96, 96, 128, True, False, True),        # W = 128: the tile is one pair of image rows (D's first block, pooled)
+    (4, 96, 96, 128, False, False, False),      # W = 128 raster
+    (2, 192, 96, 64, True, True, False),        # 192 -> 96 up @128^2 (G's last block)
+    (16, 64, 96, 4, True, False, False),        # 4x4 images: a 256-pixel tile spans 16 images
+    (2, 384, 192, 8, True, False, False),       # twelve slices (a deep layer through the same loop)
+]
+
+
+@pytest.mark.parametrize("case", V4_CASES)
+def test_conv_v4_matches_reference_and_v3(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cin, H, H), dt, 191)
+    w = rnd((Cout, Cin, 3, 3), dt, 192, 0.1)
+    bias = rnd((Cout,), torch.float32, 193)
+    Ho = H * (2 if up else 1)
+    Hy = Ho // 2 if pool else Ho
+    res = rnd((N, Cout, Hy, Hy), dt, 194)
+    big = N * Ho * Ho > 32768
+    sel = [0, N - 1] if big else list(range(N))      # big case: CPU fp64 reference for the first and the last image only
+    yref = _conv_ref(x[sel], w, 1, 1, relu, up, pool, bias, res[sel])
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    ef = L.EPI_POOL if pool else 0
+    outs = {}
+    os.environ["SG_CONV_V3"], os.environ["SG_CONV_V2"] = "force", "force"
+    for name, v4 in (("v4", "all"), ("v3", "0")):
+        os.environ["SG_CONV_V4"] = v4
+        y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, bias=bias.to(d), res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        outs[name] = y.float().cpu()
+    check(f"conv v4 {case}", nchw(outs["v4"])[sel], yref, 4e-3)
+    check(f"conv v4 vs v3 {case}", outs["v4"], outs["v3"], 4e-3)
+    # data gradient through the same kernel (flipped weights; ReLU mask / pooled-gradient broadcast / pooling-sum epilogues)
+    if Cout % 32 == 0 and (Cin % 96 == 0 or Cin % 64 == 0):
+        xr, wr = x[sel].double().requires_grad_(True), w.double()
+        y2 = _conv_ref(xr, wr, 1, 1, relu, up, pool, None, None)
+        gy = rnd((N,) + tuple(y2.shape[1:]), dt, 195)
+        y2.backward(gy[sel].double())
+        wdg = w.flip(2, 3).permute(1, 2, 3, 0).contiguous().to(d)
+        os.environ["SG_CONV_V4"] = "all"
+        dx = F.conv2d_raw(nhwc(gy).to(d), wdg.data_ptr(), Cout, Cin, 3, 3, 1, 1, 1, L.PIX_UPSAMPLE if pool else 0,
+                          L.EPI_POOL if up else 0, mask=xd if relu else None, alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        check(f"conv v4 dgrad {case}", nchw(dx.float().cpu())[sel], xr.grad, 4e-3)
+    os.environ.pop("SG_CONV_V3", None)
+    os.environ.pop("SG_CONV_V2", None)
+    os.environ.pop("SG_CONV_V4", None)
 
 
 SK_CASES = [

@@ -27,7 +27,7 @@ WIDE = ["biggan128w", "sngan32w", "wgangp128w", "bigdeep128w"]
 
 @pytest.fixture
 def forced(monkeypatch):
-    for k in ("SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_WGRAD_BJ256", "SG_WGRAD_V3"):
+    for k in ("SG_CONV_V4", "SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_WGRAD_BJ256", "SG_WGRAD_V3"):
         monkeypatch.setenv(k, "force")
 
 
