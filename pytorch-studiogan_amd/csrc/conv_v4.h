@@ -10,8 +10,8 @@
 //     of 32 x 32 = 96 registers for NB = 3): <= 168 registers per lane;
 //   * the pixel operand is staged once per 32-CHANNEL slice as a raster patch ([tile + one image row + 8 pixels either side] x 64 B,
 //     chunk swizzle c ^ (row >> 2 & 3): any 16 consecutive rows are conflict-free for ds_read_b128), 33 KB at W = 128; the nine taps
-//     read it at shifted rows exactly like conv_v3.h; weights stream per tap: 32 NB x 64 B, two buffers;
-//   * operand LDS 46 KB, staged epilogue 53 KB -> three workgroups per CU (12 waves, 3 per SIMD, from different workgroups: one
+//     read it at shifted rows exactly like conv_v3.h; weights stream per tap: 32 NB x 64 B, three buffers, two taps ahead;
+//   * operand LDS 52 KB, staged epilogue 53 KB -> three workgroups per CU (12 waves, 3 per SIMD, from different workgroups: one
 //     computes while another loads its patch or stores its tile). One barrier (4 waves) per tap = per 4 NB MFMAs of a wave.
 // Row bookkeeping (raster / quad order, nearest x2 upsample on load, image-border masks) is conv_v3.h's; epilogue: sg_conv_epilogue.
 #pragma once
@@ -141,16 +141,25 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
 
+  // Weights run TWO taps ahead through three buffers (buffer of tap t = t % 3, 9 taps per slice): a tap is only 4 NB MFMAs per wave,
+  // shorter than the L2 latency of its successor's weights, so the wait in front of the barrier that ends tap t is COUNTED -- it lets
+  // the pieces issued during tap t (for tap t + 2) stay in flight and only requires the older ones (tap t + 1). Waves 0 .. NWP - 5 issue
+  // two pieces per tap, the others one.
   const int nslice = p.nslice;
+  const bool two = wave + NW < NWP;                                  // this wave issues two weight pieces per tap
+  patch_slice(0);
+  weight_tile(0, 0, 0);
+  weight_tile(1, 0, 1);
+  __syncthreads();
   for (int s = 0; s < nslice; s++) {
-    // every wave is past the last tap of the previous slice (barrier below): the patch and weight buffer 0 may be overwritten
-    patch_slice(s);
-    weight_tile(0, s, 0);
-    __syncthreads();
+    const bool next_slice = s + 1 < nslice;
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-      if (t < 8) weight_tile((t + 1) & 1, s, t + 1);            // next tap's weights land during this tap
-      const char* ps = pbufs + (t & 1) * PB;
+      // weights of the tap after next: buffer (t + 2) % 3 = (t - 1) % 3 was read during the previous tap, every wave is past its barrier
+      const bool issue = (t + 2 < 9) || next_slice;
+      if (t + 2 < 9) weight_tile((t + 2) % 3, s, t + 2);
+      else if (next_slice) weight_tile((t + 2) % 3, s + 1, t + 2 - 9);
+      const char* ps = pbufs + (t % 3) * PB;
       const int tr = t / 3, ts = t % 3;                          // compile-time after unrolling
       unsigned qa[TJ];
 #pragma unroll
@@ -184,7 +193,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
-      __syncthreads();                                           // next tap's weights are complete; this tap's buffer is free
+      if (t == 8 && next_slice) {
+        // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
+        // workgroup; the other two workgroups of the CU keep the matrix pipe busy)
+        __syncthreads();
+        patch_slice(s + 1);
+        __syncthreads();
+      } else {
+        if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
     }
   }
 
@@ -196,7 +216,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 // LDS need (bytes) of a configuration
 static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off) {
   const int BI = 32 * NB;
-  const int ops = npx * 64 + 2 * BI * 64;
+  const int ops = npx * 64 + 3 * BI * 64;
   const int stage = 256 * (BI * 2 + 16);
   const int body = ops > stage ? ops : stage;
   if (wgt_off) *wgt_off = npx * 64;

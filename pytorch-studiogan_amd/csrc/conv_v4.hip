@@ -3,14 +3,14 @@
 #include "conv_v4.h"
 
 // SG_CONV_V4=0 disables it; =force: no minimum tile count (tests: the kernel a batch-256 problem gets, at small batch); =all: in addition
-// no channel rule (every eligible shape); default: the short-K layers (C <= 192), which conv_v3.h's one-workgroup-per-CU tiles serve worst.
+// no channel rule (every eligible shape); default: the short-K layers (C <= 384), which conv_v3.h's one-workgroup-per-CU tiles serve worst.
 bool sg_conv_fwd_v4_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
   const char* mode = getenv("SG_CONV_V4");
   if (mode && mode[0] == '0') return false;
   const bool all = mode && mode[0] == 'a', force = all || (mode && mode[0] == 'f');
   if (d->stride != 1 || (pflags & SG_PIX_TRANSPOSED) || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return false;
   if (d->C < 32 || d->C % 32 || d->ldx % 8 || !aligned16(d->x) || !aligned16(d->w)) return false;
-  if (!all && d->C > 192) return false;
+  if (!all && d->C > 384) return false;
   const bool up = (pflags & SG_PIX_UPSAMPLE) != 0, quad = (pflags & SG_PIX_QUAD) != 0;
   if (d->Ho != d->Hs * (up ? 2 : 1) || d->Wo != d->Ws * (up ? 2 : 1)) return false;
   const int wshift = ilog2_exact(d->Wo), hshift = ilog2_exact(d->Ho);

@@ -178,7 +178,7 @@ def test_conv_v4_matches_reference_and_v3(sg, case):
         torch.cuda.synchronize()
         outs[name] = y.float().cpu()
     check(f"conv v4 {case}", nchw(outs["v4"])[sel], yref, 4e-3)
-    check(f"conv v4 vs v3 {case}", outs["v4"], outs["v3"], 4e-3)
+    check(f"conv v4 vs v3 {case}", outs["v4"], outs["v3"], 6e-3)       # two bf16-rounded results, each within 4e-3 of fp64
     # data gradient through the same kernel (flipped weights; ReLU mask / pooled-gradient broadcast / pooling-sum epilogues)
     if Cout % 32 == 0 and (Cin % 96 == 0 or Cin % 64 == 0):
         xr, wr = x[sel].double().requires_grad_(True), w.double()
