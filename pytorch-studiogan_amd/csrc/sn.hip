@@ -139,26 +139,67 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(cons
   const sg_sn_layer l = L[blockIdx.y];
   const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;
   const float sig = l.sigma[0];
+  const float inv = 1.f / sig;
+  const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin, colsp = l.RS * cp;
+  // fast path (round 2): 16-byte global accesses on both sides and no per-element division -- the read side takes 4 fp32 per lane,
+  // the write side 8 outputs of one tap (cp % 8 == 0: eight consecutive image elements share their tap), gathered from the LDS row
+  const bool vec = !l.trans && (l.cols % 4 == 0) && (cp % 8 == 0) && sizeof(T) == 2 && ((reinterpret_cast<uintptr_t>(l.w) & 15) == 0) &&
+                   (!l.w_f32 || (reinterpret_cast<uintptr_t>(l.w_f32) & 15) == 0) && (!l.w_fwd || (reinterpret_cast<uintptr_t>(l.w_fwd) & 15) == 0);
   for (int o = blockIdx.x; o < rows_out; o += gridDim.x) {
-    for (int k = threadIdx.x; k < l.cols; k += 256) {
-      float val = 0.f;
-      if (o < l.rows) {
-        val = l.w[sn_widx(l, o, k)] / sig;
-        if (l.w_f32) l.w_f32[(long long)o * l.cols + k] = val;
+    if (vec) {
+      const float* src = l.w + (long long)o * l.cols;
+      for (int k = threadIdx.x * 4; k < l.cols; k += 1024) {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (o < l.rows) {
+          v = *(const f32x4*)(src + k);
+          // same operation as the scalar path (a division, not a multiplication by the reciprocal: bit-identical images)
+          v[0] = v[0] / sig; v[1] = v[1] / sig; v[2] = v[2] / sig; v[3] = v[3] / sig;
+          if (l.w_f32) *(f32x4*)(l.w_f32 + (long long)o * l.cols + k) = v;
+        }
+        u32x2 pk = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+        *(u32x2*)((bf16_t*)row + k) = pk;
       }
-      row[k] = from_f<T>(val);
+    } else {
+      for (int k = threadIdx.x; k < l.cols; k += 256) {
+        float val = 0.f;
+        if (o < l.rows) {
+          val = l.w[sn_widx(l, o, k)] / sig;
+          if (l.w_f32) l.w_f32[(long long)o * l.cols + k] = val;
+        }
+        row[k] = from_f<T>(val);
+      }
     }
     __syncthreads();
     if (l.w_fwd) {
-      const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin, colsp = l.RS * cp;
       T* dst = (T*)l.w_fwd + (long long)o * colsp;
-      for (int j = threadIdx.x; j < colsp; j += 256) {
-        const int rs = j / cp, c = j - rs * cp;
-        dst[j] = c < l.Cin ? row[c * l.RS + rs] : from_f<T>(0.f);
+      if (vec) {
+        const bf16_t* r16 = (const bf16_t*)row;
+        int j = threadIdx.x * 8;
+        int rs = j / cp, c = j - rs * cp;
+        const int drs = 2048 / cp, dc = 2048 - drs * cp;
+        for (; j < colsp; j += 2048) {
+          uint32_t w4[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) {
+            const int c0 = c + 2 * i;
+            const uint32_t lo = c0 < l.Cin ? r16[c0 * l.RS + rs] : 0u, hi = c0 + 1 < l.Cin ? r16[(c0 + 1) * l.RS + rs] : 0u;
+            w4[i] = lo | (hi << 16);
+          }
+          u32x4 v = {w4[0], w4[1], w4[2], w4[3]};
+          *(u32x4*)((bf16_t*)dst + j) = v;
+          c += dc; rs += drs;
+          if (c >= cp) { c -= cp; rs++; }
+        }
+      } else {
+        for (int j = threadIdx.x; j < colsp; j += 256) {
+          const int rs = j / cp, c = j - rs * cp;
+          dst[j] = c < l.Cin ? row[c * l.RS + rs] : from_f<T>(0.f);
+        }
       }
     }
     __syncthreads();
   }
+  (void)inv;
 }
 template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(const sg_sn_layer* L) {
   __shared__ T tile[64][130];
@@ -249,11 +290,91 @@ __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int
   if (l.natural == 2) return ((long long)c * l.RS + rs) * l.rows + o;   // [Cin][R][S][Cout]: weight gradient of a transposed conv
   return ((long long)o * l.RS + rs) * (l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin) + c;
 }
+// ---- row kernels (round 2) ---------------------------------------------------------------------------------------------------
+// k_snb_dot / k_snb_apply walk a flat element index with a 64-bit division per element and fetch the two layouts of a weight
+// ([o][rs][c] image of the gradient, [o][c][rs] master) with 36-byte-strided gathers: 0.9 / 1.8 TB/s in the r02 trace (388 + 398 us per
+// D backward). Here a block owns whole rows: the gradient row is read contiguously (16 bytes per lane) into LDS as [rs][c] at a pitch
+// = 8 (mod 32) floats, then walked in the master's order -- LDS reads at <= 3-way conflicts, global reads / read-modify-writes contiguous,
+// (c, rs) advanced incrementally. Rows with natural layout skip the staging. Layers whose row does not fit (or transposed-convolution
+// weights) stay with the old kernels.
+#define SNB_ROW_LDS_FLOATS 15872   // 62 KiB
+__host__ __device__ __forceinline__ int snb_pitch(int cp) { return cp + ((8 - (cp & 31)) + 32) % 32; }
+__host__ __device__ __forceinline__ bool snb_row_ok(const sg_sn_bwd_layer& l) {
+  if (l.trans) return false;
+  if (l.natural == 1) return true;
+  if (l.natural != 0) return false;
+  const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
+  return (cp % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.dwt) & 15) == 0) && l.RS * snb_pitch(cp) <= SNB_ROW_LDS_FLOATS;
+}
+// grid (SNB_BLOCKS, layers); APPLY = false: block partials of <dWt, W> into work; true: dw += (dWt - coef u v^T) / sigma
+template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg_sn_bwd_layer* L, float* work) {
+  extern __shared__ __attribute__((aligned(16))) float snb_row[];
+  __shared__ float sm[4];
+  __shared__ float coef_sm;
+  const sg_sn_bwd_layer l = L[blockIdx.y];
+  if (!snb_row_ok(l)) return;
+  if (!APPLY && !l.apply_sn) return;
+  float sig = 1.f, coef = 0.f;
+  if (APPLY && l.apply_sn) {
+    sig = l.sigma[0];
+    if (threadIdx.x < 64) {      // fixed-order sum of the block partials (every block computes the same value)
+      float t = 0.f;
+      for (int b = threadIdx.x; b < SNB_BLOCKS; b += 64) t += work[(long long)blockIdx.y * SNB_BLOCKS + b];
+      t = wave_sum(t);
+      if (threadIdx.x == 0) coef_sm = t;
+    }
+    __syncthreads();
+    coef = coef_sm / sig;        // <dWt, W/sigma>
+  }
+  const float inv = 1.f / sig;
+  const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
+  const int st = snb_pitch(cp);
+  const int RS = l.RS, cols = l.cols;
+  const int rowlen = RS * cp;                                   // floats of a gradient row in image layout
+  // per-thread walk of the master order k = c RS + rs, k += 256
+  const int c_init = threadIdx.x / RS, rs_init = threadIdx.x - c_init * RS;
+  const int dc = 256 / RS, drs = 256 - dc * RS;
+  // per-thread walk of the image order j = rs cp + c (4 floats per step), j += 1024
+  const int j_init = threadIdx.x * 4;
+  const int rs2_init = j_init / cp, c2_init = j_init - rs2_init * cp;
+  const int drs2 = 1024 / cp, dc2 = 1024 - drs2 * cp;
+  float acc = 0.f;
+  for (int o = blockIdx.x; o < l.rows; o += gridDim.x) {
+    const float* wrow = l.w + (long long)o * cols;
+    if (l.natural == 0) {
+      const float* grow = l.dwt + (long long)o * rowlen;
+      int rs = rs2_init, c = c2_init;
+      for (int j = j_init; j < rowlen; j += 1024) {
+        const f32x4 v = *(const f32x4*)(grow + j);
+        *(f32x4*)(snb_row + rs * st + c) = v;
+        c += dc2; rs += drs2;
+        if (c >= cp) { c -= cp; rs++; }
+      }
+      __syncthreads();
+    }
+    const float* gnat = l.dwt + (long long)o * cols;             // natural == 1
+    const float uo = (APPLY && l.apply_sn) ? l.u[o] * coef : 0.f;
+    float* drow = APPLY ? l.dw + (long long)o * cols : nullptr;
+    int c = c_init, rs = rs_init;
+    for (int k = threadIdx.x; k < cols; k += 256) {
+      const float g = l.natural == 0 ? snb_row[rs * st + c] : gnat[k];
+      if (APPLY) drow[k] += l.apply_sn ? (g - uo * l.v[k]) * inv : g;
+      else acc += g * wrow[k];
+      c += dc; rs += drs;
+      if (rs >= RS) { rs -= RS; c++; }
+    }
+    if (l.natural == 0) __syncthreads();
+  }
+  if (!APPLY) {
+    acc = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
+  }
+}
 // grid (SNB_BLOCKS, layers): block partials of <dWt, W>
 __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float* work) {
   __shared__ float sm[4];
   const sg_sn_bwd_layer l = L[blockIdx.y];
-  if (!l.apply_sn) return;
+  if (!l.apply_sn || snb_row_ok(l)) return;
   const long long total = (long long)l.rows * l.cols;
   float acc = 0.f;
   const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
@@ -276,6 +397,7 @@ __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float
 // grid (tiles, layers)
 __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, const float* work) {
   const sg_sn_bwd_layer l = L[blockIdx.y];
+  if (snb_row_ok(l)) return;
   const long long total = (long long)l.rows * l.cols;
   float sig = 1.f, coef = 0.f;
   if (l.apply_sn) {
@@ -316,9 +438,27 @@ extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd
   double bytes = 0.0;      // dot: dWt + W; apply: dWt + read-modify-write of dW
   for (int i = 0; i < n; i++) bytes += (double)layers_host[i].rows * layers_host[i].cols * 4.0 * ((layers_host[i].apply_sn ? 2 : 0) + 3);
   SgProfScope prof(st, bytes, 3);
-  if (any_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
-  long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
-  hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);
+  bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false; int row_lds = 0;
+  for (int i = 0; i < n; i++) {
+    const sg_sn_bwd_layer& l = layers_host[i];
+    if (snb_row_ok(l)) {
+      any_row = true; if (l.apply_sn) any_row_sn = true;
+      if (l.natural == 0) { const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin; const int need = l.RS * snb_pitch(cp) * 4; if (need > row_lds) row_lds = need; }
+    } else { any_old = true; if (l.apply_sn) any_old_sn = true; }
+  }
+  static bool attr_done = false;
+  if (any_row && !attr_done) {
+    SG_CHECK(hipFuncSetAttribute((const void*)k_snb_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SNB_ROW_LDS_FLOATS * 4) == hipSuccess &&
+             hipFuncSetAttribute((const void*)k_snb_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SNB_ROW_LDS_FLOATS * 4) == hipSuccess, "sg_sn_backward: LDS attribute");
+    attr_done = true;
+  }
+  if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
+  if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, n), dim3(256), row_lds, st, layers_dev, work);
+  if (any_old) {
+    long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+    hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);
+  }
+  if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, n), dim3(256), row_lds, st, layers_dev, work);
   SG_LAUNCH_CHECK();
   return 0;
 }
