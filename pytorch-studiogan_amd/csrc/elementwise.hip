@@ -115,9 +115,64 @@ template <typename T> __global__ void k_maxpool2_fwd(const T* x, int ldx, T* y, 
     if (idx) idx[i] = (uint8_t)a;
   }
 }
+// bf16, C % 8 == 0, 16-byte aligned rows: a thread owns 8 channels of one output pixel -- four 16-byte loads, one 16-byte store, 8 index
+// bytes; 32-bit index arithmetic (the scalar kernel: 2 bytes per thread and four 64-bit divisions per element, 0.9 + 1.6 ms per step)
+__global__ __launch_bounds__(256) void k_maxpool2_fwd_v8(const bf16_t* x, int ldx, bf16_t* y, int ldy, uint8_t* idx, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2, CV = C / 8;
+  const unsigned total = (unsigned)N * H2 * W2 * CV;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned q = i / CV, cv = i - q * CV;
+    const unsigned w2 = q % W2, t = q / W2, h2 = t % H2, n = t / H2;
+    const bf16_t* p = x + (((long long)n * H + 2 * h2) * W + 2 * w2) * ldx + cv * 8;
+    const u32x4 r0 = *(const u32x4*)p, r1 = *(const u32x4*)(p + ldx), r2 = *(const u32x4*)(p + (long long)W * ldx), r3 = *(const u32x4*)(p + (long long)W * ldx + ldx);
+    float v0[8], v1[8], v2[8], v3[8], m[8];
+    unpack16<bf16_t>(r0, v0); unpack16<bf16_t>(r1, v1); unpack16<bf16_t>(r2, v2); unpack16<bf16_t>(r3, v3);
+    uint32_t a_lo = 0, a_hi = 0;
+#pragma unroll
+    for (int e = 0; e < 8; e++) {
+      // first maximum in (dy,dx) row-major order wins, like torch's max_pool2d
+      float mm = v0[e]; uint32_t a = 0;
+      if (v1[e] > mm) { mm = v1[e]; a = 1; }
+      if (v2[e] > mm) { mm = v2[e]; a = 2; }
+      if (v3[e] > mm) { mm = v3[e]; a = 3; }
+      m[e] = mm;
+      if (e < 4) a_lo |= a << (8 * e); else a_hi |= a << (8 * (e - 4));
+    }
+    *(u32x4*)(y + (long long)q * ldy + cv * 8) = pack16<bf16_t>(m);
+    if (idx) { u32x2 av = {a_lo, a_hi}; *(u32x2*)(idx + (long long)q * C + cv * 8) = av; }
+  }
+}
+__global__ __launch_bounds__(256) void k_maxpool2_bwd_v8(const bf16_t* dy, int ldy, const uint8_t* idx, bf16_t* dx, int ldx, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2, CV = C / 8;
+  const unsigned total = (unsigned)N * H * W * CV;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned pix = i / CV, cv = i - pix * CV;
+    const unsigned w = pix % W, t = pix / W, h = t % H, n = t / H;
+    const long long q = ((long long)n * H2 + (h >> 1)) * W2 + (w >> 1);
+    const uint32_t pos = ((h & 1) << 1) | (w & 1);
+    const u32x2 av = *(const u32x2*)(idx + q * C + cv * 8);
+    const u32x4 g = *(const u32x4*)(dy + q * ldy + cv * 8);
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; d++) {
+      const uint32_t a0 = ((d < 2 ? av[0] : av[1]) >> (16 * (d & 1))) & 0xffu, a1 = ((d < 2 ? av[0] : av[1]) >> (16 * (d & 1) + 8)) & 0xffu;
+      o[d] = (a0 == pos ? (g[d] & 0xffffu) : 0u) | (a1 == pos ? (g[d] & 0xffff0000u) : 0u);
+    }
+    *(u32x4*)(dx + (long long)pix * ldx + cv * 8) = o;
+  }
+}
+static inline bool pool_v8_ok(int dtype, const void* a, int lda, const void* b, int ldb, const void* idx, int C, long long total_vec) {
+  return dtype == SG_DTYPE_BF16 && C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0 && (((uintptr_t)idx) & 7) == 0 &&
+         total_vec < (1ll << 31);
+}
 extern "C" int sg_maxpool2_fwd(int dtype, const void* x, int ldx, void* y, int ldy, uint8_t* idx, int N, int H, int W, int C, sg_stream_t s) {
   SG_CHECK(x && y && H % 2 == 0 && W % 2 == 0, "sg_maxpool2_fwd: bad args");
   long long total = (long long)N * (H / 2) * (W / 2) * C;
+  if (pool_v8_ok(dtype, x, ldx, y, ldy, idx, C, total / 8)) {
+    hipLaunchKernelGGL(k_maxpool2_fwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, idx, N, H, W, C);
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool2_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, ldx, (T*)y, ldy, idx, N, H, W, C));
   SG_LAUNCH_CHECK();
   return 0;
@@ -136,6 +191,11 @@ template <typename T> __global__ void k_maxpool2_bwd(const T* dy, int ldy, const
 extern "C" int sg_maxpool2_bwd(int dtype, const void* dy, int ldy, const uint8_t* idx, void* dx, int ldx, int N, int H, int W, int C, sg_stream_t s) {
   SG_CHECK(dy && dx && idx, "sg_maxpool2_bwd: null");
   long long total = (long long)N * H * W * C;
+  if (pool_v8_ok(dtype, dy, ldy, dx, ldx, idx, C, total / 8)) {
+    hipLaunchKernelGGL(k_maxpool2_bwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, ldy, idx, (bf16_t*)dx, ldx, N, H, W, C);
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_maxpool2_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, ldy, idx, (T*)dx, ldx, N, H, W, C));
   SG_LAUNCH_CHECK();
   return 0;
@@ -276,7 +336,20 @@ template <typename T> __global__ __launch_bounds__(256) void k_colsum_stream(con
   float acc[V];
 #pragma unroll
   for (int e = 0; e < V; e++) acc[e] = 0.f;
-  for (long long r = r0 + pl; r < r1; r += lanes_p) {
+  long long r = r0 + pl;                                    // four loads in flight per lane (norm.hip, k_bn_apply_stream); same summation order
+  for (; r + 3ll * lanes_p < r1; r += 4ll * lanes_p) {
+    u32x4 raw[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) raw[i] = *(const u32x4*)(x + (r + (long long)i * lanes_p) * ldx + cv * V);
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      float xv[V];
+      unpack16<T>(raw[i], xv);
+#pragma unroll
+      for (int e = 0; e < V; e++) acc[e] += xv[e];
+    }
+  }
+  for (; r < r1; r += lanes_p) {
     float xv[V];
     unpack16<T>(*(const u32x4*)(x + r * ldx + cv * V), xv);
 #pragma unroll

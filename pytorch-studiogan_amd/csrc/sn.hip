@@ -290,25 +290,27 @@ __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int
   if (l.natural == 2) return ((long long)c * l.RS + rs) * l.rows + o;   // [Cin][R][S][Cout]: weight gradient of a transposed conv
   return ((long long)o * l.RS + rs) * (l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin) + c;
 }
-// ---- row kernels (round 2) ---------------------------------------------------------------------------------------------------
+// ---- tile kernels (round 2) ---------------------------------------------------------------------------------------------------
 // k_snb_dot / k_snb_apply walk a flat element index with a 64-bit division per element and fetch the two layouts of a weight
 // ([o][rs][c] image of the gradient, [o][c][rs] master) with 36-byte-strided gathers: 0.9 / 1.8 TB/s in the r02 trace (388 + 398 us per
-// D backward). Here a block owns whole rows: the gradient row is read contiguously (16 bytes per lane) into LDS as [rs][c] at a pitch
-// = 8 (mod 32) floats, then walked in the master's order -- LDS reads at <= 3-way conflicts, global reads / read-modify-writes contiguous,
-// (c, rs) advanced incrementally. Rows with natural layout skip the staging. Layers whose row does not fit (or transposed-convolution
-// weights) stay with the old kernels.
-#define SNB_ROW_LDS_FLOATS 15872   // 62 KiB
-__host__ __device__ __forceinline__ int snb_pitch(int cp) { return cp + ((8 - (cp & 31)) + 32) % 32; }
+// D backward). Here a work item is (row o, chunk of <= 128 input channels): its RS x 128 gradient values are read as RS contiguous
+// 512-byte runs (16 bytes per lane) into LDS at a pitch = 8 (mod 32) floats, then walked in the master's order -- LDS reads at <= 3-way
+// conflicts, global reads / read-modify-writes of 128 RS contiguous floats, (c, rs) advanced incrementally, 32-bit arithmetic. 9 KB of
+// LDS per block keeps the occupancy of a streaming kernel (a first version staged whole rows: 55 KB, two blocks per CU, SLOWER than
+// the kernels it replaced -- session J). Natural-layout weights (linear, embedding) take the same walk without the staging.
+// Transposed-convolution weights and RS > 16 stay with the old kernels.
+#define SNB_CW 128
+#define SNB_ST 136                                               // 128 + 8: pitch = 8 (mod 32)
 __host__ __device__ __forceinline__ bool snb_row_ok(const sg_sn_bwd_layer& l) {
   if (l.trans) return false;
   if (l.natural == 1) return true;
   if (l.natural != 0) return false;
   const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
-  return (cp % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.dwt) & 15) == 0) && l.RS * snb_pitch(cp) <= SNB_ROW_LDS_FLOATS;
+  return (cp % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.dwt) & 15) == 0) && l.RS <= 16;
 }
 // grid (SNB_BLOCKS, layers); APPLY = false: block partials of <dWt, W> into work; true: dw += (dWt - coef u v^T) / sigma
 template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg_sn_bwd_layer* L, float* work) {
-  extern __shared__ __attribute__((aligned(16))) float snb_row[];
+  __shared__ __attribute__((aligned(16))) float tile[16 * SNB_ST];
   __shared__ float sm[4];
   __shared__ float coef_sm;
   const sg_sn_bwd_layer l = L[blockIdx.y];
@@ -327,43 +329,57 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg
     coef = coef_sm / sig;        // <dWt, W/sigma>
   }
   const float inv = 1.f / sig;
-  const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
-  const int st = snb_pitch(cp);
   const int RS = l.RS, cols = l.cols;
-  const int rowlen = RS * cp;                                   // floats of a gradient row in image layout
-  // per-thread walk of the master order k = c RS + rs, k += 256
-  const int c_init = threadIdx.x / RS, rs_init = threadIdx.x - c_init * RS;
-  const int dc = 256 / RS, drs = 256 - dc * RS;
-  // per-thread walk of the image order j = rs cp + c (4 floats per step), j += 1024
-  const int j_init = threadIdx.x * 4;
-  const int rs2_init = j_init / cp, c2_init = j_init - rs2_init * cp;
-  const int drs2 = 1024 / cp, dc2 = 1024 - drs2 * cp;
   float acc = 0.f;
-  for (int o = blockIdx.x; o < l.rows; o += gridDim.x) {
-    const float* wrow = l.w + (long long)o * cols;
-    if (l.natural == 0) {
-      const float* grow = l.dwt + (long long)o * rowlen;
-      int rs = rs2_init, c = c2_init;
-      for (int j = j_init; j < rowlen; j += 1024) {
-        const f32x4 v = *(const f32x4*)(grow + j);
-        *(f32x4*)(snb_row + rs * st + c) = v;
-        c += dc2; rs += drs2;
-        if (c >= cp) { c -= cp; rs++; }
+  if (l.natural == 1) {
+    // items = (row, chunk of 1024 columns)
+    const int nch = (cols + 1023) / 1024;
+    const int items = l.rows * nch;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+      const int o = it / nch, k0 = (it - o * nch) * 1024;
+      const long long base = (long long)o * cols;
+      const float uo = (APPLY && l.apply_sn) ? l.u[o] * coef : 0.f;
+      for (int k = k0 + threadIdx.x; k < cols && k < k0 + 1024; k += 256) {
+        const float g = l.dwt[base + k];
+        if (APPLY) l.dw[base + k] += l.apply_sn ? (g - uo * l.v[k]) * inv : g;
+        else acc += g * l.w[base + k];
+      }
+    }
+  } else {
+    const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
+    const int nch = (l.Cin + SNB_CW - 1) / SNB_CW;               // chunks of real channels (padding channels carry no gradient)
+    const int items = l.rows * nch;
+    // per-thread walks: master order k' = c RS + rs (k' += 256) and image order j = rs SNB_CW + c (4 floats per step, j += 1024)
+    const int c_init = threadIdx.x / RS, rs_init = threadIdx.x - c_init * RS;
+    const int dc = 256 / RS, drs = 256 - dc * RS;
+    const int j_init = threadIdx.x * 4;
+    const int rs2_init = j_init / SNB_CW, c2_init = j_init - rs2_init * SNB_CW;
+    for (int it = blockIdx.x; it < items; it += gridDim.x) {
+      const int o = it / nch, c0 = (it - o * nch) * SNB_CW;
+      const int cw = (cp - c0 < SNB_CW) ? cp - c0 : SNB_CW;      // stored channels of this chunk (multiple of 4)
+      const int cwr = (l.Cin - c0 < SNB_CW) ? l.Cin - c0 : SNB_CW; // real channels
+      const float* grow = l.dwt + ((long long)o * RS) * cp + c0;
+      {
+        int rs = rs2_init, c = c2_init;
+        for (int j = j_init; j < RS * SNB_CW; j += 1024) {
+          if (c < cw) *(f32x4*)(tile + rs * SNB_ST + c) = *(const f32x4*)(grow + (long long)rs * cp + c);
+          rs += 8;                                               // 1024 / SNB_CW
+        }
+      }
+      __syncthreads();
+      const long long base = (long long)o * cols + (long long)c0 * RS;
+      const float uo = (APPLY && l.apply_sn) ? l.u[o] * coef : 0.f;
+      const int kn = cwr * RS;
+      int c = c_init, rs = rs_init;
+      for (int k = threadIdx.x; k < kn; k += 256) {
+        const float g = tile[rs * SNB_ST + c];
+        if (APPLY) l.dw[base + k] += l.apply_sn ? (g - uo * l.v[c0 * RS + k]) * inv : g;
+        else acc += g * l.w[base + k];
+        c += dc; rs += drs;
+        if (rs >= RS) { rs -= RS; c++; }
       }
       __syncthreads();
     }
-    const float* gnat = l.dwt + (long long)o * cols;             // natural == 1
-    const float uo = (APPLY && l.apply_sn) ? l.u[o] * coef : 0.f;
-    float* drow = APPLY ? l.dw + (long long)o * cols : nullptr;
-    int c = c_init, rs = rs_init;
-    for (int k = threadIdx.x; k < cols; k += 256) {
-      const float g = l.natural == 0 ? snb_row[rs * st + c] : gnat[k];
-      if (APPLY) drow[k] += l.apply_sn ? (g - uo * l.v[k]) * inv : g;
-      else acc += g * wrow[k];
-      c += dc; rs += drs;
-      if (rs >= RS) { rs -= RS; c++; }
-    }
-    if (l.natural == 0) __syncthreads();
   }
   if (!APPLY) {
     acc = block_sum_256(acc, sm);
@@ -438,27 +454,19 @@ extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd
   double bytes = 0.0;      // dot: dWt + W; apply: dWt + read-modify-write of dW
   for (int i = 0; i < n; i++) bytes += (double)layers_host[i].rows * layers_host[i].cols * 4.0 * ((layers_host[i].apply_sn ? 2 : 0) + 3);
   SgProfScope prof(st, bytes, 3);
-  bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false; int row_lds = 0;
+  bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false;
   for (int i = 0; i < n; i++) {
     const sg_sn_bwd_layer& l = layers_host[i];
-    if (snb_row_ok(l)) {
-      any_row = true; if (l.apply_sn) any_row_sn = true;
-      if (l.natural == 0) { const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin; const int need = l.RS * snb_pitch(cp) * 4; if (need > row_lds) row_lds = need; }
-    } else { any_old = true; if (l.apply_sn) any_old_sn = true; }
-  }
-  static bool attr_done = false;
-  if (any_row && !attr_done) {
-    SG_CHECK(hipFuncSetAttribute((const void*)k_snb_rows<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SNB_ROW_LDS_FLOATS * 4) == hipSuccess &&
-             hipFuncSetAttribute((const void*)k_snb_rows<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SNB_ROW_LDS_FLOATS * 4) == hipSuccess, "sg_sn_backward: LDS attribute");
-    attr_done = true;
+    if (snb_row_ok(l)) { any_row = true; if (l.apply_sn) any_row_sn = true; }
+    else { any_old = true; if (l.apply_sn) any_old_sn = true; }
   }
   if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
-  if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, n), dim3(256), row_lds, st, layers_dev, work);
+  if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
   if (any_old) {
     long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
     hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);
   }
-  if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, n), dim3(256), row_lds, st, layers_dev, work);
+  if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
   SG_LAUNCH_CHECK();
   return 0;
 }
