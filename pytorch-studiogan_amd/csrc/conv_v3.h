@@ -56,7 +56,7 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
   constexpr int PB = BI * 128;                 // one weight tile (BI couts x 64 channels)
   constexpr int NPI = (BI / 8 + NW - 1) / NW;  // weight DMA pieces per wave per tap (upper bound)
   constexpr int TJ = BJ / WJ / 32, TI = BI / WI / 32;
-  static_assert(NW == 8, "8 waves");
+  static_assert(NW == 8 || NW == 4, "8 waves (2 per SIMD) or 4 waves (1 per SIMD, 512 registers: 12-16 accumulator blocks per wave)");
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -412,7 +412,7 @@ static inline int sg_launch_conv_v3(const ConvV3Params& p, const Epilogue<bf16_t
   if constexpr (BJ == 256 && (BI == 192 || BI == 128)) {      // the deep-layer configurations: three weight buffers when they fit
     static int w3_mode = -1;
     if (w3_mode < 0) { const char* e3 = getenv("SG_V3_W3"); w3_mode = (e3 && e3[0] == '0') ? 0 : 1; }
-    if (w3_mode && pb2 && sg_conv_v3_lds(BI, BJ, p.npx, true, true) > 0 && (((p.npx >> 3) + 7) / 8 + 7) / 8 <= 2) {
+    if (w3_mode && pb2 && sg_conv_v3_lds(BI, BJ, p.npx, true, true) > 0 && (((p.npx >> 3) + WJ * WI - 1) / (WJ * WI) + 7) / 8 <= 2) {
       if (relu) return up ? sg_launch_conv_v3r<BI, WJ, WI, BJ, true, true, true, true, NKL>(p, e, st) : sg_launch_conv_v3r<BI, WJ, WI, BJ, true, false, true, true, NKL>(p, e, st);
       return up ? sg_launch_conv_v3r<BI, WJ, WI, BJ, false, true, true, true, NKL>(p, e, st) : sg_launch_conv_v3r<BI, WJ, WI, BJ, false, false, true, true, NKL>(p, e, st);
     }
@@ -424,6 +424,15 @@ static inline int sg_launch_conv_v3(const ConvV3Params& p, const Epilogue<bf16_t
   return -1;
 }
 // tile choice -> instantiation, for one value of NKL (explicitly instantiated in conv_v3.hip (4) and conv_v3b.hip (2): two translation units, built in parallel)
+// four-wave variants (one wave per SIMD, 96 x 128 / 64 x 128 register tiles: 7 fragment reads per 12 MFMAs instead of 5 per 6) of the
+// deep-layer tiles; instantiated in conv_v3c.hip
+template <int NKL>
+int sg_conv_v3_dispatch_nw4(int best, int BJ, const ConvV3Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  if ((((p.npx >> 3) + 3) / 4 + 8) / 9 > 2) return -1;      // at most two patch pieces per tap and wave
+  if (best == 192 && BJ == 256) return sg_launch_conv_v3<192, 2, 2, 256, NKL>(p, e, st);
+  if (best == 128 && BJ == 256) return sg_launch_conv_v3<128, 2, 2, 256, NKL>(p, e, st);
+  return -1;
+}
 template <int NKL>
 int sg_conv_v3_dispatch(int best, int BJ, const ConvV3Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
   if (best == 192) return sg_launch_conv_v3<192, 4, 2, 256, NKL>(p, e, st);

@@ -2,6 +2,7 @@
 #include "conv_common.h"
 #include "conv_v3.h"
 extern template int sg_conv_v3_dispatch<2>(int, int, const ConvV3Params&, const Epilogue<bf16_t>&, hipStream_t);   // conv_v3b.hip
+extern template int sg_conv_v3_dispatch_nw4<4>(int, int, const ConvV3Params&, const Epilogue<bf16_t>&, hipStream_t);   // conv_v3c.hip
 
 // halo kernel (conv_v3.h) for 3x3 / stride 1 / pad 1 with >= 64 input channels; returns false when the problem is not eligible.
 // SG_CONV_V3=0 disables it, =force skips the tile-count heuristic (tests), =all also takes the shapes the default table leaves to v2.
@@ -47,6 +48,11 @@ bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.zero_off = 0; p.bias_off = 0; p.dump_off = 0;
   if (((p.npx >> 3) + 7) / 8 >= 19) return false;           // would need more than 2 patch pieces per tap and wave (never with <= 160 KB of LDS)
+  {   // SG_V3_NW4=1: four-wave variants of the 192 / 128-wide tiles (A/B switch)
+    const char* e4 = getenv("SG_V3_NW4");
+    const bool nw4 = e4 && e4[0] == '1';
+    if (nw4 && d->C % 64 == 0 && (best == 192 || best == 128) && BJ == 256 && sg_conv_v3_dispatch_nw4<4>(best, BJ, p, e, st) == 0) return true;
+  }
   const int rc = (d->C % 64 == 0) ? sg_conv_v3_dispatch<4>(best, BJ, p, e, st) : sg_conv_v3_dispatch<2>(best, BJ, p, e, st);
   return rc == 0;
 }

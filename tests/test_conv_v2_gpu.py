@@ -92,10 +92,15 @@ V3_CASES = [
 ]
 
 
+@pytest.mark.parametrize("nw4", ["0", "1"])
 @pytest.mark.parametrize("case", V3_CASES)
-def test_conv_v3_matches_reference_and_v2(sg, case):
+def test_conv_v3_matches_reference_and_v2(sg, case, nw4, monkeypatch):
+    """nw4 = 1: the four-wave (one wave per SIMD) instantiations of the 192 / 128-wide tiles (SG_V3_NW4); other tiles are unaffected."""
     from studiogan_amd import functional as F, _lib as L
     N, Cin, Cout, H, relu, up, pool = case
+    if nw4 == "1" and not (Cin % 64 == 0 and (Cout % 192 == 0 or Cout % 128 == 0)):
+        pytest.skip("no four-wave variant of this tile")
+    monkeypatch.setenv("SG_V3_NW4", nw4)
     d = torch.device("cuda:0")
     dt = torch.bfloat16
     x = rnd((N, Cin, H, H), dt, 91)
