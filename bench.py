@@ -388,6 +388,10 @@ def main():
         fid = {"metric": "FID-50k feature-extract samples/sec", "samples": per_rank * world, "batch": args.batch,
                "value": fid["f32"]["samples_per_sec"], "unit": "samples/sec", "inception_f32": fid["f32"], "inception_bf16": fid["bf16"],
                "includes": "G_ema forward (bf16) + on-device quantize/resize + InceptionV3 + softmax + fp64 moment accumulation",
+               # algorithmic work per sample: G forward 42.24 GFLOP + InceptionV3 at 299^2 11.4 GFLOP
+               "roofline_bf16": {"bound": "mfma", "gflop_per_sample": 53.64, "achieved": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3, 1), "unit": "TFLOP/s",
+                                 "peak": 2500.0, "frac": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3 / 2500.0, 4),
+                                 "kernel_trace": "profiles/r02_fid_leg_kerneltrace.txt (tools/fid_leg.py)"},
                "weights": "seeded random (pretrained FID Inception weights are not available offline)"}
     if rank != 0:
         if world > 1:
@@ -422,7 +426,7 @@ def main():
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine: sg_conv_v3_kernel (3x3 halo) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",
