@@ -261,3 +261,34 @@ def test_pil_resizers_match_pillow(sg, filt, resizer, src):
     model = M.LoadEvalModel("InceptionV3_tf", resizer, 1, False, dev, state_dict=OI.random_state_dict(0), dtype=torch.bfloat16)
     f, l = model.get_outputs(x.to(dev), quantize=True)
     assert f.shape == (2, 2048) and bool(torch.isfinite(f).all())
+
+
+@pytest.mark.parametrize("cfg", [(0, 3, 2, 0), (1, 3, 1, 1), (2, 3, 1, 1), (0, 2, 2, 0)])
+def test_pool2d_vector_kernel_matches_torch_and_scalar(sg, cfg):
+    """sg_pool2d in bf16 (k_pool2d_v8: 8 channels per thread) writing a channel slice of a wider concat tensor, against torch's pooling of
+    the same bf16 values (mode 0 max, 1 avg incl. padding, 2 avg excl. padding -- the three poolings of InceptionV3) and against the fp32
+    kernel on the up-converted input (same accumulation order: equal after rounding)."""
+    import torch.nn.functional as TF
+    from studiogan_amd import _lib as L
+    mode, k, stride, pad = cfg
+    d = torch.device("cuda:0")
+    N, H, W, C, ldy, coff = 3, 17, 17, 64, 96, 24
+    g = torch.Generator().manual_seed(17)
+    x = torch.randn(N, H, W, C, generator=g).to(torch.bfloat16)
+    OH = (H + 2 * pad - k) // stride + 1
+    xr = x.float().permute(0, 3, 1, 2)
+    if mode == 0:
+        ref = TF.max_pool2d(xr, k, stride, pad)
+    else:
+        ref = TF.avg_pool2d(xr, k, stride, pad, count_include_pad=(mode == 1))
+    xd = x.to(d)
+    y = torch.zeros(N, OH, OH, ldy, dtype=torch.bfloat16, device=d)
+    L.call("sg_pool2d", L.BF16, L.ptr(xd), L.ptr(y), N, H, W, C, k, stride, pad, mode, ldy, coff, L.stream())
+    y32 = torch.zeros(N, OH, OH, ldy, dtype=torch.float32, device=d)
+    x32 = xd.float()
+    L.call("sg_pool2d", L.F32, L.ptr(x32), L.ptr(y32), N, H, W, C, k, stride, pad, mode, ldy, coff, L.stream())
+    torch.cuda.synchronize()
+    out = y[..., coff:coff + C].float().cpu().permute(0, 3, 1, 2)
+    check(f"pool2d bf16 {cfg}", out, ref.to(torch.bfloat16).float(), 1e-6 if mode == 0 else 4e-3)
+    assert torch.equal(y[..., coff:coff + C], y32[..., coff:coff + C].to(torch.bfloat16)), "vector and scalar kernels disagree"
+    assert float(y[..., :coff].abs().max()) == 0.0 and float(y[..., coff + C:].abs().max()) == 0.0, "wrote outside its channel slice"
