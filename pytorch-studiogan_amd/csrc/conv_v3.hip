@@ -32,7 +32,10 @@ bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
     if (tiles > best_tiles) { best = cands[c]; best_tiles = tiles; }
   }
   if (I <= 32 && I % 8 == 0 && (J >= 512 * 256 || force)) { best = 32; best_tiles = (J + 511) / 512; }   // narrow outputs (G's RGB layer, 8 padded couts): HBM-bound, one cout tile
-  if (!best || (best_tiles < 160 && !force)) return false;
+  // fewer tiles than CUs: still taken for long reductions (K >= 1152, >= 16 tiles) -- the alternative is the generic engine, whose 128 x 128
+  // tiles fill the chip no better and run 3-4x slower per tile (the 1024-channel 8^2 / 4^2 layers of a batch-64 ResNet: 246 us per
+  // launch = 78 TFLOP/s in the session-O trace of the WGAN-GP workload)
+  if (!best || (best_tiles < 160 && !force && !(K >= 1152 && best_tiles >= 16))) return false;
   // force (tests): take the tile the batch-256 problem gets, so the benchmarked instantiation is the one under test at small batch
   int BJ = (best == 32 || (best == 96 && (J >= 512 * 256 || (force && J % 512 == 0)))) ? 512 : 256;
   if (best == 96) { const char* bj = getenv("SG_V3_BJ96"); if (bj && bj[0] == '2') BJ = 256; }   // A/B: 256-pixel tiles (double patch buffer) for the 96-wide layers

@@ -75,9 +75,49 @@ template <typename T> __global__ void k_avgpool2_fwd(const T* x, T* y, int N, in
     y[i] = from_f<T>(0.25f * v);
   }
 }
+// ---- 16-byte bf16 variants of the elementwise layout kernels (round 2) ------------------------------------------------------------------
+// The scalar kernels move 2 bytes per thread behind three or four 64-bit divisions; they were 20 % of BigGAN-deep's kernel time
+// (k_relu_mask 10.6 %, k_avgpool2_bwd 3.9 %, k_slice_up_fwd 2.9 %, k_avgpool2_fwd 1.3 %: gpurun session O) and 2.5 ms of the C3 step (max-pool).
+// A thread owns 8 channels of one pixel; same arithmetic in the same order as the scalar kernels -> identical results.
+static inline bool ew_v8_ok(int dtype, const void* a, const void* b, int C, int lda, int ldb, long long total_vec) {
+  return dtype == SG_DTYPE_BF16 && C % 8 == 0 && lda % 8 == 0 && ldb % 8 == 0 && (((uintptr_t)a | (uintptr_t)b) & 15) == 0 && total_vec > 0 && total_vec < (1ll << 31);
+}
+__global__ __launch_bounds__(256) void k_avgpool2_fwd_v8(const bf16_t* x, bf16_t* y, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2, CV = C / 8;
+  const unsigned total = (unsigned)N * H2 * W2 * CV;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned q = i / CV, cv = i - q * CV;
+    const unsigned w2 = q % W2, t = q / W2, h2 = t % H2, n = t / H2;
+    const bf16_t* p = x + (((long long)n * H + 2 * h2) * W + 2 * w2) * C + cv * 8;
+    float a[8], b[8], c[8], d[8];
+    unpack16<bf16_t>(*(const u32x4*)p, a); unpack16<bf16_t>(*(const u32x4*)(p + C), b);
+    unpack16<bf16_t>(*(const u32x4*)(p + (long long)W * C), c); unpack16<bf16_t>(*(const u32x4*)(p + (long long)W * C + C), d);
+#pragma unroll
+    for (int e = 0; e < 8; e++) a[e] = 0.25f * (((a[e] + b[e]) + c[e]) + d[e]);
+    *(u32x4*)(y + (long long)q * C + cv * 8) = pack16<bf16_t>(a);
+  }
+}
+__global__ __launch_bounds__(256) void k_avgpool2_bwd_v8(const bf16_t* dy, bf16_t* dx, int N, int H, int W, int C) {
+  const int H2 = H / 2, W2 = W / 2, CV = C / 8;
+  const unsigned total = (unsigned)N * H * W * CV;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned pix = i / CV, cv = i - pix * CV;
+    const unsigned w = pix % W, t = pix / W, h = t % H, n = t / H;
+    float g[8];
+    unpack16<bf16_t>(*(const u32x4*)(dy + (((long long)n * H2 + (h >> 1)) * W2 + (w >> 1)) * C + cv * 8), g);
+#pragma unroll
+    for (int e = 0; e < 8; e++) g[e] = 0.25f * g[e];
+    *(u32x4*)(dx + (long long)pix * C + cv * 8) = pack16<bf16_t>(g);
+  }
+}
 extern "C" int sg_avgpool2_fwd(int dtype, const void* x, void* y, int N, int H, int W, int C, sg_stream_t s) {
   SG_CHECK(x && y && H % 2 == 0 && W % 2 == 0, "sg_avgpool2_fwd: bad args");
   long long total = (long long)N * (H / 2) * (W / 2) * C;
+  if (ew_v8_ok(dtype, x, y, C, 8, 8, total / 8)) {
+    hipLaunchKernelGGL(k_avgpool2_fwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, N, H, W, C);
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_avgpool2_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, H, W, C));
   SG_LAUNCH_CHECK();
   return 0;
@@ -95,6 +135,11 @@ template <typename T> __global__ void k_avgpool2_bwd(const T* dy, T* dx, int N, 
 extern "C" int sg_avgpool2_bwd(int dtype, const void* dy, void* dx, int N, int H, int W, int C, sg_stream_t s) {
   SG_CHECK(dy && dx && H % 2 == 0 && W % 2 == 0, "sg_avgpool2_bwd: bad args");
   long long total = (long long)N * H * W * C;
+  if (ew_v8_ok(dtype, dy, dx, C, 8, 8, total / 8)) {
+    hipLaunchKernelGGL(k_avgpool2_bwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (bf16_t*)dx, N, H, W, C);
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_avgpool2_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (T*)dx, N, H, W, C));
   SG_LAUNCH_CHECK();
   return 0;
@@ -575,9 +620,25 @@ extern "C" int sg_add_relu(int dtype, const void* a, const void* x, void* out, l
 template <typename T> __global__ void k_relu_mask(const T* dy, const T* x, T* dx, long long n) {
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) dx[i] = (to_f<T>(x[i]) > 0.f) ? dy[i] : from_f<T>(0.f);
 }
+__global__ __launch_bounds__(256) void k_relu_mask_v8(const bf16_t* dy, const bf16_t* x, bf16_t* dx, unsigned nv) {
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < nv; i += gridDim.x * 256u) {
+    const u32x4 g = *(const u32x4*)(dy + 8ll * i);
+    float xv[8];
+    unpack16<bf16_t>(*(const u32x4*)(x + 8ll * i), xv);
+    u32x4 o;
+#pragma unroll
+    for (int d = 0; d < 4; d++) o[d] = (xv[2 * d] > 0.f ? (g[d] & 0xffffu) : 0u) | (xv[2 * d + 1] > 0.f ? (g[d] & 0xffff0000u) : 0u);
+    *(u32x4*)(dx + 8ll * i) = o;
+  }
+}
 extern "C" int sg_relu_mask(int dtype, const void* dy, const void* x, void* dx, long long n, sg_stream_t s) {
   SG_CHECK(dy && x && dx, "sg_relu_mask: null");
   if (n <= 0) return 0;
+  if (dtype == SG_DTYPE_BF16 && n % 8 == 0 && (((uintptr_t)dy | (uintptr_t)x | (uintptr_t)dx) & 15) == 0 && n / 8 < (1ll << 31)) {
+    hipLaunchKernelGGL(k_relu_mask_v8, dim3(nblk(n / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (const bf16_t*)x, (bf16_t*)dx, (unsigned)(n / 8));
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_relu_mask<T>, dim3(nblk(n, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (const T*)x, (T*)dx, n));
   SG_LAUNCH_CHECK();
   return 0;
@@ -681,9 +742,49 @@ template <typename T> __global__ void k_slice_up_fwd(const T* x, T* y, int Hs, i
     y[i] = x[(((long long)n * Hs + h / up) * Ws + w / up) * ldx + c];
   }
 }
+__global__ __launch_bounds__(256) void k_slice_up_fwd_v8(const bf16_t* x, bf16_t* y, int Hs, int Ws, int ldx, int C, int up, unsigned total) {
+  const int CV = C / 8, Wo = Ws * up, Ho = Hs * up;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned pix = i / CV, cv = i - pix * CV;
+    const unsigned w = pix % Wo, t = pix / Wo, h = t % Ho, n = t / Ho;
+    *(u32x4*)(y + (long long)pix * C + cv * 8) = *(const u32x4*)(x + (((long long)n * Hs + h / up) * Ws + w / up) * ldx + cv * 8);
+  }
+}
+__global__ __launch_bounds__(256) void k_slice_up_bwd_v8(const bf16_t* dy, bf16_t* dx, int Hs, int Ws, int ldx, int C, int up, unsigned total) {
+  const int LV = ldx / 8;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned pix = i / LV, cv = i - pix * LV;
+    const unsigned ws = pix % Ws, t = pix / Ws, hs = t % Hs, n = t / Hs;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; e++) acc[e] = 0.f;
+    if ((int)cv * 8 < C) {
+      for (int a = 0; a < up; a++)
+        for (int b = 0; b < up; b++) {
+          float v[8];
+          unpack16<bf16_t>(*(const u32x4*)(dy + (((long long)n * Hs * up + hs * up + a) * (Ws * up) + ws * up + b) * C + cv * 8), v);
+#pragma unroll
+          for (int e = 0; e < 8; e++) acc[e] += v[e];
+        }
+    }
+    *(u32x4*)(dx + (long long)pix * ldx + cv * 8) = pack16<bf16_t>(acc);
+  }
+}
+__global__ __launch_bounds__(256) void k_copy_channels_v8(const bf16_t* src, int lds, bf16_t* dst, int ldd, int C, unsigned total) {
+  const int CV = C / 8;
+  for (unsigned i = blockIdx.x * 256u + threadIdx.x; i < total; i += gridDim.x * 256u) {
+    const unsigned r = i / CV, cv = i - r * CV;
+    *(u32x4*)(dst + (long long)r * ldd + cv * 8) = *(const u32x4*)(src + (long long)r * lds + cv * 8);
+  }
+}
 extern "C" int sg_slice_up_fwd(int dtype, const void* x, void* y, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s) {
   SG_CHECK(x && y && C > 0 && C <= ldx && (up == 1 || up == 2), "sg_slice_up_fwd: bad args");
   const long long total = (long long)N * Hs * up * Ws * up * C;
+  if (ew_v8_ok(dtype, x, y, C, ldx, 8, total / 8)) {
+    hipLaunchKernelGGL(k_slice_up_fwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)x, (bf16_t*)y, Hs, Ws, ldx, C, up, (unsigned)(total / 8));
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_slice_up_fwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, Hs, Ws, ldx, C, up, total));
   SG_LAUNCH_CHECK();
   return 0;
@@ -706,6 +807,11 @@ template <typename T> __global__ void k_slice_up_bwd(const T* dy, T* dx, int Hs,
 extern "C" int sg_slice_up_bwd(int dtype, const void* dy, void* dx, int N, int Hs, int Ws, int ldx, int C, int up, sg_stream_t s) {
   SG_CHECK(dy && dx && C > 0 && C <= ldx && (up == 1 || up == 2), "sg_slice_up_bwd: bad args");
   const long long total = (long long)N * Hs * Ws * ldx;
+  if (ew_v8_ok(dtype, dy, dx, C, ldx, 8, total / 8)) {
+    hipLaunchKernelGGL(k_slice_up_bwd_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)dy, (bf16_t*)dx, Hs, Ws, ldx, C, up, (unsigned)(total / 8));
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_slice_up_bwd<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)dy, (T*)dx, Hs, Ws, ldx, C, up, total));
   SG_LAUNCH_CHECK();
   return 0;
@@ -720,6 +826,11 @@ template <typename T> __global__ void k_copy_channels(const T* src, int lds, T* 
 extern "C" int sg_copy_channels(int dtype, const void* src, int ld_src, void* dst, int ld_dst, long long rows, int C, sg_stream_t s) {
   SG_CHECK(src && dst && rows > 0 && C > 0 && C <= ld_src && C <= ld_dst, "sg_copy_channels: bad args");
   const long long total = rows * C;
+  if (ew_v8_ok(dtype, src, dst, C, ld_src, ld_dst, total / 8)) {
+    hipLaunchKernelGGL(k_copy_channels_v8, dim3(nblk(total / 8, 256)), dim3(256), 0, (hipStream_t)s, (const bf16_t*)src, ld_src, (bf16_t*)dst, ld_dst, C, (unsigned)(total / 8));
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_copy_channels<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, (const T*)src, ld_src, (T*)dst, ld_dst, C, total));
   SG_LAUNCH_CHECK();
   return 0;
