@@ -39,7 +39,10 @@ typedef __attribute__((address_space(3))) void* sg_lptr_t;
 // buffers, reused as the output staging area; sbias: BI floats in LDS (valid when epi.bias).
 template <int BI, int BJ, int NW, int TI, int TJ>
 __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* smem, const float* sbias, const Epilogue<bf16_t>& epi,
-                                                 int i0, int j0, int wi0, int wj0, float al) {
+                                                 int i0, int j0, int wi0, int wj0, float al, bool active = true) {
+  // active (wave-uniform): this wave's accumulators belong to the BJ rows staged by this call. A tile larger than its staging area is
+  // stored in several calls (conv_v4.h, 512-pixel tiles: two calls of 256 rows, two of the four waves active in each); every thread
+  // takes part in the operand pre-load and in the store loop of every call.
   const int tid = threadIdx.x, lane = tid & 63;
   // bf16 output tile: staged through LDS (the operand buffers are dead now) so that the global stores are 16 bytes per lane with
   // consecutive lanes on consecutive addresses of a row. The direct form (8 bytes per lane, 32 different rows per instruction)
@@ -71,6 +74,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
     __syncthreads();
   }
   const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
+  if (active) {
 #pragma unroll
   for (int ta = 0; ta < TI; ta++)
 #pragma unroll
@@ -117,6 +121,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
         }
       }
     }
+  }
   {
     __syncthreads();
     bf16_t* o = (bf16_t*)epi.out;

@@ -31,9 +31,11 @@ struct ConvV4Params {
   int wgt_off, zero_off, bias_off;   // LDS byte offsets: weight buffers, zero line, bias vector
 };
 
-template <int NB, bool RELU, bool UP>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
-  constexpr int BI = 32 * NB, BJ = 256, NW = 4, TI = NB, TJ = 2;
+// TJW = 32-pixel blocks per wave: 2 (tile 256 pixels, 6 accumulator blocks per wave for NB = 3, three workgroups per CU) or 4 (tile 512 pixels,
+// 12 accumulator blocks: 7 fragment reads per 12 MFMAs instead of 5 per 6, two workgroups per CU; the staged epilogue runs in two halves)
+template <int NB, bool RELU, bool UP, int TJW>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -86,11 +88,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   };
 
   // ---- fragment rows of this lane (conv_v3.h's bookkeeping) ------------------------------------------------------------------------
-  const int wj0 = wave * 64;
+  const int wj0 = wave * (32 * TJ);
   const int frow = lane & 31, fhi = lane >> 5;
   int rb[TJ];             // patch row of the centre pixel
   unsigned qinv[TJ];      // bit t set = tap t reads outside the image (or the row is outside the problem)
-  int rs0[TJ], rs2[TJ], cs0[TJ], cs2[TJ];
+  unsigned par[TJ];       // upsample on load: bit 0 = output row is odd, bit 1 = output column is odd (decides which taps stay on the source pixel)
 #pragma unroll
   for (int b = 0; b < TJ; b++) {
     const int row = j0 + wj0 + b * 32 + frow;
@@ -118,11 +120,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const int Hs = p.Ho >> 1;
       const int spc = ((n * Hs + (ho >> 1)) << p.wlog) + (wo >> 1);
       rb[b] = spc - P0;
-      rs0[b] = (ho & 1) ? 0 : -p.W; rs2[b] = (ho & 1) ? p.W : 0;
-      cs0[b] = (wo & 1) ? 0 : -1;  cs2[b] = (wo & 1) ? 1 : 0;
+      par[b] = (unsigned)(ho & 1) | ((unsigned)(wo & 1) << 1);
     } else {
       rb[b] = (((n << p.hshift) + ho) << p.wshift) + wo - P0;
-      rs0[b] = -p.W; rs2[b] = p.W; cs0[b] = -1; cs2[b] = 1;
+      par[b] = 0;
     }
   }
   // weight fragment addresses: row = cout a * 32 + frow, chunk (ks * 2 + fhi) ^ (row >> 2 & 3); ks = 1 is the address ^ 32
@@ -165,10 +166,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #pragma unroll
       for (int b = 0; b < TJ; b++) {
         int row = rb[b];
-        if (tr == 0) row += rs0[b];
-        if (tr == 2) row += rs2[b];
-        if (ts == 0) row += cs0[b];
-        if (ts == 2) row += cs2[b];
+        asm volatile("" : "+v"(row));   // keeps a tap's address arithmetic inside the tap (hoisted out of the slice loop it spills: 36 addresses)
+        if (UP) {           // source-pixel displacement of tap (tr, ts) under nearest x2: (ho + tr - 1) >> 1 and (wo + ts - 1) >> 1
+          if (tr == 0) row += (par[b] & 1u) ? 0 : -p.W;
+          if (tr == 2) row += (par[b] & 1u) ? p.W : 0;
+          if (ts == 0) row += (par[b] & 2u) ? 0 : -1;
+          if (ts == 2) row += (par[b] & 2u) ? 1 : 0;
+        } else {
+          if (tr == 0) row -= p.W;
+          if (tr == 2) row += p.W;
+          if (ts == 0) row -= 1;
+          if (ts == 2) row += 1;
+        }
         unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
         a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
         qa[b] = a;
@@ -210,7 +219,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
-  sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+  if constexpr (TJW == 2) {
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+  } else {   // 512-pixel tile, 256-row staging area: waves 0, 1 then waves 2, 3
+    sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2);
+    sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2);
+  }
 }
 
 // LDS need (bytes) of a configuration
@@ -224,23 +238,23 @@ static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, i
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU, bool UP>
+template <int NB, bool RELU, bool UP, int TJW>
 static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
-  if (lds > 64 * 1024) return -1;
+  if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP>, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
-  const int BI = 32 * NB;
-  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + 255) / 256;
-  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
+  const int BI = 32 * NB, BJ = 128 * TJW;
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
+  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
   return 0;
 }
-template <int NB>
+template <int NB, int TJW>
 static inline int sg_launch_conv_v4(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, relu = (p.flags & SG_PIX_RELU) != 0;
-  if (relu) return up ? sg_launch_conv_v4r<NB, true, true>(p, e, st) : sg_launch_conv_v4r<NB, true, false>(p, e, st);
-  return up ? sg_launch_conv_v4r<NB, false, true>(p, e, st) : sg_launch_conv_v4r<NB, false, false>(p, e, st);
+  if (relu) return up ? sg_launch_conv_v4r<NB, true, true, TJW>(p, e, st) : sg_launch_conv_v4r<NB, true, false, TJW>(p, e, st);
+  return up ? sg_launch_conv_v4r<NB, false, true, TJW>(p, e, st) : sg_launch_conv_v4r<NB, false, false, TJW>(p, e, st);
 }

@@ -23,9 +23,13 @@ bool sg_conv_fwd_v4_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   int NB;
   if (I % 96 == 0) NB = 3; else if (I % 64 == 0) NB = 2; else return false;
-  const int tiles = (I / (32 * NB)) * ((J + 255) / 256);
-  if (!force && tiles < 768) return false;                  // one full wave of three workgroups per CU
-  if ((quad || up) && (256 % (2 * d->Wo))) return false;    // the tile must cover whole pairs of image rows
+  // SG_CONV_V4_BJ=512: the 512-pixel tile (12 accumulator blocks per wave, two workgroups per CU) where the shape allows it (A/B switch)
+  const char* bj = getenv("SG_CONV_V4_BJ");
+  int BJ = (bj && bj[0] == '5') ? 512 : 256;
+  if (BJ == 512 && (J % 512 || ((quad || up) && (512 % (2 * d->Wo))))) BJ = 256;
+  const int tiles = (I / (32 * NB)) * ((J + BJ - 1) / BJ);
+  if (!force && tiles < (BJ == 512 ? 512 : 768)) return false;   // one full wave of workgroups (two / three per CU)
+  if ((quad || up) && (BJ % (2 * d->Wo))) return false;         // the tile must cover whole pairs of image rows
   if (J % d->Wo) return false;
   ConvV4Params p;
   p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;
@@ -33,9 +37,11 @@ bool sg_conv_fwd_v4_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   p.Ho = d->Ho; p.Wo = d->Wo; p.wshift = wshift; p.hshift = hshift; p.flags = pflags;
   p.I = I; p.J = J; p.K = K; p.nslice = d->C / 32;
   p.npix_src = d->N * d->Hs * d->Ws;
-  p.npx = (((up ? 64 : 256) + 2 * d->Ws + 16) + 15) & ~15;
+  p.npx = (((up ? BJ / 4 : BJ) + 2 * d->Ws + 16) + 15) & ~15;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.wgt_off = p.zero_off = p.bias_off = 0;
-  const int rc = NB == 3 ? sg_launch_conv_v4<3>(p, e, st) : sg_launch_conv_v4<2>(p, e, st);
+  int rc;
+  if (BJ == 512) rc = NB == 3 ? sg_launch_conv_v4<3, 4>(p, e, st) : sg_launch_conv_v4<2, 4>(p, e, st);
+  else rc = NB == 3 ? sg_launch_conv_v4<3, 2>(p, e, st) : sg_launch_conv_v4<2, 2>(p, e, st);
   return rc == 0;
 }
