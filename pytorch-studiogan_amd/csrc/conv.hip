@@ -46,6 +46,17 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
     if (tiles >= 512) { best = cands[c]; best_tiles = tiles; break; }
     if (tiles > best_tiles) { best = cands[c]; best_tiles = tiles; }
   }
+  if (!best && I % 8 == 0 && I >= 32) {
+    // no candidate divides the cout count (InceptionV3: 32 / 48 / 64 / 160 / 224 / 320 / 448 couts): take the one that pads least -- the kernel
+    // zero-fills weight rows >= I and its epilogue stores only the 16-byte chunks that exist. Up to 50 % padding still beats the generic
+    // engine these layers ran on (17 % of the FID leg at ~150 us per launch, profiles/r02_fid_leg_kerneltrace.txt).
+    int best_pad = 0;
+    for (int c = 0; c < 3; c++) {
+      const int padded = ((I + cands[c] - 1) / cands[c]) * cands[c];
+      if (2 * padded > 3 * I) continue;
+      if (!best || padded < best_pad) { best = cands[c]; best_pad = padded; best_tiles = (padded / cands[c]) * tj; }
+    }
+  }
   if (!best || (best_tiles < 160 && !force)) return false;
   ConvV2Params p;
   p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;

@@ -25,6 +25,9 @@ CASES = [
     (2, 24, 96, 16, 3, False, False, False),      # thin / odd chunk counts (cpt = 3, 5, 6): position recomputed from the chunk index
     (2, 40, 128, 16, 3, True, False, False),
     (2, 48, 96, 16, 3, True, True, False),
+    (2, 64, 64, 16, 3, False, False, False),      # cout count no tile divides (64 on the 96-wide tile: weight rows >= 64 zero-filled, tail chunks not stored)
+    (3, 96, 160, 17, 1, False, False, False),     # InceptionV3-like: 17 x 17 images (not a power of two), 160 couts on the 192-wide tile
+    (2, 64, 320, 8, 3, True, False, False),       # 320 couts: two tiles of 192, the second one 2/3 full
 ]
 
 
