@@ -302,3 +302,30 @@ def test_boundary_through_the_references_own_loader(name):
     # the product path has no CPU fallback: a forward on CPU raises instead of silently computing something else
     with pytest.raises(RuntimeError):
         Gen(torch.randn(2, cfgs.MODEL.z_dim), torch.zeros(2, dtype=torch.long))
+
+
+@pytest.mark.parametrize("filt", ["bicubic", "bilinear"])
+@pytest.mark.parametrize("sizes", [(32, 299), (128, 299), (512, 299), (64, 48)])
+def test_pil_coefficient_tables_reproduce_pillow(filt, sizes):
+    """metrics.pil_coeffs (the host half of the 'clean' / 'friendly' post-resizers, reference src/utils/resize.py:39-78) against Pillow itself:
+    a float32 ('F' mode) image resized by PIL equals the separable application of the coefficient tables (horizontal pass, then vertical,
+    like Pillow's ImagingResample) to float rounding. No GPU: the device kernel that consumes the tables is checked in test_eval_gpu.py."""
+    import numpy as np
+    from PIL import Image
+    from studiogan_amd import metrics as M
+    src, dst = sizes
+    rng = np.random.RandomState(5)
+    img = rng.rand(src, src).astype(np.float32) * 255.0
+    flt = {"bicubic": Image.BICUBIC, "bilinear": Image.BILINEAR}[filt]
+    ref = np.asarray(Image.fromarray(img, mode="F").resize((dst, dst), resample=flt), dtype=np.float64)
+    b, k, n = M.pil_coeffs(src, dst, filt)
+    hor = np.zeros((src, dst))
+    for xx in range(dst):
+        x0, cnt = b[xx]
+        hor[:, xx] = img[:, x0:x0 + cnt].astype(np.float64) @ k[xx, :cnt]
+    out = np.zeros((dst, dst))
+    for yy in range(dst):
+        y0, cnt = b[yy]
+        out[yy] = k[yy, :cnt] @ hor[y0:y0 + cnt]
+    err = float(np.abs(out - ref).max())      # Pillow keeps the intermediate image in float32: ~1e-4 on a 0..255 range
+    assert err <= 3e-3, err
