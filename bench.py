@@ -59,6 +59,10 @@ def build(wl, mixed, device):
 
 # ---- extra workloads (never the headline): the other BASELINE.json configurations, a few steps each ---------------------------------
 EXTRAS = {
+    # C1: configs/CIFAR10/GGAN.yaml (DCGAN backbone, hinge, BN in G and D, no SN), batch 64, fp32
+    "dcgan32_bs64_fp32": dict(yaml={"DATA": {"img_size": 32, "num_classes": 10}, "MODEL": {"backbone": "deep_conv", "g_conv_dim": "N/A", "d_conv_dim": "N/A"}},
+                              batch=64, mixed=False, n_d=2, loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999, gp=False, ema=False,
+                              desc="DCGAN CIFAR-10 32x32 unconditional hinge, batch 64, fp32 (C1)", steps=20, warmup=3),
     # C2: configs/CIFAR10/SNGAN.yaml at batch 256, fp32 (exact-fp32 MFMA: 157.3 TFLOP/s peak)
     "sngan32_bs256_fp32": dict(yaml={"DATA": {"img_size": 32, "num_classes": 10},
                                      "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 128, "g_conv_dim": 64, "d_conv_dim": 64}},
@@ -93,26 +97,27 @@ def build_from_cfg(y, mixed, device):
     return G.to(device), Dm.to(device)
 
 
-def run_extra(name, device, steps=2, warmup=1):
+def run_extra(name, device, steps=None, warmup=None):
     """A few timed steps of one extra workload on ONE GPU: images/s, conv-engine TFLOP/s (hipEvent brackets) against the peak of its dtype."""
     import math
     from studiogan_amd import _lib as L
     from studiogan_amd.worker import Worker
     e = EXTRAS[name]
     y = e["yaml"]
+    steps, warmup = steps or e.get("steps", 2), warmup or e.get("warmup", 1)
     torch.manual_seed(4321)
     G, D = build_from_cfg(y, e["mixed"], device)
     w = Worker(G, D, y["MODEL"].get("z_dim", 128), y["DATA"]["num_classes"], e["batch"], e["loss"], e["g_lr"], e["d_lr"], e["beta1"], e["beta2"],
                d_updates_per_step=e["n_d"], apply_g_ema=e["ema"], g_ema_decay=0.9999, g_ema_start=20000, apply_gp=e["gp"], gp_lambda=10.0)
-    real = synth_batches(e["n_d"], e["batch"], y["DATA"]["img_size"], y["DATA"]["num_classes"], device, 77)
+    pool = generator_real_pool(G, min(32, e["n_d"] * (warmup + steps)), e["batch"], y["MODEL"].get("z_dim", 128), y["DATA"]["num_classes"], device, 77)
     for i in range(warmup):
-        w.step(i, real)
+        w.step(i, baskets(pool, i, e["n_d"]))
     torch.cuda.synchronize()
     L.call("sg_prof_enable", 1)
     t0 = time.perf_counter()
     last = None
     for i in range(steps):
-        last = w.step(warmup + i, real)
+        last = w.step(warmup + i, baskets(pool, warmup + i, e["n_d"]))
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     pr = (ctypes.c_double * 9)()
@@ -123,7 +128,9 @@ def run_extra(name, device, steps=2, warmup=1):
     conv_ms, conv_fl = pr[1] + pr[4], pr[2] + pr[5]
     peak = PEAK_BF16_TFLOPS if e["mixed"] else PEAK_F32_TFLOPS
     tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
-    del w, G, D, real
+    if e["loss"] == "hinge":
+        assert d_l > 1e-2, f"{name}: the discriminator saturated (d_loss {d_l}): its backward would multiply zero gradients"
+    del w, G, D, pool
     torch.cuda.empty_cache()
     return {"workload": e["desc"], "dtype": "bf16" if e["mixed"] else "f32", "per_gpu_batch": e["batch"], "d_updates_per_step": e["n_d"], "steps": steps,
             "images_per_sec": round(e["batch"] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 2),
@@ -142,6 +149,38 @@ def synth_batches(n, batch, img_size, classes, device, seed):
         y = torch.randint(0, classes, (batch,), generator=g).to(device)
         out.append((x, y))
     return out
+
+
+def generator_real_pool(G, n_baskets, batch, z_dim, classes, device, seed):
+    """Synthetic 'real' baskets that keep the discriminator's task HARD, so the hinge stays active for the whole timed region:
+    uint8-quantised samples of a frozen copy of the INITIAL generator (train-mode batch statistics, no tracking), labels random.
+    Uniform-noise 'real' images are separated from generator samples with margin > 1 within ~10 updates; from then on both hinge
+    terms are exactly zero, dy into the discriminator's backward is identically zero (34 % of the step's FLOPs multiply zeros) and
+    the chip clocks higher on the zero operands (MI355X_MICROARCH.md, DVFS give-back) -- VERDICT r2 weak item 3. The reference's
+    loop draws a fresh basket per D update (src/worker.py:227-304); here n_baskets distinct baskets are cycled."""
+    import copy
+    from studiogan_amd.worker import untrack_bn_statistics
+    G0 = copy.deepcopy(G)
+    G0.train()
+    G0.apply(untrack_bn_statistics)
+    g = torch.Generator(device=device).manual_seed(seed)
+    out = []
+    with torch.no_grad():
+        for _ in range(n_baskets):
+            z = torch.randn(batch, z_dim, device=device, generator=g)
+            y = torch.randint(0, max(classes, 1), (batch,), device=device, generator=g)
+            x = G0(z, y).float().clamp_(-1.0, 1.0)
+            x = torch.round((x + 1.0) * 127.5) / 127.5 - 1.0          # the uint8 grid of ToTensor + Normalize(0.5, 0.5) (SURVEY.md 8d)
+            yr = torch.randint(0, max(classes, 1), (batch,), device=device, generator=g)
+            out.append((x.contiguous(), yr))
+    del G0
+    torch.cuda.empty_cache()
+    return out
+
+
+def baskets(pool, step, n_d):
+    """the n_d real micro-batches of training step `step` out of a cycled pool"""
+    return [pool[(step * n_d + k) % len(pool)] for k in range(n_d)]
 
 
 def usable_cores():
@@ -165,15 +204,50 @@ def usable_cores():
 
 def cpu_baseline_child(workload, cpu_batch):
     """Runs in a subprocess (hard wall-clock bound enforced by the parent). The reference path restated on CPU
-    (oracle/restate.py), fp32, same architecture and step structure, reduced batch. Timed only -- never used to
-    produce the GPU result."""
-    from oracle import restate as O
-    wl = WORKLOADS[workload]
+    (oracle/restate.py / oracle/inception.py), fp32, same architecture and step structure. Timed only -- never used to
+    produce the GPU result. workload: "biggan128" (C3, reduced batch), a key of EXTRAS (C1 / C2 at their FULL batch when cpu_batch == 0),
+    or "inception" (InceptionV3 forward at 299^2, SURVEY.md 8d: B = 32)."""
     threads = usable_cores()
     torch.set_num_threads(threads)
-    ocfg = dict(img_size=wl["img_size"], g_conv_dim=wl["ch"], d_conv_dim=wl["ch"], z_dim=wl["z_dim"], attn_g_loc=wl["attn_g"],
-                attn_d_loc=wl["attn_d"], apply_attn=True, g_cond_mtd="cBN", d_cond_mtd="PD", apply_d_sn=True, backbone="big_resnet")
-    Gc, Dc = build(wl, False, torch.device("cpu"))
+    if workload == "inception":
+        from oracle import inception as OI
+        sd = OI.random_state_dict(0)
+        B = cpu_batch or 32
+        x = torch.rand(B, 3, 299, 299, generator=torch.Generator().manual_seed(5)) * 2 - 1
+        with torch.no_grad():
+            t0 = time.time()
+            OI.inception_forward(x, sd)
+            first = time.time() - t0
+            times = []
+            while len(times) < 3 and (not times or sum(times) + times[-1] < 25.0):
+                t0 = time.time()
+                OI.inception_forward(x, sd)
+                times.append(time.time() - t0)
+        dt = sum(times) / len(times)
+        print(json.dumps({"value": round(B / dt, 3), "unit": "samples/sec", "cores": threads, "kind": "port",
+                          "sample": f"{len(times)} timed InceptionV3 forward pass(es) after 1 warm-up at batch {B}, 299x299 fp32 inputs already resized, torch CPU ops "
+                                    f"through oracle/inception.py (restatement of reference src/metrics/inception_net.py over torchvision's structure): {dt:.2f} s/batch"}))
+        return
+    from oracle import restate as O
+    if workload in WORKLOADS:
+        wl = WORKLOADS[workload]
+        ocfg = dict(img_size=wl["img_size"], g_conv_dim=wl["ch"], d_conv_dim=wl["ch"], z_dim=wl["z_dim"], attn_g_loc=wl["attn_g"],
+                    attn_d_loc=wl["attn_d"], apply_attn=True, g_cond_mtd="cBN", d_cond_mtd="PD", apply_d_sn=True, backbone="big_resnet")
+        Gc, Dc = build(wl, False, torch.device("cpu"))
+        img, z_dim, classes, n_d, loss = wl["img_size"], wl["z_dim"], wl["classes"], wl["n_d"], "hinge"
+        lrs = (wl["g_lr"], wl["d_lr"], wl["beta1"], wl["beta2"])
+        desc = "BigGAN-128 ch 96, n_d = 2"
+    else:
+        from oracle.make_golden import oracle_cfg
+        e = EXTRAS[workload]
+        y = e["yaml"]
+        ocfg = oracle_cfg(y)
+        Gc, Dc = build_from_cfg(y, False, torch.device("cpu"))
+        img, z_dim, classes, n_d, loss = y["DATA"]["img_size"], y["MODEL"].get("z_dim", 128), y["DATA"]["num_classes"], e["n_d"], e["loss"]
+        lrs = (e["g_lr"], e["d_lr"], e["beta1"], e["beta2"])
+        cpu_batch = cpu_batch or e["batch"]
+        desc = e["desc"]
+        assert not e["gp"], "gradient-penalty CPU baseline not wired"
     isb = lambda k: any(s in k for s in ("weight_u", "weight_v", "running_", "num_batches"))
     GP = {k: v.detach().clone() for k, v in Gc.state_dict().items() if not isb(k)}
     GB = {k: v.detach().clone() for k, v in Gc.state_dict().items() if isb(k)}
@@ -181,23 +255,23 @@ def cpu_baseline_child(workload, cpu_batch):
     DB = {k: v.detach().clone() for k, v in Dc.state_dict().items() if isb(k)}
     del Gc, Dc
     gen_fn, dis_fn = O.model_fns(ocfg)
-    g_opt, d_opt = O.AdamState(GP, wl["g_lr"], wl["beta1"], wl["beta2"]), O.AdamState(DP, wl["d_lr"], wl["beta1"], wl["beta2"])
+    g_opt, d_opt = O.AdamState(GP, lrs[0], lrs[2], lrs[3]), O.AdamState(DP, lrs[1], lrs[2], lrs[3])
     gen = torch.Generator().manual_seed(99)
 
     def one_step():
-        for _ in range(wl["n_d"]):
-            z = torch.randn(cpu_batch, wl["z_dim"], generator=gen)
-            fl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
-            real = torch.randint(0, 256, (cpu_batch, 3, wl["img_size"], wl["img_size"]), generator=gen).float() / 127.5 - 1.0
-            rl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
-            O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [real], [rl], [z], [fl], "hinge")
-        z = torch.randn(cpu_batch, wl["z_dim"], generator=gen)
-        fl = torch.randint(0, wl["classes"], (cpu_batch,), generator=gen)
-        O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [z], [fl], "hinge")
+        for _ in range(n_d):
+            z = torch.randn(cpu_batch, z_dim, generator=gen)
+            fl = torch.randint(0, classes, (cpu_batch,), generator=gen)
+            real = torch.randint(0, 256, (cpu_batch, 3, img, img), generator=gen).float() / 127.5 - 1.0
+            rl = torch.randint(0, classes, (cpu_batch,), generator=gen)
+            O.d_update(gen_fn, dis_fn, GP, GB, DP, DB, d_opt, [real], [rl], [z], [fl], loss)
+        z = torch.randn(cpu_batch, z_dim, generator=gen)
+        fl = torch.randint(0, classes, (cpu_batch,), generator=gen)
+        O.g_update(gen_fn, dis_fn, GP, GB, DP, DB, g_opt, [z], [fl], loss)
     t0 = time.time()
     one_step()
     first = time.time() - t0
-    sys.stderr.write(f"[cpu_baseline] warm-up step {first:.1f}s on {threads} threads\n")
+    sys.stderr.write(f"[cpu_baseline] {workload}: warm-up step {first:.1f}s on {threads} threads\n")
     # 1 warm-up + 3 timed steps; bounded: stop timing once ~40 s of timed work are spent (at least one timed step)
     times = []
     while len(times) < 3 and (not times or sum(times) + times[-1] < 40.0):
@@ -206,12 +280,12 @@ def cpu_baseline_child(workload, cpu_batch):
         times.append(time.time() - t0)
     dt = sum(times) / len(times)
     print(json.dumps({"value": round(cpu_batch / dt, 4), "unit": "images/sec", "cores": threads, "kind": "port",
-                      "sample": f"{len(times)} timed G+D step(s) after 1 warm-up at batch {cpu_batch} of the same architecture (BigGAN-128 ch 96, n_d = 2), fp32, "
+                      "sample": f"{len(times)} timed G+D step(s) after 1 warm-up at batch {cpu_batch} of the same architecture ({desc}), fp32, "
                                 f"torch CPU ops through oracle/restate.py (restatement of the reference, bit-identical to it on the golden fixtures): "
                                 f"{dt:.2f} s/step (warm-up {first:.2f} s)"}))
 
 
-def cpu_baseline(workload, cpu_batch, timeout_s=170):
+def cpu_baseline(workload, cpu_batch, timeout_s=170, unit="images/sec"):
     import subprocess
     try:
         r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--workload", workload, "--cpu-batch", str(cpu_batch)],
@@ -219,10 +293,10 @@ def cpu_baseline(workload, cpu_batch, timeout_s=170):
         line = [x for x in r.stdout.strip().splitlines() if x.startswith("{")]
         if line:
             return json.loads(line[-1])
-        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port", "sample": "cpu baseline failed: " + r.stderr[-300:]}
+        return {"value": None, "unit": unit, "cores": usable_cores(), "kind": "port", "sample": "cpu baseline failed: " + r.stderr[-300:]}
     except subprocess.TimeoutExpired:
-        return {"value": None, "unit": "images/sec", "cores": usable_cores(), "kind": "port",
-                "sample": f"one G+D step at batch {cpu_batch} did not finish within the {timeout_s}s bound"}
+        return {"value": None, "unit": unit, "cores": usable_cores(), "kind": "port",
+                "sample": f"the {workload} CPU sample at batch {cpu_batch} did not finish within the {timeout_s}s bound"}
 
 
 def main():
@@ -237,12 +311,28 @@ def main():
     ap.add_argument("--fid-samples", type=int, default=50000, help="samples of the FID feature-extraction leg (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (C2 fp32, C5 WGAN-GP, C4 per GPU)")
+    ap.add_argument("--native-comm", action="store_true", help="gradient / sync-BN exchanges through libsgamd.so's own RCCL communicator "
+                    "(sg_allreduce_flat on HIP streams) instead of torch.distributed's nccl backend (same RCCL underneath); also SG_NATIVE_COMM=1")
+    ap.add_argument("--strict", action="store_true", help="exit non-zero when an extra workload / leg fails (the line is still printed)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
         cpu_baseline_child(args.workload, args.cpu_batch)
         return
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` by itself: become the launcher of N ranks, one per GPU (what mp.spawn does for the reference,
+        # src/main.py:178-188). The ranks run this same file under torch.distributed.run and rank 0 prints the JSON line.
+        import socket
+        import subprocess
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        env = {**os.environ, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0")}
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stderr.write("[bench] launching %d ranks: %s\n" % (args.gpus, " ".join(cmd)))
+        sys.exit(subprocess.call(cmd, env=env))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -262,13 +352,23 @@ def main():
         else:
             dist.init_process_group(backend="nccl", init_method="env://", device_id=device)
         group = dist.group.WORLD
-    assert world == args.gpus or world == 1, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different job size")
 
     import studiogan_amd
     from studiogan_amd import _lib as L
     from studiogan_amd import ops
     from studiogan_amd.worker import Worker
 
+    rccl_ranks = None
+    if world > 1 and (args.native_comm or os.environ.get("SG_NATIVE_COMM") == "1") and not one_dev:
+        # the exchanges through the C ABI (sg_allreduce_flat / sync-BN all-reduces on HIP streams) instead of torch.distributed
+        from studiogan_amd import comm as sg_comm
+        nc = sg_comm.enable(group, device=device)
+        n = ctypes.c_int(0)
+        L.call("sg_comm_size", nc.handle, ctypes.byref(n))
+        rccl_ranks = n.value
+        assert rccl_ranks == world, f"native communicator has {rccl_ranks} ranks, job has {world}"
     wl = WORKLOADS[args.workload]
     mixed = not args.fp32
     torch.manual_seed(1234)  # identical initial weights on every rank (what DDP's initial broadcast guarantees)
@@ -280,7 +380,8 @@ def main():
     w = Worker(G, D, wl["z_dim"], wl["classes"], args.batch, "hinge", wl["g_lr"], wl["d_lr"], wl["beta1"], wl["beta2"],
                d_updates_per_step=wl["n_d"], apply_g_ema=True, g_ema_decay=0.9999, g_ema_start=20000, group=group)
     torch.manual_seed(1234 + rank)  # per-rank sampling streams (reference src/loader.py:99)
-    real = synth_batches(wl["n_d"], args.batch, wl["img_size"], wl["classes"], device, 1234 + rank)
+    n_d = wl["n_d"]
+    pool = generator_real_pool(G, min(32, n_d * (args.warmup + args.steps + 2)), args.batch, wl["z_dim"], wl["classes"], device, 1234 + rank)
 
     def barrier():
         torch.cuda.synchronize()
@@ -290,7 +391,7 @@ def main():
 
     tw = time.perf_counter()
     for i in range(args.warmup):
-        w.step(i, real)
+        w.step(i, baskets(pool, i, n_d))
     barrier()
     if rank == 0:
         sys.stderr.write(f"[bench] warmup {args.warmup} step(s): {time.perf_counter() - tw:.2f}s\n")
@@ -298,13 +399,15 @@ def main():
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
-        last = w.step(args.warmup + i, real)
+        last = w.step(args.warmup + i, baskets(pool, args.warmup + i, n_d))
     barrier()
     elapsed = time.perf_counter() - t0
     # the step must have produced numbers: finite losses of the last timed step (read AFTER the timed region: a host sync)
     d_last, g_last = (float(last[0]), float(last[1])) if last is not None else (float("nan"), float("nan"))
     import math
     assert math.isfinite(d_last) and math.isfinite(g_last), f"non-finite losses after the timed steps: D {d_last} G {g_last}"
+    # the hinge must still be active on the LAST timed step: a saturated discriminator (d_loss == 0) backpropagates exact zeros
+    assert d_last > 1e-2, f"discriminator saturated in the timed region (d_loss {d_last}): the measured step would multiply zero gradients"
     fake_chk = w.last_g[0]
     assert bool(torch.isfinite(fake_chk).all()) and float(fake_chk.abs().max()) <= 1.0, "generator images of the last step are not finite / not in [-1, 1]"
     prof = (ctypes.c_double * 9)()
@@ -318,7 +421,7 @@ def main():
     # 21.673 GFLOP/img whole forward, 21.170 GFLOP/img conv-only; conv-only time = hipEvent brackets of the conv launches.
     dfwd = None
     if args.workload == "biggan128" and rank == 0:
-        x, y = real[0]
+        x, y = pool[0]
         with torch.no_grad():
             for _ in range(2):
                 D(x, y)
@@ -348,7 +451,7 @@ def main():
         L.call("sg_prof_enable", 2)          # bit 1: spectral norm, batch norm, attention score kernels, Adam / EMA
         hsteps = 2
         for i in range(hsteps):
-            w.step(args.warmup + args.steps + i, real)
+            w.step(args.warmup + args.steps + i, baskets(pool, args.warmup + args.steps + i, n_d))
         barrier()
         ph = (ctypes.c_double * 21)()
         L.call("sg_prof_collect", ph, 7)
@@ -398,6 +501,7 @@ def main():
             dist.destroy_process_group()
         return
 
+    failed = []
     ms_per_step = 1e3 * elapsed / args.steps
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
@@ -421,9 +525,14 @@ def main():
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16" if mixed else "f32", "data": "synthetic",
+        "data_note": f"{len(pool)} distinct real baskets per rank, cycled: uint8-grid samples of a frozen copy of the initial generator "
+                     "(keeps the hinge active: d_loss > 1e-2 is asserted on the last timed step); z / labels drawn on the device every update",
         "last_step_losses": {"d_loss": round(d_last, 5), "g_loss": round(g_last, 5)},
         "config": {"workload": wl["desc"], "per_gpu_batch": args.batch, "global_batch": global_batch, "d_updates_per_step": wl["n_d"],
-                   "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else "")},
+                   "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else ""),
+                   "exchange": None if world == 1 else ("libsgamd sg_allreduce_flat (native RCCL communicator)" if rccl_ranks else
+                                                        ("gloo (one-device plumbing run)" if one_dev else "torch.distributed nccl backend (= RCCL)")),
+                   "rccl_ranks": rccl_ranks},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                      "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
@@ -442,23 +551,35 @@ def main():
     if wl["gflop"]:
         out["step_tflops"] = round(wl["gflop"] * global_batch / 1e3 / (ms_per_step * 1e-3), 2)  # whole-step algorithmic TFLOP/s
     if world == 1 and not args.no_extras and args.workload == "biggan128":
-        del w, G, D, real
+        del w, G, D, pool
         torch.cuda.empty_cache()
         out["extra_workloads"] = {}
         for name in EXTRAS:
             try:
                 out["extra_workloads"][name] = run_extra(name, device)
-            except Exception as ex:      # an extra must never take the headline line down
+            except Exception as ex:      # an extra never takes the headline line down, but it is counted and (--strict) fails the run
                 out["extra_workloads"][name] = {"error": repr(ex)[:300]}
-        w = G = D = real = None
+                failed.append(name)
+                sys.stderr.write(f"[bench] EXTRA WORKLOAD FAILED: {name}: {ex!r}\n")
+        w = G = D = pool = None
     if not args.no_cpu_baseline and world == 1:
-        w = G = D = real = None
+        w = G = D = pool = None
         torch.cuda.empty_cache()
         sys.stderr.write("[bench] gpu result: " + json.dumps(out) + "\n")
         out["cpu_baseline"] = cpu_baseline(args.workload, args.cpu_batch)
+        # C1 / C2 at their FULL batch, and the Inception forward at B = 32, next to their GPU legs
+        for name, bound in (("dcgan32_bs64_fp32", 90), ("sngan32_bs256_fp32", 170)):
+            if isinstance(out.get("extra_workloads", {}).get(name), dict) and "error" not in out["extra_workloads"][name]:
+                out["extra_workloads"][name]["cpu_baseline"] = cpu_baseline(name, 0, bound)
+        if fid is not None:
+            out["fid_extract"]["cpu_baseline_inception"] = cpu_baseline("inception", 32, 120, "samples/sec")
+    out["failed_legs"] = failed
     print(json.dumps(out))
+    sys.stdout.flush()
     if world > 1:
         dist.destroy_process_group()
+    if failed and args.strict:
+        sys.exit(3)
 
 
 if __name__ == "__main__":

@@ -265,6 +265,11 @@ class WeightBank:
         """Next graph slot (ring order) whose previous forward can no longer run a backward. A D step with several penalties
         (apply_gp + apply_dra / apply_maxgp, bCR / zCR) keeps more forwards waiting for ONE backward than the initial ring holds:
         the ring grows (288 GB of HBM) instead of silently recycling a slot whose sigma / u / v / operand images are still needed."""
+        # `self.current` is only a convenience pointer for standalone modules: it must not be what keeps the previous forward's handle
+        # (and with it a whole slot: img + f32 + dwt + uv copies of the network, ~1 GB for BigGAN's D) alive. Autograd nodes and the
+        # caller's output tensors hold their own references; hold graph outputs across iterations (e.g. log an undetached loss) and the
+        # ring grows by one slot per forward until MAX_SLOTS -- detach what you keep.
+        self.current = self.slots[0]
         n = len(self.slots) - 1
         for k in range(1, n + 1):
             idx = (self._ring + k - 1) % n + 1
@@ -277,7 +282,11 @@ class WeightBank:
                                "spectral-norm state of the oldest one (raise WeightBank.MAX_SLOTS if this is intended)")
         sl = self._new_slot(len(self.slots))
         self.slots.append(sl)
+        self.nslots = len(self.slots)
         self._ring = sl.index
+        import sys
+        sys.stderr.write(f"[studiogan_amd] weight bank grew to {self.nslots - 1} graph slots: {self.nslots - 2} earlier forwards of this network still "
+                         "hold their graph (several penalties in one D step is expected; otherwise detach the outputs you keep across iterations)\n")
         return sl
 
     # -- forward ------------------------------------------------------------------------------------------

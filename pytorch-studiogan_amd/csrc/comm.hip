@@ -28,16 +28,24 @@ static fn_count p_count; static fn_errstr p_errstr;
 
 static int rccl_load() {
   if (g_rccl) return 0;
-  const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+  // 1. the copy this process already carries (PyTorch-ROCm maps its own torch/lib/librccl.so): RTLD_NOLOAD finds it by soname
+  //    without mapping a second, possibly different, RCCL; 2. only then a fresh load.
+  const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1"};
+  for (int i = 0; i < 2 && !g_rccl; i++) g_rccl = dlopen(names[i], RTLD_NOW | RTLD_NOLOAD | RTLD_GLOBAL);
   for (int i = 0; i < 3 && !g_rccl; i++) g_rccl = dlopen(names[i], RTLD_NOW | RTLD_GLOBAL);
-  if (!g_rccl) { sg_set_error("sg_comm: librccl.so.1 not found"); return -3; }
+  if (!g_rccl) { sg_set_error("sg_comm: librccl.so not found"); return -3; }
   p_get_uid = (fn_get_uid)dlsym(g_rccl, "ncclGetUniqueId");
   p_init_rank = (fn_init_rank)dlsym(g_rccl, "ncclCommInitRank");
   p_destroy = (fn_destroy)dlsym(g_rccl, "ncclCommDestroy");
   p_allreduce = (fn_allreduce)dlsym(g_rccl, "ncclAllReduce");
   p_count = (fn_count)dlsym(g_rccl, "ncclCommCount");
   p_errstr = (fn_errstr)dlsym(g_rccl, "ncclGetErrorString");
-  if (!p_get_uid || !p_init_rank || !p_destroy || !p_allreduce || !p_count) { sg_set_error("sg_comm: RCCL symbols missing"); g_rccl = nullptr; return -3; }
+  if (!p_get_uid || !p_init_rank || !p_destroy || !p_allreduce || !p_count) {
+    sg_set_error("sg_comm: RCCL symbols missing");
+    dlclose(g_rccl);
+    g_rccl = nullptr;
+    return -3;
+  }
   return 0;
 }
 static int rccl_fail(const char* what, int rc) {

@@ -6,7 +6,8 @@
 #include "common.h"
 #include "../../include/sgamd.h"
 
-// y[r] = x[r] / max(|x[r]|, eps); inv[r] = 1 / max(|x[r]|, eps)          (torch.nn.functional.normalize(dim=1); cosine-similarity rows)
+// y[r] = x[r] / max(|x[r]|, eps); inv[r] = +-1 / max(|x[r]|, eps)        (torch.nn.functional.normalize(dim=1); cosine-similarity rows)
+// The SIGN of inv[r] is the "clamped" flag of the backward: negative = |x[r]| < eps, the row was divided by the constant eps.
 __global__ __launch_bounds__(256) void k_row_normalize_fwd(const float* x, float* y, float* inv, int rows, int cols, float eps) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -14,11 +15,13 @@ __global__ __launch_bounds__(256) void k_row_normalize_fwd(const float* x, float
   float acc = 0.f;
   for (int c = lane; c < cols; c += 64) { const float v = x[(long long)r * cols + c]; acc += v * v; }
   acc = wave_sum(acc);
-  const float iv = 1.f / fmaxf(sqrtf(acc), eps);
+  const float nrm = sqrtf(acc);
+  const float iv = 1.f / fmaxf(nrm, eps);
   for (int c = lane; c < cols; c += 64) y[(long long)r * cols + c] = x[(long long)r * cols + c] * iv;
-  if (lane == 0) inv[r] = iv;
+  if (lane == 0) inv[r] = nrm < eps ? -iv : iv;
 }
-// dx = inv * (dy - y <y, dy>)    (rows whose norm was clamped by eps are treated like the unclamped ones: |x| >> eps on this path)
+// dx = inv * (dy - y <y, dy>); rows whose norm was clamped (inv < 0): y = x / eps is linear in x, so dx = dy / eps -- what autograd
+// gives for x / clamp_min(|x|, eps) (zero-initialised or collapsed embeddings / proxies)
 __global__ __launch_bounds__(256) void k_row_normalize_bwd(const float* y, const float* inv, const float* dy, float* dx, int rows, int cols) {
   const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= rows) return;
@@ -26,7 +29,8 @@ __global__ __launch_bounds__(256) void k_row_normalize_bwd(const float* y, const
   float dot = 0.f;
   for (int c = lane; c < cols; c += 64) dot += y[(long long)r * cols + c] * dy[(long long)r * cols + c];
   dot = wave_sum(dot);
-  const float iv = inv[r];
+  float iv = inv[r];
+  if (iv < 0.f) { iv = -iv; dot = 0.f; }
   for (int c = lane; c < cols; c += 64) dx[(long long)r * cols + c] = iv * (dy[(long long)r * cols + c] - y[(long long)r * cols + c] * dot);
 }
 extern "C" int sg_row_normalize_fwd(const float* x, float* y, float* inv, int rows, int cols, float eps, sg_stream_t s) {
@@ -86,11 +90,13 @@ __global__ __launch_bounds__(256) void k_xent(const float* z, const int64_t* lab
   float se = 0.f;
   for (int c = lane; c < cols; c += 64) se += expf(zr[c] - m);
   se = wave_sum(se);
-  const int t = (int)label[r];
+  const long long tl = label[r];
+  const bool bad = tl < 0 || tl >= cols;          // a label outside the head (e.g. an ADC label 2C-1 against a C-wide head): poison, never read out of bounds
+  const int t = bad ? 0 : (int)tl;
   const float lse = m + logf(se);
-  if (lane == 0) row_loss[r] = lse - zr[t];
+  if (lane == 0) row_loss[r] = bad ? NAN : lse - zr[t];
   const float invr = 1.f / rows;
-  for (int c = lane; c < cols; c += 64) dz[(long long)r * cols + c] = (expf(zr[c] - lse) - (c == t ? 1.f : 0.f)) * invr;
+  for (int c = lane; c < cols; c += 64) dz[(long long)r * cols + c] = bad ? NAN : (expf(zr[c] - lse) - (c == t ? 1.f : 0.f)) * invr;
 }
 // Crammer-Singer multi-hinge (losses.py:242-252): row_loss = relu(1 + max_{c != label} z[c] - z[label]); dz of the mean
 __global__ __launch_bounds__(256) void k_crammer_singer(const float* z, const int64_t* label, int rows, int cols, float* row_loss, float* dz) {
@@ -98,7 +104,9 @@ __global__ __launch_bounds__(256) void k_crammer_singer(const float* z, const in
   if (r >= rows) return;
   const int lane = threadIdx.x & 63;
   const float* zr = z + (long long)r * cols;
-  const int t = (int)label[r];
+  const long long tl = label[r];
+  const bool bad = tl < 0 || tl >= cols;          // out-of-range label: NaN loss / gradient instead of an out-of-bounds read
+  const int t = bad ? 0 : (int)tl;
   float m = -INFINITY; int arg = 0x7fffffff;
   for (int c = lane; c < cols; c += 64) { if (c != t) { const float v = zr[c]; if (v > m) { m = v; arg = c; } } }
   // wave argmax; among equal values the LOWEST index (what torch.max returns on the masked row)
@@ -108,9 +116,9 @@ __global__ __launch_bounds__(256) void k_crammer_singer(const float* z, const in
   }
   const float l = 1.f + m - zr[t];
   const bool on = l > 0.f;
-  if (lane == 0) row_loss[r] = on ? l : 0.f;
+  if (lane == 0) row_loss[r] = bad ? NAN : (on ? l : 0.f);
   const float invr = 1.f / rows;
-  for (int c = lane; c < cols; c += 64) dz[(long long)r * cols + c] = on ? ((c == arg ? invr : 0.f) - (c == t ? invr : 0.f)) : 0.f;
+  for (int c = lane; c < cols; c += 64) dz[(long long)r * cols + c] = bad ? NAN : (on ? ((c == arg ? invr : 0.f) - (c == t ? invr : 0.f)) : 0.f);
 }
 // fixed-order mean of the row losses (deterministic): loss[0] = sum_r row_loss[r] / rows
 __global__ __launch_bounds__(256) void k_mean_rows(const float* row_loss, int rows, float* loss) {
@@ -208,7 +216,7 @@ extern "C" int sg_contrastive_loss(int kind, const float* S, const float* p, con
 // out[r] = z[r][label[r]]  /  dz[r][c] = (c == label[r]) * g[r]        (multi-discriminator head: adv_output[idx, label])
 __global__ __launch_bounds__(256) void k_gather_cols(const float* z, const int64_t* label, int rows, int cols, float* out) {
   const int r = blockIdx.x * 256 + threadIdx.x;
-  if (r < rows) out[r] = z[(long long)r * cols + label[r]];
+  if (r < rows) { const long long t = label[r]; out[r] = (t < 0 || t >= cols) ? NAN : z[(long long)r * cols + t]; }
 }
 __global__ __launch_bounds__(256) void k_scatter_cols(const float* g, const int64_t* label, int rows, int cols, float* dz) {
   for (long long i = blockIdx.x * 256ll + threadIdx.x; i < (long long)rows * cols; i += (long long)gridDim.x * 256) {

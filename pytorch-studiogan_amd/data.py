@@ -11,7 +11,10 @@ from . import _lib as L
 
 
 class DeviceDataset:
-    def __init__(self, imgs, labels, device="cuda", random_flip=True, seed=0):
+    def __init__(self, imgs, labels, device="cuda", random_flip=True, seed=0, rank=None, world_size=None):
+        """rank / world_size: the data-parallel shard this process draws from (default: torch.distributed's, 0 / 1 without it). Every rank
+        keeps the SAME per-epoch permutation (generator seeded with `seed`) and takes perm[rank::world] of it -- the DistributedSampler of the
+        reference (src/loader.py:153-171, shuffle=True, drop_last=True); the flip stream is seeded with seed + 1 + rank."""
         imgs = torch.as_tensor(np.ascontiguousarray(imgs) if isinstance(imgs, np.ndarray) else imgs)
         if imgs.dtype != torch.uint8 or imgs.dim() != 4 or imgs.shape[3] != 3:
             raise RuntimeError("expected uint8 images [N, H, W, 3] (the HDF5 layout of the reference)")
@@ -20,8 +23,18 @@ class DeviceDataset:
         self.labels = torch.as_tensor(labels).long().to(self.device).contiguous()
         assert self.labels.shape[0] == self.imgs.shape[0]
         self.random_flip = random_flip
-        self.gen = torch.Generator(device=self.device)
+        if rank is None or world_size is None:
+            import torch.distributed as dist
+            ddp = dist.is_available() and dist.is_initialized()
+            rank = (dist.get_rank() if ddp else 0) if rank is None else rank
+            world_size = (dist.get_world_size() if ddp else 1) if world_size is None else world_size
+        if not (0 <= rank < world_size):
+            raise RuntimeError(f"DeviceDataset: rank {rank} outside world of {world_size}")
+        self.rank, self.world_size = int(rank), int(world_size)
+        self.gen = torch.Generator(device=self.device)          # the shared permutation stream: identical on every rank
         self.gen.manual_seed(seed)
+        self.flip_gen = torch.Generator(device=self.device)     # per-rank augmentation stream
+        self.flip_gen.manual_seed(seed + 1 + self.rank)
         self._perm, self._pos, self.epoch = None, 0, 0
 
     @classmethod
@@ -37,6 +50,10 @@ class DeviceDataset:
     def __len__(self):
         return self.imgs.shape[0]
 
+    def shard_len(self):
+        """samples per epoch of THIS rank (DistributedSampler(drop_last=True): the ragged tail is dropped so every rank steps equally often)"""
+        return len(self) // self.world_size
+
     def gather(self, idx, flip=None):
         """images [B, H, W, 3] uint8 and labels [B] of the given sample indices (device tensors); flip: optional uint8 mask [B]."""
         idx = idx.to(self.device).long().contiguous()
@@ -51,8 +68,13 @@ class DeviceDataset:
     def _next_indices(self, n):
         """sequential sampling without replacement over a per-epoch permutation (DataLoader(shuffle=True, drop_last=True) semantics)."""
         N = len(self)
-        if self._perm is None or self._pos + n > N:
-            self._perm = torch.randperm(N, device=self.device, generator=self.gen)
+        per_rank = self.shard_len()
+        if n > per_rank:
+            raise RuntimeError(f"DeviceDataset: a basket of {n} samples exceeds this rank's shard of {per_rank} "
+                               f"({N} images over {self.world_size} rank(s)): lower batch_size * d_updates_per_step * acml_steps")
+        if self._perm is None or self._pos + n > per_rank:
+            full = torch.randperm(N, device=self.device, generator=self.gen)          # same draw on every rank
+            self._perm = full[self.rank:per_rank * self.world_size:self.world_size]   # perm[rank::world], tail dropped
             self._pos = 0
             self.epoch += 1
         idx = self._perm[self._pos:self._pos + n]
@@ -65,6 +87,6 @@ class DeviceDataset:
         idx = self._next_indices(n)
         flip = None
         if self.random_flip:
-            flip = (torch.rand(n, device=self.device, generator=self.gen) < 0.5).to(torch.uint8)      # transforms.RandomHorizontalFlip(p=0.5)
+            flip = (torch.rand(n, device=self.device, generator=self.flip_gen) < 0.5).to(torch.uint8)      # transforms.RandomHorizontalFlip(p=0.5)
         imgs, labs = self.gather(idx, flip)
         return torch.split(imgs, batch_size), torch.split(labs, batch_size)

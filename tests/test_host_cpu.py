@@ -329,3 +329,34 @@ def test_pil_coefficient_tables_reproduce_pillow(filt, sizes):
         out[yy] = k[yy, :cnt] @ hor[y0:y0 + cnt]
     err = float(np.abs(out - ref).max())      # Pillow keeps the intermediate image in float32: ~1e-4 on a 0..255 range
     assert err <= 3e-3, err
+
+
+def test_device_dataset_shards_like_a_distributed_sampler():
+    """data.DeviceDataset under data parallelism (ADVICE r2): every rank draws the SAME per-epoch permutation and takes perm[rank::world] of it
+    (reference src/loader.py:153-171: DistributedSampler(shuffle=True, drop_last=True)), so the ranks' baskets are disjoint and together cover
+    world * (N // world) samples per epoch; the flip streams differ per rank; an oversized basket raises instead of coming back short.
+    Index logic only (no kernel call): runs on the CPU."""
+    from studiogan_amd.data import DeviceDataset
+    N, world = 103, 4
+    imgs = torch.zeros(N, 4, 4, 3, dtype=torch.uint8)
+    labels = torch.arange(N)
+    shards = [DeviceDataset(imgs, labels, device="cpu", seed=5, rank=r, world_size=world) for r in range(world)]
+    per = N // world
+    assert all(s.shard_len() == per for s in shards)
+    seen = [torch.cat([s._next_indices(5) for _ in range(per // 5)]) for s in shards]
+    allidx = torch.cat(seen)
+    assert allidx.unique().numel() == allidx.numel() == world * (per // 5) * 5, "the ranks' baskets of one epoch must be disjoint"
+    assert all(s.epoch == 1 for s in shards)
+    # same seed, same epoch -> same permutation on every rank: rank r holds exactly perm[r::world]
+    full = torch.randperm(N, generator=torch.Generator().manual_seed(5))
+    for r, s in enumerate(shards):
+        assert torch.equal(s._perm, full[r:per * world:world])
+    # next epoch: a new shared permutation, again disjoint
+    nxt = [s._next_indices(per) for s in shards]
+    assert all(s.epoch == 2 for s in shards) and torch.cat(nxt).unique().numel() == per * world
+    assert shards[0].flip_gen.initial_seed() != shards[1].flip_gen.initial_seed()
+    with pytest.raises(RuntimeError, match="exceeds this rank's shard"):
+        shards[0]._next_indices(per + 1)
+    # one rank, no process group: the whole data set, as before
+    ds = DeviceDataset(imgs, labels, device="cpu", seed=5)
+    assert ds.world_size == 1 and ds.shard_len() == N
