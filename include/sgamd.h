@@ -75,6 +75,19 @@ typedef struct {
 } sg_conv_fwd_desc;
 int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream);
 
+/* Residual-block tail in ONE launch (bf16): out = epilogue( alpha * [ conv3x3(x; w) + conv1x1(up2?(x2); w2) ] + bias + bias2 ).
+ * Replaces `x0 = conv2d0(x0); out = x + x0` of the reference's blocks (src/models/big_resnet.py:28-42 GenBlock with nearest x2 on the
+ * skip input, :221-242 DiscBlock where main and skip are both average-pooled: pooling is linear, so the sum is pooled once).
+ * main: a 3x3 / stride 1 / pad 1 problem WITHOUT SG_PIX_UPSAMPLE; SG_PIX_RELU applies to x and x2 alike. x2: [N, Ho(/2), Wo(/2), ldx2] NHWC
+ * with C2 % 32 == 0 channels, w2: [Cout][C2]. sg_conv2d_fwd_skip_ok() == 1 when the fused kernel takes the problem (else run two launches). */
+typedef struct {
+  sg_conv_fwd_desc main;
+  const void* x2; const void* w2; const float* bias2;
+  int C2, ldx2, x2_up;
+} sg_conv_skip_desc;
+int sg_conv2d_fwd_skip(const sg_conv_skip_desc* d, sg_stream_t stream);
+int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d);
+
 /* dw[co][r][s][c] += alpha * sum_{n,ho,wo} dy'[n,ho,wo,co] * x'[n, ho*stride-pad+r, wo*stride-pad+s, c] (fp32 atomics) */
 typedef struct {
   int dtype;

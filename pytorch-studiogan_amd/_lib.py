@@ -28,6 +28,10 @@ class ConvFwdDesc(C.Structure):
                 ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i)]
 
 
+class ConvSkipDesc(C.Structure):
+    _fields_ = [("main", ConvFwdDesc), ("x2", _vp), ("w2", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i), ("x2_up", _i)]
+
+
 class ConvWgradDesc(C.Structure):
     _fields_ = [("dtype", _i), ("N", _i), ("xHs", _i), ("xWs", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("gHs", _i), ("gWs", _i),
                 ("Cout", _i), ("ldg", _i), ("g_flags", _i), ("Ho", _i), ("Wo", _i), ("R", _i), ("S", _i), ("stride", _i),
@@ -73,6 +77,8 @@ _PROTOS = {
     "sg_prof_enable": [_i],
     "sg_prof_collect": [C.POINTER(C.c_double), _i],
     "sg_conv2d_fwd": [C.POINTER(ConvFwdDesc), _vp],
+    "sg_conv2d_fwd_skip": [C.POINTER(ConvSkipDesc), _vp],
+    "sg_conv2d_fwd_skip_ok": [C.POINTER(ConvSkipDesc)],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_conv2d_wgrad_plan": [C.POINTER(ConvWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_wgrad_fuses_bias": [C.POINTER(ConvWgradDesc)],

@@ -3,8 +3,10 @@
 studiogan_amd.ops modules. Module / parameter / buffer names are identical to the reference's, so state_dicts
 interchange. Each block is a short chain of fused launches:
 
-  GenBlock   cBN+ReLU -> [up x2 + conv3x3] -> cBN+ReLU -> conv3x3 -> [up x2 + conv1x1 + residual add]     (5 launches + 4 tiny GEMMs)
-  DiscBlock  [ReLU + conv3x3] -> [ReLU + conv3x3 + avgpool] -> [ReLU + conv1x1 + avgpool + residual add]  (3 launches)
+  GenBlock   cBN+ReLU -> [up x2 + conv3x3] -> cBN+ReLU -> [conv3x3 + (up x2 + conv1x1 skip) fused]              (4 launches + 4 tiny GEMMs)
+  DiscBlock  [ReLU + conv3x3] -> [ReLU + conv3x3 + (ReLU + conv1x1 skip) + avgpool, fused]                 (2 launches)
+  (the 1x1 skip convolution rides in the block's last 3x3 launch as extra K-slices: functional.ConvSkipFn / csrc/conv_v4.h SKIP;
+   shapes the fused kernel does not take run as two chained launches)
 
 compute dtype: bf16 activations / weight images with fp32 accumulation, statistics, master weights and gradients when
 `mixed_precision=True` (the reference's fp16 autocast + GradScaler, big_resnet.py:124,350, becomes scaler-free bf16),
@@ -48,8 +50,8 @@ class GenBlock(nn.Module):
         h = self.bn1.forward_nhwc(x, affine, slot, relu=True)
         h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
-        h = self.conv2d2.forward_nhwc(h, slot)
-        return self.conv2d0.forward_nhwc(x, slot, in_upsample=True, res=h)
+        # conv2d2(h) + conv2d0(up(x)): one launch, the skip as extra K-slices (functional.ConvSkipFn)
+        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True)
 
 
 class Generator(nn.Module):
@@ -191,9 +193,10 @@ class DiscBlock(nn.Module):
             # nn.ReLU(inplace=True) on x also rewrites the skip tensor x0 (same storage) in the reference:
             # both paths see relu(x)  (reference big_resnet.py:221-242, config.py:476)
             h = self.conv2d1.forward_nhwc(x, slot, in_relu=True)
-            h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=self.downsample)
             if self.downsample or self.ch_mismatch:
-                return self.conv2d0.forward_nhwc(x, slot, in_relu=True, out_pool=self.downsample, res=h)
+                # pool(conv2d2(relu h)) + pool(conv2d0(relu x)) = pool(conv2d2(relu h) + conv2d0(relu x)): one launch (functional.ConvSkipFn)
+                return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, in_relu=True, out_pool=self.downsample)
+            h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=False)
             return F.AddReluFn.apply(h, x)
         h = self.bn1.forward_nhwc(x, relu=True)
         h = self.conv2d1.forward_nhwc(h, slot)

@@ -127,6 +127,38 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   return 0;
 }
 
+// fused 3x3 + 1x1-skip launch (conv_v4.h SKIP). dry: eligibility only.
+static int conv_fwd_skip(const sg_conv_skip_desc* sk, hipStream_t st, bool dry) {
+  const sg_conv_fwd_desc* d = &sk->main;
+  if (d->dtype != SG_DTYPE_BF16 || d->R != 3 || d->S != 3 || d->stride != 1 || (d->pix_flags & (SG_PIX_UPSAMPLE | SG_PIX_TRANSPOSED))) return 0;
+  const int K = 9 * d->C, I = d->Cout;
+  const long long Jll = (long long)d->N * d->Ho * d->Wo;
+  if (Jll >= (1ll << 31) || (long long)d->N * d->Hs * d->Ws * d->ldx >= (1ll << 31)) return 0;
+  const int J = (int)Jll;
+  int pflags = d->pix_flags;
+  if (d->epi_flags & SG_EPI_POOL) { if ((d->Ho & 1) || (d->Wo & 1)) return 0; pflags |= SG_PIX_QUAD; } else pflags &= ~SG_PIX_QUAD;
+  Epilogue<bf16_t> e;
+  e.out = d->out; e.out_bstride = 0; e.ldo = d->ldo; e.bias = d->bias;
+  e.res = d->res; e.res_bstride = 0; e.ldr = d->ldr; e.beta = d->beta;
+  e.mask = (const bf16_t*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
+  e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
+  if (dry) return sg_conv_fwd_v4_skip_try(d, sk, e, I, J, K, pflags, st, true) ? 1 : 0;
+  const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * ((double)K + (double)sk->C2), 0);
+  const bool ok = sg_conv_fwd_v4_skip_try(d, sk, e, I, J, K, pflags, st, false);
+  sg_prof_end(st, prof);
+  return ok ? 1 : 0;
+}
+extern "C" int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d) {
+  if (!d || !d->main.x || !d->main.w || !d->main.out || !d->x2 || !d->w2) return 0;
+  return conv_fwd_skip(d, nullptr, true);
+}
+extern "C" int sg_conv2d_fwd_skip(const sg_conv_skip_desc* d, sg_stream_t stream) {
+  SG_CHECK(d && d->main.x && d->main.w && d->main.out && d->x2 && d->w2, "sg_conv2d_fwd_skip: null pointer");
+  SG_CHECK(conv_fwd_skip(d, (hipStream_t)stream, false) == 1, "sg_conv2d_fwd_skip: problem not eligible for the fused kernel (ask sg_conv2d_fwd_skip_ok first)");
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream) {
   SG_CHECK(d && d->x && d->w && d->out, "sg_conv2d_fwd: null pointer");
   SG_CHECK(d->N > 0 && d->C > 0 && d->Cout > 0 && d->R > 0 && d->S > 0 && d->stride > 0, "sg_conv2d_fwd: bad shape");

@@ -34,6 +34,7 @@ struct ConvV3Params {
   unsigned xbytes, wbytes;
   int zero_off, bias_off; // LDS byte offsets of the zero line / bias vector (behind the output staging area)
   int dump_off;           // 1 KiB of LDS that absorbs the DMA pieces a wave has no use for (see "branch-free DMA" below)
+  int pm4, psh;           // image-row parity term of the chunk swizzle (quad row order, W >= 16; see conv_v4.h): chunk ^= ((pixel >> psh) & pm4), pm4 = 4 or 0
 };
 
 // W3: three weight buffers (PB2 only). The weights of tap t+1 are then complete and visible one barrier EARLIER than they are
@@ -97,7 +98,9 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
     unsigned off = poff0;
     asm volatile("" : "+v"(off));     // (same: one live address per piece in flight, not one per piece of the slice)
     off += (unsigned)i * pstep + (unsigned)s * 128u;
-    const bool ok = en && ((unsigned)pix < (unsigned)p.npix_src) && (s * 64 + lc * 8 < p.C);
+    const int lce = lc ^ ((pix >> p.psh) & p.pm4);                  // quad row order: the image-row parity joins the swizzle key
+    off += (unsigned)((lce - lc) * 16);
+    const bool ok = en && ((unsigned)pix < (unsigned)p.npix_src) && (s * 64 + lce * 8 < p.C);
     off = ok ? off : 0x80000000u;
     char* dst = en ? smem + buf * patch_bytes + (wave + NW * i) * 1024 : dump;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)dst, 16, (int)off, 0, 0, 0);
@@ -199,7 +202,8 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
         if (tr == 2) row += rs2[b];
         if (ts == 0) row += cs0[b];
         if (ts == 2) row += cs2[b];
-        unsigned a = (unsigned)poff + (((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1)) & 7) << 4));
+        const int ipar = ((row + P0) >> p.psh) & p.pm4;
+        unsigned a = (unsigned)poff + (((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1) ^ ipar) & 7) << 4));
         a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
         qa[b] = a;
       }
@@ -314,7 +318,8 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v3_kernel(ConvV3Params p
         if (tr == 2) row += rs2[b];
         if (ts == 0) row += cs0[b];
         if (ts == 2) row += cs2[b];
-        unsigned a = ((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1)) & 7) << 4);
+        const int ipar = ((row + P0) >> p.psh) & p.pm4;
+        unsigned a = ((unsigned)row << 7) | ((unsigned)((fhi ^ (row >> 1) ^ ipar) & 7) << 4);
         a = ((qinv[b] >> t) & 1u) ? (unsigned)(p.zero_off - (PB2 ? (s & 1) : 0) * patch_bytes) : a;
         qa[b] = a;
       }

@@ -50,6 +50,13 @@ bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, in
   p.npx = (up ? BJ / 4 : BJ) + 2 * d->Ws + 16;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.zero_off = 0; p.bias_off = 0; p.dump_off = 0;
+  {   // image-row parity in the chunk swizzle: quad row order with W >= 16 (conv_v4.h has the derivation); SG_SWZ_PAR=0 switches it off (A/B)
+    static int par_mode = -1;
+    if (par_mode < 0) { const char* ep = getenv("SG_SWZ_PAR"); par_mode = (ep && ep[0] == '0') ? 0 : 1; }
+    const bool on = par_mode && quad && p.wlog >= 4;
+    p.pm4 = on ? 4 : 0;
+    p.psh = on ? p.wlog - 2 : 0;
+  }
   if (((p.npx >> 3) + 7) / 8 >= 19) return false;           // would need more than 2 patch pieces per tap and wave (never with <= 160 KB of LDS)
   {   // SG_V3_NW4=1: four-wave variants of the 192 / 128-wide tiles (A/B switch)
     const char* e4 = getenv("SG_V3_NW4");

@@ -11,6 +11,11 @@
 //   * the pixel operand is staged once per 32-CHANNEL slice as a raster patch ([tile + one image row + 8 pixels either side] x 64 B,
 //     chunk swizzle c ^ (row >> 2 & 3): any 16 consecutive rows are conflict-free for ds_read_b128), 33 KB at W = 128; the nine taps
 //     read it at shifted rows exactly like conv_v3.h; weights stream per tap: 32 NB x 64 B, three buffers, two taps ahead;
+//     Quad row order (2 x 2 pooling epilogue / pooling-sum data gradient) puts pixels (h, w) and (h + 1, w) into the same 16-lane group of a
+//     ds_read_b128; their patch rows differ by W, a multiple of 16, so the row-keyed swizzle gave them the same 16-byte slot: a 2-way
+//     conflict on every B-fragment read of those layers (10-26 % of the LDS cycles in profiles/r02_conv_sq_counters_final.txt). The
+//     swizzle therefore also carries the PARITY OF THE IMAGE ROW (bit 1 of the chunk index ^= parity), applied on the DMA source side and
+//     in the fragment addresses; W = 8 / 4 patches are conflict-free as they are (rows r, r + 8 already differ in the key);
 //   * operand LDS 52 KB, staged epilogue 53 KB -> three workgroups per CU (12 waves, 3 per SIMD, from different workgroups: one
 //     computes while another loads its patch or stores its tile). One barrier (4 waves) per tap = per 4 NB MFMAs of a wave.
 // Row bookkeeping (raster / quad order, nearest x2 upsample on load, image-border masks) is conv_v3.h's; epilogue: sg_conv_epilogue.
@@ -29,12 +34,25 @@ struct ConvV4Params {
   int npx;                // patch pixels (multiple of 16) >= BJ(/4 with upsample) + 2 W + 16
   unsigned xbytes, wbytes;
   int wgt_off, zero_off, bias_off;   // LDS byte offsets: weight buffers, zero line, bias vector
+  int pm2, psh;           // image-row parity term of the chunk swizzle: chunk ^= ((pixel >> psh) & pm2), pm2 = 2 (quad row order, W >= 16) or 0
+  // fused 1x1 skip convolution (SKIP instantiations): acc += conv1x1(up2?(x2); w2) as extra K-slices at the centre tap
+  const bf16_t* x2; const bf16_t* w2; const float* bias2;
+  int C2, ldx2, up2, nslice2, npix2;   // C2 % 32 == 0; up2: x2 is at half resolution (nearest x2 on load); npix2 = N * Hs2 * Ws2
+  unsigned x2bytes, w2bytes;
 };
 
 // TJW = 32-pixel blocks per wave: 2 (tile 256 pixels, 6 accumulator blocks per wave for NB = 3, three workgroups per CU) or 4 (tile 512 pixels,
 // 12 accumulator blocks: 7 fragment reads per 12 MFMAs instead of 5 per 6, two workgroups per CU; the staged epilogue runs in two halves)
-template <int NB, bool RELU, bool UP, int TJW>
+//
+// SKIP: the residual block's 1x1 skip convolution rides in the same launch (reference src/models/big_resnet.py:177-192,221-242:
+// `x0 = conv2d0(x0); out = x + x0`). pool(conv3x3(h)) + pool(conv1x1(x)) = pool(conv3x3(h) + conv1x1(x)), and for a generator block
+// conv3x3(h) + conv1x1(up(x)): the skip is C2 / 32 more K-slices of the same accumulators, each a single (centre) tap, fed from a second
+// input tensor and a second weight matrix. After the main loop the patch area is free: slice by slice the skip input of the tile's own
+// pixels (no halo) is staged there (one source pixel per 2 x 2 outputs with up2) next to its 32 NB x 32 weights. This removes the skip's
+// launch, its read-modify-write of the block output and the 1x1 kernel's tile overheads.
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+  static_assert(!SKIP || (!UP && TJW == 2), "the fused skip is built for the plain 256-pixel tile");
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -53,7 +71,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   char* const pbufs = smem + p.wgt_off;
   float* sbias = (float*)(smem + p.bias_off);
   if (epi.bias) {
-    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+    for (int i = tid; i < BI; i += 64 * NW) {
+      float b = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+      if (SKIP && p.bias2 && i0 + i < epi.I) b += p.bias2[i0 + i];
+      sbias[i] = b;
+    }
   }
   if (tid < 32) ((unsigned*)(smem + p.zero_off))[tid] = 0u;
 
@@ -72,7 +94,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   auto patch_slice = [&](int s) {
     for (int g = wave; g < ngroups; g += NW) {
       const int pix = pix0 + 16 * (g - wave);
-      unsigned off = (unsigned)pix * ldx2 + (unsigned)(s * 64 + lc * 16);
+      const int lce = lc ^ ((pix >> p.psh) & p.pm2);
+      unsigned off = (unsigned)pix * ldx2 + (unsigned)(s * 64 + lce * 16);
       off = ((unsigned)pix < (unsigned)p.npix_src) ? off : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
     }
@@ -178,7 +201,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
           if (ts == 0) row -= 1;
           if (ts == 2) row += 1;
         }
-        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
+        const int ipar = ((row + P0) >> p.psh) & p.pm2;          // image-row parity of the patch row (x 2)
+        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2) ^ ipar) & 3) << 4);
         a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
         qa[b] = a;
       }
@@ -217,6 +241,74 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
     }
   }
 
+  if constexpr (SKIP) {
+    // the main loop ended behind vmcnt(0) + barrier: patch area and weight buffers are free
+    const auto rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, (int)p.x2bytes, 0x00020000);
+    const auto rsw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2bytes, 0x00020000);
+    const unsigned ldx2b = 2u * (unsigned)p.ldx2;
+    const int Q0 = p.up2 ? (j0 >> 2) : j0;                 // first skip-input pixel (raster) of this tile: the tile covers whole pairs of image rows
+    const int ng2 = (p.up2 ? BJ / 4 : BJ) >> 4;            // groups of 16 pixels
+    int rb2[TJ];
+#pragma unroll
+    for (int b = 0; b < TJ; b++) {
+      const int r = rb[b] + P0;                            // raster index of the output pixel (the main conv is not UP: patch row + P0)
+      if (p.up2) {
+        const int wo = r & (p.Wo - 1), t = r >> p.wshift, ho = t & (p.Ho - 1), n = t >> p.hshift;
+        rb2[b] = (((n * (p.Ho >> 1) + (ho >> 1)) << (p.wshift - 1)) + (wo >> 1)) - Q0;
+      } else {
+        rb2[b] = r - Q0;
+      }
+    }
+    for (int s2 = 0; s2 < p.nslice2; s2++) {
+      for (int g = wave; g < ng2; g += NW) {
+        const int pix = Q0 + 16 * g + sub;
+        const int lce = lc ^ ((pix >> p.psh) & p.pm2);
+        unsigned off = (unsigned)pix * ldx2b + (unsigned)(s2 * 64 + lce * 16);
+        off = ((unsigned)pix < (unsigned)p.npix2) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
+      }
+      for (int g = wave; g < NWP; g += NW) {
+        const int row = i0 + 16 * g + sub;
+        unsigned off = ((unsigned)row * (unsigned)p.C2 + (unsigned)(s2 * 32 + lc * 8)) * 2u;
+        off = (row < p.I) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (sg_lptr_t)(pbufs + g * 1024), 16, (int)off, 0, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      unsigned qa[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        const int row = rb2[b];
+        const int ipar = ((row + Q0) >> p.psh) & p.pm2;
+        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2) ^ ipar) & 3) << 4);
+        a = ((qinv[b] >> 4) & 1u) ? (unsigned)p.zero_off : a;        // the centre tap is outside only for rows beyond the problem
+        qa[b] = a;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8_t pf[TI], qf[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          u32x4 v = *(const u32x4*)(pbufs + (wa[a] ^ (unsigned)(ks * 32)));
+          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                        // everyone is done reading before the next slice (or the epilogue's staging) overwrites
+    }
+  }
+
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
   if constexpr (TJW == 2) {
@@ -238,19 +330,24 @@ static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, i
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU, bool UP, int TJW>
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
 static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
   const int BI = 32 * NB, BJ = 128 * TJW;
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
   return 0;
+}
+template <int NB>
+static inline int sg_launch_conv_v4_skip(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  if (p.flags & SG_PIX_RELU) return sg_launch_conv_v4r<NB, true, false, 2, true>(p, e, st);
+  return sg_launch_conv_v4r<NB, false, false, 2, true>(p, e, st);
 }
 template <int NB, int TJW>
 static inline int sg_launch_conv_v4(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {

@@ -41,7 +41,7 @@ def _c(t):
 # raw launch helpers (also used directly by the kernel-level tests)
 # ---------------------------------------------------------------------------------------------------------
 def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None,
-               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0, x_coff=0):
+               alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0, x_coff=0, desc=None):
     """x: [N,Hs,Ws,ldx] NHWC; returns [N,Ho',Wo',Cout]. w_ptr -> [Cout][R*S*Cin] in x.dtype."""
     N, Hs, Ws = x.shape[0], x.shape[1], x.shape[2]
     ldx = x.shape[3] if ldx is None else ldx
@@ -57,7 +57,7 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
     if out is None:
         odt = torch.float32 if (epi_flags & L.EPI_OUT_F32) else x.dtype
         out = torch.empty((N, Hy, Wy, Cout), dtype=odt, device=x.device)
-    d = L.ConvFwdDesc()
+    d = desc if desc is not None else L.ConvFwdDesc()
     d.dtype = L.dt(x)
     d.N, d.Hs, d.Ws, d.C, d.ldx = N, Hs, Ws, Cin, ldx
     d.Ho, d.Wo, d.Cout = Ho, Wo, Cout
@@ -73,7 +73,28 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
     d.ldo = out.shape[-1]
     d.ldr = res.shape[-1] if res is not None else 0
     d.ldm = mask.shape[-1] if mask is not None else 0
+    if desc is not None:        # the caller launches (conv2d_skip_raw)
+        return out
     L.call("sg_conv2d_fwd", d, L.stream())
+    return out
+
+
+def conv2d_skip_raw(x, w_ptr, Cin, Cout, x2, w2_ptr, C2, x2_up=False, pix_flags=0, epi_flags=0, bias=None, bias2=None, alpha=1.0, dry=False):
+    """[pool]( conv3x3(x; w) + conv1x1(up2?(x2); w2) ) + bias + bias2 in ONE launch (include/sgamd.h sg_conv2d_fwd_skip): the residual block's
+    skip convolution as extra K-slices of its last 3x3 launch. dry=True: only ask whether the fused kernel takes the problem.
+    Returns the output tensor, or None when the problem is not eligible (the caller then runs the two launches)."""
+    sk = L.ConvSkipDesc()
+    out = None
+    if dry:    # eligibility does not depend on the output pointer value, only on its alignment / pitch: a real allocation is made anyway
+        pass
+    out = conv2d_raw(x, w_ptr, Cin, Cout, 3, 3, 1, 1, 1, pix_flags, epi_flags, bias=bias, alpha=alpha, desc=sk.main)
+    sk.x2, sk.w2, sk.bias2 = L.ptr(x2), w2_ptr, L.ptr(bias2)
+    sk.C2, sk.ldx2, sk.x2_up = C2, x2.shape[3], 1 if x2_up else 0
+    if L.lib().sg_conv2d_fwd_skip_ok(L.C.byref(sk)) != 1:
+        return None
+    if dry:
+        return out
+    L.call("sg_conv2d_fwd_skip", sk, L.stream())
     return out
 
 
@@ -345,6 +366,72 @@ class ConvFn(torch.autograd.Function):
             L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())
         dres = dy if ctx.has_res else None
         return dx, None, None, dres, None, None, None
+
+
+class ConvSkipFn(torch.autograd.Function):
+    """y = [avgpool2]( conv3x3(relu?(h)) + b2 + conv1x1(up2?(relu?(x))) + b0 ): the tail of a residual block -- its last 3x3 convolution and its
+    1x1 skip convolution -- as ONE fused launch (conv_v4.h SKIP) when the kernel takes the shape, else as the two launches of ConvFn chained
+    through the residual input. Reference: src/models/big_resnet.py:28-42 (GenBlock: skip on the nearest-upsampled block input),
+    :221-242 (DiscBlock: main and skip both average-pooled; nn.ReLU(inplace=True) makes the skip see relu(x), see backbones/big_resnet.py).
+    backward: the two data gradients and the two weight gradients of the unfused form (the fusion is forward-only)."""
+
+    @staticmethod
+    def forward(ctx, h, x, w2, b2, w0, b0, rt2, rt0, slot, cfg2, cfg0):
+        bank = rt2.bank()
+        h, x = _c(h), _c(x)
+        assert cfg2.R == 3 and cfg0.R == 1 and cfg2.out_pool == cfg0.out_pool and cfg2.in_relu == cfg0.in_relu and not cfg2.in_upsample
+        pf = L.PIX_RELU if cfg2.in_relu else 0
+        ef = L.EPI_POOL if cfg2.out_pool else 0
+        al = 0.25 if cfg2.out_pool else 1.0
+        y = None
+        plain = rt2.rows_pad == rt2.rows and rt0.rows_pad == rt0.rows and b2 is not None and b0 is not None
+        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0]:
+            y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
+                                bias=b2, bias2=b0, alpha=al)
+        if y is None:
+            hh = conv2d_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows_pad, 3, 3, 1, 1, 1, pf, ef, bias=b2, alpha=al)
+            pf0 = pf | (L.PIX_UPSAMPLE if cfg0.in_upsample else 0)
+            y = conv2d_raw(x, bank.w_fwd(slot, rt0), x.shape[3], rt0.rows_pad, 1, 1, 1, 0, 0, pf0, ef, bias=b0, res=hh, alpha=al)
+        ctx.save_for_backward(h, x)
+        ctx.rt2, ctx.rt0, ctx.slot, ctx.cfg2, ctx.cfg0 = rt2, rt0, slot, cfg2, cfg0
+        ctx.w2, ctx.b2, ctx.w0, ctx.b0 = w2, b2, w0, b0
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        h, x = ctx.saved_tensors
+        rt2, rt0, slot, cfg2, cfg0 = ctx.rt2, ctx.rt0, ctx.slot, ctx.cfg2, ctx.cfg0
+        if torch.is_grad_enabled():      # create_graph=True: differentiable data gradients only (see ConvFn.backward)
+            if _param_grad_wanted(ctx.w2, ctx.b2, ctx.w0, ctx.b0):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP path)")
+            dh = ConvDgradFn.apply(dy, h, ctx.w2, rt2, slot, cfg2) if ctx.needs_input_grad[0] else None
+            dx = ConvDgradFn.apply(dy, x, ctx.w0, rt0, slot, cfg0) if ctx.needs_input_grad[1] else None
+            return (dh, dx) + (None,) * 9
+        dy = _c(dy)
+        bank = rt2.bank()
+        outs = []
+        for inp, rt, cfg, w_i, b_i, wp, bp in ((h, rt2, cfg2, 2, 3, ctx.w2, ctx.b2), (x, rt0, cfg0, 4, 5, ctx.w0, ctx.b0)):
+            k = 0 if inp is h else 1
+            N, Hs, Ws, Cin = inp.shape
+            up = 2 if cfg.in_upsample else 1
+            Ho, Wo = Hs * up, Ws * up      # 3x3 pad 1 / 1x1 pad 0, stride 1
+            pool = cfg.out_pool
+            outs.append(_conv_dgrad(dy, inp, rt, slot, cfg) if ctx.needs_input_grad[k] else None)
+            want_db = bp is not None and ctx.needs_input_grad[b_i]
+            db_done = False
+            if ctx.needs_input_grad[w_i]:
+                xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
+                g = ensure_grad(bp) if (want_db and rt.rows_pad == rt.rows) else None
+                db_done = conv2d_wgrad_raw(inp, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, 1, cfg.pad_h, cfg.pad_w, xf,
+                                           L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0, dbias=g)
+            if want_db and not db_done:
+                g = ensure_grad(bp)
+                L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, dy.shape[0] * dy.shape[1] * dy.shape[2], rt.rows, L.ptr(g), 1.0, L.stream())
+        return (outs[0], outs[1]) + (None,) * 9
+
+
+import os as _os
+_SKIP_FUSION = [_os.environ.get("SG_SKIP_FUSION", "1") != "0"]      # tests / A-B runs: SG_SKIP_FUSION=0 (or functional._SKIP_FUSION[0] = False) forces the two-launch form
 
 
 class SliceUpFn(torch.autograd.Function):

@@ -481,3 +481,47 @@ def test_wgrad_v3_full_size_layers(sg):
             outs[mode] = dw.cpu()
         os.environ.pop("SG_WGRAD_V3", None)
         check(f"wgrad v3 full size {(N, Cin, Cout, H, xf, gf)}", outs["1"], outs["0"], 2e-3)
+
+
+SKIP_CASES = [
+    # N, C (3x3 input), Cout, C2 (skip input), H (output res), relu, pool, up2      -- csrc/conv_v4.h SKIP: conv3x3(h) + conv1x1(up2?(x)) in one launch
+    (2, 192, 192, 96, 16, True, True, False),     # DiscBlock 96 -> 192 (quad rows + pooling, ReLU on both inputs), W = 16: image-row parity swizzle
+    (2, 384, 384, 192, 32, True, True, False),    # DiscBlock 192 -> 384 at the benchmarked resolution
+    (3, 96, 96, 192, 32, False, False, True),     # GenBlock 192 -> 96: skip input at half resolution, nearest x2 on load
+    (2, 192, 192, 384, 16, False, False, True),   # GenBlock 384 -> 192
+    (2, 64, 128, 32, 16, True, False, False),     # 128-wide cout tile (NB = 2), no pooling, one skip slice
+    (5, 96, 96, 96, 8, True, True, False),        # 8x8 images, J = 320: partial last tile (rows beyond the problem read the zero line)
+    (1, 768, 768, 384, 16, True, True, False),    # a deep block (C > 384: only the fused path sends it to conv_v4)
+]
+
+
+@pytest.mark.parametrize("case", SKIP_CASES)
+def test_conv_fused_skip_matches_reference_and_two_launches(sg, case):
+    """sg_conv2d_fwd_skip (the residual block's 1x1 skip convolution as extra K-slices of its last 3x3 launch) against CPU fp64 and against
+    the two chained launches it replaces; then functional.ConvSkipFn's backward (data + weight + bias gradients of both convolutions)."""
+    from studiogan_amd import functional as F, _lib as L
+    N, C, Cout, C2, H, relu, pool, up2 = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    H2 = H // 2 if up2 else H
+    h = rnd((N, C, H, H), dt, 41)
+    x = rnd((N, C2, H2, H2), dt, 42)
+    w = rnd((Cout, C, 3, 3), dt, 43, 0.1)
+    w0 = rnd((Cout, C2, 1, 1), dt, 44, 0.1)
+    b, b0 = rnd((Cout,), torch.float32, 45), rnd((Cout,), torch.float32, 46)
+    main = _conv_ref(h, w, 1, 1, relu, False, pool, b, None)
+    skip = _conv_ref(x, w0, 1, 0, relu, up2, pool, b0, None)
+    yref = main + skip
+    hd, xd = nhwc(h).to(d), nhwc(x).to(d)
+    wd, w0d = w.permute(0, 2, 3, 1).contiguous().to(d), w0.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = L.PIX_RELU if relu else 0
+    ef = L.EPI_POOL if pool else 0
+    al = 0.25 if pool else 1.0
+    y = F.conv2d_skip_raw(hd, wd.data_ptr(), C, Cout, xd, w0d.data_ptr(), C2, up2, pf, ef, bias=b.to(d), bias2=b0.to(d), alpha=al)
+    assert y is not None, "the fused kernel must take this shape"
+    hh = F.conv2d_raw(hd, wd.data_ptr(), C, Cout, 3, 3, 1, 1, 1, pf, ef, bias=b.to(d), alpha=al)
+    y2 = F.conv2d_raw(xd, w0d.data_ptr(), C2, Cout, 1, 1, 1, 0, 0, pf | (L.PIX_UPSAMPLE if up2 else 0), ef, bias=b0.to(d), res=hh, alpha=al)
+    torch.cuda.synchronize()
+    check(f"fused skip {case}", nchw(y.float().cpu()), yref, 4e-3)
+    check(f"two launches {case}", nchw(y2.float().cpu()), yref, 6e-3)
+    check(f"fused vs two launches {case}", y.float().cpu(), y2.float().cpu(), 6e-3)

@@ -59,15 +59,15 @@ def test_struct_layouts_match_c():
     import subprocess
     import tempfile
     from studiogan_amd import _lib
-    src = ('#include <stdio.h>\n#include "sgamd.h"\nint main(){printf("%zu %zu %zu %zu %zu\\n", sizeof(sg_conv_fwd_desc), '
-           'sizeof(sg_conv_wgrad_desc), sizeof(sg_gemm_desc), sizeof(sg_sn_layer), sizeof(sg_sn_bwd_layer));return 0;}\n')
+    src = ('#include <stdio.h>\n#include "sgamd.h"\nint main(){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sg_conv_fwd_desc), '
+           'sizeof(sg_conv_wgrad_desc), sizeof(sg_gemm_desc), sizeof(sg_sn_layer), sizeof(sg_sn_bwd_layer), sizeof(sg_conv_skip_desc));return 0;}\n')
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "s.c")
         open(c, "w").write(src)
         exe = os.path.join(d, "s")
         subprocess.run(["gcc", "-I", os.path.join(ROOT, "include"), c, "-o", exe], check=True)
         out = subprocess.run([exe], check=True, stdout=subprocess.PIPE, text=True).stdout.split()
-    sizes = [ctypes.sizeof(x) for x in (_lib.ConvFwdDesc, _lib.ConvWgradDesc, _lib.GemmDesc, _lib.SnLayer, _lib.SnBwdLayer)]
+    sizes = [ctypes.sizeof(x) for x in (_lib.ConvFwdDesc, _lib.ConvWgradDesc, _lib.GemmDesc, _lib.SnLayer, _lib.SnBwdLayer, _lib.ConvSkipDesc)]
     assert [int(v) for v in out] == sizes
 
 
