@@ -359,6 +359,23 @@ int sg_dgemm_tn(const double* A, const double* B, double* C, int n, sg_stream_t 
 int sg_jacobi_sweep(double* M, int n, double* offd, sg_stream_t s);    /* n even; *offd = max |<r_p, r_q>| / (|r_p| |r_q|) met in the sweep */
 int sg_row_norm_sum(const double* M, int n, double* out, sg_stream_t s);
 
+/* ---- StyleGAN2 / StyleGAN3 native operators (the reference's only CUDA code, the .cu files of src/utils/style_ops) ----------------
+ * sg_bias_act: y = clamp(gain * act(x + b)) and its gradient evaluators, the contract of the reference's `_plugin.bias_act(x, b, xref, yref,
+ * dy, grad, dim, act, alpha, gain, clamp)` (bias_act.cpp:27-94, kernel bias_act.cu:23-147). Elementwise over n values; the bias element of
+ * value i is b[(i / step_b) % size_b] (step_b = product of the dimensions behind `dim`). act = cuda_idx of bias_act.py:20-30 (1 linear,
+ * 2 relu, 3 lrelu, 4 tanh, 5 sigmoid, 6 elu, 7 selu, 8 softplus, 9 swish). grad = 0: forward (xref / yref / dy unused); grad = 1: x is the
+ * incoming gradient, yref the forward output (xref the forward input for swish); grad = 2: second-order term, dy the first-order gradient.
+ * b, xref, yref, dy may be NULL. fp32 or bf16, all tensors of the same dtype, 16-byte aligned. */
+int sg_bias_act(int dtype, const void* x, const void* b, const void* xref, const void* yref, const void* dy, void* y, long long n,
+                long long step_b, int size_b, int grad, int act, float alpha, float gain, float clamp, sg_stream_t s);
+/* sg_upfirdn2d: pad -> upsample by zero insertion -> 2-D FIR filter -> decimate in one pass over `planes` = N * C image planes
+ * (x [planes][H][W] -> y [planes][Ho][Wo], Ho = (H * upy + pady0 + pady1 - fh + downy) / downy, likewise Wo): the reference's
+ * `_plugin.upfirdn2d(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)` (upfirdn2d.cpp:25-100, kernels
+ * upfirdn2d.cu:29-104). f: fp32 [fh][fw] on the device; without flip_filter the operator is a true convolution (the filter is flipped).
+ * Negative padding crops. gain multiplies the result. */
+int sg_upfirdn2d(int dtype, const void* x, const float* f, void* y, int planes, int H, int W, int fh, int fw, int upx, int upy,
+                 int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip_filter, float gain, sg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -167,6 +167,8 @@ _PROTOS = {
     "sg_u8_to_nhwc": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
     "sg_gather_images_u8": [_vp, _vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp],
     "sg_topk_scatter": [_vp, _vp, _i, _vp, _i, _vp],
+    "sg_bias_act": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _f, _f, _f, _vp],
+    "sg_upfirdn2d": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
 }
 
 

@@ -259,28 +259,49 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
         rb2[b] = r - Q0;
       }
     }
-    for (int s2 = 0; s2 < p.nslice2; s2++) {
+    // Pipeline: RING staging slots (skip-input patch + weight tile each), slices RING - 1 ahead, ONE barrier per slice like the main loop:
+    // the barrier at the top of slice s2 says "slice s2 has landed for every wave" and "every wave is done with slice s2 - 1", so the slot
+    // of slice s2 - 1 takes slice s2 + RING - 1 right behind it. up2 (generator blocks): 4 KB patches, RING = 3; otherwise 16 KB, RING = 2.
+    const int RING = p.up2 ? 3 : 2;
+    const int P2B = (p.up2 ? BJ / 4 : BJ) * 64;
+    auto issue2 = [&](int s2, int slot) {
       for (int g = wave; g < ng2; g += NW) {
         const int pix = Q0 + 16 * g + sub;
         const int lce = lc ^ ((pix >> p.psh) & p.pm2);
         unsigned off = (unsigned)pix * ldx2b + (unsigned)(s2 * 64 + lce * 16);
         off = ((unsigned)pix < (unsigned)p.npix2) ? off : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (sg_lptr_t)(smem + slot * P2B + g * 1024), 16, (int)off, 0, 0, 0);
       }
       for (int g = wave; g < NWP; g += NW) {
         const int row = i0 + 16 * g + sub;
         unsigned off = ((unsigned)row * (unsigned)p.C2 + (unsigned)(s2 * 32 + lc * 8)) * 2u;
         off = (row < p.I) ? off : 0x80000000u;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (sg_lptr_t)(pbufs + g * 1024), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (sg_lptr_t)(pbufs + slot * PB + g * 1024), 16, (int)off, 0, 0, 0);
       }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    };
+    const int n2 = p.nslice2;
+    for (int i = 0; i < RING - 1 && i < n2; i++) issue2(i, i);
+    int slot = 0;
+    for (int s2 = 0; s2 < n2; s2++) {
+      // pieces this wave has in flight for ONE later slice (up2 only: 1 patch piece + 1 or 2 weight pieces); the wait leaves exactly those
+      const bool later = p.up2 && (s2 + 1 < n2);
+      if (!later) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      else if (two) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      {
+        const int nxt = s2 + RING - 1;
+        int nslot = slot + RING - 1; if (nslot >= RING) nslot -= RING;
+        if (nxt < n2) issue2(nxt, nslot);
+      }
+      const char* ps = pbufs + slot * PB;
+      const unsigned pbase = (unsigned)(slot * P2B);
       unsigned qa[TJ];
 #pragma unroll
       for (int b = 0; b < TJ; b++) {
         const int row = rb2[b];
         const int ipar = ((row + Q0) >> p.psh) & p.pm2;
-        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2) ^ ipar) & 3) << 4);
+        unsigned a = pbase + (((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2) ^ ipar) & 3) << 4));
         a = ((qinv[b] >> 4) & 1u) ? (unsigned)p.zero_off : a;        // the centre tap is outside only for rows beyond the problem
         qa[b] = a;
       }
@@ -289,7 +310,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
         bf16x8_t pf[TI], qf[TJ];
 #pragma unroll
         for (int a = 0; a < TI; a++) {
-          u32x4 v = *(const u32x4*)(pbufs + (wa[a] ^ (unsigned)(ks * 32)));
+          u32x4 v = *(const u32x4*)(ps + (wa[a] ^ (unsigned)(ks * 32)));
           pf[a] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
@@ -304,8 +325,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();                        // everyone is done reading before the next slice (or the epilogue's staging) overwrites
+      slot = slot + 1 == RING ? 0 : slot + 1;
     }
   }
 
@@ -320,19 +340,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
 }
 
 // LDS need (bytes) of a configuration
-static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off) {
+static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off, int skip_patch_bytes = 0) {
   const int BI = 32 * NB;
-  const int ops = npx * 64 + 3 * BI * 64;
+  // (a fused skip stages its own patches at the start of the operand area: the weight buffers must lie behind them too)
+  const int woff = npx * 64 > skip_patch_bytes ? npx * 64 : skip_patch_bytes;
+  const int ops = woff + 3 * BI * 64;
   const int stage = 256 * (BI * 2 + 16);
   const int body = ops > stage ? ops : stage;
-  if (wgt_off) *wgt_off = npx * 64;
+  if (wgt_off) *wgt_off = woff;
   if (zero_off) *zero_off = body;
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
 template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
 static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
+  const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {

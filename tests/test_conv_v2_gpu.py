@@ -524,4 +524,4 @@ def test_conv_fused_skip_matches_reference_and_two_launches(sg, case):
     torch.cuda.synchronize()
     check(f"fused skip {case}", nchw(y.float().cpu()), yref, 4e-3)
     check(f"two launches {case}", nchw(y2.float().cpu()), yref, 6e-3)
-    check(f"fused vs two launches {case}", y.float().cpu(), y2.float().cpu(), 6e-3)
+    check(f"fused vs two launches {case}", y.float().cpu(), y2.float().cpu(), 1e-2)   # two bf16 results, the unfused one rounded twice

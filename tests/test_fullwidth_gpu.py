@@ -87,7 +87,7 @@ def test_fullwidth_bf16_vs_emulating_oracle(sg, forced, name, which):
 # sqrt(f) per layer is independent of the batch; the error grows layer by layer from the output (conv2d5 1.6 %, block 5 9-13 %, block 0 17 %).
 # With ONE upstream-gradient image shared by all samples (a partly coherent signal ~ N) the oracle's floor falls 16.7 % -> 9.9 % from batch 4 to 32,
 # as does the HIP path's distance. Every comparison is bounded by max(base, 1.5 x the oracle's own movement of that tensor), measured in the test.
-CURVE = [("biggan128w", "D", False, 0.05), ("biggan128w", "G", False, 0.05), ("biggan128w", "G", True, 0.05)]
+CURVE = [("biggan128w", "D", False, 0.05), ("biggan128w", "G", False, 0.10), ("biggan128w", "G", True, 0.10)]
 
 
 @pytest.mark.parametrize("batch", [8, 32])
