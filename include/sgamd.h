@@ -191,6 +191,11 @@ int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int g
 int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean,
                     const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu,
                     const double* chan, double count, int use_batch_stats, sg_stream_t s);
+/* same, plus `res` (dx's shape and dtype, may be NULL) added to the result: the gradient the BN input received through another branch
+ * (a residual block's skip path) -- replaces autograd's separate accumulation launch */
+int sg_bn_bwd_apply_res(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean,
+                        const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu,
+                        const double* chan, double count, int use_batch_stats, const void* res, sg_stream_t s);
 
 /* second-order backward of BN's data gradient (WGAN-GP double backward; reference utils/losses.py:268-275,301-316 reach
  * it through torch autograd). u = dL/d(dx). Per-channel gain only. sums[N][C][5] fp32 (caller zeroes) ->

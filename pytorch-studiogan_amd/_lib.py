@@ -111,6 +111,7 @@ _PROTOS = {
     "sg_bn_bwd_reduce": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
     "sg_bn_bwd_finalize": [_vp, _i, _i, _vp, _i, _vp, _vp, _vp, _vp],
     "sg_bn_bwd_apply": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _i, _vp],
+    "sg_bn_bwd_apply_res": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, C.c_double, _i, _vp, _vp],
     "sg_bn_bwd2_reduce": [_i, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp, _vp],
     "sg_bn_bwd2_finalize": [_vp, _i, _i, _vp, _vp],
     "sg_bn_bwd2_dgain": [_vp, _vp, C.c_double, _vp, _i, _i, _vp, _vp],

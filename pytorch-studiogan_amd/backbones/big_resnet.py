@@ -47,11 +47,12 @@ class GenBlock(nn.Module):
         self.conv2d2 = MODULES.g_conv2d(in_channels=out_channels, out_channels=out_channels, kernel_size=3, stride=1, padding=1)
 
     def forward_nhwc(self, x, affine, slot):
-        h = self.bn1.forward_nhwc(x, affine, slot, relu=True)
+        link = F.GradLink()      # x feeds bn1 and the skip: bn1's backward adds the skip's gradient in its own launch (no autograd add)
+        h = self.bn1.forward_nhwc(x, affine, slot, relu=True, link=link)
         h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
         # conv2d2(h) + conv2d0(up(x)): one launch, the skip as extra K-slices (functional.ConvSkipFn)
-        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True)
+        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True, link=link)
 
 
 class Generator(nn.Module):
@@ -192,10 +193,12 @@ class DiscBlock(nn.Module):
         if self.apply_d_sn:
             # nn.ReLU(inplace=True) on x also rewrites the skip tensor x0 (same storage) in the reference:
             # both paths see relu(x)  (reference big_resnet.py:221-242, config.py:476)
-            h = self.conv2d1.forward_nhwc(x, slot, in_relu=True)
             if self.downsample or self.ch_mismatch:
+                link = F.GradLink()      # x feeds conv2d1 and the skip: conv2d1's data gradient takes the skip's gradient as its residual
+                h = self.conv2d1.forward_nhwc(x, slot, in_relu=True, link=link)
                 # pool(conv2d2(relu h)) + pool(conv2d0(relu x)) = pool(conv2d2(relu h) + conv2d0(relu x)): one launch (functional.ConvSkipFn)
-                return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, in_relu=True, out_pool=self.downsample)
+                return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, in_relu=True, out_pool=self.downsample, link=link)
+            h = self.conv2d1.forward_nhwc(x, slot, in_relu=True)
             h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=False)
             return F.AddReluFn.apply(h, x)
         h = self.bn1.forward_nhwc(x, relu=True)

@@ -34,7 +34,7 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   if (!aligned16(d->x) || !aligned16(d->w)) return false;
   // the kernel's only epilogue: bf16 rows, 16-byte stores; its ReLU-mask OR residual tile (bf16) is pre-staged with 16-byte loads
   if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
-  if (e.mask && e.res) return false;
+  // (mask AND residual together: sg_conv_epilogue condenses the mask tile to register bits, then stages the residual tile)
   if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
   if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   const int tj = (J + 255) / 256;

@@ -59,11 +59,10 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
   const int rows_out = pool ? BJ / 4 : BJ;
   const int jbase = pool ? (j0 >> 2) : j0, Jout = pool ? (epi.J >> 2) : epi.J;
   constexpr int CPR = BI / 8;                  // 16-byte chunks per output row
-  const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // at most one of them (launcher), bf16, 16-byte aligned rows
+  const bool pre_mask = epi.mask != nullptr, pre_res = epi.res != nullptr;    // bf16, 16-byte aligned rows (launcher)
+  const bool pre_both = pre_mask && pre_res;
   const int ncr = ((epi.I - i0 < BI ? epi.I - i0 : BI) + 7) >> 3;             // 16-byte chunks of an output row that exist (cout tail tile)
-  if (pre_mask || pre_res) {
-    const bf16_t* src = pre_mask ? epi.mask : (const bf16_t*)epi.res;
-    const int ld = pre_mask ? epi.ldm : epi.ldr;
+  auto stage_tile = [&](const bf16_t* src, int ld) {
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
@@ -71,6 +70,39 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
       if (jg < Jout && c < ncr) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
       *(u32x4*)(smem + r * CP + c * 16) = t;
     }
+  };
+  // ReLU mask AND residual in one launch (the data gradient of a block's first convolution taking the skip path's gradient as its residual:
+  // dx = mask(x) * F^T(dh) + dx_skip -- the sum autograd would otherwise run as its own elementwise launch): the staging area holds one tile,
+  // so the mask tile goes first and is condensed to 16 bits per accumulator block in registers, then the residual tile takes its place.
+  uint32_t mbits[TI * TJ];
+#pragma unroll
+  for (int q = 0; q < TI * TJ; q++) mbits[q] = 0u;
+  if (pre_both) {
+    stage_tile(epi.mask, epi.ldm);
+    __syncthreads();
+    if (active) {
+#pragma unroll
+      for (int ta = 0; ta < TI; ta++)
+#pragma unroll
+        for (int tb = 0; tb < TJ; tb++) {
+          const int jl = wj0 + tb * 32 + (lane & 31);
+          const int jo = pool ? (jl >> 2) : jl;
+          uint32_t bits = 0u;
+#pragma unroll
+          for (int g4 = 0; g4 < 4; g4++) {
+            const int il = wi0 + ta * 32 + 8 * g4 + 4 * (lane >> 5);
+            const u32x2 m = *(const u32x2*)(smem + jo * CP + il * 2);
+#pragma unroll
+            for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (bf2f(h) > 0.f) bits |= 1u << (4 * g4 + e); }
+          }
+          mbits[ta * TJ + tb] = bits;
+        }
+    }
+    __syncthreads();
+    stage_tile((const bf16_t*)epi.res, epi.ldr);
+    __syncthreads();
+  } else if (pre_mask || pre_res) {
+    stage_tile(pre_mask ? epi.mask : (const bf16_t*)epi.res, pre_mask ? epi.ldm : epi.ldr);
     __syncthreads();
   }
   const bool relu_out = (epi.flags & SG_EPI_RELU) != 0;
@@ -100,7 +132,11 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
 #pragma unroll
             for (int e = 0; e < 4; e++) v[e] += b[e];
           }
-          if (pre_mask) {
+          if (pre_both) {
+            const uint32_t bits = mbits[ta * TJ + tb] >> (4 * g4);
+#pragma unroll
+            for (int e = 0; e < 4; e++) if (!((bits >> e) & 1u)) v[e] = 0.f;
+          } else if (pre_mask) {
             const u32x2 m = *(const u32x2*)loc;
 #pragma unroll
             for (int e = 0; e < 4; e++) { const bf16_t h = (bf16_t)((m[e >> 1] >> (16 * (e & 1))) & 0xffffu); if (!(bf2f(h) > 0.f)) v[e] = 0.f; }

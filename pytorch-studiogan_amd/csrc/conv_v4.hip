@@ -32,7 +32,7 @@ bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc*
   const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2, wbytes = (long long)I * K * 2;
   if (xbytes >= (1ll << 31) || wbytes >= (1ll << 31)) return false;
   if ((e.flags & (SG_EPI_ATOMIC | SG_EPI_OUT_F32)) || (e.ldo & 7) || !aligned16(e.out)) return false;
-  if (e.mask && e.res) return false;
+  // (mask AND residual together: sg_conv_epilogue condenses the mask tile to register bits, then stages the residual tile)
   if (e.mask && ((e.ldm & 7) || !aligned16(e.mask))) return false;
   if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   int NB;

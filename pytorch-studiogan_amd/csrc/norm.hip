@@ -367,7 +367,9 @@ extern "C" int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* 
   SG_LAUNCH_CHECK();
   return 0;
 }
-template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* x, const T* dy, T* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch) {
+// res (optional): a tensor of dx's shape ADDED to the result -- the gradient the same input received through another branch (a residual block's
+// skip path), so that the sum autograd would run as its own elementwise launch rides in this one.
+template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_bwd_apply(const T* x, const T* dy, T* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch, const T* res) {
   constexpr int V = VECP ? ET<T>::VEC : 1;
   const int CV = C / V;
   const long long total = (long long)N * HW * CV;
@@ -391,12 +393,18 @@ template <typename T, bool VECP> __global__ __launch_bounds__(256) void k_bn_bwd
       if (use_batch) d -= ((float)chan[2 * c] + xh * (float)chan[2 * c + 1]) * invc;
       xv[e] = d * is;
     }
+    if (res) {
+      float rv[V];
+      if (VECP) unpack16<T>(*(const u32x4*)(res + pix * C + c0), rv); else rv[0] = to_f<T>(res[pix * C + c0]);
+#pragma unroll
+      for (int e = 0; e < V; e++) xv[e] += rv[e];
+    }
     if (VECP) *(u32x4*)(dx + pix * C + c0) = pack16<T>(xv); else dx[pix * C + c0] = from_f<T>(xv[0]);
   }
 }
 // Streaming variant (same ownership as k_bn_apply_stream): a thread keeps the 6 per-channel coefficients of its 16-byte
 // channel vector in registers; the loop body is 2 loads -> ~6 flops per element -> 1 store.
-template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stream(const T* x, const T* dy, T* dx, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch, int ppb) {
+template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stream(const T* x, const T* dy, T* dx, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, const double* chan, double count, int use_batch, int ppb, const T* res) {
   constexpr int V = ET<T>::VEC;
   const int CV = C / V;
   const int n = blockIdx.y;
@@ -442,8 +450,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stre
   for (; pix < p1; pix += lanes_p) one(*(const u32x4*)(x + base + pix * C), *(const u32x4*)(dy + base + pix * C), pix);
 }
 extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, const double* chan, double count, int use_batch_stats, sg_stream_t s) {
-  SgProfScope prof((hipStream_t)s, 3.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
+  return sg_bn_bwd_apply_res(dtype, x, dy, dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, nullptr, s);
+}
+extern "C" int sg_bn_bwd_apply_res(int dtype, const void* x, const void* dy, void* dx, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, const double* chan, double count, int use_batch_stats, const void* res, sg_stream_t s) {
+  SgProfScope prof((hipStream_t)s, (res ? 4.0 : 3.0) * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && dy && dx && mean && invstd && chan && count > 0, "sg_bn_bwd_apply: bad args");
+  SG_CHECK(!res || ((((uintptr_t)res) & 15) == 0), "sg_bn_bwd_apply_res: res must be 16-byte aligned");
   DISPATCH_T(dtype, {
     const int CV = C / ET<T>::VEC;
     if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0) && CV <= 256 && N <= 65535 && HW >= 64) {
@@ -451,9 +463,9 @@ extern "C" int sg_bn_bwd_apply(int dtype, const void* x, const void* dy, void* d
       long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
       const int gx = (int)((HW + ppb - 1) / ppb);
-      hipLaunchKernelGGL(k_bn_bwd_apply_stream<T>, dim3(gx, N), dim3(CV * lanes_p), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, (int)ppb);
-    } else if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0)) hipLaunchKernelGGL((k_bn_bwd_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
-    else hipLaunchKernelGGL((k_bn_bwd_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats);
+      hipLaunchKernelGGL(k_bn_bwd_apply_stream<T>, dim3(gx, N), dim3(CV * lanes_p), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, (int)ppb, (const T*)res);
+    } else if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0)) hipLaunchKernelGGL((k_bn_bwd_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, (const T*)res);
+    else hipLaunchKernelGGL((k_bn_bwd_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)dy, (T*)dx, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, chan, count, use_batch_stats, (const T*)res);
   });
   SG_LAUNCH_CHECK();
   return 0;

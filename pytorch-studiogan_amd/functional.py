@@ -4,6 +4,8 @@ Internal activation layout is NHWC ([N,H,W,C] contiguous, fp32 or bf16). Weight 
 WeightBank slot of the current forward (see bank.py). Gradients w.r.t. parameters are written by the kernels straight
 into the gradient arena (``p.grad`` views) -- the Functions return None for parameter inputs on purpose.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -236,8 +238,28 @@ class ConvCfg:
         self.in_relu, self.in_upsample, self.out_pool = in_relu, in_upsample, out_pool
 
 
-def _conv_dgrad(dy, x, rt, slot, cfg):
-    """data gradient of ConvFn's fused launch: dx = relu-mask(x) * F^T(dy), F = pool?(conv(up?(.))) * (0.25 if pool)."""
+class GradLink:
+    """Carries the gradient a residual block's INPUT receives through the skip path from the block tail's backward (ConvSkipFn) to the
+    backward of the block's first operator (ConvFn of a discriminator block, BNFn of a generator block), which adds it in its own launch
+    (sg_conv2d_fwd with mask AND residual / sg_bn_bwd_apply_res). Without it autograd sums the two contributions in a separate elementwise
+    launch per block (343 `add<bf16>` launches, 3.3 ms per C3 step in profiles/r03_bench_biggan128_bs256_kerneltrace_a.txt).
+    The tail's backward always runs first (autograd executes nodes in reverse creation order), stashes its dx here and returns None for
+    that input; create_graph passes (gradient penalty) do not use the link."""
+    __slots__ = ("dx",)
+
+    def __init__(self):
+        self.dx = None
+
+    def take(self):
+        t, self.dx = self.dx, None
+        return t
+
+
+_GRAD_LINK = [os.environ.get("SG_GRAD_LINK", "1") != "0"]      # SG_GRAD_LINK=0: leave the sum to autograd (A/B runs, tests)
+
+
+def _conv_dgrad(dy, x, rt, slot, cfg, res=None):
+    """data gradient of ConvFn's fused launch: dx = relu-mask(x) * F^T(dy) [+ res], F = pool?(conv(up?(.))) * (0.25 if pool)."""
     bank = rt.bank()
     N, Hs, Ws, Cin = x.shape
     up = 2 if cfg.in_upsample else 1
@@ -247,13 +269,13 @@ def _conv_dgrad(dy, x, rt, slot, cfg):
         # strided convolution: gather form of the transposed convolution with the UNflipped [Cin][r][s][Cout] image
         assert not (pool or cfg.in_upsample), "upsample / pooling fusion is stride-1 only"
         return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows_pad, Cin, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, L.PIX_TRANSPOSED, 0,
-                          mask=x if cfg.in_relu else None, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
+                          mask=x if cfg.in_relu else None, res=res, transposed_out_hw=(Hin, Win), ldx=dy.shape[3])
     pf = L.PIX_UPSAMPLE if pool else 0
     ef = L.EPI_POOL if cfg.in_upsample else 0
     # dy has rows_pad channels and the dgrad image is [cin_pad][R][S][rows_pad] (zero outside the real weights): the padded
     # channels ride along so the 16-byte loaders apply; dx comes out with cin_pad channels like x
     return conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows_pad, Cin, cfg.R, cfg.S, 1, cfg.R - 1 - cfg.pad_h, cfg.S - 1 - cfg.pad_w, pf, ef,
-                      mask=x if cfg.in_relu else None, alpha=0.25 if pool else 1.0, ldx=dy.shape[3])
+                      mask=x if cfg.in_relu else None, res=res, alpha=0.25 if pool else 1.0, ldx=dy.shape[3])
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -306,11 +328,12 @@ class ConvFn(torch.autograd.Function):
     """
 
     @staticmethod
-    def forward(ctx, x, weight, bias, res, rt, slot, cfg):
+    def forward(ctx, x, weight, bias, res, rt, slot, cfg, link=None):
         bank = rt.bank()
         x = _c(x)
         N, Hs, Ws, Cin = x.shape
         assert Cin == rt.cin_pad, f"conv input channels {Cin} != {rt.cin_pad}"
+        ctx.link = link
         pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
         ef = L.EPI_POOL if cfg.out_pool else 0
         if res is not None:
@@ -339,7 +362,7 @@ class ConvFn(torch.autograd.Function):
             if _param_grad_wanted(ctx.weight, ctx.bias):
                 raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP path)")
             dx = ConvDgradFn.apply(dy, x, ctx.weight, rt, slot, cfg) if ctx.needs_input_grad[0] else None
-            return dx, None, None, (dy if ctx.has_res else None), None, None, None
+            return dx, None, None, (dy if ctx.has_res else None), None, None, None, None
         dy = _c(dy)
         N, Hs, Ws, Cin = x.shape
         up = 2 if cfg.in_upsample else 1
@@ -349,8 +372,11 @@ class ConvFn(torch.autograd.Function):
         pool = cfg.out_pool
         scale = 0.25 if pool else 1.0
         dx = None
+        skip_dx = ctx.link.take() if ctx.link is not None else None     # the skip path's gradient w.r.t. this same input (GradLink)
         if ctx.needs_input_grad[0]:
-            dx = _conv_dgrad(dy, x, rt, slot, cfg)
+            dx = _conv_dgrad(dy, x, rt, slot, cfg, res=skip_dx)
+        elif skip_dx is not None:
+            raise RuntimeError("GradLink: a skip gradient was handed over but this convolution's input needs no gradient")
         want_db = ctx.bias is not None and ctx.needs_input_grad[2]
         db_done = False
         if ctx.needs_input_grad[1]:
@@ -365,7 +391,7 @@ class ConvFn(torch.autograd.Function):
             rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
             L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, rows, rt.rows, L.ptr(g), 1.0, L.stream())
         dres = dy if ctx.has_res else None
-        return dx, None, None, dres, None, None, None
+        return dx, None, None, dres, None, None, None, None
 
 
 class ConvSkipFn(torch.autograd.Function):
@@ -376,8 +402,9 @@ class ConvSkipFn(torch.autograd.Function):
     backward: the two data gradients and the two weight gradients of the unfused form (the fusion is forward-only)."""
 
     @staticmethod
-    def forward(ctx, h, x, w2, b2, w0, b0, rt2, rt0, slot, cfg2, cfg0):
+    def forward(ctx, h, x, w2, b2, w0, b0, rt2, rt0, slot, cfg2, cfg0, link=None):
         bank = rt2.bank()
+        ctx.link = link
         h, x = _c(h), _c(x)
         assert cfg2.R == 3 and cfg0.R == 1 and cfg2.out_pool == cfg0.out_pool and cfg2.in_relu == cfg0.in_relu and not cfg2.in_upsample
         pf = L.PIX_RELU if cfg2.in_relu else 0
@@ -406,7 +433,7 @@ class ConvSkipFn(torch.autograd.Function):
                 raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP path)")
             dh = ConvDgradFn.apply(dy, h, ctx.w2, rt2, slot, cfg2) if ctx.needs_input_grad[0] else None
             dx = ConvDgradFn.apply(dy, x, ctx.w0, rt0, slot, cfg0) if ctx.needs_input_grad[1] else None
-            return (dh, dx) + (None,) * 9
+            return (dh, dx) + (None,) * 10
         dy = _c(dy)
         bank = rt2.bank()
         outs = []
@@ -427,11 +454,14 @@ class ConvSkipFn(torch.autograd.Function):
             if want_db and not db_done:
                 g = ensure_grad(bp)
                 L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, dy.shape[0] * dy.shape[1] * dy.shape[2], rt.rows, L.ptr(g), 1.0, L.stream())
-        return (outs[0], outs[1]) + (None,) * 9
+        if ctx.link is not None and outs[1] is not None and _GRAD_LINK[0]:
+            # the block's first operator consumes x as well and runs its backward after this one: it adds this gradient in its own launch
+            ctx.link.dx = outs[1]
+            outs[1] = None
+        return (outs[0], outs[1]) + (None,) * 10
 
 
-import os as _os
-_SKIP_FUSION = [_os.environ.get("SG_SKIP_FUSION", "1") != "0"]      # tests / A-B runs: SG_SKIP_FUSION=0 (or functional._SKIP_FUSION[0] = False) forces the two-launch form
+_SKIP_FUSION = [os.environ.get("SG_SKIP_FUSION", "1") != "0"]      # tests / A-B runs: SG_SKIP_FUSION=0 (or functional._SKIP_FUSION[0] = False) forces the two-launch form
 
 
 class SliceUpFn(torch.autograd.Function):
@@ -659,8 +689,10 @@ class BNFn(torch.autograd.Function):
     (reference src/utils/ops.py:14-28,227-228; src/models/model.py:161-165)."""
 
     @staticmethod
-    def forward(ctx, x, gain, bias, running_mean, running_var, cfg):
+    def forward(ctx, x, gain, bias, running_mean, running_var, cfg, *opt):
         x = _c(x)
+        ctx.link = opt[0] if opt else None      # optional 7th argument: a GradLink (see ConvSkipFn)
+        ctx.nopt = len(opt)
         N, H, W, Cc = x.shape
         HW = H * W
         dev = x.device
@@ -710,11 +742,14 @@ class BNFn(torch.autograd.Function):
             if gsn or _param_grad_wanted(gain, bias):
                 raise NotImplementedError("create_graph=True is supported for the input gradient of per-channel BN only (WGAN-GP path)")
             dx = BNBwdFn.apply(dy, x, gain, bias, mean, invstd, cfg, ctx.count) if ctx.needs_input_grad[0] else None
-            return dx, None, None, None, None, None
+            return (dx, None, None, None, None, None) + (None,) * ctx.nopt
         dy = _c(dy)
         N, H, W, Cc = x.shape
         HW = H * W
         dev = x.device
+        skip_dx = ctx.link.take() if ctx.link is not None else None     # the skip path's gradient w.r.t. this same input (GradLink)
+        if skip_dx is not None and not ctx.needs_input_grad[0]:
+            raise RuntimeError("GradLink: a skip gradient was handed over but this batch norm's input needs no gradient")
         sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
         L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), gsn,
                1 if cfg.relu else 0, L.ptr(sums), L.stream())
@@ -727,9 +762,9 @@ class BNFn(torch.autograd.Function):
             if cfg.batch_stats and _world(cfg.group) > 1:
                 _allreduce_sum(chan, cfg.group)
             dx = torch.empty_like(x)
-            L.call("sg_bn_bwd_apply", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
-                   gsn, 1 if cfg.relu else 0, L.ptr(chan), ctx.count, 1 if cfg.batch_stats else 0, L.stream())
-        return dx, dgain, dbias, None, None, None
+            L.call("sg_bn_bwd_apply_res", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
+                   gsn, 1 if cfg.relu else 0, L.ptr(chan), ctx.count, 1 if cfg.batch_stats else 0, L.ptr(_c(skip_dx) if skip_dx is not None else None), L.stream())
+        return (dx, dgain, dbias, None, None, None) + (None,) * ctx.nopt
 
 
 class BNBwdFn(torch.autograd.Function):

@@ -110,12 +110,14 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         self._sg_dgrad_noflip = self.stride[0] != 1     # strided conv: data gradient is a transposed gather (unflipped image)
         self._sg_setup("conv", out_channels, in_channels * kh * kw, in_channels, kh * kw, sn)
 
-    def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None):
+    def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None, link=None):
+        """link: a functional.GradLink shared with the block's tail (conv_skip_nhwc): this convolution's data gradient then also adds the
+        gradient the same input receives through the skip path"""
         rt = self._sg_rt
         slot = slot if slot is not None else rt.bank().current
         kh, kw = self.kernel_size
         cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool)
-        return F.ConvFn.apply(x, self.master_weight, self.bias, res, rt, slot, cfg)
+        return F.ConvFn.apply(x, self.master_weight, self.bias, res, rt, slot, cfg, link)
 
     def forward(self, x):
         slot = _standalone_slot(self, x)
@@ -126,14 +128,14 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         return to_nchw(y)
 
 
-def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False):
+def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False, link=None):
     """Tail of a residual block: [pool](conv_main(relu?(h))) + [pool](conv_skip(up?(relu?(x)))) -- ONE fused launch when the kernel takes the
     shape (functional.ConvSkipFn), the two chained launches otherwise. conv_main: 3x3 / pad 1, conv_skip: 1x1."""
     rt2, rt0 = conv_main._sg_rt, conv_skip._sg_rt
     slot = slot if slot is not None else rt2.bank().current
     cfg2 = F.ConvCfg(3, 3, 1, 1, 1, in_relu, False, out_pool)
     cfg0 = F.ConvCfg(1, 1, 1, 0, 0, in_relu, skip_upsample, out_pool)
-    return F.ConvSkipFn.apply(h, x, conv_main.master_weight, conv_main.bias, conv_skip.master_weight, conv_skip.bias, rt2, rt0, slot, cfg2, cfg0)
+    return F.ConvSkipFn.apply(h, x, conv_main.master_weight, conv_main.bias, conv_skip.master_weight, conv_skip.bias, rt2, rt0, slot, cfg2, cfg0, link)
 
 
 class ConvTranspose2d(_WeightLayerMixin, nn.ConvTranspose2d):
@@ -204,13 +206,13 @@ class BatchNorm2d(nn.BatchNorm2d):
         mom = 0.0 if self.momentum is None else self.momentum
         return F.BNCfg(batch_stats, track, self.eps, mom, relu, self.sync_group)
 
-    def forward_nhwc(self, x, gain=None, bias=None, relu=False):
+    def forward_nhwc(self, x, gain=None, bias=None, relu=False, link=None):
         cfg = self._cfg(relu)
         if cfg.track and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         if gain is None and self.affine:
             gain, bias = self.weight, self.bias
-        return F.BNFn.apply(x, gain, bias, self.running_mean, self.running_var, cfg)
+        return F.BNFn.apply(x, gain, bias, self.running_mean, self.running_var, cfg, link)
 
     def forward(self, x):
         dtype = getattr(self, "compute_dtype", None) or (x.dtype if x.dtype in (torch.float32, torch.bfloat16) else COMPUTE_DTYPE)
@@ -228,10 +230,10 @@ class ConditionalBatchNorm2d(nn.Module):
         self.bias = MODULES.g_linear(in_features=in_features, out_features=out_features, bias=False)
         self.register_buffer("_ones", torch.ones(out_features), persistent=False)
 
-    def forward_nhwc(self, x, y, slot=None, relu=False):
+    def forward_nhwc(self, x, y, slot=None, relu=False, link=None):
         gain = self.gain.forward_rt(y, slot, const_bias=self._ones)  # 1 + gain(y) through the GEMM epilogue bias
         bias = self.bias.forward_rt(y, slot)
-        return self.bn.forward_nhwc(x, gain, bias, relu)
+        return self.bn.forward_nhwc(x, gain, bias, relu, link)
 
     def forward(self, x, y):
         _, bank = _root_and_bank(self.gain)

@@ -1,0 +1,173 @@
+"""upfirdn2d: pad -> upsample (zero insertion) -> FIR filter -> downsample, and the resampling helpers built on it
+(reference src/utils/style_ops/upfirdn2d.py:70-388; plugin contract upfirdn2d.cpp:25-100 -> csrc/style.hip sg_upfirdn2d).
+Tensors are NCHW like the reference's; every (n, c) plane is filtered independently."""
+import numpy as np
+import torch
+
+from .. import _lib as L
+
+
+def _parse_scaling(scaling):
+    if isinstance(scaling, int):
+        scaling = [scaling, scaling]
+    if not (isinstance(scaling, (list, tuple)) and all(isinstance(v, int) for v in scaling) and len(scaling) == 2):
+        raise AssertionError("scaling must be an int or a pair of ints")
+    sx, sy = scaling
+    if sx < 1 or sy < 1:
+        raise AssertionError("scaling factors must be >= 1")
+    return sx, sy
+
+
+def _parse_padding(padding):
+    if isinstance(padding, int):
+        padding = [padding, padding]
+    if not (isinstance(padding, (list, tuple)) and all(isinstance(v, int) for v in padding)):
+        raise AssertionError("padding must be an int or a list of ints")
+    if len(padding) == 2:
+        px, py = padding
+        padding = [px, px, py, py]
+    if len(padding) != 4:
+        raise AssertionError("padding must have 1, 2 or 4 entries")
+    return tuple(padding)      # padx0, padx1, pady0, pady1
+
+
+def _get_filter_size(f):
+    if f is None:
+        return 1, 1
+    if not (isinstance(f, torch.Tensor) and f.dim() in (1, 2)):
+        raise AssertionError("filter must be a 1-D or 2-D tensor")
+    fw, fh = int(f.shape[-1]), int(f.shape[0])
+    if fw < 1 or fh < 1:
+        raise AssertionError("empty filter")
+    return fw, fh
+
+
+def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=False, gain=1, separable=None):
+    """Filter constant for upfirdn2d (reference upfirdn2d.py:70-114): float32; scalars / vectors of >= 8 taps stay separable (1-D) unless asked
+    otherwise, shorter vectors become their outer product; normalised to unit sum; gain spread over the dimensions."""
+    if f is None:
+        f = 1
+    f = torch.as_tensor(f, dtype=torch.float32)
+    if f.dim() not in (0, 1, 2) or f.numel() == 0:
+        raise AssertionError("filter must be a non-empty scalar, vector or matrix")
+    if f.dim() == 0:
+        f = f[np.newaxis]
+    if separable is None:
+        separable = f.dim() == 1 and f.numel() >= 8
+    if f.dim() == 1 and not separable:
+        f = f.ger(f)
+    if f.dim() != (1 if separable else 2):
+        raise AssertionError("separable filters are 1-D, full filters 2-D")
+    if normalize:
+        f = f / f.sum()
+    if flip_filter:
+        f = f.flip(list(range(f.dim())))
+    f = f * (gain ** (f.dim() / 2))
+    return f.to(device=device)
+
+
+def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain):
+    """one sg_upfirdn2d launch; x: dense NCHW fp32 / bf16 on the GPU; f2d: [fh][fw] fp32"""
+    if not x.is_cuda:
+        raise RuntimeError("upfirdn2d: the HIP kernels need a GPU tensor (no CPU fallback on the product path)")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise RuntimeError(f"upfirdn2d: float32 / bfloat16 only, got {x.dtype}")
+    x = x.contiguous()
+    N, C, H, W = x.shape
+    fh, fw = int(f2d.shape[0]), int(f2d.shape[1])
+    Wo = (W * upx + padx0 + padx1 - fw + downx) // downx
+    Ho = (H * upy + pady0 + pady1 - fh + downy) // downy
+    if Wo < 1 or Ho < 1:
+        raise RuntimeError("upfirdn2d: the upsampled and padded image is smaller than the filter")      # upfirdn2d.cpp:49-51
+    y = torch.empty((N, C, Ho, Wo), dtype=x.dtype, device=x.device)
+    f2d = f2d.to(device=x.device, dtype=torch.float32).contiguous()
+    if N * C > 0:
+        L.call("sg_upfirdn2d", L.dt(x), L.ptr(x), L.ptr(f2d), L.ptr(y), N * C, H, W, fh, fw, upx, upy, downx, downy, padx0, padx1, pady0, pady1,
+               1 if flip_filter else 0, float(gain), L.stream())
+    return y
+
+
+_cache = {}
+
+
+def _make(up, down, padding, flip_filter, gain):
+    upx, upy = _parse_scaling(up)
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    key = (upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
+    if key in _cache:
+        return _cache[key]
+
+    class Upfirdn2d(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, f):
+            if not (isinstance(x, torch.Tensor) and x.dim() == 4):
+                raise AssertionError("upfirdn2d: x must be a 4-D NCHW tensor")
+            if f is None:
+                f = torch.ones([1, 1], dtype=torch.float32, device=x.device)
+            if f.dim() == 1 and f.shape[0] == 1:
+                f = f.square().unsqueeze(0)        # a one-tap separable filter is the 1 x 1 filter f^2
+            if not (f.dim() in (1, 2) and f.dtype == torch.float32):
+                raise AssertionError("upfirdn2d: f must be a float32 vector or matrix")
+            if f.dim() == 2:
+                y = _launch(x, f, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain)
+            else:                                  # separable: a horizontal and a vertical pass (upfirdn2d.py:233-235)
+                y = _launch(x, f.unsqueeze(0), upx, 1, downx, 1, padx0, padx1, 0, 0, flip_filter, 1.0)
+                y = _launch(y, f.unsqueeze(1), 1, upy, 1, downy, 0, 0, pady0, pady1, flip_filter, gain)
+            ctx.save_for_backward(f)
+            ctx.x_shape = x.shape
+            return y
+
+        @staticmethod
+        def backward(ctx, dy):
+            (f,) = ctx.saved_tensors
+            _, _, ih, iw = ctx.x_shape
+            _, _, oh, ow = dy.shape
+            fw, fh = _get_filter_size(f)
+            # the adjoint of upfirdn is upfirdn with up <-> down, the filter reversed and this padding (upfirdn2d.py:244-250)
+            p = [fw - padx0 - 1, iw * upx - ow * downx + padx0 - upx + 1, fh - pady0 - 1, ih * upy - oh * downy + pady0 - upy + 1]
+            dx = None
+            if ctx.needs_input_grad[0]:
+                dx = _make(up=[downx, downy], down=[upx, upy], padding=p, flip_filter=(not flip_filter), gain=gain).apply(dy, f)
+            if ctx.needs_input_grad[1]:
+                raise AssertionError("upfirdn2d: the filter is a constant (no gradient)")
+            return dx, None
+
+    _cache[key] = Upfirdn2d
+    return Upfirdn2d
+
+
+def upfirdn2d(x, f, up=1, down=1, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Pad, upsample, filter and downsample a batch of 2-D images (reference upfirdn2d.py:118-160). Pixels outside the image are zero;
+    negative padding crops; without flip_filter the filter is applied as a true convolution."""
+    if not isinstance(x, torch.Tensor):
+        raise AssertionError("upfirdn2d: x must be a tensor")
+    if impl not in ("ref", "cuda"):
+        raise AssertionError("upfirdn2d: impl must be 'ref' or 'cuda'")
+    return _make(up, down, padding, flip_filter, gain).apply(x, f)
+
+
+def filter2d(x, f, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """FIR-filter a batch of images, output padded to the input size (reference upfirdn2d.py:264-298)."""
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + fw // 2, padx1 + (fw - 1) // 2, pady0 + fh // 2, pady1 + (fh - 1) // 2]
+    return upfirdn2d(x, f, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)
+
+
+def upsample2d(x, f, up=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Upsample by an integer factor through the filter, output size a multiple of the input (reference upfirdn2d.py:302-339)."""
+    upx, upy = _parse_scaling(up)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw + upx - 1) // 2, padx1 + (fw - upx) // 2, pady0 + (fh + upy - 1) // 2, pady1 + (fh - upy) // 2]
+    return upfirdn2d(x, f, up=up, padding=p, flip_filter=flip_filter, gain=gain * upx * upy, impl=impl)
+
+
+def downsample2d(x, f, down=2, padding=0, flip_filter=False, gain=1, impl="cuda"):
+    """Downsample by an integer factor through the filter, output size a fraction of the input (reference upfirdn2d.py:343-388)."""
+    downx, downy = _parse_scaling(down)
+    padx0, padx1, pady0, pady1 = _parse_padding(padding)
+    fw, fh = _get_filter_size(f)
+    p = [padx0 + (fw - downx + 1) // 2, padx1 + (fw - downx) // 2, pady0 + (fh - downy + 1) // 2, pady1 + (fh - downy) // 2]
+    return upfirdn2d(x, f, down=down, padding=p, flip_filter=flip_filter, gain=gain, impl=impl)

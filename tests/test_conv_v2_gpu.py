@@ -525,3 +525,40 @@ def test_conv_fused_skip_matches_reference_and_two_launches(sg, case):
     check(f"fused skip {case}", nchw(y.float().cpu()), yref, 4e-3)
     check(f"two launches {case}", nchw(y2.float().cpu()), yref, 6e-3)
     check(f"fused vs two launches {case}", y.float().cpu(), y2.float().cpu(), 1e-2)   # two bf16 results, the unfused one rounded twice
+
+
+MASKRES_CASES = [
+    # N, Cin, Cout, H, R, up, pool, engine env      -- relu-mask AND residual in one epilogue (the data gradient of a block's first convolution + GradLink)
+    (2, 96, 96, 16, 3, False, False, {"SG_CONV_V4": "force"}),
+    (2, 192, 96, 16, 3, False, True, {"SG_CONV_V4": "force"}),                          # pooling-sum epilogue (dgrad of an upsampling convolution)
+    (2, 192, 192, 16, 3, False, False, {"SG_CONV_V4": "0", "SG_CONV_V3": "force"}),
+    (2, 128, 128, 16, 3, True, False, {"SG_CONV_V4": "0", "SG_CONV_V3": "force"}),      # pooled-gradient broadcast on load
+    (2, 192, 96, 16, 1, False, False, {"SG_CONV_SK": "0", "SG_CONV_V2": "force"}),
+    (3, 72, 96, 12, 3, False, False, {"SG_CONV_V4": "0", "SG_CONV_V3": "0", "SG_CONV_V2": "0"}),   # generic engine
+]
+
+
+@pytest.mark.parametrize("case", MASKRES_CASES)
+def test_conv_epilogue_mask_and_residual(sg, case, monkeypatch):
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, R, up, pool, env = case
+    for k, v in env.items():
+        monkeypatch.setenv(k, v)
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    pad = R // 2
+    x = rnd((N, Cin, H, H), dt, 51)
+    w = rnd((Cout, Cin, R, R), dt, 52, 0.1)
+    Ho = H * (2 if up else 1)
+    Hy = Ho // 2 if pool else Ho
+    m = rnd((N, Cout, Hy, Hy), dt, 53)
+    res = rnd((N, Cout, Hy, Hy), dt, 54)
+    y0 = _conv_ref(x, w, 1, pad, False, up, pool, None, None)
+    yref = y0 * (m.double() > 0) + res.double()
+    pf = L.PIX_UPSAMPLE if up else 0
+    ef = L.EPI_POOL if pool else 0
+    wd = w.permute(0, 2, 3, 1).contiguous().to(d)
+    y = F.conv2d_raw(nhwc(x).to(d), wd.data_ptr(), Cin, Cout, R, R, 1, pad, pad, pf, ef,
+                     mask=nhwc(m).to(d), res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
+    torch.cuda.synchronize()
+    check(f"mask + residual {case[:7]}", nchw(y.float().cpu()), yref, 4e-3)
