@@ -80,6 +80,14 @@ EXTRAS = {
                                                   "d_conv_dim": 128, "g_depth": 2, "d_depth": 2}},
                                   batch=256, mixed=True, n_d=2, loss="hinge", g_lr=5e-5, d_lr=2e-4, beta1=0.0, beta2=0.999, gp=False, ema=True,
                                   desc="BigGAN-Deep ImageNet-128 ch 128 depth 2, per-GPU batch 256 of the 2048 global batch, bf16, EMA on (C4 per GPU)"),
+    # C4 at the resolution BASELINE.json names: the same model at img_size 256 (reference src/models/big_resnet_deep_legacy.py:80-95: the "256"
+    # tables; attention in D at 128^2 = 16384 positions), 64 per GPU per micro-step (2048 = 8 GPUs x 64 x 4 accumulation steps)
+    "bigdeep256_bs64_bf16": dict(yaml={"DATA": {"img_size": 256, "num_classes": 1000},
+                                       "MODEL": {"backbone": "big_resnet_deep_legacy", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                                                 "apply_attn": True, "attn_g_loc": [4], "attn_d_loc": [1], "z_dim": 128, "g_shared_dim": 128, "g_conv_dim": 128,
+                                                 "d_conv_dim": 128, "g_depth": 2, "d_depth": 2}},
+                                 batch=64, mixed=True, n_d=2, loss="hinge", g_lr=5e-5, d_lr=2e-4, beta1=0.0, beta2=0.999, gp=False, ema=True,
+                                 desc="BigGAN-Deep ImageNet-256 ch 128 depth 2, per-GPU micro-batch 64 (2048 = 8 x 64 x 4 accumulation steps), bf16, EMA on (C4 at 256^2)"),
 }
 
 

@@ -132,6 +132,16 @@ CONFIGS = {
               "LOSS": {"adv_loss": "hinge"},
               "OPTIMIZATION": {"batch_size": 2, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
         batch=2, n_d=2, seed=34, compact=True, sample=512),
+    # C4 at the resolution BASELINE.json names ("BigGAN-Deep ImageNet-256"): the same yaml with img_size 256 -- the model tables support it
+    # (reference src/models/big_resnet_deep_legacy.py:84,240; SURVEY.md 8(d) "report both 128^2 and 256^2"); attention G@64^2, D@128^2 (HW = 16384)
+    "bigdeep256w": dict(
+        yaml={"DATA": {"name": "ImageNet", "img_size": 256, "num_classes": 1000},
+              "MODEL": {"backbone": "big_resnet_deep_legacy", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_g_sn": True, "apply_d_sn": True,
+                        "apply_attn": True, "attn_g_loc": [4], "attn_d_loc": [1], "z_dim": 128, "g_shared_dim": 128, "g_conv_dim": 128, "d_conv_dim": 128,
+                        "g_depth": 2, "d_depth": 2},
+              "LOSS": {"adv_loss": "hinge"},
+              "OPTIMIZATION": {"batch_size": 2, "g_lr": 0.00005, "d_lr": 0.0002, "beta1": 0.0, "beta2": 0.999, "d_updates_per_step": 2}},
+        batch=2, n_d=2, seed=35, compact=True, sample=512),
 }
 
 SAMPLE = 2048          # compact fixtures: tensors above FULL_MAX elements keep SAMPLE evenly spaced values + [sum, l2]

@@ -437,6 +437,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_bwd_apply_stre
       if (use_batch) d -= (k0[e] + xh * k1[e]) * invc;     // same evaluation order as k_bn_bwd_apply
       xv[e] = d * is[e];
     }
+    if (res) {                                                // the skip path's gradient w.r.t. the same input (see k_bn_bwd_apply)
+      float rv[V];
+      unpack16<T>(*(const u32x4*)(res + base + pix * C), rv);
+#pragma unroll
+      for (int e = 0; e < V; e++) xv[e] += rv[e];
+    }
     *(u32x4*)(dx + base + pix * C) = pack16<T>(xv);
   };
   long long pix = p0 + pl;                                   // four pixels = eight loads in flight per lane (see k_bn_apply_stream)

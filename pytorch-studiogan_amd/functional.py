@@ -412,7 +412,9 @@ class ConvSkipFn(torch.autograd.Function):
         al = 0.25 if cfg2.out_pool else 1.0
         y = None
         plain = rt2.rows_pad == rt2.rows and rt0.rows_pad == rt0.rows and b2 is not None and b0 is not None
-        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0]:
+        # measured (tools/skip_bench.py, profiles/r03_skip_bench_c.txt): the fused launch wins from 16 x 16 outputs up (0.01-0.30 ms per block
+        # tail at batch 256) and loses 0.04-0.06 ms on the 1536-channel 8 x 8 tails, whose 48 one-tap slices are all stop-and-go
+        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all"):
             y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
                                 bias=b2, bias2=b0, alpha=al)
         if y is None:
@@ -461,7 +463,7 @@ class ConvSkipFn(torch.autograd.Function):
         return (outs[0], outs[1]) + (None,) * 10
 
 
-_SKIP_FUSION = [os.environ.get("SG_SKIP_FUSION", "1") != "0"]      # tests / A-B runs: SG_SKIP_FUSION=0 (or functional._SKIP_FUSION[0] = False) forces the two-launch form
+_SKIP_FUSION = [{"0": False, "all": "all"}.get(os.environ.get("SG_SKIP_FUSION", "1"), True)]      # tests / A-B runs: SG_SKIP_FUSION=0 (or functional._SKIP_FUSION[0] = False) forces the two-launch form
 
 
 class SliceUpFn(torch.autograd.Function):

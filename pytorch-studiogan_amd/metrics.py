@@ -75,6 +75,64 @@ def synthetic_state_dict(seed=0):
     return sd
 
 
+# ---- the pin of the published FID network -------------------------------------------------------------------------
+# reference src/metrics/inception_net.py:13,117-130: torchvision inception_v3(num_classes=1008, aux_logits=False) patched with the FID blocks,
+# then `load_state_dict(load_state_dict_from_url(FID_WEIGHTS_URL))`. The file cannot be fetched here, but everything that identifies it can be
+# enforced: its name carries the first 8 hex digits of its sha256 (the torch.hub convention `<name>-<sha256 prefix>.pth`, which
+# load_state_dict_from_url(check_hash=True) verifies), and a strict load needs exactly these tensors with exactly these shapes.
+FID_WEIGHTS_URL = "https://github.com/mseitzer/pytorch-fid/releases/download/fid_weights/pt_inception-2015-12-05-6726825d.pth"
+FID_WEIGHTS_FILE = "pt_inception-2015-12-05-6726825d.pth"
+FID_WEIGHTS_SHA256_PREFIX = "6726825d"
+
+
+def inception_manifest():
+    """{state_dict key: shape} of the FID InceptionV3: 94 BasicConv2d (conv weight without bias + BatchNorm2d(eps 1e-3) weight / bias / running
+    statistics) and the 1008-way fc. `num_batches_tracked` entries are optional (a checkpoint converted from TensorFlow has none and torch's
+    strict load tolerates their absence for such BatchNorm modules)."""
+    m = {}
+    for name, (_, cin, cout, kh, kw, _, _, _) in SPEC.items():
+        m[name + ".conv.weight"] = (cout, cin, kh, kw)
+        for t in ("weight", "bias", "running_mean", "running_var"):
+            m[f"{name}.bn.{t}"] = (cout,)
+    m["fc.weight"] = (1008, 2048)
+    m["fc.bias"] = (1008,)
+    return m
+
+
+def validate_inception_state_dict(sd):
+    """What `inception.load_state_dict(state_dict)` (strict) enforces in the reference: every expected tensor present with its shape, floating
+    point, nothing else in the file. Raises RuntimeError naming the offending keys."""
+    man = inception_manifest()
+    keys = {k for k in sd if not k.endswith("num_batches_tracked")}
+    missing = sorted(set(man) - keys)
+    unexpected = sorted(keys - set(man))
+    wrong = sorted(k for k in man if k in sd and (tuple(sd[k].shape) != man[k] or not torch.is_floating_point(sd[k])))
+    if missing or unexpected or wrong:
+        def head(v):
+            return ", ".join(v[:4]) + (f" (+{len(v) - 4} more)" if len(v) > 4 else "")
+        raise RuntimeError("not an FID InceptionV3 state_dict (" + FID_WEIGHTS_FILE + "): "
+                           + (f"missing {len(missing)}: {head(missing)}; " if missing else "")
+                           + (f"unexpected {len(unexpected)}: {head(unexpected)}; " if unexpected else "")
+                           + (f"wrong shape / dtype {len(wrong)}: {head(wrong)}" if wrong else ""))
+    return True
+
+
+def load_fid_weights(path, check_hash=True):
+    """torch.load of the published FID weights with the hash check torch.hub applies to `<name>-<sha256 prefix>.pth` files and the strict
+    structural check; returns (state_dict, sha256 hex)."""
+    import hashlib
+    h = hashlib.sha256()
+    with open(path, "rb") as f:
+        for chunk in iter(lambda: f.read(1 << 20), b""):
+            h.update(chunk)
+    digest = h.hexdigest()
+    if check_hash and not digest.startswith(FID_WEIGHTS_SHA256_PREFIX):
+        raise RuntimeError(f"{path}: sha256 {digest[:16]}... does not start with {FID_WEIGHTS_SHA256_PREFIX} -- not {FID_WEIGHTS_FILE}")
+    sd = torch.load(path, map_location="cpu")
+    validate_inception_state_dict(sd)
+    return sd, digest
+
+
 class InceptionV3:
     """FID InceptionV3 (torchvision structure + the reference's FID patches, src/metrics/inception_net.py:135-249),
     inference only, BN folded into the convolutions at load time. `state_dict` uses torchvision's key names, i.e. the
@@ -257,11 +315,21 @@ class LoadEvalModel:
     "clean" (PIL bicubic) and "friendly" (PIL bilinear), reference src/utils/resize.py:49-69."""
 
     def __init__(self, eval_backbone="InceptionV3_tf", post_resizer="legacy", world_size=1, distributed_data_parallel=False, device="cuda",
-                 state_dict=None, dtype=torch.float32):
+                 state_dict=None, dtype=torch.float32, weights_path=None):
+        """state_dict: tensors under torchvision's inception_v3 names, checked against inception_manifest() like the reference's strict load
+        (anything else raises); weights_path: the published file itself, additionally checked against the sha256 prefix in its name.
+        `self.weights_pinned` says which: True only for a hash-verified file -- FID / IS values from any other weights (the seeded random
+        ones of bench.py and the tests) are NOT comparable with published numbers."""
         if eval_backbone != "InceptionV3_tf" or post_resizer not in ("legacy", "clean", "friendly"):
             raise NotImplementedError("InceptionV3_tf with the legacy / clean / friendly resizers is on the hot path (SURVEY §2)")
+        self.weights_pinned, self.weights_sha256 = False, None
+        if weights_path is not None:
+            state_dict, self.weights_sha256 = load_fid_weights(weights_path)
+            self.weights_pinned = True
         if state_dict is None:
-            raise RuntimeError("pass the FID Inception state_dict (pt_inception-2015-12-05-6726825d.pth); there is no network access here")
+            raise RuntimeError("pass the FID Inception weights (weights_path=.../" + FID_WEIGHTS_FILE + ", from " + FID_WEIGHTS_URL +
+                               ", or its state_dict); there is no network access here")
+        validate_inception_state_dict(state_dict)
         self.eval_backbone, self.post_resizer, self.device = eval_backbone, post_resizer, torch.device(device)
         self.res = 299
         self.model = InceptionV3(state_dict, self.device, dtype)

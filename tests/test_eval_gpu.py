@@ -292,3 +292,66 @@ def test_pool2d_vector_kernel_matches_torch_and_scalar(sg, cfg):
     check(f"pool2d bf16 {cfg}", out, ref.to(torch.bfloat16).float(), 1e-6 if mode == 0 else 4e-3)
     assert torch.equal(y[..., coff:coff + C], y32[..., coff:coff + C].to(torch.bfloat16)), "vector and scalar kernels disagree"
     assert float(y[..., :coff].abs().max()) == 0.0 and float(y[..., coff + C:].abs().max()) == 0.0, "wrote outside its channel slice"
+
+
+def test_inception_scalar_known_answer(sg):
+    """FID InceptionV3 on the HIP path against the convolution-free known answer of tests/inception_kat.py: centre-tap kernels + images that are
+    constant per channel collapse the network to a per-channel scalar recursion written from the block wiring alone. Catches what a
+    random-weight comparison against a structurally identical oracle could share with it: a swapped branch, a wrong concatenation order,
+    a mis-folded batch norm."""
+    import inception_kat as K
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    sd = K.centre_tap_state_dict(M.SPEC, 3)
+    vals = [[0.3, -0.5, 0.8], [-0.9, 0.1, 0.4]]
+    x = torch.tensor(vals).view(2, 3, 1, 1).expand(2, 3, 299, 299)
+    model = M.InceptionV3(sd, dev, torch.float32)
+    feat, logit = model.forward_nhwc(x.permute(0, 2, 3, 1).contiguous().to(dev))
+    torch.cuda.synchronize()
+    for i, v in enumerate(vals):
+        fk, lk = K.scalar_forward(sd, v)
+        check(f"scalar KAT features, image {i}", feat[i], fk, 1e-5)
+        check(f"scalar KAT logits, image {i}", logit[i], lk, 1e-5)
+
+
+def test_load_eval_model_rejects_foreign_weights(sg):
+    from studiogan_amd import metrics as M
+    dev = torch.device("cuda:0")
+    sd = M.synthetic_state_dict(0)
+    m = M.LoadEvalModel(device=dev, state_dict=sd)
+    assert m.weights_pinned is False and m.weights_sha256 is None        # structure checked, provenance unknown
+    bad = dict(sd)
+    bad.pop("Mixed_7c.branch_pool.conv.weight")
+    with pytest.raises(RuntimeError, match="not an FID InceptionV3 state_dict"):
+        M.LoadEvalModel(device=dev, state_dict=bad)
+
+
+def test_frechet_distance_on_device_at_2048_dimensions(sg):
+    """the production size: tr sqrtm(S1 S2) of two 2048 x 2048 covariances on the device (fp64 Cholesky + one-sided Jacobi) against scipy's
+    sqrtm route of the reference (src/metrics/fid.py:34-62); the device time is written to gpurun_out/ when that directory is writable."""
+    import os
+    import time
+    from studiogan_amd import metrics as M
+    rs = np.random.RandomState(7)
+    n = 2048
+    xa = rs.randn(3 * n, n) @ (np.eye(n) + 0.05 * rs.randn(n, n))
+    xb = rs.randn(3 * n, n) * 1.1 + 0.05
+    m1, s1, m2, s2 = xa.mean(0), np.cov(xa, rowvar=False), xb.mean(0), np.cov(xb, rowvar=False)
+    t0 = time.time()
+    ref = float(M.frechet_inception_distance(m1, s1, m2, s2))
+    t_host = time.time() - t0
+    M.frechet_inception_distance_device(m1[:64], s1[:64, :64], m2[:64], s2[:64, :64])      # warm-up (module load)
+    torch.cuda.synchronize()
+    t0 = time.time()
+    got = M.frechet_inception_distance_device(m1, s1, m2, s2)
+    torch.cuda.synchronize()
+    t_dev = time.time() - t0
+    line = f"FID back-end at n = 2048: device {t_dev:.2f} s (fp64 Cholesky + Jacobi), host scipy.linalg.sqrtm {t_host:.2f} s; values {got:.9f} vs {ref:.9f}"
+    print(line)
+    try:
+        d = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        open(os.path.join(d, "fid_backend_2048.txt"), "w").write(line + "\n")
+    except OSError:
+        pass
+    assert abs(got - ref) <= 1e-7 * abs(ref), (got, ref)

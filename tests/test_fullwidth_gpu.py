@@ -23,6 +23,9 @@ from test_blocks_gpu import bf16_vs_emulating_oracle
 pytestmark = pytest.mark.gpu
 
 WIDE = ["biggan128w", "sngan32w", "wgangp128w", "bigdeep128w"]
+# C4 at the resolution BASELINE.json names (BigGAN-Deep ImageNet-256: reference src/models/big_resnet_deep_legacy.py:80-95 "256" tables,
+# attention in D at 128^2 = 16384 positions), batch 2: the step against the reference's golden vectors and stage-wise against the oracle
+WIDE256 = ["bigdeep256w"]
 
 
 @pytest.fixture
@@ -56,12 +59,12 @@ def _dump(tag, rows):
 
 
 @pytest.mark.parametrize("mixed", [False, True])
-@pytest.mark.parametrize("name", WIDE)
+@pytest.mark.parametrize("name", WIDE + WIDE256)
 def test_fullwidth_step_vs_golden(sg, forced, name, mixed):
     step_vs_golden(name, mixed)
 
 
-@pytest.mark.parametrize("name", WIDE)
+@pytest.mark.parametrize("name", WIDE + WIDE256)
 def test_fullwidth_step_stagewise_vs_oracle(sg, forced, name):
     rows = []
     try:

@@ -270,6 +270,35 @@ def test_batchnorm(sg, dtype, mode):
 
 
 @pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("shape", [(4, 24, 6), (3, 64, 16), (2, 40, 5)])      # scalar / streaming / vector kernels of sg_bn_bwd_apply_res
+def test_batchnorm_backward_adds_the_linked_skip_gradient(sg, dtype, shape):
+    """functional.GradLink on the BN side (generator blocks): the gradient the block input receives through the skip path is added INSIDE
+    sg_bn_bwd_apply_res; dx with a link == dx without it + the handed-over tensor, on every kernel variant."""
+    from studiogan_amd import functional as F
+    d = dev()
+    N, Cc, H = shape
+    x = nhwc((rnd((N, Cc, H, H), dtype, 61) * 2 + 0.5).to(dtype)).to(d)
+    gy = nhwc(rnd((N, Cc, H, H), dtype, 62)).to(d)
+    r = nhwc(rnd((N, Cc, H, H), dtype, 63)).to(d).contiguous()
+    gain = (1 + 0.3 * torch.randn(N, Cc)).to(d)
+    bias = (0.3 * torch.randn(N, Cc)).to(d)
+    cfg = F.BNCfg(True, False, 1e-4, 0.1, True)
+    grads = []
+    for use_link in (False, True):
+        xd = x.clone().requires_grad_(True)
+        link = F.GradLink()
+        y = F.BNFn.apply(xd, gain, bias, None, None, cfg, link)
+        if use_link:
+            link.dx = r
+        y.backward(gy)
+        assert link.dx is None, "the backward must consume the handed-over gradient"
+        grads.append(xd.grad.float().cpu())
+    torch.cuda.synchronize()
+    tol = 1e-6 if dtype == torch.float32 else 1e-2
+    check(f"bn backward + linked residual {dtype} {shape}", grads[1], grads[0].double() + r.float().cpu().double(), tol)
+
+
+@pytest.mark.parametrize("dtype", DT)
 def test_softmax_pool_misc(sg, dtype):
     from studiogan_amd import functional as F, _lib as L
     d = dev()

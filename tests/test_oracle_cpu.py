@@ -341,3 +341,52 @@ def test_heads_restatement_matches_reference_fixture():
         for k, p in P.items():
             g = p.grad if p.grad is not None else torch.zeros_like(p)
             assert float((g - torch.from_numpy(z[name + "/grad/" + k])).abs().max()) < 1e-5, (name, k)
+
+
+def test_inception_oracle_matches_the_convolution_free_known_answer():
+    """oracle/inception.py against tests/inception_kat.py: with centre-tap kernels and an image that is constant per channel the FID network is a
+    per-channel scalar recursion (no convolution or pooling implementation involved) -- an independent statement of the block wiring
+    (reference src/metrics/inception_net.py:117-127,135-249 over torchvision's inception.py) that the oracle and, through
+    tests/test_eval_gpu.py::test_inception_scalar_known_answer, the HIP path must both reproduce."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import inception_kat as K
+    from oracle import inception as OI
+    sd = K.centre_tap_state_dict(OI.SPEC, 3)
+    vals = [0.3, -0.5, 0.8]
+    x = torch.tensor(vals).view(1, 3, 1, 1).expand(1, 3, 299, 299).contiguous()
+    f, lg = OI.inception_forward(x, sd)
+    fk, lk = K.scalar_forward(sd, vals)
+    assert int((fk > 0).sum()) > 500, "the known answer must exercise the network (most features non-zero)"
+    assert float((f[0].double() - fk).abs().max()) <= 1e-5 * float(fk.abs().max())
+    assert float((lg[0].double() - lk).abs().max()) <= 1e-5 * float(lk.abs().max())
+
+
+def test_inception_manifest_and_weight_file_pin(tmp_path):
+    """studiogan_amd.metrics: the strict structural check of an FID InceptionV3 state_dict and the sha256 check of the published file name
+    (reference src/metrics/inception_net.py:13,117-130: load_state_dict_from_url of pt_inception-2015-12-05-6726825d.pth + strict load)."""
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import metrics as M
+    from oracle import inception as OI
+    man = M.inception_manifest()
+    sd = OI.random_state_dict(0)
+    assert {k for k in sd if not k.endswith("num_batches_tracked")} == set(man)        # the oracle's generator and the manifest agree on the key set
+    assert all(tuple(sd[k].shape) == man[k] for k in man)
+    assert len(man) == 94 * 5 + 2 and man["fc.weight"] == (1008, 2048)
+    assert M.validate_inception_state_dict(sd)
+    assert M.validate_inception_state_dict({k: v for k, v in sd.items() if not k.endswith("num_batches_tracked")})   # a TF-converted file has none
+    for mutate in (lambda d: d.pop("fc.bias"), lambda d: d.update({"AuxLogits.fc.weight": torch.zeros(1)}),
+                   lambda d: d.update({"Conv2d_1a_3x3.conv.weight": torch.zeros(32, 3, 5, 5)}),
+                   lambda d: d.update({"fc.weight": torch.zeros(1008, 2048, dtype=torch.int32)})):
+        bad = dict(sd)
+        mutate(bad)
+        with pytest.raises(RuntimeError, match="not an FID InceptionV3 state_dict"):
+            M.validate_inception_state_dict(bad)
+    # a file that is not the published one: right structure, wrong hash
+    path = tmp_path / M.FID_WEIGHTS_FILE
+    torch.save(sd, path)
+    with pytest.raises(RuntimeError, match="does not start with 6726825d"):
+        M.load_fid_weights(str(path))
+    sd2, digest = M.load_fid_weights(str(path), check_hash=False)
+    assert len(digest) == 64 and set(sd2) == set(sd)
+    assert M.FID_WEIGHTS_URL.endswith(M.FID_WEIGHTS_FILE) and M.FID_WEIGHTS_SHA256_PREFIX in M.FID_WEIGHTS_FILE
