@@ -129,13 +129,16 @@ class Generator(nn.Module):
         act = self.linear0.forward_rt(z0, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
         counter = 0
-        for blocklist in self.blocks:
+        nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
+        for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
                 if isinstance(block, ops.SelfAttention):
                     act = block.forward_nhwc(act, slot)
                 else:
                     act = block.forward_nhwc(act, affines[counter], slot)
                     counter += 1
+            if nxt is not None:
+                act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)
@@ -267,8 +270,11 @@ class Discriminator(nn.Module):
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, x))
         h = ops.to_nhwc(x, dtype, self.blocks[0][0].cpad)
-        for blocklist in self.blocks:
+        nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
+        for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
                 h = block.forward_nhwc(h, slot)
+            if nxt is not None:
+                h = bank.mark(h, nxt[bi])          # data parallelism: the backward's return to this point releases the gradients behind it
         h = F.ReluSumFn.apply(h)
         return apply_heads(self, h, label, slot, adc_fake)

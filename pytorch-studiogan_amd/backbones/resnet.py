@@ -98,12 +98,15 @@ class Generator(nn.Module):
             affines = TF.one_hot(label, num_classes=self.num_classes).to(torch.float32)
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
-        for blocklist in self.blocks:
+        nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
+        for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
                 if isinstance(block, ops.SelfAttention):
                     act = block.forward_nhwc(act, slot)
                 else:
                     act = block.forward_nhwc(act, affines, slot)
+            if nxt is not None:
+                act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)

@@ -154,10 +154,31 @@ class _Holder:
         self.obj = None
 
 
+class GradReadyFn(torch.autograd.Function):
+    """Identity on an activation at a block boundary of a network. Its backward tells the network's exchange plan (optim.ExchangePlan) that the
+    backward pass has come back to this point: every parameter used BEHIND it in the forward now has its final gradient, so the all-reduce of
+    that part of the flat gradient arena can start while the rest of the backward still runs (what DistributedDataParallel's buckets do for
+    the reference, src/models/model.py:171-180). create_graph passes (gradient penalty) are ignored."""
+
+    @staticmethod
+    def forward(ctx, act, plan, bank_ref, offset):
+        ctx.plan, ctx.bank_ref, ctx.offset = plan, bank_ref, offset
+        return act.view_as(act)
+
+    @staticmethod
+    def backward(ctx, dy):
+        if not torch.is_grad_enabled():
+            bank = ctx.bank_ref()
+            if bank is not None:
+                ctx.plan.crossed(ctx.offset, bank)
+        return dy, None, None, None
+
+
 class LayerRT:
     """Runtime record of one weight-bearing layer inside a bank."""
     __slots__ = ("module", "index", "param", "kind", "rows", "cols", "Cin", "RS", "apply_sn", "rows_pad", "want_fwd", "want_dgrad",
-                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank", "trans", "noflip", "cin_pad")
+                 "want_f32", "fwd_off", "dgrad_off", "f32_off", "dwt_off", "uv_off", "work_off", "natural_dwt", "bank", "trans", "noflip", "cin_pad",
+                 "param_off")
 
 
 class _Slot:
@@ -230,6 +251,7 @@ class WeightBank:
             uv_elems += _align(r.rows) + _align(r.cols)
             r.work_off = work
             work += self.SN_SPLITS * r.cols + r.rows
+            r.param_off = arena_of(r.param)[1]        # position of the master weight in the flat arena (exchange ranges)
             m._sg_rt = r
             self.layers.append(r)
         self.work = torch.zeros(max(work, self.SNB_BLOCKS * len(layers)) + 64, device=dev, dtype=torch.float32)
@@ -241,6 +263,39 @@ class WeightBank:
         self.current = self.slots[0]
         self._cb_queued = False
         self.es = es
+        self.exchange = None        # optim.ExchangePlan of the optimizer that owns this network's parameters (data parallelism only)
+
+    def boundaries(self, blocks):
+        """For each entry of `blocks` (the network's top-level block list, in forward order): the first parameter, in arena order, of what
+        runs behind it -- the argument of mark(). Cached. None where nothing follows."""
+        b = self.__dict__.get("_boundaries")
+        if b is None:
+            root = self.root_ref()
+            plist = list(root.parameters())
+            order = {id(p): k for k, p in enumerate(plist)}
+            b, last = [], -1
+            for blk in blocks:
+                ids = [order[id(p)] for p in blk.parameters()]
+                if ids and min(ids) <= last:      # registration order is not forward order: no early exchange for this network
+                    b = [None] * len(blocks)
+                    break
+                nxt = (max(ids) + 1) if ids else None
+                last = max(ids) if ids else last
+                b.append(plist[nxt] if (nxt is not None and nxt < len(plist)) else None)
+            self._boundaries = b
+        return b
+
+    def mark(self, act, next_param):
+        """Block boundary in a backbone's forward: `next_param` is the first parameter (in arena order) of what runs behind this point.
+        No-op unless a data-parallel optimizer attached an exchange plan and a graph is being built."""
+        plan = self.exchange
+        if plan is None or next_param is None or not torch.is_grad_enabled() or not act.requires_grad:
+            return act
+        ent = arena_of(next_param)
+        if ent is None or ent[0] is not self.params:
+            return act
+        plan.expect(ent[1])
+        return GradReadyFn.apply(act, plan, weakref.ref(self), ent[1])
 
     MAX_SLOTS = 12
 
@@ -376,13 +431,23 @@ class WeightBank:
         return slot.dwt[r.dwt_off:r.dwt_off + r.rows_pad * r.RS * r.cin_pad].view(r.rows_pad, r.RS * r.cin_pad)
 
     # -- backward of the normalisation, batched ----------------------------------------------------------------
-    def flush(self):
-        self._cb_queued = False
+    def flush(self, lo=None, hi=None):
+        """Fold the pending dL/dW_sn scratch of every forward into the gradient arena. lo / hi (arena offsets): only the layers whose master
+        weight lies in [lo, hi) -- the early gradient exchange folds a finished range while the backward is still running; the engine
+        callback at the end of the pass (no arguments) takes whatever is left."""
+        if lo is None:
+            self._cb_queued = False
         for slot in self.slots[1:]:
             if not slot.pending:
                 continue
-            key = tuple(sorted(slot.pending))
-            slot.pending = []
+            if lo is None:
+                key = tuple(sorted(slot.pending))
+                slot.pending = []
+            else:
+                key = tuple(sorted(i for i in slot.pending if lo <= self.layers[i].param_off < hi))
+                if not key:
+                    continue
+                slot.pending = [i for i in slot.pending if i not in key]
             ent = slot.bwd_cache.get(key)
             if ent is None:
                 arr = (L.SnBwdLayer * len(key))()

@@ -4,7 +4,7 @@ streams instead of torch.distributed collectives. Replaces DistributedDataParall
 src/models/model.py:157-180.
 
 torch.distributed is only used ONCE, to hand rank 0's 128-byte RCCL unique id to the other ranks (any rendezvous would do).
-Opt-in: `studiogan_amd.comm.enable(group)` (bench.py: SG_NATIVE_COMM=1). Without it the same exchanges run through
+Opt-in: `studiogan_amd.comm.enable(group)` (bench.py: --native-comm or SG_NATIVE_COMM=1). Without it the same exchanges run through
 torch.distributed (backend "nccl" == RCCL on ROCm), which is also what the gloo-based CPU / one-GPU tests drive.
 """
 import ctypes as C
@@ -29,26 +29,41 @@ class NativeComm:
         uid = (C.c_char * 128)()
         if self.rank == 0:
             L.call("sg_comm_unique_id", uid)
+        src = 0 if (group is None or not ddp) else dist.get_global_rank(group, 0)
         if self.world > 1:
             box = [bytes(uid.raw)]
-            src = 0 if group is None else dist.get_global_rank(group, 0)
             dist.broadcast_object_list(box, src=src, group=group, device=device)
             uid = (C.c_char * 128).from_buffer_copy(box[0])
         self.handle = C.c_void_p()
         L.call("sg_comm_init_rank", uid, self.world, self.rank, C.byref(self.handle))
+        # A SECOND communicator for the gradient exchange: it runs on the side stream, possibly while sync-BN all-reduces of the same
+        # backward pass run on the compute stream -- two streams must not share one RCCL communicator (operations of a communicator have to
+        # be issued in the same order on every rank, and stream interleaving does not guarantee that).
+        uid2 = (C.c_char * 128)()
+        if self.rank == 0:
+            L.call("sg_comm_unique_id", uid2)
+        if self.world > 1:
+            box = [bytes(uid2.raw)]
+            dist.broadcast_object_list(box, src=src, group=group, device=device)
+            uid2 = (C.c_char * 128).from_buffer_copy(box[0])
+        self.grad_handle = C.c_void_p()
+        L.call("sg_comm_init_rank", uid2, self.world, self.rank, C.byref(self.grad_handle))
         self.stream = torch.cuda.Stream()      # side stream of the pipelined gradient exchange
 
-    def allreduce_(self, t, stream=None):
-        """in-place sum of a contiguous fp32 / fp64 CUDA tensor over the ranks, enqueued on `stream` (default: the current stream)."""
+    def allreduce_(self, t, stream=None, grad=False):
+        """in-place sum of a contiguous fp32 / fp64 CUDA tensor over the ranks, enqueued on `stream` (default: the current stream).
+        grad=True: on the gradient-exchange communicator (side stream), else on the one the sync-BN statistics use (compute stream)."""
         assert t.is_cuda and t.is_contiguous() and t.dtype in (torch.float32, torch.float64)
-        L.call("sg_allreduce_flat", self.handle, t.data_ptr(), t.numel(), L.F32 if t.dtype == torch.float32 else L.F64,
+        L.call("sg_allreduce_flat", self.grad_handle if grad else self.handle, t.data_ptr(), t.numel(), L.F32 if t.dtype == torch.float32 else L.F64,
                stream if stream is not None else L.stream())
         return t
 
     def close(self):
-        if self.handle:
-            L.call("sg_comm_destroy", self.handle)
-            self.handle = C.c_void_p()
+        for name in ("handle", "grad_handle"):
+            h = getattr(self, name, None)
+            if h:
+                L.call("sg_comm_destroy", h)
+                setattr(self, name, C.c_void_p())
 
 
 def enable(group=None, device=None):

@@ -5,6 +5,8 @@ bucketed all-reduce (reference src/models/model.py:171-180): gradients of a netw
 buffer, so the exchange is a few large RCCL all-reduces issued once per update (not per accumulation micro-step),
 pipelined against the optimizer kernel chunk by chunk.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -68,6 +70,67 @@ def sync_replicas(module, group=None, src=0):
     return module
 
 
+class ExchangePlan:
+    """Early data-parallel gradient exchange of ONE network: the all-reduce of a finished tail of the flat gradient arena is issued from
+    inside the backward pass, as soon as the pass has come back across a block boundary that every forward of this update has passed
+    (bank.GradReadyFn), and overlaps the backward of the blocks in front of it; FusedAdam.step then only waits for those reductions and
+    exchanges what is left. Replaces DistributedDataParallel's bucketed all-reduce during backward (reference src/models/model.py:171-180).
+
+    Parameters sit in the arena in module order = forward order (block granularity), the backward visits them tail first, so the finished
+    part is always [offset of the boundary, start of what was already exchanged). A range is sent once it holds >= min_elems gradients
+    (few, large collectives: xGMI is per-link bound). Gradient penalties (create_graph passes), gradient accumulation micro-steps and anything
+    else that does not arm the plan fall back to the exchange inside step()."""
+
+    def __init__(self, arena, min_elems=8 << 20):
+        self.arena, self.min_elems = arena, int(os.environ.get("SG_EXCHANGE_MIN_ELEMS", min_elems))
+        self.group = None
+        self.reset()
+
+    def reset(self):
+        self.armed = False
+        self.expected, self.seen = {}, {}
+        self.done_lo = self.arena.numel
+        self.inflight = []          # (lo, hi, handle): torch.distributed Work or a torch.cuda.Event on the native communicator's stream
+        self.issued_in_backward = 0
+
+    def expect(self, off):
+        self.expected[off] = self.expected.get(off, 0) + 1
+
+    def arm(self, group):
+        self.armed, self.group = True, group
+
+    def crossed(self, off, bank):
+        self.seen[off] = self.seen.get(off, 0) + 1          # (counted for every plain backward: accumulation micro-steps before the armed one)
+        if not self.armed:
+            return
+        if self.seen[off] < self.expected.get(off, 0) or off >= self.done_lo:
+            return                                          # another forward of this update still has to come back across this boundary
+        lo, hi = off, self.done_lo
+        if hi - lo < self.min_elems and lo > 0:
+            return                                          # too small to be worth a collective of its own: rides with the next boundary
+        bank.flush(lo, hi)                                  # spectral-norm backward of the finished layers -> gradient arena
+        g = self.arena.grad[lo:hi]
+        nc = _comm.native_for(self.group)
+        if nc is not None:
+            main = torch.cuda.current_stream()
+            ready = torch.cuda.Event()
+            ready.record(main)
+            nc.stream.wait_event(ready)
+            nc.allreduce_(g, stream=nc.stream.cuda_stream, grad=True)
+            done = torch.cuda.Event()
+            done.record(nc.stream)
+            self.inflight.append((lo, hi, done))
+        else:
+            self.inflight.append((lo, hi, dist.all_reduce(g, group=self.group, async_op=True)))
+        self.done_lo = lo
+        self.issued_in_backward += 1
+
+    def take(self):
+        """-> (ranges already on the wire [(lo, hi, handle)], end of the part step() still has to exchange)"""
+        out, rest = self.inflight, self.done_lo
+        return out, rest
+
+
 def _arena_for(params):
     ents = [arena_of(p) for p in params]
     if any(e is None for e in ents) or len({id(e[0]) for e in ents}) != 1 or not ents[0][0].intact():
@@ -87,6 +150,39 @@ class FusedAdam(torch.optim.Optimizer):
         self._t = 0
         self.comm_chunks = comm_chunks
         self._replicas_checked = False
+        self._module = None
+        self._plan = None
+        self.exchange_stats = {"early_ranges": 0, "early_elems": 0, "late_elems": 0}
+
+    def attach(self, module):
+        """Tell the optimizer which network its parameters belong to: under data parallelism the network's block boundaries then start the
+        gradient all-reduce of finished arena ranges during the backward pass (ExchangePlan). Optional -- without it the whole exchange
+        happens inside step()."""
+        self._module = module
+        return self
+
+    def arm_exchange(self, group):
+        """Call right before the backward of the LAST accumulation micro-step of an update (Worker does): from now on a block boundary the
+        backward comes back to may send its finished gradients. SG_EARLY_EXCHANGE=0 disables it."""
+        if self._module is None or group is None or os.environ.get("SG_EARLY_EXCHANGE", "1") == "0":
+            return False
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+            return False
+        h = self._module.__dict__.get("_sg_bank_holder")
+        bank = h.obj if h is not None else None
+        a = self._state()
+        if bank is None or bank.params is not a:
+            return False
+        if self._plan is None or self._plan.arena is not a:
+            self._plan = ExchangePlan(a)
+        if bank.exchange is not self._plan:
+            bank.exchange = self._plan        # boundaries of forwards run from now on register with the plan
+            self._plan.reset()
+            return False                      # (this update's forwards ran without marks: plain exchange in step())
+        if not self._replicas_checked:
+            return False                      # the first exchange also verifies the replicas: keep it in step()
+        self._plan.arm(group)
+        return True
 
     def _state(self):
         params = self.param_groups[0]["params"]
@@ -141,6 +237,8 @@ class FusedAdam(torch.optim.Optimizer):
 
     def zero_grad(self, set_to_none=False):
         a = self._state()
+        if self._plan is not None:
+            self._plan.reset()
         a.grad.zero_()
         for p, o in zip(a.params, a.offsets):
             p.grad = a.grad[o:o + p.numel()].view(p.shape)
@@ -170,7 +268,28 @@ class FusedAdam(torch.optim.Optimizer):
             assert_replicas_identical(a.data, group, "parameters of the network handed to FusedAdam")
             self._replicas_checked = True
         nc = _comm.native_for(group) if world > 1 else None
-        if nc is not None:
+        if world > 1 and self._plan is not None and self._plan.inflight:
+            # ranges whose all-reduce was issued from inside the backward pass: wait for each, apply Adam to it, then fall through with n
+            # shortened to what is still to be exchanged
+            early, rest = self._plan.take()
+            main = torch.cuda.current_stream()
+            for lo, hi, handle in early:
+                if isinstance(handle, torch.cuda.Event):
+                    main.wait_event(handle)
+                else:
+                    handle.wait()
+                L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
+                       self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
+                       g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)
+                self.exchange_stats["early_ranges"] += 1
+                self.exchange_stats["early_elems"] += hi - lo
+            n = rest
+            self._plan.reset()
+        if world > 1:
+            self.exchange_stats["late_elems"] += n
+        if n == 0:
+            pass
+        elif nc is not None:
             # the same pipeline through the C ABI (sg_allreduce_flat): the reductions queue on the communicator's side stream behind
             # an event that marks "gradients complete"; the Adam launch of chunk i waits for ITS reduction only
             ranges = chunk_ranges(n, self.comm_chunks)
@@ -180,7 +299,7 @@ class FusedAdam(torch.optim.Optimizer):
             nc.stream.wait_event(ready)
             done = []
             for lo, hi in ranges:
-                nc.allreduce_(a.grad[lo:hi], stream=nc.stream.cuda_stream)
+                nc.allreduce_(a.grad[lo:hi], stream=nc.stream.cuda_stream, grad=True)
                 ev = torch.cuda.Event()
                 ev.record(nc.stream)
                 done.append(ev)

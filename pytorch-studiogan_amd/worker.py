@@ -108,6 +108,13 @@ class Worker:
             sync_replicas(Dis, group)
         self.g_optimizer = FusedAdam(Gen.parameters(), lr=g_lr, betas=(beta1, beta2), eps=1e-6)
         self.d_optimizer = FusedAdam(Dis.parameters(), lr=d_lr, betas=(beta1, beta2), eps=1e-6)
+        if group is not None:
+            # data parallelism: the networks' block boundaries start the gradient all-reduce of finished arena ranges during backward
+            # (optim.ExchangePlan: what DDP's buckets do for the reference, src/models/model.py:171-180)
+            self.g_optimizer.attach(Gen)
+            self.d_optimizer.attach(Dis)
+        # update procedures with a create_graph pass inside keep the whole exchange in step()
+        self._plain_d_update = not (apply_gp or apply_r1_reg or apply_maxgp or apply_dra)
         self.Gen_ema, self.ema = None, None
         if apply_g_ema:
             self.Gen_ema = copy.deepcopy(Gen)
@@ -125,7 +132,7 @@ class Worker:
         dis_acml_loss = None
         for _ in range(self.n_d):
             self.d_optimizer.zero_grad()
-            for _ in range(self.acml):
+            for micro in range(self.acml):
                 real_images, real_labels = real_batches[k]
                 zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
                 k += 1
@@ -173,6 +180,8 @@ class Worker:
                     self.r1_penalty = sg_losses.cal_r1_reg(adv_output=real_dict["adv_output"], images=real_images, device=self.device)
                     dis_acml_loss = dis_acml_loss + self.r1_lambda * self.r1_penalty
                 dis_acml_loss = dis_acml_loss / self.acml
+                if self.group is not None and self._plain_d_update and micro == self.acml - 1:
+                    self.d_optimizer.arm_exchange(self.group)      # last micro-step: finished gradient ranges go on the wire during backward
                 dis_acml_loss.backward()
                 dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
             self.d_optimizer.step(group=self.group)
@@ -188,7 +197,7 @@ class Worker:
         gen_acml_loss = None
         for _ in range(self.n_g):
             self.g_optimizer.zero_grad()
-            for _ in range(self.acml):
+            for micro in range(self.acml):
                 zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
                 k += 1
                 fake_images = self.Gen(zs, fake_labels)
@@ -208,6 +217,8 @@ class Worker:
                         adc_fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
                         gen_acml_loss = gen_acml_loss - self.cond_lambda * self.cond_loss(**adc_fake_dict)
                 gen_acml_loss = gen_acml_loss / self.acml
+                if self.group is not None and micro == self.acml - 1:
+                    self.g_optimizer.arm_exchange(self.group)
                 gen_acml_loss.backward()
                 gen_acml_loss = gen_acml_loss.detach()
             # Adam and the EMA of the generator copy (src/worker.py:630-634,675-676) in one launch

@@ -29,20 +29,20 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, name, desync, ret):
+def _run(rank, world, port, name, desync, ret, steps=1):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ret[rank] = _job(rank, world, name, desync)
+        ret[rank] = _job(rank, world, name, desync, steps)
     finally:
         if world > 1:
             dist.destroy_process_group()
 
 
-def _job(rank, world, name, desync):
+def _job(rank, world, name, desync, steps=1):
     import studiogan_amd  # noqa: F401
     from studiogan_amd import ops
     from studiogan_amd.worker import Worker
@@ -84,15 +84,24 @@ def _job(rank, world, name, desync):
     w.train_generator(0, [(put("z1"), put("fl1"))])
     torch.cuda.synchronize()
     g_grad = {k: p.grad.detach().cpu().clone() / world for k, p in G.named_parameters()}
+    early = None
+    if steps > 1:
+        # further updates: from the second one on the block boundaries put finished gradient ranges on the wire DURING the backward
+        # (optim.ExchangePlan; the first exchange stays in step() because it also verifies the replicas)
+        for it in range(1, steps):
+            w.train_discriminator(it, [(put("real0"), put("rl0"))], [(put(f"z{it % 2}"), put(f"fl{it % 2}"))])
+            w.train_generator(it, [(put("z1"), put("fl1"))])
+        torch.cuda.synchronize()
+        early = {"D": dict(w.d_optimizer.exchange_stats), "G": dict(w.g_optimizer.exchange_stats)}
     state = {"D/" + k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
     state.update({"G/" + k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
-    return {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught}
+    return {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught, "early": early}
 
 
-def _spawn(world, name, desync=False):
+def _spawn(world, name, desync=False, steps=1):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_run, args=(world, _free_port(), name, desync, ret), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, _free_port(), name, desync, ret, steps), nprocs=world, join=True)
     return dict(ret)
 
 
@@ -165,3 +174,23 @@ def test_native_rccl_entry_points_single_rank(sg):
     xf = x.float().reshape(-1, Cc).double().cpu()
     assert torch.allclose(out[0][0].double(), xf.mean(0), atol=1e-5)
     nc.close()
+
+
+@pytest.mark.parametrize("name", ["biggan32", "resgan32"])
+def test_early_gradient_exchange_matches_the_exchange_in_step(sg, name, monkeypatch):
+    """optim.ExchangePlan: three D + G updates on two ranks with the all-reduce of finished arena ranges issued from inside the backward
+    pass (block-boundary marks, bank.GradReadyFn) against the same updates with the whole exchange in FusedAdam.step (SG_EARLY_EXCHANGE=0):
+    bit-identical parameters and buffers on both ranks, and the early path really ran (ranges sent from the backward of the second and
+    third update of both networks)."""
+    monkeypatch.setenv("SG_EXCHANGE_MIN_ELEMS", "256")        # width-8 networks: let every boundary that closes 256 gradients send
+    monkeypatch.setenv("SG_EARLY_EXCHANGE", "1")
+    on = _spawn(2, name, steps=3)
+    monkeypatch.setenv("SG_EARLY_EXCHANGE", "0")
+    off = _spawn(2, name, steps=3)
+    for k in on[0]["state"]:
+        assert torch.equal(on[0]["state"][k], on[1]["state"][k]), f"replicas diverged with the early exchange: {k}"
+        assert torch.equal(on[0]["state"][k], off[0]["state"][k]), f"early exchange changed the result: {k}"
+    for net in ("D", "G"):
+        st = on[0]["early"][net]
+        assert st["early_ranges"] >= 2 and st["early_elems"] > 0, (net, st)
+        assert off[0]["early"][net]["early_ranges"] == 0
