@@ -502,7 +502,7 @@ def main():
                # algorithmic work per sample: G forward 42.24 GFLOP + InceptionV3 at 299^2 11.4 GFLOP
                "roofline_bf16": {"bound": "mfma", "gflop_per_sample": 53.64, "achieved": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3, 1), "unit": "TFLOP/s",
                                  "peak": 2500.0, "frac": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3 / 2500.0, 4),
-                                 "kernel_trace": "profiles/r02_fid_leg_kerneltrace.txt (tools/fid_leg.py)"},
+                                 "kernel_trace": "profiles/r03_fid_leg_kerneltrace.txt (tools/fid_leg.py, traced at the round-3 code state)"},
                "weights": "seeded random (pretrained FID Inception weights are not available offline)"}
     if rank != 0:
         if world > 1:

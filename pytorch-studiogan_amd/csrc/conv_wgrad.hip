@@ -190,6 +190,56 @@ __global__ __launch_bounds__(256) void k_splitk_reduce(const float* partial, flo
   }
 }
 
+// 16-byte variant (round 3): a lane owns FOUR consecutive outputs (one 16-byte load per split and lane, 1 KB per wave instruction instead of
+// 256 B), 256 threads = 64 lanes x 4 split phases, eight loads in flight per lane. The partial tiles of one layer are 85 MB however the layer
+// is shaped (768 workgroups x a 288 x 96 fp32 tile), read once: the scalar kernel above moved them at 1.8 TB/s (48 us per launch, 104 launches,
+// 5 ms per C3 step in profiles/r03_bench_biggan128_bs256_kerneltrace_a.txt). Same fixed summation order per output -> deterministic.
+__global__ __launch_bounds__(256) void k_splitk_reduce_v4(const float* partial, float* out, int splits, long long n, long long stride, float* out2, long long n2) {
+  __shared__ f32x4 sm[4][64];
+  const long long nt4 = (n + n2) >> 2, n4 = n >> 2;
+  const int li = threadIdx.x & 63, q = threadIdx.x >> 6;
+  for (long long i0 = blockIdx.x * 64ll; i0 < nt4; i0 += (long long)gridDim.x * 64) {
+    const long long i = i0 + li;
+    f32x4 a[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) a[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (i < nt4) {
+      const float* src = partial + 4 * i;
+      int s = q;
+      for (; s + 28 < splits; s += 32) {
+        f32x4 v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = *(const f32x4*)(src + (long long)(s + 4 * k) * stride);
+#pragma unroll
+        for (int k = 0; k < 8; k++) a[k] += v[k];
+      }
+      for (; s < splits; s += 4) a[0] += *(const f32x4*)(src + (long long)s * stride);
+    }
+    sm[q][li] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+    __syncthreads();
+    if (q == 0 && i < nt4) {
+      const f32x4 t = (sm[0][li] + sm[1][li]) + (sm[2][li] + sm[3][li]);
+      float* dst = i < n4 ? out + 4 * i : out2 + 4 * (i - n4);
+      f32x4 o = *(f32x4*)dst;
+      *(f32x4*)dst = o + t;
+    }
+    __syncthreads();
+  }
+}
+static void splitk_reduce_launch(const float* partial, float* out, int splits, long long n, long long stride, float* out2, long long n2, hipStream_t st) {
+  if (stride == 0) stride = n;
+  static int mode = -1;
+  if (mode < 0) { const char* e = getenv("SG_REDUCE_V4"); mode = (e && e[0] == '0') ? 0 : 1; }
+  const bool v4 = mode && (n % 4 == 0) && (n2 % 4 == 0) && (stride % 4 == 0) && ((((uintptr_t)partial | (uintptr_t)out | (uintptr_t)out2) & 15) == 0);
+  if (v4) {
+    long long blocks = ((n + n2) / 4 + 63) / 64; if (blocks > 8192) blocks = 8192; if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(k_splitk_reduce_v4, dim3((int)blocks), dim3(256), 0, st, partial, out, splits, n, stride, out2, n2);
+  } else {
+    long long blocks = (n + n2 + 63) / 64; if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, partial, out, splits, n, stride, out2, n2);
+  }
+}
+
 template <typename T, bool TR, bool FAST>
 static void conv_wgrad_launch(const sg_conv_wgrad_desc* d, const Epilogue<T>& e, int I, int J, int K, int BI, int BJ, int splits, hipStream_t st) {
   typedef ConvPixMC<T, FAST> LM;
@@ -238,8 +288,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
     if (sk.ok && d->work && d->work_floats >= (long long)sk.nw * sk.n) {
       const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
       if (wgrad_sk_launch(d, sk, st) != 0) { sg_set_error("sg_conv2d_wgrad: streaming kernel launch failed"); return -2; }
-      long long blocks = (sk.n + 63) / 64; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, sk.nw, sk.n);
+      splitk_reduce_launch((const float*)d->work, d->dw, sk.nw, sk.n, 0, nullptr, 0, st);
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;
@@ -250,9 +299,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
     if (v3.ok && d->work && d->work_floats >= (long long)v3.splits * v3.stride) {
       const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
       if (wgrad_v3_launch(d, v3, st) != 0) { sg_set_error("sg_conv2d_wgrad: halo kernel launch failed"); return -2; }
-      long long blocks = (v3.stride + 63) / 64; if (blocks > 8192) blocks = 8192;
-      hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, v3.splits, v3.n, v3.stride, d->dbias,
-                         (long long)(d->dbias ? d->Cout : 0));
+      splitk_reduce_launch((const float*)d->work, d->dw, v3.splits, v3.n, v3.stride, d->dbias, (long long)(d->dbias ? d->Cout : 0), st);
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;
@@ -277,8 +324,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   else if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
   else conv_wgrad_launch<T, TR, false>(d, e, I, J, K, BI, BJ, splits, st);
   if (two_stage) {
-    long long blocks = (n + 63) / 64; if (blocks > 8192) blocks = 8192;
-    hipLaunchKernelGGL(k_splitk_reduce, dim3((int)blocks), dim3(256), 0, st, (const float*)d->work, d->dw, splits, n);
+    splitk_reduce_launch((const float*)d->work, d->dw, splits, n, 0, nullptr, 0, st);
   }
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();

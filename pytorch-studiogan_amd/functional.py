@@ -439,6 +439,13 @@ class ConvSkipFn(torch.autograd.Function):
         dy = _c(dy)
         bank = rt2.bank()
         outs = []
+        # both biases see the same gradient (the column sums of dy): when the halo weight-gradient kernel of the 3x3 convolution produces it
+        # on the side, it goes to a scratch vector that is then added to BOTH bias gradients -- the 1x1's own pass over dy (sg_colsum) is gone
+        want2 = ctx.b2 is not None and ctx.needs_input_grad[3]
+        want0 = ctx.b0 is not None and ctx.needs_input_grad[5]
+        shared_db = None
+        if want2 and want0 and ctx.needs_input_grad[2] and rt2.rows_pad == rt2.rows and rt0.rows == rt2.rows:
+            shared_db = torch.zeros(rt2.rows, dtype=torch.float32, device=dy.device)
         for inp, rt, cfg, w_i, b_i, wp, bp in ((h, rt2, cfg2, 2, 3, ctx.w2, ctx.b2), (x, rt0, cfg0, 4, 5, ctx.w0, ctx.b0)):
             k = 0 if inp is h else 1
             N, Hs, Ws, Cin = inp.shape
@@ -451,8 +458,20 @@ class ConvSkipFn(torch.autograd.Function):
             if ctx.needs_input_grad[w_i]:
                 xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
                 g = ensure_grad(bp) if (want_db and rt.rows_pad == rt.rows) else None
+                if k == 0 and shared_db is not None:
+                    g = shared_db
+                elif k == 1 and shared_db is not None:
+                    g = None                     # filled from the shared vector below
                 db_done = conv2d_wgrad_raw(inp, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, 1, cfg.pad_h, cfg.pad_w, xf,
                                            L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0, dbias=g)
+                if k == 0 and shared_db is not None:
+                    if db_done:
+                        for bq in (ctx.b2, ctx.b0):
+                            L.call("sg_axpby", L.F32, L.ptr(shared_db), L.ptr(ensure_grad(bq)), rt2.rows, 1.0, 1.0, L.stream())
+                        continue
+                    shared_db = None             # the kernel did not fuse the bias gradient: each convolution runs its own column sum
+                elif k == 1 and shared_db is not None:
+                    continue
             if want_db and not db_done:
                 g = ensure_grad(bp)
                 L.call("sg_colsum", L.dt(dy), L.ptr(dy), dy.shape[3], None, 0, dy.shape[0] * dy.shape[1] * dy.shape[2], rt.rows, L.ptr(g), 1.0, L.stream())
