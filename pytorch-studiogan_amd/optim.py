@@ -92,6 +92,8 @@ class ExchangePlan:
         self.done_lo = self.arena.numel
         self.inflight = []          # (lo, hi, handle): torch.distributed Work or a torch.cuda.Event on the native communicator's stream
         self.issued_in_backward = 0
+        self.selftest = os.environ.get("SG_EXCHANGE_SELFTEST") == "1"      # one process: no collective, snapshot the range instead; step() then
+        self.snapshots = []                                                # checks that nothing was written into it afterwards
 
     def expect(self, off):
         self.expected[off] = self.expected.get(off, 0) + 1
@@ -111,7 +113,9 @@ class ExchangePlan:
         bank.flush(lo, hi)                                  # spectral-norm backward of the finished layers -> gradient arena
         g = self.arena.grad[lo:hi]
         nc = _comm.native_for(self.group)
-        if nc is not None:
+        if self.selftest:
+            self.snapshots.append((lo, hi, g.clone()))
+        elif nc is not None:
             main = torch.cuda.current_stream()
             ready = torch.cuda.Event()
             ready.record(main)
@@ -164,9 +168,10 @@ class FusedAdam(torch.optim.Optimizer):
     def arm_exchange(self, group):
         """Call right before the backward of the LAST accumulation micro-step of an update (Worker does): from now on a block boundary the
         backward comes back to may send its finished gradients. SG_EARLY_EXCHANGE=0 disables it."""
-        if self._module is None or group is None or os.environ.get("SG_EARLY_EXCHANGE", "1") == "0":
+        selftest = os.environ.get("SG_EXCHANGE_SELFTEST") == "1"
+        if self._module is None or (group is None and not selftest) or os.environ.get("SG_EARLY_EXCHANGE", "1") == "0":
             return False
-        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        if not selftest and (not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2):
             return False
         h = self._module.__dict__.get("_sg_bank_holder")
         bank = h.obj if h is not None else None
@@ -179,10 +184,30 @@ class FusedAdam(torch.optim.Optimizer):
             bank.exchange = self._plan        # boundaries of forwards run from now on register with the plan
             self._plan.reset()
             return False                      # (this update's forwards ran without marks: plain exchange in step())
-        if not self._replicas_checked:
+        if not self._replicas_checked and not selftest:
             return False                      # the first exchange also verifies the replicas: keep it in step()
         self._plan.arm(group)
         return True
+
+    def _selftest_check(self, a):
+        """SG_EXCHANGE_SELFTEST=1 (single process): every range the backward would have put on the wire must still hold exactly the values it
+        held at that moment -- i.e. its gradients really were final. Raises with the names of the parameters that changed."""
+        plan = self._plan
+        if plan is None or not plan.snapshots:
+            return
+        bad = []
+        for lo, hi, snap in plan.snapshots:
+            cur = a.grad[lo:hi]
+            if not torch.equal(cur, snap):
+                for p, o in zip(a.params, a.offsets):
+                    if lo <= o < hi and not torch.equal(a.grad[o:o + p.numel()], snap[o - lo:o - lo + p.numel()]):
+                        name = next((n for n, q in self._module.named_parameters() if q is p), "?") if self._module is not None else "?"
+                        bad.append(name)
+        self.exchange_stats["early_ranges"] += len(plan.snapshots)
+        self.exchange_stats["early_elems"] += sum(h - l for l, h, _ in plan.snapshots)
+        plan.reset()
+        if bad:
+            raise RuntimeError("early gradient exchange: these parameters received gradient AFTER their arena range was sent: " + ", ".join(bad[:12]))
 
     def _state(self):
         params = self.param_groups[0]["params"]
@@ -268,6 +293,8 @@ class FusedAdam(torch.optim.Optimizer):
             assert_replicas_identical(a.data, group, "parameters of the network handed to FusedAdam")
             self._replicas_checked = True
         nc = _comm.native_for(group) if world > 1 else None
+        if world == 1 and self._plan is not None and self._plan.selftest:
+            self._selftest_check(a)
         if world > 1 and self._plan is not None and self._plan.inflight:
             # ranges whose all-reduce was issued from inside the backward pass: wait for each, apply Adam to it, then fall through with n
             # shortened to what is still to be exchanged

@@ -108,7 +108,9 @@ class Worker:
             sync_replicas(Dis, group)
         self.g_optimizer = FusedAdam(Gen.parameters(), lr=g_lr, betas=(beta1, beta2), eps=1e-6)
         self.d_optimizer = FusedAdam(Dis.parameters(), lr=d_lr, betas=(beta1, beta2), eps=1e-6)
-        if group is not None:
+        import os as _os
+        self._xchg = group is not None or _os.environ.get("SG_EXCHANGE_SELFTEST") == "1"
+        if self._xchg:
             # data parallelism: the networks' block boundaries start the gradient all-reduce of finished arena ranges during backward
             # (optim.ExchangePlan: what DDP's buckets do for the reference, src/models/model.py:171-180)
             self.g_optimizer.attach(Gen)
@@ -180,7 +182,7 @@ class Worker:
                     self.r1_penalty = sg_losses.cal_r1_reg(adv_output=real_dict["adv_output"], images=real_images, device=self.device)
                     dis_acml_loss = dis_acml_loss + self.r1_lambda * self.r1_penalty
                 dis_acml_loss = dis_acml_loss / self.acml
-                if self.group is not None and self._plain_d_update and micro == self.acml - 1:
+                if self._xchg and self._plain_d_update and micro == self.acml - 1:
                     self.d_optimizer.arm_exchange(self.group)      # last micro-step: finished gradient ranges go on the wire during backward
                 dis_acml_loss.backward()
                 dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
@@ -217,7 +219,7 @@ class Worker:
                         adc_fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
                         gen_acml_loss = gen_acml_loss - self.cond_lambda * self.cond_loss(**adc_fake_dict)
                 gen_acml_loss = gen_acml_loss / self.acml
-                if self.group is not None and micro == self.acml - 1:
+                if self._xchg and micro == self.acml - 1:
                     self.g_optimizer.arm_exchange(self.group)
                 gen_acml_loss.backward()
                 gen_acml_loss = gen_acml_loss.detach()

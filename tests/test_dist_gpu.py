@@ -180,17 +180,57 @@ def test_native_rccl_entry_points_single_rank(sg):
 def test_early_gradient_exchange_matches_the_exchange_in_step(sg, name, monkeypatch):
     """optim.ExchangePlan: three D + G updates on two ranks with the all-reduce of finished arena ranges issued from inside the backward
     pass (block-boundary marks, bank.GradReadyFn) against the same updates with the whole exchange in FusedAdam.step (SG_EARLY_EXCHANGE=0):
-    bit-identical parameters and buffers on both ranks, and the early path really ran (ranges sent from the backward of the second and
+    the two ranks bit-identical to each other, the result equal to the in-step exchange up to the +-lr kicks of noise-gradient elements
+    (tests/test_dist_gpu.py::test_exchange_ranges_are_final_when_sent checks tensor by tensor that a sent range never changes afterwards),
+    and the early path really ran (ranges sent from the backward of the second and
     third update of both networks)."""
     monkeypatch.setenv("SG_EXCHANGE_MIN_ELEMS", "256")        # width-8 networks: let every boundary that closes 256 gradients send
     monkeypatch.setenv("SG_EARLY_EXCHANGE", "1")
     on = _spawn(2, name, steps=3)
     monkeypatch.setenv("SG_EARLY_EXCHANGE", "0")
     off = _spawn(2, name, steps=3)
+    from util import Collector, load_golden, hyper
+    lr = max(hyper(load_golden(name)[1]["yaml"])[k] for k in ("g_lr", "d_lr"))
+    C = Collector()
     for k in on[0]["state"]:
         assert torch.equal(on[0]["state"][k], on[1]["state"][k]), f"replicas diverged with the early exchange: {k}"
-        assert torch.equal(on[0]["state"][k], off[0]["state"][k]), f"early exchange changed the result: {k}"
+        a, b = on[0]["state"][k], off[0]["state"][k]
+        if a.dtype.is_floating_point:
+            # two separate runs are not bit-identical (fp64 atomics in the BN statistics): an element whose gradient is rounding noise -- a conv
+            # bias in front of a batch norm -- moves by +-lr per update with either sign, everything else agrees to rounding
+            C.check("early vs in-step " + k, a, b, 2e-3, floor=0.05, abs_ok=3 * 2.2 * lr)
+        else:
+            assert torch.equal(a, b), k
+    C.finish()
     for net in ("D", "G"):
         st = on[0]["early"][net]
         assert st["early_ranges"] >= 2 and st["early_elems"] > 0, (net, st)
         assert off[0]["early"][net]["early_ranges"] == 0
+
+
+@pytest.mark.parametrize("name", ["biggan32", "resgan32", "bigdeep32", "sngan32"])
+def test_exchange_ranges_are_final_when_sent(sg, name, monkeypatch):
+    """optim.ExchangePlan in its single-process self-test mode (SG_EXCHANGE_SELFTEST=1): every arena range that a block boundary would put on the
+    wire during the backward pass is snapshotted instead, and FusedAdam.step raises if any gradient in it changed afterwards -- i.e. the
+    'everything behind this boundary is final' claim is checked tensor by tensor, for D (two forwards per update) and G."""
+    from studiogan_amd.worker import Worker
+    from util import load_golden, sub, hyper
+    from test_model_gpu import build_from_yaml
+    monkeypatch.setenv("SG_EXCHANGE_SELFTEST", "1")
+    monkeypatch.setenv("SG_EXCHANGE_MIN_ELEMS", "64")
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    G, D = build_from_yaml(y, False, dev)
+    G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+    D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+               d_updates_per_step=1, apply_g_ema=False)
+    ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+    for it in range(3):
+        w.train_discriminator(it, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"])])
+        w.train_generator(it, [(ins["z1"], ins["fl1"])])
+    torch.cuda.synchronize()
+    for net, o in (("D", w.d_optimizer), ("G", w.g_optimizer)):
+        assert o.exchange_stats["early_ranges"] >= 2, (net, o.exchange_stats)
