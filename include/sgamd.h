@@ -380,6 +380,14 @@ int sg_bias_act(int dtype, const void* x, const void* b, const void* xref, const
  * Negative padding crops. gain multiplies the result. */
 int sg_upfirdn2d(int dtype, const void* x, const float* f, void* y, int planes, int H, int W, int fh, int fw, int upx, int upy,
                  int downx, int downy, int padx0, int padx1, int pady0, int pady1, int flip_filter, float gain, sg_stream_t s);
+/* sg_filtered_lrelu: the forward of the reference's fused `_plugin.filtered_lrelu` (filtered_lrelu.cpp / .cu; definition filtered_lrelu.py:120-155)
+ * for SEPARABLE filters in ONE launch: y = downfir_fd(clamp(lrelu(upfir_fu(x + b; up, padding, gain up^2), slope) * gain); down) on [N][C][H][W]
+ * -> [N][C][Ho][Wo], Ho = (H * up + py0 + py1 - (fu_n - 1) - (fd_n - 1) + (down - 1)) / down. fu / fd: fp32 taps on the device (a one-tap {1}
+ * filter = identity), b: per-channel bias of x's dtype or NULL, clamp < 0 = none. The up-sampled intermediate stays in LDS. Returns -3 when a
+ * tile exceeds the LDS budget (run the chain sg_bias_act -> sg_upfirdn2d -> sg_bias_act -> sg_upfirdn2d instead, as for 2-D filters). */
+int sg_filtered_lrelu(int dtype, const void* x, const float* fu, const float* fd, const void* b, void* y, int N, int C, int H, int W,
+                      int fu_n, int fd_n, int up, int down, int px0, int px1, int py0, int py1, float gain, float slope, float clamp,
+                      int flip_filter, sg_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -170,6 +170,7 @@ _PROTOS = {
     "sg_topk_scatter": [_vp, _vp, _i, _vp, _i, _vp],
     "sg_bias_act": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _f, _f, _f, _vp],
     "sg_upfirdn2d": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
+    "sg_filtered_lrelu": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp],
 }
 
 

@@ -26,7 +26,9 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   const char* mode = getenv("SG_CONV_V2");
   const bool disabled = mode && mode[0] == '0';
   const bool force = mode && mode[0] == 'f';
-  if (disabled || d->stride != 1 || (pflags & SG_PIX_TRANSPOSED)) return false;
+  if (disabled || (pflags & SG_PIX_TRANSPOSED)) return false;
+  // stride 2 (round 3: InceptionV3's reduction layers ran on the generic engine): plain row order, no upsample-on-load
+  if (d->stride != 1 && (d->stride != 2 || (pflags & (SG_PIX_UPSAMPLE | SG_PIX_QUAD)) || getenv("SG_CONV_V2_STRIDE2_OFF"))) return false;
   if (d->C % 8 || d->ldx % 8 || d->R * d->S > 25 || J < 256) return false;
   // descriptor extents: offsets with bit 31 (activations) / bit 30 (weights) set must be out of range
   const long long xbytes = (((long long)d->N * d->Hs * d->Ws - 1) * d->ldx + d->C) * 2, wbytes = (long long)I * K * 2;
@@ -63,7 +65,7 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
   p.N = d->N; p.Hs = d->Hs; p.Ws = d->Ws; p.C = d->C; p.ldx = d->ldx;
   const int up = (pflags & SG_PIX_UPSAMPLE) ? 2 : 1;
   p.Hin = d->Hs * up; p.Win = d->Ws * up; p.Ho = d->Ho; p.Wo = d->Wo;
-  p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags;
+  p.R = d->R; p.S = d->S; p.pad_h = d->pad_h; p.pad_w = d->pad_w; p.flags = pflags; p.stride = d->stride;
   p.I = I; p.J = J; p.K = K; p.cpt = d->C / 8; p.ntap = d->R * d->S;
   p.wshift = ilog2_exact(d->Wo); p.hshift = ilog2_exact(d->Ho);
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;

@@ -23,6 +23,7 @@ struct ConvV2Params {
   int N, Hs, Ws, C, ldx;
   int Hin, Win, Ho, Wo;
   int R, S, pad_h, pad_w;
+  int stride;             // 1, or 2 without upsample-on-load / quad row order (InceptionV3's reduction layers): output (ho, wo) is centred on input (ho * stride, wo * stride)
   int flags;
   int I, J, K;
   int cpt;    // 16-byte chunks per tap = C / 8
@@ -231,14 +232,14 @@ __global__ __launch_bounds__(64 * WJ * WI) void sg_conv_v2_kernel(ConvV2Params p
     if (row < p.J) {     // halo bit mask, one bit per tap (nested loops: no division by S per tap -- that cost 7 us per tile)
       int t = 0;
       for (int rr = 0; rr < p.R; rr++) {
-        const bool hok = (unsigned)(ho - p.pad_h + rr) < (unsigned)p.Hin;
+        const bool hok = (unsigned)(ho * p.stride - p.pad_h + rr) < (unsigned)p.Hin;
         for (int ss = 0; ss < p.S; ss++, t++)
-          if (hok && (unsigned)(wo - p.pad_w + ss) < (unsigned)p.Win) m |= 1u << t;
+          if (hok && (unsigned)(wo * p.stride - p.pad_w + ss) < (unsigned)p.Win) m |= 1u << t;
       }
     }
     qinv[i] = ~m;
     qph[i] = UP && (ho & 1); qpw[i] = UP && (wo & 1);
-    const int hs = UP ? (ho >> 1) : ho, ws = UP ? (wo >> 1) : wo;
+    const int hs = UP ? (ho >> 1) : ho * p.stride, ws = UP ? (wo >> 1) : wo * p.stride;
     qoff[i] = ((unsigned)(n * p.Hs + hs) * (unsigned)p.Ws + (unsigned)ws) * ldx2;
   }
   unsigned poff[NPI];     // byte offset of the weight row; 0x40000000 = row outside the problem

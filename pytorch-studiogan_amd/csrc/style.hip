@@ -242,3 +242,128 @@ extern "C" int sg_upfirdn2d(int dtype, const void* x, const float* f, void* y, i
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- filtered_lrelu, forward, separable filters: ONE launch ------------------------------------------------------------------------------
+// reference src/utils/style_ops/filtered_lrelu.cu (the 1284-line tiled CUDA kernel) / filtered_lrelu.py:120-155 (its definition as a chain):
+//   y = downfir_fd( clamp( lrelu( upfir_fu(x + b; up, padding, gain up^2), slope ) * gain ) ; down )
+// Per workgroup: one output tile of one (n, c) plane. Everything between the input tile and the output tile lives in LDS as fp32:
+//   in [IH][IW] (x + b, zeros outside the image) -> horizontal up-FIR -> t1 [IH][AW] -> vertical up-FIR + leaky ReLU + gain + clamp -> mid [AH][AW]
+//   -> horizontal down-FIR -> t2 [AH][TW] -> vertical down-FIR -> y tile [TH][TW]
+// so the up-sampled intermediate (up^2 x the input) never reaches HBM -- the chain of four launches writes and reads it twice.
+// The up-FIR visits only the polyphase taps that meet a real sample (fu_n / up multiply-adds per value and axis).
+struct FlreluArgs {
+  const void* x; const void* b; const float* fu; const float* fd; void* y;
+  int planes, C, H, W, Ho, Wo;
+  int fu_n, fd_n, up, down, px0, py0;
+  int flip; float gain, slope, clamp;
+  int TH, TW, AH, AW, IH, IW;          // tile extents: output, activated intermediate, input
+};
+template <typename T>
+__global__ __launch_bounds__(256) void k_filtered_lrelu(FlreluArgs a) {
+  extern __shared__ float fl_sm[];
+  float* s_fu = fl_sm;                                  // [fu_n] flipped as needed, x up (per-axis gain)
+  float* s_fd = s_fu + a.fu_n;                          // [fd_n]
+  float* s_in = s_fd + a.fd_n;                          // [IH][IW]
+  float* s_t1 = s_in + a.IH * a.IW;                     // [IH][AW]
+  float* s_mid = s_t1 + a.IH * a.AW;                    // [AH][AW]
+  float* s_t2 = s_mid + a.AH * a.AW;                    // [AH][TW]
+  const int tid = threadIdx.x;
+  for (int i = tid; i < a.fu_n; i += 256) s_fu[i] = a.fu[a.flip ? i : a.fu_n - 1 - i] * (float)a.up;
+  for (int i = tid; i < a.fd_n; i += 256) s_fd[i] = a.fd[a.flip ? i : a.fd_n - 1 - i];
+  const int tx = (a.Wo + a.TW - 1) / a.TW, ty = (a.Ho + a.TH - 1) / a.TH;
+  int bid = blockIdx.x;
+  const int bx = bid % tx; bid /= tx;
+  const int by = bid % ty;
+  const int pl = bid / ty;
+  const int ox0 = bx * a.TW, oy0 = by * a.TH;
+  const int jx0 = ox0 * a.down, jy0 = oy0 * a.down;     // first intermediate (up-sampled + filtered) coordinate of the tile
+  // first input sample any up-FIR tap of the tile can meet: smallest k >= 0 with k * up >= j0 - p0
+  auto first_in = [&](int j0, int p0) { const int v = j0 - p0; return v <= 0 ? 0 : (v + a.up - 1) / a.up; };
+  const int ix0 = first_in(jx0, a.px0), iy0 = first_in(jy0, a.py0);
+  const T* xp = (const T*)a.x + (long long)pl * a.H * a.W;
+  const float bias = a.b ? to_f<T>(((const T*)a.b)[pl % a.C]) : 0.f;
+  for (int e = tid; e < a.IH * a.IW; e += 256) {
+    const int r = e / a.IW, c = e - r * a.IW;
+    const int iy = iy0 + r, ix = ix0 + c;
+    s_in[e] = (iy < a.H && ix < a.W) ? to_f<T>(xp[(long long)iy * a.W + ix]) + bias : 0.f;
+  }
+  __syncthreads();
+  // horizontal up-FIR: t1[r][j] = sum_t fu'[t] * xu[jx0 + j + t - px0]
+  for (int e = tid; e < a.IH * a.AW; e += 256) {
+    const int r = e / a.AW, j = e - r * a.AW;
+    const int u0 = jx0 + j - a.px0;                     // zero-inserted coordinate of tap 0
+    int t = ((-u0) % a.up + a.up) % a.up;               // first tap on a real sample
+    float acc = 0.f;
+    for (; t < a.fu_n; t += a.up) {
+      const int u = u0 + t;
+      if (u < 0) continue;
+      const int c = u / a.up - ix0;
+      if (c >= a.IW) break;
+      acc += s_fu[t] * s_in[r * a.IW + c];              // (columns beyond the image hold zeros)
+    }
+    s_t1[e] = acc;
+  }
+  __syncthreads();
+  // vertical up-FIR, then leaky ReLU, gain, clamp
+  for (int e = tid; e < a.AH * a.AW; e += 256) {
+    const int i = e / a.AW, j = e - i * a.AW;
+    const int u0 = jy0 + i - a.py0;
+    int t = ((-u0) % a.up + a.up) % a.up;
+    float acc = 0.f;
+    for (; t < a.fu_n; t += a.up) {
+      const int u = u0 + t;
+      if (u < 0) continue;
+      const int r = u / a.up - iy0;
+      if (r >= a.IH) break;
+      acc += s_fu[t] * s_t1[r * a.AW + j];
+    }
+    float v = (acc > 0.f ? acc : acc * a.slope) * a.gain;
+    if (a.clamp >= 0.f) v = fminf(fmaxf(v, -a.clamp), a.clamp);
+    s_mid[e] = v;
+  }
+  __syncthreads();
+  // horizontal down-FIR: t2[i][ox] = sum_t fd'[t] * mid[i][ox * down + t]
+  for (int e = tid; e < a.AH * a.TW; e += 256) {
+    const int i = e / a.TW, ox = e - i * a.TW;
+    float acc = 0.f;
+    const float* m = s_mid + i * a.AW + ox * a.down;
+    for (int t = 0; t < a.fd_n; t++) acc += s_fd[t] * m[t];
+    s_t2[e] = acc;
+  }
+  __syncthreads();
+  T* yp = (T*)a.y + (long long)pl * a.Ho * a.Wo;
+  for (int e = tid; e < a.TH * a.TW; e += 256) {
+    const int oy = e / a.TW, ox = e - oy * a.TW;
+    if (oy0 + oy >= a.Ho || ox0 + ox >= a.Wo) continue;
+    float acc = 0.f;
+    for (int t = 0; t < a.fd_n; t++) acc += s_fd[t] * s_t2[(oy * a.down + t) * a.TW + ox];
+    yp[(long long)(oy0 + oy) * a.Wo + ox0 + ox] = from_f<T>(acc);
+  }
+}
+// fu / fd: separable fp32 filters on the device (fu_n / fd_n taps, >= 1; a one-tap {1} filter is the identity). Returns -3 when the tile does
+// not fit the kernel's LDS budget (the caller then runs the chain of sg_bias_act / sg_upfirdn2d launches, which has no such limit).
+extern "C" int sg_filtered_lrelu(int dtype, const void* x, const float* fu, const float* fd, const void* b, void* y, int N, int C, int H, int W,
+                                 int fu_n, int fd_n, int up, int down, int px0, int px1, int py0, int py1, float gain, float slope, float clamp,
+                                 int flip_filter, sg_stream_t s) {
+  SG_CHECK(x && fu && fd && y && N > 0 && C > 0 && H > 0 && W > 0, "sg_filtered_lrelu: bad tensor arguments");
+  SG_CHECK(fu_n >= 1 && fd_n >= 1 && up >= 1 && down >= 1 && gain > 0.f && slope >= 0.f, "sg_filtered_lrelu: bad filter / factor / gain arguments");
+  const int Wo = (W * up + px0 + px1 - (fu_n - 1) - (fd_n - 1) + (down - 1)) / down;
+  const int Ho = (H * up + py0 + py1 - (fu_n - 1) - (fd_n - 1) + (down - 1)) / down;
+  SG_CHECK(Wo >= 1 && Ho >= 1, "sg_filtered_lrelu: empty output");
+  FlreluArgs a;
+  a.x = x; a.b = b; a.fu = fu; a.fd = fd; a.y = y; a.planes = N * C; a.C = C; a.H = H; a.W = W; a.Ho = Ho; a.Wo = Wo;
+  a.fu_n = fu_n; a.fd_n = fd_n; a.up = up; a.down = down; a.px0 = px0; a.py0 = py0; a.flip = flip_filter ? 1 : 0;
+  a.gain = gain; a.slope = slope; a.clamp = clamp;
+  a.TH = Ho < 16 ? Ho : 16; a.TW = Wo < 16 ? Wo : 16;
+  a.AH = (a.TH - 1) * down + fd_n; a.AW = (a.TW - 1) * down + fd_n;
+  a.IH = (a.AH + fu_n - 1 + up - 1) / up + 1; a.IW = (a.AW + fu_n - 1 + up - 1) / up + 1;
+  const size_t lds = sizeof(float) * ((size_t)fu_n + fd_n + (size_t)a.IH * a.IW + (size_t)a.IH * a.AW + (size_t)a.AH * a.AW + (size_t)a.AH * a.TW);
+  if (lds > 64 * 1024) { sg_set_error("sg_filtered_lrelu: tile does not fit the LDS budget (use the operator chain)"); return -3; }
+  const long long blocks = (long long)a.planes * ((Ho + a.TH - 1) / a.TH) * ((Wo + a.TW - 1) / a.TW);
+  SG_CHECK(blocks < (1ll << 31), "sg_filtered_lrelu: too many tiles");
+  if (dtype == SG_DTYPE_F32) hipLaunchKernelGGL(k_filtered_lrelu<float>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
+  else if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_filtered_lrelu<bf16_t>, dim3((unsigned)blocks), dim3(256), lds, (hipStream_t)s, a);
+  else { sg_set_error("sg_filtered_lrelu: fp32 / bf16 only"); return -1; }
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -562,3 +562,36 @@ def test_conv_epilogue_mask_and_residual(sg, case, monkeypatch):
                      mask=nhwc(m).to(d), res=nhwc(res).to(d), alpha=0.25 if pool else 1.0)
     torch.cuda.synchronize()
     check(f"mask + residual {case[:7]}", nchw(y.float().cpu()), yref, 4e-3)
+
+
+STRIDE2_CASES = [
+    # N, Cin, Cout, H, R, pad      -- stride-2 convolutions on the conv_v2 tile kernels (InceptionV3's reduction layers)
+    (4, 96, 96, 35, 3, 0),          # Mixed_6a.branch3x3dbl_3: 35 -> 17, valid
+    (2, 288, 384, 35, 3, 0),        # Mixed_6a.branch3x3
+    (3, 192, 320, 17, 3, 0),        # Mixed_7a.branch3x3_2: 17 -> 8, cout count no tile divides
+    (2, 64, 128, 16, 3, 1),         # padded, even size (DCGAN-style 4x4 s2 has its own transposed path; this is the plain strided form)
+    (2, 64, 96, 16, 1, 0),          # 1x1 stride 2
+]
+
+
+@pytest.mark.parametrize("case", STRIDE2_CASES)
+def test_conv_v2_stride2_matches_reference_and_generic(sg, case, monkeypatch):
+    from studiogan_amd import functional as F
+    N, Cin, Cout, H, R, pad = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cin, H, H), dt, 81)
+    w = rnd((Cout, Cin, R, R), dt, 82, 0.1)
+    bias = rnd((Cout,), torch.float32, 83)
+    yref = _conv_ref(x, w, 2, pad, False, False, False, bias, None)
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    outs = {}
+    for mode in ("force", "0"):
+        monkeypatch.setenv("SG_CONV_V2", mode)
+        y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, R, R, 2, pad, pad, 0, 0, bias=bias.to(d))
+        torch.cuda.synchronize()
+        outs[mode] = y.float().cpu()
+    assert tuple(nchw(outs["force"]).shape) == tuple(yref.shape)
+    check(f"conv v2 stride 2 {case}", nchw(outs["force"]), yref, 4e-3)
+    check(f"generic stride 2 {case}", nchw(outs["0"]), yref, 4e-3)
+    check(f"conv v2 vs generic stride 2 {case}", outs["force"], outs["0"], 4e-3)

@@ -88,6 +88,14 @@ def test_filtered_lrelu_matches_reference_vectors(sg, case):
     gx, gb = torch.autograd.grad(y, [x, b], _t(z, p + "gy").to(DEV))
     check(f"filtered_lrelu {tag} dx", gx, _t(z, p + "dx"), 3e-5)
     check(f"filtered_lrelu {tag} db", gb, _t(z, p + "db"), 3e-5)
+    # the one-launch forward (separable filters) against the four-launch operator chain
+    FL._FUSED[0] = False
+    try:
+        y2 = FL.filtered_lrelu(x, fu=None if fu is None else fu.to(DEV), fd=None if fd is None else fd.to(DEV), b=b, up=up, down=down, padding=pad,
+                               gain=float(gain), slope=slope, clamp=clamp, flip_filter=flip)
+    finally:
+        FL._FUSED[0] = True
+    check(f"filtered_lrelu {tag} fused vs chain", y, y2.detach().cpu(), 3e-5)
 
 
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
