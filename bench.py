@@ -522,7 +522,8 @@ def main():
     # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
     traffic, traffic_src = None, None
     try:
-        tname = "r02_conv_hbm_traffic_pmc.json" if os.path.exists(os.path.join(ROOT, "profiles", "r02_conv_hbm_traffic_pmc.json")) else "r01_conv_hbm_traffic_pmc_v2.json"
+        tname = next(n for n in ("r03_conv_hbm_traffic_pmc.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc_v2.json")
+                     if os.path.exists(os.path.join(ROOT, "profiles", n)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         if args.workload == "biggan128" and mixed and args.batch == 256:
             traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
@@ -543,7 +544,7 @@ def main():
                    "rccl_ranks": rccl_ranks},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels; with the block's 1x1 skip fused in from 16x16 outputs up) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",
