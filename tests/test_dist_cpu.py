@@ -166,3 +166,79 @@ def test_gather_layer_forward_concat_and_local_gradient():
     from studiogan_amd import losses as SL
     t = torch.randn(4)
     assert SL.gather_logits(t, None) is t
+
+
+class _FakeArena:
+    def __init__(self, n):
+        self.numel = n
+        self.grad = torch.zeros(n)
+
+
+class _FakeBank:
+    """stands in for bank.WeightBank: records which arena ranges the plan asked to fold"""
+    def __init__(self):
+        self.folded = []
+
+    def flush(self, lo=None, hi=None):
+        self.folded.append((lo, hi))
+
+
+def _exchange_plan_job(rank, world):
+    """optim.ExchangePlan's range logic on CPU tensors over gloo: a network of five 'blocks' whose parameters sit at arena offsets
+    0 / 1000 / 3000 / 3200 / 6000 (total 8000), two forwards per update (a discriminator update), min range 1500 elements."""
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd.optim import ExchangePlan
+    a = _FakeArena(8000)
+    a.grad[:] = torch.arange(8000, dtype=torch.float32) * (rank + 1)      # rank r holds (r + 1) * i: the all-reduced sum is 3 i at world 2
+    plan = ExchangePlan(a, min_elems=1500)
+    bank = _FakeBank()
+    bounds = [1000, 3000, 3200, 6000]            # offset of the first parameter BEHIND each block boundary
+    for _ in range(2):                            # two forwards register the same boundaries
+        for off in bounds:
+            plan.expect(off)
+    log = []
+    # an unarmed plain backward (an earlier accumulation micro-step would look like this) only counts
+    for off in reversed(bounds):
+        plan.crossed(off, bank)
+    assert plan.inflight == [] and bank.folded == []
+    plan.reset()
+    for _ in range(2):
+        for off in bounds:
+            plan.expect(off)
+    plan.arm(dist.group.WORLD)
+    # first forward's backward (the later-created graph runs first): nothing may be sent yet
+    for off in reversed(bounds):
+        plan.crossed(off, bank)
+        log.append(len(plan.inflight))
+    assert log == [0, 0, 0, 0] and bank.folded == []
+    # second forward's backward: 6000 closes [6000, 8000) = 2000 >= 1500 -> sent; 3200 closes only [3200, 6000) = 2800 -> sent;
+    # 3000 closes [3000, 3200) = 200 < 1500 -> waits; 1000 closes [1000, 3200) = 2200 -> sent (takes the waiting range along)
+    sent = []
+    for off in reversed(bounds):
+        plan.crossed(off, bank)
+        sent.append([(lo, hi) for lo, hi, _ in plan.inflight])
+    assert sent[0] == [(6000, 8000)] and sent[1] == [(6000, 8000), (3200, 6000)] and sent[2] == sent[1]
+    assert sent[3] == [(6000, 8000), (3200, 6000), (1000, 3200)]
+    assert bank.folded == [(6000, 8000), (3200, 6000), (1000, 3200)], "each sent range is folded first, exactly once"
+    early, rest = plan.take()
+    assert rest == 1000                                       # the head of the arena is left for step()
+    for lo, hi, work in early:
+        work.wait()
+    ref = torch.arange(8000, dtype=torch.float32)
+    s = sum(r + 1 for r in range(world))
+    ok_early = bool(torch.equal(a.grad[1000:], ref[1000:] * s))
+    ok_head = bool(torch.equal(a.grad[:1000], ref[:1000] * (rank + 1)))     # untouched
+    # a boundary at or behind what was already sent is ignored; reset re-arms cleanly
+    plan.crossed(6000, bank)
+    n_after = len(plan.inflight)
+    plan.reset()
+    return ok_early, ok_head, n_after, plan.done_lo, plan.armed
+
+
+def test_exchange_plan_ranges_gloo():
+    res = _spawn(_exchange_plan_job)
+    for r in range(2):
+        ok_early, ok_head, n_after, done_lo, armed = res[r]
+        assert ok_early, "ranges sent from the backward must hold the all-reduced sum"
+        assert ok_head, "the head of the arena must be left to step()"
+        assert n_after == 3 and done_lo == 8000 and armed is False
