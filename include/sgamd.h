@@ -87,6 +87,9 @@ typedef struct {
 } sg_conv_skip_desc;
 int sg_conv2d_fwd_skip(const sg_conv_skip_desc* d, sg_stream_t stream);
 int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d);
+/* Number of sg_conv2d_fwd problems this process has run on the row-streaming kernel (csrc/conv_rs.h: 3x3, <= 32 output channels, 128-pixel-wide
+ * bf16 images -- the RGB layers of the 128 x 128 configurations). Introspection for tests and benchmarks: which engine took a shape. */
+long long sg_conv_rs_launches(void);
 
 /* dw[co][r][s][c] += alpha * sum_{n,ho,wo} dy'[n,ho,wo,co] * x'[n, ho*stride-pad+r, wo*stride-pad+s, c] (fp32 atomics) */
 typedef struct {

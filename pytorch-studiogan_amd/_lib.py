@@ -79,6 +79,7 @@ _PROTOS = {
     "sg_conv2d_fwd": [C.POINTER(ConvFwdDesc), _vp],
     "sg_conv2d_fwd_skip": [C.POINTER(ConvSkipDesc), _vp],
     "sg_conv2d_fwd_skip_ok": [C.POINTER(ConvSkipDesc)],
+    "sg_conv_rs_launches": [],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_conv2d_wgrad_plan": [C.POINTER(ConvWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_wgrad_fuses_bias": [C.POINTER(ConvWgradDesc)],
@@ -193,6 +194,7 @@ def lib():
             fn = getattr(l, name)
             fn.argtypes = args
             fn.restype = _i
+        l.sg_conv_rs_launches.restype = _ll
         _lib = l
     return _lib
 

@@ -91,6 +91,10 @@ template <typename T> static bool conv_fwd_v4_try(const sg_conv_fwd_desc*, const
 template <> bool conv_fwd_v4_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
   return sg_conv_fwd_v4_try(d, e, I, J, K, pflags, st);      // conv_v4.hip
 }
+template <typename T> static bool conv_fwd_rs_try(const sg_conv_fwd_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
+template <> bool conv_fwd_rs_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
+  return sg_conv_fwd_rs_try(d, e, I, J, K, pflags, st);      // conv_rs.hip
+}
 template <typename T> static bool conv_fwd_sk_try(const sg_conv_fwd_desc*, const Epilogue<T>&, int, int, int, int, hipStream_t) { return false; }
 template <> bool conv_fwd_sk_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st) {
   return sg_conv_fwd_sk_try(d, e, I, J, K, pflags, st);      // conv_sk.hip
@@ -119,6 +123,7 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
   if (w_vec && x_vec && conv_fwd_sk_try<T>(d, e, I, J, K, pflags, st)) {}
+  else if (w_vec && x_vec && conv_fwd_rs_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec && conv_fwd_v4_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) {}
   else if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}

@@ -30,4 +30,5 @@ static void fill_geom(PixGeom<T>& g, const void* x, int N, int Hs, int Ws, int C
 bool sg_conv_fwd_v3_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);
 bool sg_conv_fwd_sk_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);
 bool sg_conv_fwd_v4_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);
+bool sg_conv_fwd_rs_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st);   // conv_rs.hip
 bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc* sk, const Epilogue<bf16_t>& e, int I, int J, int K, int pflags, hipStream_t st, bool dry);

@@ -244,11 +244,18 @@ class GradLink:
     (sg_conv2d_fwd with mask AND residual / sg_bn_bwd_apply_res). Without it autograd sums the two contributions in a separate elementwise
     launch per block (343 `add<bf16>` launches, 3.3 ms per C3 step in profiles/r03_bench_biggan128_bs256_kerneltrace_a.txt).
     The tail's backward always runs first (autograd executes nodes in reverse creation order), stashes its dx here and returns None for
-    that input; create_graph passes (gradient penalty) do not use the link."""
-    __slots__ = ("dx",)
+    that input; create_graph passes (gradient penalty) do not use the link.
 
-    def __init__(self):
+    chain=True (SelfAttention): SEVERAL convolutions read the same x (theta / phi / g) next to the residual. AttnOutFn's backward stashes the
+    residual's gradient; each of the convolutions takes what is stashed as the residual of its own data-gradient launch and stashes the sum
+    again, and the one that runs last (`pending` counts them, so the order among them does not matter) hands the total to autograd: the three
+    `add<bf16>` launches per attention backward (0.3 ms at 64 x 64 x 96, batch 256) become three residual reads."""
+    __slots__ = ("dx", "chain", "pending")
+
+    def __init__(self, chain=False):
         self.dx = None
+        self.chain = chain
+        self.pending = 0
 
     def take(self):
         t, self.dx = self.dx, None
@@ -334,6 +341,8 @@ class ConvFn(torch.autograd.Function):
         N, Hs, Ws, Cin = x.shape
         assert Cin == rt.cin_pad, f"conv input channels {Cin} != {rt.cin_pad}"
         ctx.link = link
+        if link is not None and link.chain:
+            link.pending += 1
         pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
         ef = L.EPI_POOL if cfg.out_pool else 0
         if res is not None:
@@ -377,6 +386,10 @@ class ConvFn(torch.autograd.Function):
             dx = _conv_dgrad(dy, x, rt, slot, cfg, res=skip_dx)
         elif skip_dx is not None:
             raise RuntimeError("GradLink: a skip gradient was handed over but this convolution's input needs no gradient")
+        if ctx.link is not None and ctx.link.chain:
+            ctx.link.pending -= 1
+            if ctx.link.pending > 0 and dx is not None:      # not the last reader of x: the next one adds this in its own launch
+                ctx.link.dx, dx = dx, None
         want_db = ctx.bias is not None and ctx.needs_input_grad[2]
         db_done = False
         if ctx.needs_input_grad[1]:
@@ -1069,9 +1082,10 @@ class AttnOutFn(torch.autograd.Function):
     """y = x + sigma * conv1x1(o)   (reference src/utils/ops.py:102-103), sigma read from device memory."""
 
     @staticmethod
-    def forward(ctx, x, o, weight, sigma, rt, slot):
+    def forward(ctx, x, o, weight, sigma, rt, slot, link=None):
         bank = rt.bank()
         x, o = _c(x), _c(o)
+        ctx.link = link
         y = conv2d_raw(o, bank.w_fwd(slot, rt), rt.Cin, rt.rows, 1, 1, res=x, alpha_ptr=sigma)
         ctx.save_for_backward(o, sigma)
         ctx.rt, ctx.slot = rt, slot
@@ -1095,7 +1109,10 @@ class AttnOutFn(torch.autograd.Function):
             do = conv2d_raw(dy, bank.w_dgrad(slot, rt), rt.rows, rt.Cin, 1, 1, alpha_ptr=sigma)
         if ctx.needs_input_grad[2]:
             conv2d_wgrad_raw(o, dy, bank.dwt(slot, rt), rt.Cin, rt.rows, 1, 1, H, W, alpha_ptr=sigma)
-        return dy, do, None, None, None, None
+        dx = dy
+        if ctx.link is not None and ctx.link.pending > 0 and ctx.needs_input_grad[0]:
+            ctx.link.dx, dx = dy, None      # theta / phi / g read the same x: their data gradients pick this up as a residual (GradLink chain)
+        return dx, do, None, None, None, None, None
 
 
 # ---------------------------------------------------------------------------------------------------------

@@ -260,13 +260,15 @@ class SelfAttention(nn.Module):
         self.sigma = nn.Parameter(torch.zeros(1), requires_grad=True)
 
     def forward_nhwc(self, x, slot=None):
-        theta = self.conv1x1_theta.forward_nhwc(x, slot)
-        phi = self.conv1x1_phi.forward_nhwc(x, slot)
-        g = self.conv1x1_g.forward_nhwc(x, slot)
+        # x has four readers (theta, phi, g, the residual): their gradients are summed inside the three data-gradient launches
+        link = F.GradLink(chain=True) if (F._GRAD_LINK[0] and torch.is_grad_enabled() and x.requires_grad) else None
+        theta = self.conv1x1_theta.forward_nhwc(x, slot, link=link)
+        phi = self.conv1x1_phi.forward_nhwc(x, slot, link=link)
+        g = self.conv1x1_g.forward_nhwc(x, slot, link=link)
         o = F.AttnCoreFn.apply(theta, phi, g)
         rt = self.conv1x1_attn._sg_rt
         slot = slot if slot is not None else rt.bank().current
-        return F.AttnOutFn.apply(x, o, self.conv1x1_attn.master_weight, self.sigma, rt, slot)
+        return F.AttnOutFn.apply(x, o, self.conv1x1_attn.master_weight, self.sigma, rt, slot, link)
 
     def forward(self, x):
         _, bank = _root_and_bank(self.conv1x1_theta)

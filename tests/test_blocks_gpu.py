@@ -86,6 +86,50 @@ def discriminator_fwd_bwd(name, mixed):
 
 
 @pytest.mark.parametrize("mixed", [False, True])
+def test_attention_input_gradient_chain_matches_autograd_sum(sg, mixed):
+    """functional.GradLink(chain=True) in ops.SelfAttention: the four gradients the attention input receives (theta / phi / g / residual) are
+    summed inside the three 1x1 data-gradient launches. Same network, same inputs, SG_GRAD_LINK on vs off: every gradient agrees (fp32: to
+    rounding of the summation order; bf16: one bf16 rounding per partial sum that autograd's add<bf16> makes as well), and with the link on
+    the three data-gradient launches of the attention really carry a residual."""
+    from studiogan_amd import functional as F
+    dev = torch.device("cuda:0")
+    fix, meta = load_golden("biggan32")
+    y = meta["yaml"]
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 3)
+    _, D = build_from_yaml(y, mixed, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    x, lab = fix["in/real0"].clone(), fix["in/rl0"]
+    sd = {k: v.clone() for k, v in D.state_dict().items()}
+    got, with_res = [], []
+    orig, keep = F._conv_dgrad, F._GRAD_LINK[0]
+    try:
+        for on in (False, True):
+            n = [0]
+
+            def counting(dy, xx, rt, slot, cfg, res=None):
+                n[0] += (res is not None) and cfg.R == 1 and not cfg.in_relu
+                return orig(dy, xx, rt, slot, cfg, res=res)
+            F._conv_dgrad, F._GRAD_LINK[0] = counting, on
+            D.load_state_dict(sd)      # same power-iteration state for both passes
+            for p in D.parameters():
+                p.grad = None
+            xd = x.to(dev).requires_grad_(True)
+            D(xd, lab.to(dev))["adv_output"].sum().backward()
+            torch.cuda.synchronize()
+            got.append({"dx": xd.grad.float().cpu(), **{k: p.grad.float().cpu() for k, p in D.named_parameters()}})
+            with_res.append(n[0])
+    finally:
+        F._conv_dgrad, F._GRAD_LINK[0] = orig, keep
+    assert with_res == [0, 3], with_res
+    C = Collector()
+    for k in got[0]:
+        C.check("chain vs autograd sum: " + k, got[1][k], got[0][k], 1e-5 if not mixed else 2e-2, l2=True)
+    C.finish()
+
+
+@pytest.mark.parametrize("mixed", [False, True])
 @pytest.mark.parametrize("bn_mode", ["track", "untrack", "eval"])
 @pytest.mark.parametrize("name", NAMES)
 def test_generator_fwd_bwd(sg, name, mixed, bn_mode):

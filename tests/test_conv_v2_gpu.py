@@ -595,3 +595,50 @@ def test_conv_v2_stride2_matches_reference_and_generic(sg, case, monkeypatch):
     check(f"conv v2 stride 2 {case}", nchw(outs["force"]), yref, 4e-3)
     check(f"generic stride 2 {case}", nchw(outs["0"]), yref, 4e-3)
     check(f"conv v2 vs generic stride 2 {case}", outs["force"], outs["0"], 4e-3)
+
+
+RS_CASES = [
+    # N, Cin, Cout, H, relu_in, relu_out, bias, alpha, strip rows (SG_CONV_RS_SH; 0 = the launcher's choice)
+    # -- csrc/conv_rs.h: the row-streaming kernel of the RGB layers (3x3, <= 32 output channels, 128-pixel-wide images, weights in registers)
+    (2, 96, 8, 128, False, False, True, 1.0, 128),      # one strip per image: top / bottom image borders inside the walk (G's RGB layer at batch 256)
+    (2, 96, 8, 128, False, False, False, 1.0, 0),       # the launcher's strips (8 rows at this batch): halo rows from the neighbouring strips
+    (3, 96, 8, 128, True, True, True, 0.5, 32),         # ReLU on load, ReLU on store, scale
+    (2, 64, 16, 128, False, False, True, 1.0, 16),      # 64 input channels (18 DMA pieces per row), two cout groups
+    (2, 96, 32, 128, False, False, True, 1.0, 64),      # a full 32-cout tile
+    (1, 96, 24, 64, False, False, True, 1.0, 4),        # 64 x 128 images (H != W), three cout groups, 4-row strips (the ring wraps inside the prologue)
+]
+
+
+@pytest.mark.parametrize("case", RS_CASES)
+def test_conv_rs_matches_reference_and_halo_kernel(sg, case, monkeypatch):
+    """The row-streaming kernel against CPU fp64 and against the halo kernel it replaces on these shapes (SG_CONV_RS=0), forward and -- as the
+    data gradient of the discriminator's RGB stem runs it -- with the flipped [Cin][R][S][Cout] image."""
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, relu_in, relu_out, with_bias, alpha, sh = case
+    Wd = 128
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cin, H, Wd), dt, 171)
+    w = rnd((Cout, Cin, 3, 3), dt, 172, 0.1)
+    bias = rnd((Cout,), torch.float32, 173) if with_bias else None
+    yref = _conv_ref(x, w, 1, 1, relu_in, False, False, None, None) * alpha
+    if bias is not None:
+        yref = yref + bias.double().view(1, -1, 1, 1)
+    if relu_out:
+        yref = torch.relu(yref)
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = L.PIX_RELU if relu_in else 0
+    ef = L.EPI_RELU if relu_out else 0
+    outs = {}
+    for mode in ("force", "0"):
+        monkeypatch.setenv("SG_CONV_RS", mode)
+        if sh:
+            monkeypatch.setenv("SG_CONV_RS_SH", str(sh))
+        before = L.lib().sg_conv_rs_launches()
+        y = F.conv2d_raw(xd, wd.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, bias=None if bias is None else bias.to(d), alpha=alpha)
+        torch.cuda.synchronize()
+        assert L.lib().sg_conv_rs_launches() - before == (1 if mode == "force" else 0), "the wrong engine took the problem"
+        outs[mode] = y.float().cpu()
+    check(f"conv rs {case}", nchw(outs["force"]), yref, 4e-3)
+    check(f"conv rs vs halo kernel {case}", outs["force"], outs["0"], 4e-3)
+    assert not torch.equal(outs["force"], torch.zeros_like(outs["force"]))
