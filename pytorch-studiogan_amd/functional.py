@@ -86,9 +86,7 @@ def conv2d_skip_raw(x, w_ptr, Cin, Cout, x2, w2_ptr, C2, x2_up=False, pix_flags=
     skip convolution as extra K-slices of its last 3x3 launch. dry=True: only ask whether the fused kernel takes the problem.
     Returns the output tensor, or None when the problem is not eligible (the caller then runs the two launches)."""
     sk = L.ConvSkipDesc()
-    out = None
-    if dry:    # eligibility does not depend on the output pointer value, only on its alignment / pitch: a real allocation is made anyway
-        pass
+    # (dry: eligibility does not depend on the output pointer's value, only on its alignment / pitch -- a real allocation is made anyway)
     out = conv2d_raw(x, w_ptr, Cin, Cout, 3, 3, 1, 1, 1, pix_flags, epi_flags, bias=bias, alpha=alpha, desc=sk.main)
     sk.x2, sk.w2, sk.bias2 = L.ptr(x2), w2_ptr, L.ptr(bias2)
     sk.C2, sk.ldx2, sk.x2_up = C2, x2.shape[3], 1 if x2_up else 0
