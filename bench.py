@@ -544,7 +544,7 @@ def main():
                    "rccl_ranks": rccl_ranks},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels; with the block's 1x1 skip fused in from 16x16 outputs up) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels; with the block's 1x1 skip fused in from 16x16 outputs up) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers at 128 x 128) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",

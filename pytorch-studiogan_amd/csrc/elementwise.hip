@@ -345,8 +345,51 @@ template <typename T> __global__ __launch_bounds__(256) void k_dot(const T* x, c
     unsafeAtomicAdd(out, acc * sc);
   }
 }
+// 16-byte loads, four pairs in flight per thread (the element-wise walk above moved the two 201 MB operands of the attention gate's gradient at
+// 1.6 TB/s: 252 us per call, five calls per C3 step in profiles/r03_bench_biggan128_bs256_kerneltrace_final.txt)
+template <typename T> __global__ __launch_bounds__(256) void k_dot_vec(const T* x, const T* y, long long nvec, float* out, float scale, const float* scale_ptr) {
+  constexpr int V = ET<T>::VEC;
+  __shared__ float sm[4];
+  const long long stride = (long long)gridDim.x * 256;
+  float acc = 0.f;
+  long long i = blockIdx.x * 256ll + threadIdx.x;
+  for (; i + 3 * stride < nvec; i += 4 * stride) {
+    u32x4 a[4], b[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) { a[k] = *(const u32x4*)(x + (i + k * stride) * V); b[k] = *(const u32x4*)(y + (i + k * stride) * V); }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      float xa[V], ya[V];
+      unpack16<T>(a[k], xa); unpack16<T>(b[k], ya);
+#pragma unroll
+      for (int e = 0; e < V; e++) acc += xa[e] * ya[e];
+    }
+  }
+  for (; i < nvec; i += stride) {
+    float xa[V], ya[V];
+    unpack16<T>(*(const u32x4*)(x + i * V), xa); unpack16<T>(*(const u32x4*)(y + i * V), ya);
+#pragma unroll
+    for (int e = 0; e < V; e++) acc += xa[e] * ya[e];
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) {
+    float sc = scale; if (scale_ptr) sc *= *scale_ptr;
+    unsafeAtomicAdd(out, acc * sc);
+  }
+}
 extern "C" int sg_dot(int dtype, const void* x, const void* y, long long n, float* out, float scale, const float* scale_ptr, sg_stream_t s) {
   SG_CHECK(x && y && out, "sg_dot: null");
+  bool done = false;
+  DISPATCH_T(dtype, {
+    constexpr int V = ET<T>::VEC;
+    if (n % V == 0 && n >= (1ll << 16) && (((uintptr_t)x | (uintptr_t)y) & 15) == 0) {
+      const long long nvec = n / V;
+      int blocks = nblk(nvec, 256 * 4); if (blocks > 2048) blocks = 2048;
+      hipLaunchKernelGGL(k_dot_vec<T>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, nvec, out, scale, scale_ptr);
+      done = true;
+    }
+  });
+  if (done) { SG_LAUNCH_CHECK(); return 0; }
   int blocks = nblk(n, 256 * 8); if (blocks > 1024) blocks = 1024;
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_dot<T>, dim3(blocks), dim3(256), 0, (hipStream_t)s, (const T*)x, (const T*)y, n, out, scale, scale_ptr));
   SG_LAUNCH_CHECK();
@@ -512,12 +555,20 @@ extern "C" int sg_pd_head_fwd(const float* h, const float* w1, const float* b1, 
   SG_LAUNCH_CHECK();
   return 0;
 }
-__global__ void k_pd_head_bwd(const float* h, const float* w1, const float* emb, const float* dadv, float* dh, float* dw1, float* db1, float* demb, int B, int C) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+// block = 32 channels x 8 batch lanes: a thread walks its eighth of the batch with independent, unrolled loads; the weight-gradient partials of
+// the 8 lanes are combined through LDS in a fixed order (deterministic, no atomics). The one-thread-per-channel loop this replaces walked the
+// whole batch with a load -> store -> load dependency per sample: 199 us per call at batch 256 x 1536 channels (r03 kernel trace), all latency.
+__global__ __launch_bounds__(256) void k_pd_head_bwd(const float* __restrict__ h, const float* __restrict__ w1, const float* __restrict__ emb,
+                                                     const float* __restrict__ dadv, float* __restrict__ dh, float* __restrict__ dw1,
+                                                     float* __restrict__ db1, float* __restrict__ demb, int B, int C) {
+  __shared__ float sm[8][32];
+  const int cl = threadIdx.x & 31, bl = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + cl;
+  float aw = 0.f;
   if (c < C) {
-    float aw = 0.f;
     const float w = w1[c];
-    for (int b = 0; b < B; b++) {
+#pragma unroll 4
+    for (int b = bl; b < B; b += 8) {
       const float g = dadv[b];
       const float hv = h[(long long)b * C + c];
       float wt = w;
@@ -525,9 +576,16 @@ __global__ void k_pd_head_bwd(const float* h, const float* w1, const float* emb,
       dh[(long long)b * C + c] = g * wt;
       aw += g * hv;
     }
-    dw1[c] += aw;
   }
-  if (c == 0 && db1) {
+  sm[bl][cl] = aw;
+  __syncthreads();
+  if (bl == 0 && c < C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; k++) t += sm[k][cl];
+    dw1[c] += t;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0 && db1) {
     float ab = 0.f;
     for (int b = 0; b < B; b++) ab += dadv[b];
     db1[0] += ab;
@@ -535,7 +593,7 @@ __global__ void k_pd_head_bwd(const float* h, const float* w1, const float* emb,
 }
 extern "C" int sg_pd_head_bwd(const float* h, const float* w1, const float* emb, const float* dadv, float* dh, float* dw1, float* db1, float* demb, int B, int C, sg_stream_t s) {
   SG_CHECK(h && w1 && dadv && dh && dw1 && (!emb || demb), "sg_pd_head_bwd: null");
-  hipLaunchKernelGGL(k_pd_head_bwd, dim3((C + 63) / 64), dim3(64), 0, (hipStream_t)s, h, w1, emb, dadv, dh, dw1, db1, demb, B, C);
+  hipLaunchKernelGGL(k_pd_head_bwd, dim3((C + 31) / 32), dim3(256), 0, (hipStream_t)s, h, w1, emb, dadv, dh, dw1, db1, demb, B, C);
   SG_LAUNCH_CHECK();
   return 0;
 }

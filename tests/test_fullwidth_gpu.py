@@ -1,7 +1,7 @@
 """GPU: parity of the BENCHMARKED configurations at their real channel widths and resolutions (tests/golden/*w: BigGAN-128 ch 96 =
 configs/ImageNet/BigGAN-256.yaml, SNGAN-32 ch 64, WGAN-GP ResNet-128, BigGAN-deep-128 ch 128), with the tile-count / problem-size
-heuristics of the dispatchers switched off (SG_CONV_V3 / SG_CONV_V2 / SG_CONV_SK = force, SG_WGRAD_BJ256 = force) so that the
-kernels bench.py runs at batch 256 -- halo conv_v3 (incl. the 96x512 tile), streaming conv_sk, conv_v2, wgrad_v2 (both cout tiles),
+heuristics of the dispatchers switched off (SG_CONV_V3 / SG_CONV_V2 / SG_CONV_SK / SG_CONV_RS = force, SG_WGRAD_BJ256 = force) so that the
+kernels bench.py runs at batch 256 -- halo conv_v3 (incl. the 96x512 tile), streaming conv_sk, row-streaming conv_rs (RGB layers), conv_v2, wgrad_v2 (both cout tiles),
 fused attention at HW = 4096 -- are the kernels under test at the fixtures' small batch.
 
 Three comparisons per fixture (the width-8 fixtures get the same three in test_model_gpu.py / test_blocks_gpu.py):
@@ -30,7 +30,7 @@ WIDE256 = ["bigdeep256w"]
 
 @pytest.fixture
 def forced(monkeypatch):
-    for k in ("SG_CONV_V4", "SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_WGRAD_BJ256", "SG_WGRAD_V3"):
+    for k in ("SG_CONV_V4", "SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_CONV_RS", "SG_WGRAD_BJ256", "SG_WGRAD_V3"):
         monkeypatch.setenv(k, "force")
 
 

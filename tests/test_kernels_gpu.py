@@ -587,3 +587,44 @@ def test_attention_fused_backward_matches_unfused_chain(sg, shape):
         check(f"fused bwd dg vs fp64 ({what})", dg1.float().cpu(), gr.grad, 3e-2)
         dref = (do.double().cpu() * o).sum(-1)
         check(f"delta ({what})", delta.cpu().double(), dref, 5e-3)
+
+
+@pytest.mark.parametrize("dtype", DT)
+@pytest.mark.parametrize("n", [1000, 65536, 8 * 123457, 3 * 1048576 + 8])      # scalar walk; 16-byte path with the 4-deep body / its tail
+def test_dot_product(sg, dtype, n):
+    """sg_dot (the attention gate's gradient <dy, conv1x1(o)> and the squared-norm statistics): out += scale * <x, y>, both code paths."""
+    from studiogan_amd import _lib as L
+    d = dev()
+    x = torch.randn(n, generator=torch.Generator().manual_seed(5)).to(dtype)
+    y = torch.randn(n, generator=torch.Generator().manual_seed(6)).to(dtype)
+    ref = 0.5 + 0.25 * float((x.double() * y.double()).sum())
+    xd, yd = x.to(d), y.to(d)
+    out = torch.full((1,), 0.5, dtype=torch.float32, device=d)
+    L.call("sg_dot", L.dt(dtype), xd.data_ptr(), yd.data_ptr(), n, out.data_ptr(), 0.25, None, L.stream())
+    torch.cuda.synchronize()
+    assert abs(float(out) - ref) <= 2e-4 * (abs(ref) + n ** 0.5), (float(out), ref)
+
+
+@pytest.mark.parametrize("with_emb", [False, True])
+@pytest.mark.parametrize("shape", [(5, 40), (256, 1536), (37, 96)])
+def test_projection_head_backward(sg, shape, with_emb):
+    """sg_pd_head_bwd: dh = dadv (w1 + emb), dw1 += sum_b dadv h, db1 += sum dadv, demb = dadv h (reference big_resnet.py:363,387 backward)."""
+    from studiogan_amd import _lib as L
+    d = dev()
+    B, Cc = shape
+    g = torch.Generator().manual_seed(11)
+    h, w1, emb, dadv = torch.randn(B, Cc, generator=g), torch.randn(Cc, generator=g), torch.randn(B, Cc, generator=g), torch.randn(B, generator=g)
+    dw0, db0 = torch.randn(Cc, generator=g), torch.randn(1, generator=g)
+    hd, wd, ed, gd = h.to(d), w1.to(d), emb.to(d), dadv.to(d)
+    dh = torch.empty(B, Cc, device=d)
+    demb = torch.empty(B, Cc, device=d)
+    dw1, db1 = dw0.to(d), db0.to(d)
+    L.call("sg_pd_head_bwd", hd.data_ptr(), wd.data_ptr(), ed.data_ptr() if with_emb else None, gd.data_ptr(), dh.data_ptr(), dw1.data_ptr(),
+           db1.data_ptr(), demb.data_ptr() if with_emb else None, B, Cc, L.stream())
+    torch.cuda.synchronize()
+    wt = w1.double()[None, :] + (emb.double() if with_emb else 0.0)
+    check("pd head dh", dh.cpu(), dadv.double()[:, None] * wt, 1e-5)
+    check("pd head dw1", dw1.cpu(), dw0.double() + (dadv.double()[:, None] * h.double()).sum(0), 1e-5)
+    check("pd head db1", db1.cpu(), db0.double() + dadv.double().sum(), 1e-5)
+    if with_emb:
+        check("pd head demb", demb.cpu(), dadv.double()[:, None] * h.double(), 1e-5)

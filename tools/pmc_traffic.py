@@ -10,7 +10,7 @@ import json
 import re
 import sys
 
-CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
+CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
 
 
 def collect(path, counter):
@@ -40,7 +40,7 @@ def main():
         if "k_splitk_reduce" not in k:      # the reduce belongs to the weight-gradient launch that precedes it
             tot_n += n
         tot_b += rd + wr
-    print(json.dumps({"kernel_family": "convolution engine (sg_conv_v4 / sg_conv_v3 / sg_conv_v2 / sg_conv_sk / sg_wgrad_v3 / sg_wgrad_v2 / sg_wgrad_sk / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
+    print(json.dumps({"kernel_family": "convolution engine (sg_conv_v4 / sg_conv_v3 / sg_conv_v2 / sg_conv_sk / sg_conv_rs / sg_wgrad_v3 / sg_wgrad_v2 / sg_wgrad_sk / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
                       "hbm_bytes_per_launch": round(tot_b / max(tot_n, 1)), "read_side_doubled": True,
                       "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 --no-extras --fid-samples 0 --no-cpu-baseline; launches = sg_conv2d_fwd / sg_conv2d_wgrad calls (a weight-gradient launch includes its split-K reduce)",
                       "per_kernel": rows}, indent=1))
