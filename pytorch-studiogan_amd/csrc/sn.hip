@@ -22,7 +22,7 @@ template <class LAYER> __device__ __forceinline__ long long sn_widx(const LAYER&
 }
 
 // grid (col tiles of 1024, SN_SPLITS, layers): partial[split][k] = sum over the split's rows of W[o][k] u[o].
-// A thread owns 4 adjacent columns (one 16-byte load per row, 4 KB contiguous per row and block) and keeps 16 (8) rows in flight: the
+// A thread owns 4 adjacent columns (one 16-byte load per row, 4 KB contiguous per row and block) and keeps 8 rows in flight (16 measured SLOWER, 129 -> 153 us per launch, session r3n): the
 // one-float-per-thread column walk this replaces touched 1 KB per 55 KB row and ran at 0.35-0.95 TB/s (r01 kernel trace).
 __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* work) {
   const sg_sn_layer l = L[blockIdx.z];
@@ -36,13 +36,6 @@ __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* wor
     const float* wp = l.w + k;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     int o = o0;
-    for (; o + 16 <= o1; o += 16) {      // 16 rows in flight where the split has them (the 1536-row layers: 96 rows per split, 224 blocks per layer)
-      f32x4 r[16]; float uu[16];
-#pragma unroll
-      for (int e = 0; e < 16; e++) { r[e] = *(const f32x4*)(wp + (long long)(o + e) * l.cols); uu[e] = l.u[o + e]; }
-#pragma unroll
-      for (int e = 0; e < 16; e++) { acc[0] += r[e][0] * uu[e]; acc[1] += r[e][1] * uu[e]; acc[2] += r[e][2] * uu[e]; acc[3] += r[e][3] * uu[e]; }
-    }
     for (; o + 8 <= o1; o += 8) {
       f32x4 r[8]; float uu[8];
 #pragma unroll
@@ -70,23 +63,12 @@ __global__ __launch_bounds__(256) void k_sn_v(const sg_sn_layer* L, float* work,
   if (!l.apply_sn || !l.do_power_iter) return;
   float* part = work + l.work_off;
   float nn = 0.f;
-  // four columns per pass: 64 loads in flight before the first store (a store to part[] orders everything behind it); same summation order
-  for (int k0 = threadIdx.x; k0 < l.cols; k0 += 256 * 4) {
-    float pv[4][SN_SPLITS];
+  for (int k = threadIdx.x; k < l.cols; k += 256) {
+    float t = 0.f;
 #pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int k = k0 + 256 * e;
-#pragma unroll
-      for (int s = 0; s < SN_SPLITS; s++) pv[e][s] = k < l.cols ? part[(long long)s * l.cols + k] : 0.f;
-    }
-#pragma unroll
-    for (int e = 0; e < 4; e++) {
-      const int k = k0 + 256 * e;
-      float t = 0.f;
-#pragma unroll
-      for (int s = 0; s < SN_SPLITS; s++) t += pv[e][s];
-      if (k < l.cols) { part[k] = t; nn += t * t; }  // same thread re-reads part[k] below
-    }
+    for (int s = 0; s < SN_SPLITS; s++) t += part[(long long)s * l.cols + k];
+    part[k] = t;  // same thread re-reads it below
+    nn += t * t;
   }
   nn = block_sum_256(nn, sm);
   const float inv = 1.f / fmaxf(sqrtf(nn), eps);
