@@ -15,11 +15,9 @@ MI355X-first layout of the *weight side* of the hot path:
 Parameter names/shapes stay exactly the reference's (`weight_orig`, `weight_u`, `weight_v`, `bias`, ...), so
 `state_dict()` / `load_state_dict(strict=True)` interchange with StudioGAN checkpoints (reference src/utils/ckpt.py:38).
 """
-import ctypes as C
 import weakref
 
 import torch
-import torch.nn as nn
 
 from . import _lib as L
 

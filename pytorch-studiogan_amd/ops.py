@@ -10,7 +10,6 @@ import torch.nn as nn
 from torch.nn import init
 import torch.nn.functional as F_
 
-from . import _lib as L
 from . import functional as F
 from .bank import get_bank
 
