@@ -642,3 +642,43 @@ def test_conv_rs_matches_reference_and_halo_kernel(sg, case, monkeypatch):
     check(f"conv rs {case}", nchw(outs["force"]), yref, 4e-3)
     check(f"conv rs vs halo kernel {case}", outs["force"], outs["0"], 4e-3)
     assert not torch.equal(outs["force"], torch.zeros_like(outs["force"]))
+
+
+RS96_CASES = [
+    # N, H, relu_in, pool, relu_out, bias, strip rows     -- csrc/conv_rs96.h (EXPERIMENTAL, default off): 96 -> 96 channels, 3x3, 128-pixel-wide images
+    (2, 128, False, False, False, True, 128),       # G's last 3x3 (plain + bias), one strip per image
+    (2, 128, True, True, False, True, 0),           # D's first-block tail: ReLU on load, 2x2 average pooling (alpha = 0.25), launcher's strips
+    (3, 64, True, False, True, False, 16),          # 64 x 128 images, ReLU on store, no bias
+    (2, 128, False, True, False, True, 2),          # pooling with two-row strips (every strip one pooled row)
+]
+
+
+@pytest.mark.skipif(os.environ.get("SG_EXPERIMENTAL") != "1", reason="conv_rs96.h was written without GPU time left (round 3): enable with SG_EXPERIMENTAL=1")
+@pytest.mark.parametrize("case", RS96_CASES)
+def test_conv_rs96_matches_reference_and_halo_kernel(sg, case, monkeypatch):
+    from studiogan_amd import functional as F, _lib as L
+    N, H, relu_in, pool, relu_out, with_bias, sh = case
+    Wd, Cc = 128, 96
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    x = rnd((N, Cc, H, Wd), dt, 271)
+    w = rnd((Cc, Cc, 3, 3), dt, 272, 0.05)
+    bias = rnd((Cc,), torch.float32, 273) if with_bias else None
+    yref = _conv_ref(x, w, 1, 1, relu_in, False, pool, bias, None)
+    if relu_out:
+        yref = torch.relu(yref)
+    xd, wd = nhwc(x).to(d), w.permute(0, 2, 3, 1).contiguous().to(d)
+    pf = L.PIX_RELU if relu_in else 0
+    ef = (L.EPI_POOL if pool else 0) | (L.EPI_RELU if relu_out else 0)
+    outs = {}
+    for mode in ("force", "0"):
+        monkeypatch.setenv("SG_CONV_RS96", mode)
+        if sh:
+            monkeypatch.setenv("SG_CONV_RS_SH", str(sh))
+        before = L.lib().sg_conv_rs_launches()
+        y = F.conv2d_raw(xd, wd.data_ptr(), Cc, Cc, 3, 3, 1, 1, 1, pf, ef, bias=None if bias is None else bias.to(d), alpha=0.25 if pool else 1.0)
+        torch.cuda.synchronize()
+        assert L.lib().sg_conv_rs_launches() - before == (1 if mode == "force" else 0), "the wrong engine took the problem"
+        outs[mode] = y.float().cpu()
+    check(f"conv rs96 {case}", nchw(outs["force"]), yref, 4e-3)
+    check(f"conv rs96 vs halo kernel {case}", outs["force"], outs["0"], 4e-3)
