@@ -23,7 +23,7 @@
 //     "at most PPW outstanding" leaves only pieces of the newest row whether or not the store has retired
 //   * per step and CU: 54 MFMAs x 32 cycles per SIMD (1728 cycles; 3/4 of each 32-cout MFMA is padding at 8 couts) against 4 waves x 54
 //     conflict-free ds_read_b128 = 864 LDS cycles, and 24.6 KB of HBM per 0.75 us step is ~8 TB/s over 256 CUs: matrix pipe and HBM run
-//     out together, ~0.11 ms per launch at batch 256
+//     out together, ~0.11 ms per launch at batch 256 by that count; measured 0.195 ms (4.5 TB/s), see the note at the DMA issue below
 //   * epilogue in registers: scale, bias, ReLU, bf16 pack (no mask / residual / pooling: the launcher leaves those to conv_v3.h)
 #pragma once
 #include "conv_v2.h"
@@ -163,8 +163,9 @@ __global__ __launch_bounds__(256) void sg_conv_rs_kernel(ConvRsParams p, Epilogu
 #pragma unroll
       for (int ks = 0; ks < NKT; ks++) {
         acc[ks & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[t][ks], qf[t & 1][ks], acc[ks & 1], 0, 0, 0);
-        // the PPW pieces of row j + 4, one behind each of the step's first MFMAs: a piece costs 60-180 issue cycles, which in front of the
-        // step's first MFMA were 7 pieces of idle matrix pipe per row (first version: 0.198 ms per launch at batch 256, r3l)
+        // the PPW pieces of row j + 4, one behind each of the step's first MFMAs (a piece costs 60-180 issue cycles). Measured against the
+        // first version, which issued all of them in front of the step's first MFMA: 0.198 -> 0.195 ms per launch at batch 256 (r3l / r3m) --
+        // nothing; the kernel waits on the memory system (4.5 TB/s, HBM traffic by PMC = 1.0003 x the algorithmic bytes), not on issue slots
         if (t * NKT + ks < PPW) {
           __builtin_amdgcn_sched_barrier(0);
           issue_piece(j + 4, t * NKT + ks);
