@@ -360,3 +360,16 @@ def test_device_dataset_shards_like_a_distributed_sampler():
     # one rank, no process group: the whole data set, as before
     ds = DeviceDataset(imgs, labels, device="cpu", seed=5)
     assert ds.world_size == 1 and ds.shard_len() == N
+
+
+@pytest.mark.parametrize("relu,pool", [(False, False), (True, True)])
+def test_conv_rs96_index_model(relu, pool):
+    """tools/rs96_model.py replays csrc/conv_rs96.h (experimental, not yet run on a GPU) lane by lane with the kernel's own address formulas
+    -- DMA piece mapping, ring slots, fragment addresses, MFMA layout, register epilogue incl. pooling -- against a direct convolution.
+    Integer data: the result must be exact. Two strips per image, so strip-interior halo rows and the image borders are both walked."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("rs96_model", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools", "rs96_model.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    assert m.run(N=1, H=4, SH=2, relu=relu, pool=pool, seed=3) == 0.0
