@@ -91,6 +91,50 @@ int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d);
  * bf16 images -- the RGB layers of the 128 x 128 configurations). Introspection for tests and benchmarks: which engine took a shape. */
 long long sg_conv_rs_launches(void);
 
+/* ---- "quad" convolutions: a 3x3 / pad-1 convolution next to a 2x resampling, through the exact filter identity (csrc/conv_q.h) -------
+ * SG_Q_POOL: out[N,Hl,Wl,Cout] = epilogue( alpha * avgpool2(conv3x3(relu?(x); w)) + bias ),  x: [N,2Hl,2Wl,C]
+ *            = conv4x4 / stride 2 / pad 1 with the pooled filter: replaces `conv2d2` + `average_pooling` of the reference's discriminator
+ *            blocks (src/models/big_resnet.py:177-192,221-242) and the data gradient of SG_Q_UP.
+ * SG_Q_UP:   out[N,2Hl,2Wl,Cout] = epilogue( alpha * conv3x3(nearest_up2(relu?(x)); w) + bias ),  x: [N,Hl,Wl,C]
+ *            = four 2x2 convolutions, one per output parity: replaces `F.interpolate(scale_factor=2)` + `conv2d1` of the generator blocks
+ *            (big_resnet.py:28-42) and the data gradient of SG_Q_POOL. mask / res / out are tensors of the FINE grid.
+ * 16 C MACs per low-resolution position and output channel instead of 36 C. wq: the quad filter image [Cout][4 views][4 taps][C] written by
+ * sg_quad_pack from the 3x3 image (mode 0 / 1: forward images of POOL / UP from [Cout][3][3][C]; mode 2 / 3: the data-gradient images of
+ * POOL / UP -- to be run with form UP / POOL -- from the flipped transposed image [Cin][2-r][2-s][Cout] the 3x3 data gradient uses).
+ * bf16, C % 32 == 0, Cout % 64 == 0 or % 96 == 0, Hl / Wl powers of two, Wl >= 4. Epilogue order as sg_conv2d_fwd: scale, bias, mask, residual, ReLU. */
+#define SG_Q_POOL 0
+#define SG_Q_UP 1
+typedef struct {
+  int dtype, form;
+  int N, Hl, Wl;                  /* the LOW-resolution grid */
+  int C, ldx, Cout;
+  int pix_flags, epi_flags;       /* SG_PIX_RELU; SG_EPI_RELU */
+  float alpha, beta;
+  const void* x; const void* wq;
+  const float* bias; const void* res; const void* mask; void* out; const float* alpha_ptr;
+  int ldo, ldr, ldm;
+} sg_convq_desc;
+int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream);
+int sg_conv2d_q_ok(const sg_convq_desc* d);            /* 1 when sg_conv2d_q takes the problem */
+int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int M, int Cs, sg_stream_t stream);
+/* weight gradient of the same two forms: dw[co][r][s][c] (the 3x3 gradient image, fp32, accumulated) += alpha * (gradient w.r.t. the
+ * quad filter, folded back through the transpose of sg_quad_pack's sums); dbias[co] += sum of dy (optional). POOL: x fine, dy low;
+ * UP: x low, dy fine. work: scratch for the deterministic two-stage reduction, sized by sg_conv2d_q_wgrad_plan (*splits == 0: not eligible). */
+typedef struct {
+  int dtype, form;
+  int N, Hl, Wl;
+  int C, ldx, x_flags;            /* SG_PIX_RELU */
+  int Cout, ldg;
+  float alpha; const float* alpha_ptr;
+  const void* x; const void* dy; float* dw; float* dbias;
+  float* work; long long work_floats;
+  int splits;                     /* 0 = auto */
+} sg_convq_wgrad_desc;
+int sg_conv2d_q_wgrad_plan(const sg_convq_wgrad_desc* d, int* splits, long long* work_floats);
+int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t stream);
+/* sg_prof_collect with a fourth column per kind: FLOPs the launches really executed (quad launches: 16 / 36 of the algorithmic count) */
+int sg_prof_collect_ex(double* out, int nkinds);
+
 /* dw[co][r][s][c] += alpha * sum_{n,ho,wo} dy'[n,ho,wo,co] * x'[n, ho*stride-pad+r, wo*stride-pad+s, c] (fp32 atomics) */
 typedef struct {
   int dtype;

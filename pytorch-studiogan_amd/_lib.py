@@ -16,6 +16,7 @@ CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, F64 = 0, 1, 2
 PIX_RELU, PIX_UPSAMPLE, PIX_QUAD, PIX_TRANSPOSED = 1, 2, 4, 8
+Q_POOL, Q_UP = 0, 1
 EPI_OUT_F32, EPI_ATOMIC, EPI_POOL, EPI_RELU, EPI_RES_F32 = 1, 2, 4, 8, 16
 
 _vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
@@ -37,6 +38,18 @@ class ConvWgradDesc(C.Structure):
                 ("Cout", _i), ("ldg", _i), ("g_flags", _i), ("Ho", _i), ("Wo", _i), ("R", _i), ("S", _i), ("stride", _i),
                 ("pad_h", _i), ("pad_w", _i), ("alpha", _f), ("x", _vp), ("dy", _vp), ("dw", _vp), ("alpha_ptr", _vp),
                 ("splits", _i), ("no_tr", _i), ("work", _vp), ("work_floats", _ll), ("dbias", _vp)]
+
+
+class ConvQDesc(C.Structure):
+    _fields_ = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("Cout", _i),
+                ("pix_flags", _i), ("epi_flags", _i), ("alpha", _f), ("beta", _f), ("x", _vp), ("wq", _vp), ("bias", _vp), ("res", _vp),
+                ("mask", _vp), ("out", _vp), ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i)]
+
+
+class ConvQWgradDesc(C.Structure):
+    _fields_ = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("Cout", _i),
+                ("ldg", _i), ("alpha", _f), ("alpha_ptr", _vp), ("x", _vp), ("dy", _vp), ("dw", _vp), ("dbias", _vp), ("work", _vp),
+                ("work_floats", _ll), ("splits", _i)]
 
 
 class GemmDesc(C.Structure):
@@ -80,6 +93,12 @@ _PROTOS = {
     "sg_conv2d_fwd_skip": [C.POINTER(ConvSkipDesc), _vp],
     "sg_conv2d_fwd_skip_ok": [C.POINTER(ConvSkipDesc)],
     "sg_conv_rs_launches": [],
+    "sg_conv2d_q": [C.POINTER(ConvQDesc), _vp],
+    "sg_conv2d_q_ok": [C.POINTER(ConvQDesc)],
+    "sg_quad_pack": [_i, _i, _vp, _vp, _i, _i, _vp],
+    "sg_conv2d_q_wgrad_plan": [C.POINTER(ConvQWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
+    "sg_conv2d_q_wgrad": [C.POINTER(ConvQWgradDesc), _vp],
+    "sg_prof_collect_ex": [C.POINTER(C.c_double), _i],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_conv2d_wgrad_plan": [C.POINTER(ConvWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_wgrad_fuses_bias": [C.POINTER(ConvWgradDesc)],

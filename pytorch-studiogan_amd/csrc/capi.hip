@@ -21,6 +21,7 @@ static int g_prof_on = 0;
 static int g_prof_n = 0;
 static hipEvent_t g_ev0[SG_PROF_MAX], g_ev1[SG_PROF_MAX];
 static double g_flops[SG_PROF_MAX];
+static double g_exec[SG_PROF_MAX];      // FLOPs the launch really executes (quad convolutions: 16 / 36 of the algorithmic count)
 static int g_kind[SG_PROF_MAX];
 static int g_ev_created = 0;
 
@@ -39,9 +40,13 @@ extern "C" int sg_prof_enable(int on) {
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind) {
   if (!(g_prof_on & (kind < 3 ? 1 : 2)) || g_prof_n >= SG_PROF_MAX) return -1;
   const int i = g_prof_n++;
-  g_flops[i] = flops; g_kind[i] = kind;
+  g_flops[i] = flops; g_exec[i] = flops; g_kind[i] = kind;
   hipEventRecord(g_ev0[i], st);
   return i;
+}
+// a launch that reaches the algorithmic result with fewer operations (conv_q.h) reports what it executes
+extern "C" void sg_prof_set_executed(int slot, double flops) {
+  if (slot >= 0) g_exec[slot] = flops;
 }
 extern "C" void sg_prof_end(hipStream_t st, int slot) {
   if (slot >= 0) hipEventRecord(g_ev1[slot], st);
@@ -55,6 +60,19 @@ extern "C" int sg_prof_collect(double* out, int nkinds) {
     const int k = g_kind[i];
     if (k < 0 || k >= nkinds) continue;
     out[k * 3 + 0] += 1.0; out[k * 3 + 1] += ms; out[k * 3 + 2] += g_flops[i];
+  }
+  g_prof_n = 0;
+  return 0;
+}
+// same, four columns per kind: {launches, total ms, algorithmic flops, executed flops}
+extern "C" int sg_prof_collect_ex(double* out, int nkinds) {
+  for (int k = 0; k < nkinds * 4; k++) out[k] = 0.0;
+  for (int i = 0; i < g_prof_n; i++) {
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev0[i], g_ev1[i]) != hipSuccess) { sg_set_error("sg_prof_collect_ex: events not complete (synchronise first)"); return -2; }
+    const int k = g_kind[i];
+    if (k < 0 || k >= nkinds) continue;
+    out[k * 4 + 0] += 1.0; out[k * 4 + 1] += ms; out[k * 4 + 2] += g_flops[i]; out[k * 4 + 3] += g_exec[i];
   }
   g_prof_n = 0;
   return 0;

@@ -150,6 +150,7 @@ __device__ __forceinline__ float block_max_256(float v, float* sm) {
 extern "C" void sg_set_error(const char* msg);
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind);
 extern "C" void sg_prof_end(hipStream_t st, int slot);
+extern "C" void sg_prof_set_executed(int slot, double flops);
 // scope guard around an entry point's launches for the in-library profiler (capi.hip): kinds 0-2 = MFMA contraction engine (work in
 // FLOP), kinds 3-6 = HBM-bound families (work in algorithmic BYTES): 3 spectral norm, 4 batch norm, 5 attention scores, 6 Adam / EMA
 struct SgProfScope {

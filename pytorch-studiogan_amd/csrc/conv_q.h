@@ -1,0 +1,251 @@
+// conv_q.h -- "quad" forward / data-gradient kernel: the 3x3 / pad-1 convolutions that sit next to a 2x resampling, computed through the
+// exact identity that folds the resampling into the filter (bf16, C % 32 == 0):
+//
+//   POOL form   avgpool2(conv3x3(x; w))           = conv4x4, stride 2, pad 1 (x; w'),   w'[u][v] = 1/4 sum_{i,j in {0,1}} w[u - i][v - j]
+//               (the discriminator blocks' `conv2d2` + `average_pooling`, reference src/models/big_resnet.py:177-192,221-242; and the data
+//               gradient of the UP form)
+//   UP form     conv3x3(nearest_up2(x); w)[2i+a, 2j+b] = conv2x2(x; w''_ab) at (i, j)  (four phase filters of 2 x 2 taps, sums of the 3 x 3 taps
+//               that land on the same source pixel) -- the generator blocks' `F.interpolate` + `conv2d1` (big_resnet.py:28-42) and the data
+//               gradient of the POOL form
+//
+// Either way a low-resolution position costs 16 C MACs per output channel instead of 36 C: 2.25 x fewer MFMAs for the same result (the
+// filter sums are taken in fp32 from the normalised weights and rounded to bf16 once: csrc/conv_q.hip sg_quad_pack).
+//
+// One kernel serves both forms. Everything is indexed on the LOW-resolution grid [N][Hl][Wl] (raster index q):
+//   * the fine tensor [N][2 Hl][2 Wl][C] is four "views" (a, b) = (row parity, column parity): view pixel q lives at fine pixel
+//     fp(q) = (q >> wlog) * 4 Wl + a * 2 Wl + 2 (q & (Wl - 1)) + b. POOL reads its input through the four views (one after the other, as
+//     four times C / 32 channel slices of the same accumulators); UP writes its output (and reads its ReLU mask / residual) through ONE view
+//     per workgroup (blockIdx decides the phase);
+//   * per (view, 32-channel slice) the pixel operand is staged once as a raster patch with a one-row halo, exactly like conv_v4.h, and the
+//     FOUR taps (ti, tj) read it at low-resolution offsets (ti - ea, tj - eb), (ea, eb) = (a, b) for POOL and (1 - a, 1 - b) for UP;
+//   * weights: the quad image [Cout][view][tap][C] (K = 16 C), one 32 NB x 32 tile per (view, slice, tap), two taps ahead through four buffers
+//     with counted waits (conv_v4.h's scheme; four buffers because a slice has four taps).
+// Tile = 256 low-resolution pixels x 32 NB couts, 4 waves, <= 53 KB of LDS: three workgroups per CU.
+#pragma once
+#include "conv_v2.h"
+
+struct ConvQParams {
+  const bf16_t* x; const bf16_t* w;
+  int form;               // 0 = POOL (input through the four views), 1 = UP (output through one view per workgroup)
+  int Wl, wlog, hlog;     // low-resolution width (power of two >= 4), log2 Wl, log2 Hl
+  int C, ldx;             // input channels, pixel pitch of x (elements)
+  int I, J, K;            // couts, N * Hl * Wl, 16 C
+  int nslice;             // C / 32
+  int npx;                // patch pixels (multiple of 16) >= 256 + 2 Wl + 16
+  int flags;              // SG_PIX_RELU
+  unsigned xbytes, wbytes;
+  int wgt_off, zero_off, bias_off;
+};
+
+template <int NB, bool RELU>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+  constexpr int BI = 32 * NB, BJ = 256, NW = 4, TI = NB, TJ = 2;
+  constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
+  constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nt = tilesI * tilesJ * nph;
+  int bid = blockIdx.x;
+  {
+    const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  // the phases and cout tiles of one pixel tile are neighbours in launch order: they share the patch through the XCD's L2
+  const int tI = bid % tilesI;
+  const int rest = bid / tilesI;
+  const int ph = rest % nph, tJ = rest / nph;
+  const int i0 = tI * BI, j0 = tJ * BJ;
+  char* const pbufs = smem + p.wgt_off;
+  float* sbias = (float*)(smem + p.bias_off);
+  if (epi.bias) {
+    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+  }
+  if (tid < 32) ((unsigned*)(smem + p.zero_off))[tid] = 0u;
+
+  const auto rsx = __builtin_amdgcn_make_buffer_rsrc((void*)p.x, 0, (int)p.xbytes, 0x00020000);
+  const auto rsw = __builtin_amdgcn_make_buffer_rsrc((void*)p.w, 0, (int)p.wbytes, 0x00020000);
+  // DMA piece = 1 KiB = 16 rows x 64 B, LDS linear in lane order: lane -> (row sub = lane >> 2, physical chunk lane & 3); the logical
+  // 16-byte chunk it fetches is the swizzle inverse: lc = (lane & 3) ^ (row >> 2 & 3), and row = 16 g + sub gives (sub >> 2) & 3.
+  const int sub = lane >> 2;
+  const int lc = (lane & 3) ^ ((lane >> 4) & 3);
+  const unsigned ldxb = 2u * (unsigned)p.ldx;
+  const bool pool = p.form == 0;
+  const int wmask = p.Wl - 1;
+
+  // ---- patch DMA: groups of 16 consecutive low-resolution pixels, group g = wave + 4 i ---------------------------------------------
+  const int P0 = j0 - p.Wl - 8;                                      // raster index of patch row 0
+  const int ngroups = p.npx >> 4;
+  const int pix0 = P0 + 16 * wave + sub;
+  auto patch_slice = [&](int view, int s) {
+    const int vadd = pool ? ((view >> 1) * 2 * p.Wl + (view & 1)) : 0;
+    for (int g = wave; g < ngroups; g += NW) {
+      const int pix = pix0 + 16 * (g - wave);
+      // POOL: view pixel -> fine pixel; out-of-range low-resolution indices (tile halo beyond the tensor) read zeros
+      const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
+      unsigned off = src * ldxb + (unsigned)(s * 64 + lc * 16);
+      off = ((unsigned)pix < (unsigned)p.J) ? off : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+  // ---- weight DMA: BI rows x 32 channels of (view, slice s, tap t) ------------------------------------------------------------------
+  auto weight_tile = [&](int buf, int view, int s, int t) {
+    for (int g = wave; g < NWP; g += NW) {
+      const int row = i0 + 16 * g + sub;
+      unsigned off = ((unsigned)row * (unsigned)p.K + (unsigned)((view * 4 + t) * p.C + s * 32 + lc * 8)) * 2u;
+      off = (row < p.I) ? off : 0x80000000u;
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)off, 0, 0, 0);
+    }
+  };
+
+  // ---- fragment rows of this lane ----------------------------------------------------------------------------------------------------
+  const int wj0 = wave * (32 * TJ);
+  const int frow = lane & 31, fhi = lane >> 5;
+  int rb[TJ];             // patch row of the centre pixel
+  unsigned qval[TJ];      // bit (dr + 1) * 3 + (dc + 1) set = the low-resolution neighbour (dr, dc) is inside the image
+#pragma unroll
+  for (int b = 0; b < TJ; b++) {
+    const int row = j0 + wj0 + b * 32 + frow;
+    const int wo = row & wmask, ho = (row >> p.wlog) & ((1 << p.hlog) - 1);
+    unsigned m = 0;
+    if (row < p.J) {
+#pragma unroll
+      for (int rr = 0; rr < 3; rr++)
+#pragma unroll
+        for (int ss = 0; ss < 3; ss++)
+          if ((unsigned)(ho - 1 + rr) < (unsigned)(1 << p.hlog) && (unsigned)(wo - 1 + ss) < (unsigned)p.Wl) m |= 1u << (rr * 3 + ss);
+    }
+    qval[b] = m;
+    rb[b] = row - P0;
+  }
+  // weight fragment addresses: row = cout a * 32 + frow, chunk (ks * 2 + fhi) ^ (row >> 2 & 3); ks = 1 is the address ^ 32
+  unsigned wa[TI];
+#pragma unroll
+  for (int a = 0; a < TI; a++) {
+    const int row = a * 32 + frow;
+    wa[a] = (unsigned)(row * 64 + ((fhi ^ ((row >> 2) & 3)) << 4));
+  }
+
+  f32x16 acc[TI][TJ];
+#pragma unroll
+  for (int a = 0; a < TI; a++)
+#pragma unroll
+    for (int b = 0; b < TJ; b++)
+#pragma unroll
+      for (int r = 0; r < 16; r++) acc[a][b][r] = 0.f;
+
+  // virtual slices: POOL walks (view 0..3) x (C / 32); UP walks the C / 32 slices of its one view (= phase)
+  const int nv = pool ? 4 : 1;
+  const int nslice = p.nslice;
+  const int nvs = nv * nslice;
+  const bool two = wave + NW < NWP;                                  // this wave issues two weight pieces per tap
+  int view = pool ? 0 : ph, s = 0;
+  patch_slice(view, 0);
+  weight_tile(0, view, 0, 0);
+  weight_tile(1, view, 0, 1);
+  __syncthreads();
+  for (int vs = 0; vs < nvs; vs++) {
+    const bool next_slice = vs + 1 < nvs;
+    int nview = view, ns = s + 1;
+    if (ns == nslice) { ns = 0; nview = view + 1; }
+    // tap origin of this view on the low-resolution grid
+    const int ea = pool ? (view >> 1) : 1 - (view >> 1);
+    const int eb = pool ? (view & 1) : 1 - (view & 1);
+    const int org = -ea * p.Wl - eb;                                 // patch-row displacement of tap (0, 0)
+    const int vbit0 = (1 - ea) * 3 + (1 - eb);                       // validity bit of tap (0, 0)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
+      const bool issue = (t + 2 < 4) || next_slice;
+      if (t + 2 < 4) weight_tile(t + 2, view, s, t + 2);
+      else if (next_slice) weight_tile(t - 2, nview, ns, t - 2);
+      const char* ps = pbufs + t * PB;
+      const int ti = t >> 1, tj = t & 1;                           // compile-time after unrolling
+      unsigned qa[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        int row = rb[b] + org;
+        asm volatile("" : "+v"(row));
+        if (ti) row += p.Wl;
+        if (tj) row += 1;
+        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
+        a = ((qval[b] >> (vbit0 + ti * 3 + tj)) & 1u) ? a : (unsigned)p.zero_off;
+        qa[b] = a;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8_t pf[TI], qf[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          u32x4 v = *(const u32x4*)(ps + (wa[a] ^ (unsigned)(ks * 32)));
+          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+      if (t == 3 && next_slice) {
+        // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
+        // workgroup; the other two workgroups of the CU keep the matrix pipe busy)
+        __syncthreads();
+        patch_slice(nview, ns);
+        __syncthreads();
+      } else {
+        if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+      }
+    }
+    view = nview; s = ns;
+  }
+
+  float al = epi.alpha;
+  if (epi.alpha_ptr) al *= *epi.alpha_ptr;
+  if (pool) {
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+  } else {
+    // UP: output / mask / residual rows go through the view of this workgroup's phase
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, p.wlog, (ph >> 1) * 2 * p.Wl + (ph & 1));
+  }
+}
+
+// LDS need (bytes) of a configuration
+static inline int sg_conv_q_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off) {
+  const int BI = 32 * NB;
+  const int woff = npx * 64;
+  const int ops = woff + 4 * BI * 64;
+  const int stage = 256 * (BI * 2 + 16);
+  const int body = ops > stage ? ops : stage;
+  if (wgt_off) *wgt_off = woff;
+  if (zero_off) *zero_off = body;
+  if (bias_off) *bias_off = body + 128;
+  return body + 128 + BI * 4;
+}
+template <int NB, bool RELU>
+static inline int sg_launch_conv_qr(ConvQParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const int lds = sg_conv_q_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
+  if (lds > 80 * 1024) return -1;
+  static bool attr_done = false;
+  if (!attr_done) {
+    if (hipFuncSetAttribute((const void*)sg_conv_q_kernel<NB, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    attr_done = true;
+  }
+  const int BI = 32 * NB, BJ = 256;
+  const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ, nph = p.form == 0 ? 1 : 4;
+  hipLaunchKernelGGL((sg_conv_q_kernel<NB, RELU>), dim3(tilesI * tilesJ * nph), dim3(256), lds, st, p, e, tilesI, tilesJ, nph);
+  return 0;
+}
+template <int NB>
+static inline int sg_launch_conv_q(const ConvQParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true>(p, e, st) : sg_launch_conv_qr<NB, false>(p, e, st);
+}

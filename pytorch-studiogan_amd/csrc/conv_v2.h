@@ -38,9 +38,15 @@ typedef __attribute__((address_space(3))) void* sg_lptr_t;
 // ---- the epilogue shared by conv_v2 / conv_v3 -------------------------------------------------------------------------
 // acc[TI][TJ]: 32x32 accumulator blocks of this wave (block (a,b) = couts wi0+32a.., pixels wj0+32b..); smem: the (dead) operand
 // buffers, reused as the output staging area; sbias: BI floats in LDS (valid when epi.bias).
-template <int BI, int BJ, int NW, int TI, int TJ>
+// VMAP (conv_q.h, UP form): the tile's rows are positions of a LOW-resolution grid and the output / mask / residual tensors are one parity
+// view of the tensor at twice the resolution: global row of tile row jg = ((jg >> vlog) << (vlog + 2)) + ((jg & (2^vlog - 1)) << 1) + vadd.
+template <int BI, int BJ, int NW, int TI, int TJ, bool VMAP = false>
 __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* smem, const float* sbias, const Epilogue<bf16_t>& epi,
-                                                 int i0, int j0, int wi0, int wj0, float al, bool active = true) {
+                                                 int i0, int j0, int wi0, int wj0, float al, bool active = true, int vlog = 0, int vadd = 0) {
+  auto grow = [&](int jg) -> long long {
+    if (VMAP) return (long long)(((jg >> vlog) << (vlog + 2)) + ((jg & ((1 << vlog) - 1)) << 1) + vadd);
+    return (long long)jg;
+  };
   // active (wave-uniform): this wave's accumulators belong to the BJ rows staged by this call. A tile larger than its staging area is
   // stored in several calls (conv_v4.h, 512-pixel tiles: two calls of 256 rows, two of the four waves active in each); every thread
   // takes part in the operand pre-load and in the store loop of every call.
@@ -68,7 +74,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
       u32x4 t = {0u, 0u, 0u, 0u};
-      if (jg < Jout && c < ncr) t = *(const u32x4*)(src + (long long)jg * ld + i0 + c * 8);
+      if (jg < Jout && c < ncr) t = *(const u32x4*)(src + grow(jg) * ld + i0 + c * 8);
       *(u32x4*)(smem + r * CP + c * 16) = t;
     }
   };
@@ -165,7 +171,7 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
-      if (jg < Jout && c < ncr) *(u32x4*)(o + (long long)jg * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
+      if (jg < Jout && c < ncr) *(u32x4*)(o + grow(jg) * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
     }
   }
 }

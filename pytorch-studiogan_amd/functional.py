@@ -129,6 +129,65 @@ def conv2d_wgrad_raw(x, dy, dw_ptr, Cin, Cout, R, S, Ho, Wo, stride=1, pad_h=0, 
     return fused
 
 
+def quad_pack_raw(src_ptr, dst, mode, M, Cs):
+    """quad filter image [M][16][Cs] (dst tensor) of the 3x3 image at src_ptr ([M][9][Cs], dst.dtype); mode: include/sgamd.h sg_quad_pack"""
+    L.call("sg_quad_pack", L.dt(dst), mode, src_ptr, L.ptr(dst), M, Cs, L.stream())
+    return dst
+
+
+def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None, alpha=1.0, beta=1.0, dry=False):
+    """The quad forms of a 3x3 / pad-1 convolution next to a 2x resampling (include/sgamd.h sg_conv2d_q). form Q_POOL: x [N,2Hl,2Wl,C] ->
+    [N,Hl,Wl,Cout] = avgpool2(conv3x3(x)); form Q_UP: x [N,Hl,Wl,C] -> [N,2Hl,2Wl,Cout] = conv3x3(up2(x)). Returns None when not eligible."""
+    N = x.shape[0]
+    if form == L.Q_POOL:
+        if x.shape[1] % 2 or x.shape[2] % 2:
+            return None
+        Hl, Wl = x.shape[1] // 2, x.shape[2] // 2
+        oshape = (N, Hl, Wl, Cout)
+    else:
+        Hl, Wl = x.shape[1], x.shape[2]
+        oshape = (N, 2 * Hl, 2 * Wl, Cout)
+    if x.dtype != torch.bfloat16:
+        return None
+    d = L.ConvQDesc()
+    d.dtype, d.form = L.dt(x), form
+    d.N, d.Hl, d.Wl, d.C, d.ldx, d.Cout = N, Hl, Wl, Cin, x.shape[3], Cout
+    d.pix_flags, d.epi_flags, d.alpha, d.beta = pix_flags, epi_flags, alpha, beta
+    out = torch.empty(oshape, dtype=x.dtype, device=x.device)
+    d.x, d.wq, d.bias, d.res, d.mask, d.out = L.ptr(x), wq_ptr, L.ptr(bias), L.ptr(res), L.ptr(mask), L.ptr(out)
+    d.ldo = Cout
+    d.ldr = res.shape[-1] if res is not None else 0
+    d.ldm = mask.shape[-1] if mask is not None else 0
+    if L.lib().sg_conv2d_q_ok(L.C.byref(d)) != 1:
+        return None
+    if not dry:
+        L.call("sg_conv2d_q", d, L.stream())
+    return out
+
+
+def conv2d_q_wgrad_raw(x, dy, dw_ptr, form, Cin, Cout, x_flags=0, alpha=1.0, dbias=None, splits=0):
+    """dw3x3 (fp32 [Cout][9][Cin] at dw_ptr) += weight gradient of the quad form (include/sgamd.h sg_conv2d_q_wgrad); dbias += column sums of dy.
+    Returns False when the kernel does not take the problem (nothing launched)."""
+    if x.dtype != torch.bfloat16:
+        return False
+    d = L.ConvQWgradDesc()
+    d.dtype, d.form = L.dt(x), form
+    lo = dy if form == L.Q_POOL else x
+    d.N, d.Hl, d.Wl = lo.shape[0], lo.shape[1], lo.shape[2]
+    d.C, d.ldx, d.x_flags, d.Cout, d.ldg = Cin, x.shape[3], x_flags, Cout, dy.shape[3]
+    d.alpha = alpha
+    d.x, d.dy, d.dw, d.dbias = L.ptr(x), L.ptr(dy), dw_ptr, L.ptr(dbias)
+    d.splits = splits
+    sp, wf = L.C.c_int(0), L.C.c_longlong(0)
+    L.call("sg_conv2d_q_wgrad_plan", d, L.C.byref(sp), L.C.byref(wf))
+    if sp.value == 0:
+        return False
+    work = torch.empty(wf.value, dtype=torch.float32, device=x.device)
+    d.work, d.work_floats, d.splits = work.data_ptr(), wf.value, sp.value
+    L.call("sg_conv2d_q_wgrad", d, L.stream())
+    return True
+
+
 def gemm_raw(dtype, p, p_form, ldp, q, q_form, ldq, out, ldo, I, J, K, batch=1, p_bs=0, q_bs=0, out_bs=0, bias=None, res=None,
              res_bs=0, ldr=0, beta=1.0, alpha=1.0, alpha_ptr=None, epi_flags=0, splits=1, no_tr=0):
     """OUT[b][j][i] = beta*res + alpha * sum_k P(i,k) Q(j,k) + bias[i]; p/q/out may be tensors or raw pointers."""

@@ -1,0 +1,153 @@
+"""GPU: the quad convolutions (csrc/conv_q.h, wgrad_q.h, conv_q.hip) -- avgpool2(conv3x3(x)) as a 4x4 / stride-2 convolution and
+conv3x3(up2(x)) as four 2x2 phase convolutions -- against torch's own conv2d + avg_pool2d / interpolate on the CPU (fp32 accumulation of the
+same bf16 inputs), forward, data gradient and weight gradient, with every fused flag, on shapes that select every chunk geometry of the
+weight-gradient kernel. Replaces src/models/big_resnet.py:28-42 (F.interpolate + conv2d1) and :177-192,221-242 (conv2d2 + average_pooling)."""
+import pytest
+import torch
+
+import quad_ref as Q
+from util import check
+from test_kernels_gpu import rnd
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev(t):
+    return t.to(torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("mode", [0, 1, 2, 3])
+def test_quad_pack_matches_reference(sg, mode):
+    from studiogan_amd import functional as F
+    M, Cs = 96, 64
+    for dt in (torch.bfloat16, torch.float32):
+        w = rnd((M, 3, 3, Cs), dt, 300 + mode, 0.1)
+        dst = torch.empty(M, 16, Cs, dtype=dt, device="cuda:0")
+        wd = _dev(w)
+        F.quad_pack_raw(wd.data_ptr(), dst, mode, M, Cs)
+        torch.cuda.synchronize()
+        ref = Q.quad_pack_ref(w.double(), mode).reshape(M, 16, Cs)
+        check(f"quad pack mode {mode} {dt}", dst.float().cpu(), ref, 4e-3 if dt == torch.bfloat16 else 1e-6)
+
+
+FWD_CASES = [
+    # form, N, Hl, Wl, C, Cout, relu_in, bias, mask, res, relu_out
+    (0, 2, 8, 8, 64, 96, False, True, False, False, False),
+    (0, 2, 8, 8, 96, 96, True, True, False, False, False),       # D block tail: ReLU on load
+    (0, 3, 4, 4, 32, 64, True, False, False, True, True),        # 4 x 4 low-resolution images, residual + ReLU on store, 64-cout tile
+    (0, 1, 16, 64, 96, 192, True, True, False, False, False),    # wide rows, two cout tiles
+    (0, 5, 2, 4, 32, 64, False, True, False, False, False),      # J = 40: partial tile, Hl = 2
+    (0, 2, 32, 32, 64, 64, False, True, False, False, False),    # several pixel tiles
+    (1, 2, 8, 8, 64, 96, False, True, False, False, False),
+    (1, 2, 8, 8, 96, 96, False, True, True, False, False),       # data gradient of a D block tail: ReLU mask of the fine tensor
+    (1, 3, 4, 4, 32, 64, False, False, True, True, False),       # mask AND residual (GradLink)
+    (1, 1, 16, 64, 96, 192, False, True, False, False, False),
+    (1, 5, 2, 4, 32, 64, True, True, False, False, True),
+    (1, 2, 32, 32, 64, 64, False, False, False, True, False),
+]
+
+
+@pytest.mark.parametrize("case", FWD_CASES)
+def test_conv_q_matches_torch(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    form, N, Hl, Wl, C, Cout, relu_in, with_bias, with_mask, with_res, relu_out = case
+    dt = torch.bfloat16
+    Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
+    Hy, Wy = (Hl, Wl) if form == 0 else (2 * Hl, 2 * Wl)
+    x = rnd((N, Hx, Wx, C), dt, 311)
+    w9 = rnd((Cout, 3, 3, C), dt, 312, 0.1)
+    bias = rnd((Cout,), torch.float32, 313) if with_bias else None
+    mask = rnd((N, Hy, Wy, Cout), dt, 314) if with_mask else None
+    res = rnd((N, Hy, Wy, Cout), dt, 315) if with_res else None
+    xf, wf = x.float(), w9.float()
+    ref = Q.pool_conv_torch(xf, wf, relu_in) if form == 0 else Q.up_conv_torch(xf, wf, relu_in)
+    if bias is not None:
+        ref = ref + bias
+    if mask is not None:
+        ref = ref * (mask.float() > 0)
+    if res is not None:
+        ref = ref + res.float()
+    if relu_out:
+        ref = torch.relu(ref)
+    wq = torch.empty(Cout, 16, C, dtype=dt, device="cuda:0")
+    w9d = _dev(w9)
+    F.quad_pack_raw(w9d.data_ptr(), wq, form, Cout, C)
+    y = F.conv2d_q_raw(_dev(x), wq.data_ptr(), form, C, Cout, L.PIX_RELU if relu_in else 0, L.EPI_RELU if relu_out else 0,
+                       bias=None if bias is None else _dev(bias), res=None if res is None else _dev(res), mask=None if mask is None else _dev(mask))
+    assert y is not None, "the quad kernel refused an eligible problem"
+    torch.cuda.synchronize()
+    check(f"conv_q {case}", y.float().cpu(), ref, 6e-3)
+    # against the index-level restatement run on the kernel's OWN bf16 filter image: only accumulation order and the output rounding differ
+    xx = torch.relu(xf) if relu_in else xf
+    r2 = Q.convq_ref(xx.double(), wq.float().cpu().double().reshape(Cout, 4, 4, C), form)
+    if bias is not None:
+        r2 = r2 + bias.double()
+    if mask is not None:
+        r2 = r2 * (mask.double() > 0)
+    if res is not None:
+        r2 = r2 + res.double()
+    if relu_out:
+        r2 = torch.relu(r2)
+    check(f"conv_q vs restatement {case}", y.float().cpu(), r2, 4e-3)
+
+
+def test_conv_q_data_gradients_match_autograd(sg):
+    """dgrad of POOL = UP form with the mode-2 image, dgrad of UP = POOL form with the mode-3 image (from the flipped transposed 3x3 image)"""
+    from studiogan_amd import functional as F, _lib as L
+    dt = torch.bfloat16
+    N, Hl, Wl, C, Cout = 2, 8, 16, 64, 96
+    w9 = rnd((Cout, 3, 3, C), dt, 321, 0.1)
+    wft = Q.flipped_transposed(w9)                      # [C][3][3][Cout]
+    wftd = _dev(wft)
+    for form in (0, 1):
+        Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
+        x = rnd((N, Hx, Wx, C), dt, 322).float().requires_grad_(True)
+        y = Q.pool_conv_torch(x, w9.float()) if form == 0 else Q.up_conv_torch(x, w9.float())
+        dy = rnd(tuple(y.shape), dt, 323)
+        (dx,) = torch.autograd.grad(y, x, dy.float())
+        wq = torch.empty(C, 16, Cout, dtype=dt, device="cuda:0")
+        F.quad_pack_raw(wftd.data_ptr(), wq, 2 + form, C, Cout)
+        got = F.conv2d_q_raw(_dev(dy), wq.data_ptr(), 1 - form, Cout, C)
+        assert got is not None
+        torch.cuda.synchronize()
+        check(f"conv_q dgrad of form {form}", got.float().cpu(), dx, 6e-3)
+
+
+WG_CASES = [
+    # form, N, Hl, Wl, C, Cout, relu, bias
+    (0, 4, 4, 4, 64, 96, True, True),         # WC = 4: chunks of four 4 x 4 images, S = 2
+    (1, 4, 4, 4, 32, 64, False, True),        # S = 1, NB = 2
+    (0, 2, 8, 8, 96, 96, True, True),         # WC = 8, S = 1 (C % 64 != 0)
+    (1, 2, 8, 8, 64, 192, False, True),       # two cout tiles
+    (0, 1, 16, 16, 64, 64, False, False),     # WC = 16
+    (1, 1, 16, 16, 128, 96, False, True),     # two input-channel groups
+    (0, 1, 8, 32, 64, 96, True, True),        # WC = 32
+    (1, 2, 4, 32, 32, 96, False, False),
+    (0, 1, 4, 64, 64, 96, False, True),       # WC = 64
+    (1, 1, 2, 128, 64, 64, False, True),      # two chunks per image row
+]
+
+
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad_q_matches_autograd(sg, case):
+    from studiogan_amd import functional as F, _lib as L
+    form, N, Hl, Wl, C, Cout, relu, with_bias = case
+    dt = torch.bfloat16
+    Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
+    x = rnd((N, Hx, Wx, C), dt, 331)
+    w9 = rnd((Cout, 3, 3, C), dt, 332, 0.1).float().requires_grad_(True)
+    y = Q.pool_conv_torch(x.float(), w9, relu) if form == 0 else Q.up_conv_torch(x.float(), w9, relu)
+    dy = rnd(tuple(y.shape), dt, 333)
+    (dw,) = torch.autograd.grad(y, w9, dy.float())
+    for splits in (0, 1, 3):
+        dwd = torch.zeros(Cout, 9, C, dtype=torch.float32, device="cuda:0")
+        dwd[0, 0, 0] = 1.0                              # the kernel ACCUMULATES
+        db = torch.zeros(Cout, dtype=torch.float32, device="cuda:0") if with_bias else None
+        ok = F.conv2d_q_wgrad_raw(_dev(x), _dev(dy), dwd.data_ptr(), form, C, Cout, L.PIX_RELU if relu else 0, dbias=db, splits=splits)
+        assert ok, "the quad weight-gradient kernel refused an eligible problem"
+        torch.cuda.synchronize()
+        got = dwd.cpu().reshape(Cout, 3, 3, C)
+        got[0, 0, 0, 0] -= 1.0
+        check(f"wgrad_q {case} splits {splits}", got, dw, 3e-3)
+        if with_bias:
+            check(f"wgrad_q bias {case} splits {splits}", db.cpu(), dy.float().sum((0, 1, 2)), 2e-3)
