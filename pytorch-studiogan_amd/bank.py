@@ -311,6 +311,8 @@ class WeightBank:
         sl.pending = []
         sl.desc_cache = {}
         sl.bwd_cache = {}
+        sl.quad = {}            # (layer index, mode) -> [quad filter image, id of the forward it was packed for]  (w_quad)
+        sl.fwd_id = 0
         sl.live = None          # weakref to the handle of the forward that currently owns the slot
         return sl
 
@@ -393,6 +395,8 @@ class WeightBank:
         arr, dev_tab = self._desc(slot, flags)
         L.call("sg_sn_forward", self.sgdt, dev_tab.data_ptr(), arr, len(self.layers), self.eps, self.work.data_ptr(),
                self.work.numel(), L.stream())
+        self._fwd_counter = self.__dict__.get("_fwd_counter", 0) + 1
+        slot.fwd_id = self._fwd_counter      # (handle and physical slot share one attribute dict)
         self.current = slot
         return slot
 
@@ -405,6 +409,24 @@ class WeightBank:
 
     def w_f32(self, slot, r):
         return slot.f32.data_ptr() + 4 * r.f32_off
+
+    def w_quad(self, slot, r, mode):
+        """Quad filter image of a 3x3 / pad-1 layer that sits next to a 2x resampling (csrc/conv_q.h), packed on first use in each forward from the
+        normalised bf16 images sg_sn_forward has just written: mode 0 / 1 = forward image of the POOL (conv + avg-pool) / UP (upsample + conv)
+        form from the forward image; mode 2 / 3 = their data-gradient images from the flipped transposed image."""
+        key = (r.index, mode)
+        ent = slot.quad.get(key)
+        if ent is None:
+            ent = [torch.empty(r.rows_pad * 16 * r.cin_pad, dtype=self.dtype, device=self.device), -1]
+            slot.quad[key] = ent
+        if ent[1] != slot.fwd_id:
+            if mode < 2:
+                src, M, Cs = self.w_fwd(slot, r), r.rows_pad, r.cin_pad
+            else:
+                src, M, Cs = self.w_dgrad(slot, r), r.cin_pad, r.rows_pad
+            L.call("sg_quad_pack", self.sgdt, mode, src, ent[0].data_ptr(), M, Cs, L.stream())
+            ent[1] = slot.fwd_id
+        return ent[0].data_ptr()
 
     def w_f32_tensor(self, slot, r):
         return slot.f32[r.f32_off:r.f32_off + r.rows * r.cols].view(r.rows, r.cols)

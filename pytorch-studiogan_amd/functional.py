@@ -322,10 +322,62 @@ class GradLink:
 _GRAD_LINK = [os.environ.get("SG_GRAD_LINK", "1") != "0"]      # SG_GRAD_LINK=0: leave the sum to autograd (A/B runs, tests)
 
 
+_QUAD = [os.environ.get("SG_QUAD", "1") != "0"]      # SG_QUAD=0: the 3x3 kernels everywhere (A/B runs, tests)
+
+
+def _quad_form(rt, cfg, x):
+    """Q_POOL / Q_UP when this launch is a 3x3 / pad-1 convolution next to a 2x resampling that the quad kernels take (csrc/conv_q.h: the same
+    result through the pooled / phase filters, 16 C instead of 36 C MACs per low-resolution position), else None."""
+    if not _QUAD[0] or x.dtype != torch.bfloat16 or cfg.R != 3 or cfg.S != 3 or cfg.stride != 1 or cfg.pad_h != 1 or cfg.pad_w != 1:
+        return None
+    if cfg.out_pool == cfg.in_upsample or rt.trans or rt.RS != 9:
+        return None
+    if rt.cin_pad % 32 or (rt.rows_pad % 64 and rt.rows_pad % 96):
+        return None
+    return L.Q_POOL if cfg.out_pool else L.Q_UP
+
+
+def _conv_fwd(x, rt, slot, cfg, bias, res=None):
+    """ConvFn's forward launch: [res +] avgpool2?(conv(up2?(relu?(x)))) + bias"""
+    bank = rt.bank()
+    Cin = x.shape[3]
+    form = _quad_form(rt, cfg, x)
+    if form is not None:
+        y = conv2d_q_raw(x, bank.w_quad(slot, rt, form), form, Cin, rt.rows_pad, L.PIX_RELU if cfg.in_relu else 0, 0, bias=bias, res=res)
+        if y is not None:
+            return y
+    pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
+    ef = L.EPI_POOL if cfg.out_pool else 0
+    return conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, pf, ef, bias=bias, res=res,
+                      alpha=0.25 if cfg.out_pool else 1.0)
+
+
+def _conv_wgrad(x, dy, rt, slot, cfg, dbias=None):
+    """weight gradient of ConvFn's launch into the bank's fp32 scratch; returns True when the bias gradient (dbias) was produced on the side"""
+    bank = rt.bank()
+    N, Hs, Ws, Cin = x.shape
+    form = _quad_form(rt, cfg, x)
+    if form is not None and conv2d_q_wgrad_raw(x, dy, bank.dwt(slot, rt), form, Cin, rt.rows_pad, L.PIX_RELU if cfg.in_relu else 0, dbias=dbias):
+        return dbias is not None
+    up = 2 if cfg.in_upsample else 1
+    Ho = (Hs * up + 2 * cfg.pad_h - cfg.R) // cfg.stride + 1
+    Wo = (Ws * up + 2 * cfg.pad_w - cfg.S) // cfg.stride + 1
+    pool = cfg.out_pool
+    xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
+    return conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w, xf,
+                            L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0, dbias=dbias)
+
+
 def _conv_dgrad(dy, x, rt, slot, cfg, res=None):
     """data gradient of ConvFn's fused launch: dx = relu-mask(x) * F^T(dy) [+ res], F = pool?(conv(up?(.))) * (0.25 if pool)."""
     bank = rt.bank()
     N, Hs, Ws, Cin = x.shape
+    form = _quad_form(rt, cfg, x)
+    if form is not None and dy.shape[3] == rt.rows_pad:
+        # the data gradient of one quad form is the other form with the transformed flipped image (sg_quad_pack modes 2 / 3)
+        dx = conv2d_q_raw(dy, bank.w_quad(slot, rt, 2 + form), 1 - form, rt.rows_pad, Cin, 0, 0, mask=x if cfg.in_relu else None, res=res)
+        if dx is not None:
+            return dx
     up = 2 if cfg.in_upsample else 1
     Hin, Win = Hs * up, Ws * up
     pool = cfg.out_pool
@@ -400,16 +452,13 @@ class ConvFn(torch.autograd.Function):
         ctx.link = link
         if link is not None and link.chain:
             link.pending += 1
-        pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
-        ef = L.EPI_POOL if cfg.out_pool else 0
         if res is not None:
             res = _c(res)
         bias_k = bias
         if bias is not None and rt.rows_pad != rt.rows:      # padded output channels: the epilogue reads rows_pad bias entries
             bias_k = torch.zeros(rt.rows_pad, dtype=torch.float32, device=x.device)
             bias_k[:rt.rows].copy_(bias.detach())
-        y = conv2d_raw(x, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w, pf, ef, bias=bias_k, res=res,
-                       alpha=0.25 if cfg.out_pool else 1.0)
+        y = _conv_fwd(x, rt, slot, cfg, bias_k, res)
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
         ctx.bias = bias
@@ -450,12 +499,9 @@ class ConvFn(torch.autograd.Function):
         want_db = ctx.bias is not None and ctx.needs_input_grad[2]
         db_done = False
         if ctx.needs_input_grad[1]:
-            xf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
-            gf = L.PIX_UPSAMPLE if pool else 0
             # the halo weight-gradient kernel holds the dy fragments anyway: the bias gradient rides along (no separate pass over dy)
             g = ensure_grad(ctx.bias) if (want_db and rt.rows_pad == rt.rows) else None
-            db_done = conv2d_wgrad_raw(x, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w, xf, gf,
-                                       alpha=scale, dbias=g)
+            db_done = _conv_wgrad(x, dy, rt, slot, cfg, dbias=g)
         if want_db and not db_done:
             g = ensure_grad(ctx.bias)
             rows = dy.shape[0] * dy.shape[1] * dy.shape[2]
@@ -484,11 +530,12 @@ class ConvSkipFn(torch.autograd.Function):
         plain = rt2.rows_pad == rt2.rows and rt0.rows_pad == rt0.rows and b2 is not None and b0 is not None
         # measured (tools/skip_bench.py, profiles/r03_skip_bench_c.txt): the fused launch wins from 16 x 16 outputs up (0.01-0.30 ms per block
         # tail at batch 256) and loses 0.04-0.06 ms on the 1536-channel 8 x 8 tails, whose 48 one-tap slices are all stop-and-go
-        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all"):
+        # (a pooled tail goes through the quad kernel -- 2.25 x fewer MFMAs than the fused 3x3 launch -- and the 1x1 skip adds itself as a residual launch)
+        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
             y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
                                 bias=b2, bias2=b0, alpha=al)
         if y is None:
-            hh = conv2d_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows_pad, 3, 3, 1, 1, 1, pf, ef, bias=b2, alpha=al)
+            hh = _conv_fwd(h, rt2, slot, cfg2, b2)
             pf0 = pf | (L.PIX_UPSAMPLE if cfg0.in_upsample else 0)
             y = conv2d_raw(x, bank.w_fwd(slot, rt0), x.shape[3], rt0.rows_pad, 1, 1, 1, 0, 0, pf0, ef, bias=b0, res=hh, alpha=al)
         ctx.save_for_backward(h, x)
@@ -514,7 +561,7 @@ class ConvSkipFn(torch.autograd.Function):
         want2 = ctx.b2 is not None and ctx.needs_input_grad[3]
         want0 = ctx.b0 is not None and ctx.needs_input_grad[5]
         shared_db = None
-        if want2 and want0 and ctx.needs_input_grad[2] and rt2.rows_pad == rt2.rows and rt0.rows == rt2.rows:
+        if want2 and want0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[4] and rt2.rows_pad == rt2.rows and rt0.rows == rt2.rows:
             shared_db = torch.zeros(rt2.rows, dtype=torch.float32, device=dy.device)
         for inp, rt, cfg, w_i, b_i, wp, bp in ((h, rt2, cfg2, 2, 3, ctx.w2, ctx.b2), (x, rt0, cfg0, 4, 5, ctx.w0, ctx.b0)):
             k = 0 if inp is h else 1
@@ -532,8 +579,7 @@ class ConvSkipFn(torch.autograd.Function):
                     g = shared_db
                 elif k == 1 and shared_db is not None:
                     g = None                     # filled from the shared vector below
-                db_done = conv2d_wgrad_raw(inp, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, 1, cfg.pad_h, cfg.pad_w, xf,
-                                           L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0, dbias=g)
+                db_done = _conv_wgrad(inp, dy, rt, slot, cfg, dbias=g)
                 if k == 0 and shared_db is not None:
                     if db_done:
                         for bq in (ctx.b2, ctx.b0):
