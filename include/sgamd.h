@@ -113,10 +113,17 @@ typedef struct {
   const void* x; const void* wq;
   const float* bias; const void* res; const void* mask; void* out; const float* alpha_ptr;
   int ldo, ldr, ldm;
+  /* optional (SG_Q_POOL): the block's 1x1 skip convolution in the same launch, out += avgpool2(conv1x1(relu?(x2); w2)) + bias2.
+   * x2: [N,2Hl,2Wl,ldx2] with C2 % 32 == 0 channels; w2q: [Cout][C2] = the skip filter x 1/4 (sg_quad_pack_batch mode 4). NULL = none. */
+  const void* x2; const void* w2q; const float* bias2;
+  int C2, ldx2;
 } sg_convq_desc;
 int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream);
 int sg_conv2d_q_ok(const sg_convq_desc* d);            /* 1 when sg_conv2d_q takes the problem */
 int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int M, int Cs, sg_stream_t stream);
+/* the same for n images in one launch (items_dev: the table in device memory, items_host: the same table on the host) */
+typedef struct { const void* src; void* dst; int M, Cs, mode, pad_; } sg_quad_item;   /* mode 4: dst[M][Cs] = src[M][Cs] / 4 (the fused skip's filter) */
+int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, const sg_quad_item* items_host, int n, sg_stream_t stream);
 /* weight gradient of the same two forms: dw[co][r][s][c] (the 3x3 gradient image, fp32, accumulated) += alpha * (gradient w.r.t. the
  * quad filter, folded back through the transpose of sg_quad_pack's sums); dbias[co] += sum of dy (optional). POOL: x fine, dy low;
  * UP: x low, dy fine. work: scratch for the deterministic two-stage reduction, sized by sg_conv2d_q_wgrad_plan (*splits == 0: not eligible). */

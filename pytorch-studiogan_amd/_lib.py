@@ -43,13 +43,18 @@ class ConvWgradDesc(C.Structure):
 class ConvQDesc(C.Structure):
     _fields_ = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("Cout", _i),
                 ("pix_flags", _i), ("epi_flags", _i), ("alpha", _f), ("beta", _f), ("x", _vp), ("wq", _vp), ("bias", _vp), ("res", _vp),
-                ("mask", _vp), ("out", _vp), ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i)]
+                ("mask", _vp), ("out", _vp), ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i),
+                ("x2", _vp), ("w2q", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i)]
 
 
 class ConvQWgradDesc(C.Structure):
     _fields_ = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("Cout", _i),
                 ("ldg", _i), ("alpha", _f), ("alpha_ptr", _vp), ("x", _vp), ("dy", _vp), ("dw", _vp), ("dbias", _vp), ("work", _vp),
                 ("work_floats", _ll), ("splits", _i)]
+
+
+class QuadItem(C.Structure):
+    _fields_ = [("src", _vp), ("dst", _vp), ("M", _i), ("Cs", _i), ("mode", _i), ("pad_", _i)]
 
 
 class GemmDesc(C.Structure):
@@ -96,6 +101,7 @@ _PROTOS = {
     "sg_conv2d_q": [C.POINTER(ConvQDesc), _vp],
     "sg_conv2d_q_ok": [C.POINTER(ConvQDesc)],
     "sg_quad_pack": [_i, _i, _vp, _vp, _i, _i, _vp],
+    "sg_quad_pack_batch": [_i, _vp, C.POINTER(QuadItem), _i, _vp],
     "sg_conv2d_q_wgrad_plan": [C.POINTER(ConvQWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_q_wgrad": [C.POINTER(ConvQWgradDesc), _vp],
     "sg_prof_collect_ex": [C.POINTER(C.c_double), _i],

@@ -312,6 +312,7 @@ class WeightBank:
         sl.desc_cache = {}
         sl.bwd_cache = {}
         sl.quad = {}            # (layer index, mode) -> [quad filter image, id of the forward it was packed for]  (w_quad)
+        sl.quad_tab = {}        # tuple of (layer index, mode) -> (host table, device table) of one sg_quad_pack_batch launch
         sl.fwd_id = 0
         sl.live = None          # weakref to the handle of the forward that currently owns the slot
         return sl
@@ -397,6 +398,7 @@ class WeightBank:
                self.work.numel(), L.stream())
         self._fwd_counter = self.__dict__.get("_fwd_counter", 0) + 1
         slot.fwd_id = self._fwd_counter      # (handle and physical slot share one attribute dict)
+        self._pack_quad(slot, (0, 1, 4))     # the forward quad images this network is known to use (csrc/conv_q.h), one launch
         self.current = slot
         return slot
 
@@ -411,22 +413,50 @@ class WeightBank:
         return slot.f32.data_ptr() + 4 * r.f32_off
 
     def w_quad(self, slot, r, mode):
-        """Quad filter image of a 3x3 / pad-1 layer that sits next to a 2x resampling (csrc/conv_q.h), packed on first use in each forward from the
-        normalised bf16 images sg_sn_forward has just written: mode 0 / 1 = forward image of the POOL (conv + avg-pool) / UP (upsample + conv)
-        form from the forward image; mode 2 / 3 = their data-gradient images from the flipped transposed image."""
+        """Quad filter image of a 3x3 / pad-1 layer that sits next to a 2x resampling (csrc/conv_q.h) for this forward: mode 0 / 1 = forward image
+        of the POOL (conv + avg-pool) / UP (upsample + conv) form, from the forward image sg_sn_forward has just written; mode 2 / 3 = their
+        data-gradient images from the flipped transposed image. Which (layer, mode) pairs a network uses is learnt on first use; from then on
+        begin_forward packs all forward images in ONE launch and the first data-gradient request of a backward packs all of those."""
         key = (r.index, mode)
         ent = slot.quad.get(key)
-        if ent is None:
-            ent = [torch.empty(r.rows_pad * 16 * r.cin_pad, dtype=self.dtype, device=self.device), -1]
-            slot.quad[key] = ent
-        if ent[1] != slot.fwd_id:
-            if mode < 2:
-                src, M, Cs = self.w_fwd(slot, r), r.rows_pad, r.cin_pad
-            else:
-                src, M, Cs = self.w_dgrad(slot, r), r.cin_pad, r.rows_pad
-            L.call("sg_quad_pack", self.sgdt, mode, src, ent[0].data_ptr(), M, Cs, L.stream())
-            ent[1] = slot.fwd_id
-        return ent[0].data_ptr()
+        if ent is not None and ent[1] == slot.fwd_id:
+            return ent[0].data_ptr()
+        known = self.__dict__.setdefault("_quad_known", set())
+        known.add(key)
+        self._pack_quad(slot, (2, 3) if mode in (2, 3) else None, only=None if mode in (2, 3) else key)
+        return slot.quad[key][0].data_ptr()
+
+    def _pack_quad(self, slot, modes, only=None):
+        """one sg_quad_pack_batch launch for the known (layer, mode) pairs of `modes` that this forward has not packed yet (only: just that pair)"""
+        known = self.__dict__.get("_quad_known")
+        if not known:
+            return
+        keys = [only] if only is not None else sorted(k for k in known if k[1] in modes)
+        keys = tuple(k for k in keys if not (k in slot.quad and slot.quad[k][1] == slot.fwd_id))
+        if not keys or (keys[0][1] in (2, 3) and slot.dwt is None):
+            return
+        tab = slot.quad_tab.get(keys)
+        if tab is None:
+            arr = (L.QuadItem * len(keys))()
+            for j, (idx, mode) in enumerate(keys):
+                r = self.layers[idx]
+                ent = slot.quad.get((idx, mode))
+                if ent is None:
+                    ent = [torch.empty(r.rows_pad * (r.RS if mode == 4 else 16) * r.cin_pad, dtype=self.dtype, device=self.device), -1]
+                    slot.quad[(idx, mode)] = ent
+                it = arr[j]
+                if mode == 4:        # the 1x1 skip filter of a pooled block tail x 1/4
+                    it.src, it.M, it.Cs = self.w_fwd(slot, r), r.rows_pad, r.RS * r.cin_pad
+                elif mode < 2:
+                    it.src, it.M, it.Cs = self.w_fwd(slot, r), r.rows_pad, r.cin_pad
+                else:
+                    it.src, it.M, it.Cs = self.w_dgrad(slot, r), r.cin_pad, r.rows_pad
+                it.dst, it.mode = ent[0].data_ptr(), mode
+            tab = (arr, torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device))
+            slot.quad_tab[keys] = tab
+        L.call("sg_quad_pack_batch", self.sgdt, tab[1].data_ptr(), tab[0], len(keys), L.stream())
+        for k in keys:
+            slot.quad[k][1] = slot.fwd_id
 
     def w_f32_tensor(self, slot, r):
         return slot.f32[r.f32_off:r.f32_off + r.rows * r.cols].view(r.rows, r.cols)

@@ -31,15 +31,29 @@ struct ConvQParams {
   int C, ldx;             // input channels, pixel pitch of x (elements)
   int I, J, K;            // couts, N * Hl * Wl, 16 C
   int nslice;             // C / 32
-  int npx;                // patch pixels (multiple of 16) >= 256 + 2 Wl + 16
+  int npx;                // patch pixels (multiple of 16) >= BJ + 2 Wl + 16
+  int bj;                 // pixel tile: 256 or 128
   int flags;              // SG_PIX_RELU
   unsigned xbytes, wbytes;
   int wgt_off, zero_off, bias_off;
+  // fused 1x1 skip (SKIP instantiations, POOL form): acc += sum over the four views of conv1x1(relu?(x2_view); w2), w2 = 1/4 of the skip filter
+  const bf16_t* x2; const bf16_t* w2; const float* bias2;
+  int C2, ldx2, nslice2;
+  unsigned x2bytes, w2bytes;
 };
 
-template <int NB, bool RELU>
+// TJW = 32-pixel blocks per wave: 2 (tile of 256 low-resolution pixels) or 1 (128: twice the workgroups for the layers whose whole low-resolution
+// grid is a few thousand positions -- the 1536-channel 8 x 8 -> 4 x 4 tail has 256 tiles of 256 x 96 at batch 256, one per CU where three fit)
+//
+// SKIP (POOL form): the discriminator block's 1x1 skip convolution rides in the same launch (reference src/models/big_resnet.py:221-242:
+// `x0 = conv2d0(x0); x0 = average_pooling(x0); out = x + x0`): avgpool2(conv1x1(x2)) = sum over the four parity views of conv1x1(x2_view; w2 / 4),
+// i.e. 4 C2 / 32 more K-slices of the same accumulators with ONE tap each (no halo), staged through two slots of the operand area behind the
+// main loop. These slices are bound by the staging traffic, not by their 4 NB MFMAs: what they read is the fine skip input, once -- what the
+// separate 1x1 launch read from HBM as well, without its output round trip (0.09-0.18 ms per block tail at batch 256,
+// profiles/r04_dfwd_timeline_e.txt).
+template <int NB, bool RELU, int TJW = 2, bool SKIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
-  constexpr int BI = 32 * NB, BJ = 256, NW = 4, TI = NB, TJ = 2;
+  constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -60,7 +74,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   char* const pbufs = smem + p.wgt_off;
   float* sbias = (float*)(smem + p.bias_off);
   if (epi.bias) {
-    for (int i = tid; i < BI; i += 64 * NW) sbias[i] = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+    for (int i = tid; i < BI; i += 64 * NW) {
+      float b = (i0 + i < epi.I) ? epi.bias[i0 + i] : 0.f;
+      if (SKIP && p.bias2 && i0 + i < epi.I) b += p.bias2[i0 + i];
+      sbias[i] = b;
+    }
   }
   if (tid < 32) ((unsigned*)(smem + p.zero_off))[tid] = 0u;
 
@@ -209,6 +227,71 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     view = nview; s = ns;
   }
 
+  if constexpr (SKIP) {
+    // the main loop ended behind vmcnt(0) + barrier: the operand area is free. Slot i: patch at i * P2B, weights at 2 * P2B + i * PB.
+    const auto rsx2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.x2, 0, (int)p.x2bytes, 0x00020000);
+    const auto rsw2 = __builtin_amdgcn_make_buffer_rsrc((void*)p.w2, 0, (int)p.w2bytes, 0x00020000);
+    const unsigned ldx2b = 2u * (unsigned)p.ldx2;
+    constexpr int P2B = BJ * 64, NG2 = BJ / 16;
+    char* const w2bufs = smem + 2 * P2B;
+    const int n2 = 4 * p.nslice2;
+    auto issue2 = [&](int vs2, int slot) {
+      const int v2 = vs2 / p.nslice2, s2 = vs2 - v2 * p.nslice2;
+      const int vadd = (v2 >> 1) * 2 * p.Wl + (v2 & 1);
+      for (int g = wave; g < NG2; g += NW) {
+        const int pix = j0 + 16 * g + sub;
+        const unsigned src = (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd);
+        unsigned off = src * ldx2b + (unsigned)(s2 * 64 + lc * 16);
+        off = (pix < p.J) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (sg_lptr_t)(smem + slot * P2B + g * 1024), 16, (int)off, 0, 0, 0);
+      }
+      for (int g = wave; g < NWP; g += NW) {
+        const int row = i0 + 16 * g + sub;
+        unsigned off = ((unsigned)row * (unsigned)p.C2 + (unsigned)(s2 * 32 + lc * 8)) * 2u;
+        off = (row < p.I) ? off : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw2, (sg_lptr_t)(w2bufs + slot * PB + g * 1024), 16, (int)off, 0, 0, 0);
+      }
+    };
+    issue2(0, 0);
+    int slot = 0;
+    for (int vs2 = 0; vs2 < n2; vs2++) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();                    // slice vs2 has landed for every wave; every wave is done with slice vs2 - 1
+      if (vs2 + 1 < n2) issue2(vs2 + 1, slot ^ 1);
+      const char* ps = w2bufs + slot * PB;
+      const unsigned pbase = (unsigned)(slot * P2B);
+      unsigned qa[TJ];
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        const int row = wj0 + b * 32 + frow;             // tile-local pixel (the skip patch has no halo)
+        unsigned a = pbase + (((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4));
+        a = ((qval[b] >> 4) & 1u) ? a : (unsigned)p.zero_off;        // the centre bit is clear only for rows beyond the problem
+        qa[b] = a;
+      }
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        bf16x8_t pf[TI], qf[TJ];
+#pragma unroll
+        for (int a = 0; a < TI; a++) {
+          u32x4 v = *(const u32x4*)(ps + (wa[a] ^ (unsigned)(ks * 32)));
+          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+          if (RELU) v = relu16<bf16_t>(v);
+          qf[b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+#pragma unroll
+        for (int a = 0; a < TI; a++)
+#pragma unroll
+          for (int b = 0; b < TJ; b++)
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+      }
+      slot ^= 1;
+    }
+  }
+
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
   if (pool) {
@@ -220,32 +303,39 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // LDS need (bytes) of a configuration
-static inline int sg_conv_q_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off) {
+static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, int* wgt_off, int* zero_off, int* bias_off) {
   const int BI = 32 * NB;
   const int woff = npx * 64;
   const int ops = woff + 4 * BI * 64;
-  const int stage = 256 * (BI * 2 + 16);
-  const int body = ops > stage ? ops : stage;
+  const int stage = BJ * (BI * 2 + 16);
+  const int skp = skip ? 2 * BJ * 64 + 2 * BI * 64 : 0;      // two staging slots of the fused skip (patch + weights each)
+  int body = ops > stage ? ops : stage;
+  if (skp > body) body = skp;
   if (wgt_off) *wgt_off = woff;
   if (zero_off) *zero_off = body;
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU>
+template <int NB, bool RELU, int TJW, bool SKIP>
 static inline int sg_launch_conv_qr(ConvQParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  const int lds = sg_conv_q_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off);
+  constexpr int BI = 32 * NB, BJ = 128 * TJW;
+  const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_q_kernel<NB, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_q_kernel<NB, RELU, TJW, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
-  const int BI = 32 * NB, BJ = 256;
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ, nph = p.form == 0 ? 1 : 4;
-  hipLaunchKernelGGL((sg_conv_q_kernel<NB, RELU>), dim3(tilesI * tilesJ * nph), dim3(256), lds, st, p, e, tilesI, tilesJ, nph);
+  hipLaunchKernelGGL((sg_conv_q_kernel<NB, RELU, TJW, SKIP>), dim3(tilesI * tilesJ * nph), dim3(256), lds, st, p, e, tilesI, tilesJ, nph);
   return 0;
+}
+template <int NB, bool SKIP>
+static inline int sg_launch_conv_qs(const ConvQParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  if (p.bj == 128) return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true, 1, SKIP>(p, e, st) : sg_launch_conv_qr<NB, false, 1, SKIP>(p, e, st);
+  return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true, 2, SKIP>(p, e, st) : sg_launch_conv_qr<NB, false, 2, SKIP>(p, e, st);
 }
 template <int NB>
 static inline int sg_launch_conv_q(const ConvQParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true>(p, e, st) : sg_launch_conv_qr<NB, false>(p, e, st);
+  return p.x2 ? sg_launch_conv_qs<NB, true>(p, e, st) : sg_launch_conv_qs<NB, false>(p, e, st);
 }

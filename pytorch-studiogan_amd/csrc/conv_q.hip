@@ -83,6 +83,79 @@ extern "C" int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int
   return 0;
 }
 
+// All quad images of a network in ONE launch (the weight bank packs them right behind sg_sn_forward; one launch per image was 60 us x 135
+// launches per C3 step in profiles/r04_bench_biggan128_bs256_kerneltrace_e.txt). Block b finds its item by a scan of the (short) table.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* items, int n) {
+  constexpr int V = ET<T>::VEC;
+  long long base = 0;
+  int it = 0;
+  long long blk = blockIdx.x;
+  for (; it < n; it++) {
+    const long long nb = ((long long)items[it].M * (items[it].Cs / V) + 255) / 256;
+    if (blk < base + nb) break;
+    base += nb;
+  }
+  if (it >= n) return;
+  const sg_quad_item q = items[it];
+  const int cv = q.Cs / V;
+  const long long i = (blk - base) * 256 + threadIdx.x;
+  if (i >= (long long)q.M * cv) return;
+  if (q.mode == 4) {           // the 1x1 skip filter of a pooled block tail, x 1/4 (exact in bf16): [M][Cs] -> [M][Cs]
+    float o[V];
+    unpack16<T>(*(const u32x4*)((const T*)q.src + i * V), o);
+#pragma unroll
+    for (int e = 0; e < V; e++) o[e] *= 0.25f;
+    *(u32x4*)((T*)q.dst + i * V) = pack16<T>(o);
+    return;
+  }
+  const bool pool_like = q.mode == 0 || q.mode == 3;
+  const float scale = (q.mode == 0 || q.mode == 2) ? 0.25f : 1.f;
+  const long long m = i / cv;
+  const int c = (int)(i - m * cv) * V;
+  const T* s0 = (const T*)q.src + m * 9 * q.Cs + c;
+  float w[9][V];
+#pragma unroll
+  for (int k = 0; k < 9; k++) unpack16<T>(*(const u32x4*)(s0 + (long long)k * q.Cs), w[k]);
+  T* d0 = (T*)q.dst + m * 16 * q.Cs + c;
+#pragma unroll
+  for (int view = 0; view < 4; view++)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int pr = quad_pat(pool_like, view >> 1, t >> 1), pc = quad_pat(pool_like, view & 1, t & 1);
+      float o[V];
+#pragma unroll
+      for (int e = 0; e < V; e++) o[e] = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; r++)
+#pragma unroll
+        for (int s = 0; s < 3; s++)
+          if (((pr >> r) & 1) && ((pc >> s) & 1)) {
+#pragma unroll
+            for (int e = 0; e < V; e++) o[e] += w[r * 3 + s][e];
+          }
+#pragma unroll
+      for (int e = 0; e < V; e++) o[e] *= scale;
+      *(u32x4*)(d0 + (long long)(view * 4 + t) * q.Cs) = pack16<T>(o);
+    }
+}
+extern "C" int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, const sg_quad_item* items_host, int n, sg_stream_t stream) {
+  SG_CHECK(items_dev && items_host && n > 0 && n <= 64, "sg_quad_pack_batch: bad arguments");
+  const int V = dtype == SG_DTYPE_BF16 ? 8 : 4;
+  long long blocks = 0;
+  for (int i = 0; i < n; i++) {
+    const sg_quad_item& q = items_host[i];
+    SG_CHECK(q.src && q.dst && q.M > 0 && q.Cs > 0 && q.Cs % V == 0 && q.mode >= 0 && q.mode <= 4 && aligned16(q.src) && aligned16(q.dst), "sg_quad_pack_batch: bad item");
+    blocks += ((long long)q.M * (q.Cs / V) + 255) / 256;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_quad_pack_batch<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, items_dev, n);
+  else if (dtype == SG_DTYPE_F32) hipLaunchKernelGGL(k_quad_pack_batch<float>, dim3((unsigned)blocks), dim3(256), 0, st, items_dev, n);
+  else { sg_set_error("sg_quad_pack_batch: bad dtype"); return -1; }
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+
 // ---- forward / data gradient ---------------------------------------------------------------------------------------------------------
 static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>& e, int& NB) {
   if (d->dtype != SG_DTYPE_BF16 || (d->form != SG_Q_POOL && d->form != SG_Q_UP)) return false;
@@ -104,10 +177,26 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
   p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->wq;
   p.form = d->form; p.Wl = d->Wl; p.wlog = wlog; p.hlog = hlog;
   p.C = d->C; p.ldx = d->ldx; p.I = d->Cout; p.J = (int)J; p.K = 16 * d->C; p.nslice = d->C / 32;
-  p.npx = ((256 + 2 * d->Wl + 16) + 15) & ~15;
+  {
+    // pixel tile: 256 low-resolution positions, or 128 when that leaves fewer than two workgroups per CU (SG_CONV_Q_BJ=128 / 256 forces one: tests, A/B)
+    const int nph = d->form == SG_Q_POOL ? 1 : 4;
+    const long long tiles256 = (long long)(d->Cout / (32 * NB)) * ((J + 255) / 256) * nph;
+    p.bj = tiles256 < 512 ? 128 : 256;
+    if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; }
+  }
+  p.npx = ((p.bj + 2 * d->Wl + 16) + 15) & ~15;
   p.flags = d->pix_flags;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.wgt_off = p.zero_off = p.bias_off = 0;
+  p.x2 = nullptr; p.w2 = nullptr; p.bias2 = nullptr; p.C2 = p.ldx2 = p.nslice2 = 0; p.x2bytes = p.w2bytes = 0;
+  if (d->x2) {
+    if (d->form != SG_Q_POOL || !d->w2q || d->C2 < 32 || d->C2 % 32 || d->ldx2 % 8 || !aligned16(d->x2) || !aligned16(d->w2q)) return false;
+    if (d->bias2 && !d->bias) return false;
+    const long long x2bytes = ((4 * J - 1) * d->ldx2 + d->C2) * 2, w2bytes = (long long)d->Cout * d->C2 * 2;
+    if (x2bytes >= (1ll << 31) || w2bytes >= (1ll << 31)) return false;
+    p.x2 = (const bf16_t*)d->x2; p.w2 = (const bf16_t*)d->w2q; p.bias2 = d->bias2;
+    p.C2 = d->C2; p.ldx2 = d->ldx2; p.nslice2 = d->C2 / 32; p.x2bytes = (unsigned)x2bytes; p.w2bytes = (unsigned)w2bytes;
+  }
   e.out = d->out; e.out_bstride = 0; e.ldo = d->ldo; e.bias = d->bias;
   e.res = d->res; e.res_bstride = 0; e.ldr = d->ldr; e.beta = d->beta;
   e.mask = (const bf16_t*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
@@ -125,8 +214,9 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   SG_CHECK(convq_plan(d, p, e, NB), "sg_conv2d_q: problem not eligible for the quad kernel (ask sg_conv2d_q_ok first)");
   hipStream_t st = (hipStream_t)stream;
   // algorithmic work = the 3x3 convolution over the fine grid this launch stands for; executed = 16 C MACs per low-resolution position
-  const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * 9.0 * (double)d->C, 0);
-  sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * 16.0 * (double)d->C);
+  const double c2 = d->x2 ? (double)d->C2 : 0.0;      // the fused skip stands for a 1x1 convolution over the fine grid
+  const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
+  sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * (16.0 * (double)d->C + 4.0 * c2));
   const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, st) : sg_launch_conv_q<2>(p, e, st);
   sg_prof_end(st, prof);
   SG_CHECK(rc == 0, "sg_conv2d_q: launch failed");

@@ -5,12 +5,16 @@
 
 static long long g_rs_launches = 0;
 
-// EXPERIMENTAL, default off (SG_CONV_RS96=1 / force): the 96 -> 96 channel row-streaming kernel (conv_rs96.h). Never run on a GPU yet.
+// the 96 -> 96 channel row-streaming kernel (conv_rs96.h). Round 4, first execution (profiles/r04_conv_rs96_first_run.txt): parity green; the
+// plain variant 0.986 -> 0.811 ms per launch at batch 256 (858 TFLOP/s: the generator's last 3x3) -- on by default; the pooling variant is
+// SLOWER than the halo kernel (1.027 vs 0.926 ms) and the pooled layers run on the quad kernel anyway: only with SG_CONV_RS96=1 / force.
+// SG_CONV_RS96=0 switches the kernel off.
 static bool conv_fwd_rs96_try(const sg_conv_fwd_desc* d, const Epilogue<bf16_t>& e, int I, int K, int pflags, hipStream_t st) {
   const char* m = getenv("SG_CONV_RS96");
-  if (!m || (m[0] != '1' && m[0] != 'f')) return false;
-  const bool force = m[0] == 'f';
+  if (m && m[0] == '0') return false;
+  const bool force = m && m[0] == 'f';
   const bool pool = (e.flags & SG_EPI_POOL) != 0;
+  if (pool && !(m && (m[0] == '1' || m[0] == 'f'))) return false;
   if (d->stride != 1 || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return false;
   if (pflags & (SG_PIX_TRANSPOSED | SG_PIX_UPSAMPLE)) return false;
   if (((pflags & SG_PIX_QUAD) != 0) != pool) return false;

@@ -1,6 +1,7 @@
-// conv_rs96.h -- EXPERIMENTAL (default off: SG_CONV_RS96=1; written at the end of round 3 without GPU time left to run it -- builds, never executed;
-// its tests in tests/test_conv_v2_gpu.py are skipped unless SG_EXPERIMENTAL=1). Its index arithmetic IS checked: tools/rs96_model.py replays the
-// kernel lane by lane on the CPU with these formulas against a direct convolution (exact on integer data; tests/test_host_cpu.py).
+// conv_rs96.h -- row-streaming 96 -> 96 channel 3x3 kernel. Written at the end of round 3 without GPU time; first executed in round 4
+// (tools/sessions/r4a.sh): parity green against CPU fp64 and the halo kernel (tests/test_conv_v2_gpu.py), plain variant 0.986 -> 0.811 ms per launch
+// at batch 256, pooling variant slower than the halo kernel (profiles/r04_conv_rs96_first_run.txt). Its index arithmetic is also replayed lane by
+// lane on the CPU (tools/rs96_model.py, tests/test_host_cpu.py).
 //
 // The row-streaming structure of conv_rs.h for the 96 -> 96 channel 3x3 convolutions at 128 x 128 (bf16): the layers that carry most of the
 // FLOPs of the BigGAN-128 discriminator's first block and of the generator's last one, and that the halo kernels run at 0.29-0.38 of the MFMA

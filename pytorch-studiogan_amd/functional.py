@@ -135,7 +135,8 @@ def quad_pack_raw(src_ptr, dst, mode, M, Cs):
     return dst
 
 
-def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None, alpha=1.0, beta=1.0, dry=False):
+def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None, alpha=1.0, beta=1.0, dry=False,
+                 x2=None, w2q_ptr=None, bias2=None):
     """The quad forms of a 3x3 / pad-1 convolution next to a 2x resampling (include/sgamd.h sg_conv2d_q). form Q_POOL: x [N,2Hl,2Wl,C] ->
     [N,Hl,Wl,Cout] = avgpool2(conv3x3(x)); form Q_UP: x [N,Hl,Wl,C] -> [N,2Hl,2Wl,Cout] = conv3x3(up2(x)). Returns None when not eligible."""
     N = x.shape[0]
@@ -158,6 +159,8 @@ def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None
     d.ldo = Cout
     d.ldr = res.shape[-1] if res is not None else 0
     d.ldm = mask.shape[-1] if mask is not None else 0
+    if x2 is not None:      # Q_POOL: the block's 1x1 skip convolution in the same launch (x2: fine tensor, w2q: its filter x 1/4)
+        d.x2, d.w2q, d.bias2, d.C2, d.ldx2 = L.ptr(x2), w2q_ptr, L.ptr(bias2), x2.shape[3], x2.shape[3]
     if L.lib().sg_conv2d_q_ok(L.C.byref(d)) != 1:
         return None
     if not dry:
@@ -534,6 +537,10 @@ class ConvSkipFn(torch.autograd.Function):
         if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
             y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
                                 bias=b2, bias2=b0, alpha=al)
+        if y is None and plain and _quad_form(rt2, cfg2, h) == L.Q_POOL and _SKIP_FUSION[0] and rt0.cin_pad % 32 == 0 and not cfg0.in_upsample:
+            # pooled tail on the quad kernel with the skip as extra one-tap K-slices of the same launch (conv_q.h SKIP)
+            y = conv2d_q_raw(h, bank.w_quad(slot, rt2, L.Q_POOL), L.Q_POOL, h.shape[3], rt2.rows, pf, 0, bias=b2,
+                             x2=x, w2q_ptr=bank.w_quad(slot, rt0, 4), bias2=b0)
         if y is None:
             hh = _conv_fwd(h, rt2, slot, cfg2, b2)
             pf0 = pf | (L.PIX_UPSAMPLE if cfg0.in_upsample else 0)

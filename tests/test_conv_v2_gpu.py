@@ -645,7 +645,7 @@ def test_conv_rs_matches_reference_and_halo_kernel(sg, case, monkeypatch):
 
 
 RS96_CASES = [
-    # N, H, relu_in, pool, relu_out, bias, strip rows     -- csrc/conv_rs96.h (EXPERIMENTAL, default off): 96 -> 96 channels, 3x3, 128-pixel-wide images
+    # N, H, relu_in, pool, relu_out, bias, strip rows     -- csrc/conv_rs96.h: 96 -> 96 channels, 3x3, 128-pixel-wide images
     (2, 128, False, False, False, True, 128),       # G's last 3x3 (plain + bias), one strip per image
     (2, 128, True, True, False, True, 0),           # D's first-block tail: ReLU on load, 2x2 average pooling (alpha = 0.25), launcher's strips
     (3, 64, True, False, True, False, 16),          # 64 x 128 images, ReLU on store, no bias
@@ -653,7 +653,6 @@ RS96_CASES = [
 ]
 
 
-@pytest.mark.skipif(os.environ.get("SG_EXPERIMENTAL") != "1", reason="conv_rs96.h was written without GPU time left (round 3): enable with SG_EXPERIMENTAL=1")
 @pytest.mark.parametrize("case", RS96_CASES)
 def test_conv_rs96_matches_reference_and_halo_kernel(sg, case, monkeypatch):
     from studiogan_amd import functional as F, _lib as L

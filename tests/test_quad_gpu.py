@@ -47,9 +47,11 @@ FWD_CASES = [
 ]
 
 
+@pytest.mark.parametrize("bj", ["256", "128"])
 @pytest.mark.parametrize("case", FWD_CASES)
-def test_conv_q_matches_torch(sg, case):
+def test_conv_q_matches_torch(sg, case, bj, monkeypatch):
     from studiogan_amd import functional as F, _lib as L
+    monkeypatch.setenv("SG_CONV_Q_BJ", bj)          # both pixel tiles (the launcher picks 128 when 256 leaves the chip under-filled)
     form, N, Hl, Wl, C, Cout, relu_in, with_bias, with_mask, with_res, relu_out = case
     dt = torch.bfloat16
     Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
@@ -151,3 +153,40 @@ def test_wgrad_q_matches_autograd(sg, case):
         check(f"wgrad_q {case} splits {splits}", got, dw, 3e-3)
         if with_bias:
             check(f"wgrad_q bias {case} splits {splits}", db.cpu(), dy.float().sum((0, 1, 2)), 2e-3)
+
+
+SKIP_CASES = [
+    # N, Hl, Wl, C, Cout, C2, relu, bj
+    (2, 8, 8, 64, 96, 32, True, "256"),
+    (2, 8, 8, 96, 192, 96, True, "128"),
+    (3, 4, 4, 64, 64, 64, False, "256"),
+    (1, 16, 32, 192, 192, 96, True, "256"),
+]
+
+
+@pytest.mark.parametrize("case", SKIP_CASES)
+def test_conv_q_fused_skip_matches_torch(sg, case, monkeypatch):
+    """POOL form with the block's 1x1 skip in the same launch: avgpool2(conv3x3(relu h) + conv1x1(relu x)) + b2 + b0 (reference
+    src/models/big_resnet.py:221-242)"""
+    from studiogan_amd import functional as F, _lib as L
+    N, Hl, Wl, C, Cout, C2, relu, bj = case
+    monkeypatch.setenv("SG_CONV_Q_BJ", bj)
+    dt = torch.bfloat16
+    h = rnd((N, 2 * Hl, 2 * Wl, C), dt, 341)
+    x = rnd((N, 2 * Hl, 2 * Wl, C2), dt, 342)
+    w9 = rnd((Cout, 3, 3, C), dt, 343, 0.1)
+    w0 = rnd((Cout, C2), dt, 344, 0.2)
+    b2, b0 = rnd((Cout,), torch.float32, 345), rnd((Cout,), torch.float32, 346)
+    ref = Q.pool_conv_torch(h.float(), w9.float(), relu) + b2 + b0
+    xx = torch.relu(x.float()) if relu else x.float()
+    sk = torch.einsum("nhwc,oc->nhwo", xx, w0.float())
+    ref = ref + 0.25 * (sk[:, 0::2, 0::2] + sk[:, 0::2, 1::2] + sk[:, 1::2, 0::2] + sk[:, 1::2, 1::2])
+    wq = torch.empty(Cout, 16, C, dtype=dt, device="cuda:0")
+    w9d, w0d = _dev(w9), _dev(w0)
+    F.quad_pack_raw(w9d.data_ptr(), wq, 0, Cout, C)
+    w0q = (w0d.float() * 0.25).to(dt)
+    y = F.conv2d_q_raw(_dev(h), wq.data_ptr(), L.Q_POOL, C, Cout, L.PIX_RELU if relu else 0, 0, bias=_dev(b2),
+                       x2=_dev(x), w2q_ptr=w0q.data_ptr(), bias2=_dev(b0))
+    assert y is not None
+    torch.cuda.synchronize()
+    check(f"conv_q fused skip {case}", y.float().cpu(), ref, 6e-3)

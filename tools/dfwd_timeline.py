@@ -9,7 +9,7 @@ import csv
 import re
 import sys
 
-CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_gemm_kernel<.*ConvPix")
+CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_conv_rs96_kernel|sg_conv_q_kernel|sg_gemm_kernel<.*ConvPix")
 
 
 def short(n):
