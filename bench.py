@@ -46,6 +46,53 @@ WORKLOADS = {
 }
 
 
+# kernel families of the convolution engine as the in-library launch profiler tags them (csrc/common.h SG_ENG_*)
+ENGINES = ["other", "sg_conv_sk_kernel", "sg_conv_rs_kernel / sg_conv_rs96_kernel", "sg_conv_v4_kernel", "sg_conv_v3_kernel", "sg_conv_v2_kernel",
+           "sg_gemm_kernel<ConvPix>", "sg_conv_v4_kernel<SKIP>", "sg_conv_q_kernel", "sg_conv_q_kernel<SKIP>", "sg_wgrad_sk_kernel", "sg_wgrad_v3_kernel",
+           "sg_wgrad_v2_kernel", "sg_gemm_kernel<wgrad>", "sg_wgrad_q_kernel"]
+
+
+def per_kernel_table(L, nsteps, peak, pmc=None):
+    """roofline.per_kernel: the convolution engine's launches of the timed region by kernel family (hipEvent time per launch, recorded on the launch
+    stream by libsgamd.so): launches / step, ms / step, algorithmic and executed TFLOP/s, fraction of the MFMA peak, algorithmic HBM bytes per launch,
+    and -- when a PMC summary of the same command is committed under profiles/ -- measured HBM bytes / algorithmic bytes."""
+    n = len(ENGINES)
+    t = (ctypes.c_double * (n * 5))()
+    L.call("sg_prof_collect_tags", t, n)
+    rows = {}
+    for i, name in enumerate(ENGINES):
+        cnt, ms, fl, ex, by = t[i * 5:i * 5 + 5]
+        if cnt == 0:
+            continue
+        r = {"launches_per_step": round(cnt / nsteps, 1), "ms_per_step": round(ms / nsteps, 3),
+             "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else None,
+             "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+             "algorithmic_MB_per_launch": round(by / cnt / 1e6, 1), "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
+        if pmc:
+            # measured HBM bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/pmc_traffic.py) of the family's
+            # kernel templates over the algorithmic bytes; a weight-gradient family includes the split-K reduce launches that follow its kernels
+            key = name.split(" ")[0].split("<")[0]
+            skip = "SKIP" in name
+            def member(k):
+                if key not in k:
+                    return False
+                if key == "sg_conv_v4_kernel":
+                    return k.rstrip().endswith("true>") == skip
+                if key == "sg_conv_q_kernel":
+                    return k.rstrip().endswith("true>") == skip
+                if key == "sg_gemm_kernel":
+                    return "ConvPix" in k
+                return True
+            meas = [v for v in pmc if member(v["kernel"])]
+            tot_b = sum(v["bytes_per_launch"] * v["launches"] for v in meas)
+            tot_n = sum(v["launches"] for v in meas)
+            if tot_n and by > 0:
+                r["pmc_MB_per_launch"] = round(tot_b / tot_n / 1e6, 1)
+                r["pmc_bytes_over_algorithmic"] = round((tot_b / tot_n) / (by / cnt), 3)
+        rows[name] = r
+    return rows
+
+
 def build(wl, mixed, device):
     from studiogan_amd import ops
     from studiogan_amd.backbones import big_resnet
@@ -418,9 +465,19 @@ def main():
     assert d_last > 1e-2, f"discriminator saturated in the timed region (d_loss {d_last}): the measured step would multiply zero gradients"
     fake_chk = w.last_g[0]
     assert bool(torch.isfinite(fake_chk).all()) and float(fake_chk.abs().max()) <= 1.0, "generator images of the last step are not finite / not in [-1, 1]"
-    prof = (ctypes.c_double * 9)()
-    L.call("sg_prof_collect", prof, 3)
+    pmc_tab, pmc_src = None, None
+    try:
+        pmc_name = next(n for n in ("r04_conv_hbm_traffic_pmc.json",) if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        pmc_tab = json.load(open(os.path.join(ROOT, "profiles", pmc_name))).get("per_kernel")
+        pmc_src = "profiles/" + pmc_name
+    except Exception:
+        pass
+    per_kernel = per_kernel_table(L, args.steps, PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS, pmc_tab)
+    prof4 = (ctypes.c_double * 12)()
+    L.call("sg_prof_collect_ex", prof4, 3)
     L.call("sg_prof_enable", 0)
+    prof = [prof4[(i // 3) * 4 + (i % 3)] for i in range(9)]          # {launches, ms, algorithmic flops} per kind, as before
+    conv_exec_flop = prof4[3] + prof4[7]
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -442,9 +499,11 @@ def main():
                 D(x, y)
             e1.record()
             torch.cuda.synchronize()
-        pd = (ctypes.c_double * 9)()
-        L.call("sg_prof_collect", pd, 3)
+        dfwd_kernels = per_kernel_table(L, it, PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS)
+        pd4 = (ctypes.c_double * 12)()
+        L.call("sg_prof_collect_ex", pd4, 3)
         L.call("sg_prof_enable", 0)
+        pd = [pd4[(i // 3) * 4 + (i % 3)] for i in range(9)]
         fwd_ms = e0.elapsed_time(e1) / it
         conv_only_ms = pd[1] / it
         pk = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
@@ -452,7 +511,12 @@ def main():
                 "forward_ms": round(fwd_ms, 3), "forward_tflops": round(21.673 * args.batch / fwd_ms, 1),
                 "conv_stack_ms": round(conv_only_ms, 3), "conv_launches": int(pd[0] / it),
                 "conv_stack_tflops": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
-                "conv_stack_frac_of_peak": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None, "peak_tflops": pk}
+                "conv_stack_frac_of_peak": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None, "peak_tflops": pk,
+                # algorithmic = the reference's op graph (3x3 convolution + AvgPool2d as written in src/models/big_resnet.py:177-242); the pooled
+                # block tails run as 4x4 / stride-2 convolutions with the pre-summed filter (csrc/conv_q.h): 16/36 of those MACs are executed
+                "conv_stack_executed_tflops": round(pd4[3] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
+                "conv_stack_executed_frac_of_peak": round(pd4[3] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None,
+                "per_kernel": dfwd_kernels}
     # ---- HBM-bound kernel families of the step: algorithmic bytes / hipEvent time per family over two more steps --------
     hbm = None
     if rank == 0 or world > 1:
@@ -522,7 +586,7 @@ def main():
     # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
     traffic, traffic_src = None, None
     try:
-        tname = next(n for n in ("r03_conv_hbm_traffic_pmc.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc_v2.json")
+        tname = next(n for n in ("r04_conv_hbm_traffic_pmc.json", "r03_conv_hbm_traffic_pmc.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc_v2.json")
                      if os.path.exists(os.path.join(ROOT, "profiles", n)))
         tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
         if args.workload == "biggan128" and mixed and args.batch == 256:
@@ -544,9 +608,17 @@ def main():
                    "rccl_ranks": rccl_ranks},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine: sg_conv_v4_kernel (3x3 halo, <= 384 channels; with the block's 1x1 skip fused in from 16x16 outputs up) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers at 128 x 128) / sg_conv_v2_kernel / sg_wgrad_v3_kernel (3x3 halo) / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel (implicit-GEMM conv fwd/dgrad/wgrad)",
+                     "kernel": "convolution engine (family; per_kernel has the members, dominant_kernel the largest): sg_conv_q_kernel / sg_wgrad_q_kernel (3x3 next to a 2x resampling as 4x4-stride-2 / four 2x2 phase convolutions) / sg_conv_v4_kernel (3x3 halo, <= 384 channels, G tails with the 1x1 skip fused) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers) / sg_conv_v2_kernel / sg_wgrad_v3_kernel / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel",
+                     "executed_tflops": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
+                     "executed_frac": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms > 0 else None,
+                     "achieved_note": "achieved = ALGORITHMIC FLOPs of the reference's op graph (3x3 convolutions over the fine grid) / hipEvent time; the convolutions next to "
+                                      "a 2x resampling run through the exact pooled / phase-filter identity (csrc/conv_q.h) and execute 16/36 of them: executed_* counts the MFMAs issued",
+                     "dominant_kernel": max(per_kernel.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if per_kernel else None,
+                     "per_kernel": per_kernel, "per_kernel_pmc_source": pmc_src,
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
+                     "algorithmic_bytes_per_launch": round(sum(v["algorithmic_MB_per_launch"] * 1e6 * v["launches_per_step"] for v in per_kernel.values()) /
+                                                           max(sum(v["launches_per_step"] for v in per_kernel.values()), 1e-9)) if per_kernel else None,
                      "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",
                      "conv_ms_per_step": round(conv_ms / args.steps, 2),
                      "gemm_ms_per_step": round(prof[7] / args.steps, 2)},

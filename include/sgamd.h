@@ -141,6 +141,9 @@ int sg_conv2d_q_wgrad_plan(const sg_convq_wgrad_desc* d, int* splits, long long*
 int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t stream);
 /* sg_prof_collect with a fourth column per kind: FLOPs the launches really executed (quad launches: 16 / 36 of the algorithmic count) */
 int sg_prof_collect_ex(double* out, int nkinds);
+/* per kernel family of the convolution engine (ids: csrc/common.h SG_ENG_*, names: bench.py ENGINES): out[id * 5 + {0..4}] = {launches, total ms,
+ * algorithmic FLOPs, executed FLOPs, algorithmic HBM bytes}. Does not reset the log: call it BEFORE sg_prof_collect / sg_prof_collect_ex. */
+int sg_prof_collect_tags(double* out, int ntags);
 
 /* dw[co][r][s][c] += alpha * sum_{n,ho,wo} dy'[n,ho,wo,co] * x'[n, ho*stride-pad+r, wo*stride-pad+s, c] (fp32 atomics) */
 typedef struct {

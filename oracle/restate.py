@@ -170,6 +170,13 @@ def self_attention(x, P, B, name, sn_iter=True, E=IDENT):
 # ---------------------------------------------------------------------------------------------------------
 # BigGAN (models/big_resnet.py)
 # ---------------------------------------------------------------------------------------------------------
+def _tap(cfg, bi, act):
+    """Block boundary `bi` of a network restatement (-1: in front of the first block): identity, unless the caller passed cfg['taps'] -- the
+    teacher-forced block tests (tests/test_blocks_gpu.py) record the boundary activations and their gradients there."""
+    t = cfg.get("taps")
+    return act if t is None else t(bi, act)
+
+
 def biggan_dims(img_size, ch):
     g_in = {32: [4, 4, 4], 64: [16, 8, 4, 2], 128: [16, 16, 8, 4, 2], 256: [16, 16, 8, 8, 4, 2]}[img_size]
     g_out = {32: [4, 4, 4], 64: [8, 4, 2, 1], 128: [16, 8, 4, 2, 1], 256: [16, 8, 8, 4, 2, 1]}[img_size]
@@ -192,7 +199,7 @@ def biggan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
     else:
         affines = list(zs[1:])
     E = emu_of(cfg)
-    act = E.q(linear(zs[0], P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
+    act = _tap(cfg, -1, E.q(linear(zs[0], P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4))
     bi = 0
     for index in range(nb):
         pre = f"blocks.{bi}.0"
@@ -203,10 +210,10 @@ def biggan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
         x = E.q(torch.relu(cond_batch_norm(E.qb(x), affines[index], P, B, pre + ".bn2", bn_mode, sn_iter)))
         x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E))
         x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
-        act = E.q(x + x0)
+        act = _tap(cfg, bi, E.q(x + x0))
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
+            act = _tap(cfg, bi, self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E))
             bi += 1
     act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
     return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
@@ -262,9 +269,10 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
             else:
                 x0 = E.qb(x0)
             h = E.q(y + x0)
+        h = _tap(cfg, bi, h)
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
-            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
+            h = _tap(cfg, bi, self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E))
             bi += 1
     h = E.qb(h)
     h = torch.sum(torch.relu(h), dim=[2, 3])
@@ -288,7 +296,7 @@ def biggan_deep_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
         affine = torch.cat([F.embedding(label, P["shared.weight"]), z], 1)
     else:
         affine = z
-    act = E.q(linear(affine, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
+    act = _tap(cfg, -1, E.q(linear(affine, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4))
     bi = 0
     for index in range(len(g_in)):
         for gi in range(depth):
@@ -309,10 +317,10 @@ def biggan_deep_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
             x = conv(x, P, B, pre + ".conv2d4", 0, sn_iter, E)
             if up:
                 x0 = E.q(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"))
-            act = E.q(x + x0)
+            act = _tap(cfg, bi, E.q(x + x0))
             bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
+            act = _tap(cfg, bi, self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E))
             bi += 1
     act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
     return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))
@@ -331,7 +339,7 @@ def biggan_deep_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True
     d_in, d_out, d_down = biggan_deep_dims(cfg["img_size"], cfg["d_conv_dim"])
     E = emu_of(cfg)
     depth = cfg["d_depth"]
-    h = E.q(conv(E.q(x), P, B, "input_conv", 1, sn_iter, E))
+    h = _tap(cfg, -1, E.q(conv(E.q(x), P, B, "input_conv", 1, sn_iter, E)))
     bi = 0
     for index in range(len(d_in)):
         for di in range(depth):
@@ -352,10 +360,10 @@ def biggan_deep_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True
                 x0 = E.q(F.avg_pool2d(E.qb(x0), 2))
             if cin != cout:
                 x0 = torch.cat([x0, E.q(conv(x0, P, B, pre + ".conv2d0", 0, sn_iter, E))], 1)
-            h = E.q(y + x0)
+            h = _tap(cfg, bi, E.q(y + x0))
             bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_d_loc"]:
-            h = self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E)
+            h = _tap(cfg, bi, self_attention(h, P, B, f"blocks.{bi}.0", sn_iter, E))
             bi += 1
     h = torch.sum(torch.relu(E.qb(h)), dim=[2, 3])
     adv = torch.squeeze(linear(h, P, B, "linear1", sn_iter))

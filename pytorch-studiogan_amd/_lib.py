@@ -105,6 +105,7 @@ _PROTOS = {
     "sg_conv2d_q_wgrad_plan": [C.POINTER(ConvQWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_q_wgrad": [C.POINTER(ConvQWgradDesc), _vp],
     "sg_prof_collect_ex": [C.POINTER(C.c_double), _i],
+    "sg_prof_collect_tags": [C.POINTER(C.c_double), _i],
     "sg_conv2d_wgrad": [C.POINTER(ConvWgradDesc), _vp],
     "sg_conv2d_wgrad_plan": [C.POINTER(ConvWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_wgrad_fuses_bias": [C.POINTER(ConvWgradDesc)],

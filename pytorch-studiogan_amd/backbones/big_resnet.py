@@ -128,6 +128,7 @@ class Generator(nn.Module):
 
         act = self.linear0.forward_rt(z0, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
+        act = ops.block_boundary(self, -1, act)
         counter = 0
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
         for bi, blocklist in enumerate(self.blocks):
@@ -139,6 +140,7 @@ class Generator(nn.Module):
                     counter += 1
             if nxt is not None:
                 act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
+            act = ops.block_boundary(self, bi, act)
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)
@@ -276,5 +278,6 @@ class Discriminator(nn.Module):
                 h = block.forward_nhwc(h, slot)
             if nxt is not None:
                 h = bank.mark(h, nxt[bi])          # data parallelism: the backward's return to this point releases the gradients behind it
+            h = ops.block_boundary(self, bi, h)
         h = F.ReluSumFn.apply(h)
         return apply_heads(self, h, label, slot, adc_fake)

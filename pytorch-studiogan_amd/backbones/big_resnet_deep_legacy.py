@@ -116,6 +116,7 @@ class Generator(nn.Module):
         affine = z
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
+        act = ops.block_boundary(self, -1, act)
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
         for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
@@ -125,6 +126,7 @@ class Generator(nn.Module):
                     act = block.forward_nhwc(act, affine, slot)
             if nxt is not None:
                 act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
+            act = ops.block_boundary(self, bi, act)
         act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)
@@ -223,11 +225,13 @@ class Discriminator(nn.Module):
         slot = bank.begin_forward(_need_graph(self, x))
         h = ops.to_nhwc(x, dtype, 8)
         h = self.input_conv.forward_nhwc(h, slot)
+        h = ops.block_boundary(self, -1, h)
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
         for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
                 h = block.forward_nhwc(h, slot)
             if nxt is not None:
                 h = bank.mark(h, nxt[bi])          # data parallelism: the backward's return to this point releases the gradients behind it
+            h = ops.block_boundary(self, bi, h)
         h = F.ReluSumFn.apply(h)
         return apply_heads(self, h, label, slot, adc_fake)

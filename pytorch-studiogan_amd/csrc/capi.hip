@@ -22,6 +22,8 @@ static int g_prof_n = 0;
 static hipEvent_t g_ev0[SG_PROF_MAX], g_ev1[SG_PROF_MAX];
 static double g_flops[SG_PROF_MAX];
 static double g_exec[SG_PROF_MAX];      // FLOPs the launch really executes (quad convolutions: 16 / 36 of the algorithmic count)
+static double g_bytes[SG_PROF_MAX];     // algorithmic HBM bytes of the launch (every operand read once, the result written once)
+static int g_tag[SG_PROF_MAX];          // which kernel family took the problem (SG_ENG_*)
 static int g_kind[SG_PROF_MAX];
 static int g_ev_created = 0;
 
@@ -40,7 +42,7 @@ extern "C" int sg_prof_enable(int on) {
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind) {
   if (!(g_prof_on & (kind < 3 ? 1 : 2)) || g_prof_n >= SG_PROF_MAX) return -1;
   const int i = g_prof_n++;
-  g_flops[i] = flops; g_exec[i] = flops; g_kind[i] = kind;
+  g_flops[i] = flops; g_exec[i] = flops; g_kind[i] = kind; g_bytes[i] = 0.0; g_tag[i] = 0;
   hipEventRecord(g_ev0[i], st);
   return i;
 }
@@ -62,6 +64,23 @@ extern "C" int sg_prof_collect(double* out, int nkinds) {
     out[k * 3 + 0] += 1.0; out[k * 3 + 1] += ms; out[k * 3 + 2] += g_flops[i];
   }
   g_prof_n = 0;
+  return 0;
+}
+extern "C" void sg_prof_tag(int slot, int engine, double alg_bytes) {
+  if (slot >= 0) { g_tag[slot] = engine; g_bytes[slot] = alg_bytes; }
+}
+// per kernel family (SG_ENG_* of common.h): out[tag * 5 + {0..4}] = {launches, total ms, algorithmic flops, executed flops, algorithmic bytes}.
+// Does NOT reset the log (call it before sg_prof_collect / sg_prof_collect_ex).
+extern "C" int sg_prof_collect_tags(double* out, int ntags) {
+  for (int k = 0; k < ntags * 5; k++) out[k] = 0.0;
+  for (int i = 0; i < g_prof_n; i++) {
+    if (g_kind[i] > 1) continue;            // convolution engine only
+    float ms = 0.f;
+    if (hipEventElapsedTime(&ms, g_ev0[i], g_ev1[i]) != hipSuccess) { sg_set_error("sg_prof_collect_tags: events not complete (synchronise first)"); return -2; }
+    const int k = g_tag[i];
+    if (k < 0 || k >= ntags) continue;
+    out[k * 5 + 0] += 1.0; out[k * 5 + 1] += ms; out[k * 5 + 2] += g_flops[i]; out[k * 5 + 3] += g_exec[i]; out[k * 5 + 4] += g_bytes[i];
+  }
   return 0;
 }
 // same, four columns per kind: {launches, total ms, algorithmic flops, executed flops}

@@ -151,6 +151,10 @@ extern "C" void sg_set_error(const char* msg);
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind);
 extern "C" void sg_prof_end(hipStream_t st, int slot);
 extern "C" void sg_prof_set_executed(int slot, double flops);
+extern "C" void sg_prof_tag(int slot, int engine, double alg_bytes);
+// kernel families of the convolution engine, as the launch profiler reports them (sg_prof_collect_tags; names in bench.py ENGINES)
+enum { SG_ENG_OTHER = 0, SG_ENG_CONV_SK, SG_ENG_CONV_RS, SG_ENG_CONV_V4, SG_ENG_CONV_V3, SG_ENG_CONV_V2, SG_ENG_CONV_GEMM, SG_ENG_CONV_V4_SKIP, SG_ENG_CONV_Q,
+       SG_ENG_CONV_Q_SKIP, SG_ENG_WGRAD_SK, SG_ENG_WGRAD_V3, SG_ENG_WGRAD_V2, SG_ENG_WGRAD_GEMM, SG_ENG_WGRAD_Q, SG_ENG_COUNT };
 // scope guard around an entry point's launches for the in-library profiler (capi.hip): kinds 0-2 = MFMA contraction engine (work in
 // FLOP), kinds 3-6 = HBM-bound families (work in algorithmic BYTES): 3 spectral norm, 4 batch norm, 5 attention scores, 6 Adam / EMA
 struct SgProfScope {

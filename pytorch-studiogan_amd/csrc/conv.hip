@@ -122,13 +122,20 @@ template <typename T> static int conv_fwd_t(const sg_conv_fwd_desc* d, hipStream
   e.mask = (const T*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
   e.alpha = d->alpha; e.alpha_ptr = d->alpha_ptr; e.flags = d->epi_flags; e.I = I; e.J = J;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 0);
-  if (w_vec && x_vec && conv_fwd_sk_try<T>(d, e, I, J, K, pflags, st)) {}
-  else if (w_vec && x_vec && conv_fwd_rs_try<T>(d, e, I, J, K, pflags, st)) {}
-  else if (w_vec && x_vec && conv_fwd_v4_try<T>(d, e, I, J, K, pflags, st)) {}
-  else if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) {}
-  else if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) {}
+  int eng = SG_ENG_CONV_GEMM;
+  if (w_vec && x_vec && conv_fwd_sk_try<T>(d, e, I, J, K, pflags, st)) eng = SG_ENG_CONV_SK;
+  else if (w_vec && x_vec && conv_fwd_rs_try<T>(d, e, I, J, K, pflags, st)) eng = SG_ENG_CONV_RS;
+  else if (w_vec && x_vec && conv_fwd_v4_try<T>(d, e, I, J, K, pflags, st)) eng = SG_ENG_CONV_V4;
+  else if (w_vec && x_vec && conv_fwd_v3_try<T>(d, e, I, J, K, pflags, st)) eng = SG_ENG_CONV_V3;
+  else if (w_vec && x_vec && conv_fwd_v2_try<T>(d, e, I, J, K, pflags, st)) eng = SG_ENG_CONV_V2;
   else if (w_vec && x_vec) conv_fwd_launch<T, true>(d, e, I, J, K, pflags, st);   // all-vector kernels: no gather code in the k-loop
   else conv_fwd_launch<T, false>(d, e, I, J, K, pflags, st);
+  {
+    // algorithmic HBM bytes: input, filter, result (pooled size when pooling), ReLU-mask / residual operands once each
+    const double es = sizeof(T), jout = (d->epi_flags & SG_EPI_POOL) ? (double)J / 4.0 : (double)J;
+    const double b = es * ((double)d->N * d->Hs * d->Ws * d->C + (double)I * K + jout * I * (1.0 + (d->mask ? 1.0 : 0.0) + (d->res ? 1.0 : 0.0)));
+    sg_prof_tag(prof, eng, b);
+  }
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;
@@ -152,6 +159,11 @@ static int conv_fwd_skip(const sg_conv_skip_desc* sk, hipStream_t st, bool dry) 
   if (dry) return sg_conv_fwd_v4_skip_try(d, sk, e, I, J, K, pflags, st, true) ? 1 : 0;
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * ((double)K + (double)sk->C2), 0);
   const bool ok = sg_conv_fwd_v4_skip_try(d, sk, e, I, J, K, pflags, st, false);
+  {
+    const double jout = (d->epi_flags & SG_EPI_POOL) ? (double)J / 4.0 : (double)J;
+    const double x2 = (double)d->N * (sk->x2_up ? (d->Ho / 2) * (d->Wo / 2) : d->Ho * d->Wo) * sk->C2;
+    sg_prof_tag(prof, SG_ENG_CONV_V4_SKIP, 2.0 * ((double)d->N * d->Hs * d->Ws * d->C + x2 + (double)I * (K + sk->C2) + jout * I));
+  }
   sg_prof_end(st, prof);
   return ok ? 1 : 0;
 }

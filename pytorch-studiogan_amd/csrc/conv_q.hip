@@ -218,6 +218,12 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * (16.0 * (double)d->C + 4.0 * c2));
   const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, st) : sg_launch_conv_q<2>(p, e, st);
+  {
+    // algorithmic HBM bytes: input (+ skip input), quad filter(s), result (+ mask / residual), bf16
+    const double J = (double)p.J, jin = d->form == SG_Q_POOL ? 4.0 * J : J, jout = d->form == SG_Q_POOL ? J : 4.0 * J;
+    sg_prof_tag(prof, d->x2 ? SG_ENG_CONV_Q_SKIP : SG_ENG_CONV_Q,
+                2.0 * (jin * d->C + (d->x2 ? 4.0 * J * d->C2 + (double)d->Cout * d->C2 : 0.0) + 16.0 * d->C * d->Cout + jout * d->Cout * (1.0 + (d->mask ? 1.0 : 0.0) + (d->res ? 1.0 : 0.0))));
+  }
   sg_prof_end(st, prof);
   SG_CHECK(rc == 0, "sg_conv2d_q: launch failed");
   SG_LAUNCH_CHECK();
@@ -342,6 +348,8 @@ extern "C" int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t strea
     hipLaunchKernelGGL(k_quad_reduce_fold, dim3(nmain + nbias), dim3(256), 0, st, (const float*)d->work, d->dw, s.splits, s.stride, d->Cout, d->C,
                        pl ? 1 : 0, pl ? 0.25f : 1.f, d->dbias, s.n, pl ? 1 : 4, nmain);
   }
+  // algorithmic HBM bytes: x and dy once (bf16), the fp32 3x3 gradient read and written
+  sg_prof_tag(prof, SG_ENG_WGRAD_Q, 2.0 * ((double)xpix * d->C + (double)gpix * d->Cout) + 8.0 * 9.0 * (double)d->C * d->Cout);
   sg_prof_end(st, prof);
   SG_CHECK(rc == 0, "sg_conv2d_q_wgrad: launch failed");
   SG_LAUNCH_CHECK();

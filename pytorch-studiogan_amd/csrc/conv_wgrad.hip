@@ -275,6 +275,10 @@ template <> bool wgrad_v2_launch<bf16_t>(const sg_conv_wgrad_desc* d, const Epil
   return sg_launch_wgrad_v2(p, e, splits, st) == 0;
 }
 
+// algorithmic HBM bytes of a weight gradient: x and dy once (stored sizes), the fp32 gradient read and written
+template <typename T> static double wgrad_alg_bytes(const sg_conv_wgrad_desc* d) {
+  return sizeof(T) * ((double)d->N * d->xHs * d->xWs * d->C + (double)d->N * d->gHs * d->gWs * d->Cout) + 8.0 * (double)d->R * d->S * d->C * d->Cout;
+}
 template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc* d, hipStream_t st) {
   const int I = d->R * d->S * d->C;
   const int J = d->Cout;
@@ -289,6 +293,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
       const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
       if (wgrad_sk_launch(d, sk, st) != 0) { sg_set_error("sg_conv2d_wgrad: streaming kernel launch failed"); return -2; }
       splitk_reduce_launch((const float*)d->work, d->dw, sk.nw, sk.n, 0, nullptr, 0, st);
+      sg_prof_tag(prof, SG_ENG_WGRAD_SK, wgrad_alg_bytes<T>(d));
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;
@@ -300,6 +305,7 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
       const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
       if (wgrad_v3_launch(d, v3, st) != 0) { sg_set_error("sg_conv2d_wgrad: halo kernel launch failed"); return -2; }
       splitk_reduce_launch((const float*)d->work, d->dw, v3.splits, v3.n, v3.stride, d->dbias, (long long)(d->dbias ? d->Cout : 0), st);
+      sg_prof_tag(prof, SG_ENG_WGRAD_V3, wgrad_alg_bytes<T>(d));
       sg_prof_end(st, prof);
       SG_LAUNCH_CHECK();
       return 0;
@@ -320,12 +326,14 @@ template <typename T, bool TR> static int conv_wgrad_t(const sg_conv_wgrad_desc*
   const int prof = sg_prof_begin(st, 2.0 * (double)I * (double)J * (double)K, 1);
   const bool fast = (d->C % ET<T>::VEC == 0) && (d->ldx % ET<T>::VEC == 0) && aligned16(d->x) &&
                     (d->Cout % ET<T>::VEC == 0) && (d->ldg % ET<T>::VEC == 0) && aligned16(d->dy);
-  if (v2 && wgrad_v2_launch<T>(d, e, I, J, K, splits, st)) {}
+  int eng = SG_ENG_WGRAD_GEMM;
+  if (v2 && wgrad_v2_launch<T>(d, e, I, J, K, splits, st)) eng = SG_ENG_WGRAD_V2;
   else if (fast) conv_wgrad_launch<T, TR, true>(d, e, I, J, K, BI, BJ, splits, st);
   else conv_wgrad_launch<T, TR, false>(d, e, I, J, K, BI, BJ, splits, st);
   if (two_stage) {
     splitk_reduce_launch((const float*)d->work, d->dw, splits, n, 0, nullptr, 0, st);
   }
+  sg_prof_tag(prof, eng, wgrad_alg_bytes<T>(d));
   sg_prof_end(st, prof);
   SG_LAUNCH_CHECK();
   return 0;

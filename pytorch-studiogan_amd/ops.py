@@ -41,6 +41,15 @@ def to_nchw(y):
     return y.permute(0, 3, 1, 2)
 
 
+def block_boundary(net, bi, act):
+    """Block boundary `bi` of a backbone's forward (-1: in front of the first block). A no-op unless a test installed a teacher on the network
+    (`net._sg_teacher`, tests/test_blocks_gpu.py TeacherForcing): then the activation is handed to it -- it records the block's output and may
+    return the tensor the NEXT block is to read instead (teacher forcing: every block sees the emulating oracle's input and upstream gradient,
+    nothing compounds across blocks)."""
+    tf = net.__dict__.get("_sg_teacher")
+    return act if tf is None else tf(bi, act)
+
+
 def _root_and_bank(m):
     """Bank that serves module m: the enclosing network's (set by the backbone) or a private single-layer one."""
     root = m.__dict__.get("_sg_root")

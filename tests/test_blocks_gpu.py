@@ -357,11 +357,46 @@ def test_bf16_vs_emulating_oracle(sg, name, which):
     bf16_vs_emulating_oracle(name, which)
 
 
+class Taps:
+    """cfg['taps'] of an oracle network function (oracle/restate.py _tap): keeps every block-boundary activation and, after backward, its gradient"""
+
+    def __init__(self):
+        self.act = {}
+
+    def __call__(self, bi, act):
+        act.retain_grad()
+        self.act[bi] = act
+        return act
+
+
+class TeacherForcing:
+    """net._sg_teacher (pytorch-studiogan_amd/ops.py block_boundary): records the output of every block and makes the next block read the tensor
+    given for that boundary -- a fresh leaf, so the block's backward stops there"""
+
+    def __init__(self, inputs):
+        self.inputs, self.out, self.leaf = inputs, {}, {}
+
+    def __call__(self, bi, act):
+        self.out[bi] = act
+        t = self.inputs.get(bi)
+        if t is None:
+            return act
+        leaf = t.detach().clone().requires_grad_(True)
+        self.leaf[bi] = leaf
+        return leaf
+
+
+class TapsReplace(TeacherForcing):
+    """the same hook on the ORACLE side: the perturbed-weights run that measures the teacher-forced noise floor reads the unperturbed run's
+    boundary activations"""
+
+
+TEACHER_TOL = 1e-2     # relative-L2 bound of the teacher-forced block comparisons (VERDICT r3 next-2)
 FLOOR_EPS = 1e-5       # relative weight perturbation of the oracle's own noise-floor run (tools/bf16_noise_floor.py)
 FLOOR_FACTOR = 1.5
 
 
-def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floor=None, shared_objective=False):
+def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floor=None, shared_objective=False, teacher=None):
     """bf16 mode against the oracle run with `Bf16Emu` (oracle/restate.py): the same bf16 rounding at the same storage points
     (activations, activation gradients, weight images), fp32 everywhere else. Per operator the model is exact to 3e-5
     (conv / BN forward + backward) and 8e-3 (attention backward) -- tools/diag_bf16.py, measured on MI355X; over a whole
@@ -377,7 +412,13 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
     batch size (profiles/r03_bf16_batch_curve.txt): the weight gradient of the random linear functional used here is a random-walk sum
     over pixels (signal ~ sqrt(N)), and the units whose ReLU mask flips under rounding noise contribute sqrt(f N) to it, so the ratio does
     not fall with the batch. shared_objective=True uses ONE upstream-gradient image for all samples (partly coherent signal ~ N): there the
-    floor does fall with the batch. Returns (whole-network gradient error, its floor)."""
+    floor does fall with the batch. Returns (whole-network gradient error, its floor).
+
+    teacher (default: on for the backbones with block-boundary hooks, big_resnet / big_resnet_deep_legacy): the DISCRIMINATING bf16 check. The same
+    oracle run keeps every block-boundary activation and its gradient (oracle/restate.py _tap); a second HIP pass feeds each block the oracle's
+    input and upstream gradient (ops.block_boundary), so nothing compounds across blocks and no ReLU-mask flip of an earlier block reaches a later
+    one: every block output, every block-input gradient and every weight gradient must agree to 1e-2 relative-L2 -- a 10-50 % error in one
+    weight-gradient kernel, invisible under the whole-network floor of the generators, fails here."""
     dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
     y = meta["yaml"]
@@ -407,18 +448,19 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
         fix["in/z0"] = torch.randn(batch, y["MODEL"].get("z_dim", 128), generator=gi)
         fix["in/fl0"] = torch.randint(0, nc_, (batch,), generator=gi)
 
-    def oracle_run(leaves):
+    def oracle_run(leaves, taps=None):
         """-> dict of output tensors, input gradient (D) ; leaves carry .grad afterwards"""
         Bc = {k: v.clone() for k, v in B.items()}
+        cfg_ = ocfg if taps is None else dict(ocfg, taps=taps)
         if which == "D":
             x, lab = fix["in/real0"].clone(), fix["in/rl0"]
             gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1]).repeat((x.shape[0] + 7) // 8)[:x.shape[0]]
             xo = x.clone().requires_grad_(True)
-            adv_o, h_o = O.model_fns(ocfg)[1](xo, lab, leaves, Bc)
+            adv_o, h_o = O.model_fns(cfg_)[1](xo, lab, leaves, Bc)
             (adv_o * gadv).sum().backward()
             return {"D adv": adv_o.detach(), "D h": h_o.detach(), "D dx": xo.grad}
         z, lab = fix["in/z0"], fix["in/fl0"]
-        img_o = O.model_fns(ocfg)[0](z, lab, leaves, Bc, bn_mode="track")
+        img_o = O.model_fns(cfg_)[0](z, lab, leaves, Bc, bn_mode="track")
         (img_o * gimg).sum().backward()
         return {"G img": img_o.detach()}
 
@@ -428,7 +470,10 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
         gg = torch.Generator().manual_seed(11)
         gimg = torch.randn(1, 3, S, S, generator=gg).expand(nb, 3, S, S).contiguous() if shared_objective else torch.randn(nb, 3, S, S, generator=gg)
     leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
-    ref = oracle_run(leaves)
+    if teacher is None:
+        teacher = y["MODEL"]["backbone"] in ("big_resnet", "big_resnet_deep_legacy")
+    taps = Taps() if teacher else None
+    ref = oracle_run(leaves, taps)
     fl = {}
     whole_floor = 0.0
     if floor:
@@ -477,6 +522,86 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
     C.rows.append((which + " grad WHOLE-NETWORK", whole, wt))
     C.rows.append((which + " grad WHOLE-NETWORK oracle-own-floor", whole_floor, float("inf")))
     print(f"{which + ' grad WHOLE-NETWORK':52s} l2={whole:.3e} tol={wt:.1e} (oracle's own movement under a 1e-5 weight perturbation: {whole_floor:.3e}) {'ok' if whole <= wt else 'FAIL'}")
+    tfl = {}
+    if teacher and taps.act and which == "G":
+        # The generators' blocks hold two to four cBN + ReLU stages each: at the fixtures' batch of 2 a 4 x 4 map gives a channel 32 samples, the
+        # batch-norm backward subtracts two means from the gradient, and a rounding-level disagreement flips ReLU units INSIDE the block. How far that
+        # moves a teacher-forced quantity is measured like the whole-network floor: the oracle once more, weights perturbed by a relative 1e-5,
+        # every block reading the UNPERTURBED run's input and upstream gradient. (The discriminators have no BN: their bound stays 1e-2 flat.)
+        gp3 = torch.Generator().manual_seed(6)
+        leaves3 = {k: (v * (1 + FLOOR_EPS * torch.randn(v.shape, generator=gp3))).requires_grad_(True) for k, v in P.items()}
+        rep = TapsReplace({bi: a.detach() for bi, a in taps.act.items()})
+        Bc3 = {k: v.clone() for k, v in B.items()}
+        img3 = O.model_fns(dict(ocfg, taps=rep))[0](fix["in/z0"], fix["in/fl0"], leaves3, Bc3, bn_mode="track")
+        order3 = sorted(rep.out)
+        torch.autograd.backward([rep.out[b] for b in order3] + [img3], [taps.act[b].grad for b in order3] + [gimg])
+        rl2 = lambda a, b, fk=0.0: float((a.double() - b.double()).norm() / max(float(b.double().norm()), fk, 1e-30))
+        for b in order3:
+            tfl[f"out {b}"] = rl2(rep.out[b].detach(), taps.act[b].detach())
+            tfl[f"dx {b}"] = rl2(rep.leaf[b].grad, taps.act[b].grad)
+        gmax3 = max(float(v.grad.abs().max()) for v in leaves.values())
+        for k in leaves:
+            tfl["grad " + k] = rl2(leaves3[k].grad, leaves[k].grad, (1.0 if k.endswith("sigma") else 1e-2) * gmax3 * (leaves[k].numel() ** 0.5))
+
+    def run_teacher(tag, factor):
+        """one teacher-forced HIP pass; every comparison bounded by max(base, factor x the measured floor of that tensor)"""
+        def ttol(key):
+            base = 2e-2 if "conv1x1_" in key else TEACHER_TOL      # attention backward: 8e-3 per operator (tools/diag_bf16.py)
+            return max(base, factor * tfl.get(key, 0.0))
+        net.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)   # u / v / BN state as the oracle saw them
+        for p in net.parameters():
+            p.grad = None
+        to_dev = lambda t: t.detach().permute(0, 2, 3, 1).contiguous().to(dev).to(torch.bfloat16)
+        tf = TeacherForcing({bi: to_dev(a) for bi, a in taps.act.items()})
+        net.__dict__["_sg_teacher"] = tf
+        try:
+            if which == "D":
+                final = D(fix["in/real0"].to(dev), fix["in/rl0"].to(dev))["adv_output"]
+                gfinal = gadv.to(dev)
+            else:
+                final = G(fix["in/z0"].to(dev), fix["in/fl0"].to(dev))
+                gfinal = gimg.to(dev)
+            order = sorted(b for b in tf.out if b in taps.act)
+            roots = [tf.out[b] for b in order] + [final]
+            grads = [to_dev(taps.act[b].grad) for b in order] + [gfinal.to(final.dtype) if final.dtype != gfinal.dtype else gfinal]
+            torch.autograd.backward(roots, grads)
+            torch.cuda.synchronize()
+        finally:
+            net.__dict__.pop("_sg_teacher", None)
+        back = lambda t: t.detach().float().permute(0, 3, 1, 2)
+        pre = f"{which} teacher-forced{tag}"
+        for b in order:
+            C.check(f"{pre} block {b} out", back(tf.out[b]), taps.act[b].detach(), ttol(f"out {b}"), l2=True)
+            if b in tf.leaf:
+                gref = taps.act[b].grad
+                C.check(f"{pre} dx into block {b + 1}", back(tf.leaf[b].grad), gref, ttol(f"dx {b}"), floor=1e-3 * float(gref.abs().max()), l2=True)
+        C.check(f"{pre} final", final, ref["D adv"] if which == "D" else ref["G img"], TEACHER_TOL, l2=True)
+        worst_tf = 0.0
+        for k, p in net.named_parameters():
+            e = C.check(f"{pre} grad " + k, p.grad, leaves[k].grad, ttol("grad " + k), floor=(1.0 if k.endswith("sigma") else 1e-2) * gmax, l2=True)
+            worst_tf = max(worst_tf, e)
+        print(f"{pre}: worst weight-gradient error {worst_tf:.3e}; worst measured floor {max(tfl.values()) if tfl else 0.0:.3e} (bound = max(1e-2, {factor} x floor) per tensor)")
+        C.rows.append((pre + " WORST weight gradient", worst_tf, float("inf")))
+
+    if teacher and taps.act:
+        # ---- teacher-forced pass: every block on the oracle's own input and upstream gradient ------------------------------------------------
+        from studiogan_amd import functional as SF
+        if which == "G" and full and SF._QUAD[0]:
+            # The upsample + 3x3 layers run through the phase-filter identity (csrc/conv_q.h): their bf16 filter image is the rounded SUM of the
+            # taps that share a source pixel -- one rounding per filter entry, like the oracle's, but not the same one. Inside a generator block
+            # that extra 2e-3 flips more ReLU units behind the cBN than the single-rounding floor model allows for (measured, session r4k:
+            # with SG_QUAD=0 every tensor is within 1.5 x floor; with the quad kernels conv2d1's weight gradient sits at 2.6 x). So: the 3x3
+            # kernels must meet the 1.5 x bound, the quad kernels 3 x -- and are pinned bit-tight against torch in tests/test_quad_gpu.py.
+            SF._QUAD[0] = False
+            try:
+                run_teacher(" (3x3 kernels)", FLOOR_FACTOR)
+            finally:
+                SF._QUAD[0] = True
+            run_teacher("", 2 * FLOOR_FACTOR)
+        else:
+            run_teacher("", FLOOR_FACTOR)
+        if tfl:
+            C.rows.append((which + " teacher-forced WORST oracle-own-floor", max(tfl.values()), float("inf")))
     if report is not None:
         report.extend(C.rows)
         report.extend((which + " floor " + k, v, float("inf")) for k, v in fl.items())

@@ -10,7 +10,8 @@ import json
 import re
 import sys
 
-CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
+CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_conv_rs96_kernel|sg_conv_q_kernel|sg_wgrad_q_kernel|k_quad_reduce_fold|"
+                  r"sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
 
 
 def collect(path, counter):
@@ -35,9 +36,9 @@ def main():
         n = max(fetch.get(k, [0, 0])[0], write.get(k, [0, 0])[0])
         rd = 2.0 * fetch.get(k, [0, 0.0])[1] * 1024.0
         wr = write.get(k, [0, 0.0])[1] * 1024.0
-        rows.append({"kernel": k[:100], "launches": n, "read_GB": round(rd / 1e9, 3), "write_GB": round(wr / 1e9, 3),
+        rows.append({"kernel": k[:160], "launches": n, "read_GB": round(rd / 1e9, 3), "write_GB": round(wr / 1e9, 3),
                      "bytes_per_launch": round((rd + wr) / max(n, 1))})
-        if "k_splitk_reduce" not in k:      # the reduce belongs to the weight-gradient launch that precedes it
+        if "k_splitk_reduce" not in k and "k_quad_reduce_fold" not in k:      # the reduce belongs to the weight-gradient launch that precedes it
             tot_n += n
         tot_b += rd + wr
     print(json.dumps({"kernel_family": "convolution engine (sg_conv_v4 / sg_conv_v3 / sg_conv_v2 / sg_conv_sk / sg_conv_rs / sg_wgrad_v3 / sg_wgrad_v2 / sg_wgrad_sk / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
