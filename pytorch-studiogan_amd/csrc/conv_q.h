@@ -33,6 +33,7 @@ struct ConvQParams {
   int nslice;             // C / 32
   int npx;                // patch pixels (multiple of 16) >= BJ + 2 Wl + 16
   int bj;                 // pixel tile: 256 or 128
+  int patchb;             // bytes of one patch buffer (npx * 64)
   int flags;              // SG_PIX_RELU
   unsigned xbytes, wbytes;
   int wgt_off, zero_off, bias_off;
@@ -51,8 +52,17 @@ struct ConvQParams {
 // main loop. These slices are bound by the staging traffic, not by their 4 NB MFMAs: what they read is the fine skip input, once -- what the
 // separate 1x1 launch read from HBM as well, without its output round trip (0.09-0.18 ms per block tail at batch 256,
 // profiles/r04_dfwd_timeline_e.txt).
-template <int NB, bool RELU, int TJW = 2, bool SKIP = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+//
+// NPMIN > 0: the DOUBLE-BUFFERED variant (two workgroups per CU instead of three). The single-buffered loop stops at every slice boundary to
+// reload the patch -- every four taps here, against nine in conv_v4.h. With two patch buffers the next slice's patch is requested at the first
+// tap of the current one and has the whole slice to land; the weights then run THREE taps ahead so that the vector-memory counter (which
+// retires in order) never has to drain the patch early: per slice the issue order is W3, P', W0', W1', W2' and the wait in front of the
+// barrier that ends tap t needs the weights of tap t + 1 only: vmcnt(n_p + 2 n_w) behind taps 0-2 (leaves P' and two weight tiles in flight),
+// vmcnt(2 n_w) behind tap 3 (P' and W0' have landed). NPMIN = the smallest number of patch pieces a wave issues (compile-time immediate;
+// waves with one piece more only wait a little earlier than they must).
+template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 : 3, NPMIN ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+  constexpr bool DB = NPMIN > 0;
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int P0 = j0 - p.Wl - 8;                                      // raster index of patch row 0
   const int ngroups = p.npx >> 4;
   const int pix0 = P0 + 16 * wave + sub;
-  auto patch_slice = [&](int view, int s) {
+  auto patch_slice = [&](int view, int s, int pbase = 0) {
     const int vadd = pool ? ((view >> 1) * 2 * p.Wl + (view & 1)) : 0;
     for (int g = wave; g < ngroups; g += NW) {
       const int pix = pix0 + 16 * (g - wave);
@@ -104,7 +114,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
       const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
       unsigned off = src * ldxb + (unsigned)(s * 64 + lc * 16);
       off = ((unsigned)pix < (unsigned)p.J) ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + pbase + g * 1024), 16, (int)off, 0, 0, 0);
     }
   };
   // ---- weight DMA: BI rows x 32 channels of (view, slice s, tap t) ------------------------------------------------------------------
@@ -162,9 +172,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   patch_slice(view, 0);
   weight_tile(0, view, 0, 0);
   weight_tile(1, view, 0, 1);
+  if (DB) weight_tile(2, view, 0, 2);
   __syncthreads();
   for (int vs = 0; vs < nvs; vs++) {
     const bool next_slice = vs + 1 < nvs;
+    const unsigned pb = DB ? (unsigned)((vs & 1) * p.patchb) : 0u;
     int nview = view, ns = s + 1;
     if (ns == nslice) { ns = 0; nview = view + 1; }
     // tap origin of this view on the low-resolution grid
@@ -176,8 +188,17 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     for (int t = 0; t < 4; t++) {
       // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
       const bool issue = (t + 2 < 4) || next_slice;
-      if (t + 2 < 4) weight_tile(t + 2, view, s, t + 2);
-      else if (next_slice) weight_tile(t - 2, nview, ns, t - 2);
+      if constexpr (DB) {
+        if (t == 0) {
+          weight_tile(3, view, s, 3);
+          if (next_slice) patch_slice(nview, ns, ((vs + 1) & 1) * p.patchb);
+        } else if (next_slice) {
+          weight_tile(t - 1, nview, ns, t - 1);
+        }
+      } else {
+        if (t + 2 < 4) weight_tile(t + 2, view, s, t + 2);
+        else if (next_slice) weight_tile(t - 2, nview, ns, t - 2);
+      }
       const char* ps = pbufs + t * PB;
       const int ti = t >> 1, tj = t & 1;                           // compile-time after unrolling
       unsigned qa[TJ];
@@ -187,7 +208,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
         asm volatile("" : "+v"(row));
         if (ti) row += p.Wl;
         if (tj) row += 1;
-        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
+        unsigned a = pb + (((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4));
         a = ((qval[b] >> (vbit0 + ti * 3 + tj)) & 1u) ? a : (unsigned)p.zero_off;
         qa[b] = a;
       }
@@ -211,7 +232,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
-      if (t == 3 && next_slice) {
+      if constexpr (DB) {
+        // counted waits (see the kernel comment): n_w = 2 for the waves that issue two weight pieces per tap, else 1
+        if (next_slice) {
+          if (t < 3) { if (two) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPMIN + 4) : "memory"); else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPMIN + 2) : "memory"); }
+          else { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        } else {
+          if (t == 0) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+          else if (t == 1) { if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+          else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __builtin_amdgcn_s_barrier();
+      } else if (t == 3 && next_slice) {
         // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
         // workgroup; the other two workgroups of the CU keep the matrix pipe busy)
         __syncthreads();
@@ -303,9 +335,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 // LDS need (bytes) of a configuration
-static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, int* wgt_off, int* zero_off, int* bias_off) {
+static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, bool db, int* wgt_off, int* zero_off, int* bias_off) {
   const int BI = 32 * NB;
-  const int woff = npx * 64;
+  const int woff = npx * 64 * (db ? 2 : 1);
   const int ops = woff + 4 * BI * 64;
   const int stage = BJ * (BI * 2 + 16);
   const int skp = skip ? 2 * BJ * 64 + 2 * BI * 64 : 0;      // two staging slots of the fused skip (patch + weights each)
@@ -316,26 +348,35 @@ static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, int* wgt_off
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU, int TJW, bool SKIP>
+template <int NB, bool RELU, int TJW, bool SKIP, int NPMIN>
 static inline int sg_launch_conv_qr(ConvQParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BI = 32 * NB, BJ = 128 * TJW;
-  const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, &p.wgt_off, &p.zero_off, &p.bias_off);
+  p.patchb = p.npx * 64;
+  const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, NPMIN > 0, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_q_kernel<NB, RELU, TJW, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_q_kernel<NB, RELU, TJW, SKIP, NPMIN>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ, nph = p.form == 0 ? 1 : 4;
-  hipLaunchKernelGGL((sg_conv_q_kernel<NB, RELU, TJW, SKIP>), dim3(tilesI * tilesJ * nph), dim3(256), lds, st, p, e, tilesI, tilesJ, nph);
+  hipLaunchKernelGGL((sg_conv_q_kernel<NB, RELU, TJW, SKIP, NPMIN>), dim3(tilesI * tilesJ * nph), dim3(256), lds, st, p, e, tilesI, tilesJ, nph);
   return 0;
 }
-template <int NB, bool SKIP>
-static inline int sg_launch_conv_qs(const ConvQParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  if (p.bj == 128) return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true, 1, SKIP>(p, e, st) : sg_launch_conv_qr<NB, false, 1, SKIP>(p, e, st);
-  return (p.flags & SG_PIX_RELU) ? sg_launch_conv_qr<NB, true, 2, SKIP>(p, e, st) : sg_launch_conv_qr<NB, false, 2, SKIP>(p, e, st);
+template <int NB, bool SKIP, bool RELU>
+static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
+  if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
+  if (db) {       // double-buffered patch: the smallest per-wave piece count is a compile-time immediate of the counted waits
+    const int npmin = (p.npx >> 4) >> 2;
+    if (npmin == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 4>(p, e, st);
+    if (npmin == 5) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 5>(p, e, st);
+    if (npmin == 6) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 6>(p, e, st);
+  }
+  return sg_launch_conv_qr<NB, RELU, 2, SKIP, 0>(p, e, st);
 }
 template <int NB>
-static inline int sg_launch_conv_q(const ConvQParams& p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  return p.x2 ? sg_launch_conv_qs<NB, true>(p, e, st) : sg_launch_conv_qs<NB, false>(p, e, st);
+static inline int sg_launch_conv_q(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
+  const bool relu = (p.flags & SG_PIX_RELU) != 0;
+  if (p.x2) return relu ? sg_launch_conv_qd<NB, true, true>(p, e, db, st) : sg_launch_conv_qd<NB, true, false>(p, e, db, st);
+  return relu ? sg_launch_conv_qd<NB, false, true>(p, e, db, st) : sg_launch_conv_qd<NB, false, false>(p, e, db, st);
 }

@@ -85,6 +85,9 @@ extern "C" int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int
 
 // All quad images of a network in ONE launch (the weight bank packs them right behind sg_sn_forward; one launch per image was 60 us x 135
 // launches per C3 step in profiles/r04_bench_biggan128_bs256_kerneltrace_e.txt). Block b finds its item by a scan of the (short) table.
+// A thread owns ONE output vector (row m, quad tap vt, 8 / 4 channels): it sums the one, two or four 3x3 taps that feed it and stores 16 bytes.
+// (The first version gave a thread all 16 outputs of its (m, channels): 9 loads, 16 stores, 108 VGPRs -- 1.8 TB/s; the 3x3 rows are re-read from
+// L2 here, the HBM traffic is the same.)
 template <typename T>
 __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* items, int n) {
   constexpr int V = ET<T>::VEC;
@@ -92,7 +95,8 @@ __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* ite
   int it = 0;
   long long blk = blockIdx.x;
   for (; it < n; it++) {
-    const long long nb = ((long long)items[it].M * (items[it].Cs / V) + 255) / 256;
+    const long long per = (long long)items[it].M * (items[it].Cs / V) * (items[it].mode == 4 ? 1 : 16);
+    const long long nb = (per + 255) / 256;
     if (blk < base + nb) break;
     base += nb;
   }
@@ -100,8 +104,8 @@ __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* ite
   const sg_quad_item q = items[it];
   const int cv = q.Cs / V;
   const long long i = (blk - base) * 256 + threadIdx.x;
-  if (i >= (long long)q.M * cv) return;
   if (q.mode == 4) {           // the 1x1 skip filter of a pooled block tail, x 1/4 (exact in bf16): [M][Cs] -> [M][Cs]
+    if (i >= (long long)q.M * cv) return;
     float o[V];
     unpack16<T>(*(const u32x4*)((const T*)q.src + i * V), o);
 #pragma unroll
@@ -109,35 +113,32 @@ __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* ite
     *(u32x4*)((T*)q.dst + i * V) = pack16<T>(o);
     return;
   }
+  if (i >= (long long)q.M * cv * 16) return;
   const bool pool_like = q.mode == 0 || q.mode == 3;
   const float scale = (q.mode == 0 || q.mode == 2) ? 0.25f : 1.f;
-  const long long m = i / cv;
-  const int c = (int)(i - m * cv) * V;
+  const int c = (int)(i % cv) * V;
+  const long long mv = i / cv;
+  const int vt = (int)(mv & 15);
+  const long long m = mv >> 4;
+  const int view = vt >> 2, t = vt & 3;
+  const int pr = quad_pat(pool_like, view >> 1, t >> 1), pc = quad_pat(pool_like, view & 1, t & 1);
   const T* s0 = (const T*)q.src + m * 9 * q.Cs + c;
-  float w[9][V];
+  float o[V];
 #pragma unroll
-  for (int k = 0; k < 9; k++) unpack16<T>(*(const u32x4*)(s0 + (long long)k * q.Cs), w[k]);
-  T* d0 = (T*)q.dst + m * 16 * q.Cs + c;
+  for (int e = 0; e < V; e++) o[e] = 0.f;
 #pragma unroll
-  for (int view = 0; view < 4; view++)
+  for (int r = 0; r < 3; r++)
 #pragma unroll
-    for (int t = 0; t < 4; t++) {
-      const int pr = quad_pat(pool_like, view >> 1, t >> 1), pc = quad_pat(pool_like, view & 1, t & 1);
-      float o[V];
+    for (int s = 0; s < 3; s++)
+      if (((pr >> r) & 1) && ((pc >> s) & 1)) {
+        float w[V];
+        unpack16<T>(*(const u32x4*)(s0 + (long long)(r * 3 + s) * q.Cs), w);
 #pragma unroll
-      for (int e = 0; e < V; e++) o[e] = 0.f;
+        for (int e = 0; e < V; e++) o[e] += w[e];
+      }
 #pragma unroll
-      for (int r = 0; r < 3; r++)
-#pragma unroll
-        for (int s = 0; s < 3; s++)
-          if (((pr >> r) & 1) && ((pc >> s) & 1)) {
-#pragma unroll
-            for (int e = 0; e < V; e++) o[e] += w[r * 3 + s][e];
-          }
-#pragma unroll
-      for (int e = 0; e < V; e++) o[e] *= scale;
-      *(u32x4*)(d0 + (long long)(view * 4 + t) * q.Cs) = pack16<T>(o);
-    }
+  for (int e = 0; e < V; e++) o[e] *= scale;
+  *(u32x4*)((T*)q.dst + (m * 16 + vt) * q.Cs + c) = pack16<T>(o);
 }
 extern "C" int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, const sg_quad_item* items_host, int n, sg_stream_t stream) {
   SG_CHECK(items_dev && items_host && n > 0 && n <= 64, "sg_quad_pack_batch: bad arguments");
@@ -146,7 +147,7 @@ extern "C" int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, cons
   for (int i = 0; i < n; i++) {
     const sg_quad_item& q = items_host[i];
     SG_CHECK(q.src && q.dst && q.M > 0 && q.Cs > 0 && q.Cs % V == 0 && q.mode >= 0 && q.mode <= 4 && aligned16(q.src) && aligned16(q.dst), "sg_quad_pack_batch: bad item");
-    blocks += ((long long)q.M * (q.Cs / V) + 255) / 256;
+    blocks += ((long long)q.M * (q.Cs / V) * (q.mode == 4 ? 1 : 16) + 255) / 256;
   }
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_quad_pack_batch<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, items_dev, n);
@@ -217,7 +218,14 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   const double c2 = d->x2 ? (double)d->C2 : 0.0;      // the fused skip stands for a 1x1 convolution over the fine grid
   const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * (16.0 * (double)d->C + 4.0 * c2));
-  const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, st) : sg_launch_conv_q<2>(p, e, st);
+  // SG_CONV_Q_DB=1: the double-buffered-patch variant (conv_q.h NPMIN; two workgroups per CU) -- A/B switch
+  // double-buffered-patch variant (conv_q.h NPMIN; two workgroups per CU). Measured (profiles/r04_quad_bench_l_db.txt): slower than the three
+  // single-buffered workgroups everywhere (sum of the C3 layers 4.79 -> 5.07 ms forward, 4.97 -> 5.43 ms data gradient) EXCEPT on the 4 x 4
+  // low-resolution grids of the UP form (0.349 -> 0.307 and 0.367 -> 0.318 ms), whose patches are 16 images of 16 pixels and whose slices are
+  // pure weight streaming: default on there only. SG_CONV_Q_DB=1 / 0 forces it on / off (read per call: the tests switch it).
+  const char* ev_db = getenv("SG_CONV_Q_DB");
+  const int db_mode = ev_db ? (ev_db[0] == '1' ? 1 : 0) : ((d->Wl == 4 && d->form == SG_Q_UP) ? 1 : 0);
+  const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, db_mode, st) : sg_launch_conv_q<2>(p, e, db_mode, st);
   {
     // algorithmic HBM bytes: input (+ skip input), quad filter(s), result (+ mask / residual), bf16
     const double J = (double)p.J, jin = d->form == SG_Q_POOL ? 4.0 * J : J, jout = d->form == SG_Q_POOL ? J : 4.0 * J;

@@ -47,11 +47,12 @@ FWD_CASES = [
 ]
 
 
-@pytest.mark.parametrize("bj", ["256", "128"])
+@pytest.mark.parametrize("bj", ["256", "128", "256db"])
 @pytest.mark.parametrize("case", FWD_CASES)
 def test_conv_q_matches_torch(sg, case, bj, monkeypatch):
     from studiogan_amd import functional as F, _lib as L
-    monkeypatch.setenv("SG_CONV_Q_BJ", bj)          # both pixel tiles (the launcher picks 128 when 256 leaves the chip under-filled)
+    monkeypatch.setenv("SG_CONV_Q_BJ", bj[:3])      # both pixel tiles (the launcher picks 128 when 256 leaves the chip under-filled)
+    monkeypatch.setenv("SG_CONV_Q_DB", "1" if bj.endswith("db") else "0")      # and the double-buffered-patch variant of the 256 tile
     form, N, Hl, Wl, C, Cout, relu_in, with_bias, with_mask, with_res, relu_out = case
     dt = torch.bfloat16
     Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
@@ -161,6 +162,8 @@ SKIP_CASES = [
     (2, 8, 8, 96, 192, 96, True, "128"),
     (3, 4, 4, 64, 64, 64, False, "256"),
     (1, 16, 32, 192, 192, 96, True, "256"),
+    (1, 16, 32, 192, 192, 96, True, "256db"),
+    (2, 8, 64, 96, 96, 32, False, "256db"),
 ]
 
 
@@ -170,7 +173,8 @@ def test_conv_q_fused_skip_matches_torch(sg, case, monkeypatch):
     src/models/big_resnet.py:221-242)"""
     from studiogan_amd import functional as F, _lib as L
     N, Hl, Wl, C, Cout, C2, relu, bj = case
-    monkeypatch.setenv("SG_CONV_Q_BJ", bj)
+    monkeypatch.setenv("SG_CONV_Q_BJ", bj[:3])
+    monkeypatch.setenv("SG_CONV_Q_DB", "1" if bj.endswith("db") else "0")
     dt = torch.bfloat16
     h = rnd((N, 2 * Hl, 2 * Wl, C), dt, 341)
     x = rnd((N, 2 * Hl, 2 * Wl, C2), dt, 342)
@@ -190,3 +194,28 @@ def test_conv_q_fused_skip_matches_torch(sg, case, monkeypatch):
     assert y is not None
     torch.cuda.synchronize()
     check(f"conv_q fused skip {case}", y.float().cpu(), ref, 6e-3)
+
+
+def test_quad_pack_batch_matches_reference(sg):
+    """every image of a network in one launch (what the weight bank runs behind sg_sn_forward): modes 0-3 and the scaled skip filter (mode 4)"""
+    from studiogan_amd import _lib as L
+    dt = torch.bfloat16
+    specs = [(0, 96, 64), (1, 64, 96), (2, 32, 192), (3, 96, 32), (4, 192, 96), (0, 64, 32)]
+    srcs, dsts, refs = [], [], []
+    arr = (L.QuadItem * len(specs))()
+    for j, (mode, M, Cs) in enumerate(specs):
+        if mode == 4:
+            w = rnd((M, Cs), dt, 400 + j, 0.3)
+            refs.append(w.double() * 0.25)
+            dst = torch.empty(M, Cs, dtype=dt, device="cuda:0")
+        else:
+            w = rnd((M, 3, 3, Cs), dt, 400 + j, 0.1)
+            refs.append(Q.quad_pack_ref(w.double(), mode).reshape(M, 16, Cs))
+            dst = torch.empty(M, 16, Cs, dtype=dt, device="cuda:0")
+        srcs.append(_dev(w)); dsts.append(dst)
+        arr[j].src, arr[j].dst, arr[j].M, arr[j].Cs, arr[j].mode = srcs[-1].data_ptr(), dst.data_ptr(), M, Cs, mode
+    tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to("cuda:0")
+    L.call("sg_quad_pack_batch", L.BF16, tab.data_ptr(), arr, len(specs), L.stream())
+    torch.cuda.synchronize()
+    for j, (mode, M, Cs) in enumerate(specs):
+        check(f"quad pack batch item {j} mode {mode}", dsts[j].float().cpu(), refs[j], 4e-3)
