@@ -368,6 +368,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (C2 fp32, C5 WGAN-GP, C4 per GPU)")
     ap.add_argument("--native-comm", action="store_true", help="gradient / sync-BN exchanges through libsgamd.so's own RCCL communicator "
                     "(sg_allreduce_flat on HIP streams) instead of torch.distributed's nccl backend (same RCCL underneath); also SG_NATIVE_COMM=1")
+    ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the GLOBAL batch, every rank takes batch / world of it (what the reference does: "
+                    "src/loader.py:162 divides the configured batch over the ranks); default is weak scaling (--batch per GPU)")
     ap.add_argument("--strict", action="store_true", help="exit non-zero when an extra workload / leg fails (the line is still printed)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -409,6 +411,10 @@ def main():
         group = dist.group.WORLD
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: refusing to print a line for a different job size")
+    if args.strong:
+        if args.batch % world:
+            raise SystemExit(f"bench.py --strong: global batch {args.batch} is not a multiple of the {world} ranks")
+        args.batch //= world            # from here on args.batch is the per-rank batch, as in the weak-scaling run
 
     import studiogan_amd
     from studiogan_amd import _lib as L
@@ -451,12 +457,22 @@ def main():
     if rank == 0:
         sys.stderr.write(f"[bench] warmup {args.warmup} step(s): {time.perf_counter() - tw:.2f}s\n")
     L.call("sg_prof_enable", 1)
+    if world > 1:
+        from studiogan_amd import comm as sg_comm_t
+        sg_comm_t.timing(True)          # event pairs on the compute stream around every wait on a collective (comm.exposed)
     t0 = time.perf_counter()
     last = None
     for i in range(args.steps):
         last = w.step(args.warmup + i, baskets(pool, args.warmup + i, n_d))
     barrier()
     elapsed = time.perf_counter() - t0
+    exposed_comm_ms = None
+    if world > 1:
+        exposed_comm_ms = sg_comm_t.timing_ms()
+        sg_comm_t.timing(False)
+        tx = torch.tensor([exposed_comm_ms], dtype=torch.float64, device=device)
+        dist.all_reduce(tx, op=dist.ReduceOp.MAX)
+        exposed_comm_ms = float(tx.item())
     # the step must have produced numbers: finite losses of the last timed step (read AFTER the timed region: a host sync)
     d_last, g_last = (float(last[0]), float(last[1])) if last is not None else (float("nan"), float("nan"))
     import math
@@ -596,7 +612,7 @@ def main():
     out = {
         "metric": "images/sec (G+D step) BigGAN ImageNet-128 bs256",
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "strong" if args.strong else "weak", "vs_baseline": None,
         "dtype": "bf16" if mixed else "f32", "data": "synthetic",
         "data_note": f"{len(pool)} distinct real baskets per rank, cycled: uint8-grid samples of a frozen copy of the initial generator "
                      "(keeps the hinge active: d_loss > 1e-2 is asserted on the last timed step); z / labels drawn on the device every update",
@@ -605,7 +621,10 @@ def main():
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else ""),
                    "exchange": None if world == 1 else ("libsgamd sg_allreduce_flat (native RCCL communicator)" if rccl_ranks else
                                                         ("gloo (one-device plumbing run)" if one_dev else "torch.distributed nccl backend (= RCCL)")),
-                   "rccl_ranks": rccl_ranks},
+                   "rccl_ranks": rccl_ranks,
+                   # time the compute stream spent waiting for collectives (sync-BN all-reduces run on it; waits on the gradient reductions in
+                   # FusedAdam.step), max over ranks: hipEvent pairs around every such point (studiogan_amd.comm.exposed)
+                   "exposed_comm_ms_per_step": None if exposed_comm_ms is None else round(exposed_comm_ms / args.steps, 3)},
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                      "kernel": "convolution engine (family; per_kernel has the members, dominant_kernel the largest): sg_conv_q_kernel / sg_wgrad_q_kernel (3x3 next to a 2x resampling as 4x4-stride-2 / four 2x2 phase convolutions) / sg_conv_v4_kernel (3x3 halo, <= 384 channels, G tails with the 1x1 skip fused) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers) / sg_conv_v2_kernel / sg_wgrad_v3_kernel / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel",

@@ -15,6 +15,42 @@ import torch.distributed as dist
 from . import _lib as L
 
 _REGISTRY = {}     # id(process group) or "world" -> NativeComm
+_TIMING = None     # comm.timing(True): [(start, end)] hipEvent pairs on the compute stream around every collective it has to wait for
+
+
+def timing(on):
+    """Measure the EXPOSED communication of the data-parallel step (bench.py `exposed_comm_ms_per_step`): with it on, every point where the
+    compute stream waits for a collective -- the sync-BN all-reduces, which run on it, and the waits on the gradient reductions in
+    FusedAdam.step -- is bracketed by a pair of events recorded on that stream; what elapses between them is time the stream could not compute."""
+    global _TIMING
+    _TIMING = [] if on else None
+
+
+class exposed:
+    """with comm.exposed(): <issue / wait for a collective on the current stream>"""
+
+    def __enter__(self):
+        if _TIMING is not None:
+            self.a = torch.cuda.Event(enable_timing=True)
+            self.a.record(torch.cuda.current_stream())
+        return self
+
+    def __exit__(self, *exc):
+        if _TIMING is not None:
+            b = torch.cuda.Event(enable_timing=True)
+            b.record(torch.cuda.current_stream())
+            _TIMING.append((self.a, b))
+        return False
+
+
+def timing_ms():
+    """total exposed time since the last call (synchronises the device)"""
+    if _TIMING is None:
+        return None
+    torch.cuda.synchronize()
+    ms = sum(a.elapsed_time(b) for a, b in _TIMING)
+    _TIMING.clear()
+    return ms
 
 
 def _key(group):

@@ -65,8 +65,10 @@ static V3Plan wgrad_v3_plan(const sg_conv_wgrad_desc* d) {
   const bool force = mode && mode[0] == 'f';                            // test hook: no lower bound on the problem size
   if (d->dtype != SG_DTYPE_BF16 || d->stride != 1 || d->no_tr || d->R != 3 || d->S != 3 || d->pad_h != 1 || d->pad_w != 1) return s;
   if ((d->x_flags | d->g_flags) & SG_PIX_TRANSPOSED) return s;
-  if (d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo % 64) return s;
-  if (d->Wo < 64 && d->Ho % (64 / d->Wo)) return s;                     // a chunk = 64 / W whole image rows
+  if (d->Wo != 4 && d->Wo != 8 && d->Wo != 16 && d->Wo != 32 && d->Wo % 64) return s;
+  if (d->Wo == 4) {     // (round 4) 4 x 4 images: a chunk is four whole images, plain operands only
+    if (d->Ho != 4 || d->N % 4 || ((d->x_flags | d->g_flags) & SG_PIX_UPSAMPLE)) return s;
+  } else if (d->Wo < 64 && d->Ho % (64 / d->Wo)) return s;              // a chunk = 64 / W whole image rows
   if (d->C % 32 || d->ldx % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return s;
   if (d->Cout % 96 == 0) s.NB = 3; else if (d->Cout % 64 == 0) s.NB = 2; else return s;
   const long long K = (long long)d->N * d->Ho * d->Wo;

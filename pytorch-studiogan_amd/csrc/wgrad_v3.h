@@ -47,12 +47,15 @@ template <int NB, int WC, int KS>
 __device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, uint32_t relu_bound, bool extra,
                                          float* csum, bool do_csum) {
   constexpr int PW = WC + 2, GPITCH = NB * 64;
-  constexpr int KX = ((KS * 16) / WC) * PW * 64 + ((KS * 16) % WC) * 64;       // patch byte offset of pixels KS * 16 .. of the chunk raster
+  // patch byte offset of pixels KS * 16 .. of the chunk raster. WC == 4 (round 4): a chunk is FOUR whole 4 x 4 images, each with its own 6 x 6
+  // halo patch; a 16-pixel k-step is one image, and the second half of a fragment (+ 4 pixels) is the next image row
+  constexpr int KX = WC == 4 ? KS * 36 * 64 : ((KS * 16) / WC) * PW * 64 + ((KS * 16) % WC) * 64;
+  constexpr int A2 = WC == 4 ? PW * 64 : 256;
   constexpr int KG = KS * 16 * GPITCH;
   u32x2 al[3], ah[3], bl[NB], bh[NB], xl, xh;
-  w3_tr_read<KX>(a0, al[0]); w3_tr_read<KX + 256>(a0, ah[0]);
-  w3_tr_read<KX>(a1, al[1]); w3_tr_read<KX + 256>(a1, ah[1]);
-  w3_tr_read<KX>(a2, al[2]); w3_tr_read<KX + 256>(a2, ah[2]);
+  w3_tr_read<KX>(a0, al[0]); w3_tr_read<KX + A2>(a0, ah[0]);
+  w3_tr_read<KX>(a1, al[1]); w3_tr_read<KX + A2>(a1, ah[1]);
+  w3_tr_read<KX>(a2, al[2]); w3_tr_read<KX + A2>(a2, ah[2]);
   w3_tr_read<KG>(b0, bl[0]); w3_tr_read<KG + 4 * GPITCH>(b0, bh[0]);
   w3_tr_read<KG + 64>(b0, bl[1]); w3_tr_read<KG + 64 + 4 * GPITCH>(b0, bh[1]);
   if constexpr (NB == 3) { w3_tr_read<KG + 128>(b0, bl[2]); w3_tr_read<KG + 128 + 4 * GPITCH>(b0, bh[2]); }
@@ -100,9 +103,10 @@ __device__ __forceinline__ void w3_kstep(f32x16* acc, unsigned a0, unsigned a1, 
 // NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in pixels: 64 = one row segment, 32 / 16 / 8 = 2 / 4 / 8 whole rows of a 32 / 16 / 8-wide image
 template <int NB, int WC>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_wgrad_v3_kernel(WgradV3Params p) {
-  constexpr int RC = 64 / WC;                       // image rows per chunk
-  constexpr int PW = WC + 2, PR = RC + 2;           // patch extent in pixels
-  constexpr int XBYTES = PR * PW * 64;              // patch: 64 B (32 channels) per pixel
+  constexpr int NIMG = WC == 4 ? 4 : 1;             // images per chunk (WC == 4: four whole 4 x 4 images)
+  constexpr int RC = 64 / WC / NIMG;                // image rows per chunk (per image part)
+  constexpr int PW = WC + 2, PR = RC + 2;           // patch extent in pixels (per image part)
+  constexpr int XBYTES = NIMG * PR * PW * 64;       // patch: 64 B (32 channels) per pixel
   constexpr int NPX = (XBYTES + 1023) / 1024;       // LDS-DMA pieces of the patch
   constexpr int GPITCH = NB * 64;
   constexpr int NPG = 64 * GPITCH / 1024;           // pieces of the dy tile (4 NB)
@@ -122,33 +126,34 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int tl = bid - split * tiles;
   const int cis = tl % p.nci, cot = tl / p.nci;
   const int ci0 = cis * 32, co0 = cot * (32 * NB);
-  const int cpr = p.W / WC;                         // chunks per image-row group
-  const int cpi = (p.H / RC) * cpr;                 // chunks per image
+  const int cpr = WC == 4 ? 1 : p.W / WC;           // chunks per image-row group
+  const int cpi = WC == 4 ? 1 : (p.H / RC) * cpr;   // chunks per image (WC == 4: a chunk is four images)
 
   auto issue = [&](int c, int buf) {
-    const int n = c / cpi;
-    const int rem = c - n * cpi;
-    const int rg = rem / cpr, cx = rem - rg * cpr;
-    const int h0 = rg * RC, w0 = cx * WC;
+    int n, h0, w0;
+    if (WC == 4) { n = 4 * c; h0 = 0; w0 = 0; }
+    else { n = c / cpi; const int rem = c - n * cpi; const int rg = rem / cpr, cx = rem - rg * cpr; h0 = rg * RC; w0 = cx * WC; }
     char* base = smem + buf * BUF;
     for (int j = wave; j < NPX; j += 4) {
       const int o = j * 1024 + lane * 16;
-      const int pp = o >> 6, cb = o & 63;
+      const int pp0 = o >> 6, cb = o & 63;
+      const int kimg = pp0 / (PR * PW), pp = pp0 - kimg * (PR * PW);
       const int pr = pp / PW, pc = pp - pr * PW;
       int hh = h0 + pr - 1, ww = w0 + pc - 1;
-      const bool ok = (pr < PR) & ((unsigned)hh < (unsigned)p.H) & ((unsigned)ww < (unsigned)p.W);
+      const bool ok = (kimg < NIMG) & ((unsigned)hh < (unsigned)p.H) & ((unsigned)ww < (unsigned)p.W);
       if (p.x_up) { hh >>= 1; ww >>= 1; }
-      unsigned off = (((unsigned)(n * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + (unsigned)ci0) * 2u + (unsigned)cb;
+      unsigned off = (((unsigned)((n + kimg) * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + (unsigned)ci0) * 2u + (unsigned)cb;
       off = ok ? off : 0x80000000u;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(base + j * 1024), 16, (int)off, 0, 0, 0);
     }
     for (int j = wave; j < NPG; j += 4) {
       const int o = j * 1024 + lane * 16;
       const int px = o / GPITCH, cb = o - px * GPITCH;
-      const int cr = px / WC, cc = px - cr * WC;
+      int kimg = 0, cr, cc;
+      if (WC == 4) { kimg = px >> 4; cr = (px >> 2) & 3; cc = px & 3; } else { cr = px / WC; cc = px - cr * WC; }
       int hh = h0 + cr, ww = w0 + cc;
       if (p.g_up) { hh >>= 1; ww >>= 1; }
-      const unsigned off = (((unsigned)(n * p.gHs + hh) * (unsigned)p.gWs + (unsigned)ww) * (unsigned)p.ldg + (unsigned)co0) * 2u + (unsigned)cb;
+      const unsigned off = (((unsigned)((n + kimg) * p.gHs + hh) * (unsigned)p.gWs + (unsigned)ww) * (unsigned)p.ldg + (unsigned)co0) * 2u + (unsigned)cb;
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + GOFF + j * 1024), 16, (int)off, 0, 0, 0);
     }
   };
@@ -223,7 +228,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 
 template <int NB, int WC>
 static inline int sg_launch_wgrad_v3_t(const WgradV3Params& p, hipStream_t st) {
-  constexpr int RC = 64 / WC, XB = (RC + 2) * (WC + 2) * 64;
+  constexpr int NIMG = WC == 4 ? 4 : 1, RC = 64 / WC / NIMG, XB = NIMG * (RC + 2) * (WC + 2) * 64;
   constexpr int LDS = 2 * (((XB + 1023) / 1024) * 1024 + 64 * NB * 64);
   static bool attr_done = false;
   if (!attr_done) {
@@ -237,10 +242,12 @@ static inline int sg_launch_wgrad_v3(const WgradV3Params& p, int NB, hipStream_t
   const int wc = p.W >= 64 ? 64 : p.W;
   if (NB == 3) {
     switch (wc) { case 64: return sg_launch_wgrad_v3_t<3, 64>(p, st); case 32: return sg_launch_wgrad_v3_t<3, 32>(p, st);
-                  case 16: return sg_launch_wgrad_v3_t<3, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<3, 8>(p, st); }
+                  case 16: return sg_launch_wgrad_v3_t<3, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<3, 8>(p, st);
+                  case 4: return sg_launch_wgrad_v3_t<3, 4>(p, st); }
   } else {
     switch (wc) { case 64: return sg_launch_wgrad_v3_t<2, 64>(p, st); case 32: return sg_launch_wgrad_v3_t<2, 32>(p, st);
-                  case 16: return sg_launch_wgrad_v3_t<2, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<2, 8>(p, st); }
+                  case 16: return sg_launch_wgrad_v3_t<2, 16>(p, st); case 8: return sg_launch_wgrad_v3_t<2, 8>(p, st);
+                  case 4: return sg_launch_wgrad_v3_t<2, 4>(p, st); }
   }
   return -1;
 }

@@ -28,7 +28,8 @@ def pipelined_allreduce(flat, ranges, group=None):
     ranges still on the wire."""
     works = [(lo, hi, dist.all_reduce(flat[lo:hi], group=group, async_op=True)) for lo, hi in ranges]
     for lo, hi, w in works:
-        w.wait()
+        with _comm.exposed():
+            w.wait()
         yield lo, hi
 
 
@@ -87,6 +88,13 @@ class ExchangePlan:
         self.reset()
 
     def reset(self):
+        # an all-reduce still in flight (a backward that sent ranges but whose step() never ran: exception, skipped step, custom loop) must
+        # not race with the zeroing / next accumulation of the gradients it reads
+        for _, _, handle in getattr(self, "inflight", ()):
+            if isinstance(handle, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(handle)
+            else:
+                handle.wait()
         self.armed = False
         self.expected, self.seen = {}, {}
         self.done_lo = self.arena.numel
@@ -167,9 +175,13 @@ class FusedAdam(torch.optim.Optimizer):
 
     def arm_exchange(self, group):
         """Call right before the backward of the LAST accumulation micro-step of an update (Worker does): from now on a block boundary the
-        backward comes back to may send its finished gradients. SG_EARLY_EXCHANGE=0 disables it."""
+        backward comes back to may send its finished gradients.
+        OPT-IN (SG_EARLY_EXCHANGE=1): the path has only ever run with two gloo ranks on one device. On the native path it puts gradient
+        all-reduces on a second RCCL communicator while sync-BN all-reduces run on the first -- two communicators in flight with no cross-rank
+        ordering is a documented hang hazard -- so until a multi-GPU run has shown it green the default is the exchange inside step()
+        (chunked all-reduce overlapped with the optimizer launches), which has no collective in flight next to another one."""
         selftest = os.environ.get("SG_EXCHANGE_SELFTEST") == "1"
-        if self._module is None or (group is None and not selftest) or os.environ.get("SG_EARLY_EXCHANGE", "1") == "0":
+        if self._module is None or (group is None and not selftest) or (os.environ.get("SG_EARLY_EXCHANGE", "0") != "1" and not selftest):
             return False
         if not selftest and (not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2):
             return False
@@ -301,17 +313,20 @@ class FusedAdam(torch.optim.Optimizer):
             early, rest = self._plan.take()
             main = torch.cuda.current_stream()
             for lo, hi, handle in early:
-                if isinstance(handle, torch.cuda.Event):
-                    main.wait_event(handle)
-                else:
-                    handle.wait()
+                with _comm.exposed():
+                    if isinstance(handle, torch.cuda.Event):
+                        main.wait_event(handle)
+                    else:
+                        handle.wait()
                 L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
                        self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)
                 self.exchange_stats["early_ranges"] += 1
                 self.exchange_stats["early_elems"] += hi - lo
             n = rest
-            self._plan.reset()
+        if self._plan is not None and (self._plan.armed or self._plan.expected or self._plan.seen):
+            self._plan.inflight = []         # (waited for above)
+            self._plan.reset()               # a plan that sent nothing must not stay armed into the other network's update either
         if world > 1:
             self.exchange_stats["late_elems"] += n
         if n == 0:
@@ -331,7 +346,8 @@ class FusedAdam(torch.optim.Optimizer):
                 ev.record(nc.stream)
                 done.append(ev)
             for (lo, hi), ev in zip(ranges, done):
-                main.wait_event(ev)
+                with _comm.exposed():
+                    main.wait_event(ev)
                 L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo, a.grad.data_ptr() + 4 * lo, self._m.data_ptr() + 4 * lo,
                        self._v.data_ptr() + 4 * lo, (ema_ptr + 4 * lo) if ema_ptr else None, hi - lo, g["lr"], g["betas"][0], g["betas"][1],
                        g["eps"], g["weight_decay"], self._t, decay, 1.0 / world, st)

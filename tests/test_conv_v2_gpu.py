@@ -410,6 +410,8 @@ WV3_CASES = [
     (4, 64, 96, 16, True, False, False),        # W = 16: chunk = four image rows
     (4, 96, 64, 8, False, False, False),        # W = 8: chunk = a whole image, a k-step = two rows
     (4, 64, 64, 8, True, True, True),           # W = 16 after the upsample, pooled dy at 8 x 8
+    (8, 96, 96, 4, True, False, False),         # W = 4 (round 4): chunk = four whole 4 x 4 images, each with its own 6 x 6 halo patch
+    (4, 64, 192, 4, False, False, False),       # W = 4, one chunk, two cout tiles
 ]
 
 
