@@ -84,7 +84,11 @@ typedef struct {
   sg_conv_fwd_desc main;
   const void* x2; const void* w2; const float* bias2;
   int C2, ldx2, x2_up;
+  float* stats;   /* optional: [sg_conv2d_fwd_skip_stat_rows()][Cout][2] floats, per 256-pixel tile the sum and the sum of squares of the (bf16) result
+                     per channel -- the statistics of the batch norm behind this convolution, taken in the epilogue (no extra pass over the
+                     activation); reduce with sg_bn_stats_from_tiles. Ignored with SG_EPI_POOL. */
 } sg_conv_skip_desc;
+int sg_conv2d_fwd_skip_stat_rows(const sg_conv_skip_desc* d);
 int sg_conv2d_fwd_skip(const sg_conv_skip_desc* d, sg_stream_t stream);
 int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d);
 /* Number of sg_conv2d_fwd problems this process has run on the row-streaming kernel (csrc/conv_rs.h: 3x3, <= 32 output channels, 128-pixel-wide
@@ -117,7 +121,9 @@ typedef struct {
    * x2: [N,2Hl,2Wl,ldx2] with C2 % 32 == 0 channels; w2q: [Cout][C2] = the skip filter x 1/4 (sg_quad_pack_batch mode 4). NULL = none. */
   const void* x2; const void* w2q; const float* bias2;
   int C2, ldx2;
+  float* stats;   /* optional: per-tile batch-norm statistics of the result, [sg_conv2d_q_stat_rows()][Cout][2] floats (see sg_conv_skip_desc) */
 } sg_convq_desc;
+int sg_conv2d_q_stat_rows(const sg_convq_desc* d);
 int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream);
 int sg_conv2d_q_ok(const sg_convq_desc* d);            /* 1 when sg_conv2d_q takes the problem */
 int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int M, int Cs, sg_stream_t stream);
@@ -216,6 +222,8 @@ int sg_colsum(int dtype, const void* x, int ldx, const void* mask, int ldm, long
 int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_stream_t s);
 /* mean, invstd from (all-reduced) partial sums; updates running stats when running_mean != NULL
  * (unbiased variance, momentum) -- torch.nn.functional.batch_norm training semantics */
+/* partial[2 c + {0, 1}] (fp64, caller-zeroed) += the per-tile sums a convolution epilogue wrote (sg_conv_skip_desc.stats / sg_convq_desc.stats) */
+int sg_bn_stats_from_tiles(const float* stats, int nrows, int C, double* partial, sg_stream_t s);
 int sg_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd,
                    float* running_mean, float* running_var, sg_stream_t s);
 /* ---- data-parallel exchanges over RCCL (one process per GPU; replaces DistributedDataParallel's bucketed gradient all-reduce and

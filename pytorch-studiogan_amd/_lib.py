@@ -30,7 +30,7 @@ class ConvFwdDesc(C.Structure):
 
 
 class ConvSkipDesc(C.Structure):
-    _fields_ = [("main", ConvFwdDesc), ("x2", _vp), ("w2", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i), ("x2_up", _i)]
+    _fields_ = [("main", ConvFwdDesc), ("x2", _vp), ("w2", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i), ("x2_up", _i), ("stats", _vp)]
 
 
 class ConvWgradDesc(C.Structure):
@@ -44,7 +44,7 @@ class ConvQDesc(C.Structure):
     _fields_ = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("Cout", _i),
                 ("pix_flags", _i), ("epi_flags", _i), ("alpha", _f), ("beta", _f), ("x", _vp), ("wq", _vp), ("bias", _vp), ("res", _vp),
                 ("mask", _vp), ("out", _vp), ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i),
-                ("x2", _vp), ("w2q", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i)]
+                ("x2", _vp), ("w2q", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i), ("stats", _vp)]
 
 
 class ConvQWgradDesc(C.Structure):
@@ -100,6 +100,9 @@ _PROTOS = {
     "sg_conv_rs_launches": [],
     "sg_conv2d_q": [C.POINTER(ConvQDesc), _vp],
     "sg_conv2d_q_ok": [C.POINTER(ConvQDesc)],
+    "sg_conv2d_q_stat_rows": [C.POINTER(ConvQDesc)],
+    "sg_conv2d_fwd_skip_stat_rows": [C.POINTER(ConvSkipDesc)],
+    "sg_bn_stats_from_tiles": [_vp, _i, _i, _vp, _vp],
     "sg_quad_pack": [_i, _i, _vp, _vp, _i, _i, _vp],
     "sg_quad_pack_batch": [_i, _vp, C.POINTER(QuadItem), _i, _vp],
     "sg_conv2d_q_wgrad_plan": [C.POINTER(ConvQWgradDesc), C.POINTER(_i), C.POINTER(_ll)],

@@ -49,10 +49,11 @@ class GenBlock(nn.Module):
     def forward_nhwc(self, x, affine, slot):
         link = F.GradLink()      # x feeds bn1 and the skip: bn1's backward adds the skip's gradient in its own launch (no autograd add)
         h = self.bn1.forward_nhwc(x, affine, slot, relu=True, link=link)
-        h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True)
+        # (stats=True: a batch norm reads the result next -- bn2 / the next block's bn1 / bn4: its statistics come out of the convolution's epilogue)
+        h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True, stats=True)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
         # conv2d2(h) + conv2d0(up(x)): one launch, the skip as extra K-slices (functional.ConvSkipFn)
-        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True, link=link)
+        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True, link=link, stats=True)
 
 
 class Generator(nn.Module):

@@ -167,6 +167,12 @@ static int conv_fwd_skip(const sg_conv_skip_desc* sk, hipStream_t st, bool dry) 
   sg_prof_end(st, prof);
   return ok ? 1 : 0;
 }
+// rows of the per-tile statistics buffer a fused launch with d->stats writes ([rows][Cout][2] floats): 256-pixel tiles
+extern "C" int sg_conv2d_fwd_skip_stat_rows(const sg_conv_skip_desc* d) {
+  if (!d) return 0;
+  const long long J = (long long)d->main.N * d->main.Ho * d->main.Wo;
+  return (int)((J + 255) / 256);
+}
 extern "C" int sg_conv2d_fwd_skip_ok(const sg_conv_skip_desc* d) {
   if (!d || !d->main.x || !d->main.w || !d->main.out || !d->x2 || !d->w2) return 0;
   return conv_fwd_skip(d, nullptr, true);

@@ -41,6 +41,7 @@ struct ConvQParams {
   const bf16_t* x2; const bf16_t* w2; const float* bias2;
   int C2, ldx2, nslice2;
   unsigned x2bytes, w2bytes;
+  float* stats;           // optional [tilesJ * nph][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue)
 };
 
 // TJW = 32-pixel blocks per wave: 2 (tile of 256 low-resolution pixels) or 1 (128: twice the workgroups for the layers whose whole low-resolution
@@ -327,10 +328,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
   if (pool) {
-    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
   } else {
     // UP: output / mask / residual rows go through the view of this workgroup's phase
-    sg_conv_epilogue<BI, BJ, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, p.wlog, (ph >> 1) * 2 * p.Wl + (ph & 1));
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, p.wlog, (ph >> 1) * 2 * p.Wl + (ph & 1),
+                                               p.stats, p.I, tJ * nph + ph);
   }
 }
 

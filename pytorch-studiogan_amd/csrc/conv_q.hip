@@ -198,6 +198,7 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
     p.x2 = (const bf16_t*)d->x2; p.w2 = (const bf16_t*)d->w2q; p.bias2 = d->bias2;
     p.C2 = d->C2; p.ldx2 = d->ldx2; p.nslice2 = d->C2 / 32; p.x2bytes = (unsigned)x2bytes; p.w2bytes = (unsigned)w2bytes;
   }
+  p.stats = d->stats;
   e.out = d->out; e.out_bstride = 0; e.ldo = d->ldo; e.bias = d->bias;
   e.res = d->res; e.res_bstride = 0; e.ldr = d->ldr; e.beta = d->beta;
   e.mask = (const bf16_t*)d->mask; e.mask_bstride = 0; e.ldm = d->ldm; e.split_stride = 0;
@@ -208,6 +209,13 @@ extern "C" int sg_conv2d_q_ok(const sg_convq_desc* d) {
   if (!d || !d->x || !d->wq || !d->out) return 0;
   ConvQParams p; Epilogue<bf16_t> e; int NB;
   return convq_plan(d, p, e, NB) ? 1 : 0;
+}
+// rows of the per-tile statistics buffer a launch with d->stats writes ([rows][Cout][2] floats): pixel tiles x phases; 0 = not eligible
+extern "C" int sg_conv2d_q_stat_rows(const sg_convq_desc* d) {
+  if (!d || !d->x || !d->wq || !d->out) return 0;
+  ConvQParams p; Epilogue<bf16_t> e; int NB;
+  if (!convq_plan(d, p, e, NB)) return 0;
+  return ((p.J + p.bj - 1) / p.bj) * (d->form == SG_Q_POOL ? 1 : 4);
 }
 extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   SG_CHECK(d && d->x && d->wq && d->out, "sg_conv2d_q: null pointer");

@@ -42,7 +42,8 @@ typedef __attribute__((address_space(3))) void* sg_lptr_t;
 // view of the tensor at twice the resolution: global row of tile row jg = ((jg >> vlog) << (vlog + 2)) + ((jg & (2^vlog - 1)) << 1) + vadd.
 template <int BI, int BJ, int NW, int TI, int TJ, bool VMAP = false>
 __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* smem, const float* sbias, const Epilogue<bf16_t>& epi,
-                                                 int i0, int j0, int wi0, int wj0, float al, bool active = true, int vlog = 0, int vadd = 0) {
+                                                 int i0, int j0, int wi0, int wj0, float al, bool active = true, int vlog = 0, int vadd = 0,
+                                                 float* stats = nullptr, int stats_C = 0, int stats_row = 0) {
   auto grow = [&](int jg) -> long long {
     if (VMAP) return (long long)(((jg >> vlog) << (vlog + 2)) + ((jg & ((1 << vlog) - 1)) << 1) + vadd);
     return (long long)jg;
@@ -165,8 +166,44 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
       }
     }
   }
+  __syncthreads();
+  if (stats) {
+    // Batch-norm statistics of the layer behind this convolution, taken from the staged tile (the bf16 values the BN kernels would read back
+    // from HBM): per channel the sum and the sum of squares over this tile's rows, written to stats[stats_row][channel][2]; the fp64 reduction
+    // over the tiles is sg_bn_stats_from_tiles. Replaces the separate statistics pass over the activation (csrc/norm.hip k_bn_partial_stream:
+    // one full read of every generator activation, 5 ms per C3 step). A wave owns BI / 8 channel pairs, its lanes split the rows RG ways.
+    constexpr int PWV = BI / 2 / NW, RG = 64 / PWV;
+    const int wv = tid >> 6, pl = lane % PWV, rg = lane / PWV;
+    int rows_valid = Jout - jbase;
+    if (rows_valid > rows_out) rows_valid = rows_out;
+    float s1a = 0.f, s2a = 0.f, s1b = 0.f, s2b = 0.f;
+    const int c2 = wv * PWV + pl;
+    if (rg < RG) {
+      // (fixed trip count, eight reads in flight: with the data-dependent bound the loop ran one LDS round trip per row, ~1.6 us per tile)
+      constexpr int NIT = (BJ + RG - 1) / RG;
+      const char* base = smem + rg * CP + c2 * 4;
+#pragma unroll 8
+      for (int k = 0; k < NIT; k++) {
+        const int r = rg + k * RG;
+        uint32_t v = *(const uint32_t*)(base + (r < BJ ? k * (RG * CP) : 0));      // (the last iterations of the higher row groups fall behind the tile: masked)
+        v = r < rows_valid ? v : 0u;
+        const float a = __uint_as_float(v << 16), b = __uint_as_float(v & 0xffff0000u);
+        s1a += a; s2a += a * a; s1b += b; s2b += b * b;
+      }
+    }
+    float t1a = s1a, t2a = s2a, t1b = s1b, t2b = s2b;
+#pragma unroll
+    for (int k = 1; k < RG; k++) {
+      t1a += __shfl(s1a, lane + k * PWV, 64); t2a += __shfl(s2a, lane + k * PWV, 64);
+      t1b += __shfl(s1b, lane + k * PWV, 64); t2b += __shfl(s2b, lane + k * PWV, 64);
+    }
+    const int c = i0 + 2 * c2;
+    if (rg == 0 && c < epi.I) {
+      f32x4 o4 = {t1a, t2a, t1b, t2b};
+      *(f32x4*)(stats + ((long long)stats_row * stats_C + c) * 2) = o4;
+    }
+  }
   {
-    __syncthreads();
     bf16_t* o = (bf16_t*)epi.out;
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;

@@ -39,6 +39,7 @@ struct ConvV4Params {
   const bf16_t* x2; const bf16_t* w2; const float* bias2;
   int C2, ldx2, up2, nslice2, npix2;   // C2 % 32 == 0; up2: x2 is at half resolution (nearest x2 on load); npix2 = N * Hs2 * Ws2
   unsigned x2bytes, w2bytes;
+  float* stats;           // optional [tilesJ][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue), 256-pixel tiles only
 };
 
 // TJW = 32-pixel blocks per wave: 2 (tile 256 pixels, 6 accumulator blocks per wave for NB = 3, three workgroups per CU) or 4 (tile 512 pixels,
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
   if constexpr (TJW == 2) {
-    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al);
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
   } else {   // 512-pixel tile, 256-row staging area: waves 0, 1 then waves 2, 3
     sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2);
     sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2);

@@ -63,7 +63,9 @@ bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc*
     p.psh = on ? p.wlog - 1 : 0;
   }
   p.x2 = nullptr; p.w2 = nullptr; p.bias2 = nullptr; p.C2 = p.ldx2 = p.up2 = p.nslice2 = p.npix2 = 0; p.x2bytes = p.w2bytes = 0;
+  p.stats = nullptr;
   if (sk) {
+    p.stats = (e.flags & SG_EPI_POOL) ? nullptr : sk->stats;     // (tile rows = output rows; the pooled tail of a D block feeds no batch norm)
     p.x2 = (const bf16_t*)sk->x2; p.w2 = (const bf16_t*)sk->w2; p.bias2 = sk->bias2;
     p.C2 = sk->C2; p.ldx2 = sk->ldx2; p.up2 = sk->x2_up ? 1 : 0; p.nslice2 = sk->C2 / 32;
     p.npix2 = d->N * (sk->x2_up ? (d->Ho / 2) * (d->Wo / 2) : d->Ho * d->Wo);

@@ -100,6 +100,39 @@ extern "C" int sg_bn_partial_stats(int dtype, const void* x, int ldx, long long 
   SG_LAUNCH_CHECK();
   return 0;
 }
+// partial[2 c + {0, 1}] += sum over the tile rows of stats[row][c][{0, 1}] (the per-tile sums a convolution epilogue wrote: conv_v2.h
+// sg_conv_epilogue `stats`). Block (64 channels x 4 row phases), fixed summation order per block, fp64; blocks of different row groups meet in
+// fp64 atomics like k_bn_partial_stream's.
+__global__ __launch_bounds__(256) void k_bn_stats_from_tiles(const float* stats, int nrows, int C, double* partial, int rpb) {
+  __shared__ double sm[2][4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cx;
+  int r0 = blockIdx.y * rpb, r1 = r0 + rpb;
+  if (r1 > nrows) r1 = nrows;
+  double s1 = 0.0, s2 = 0.0;
+  if (c < C) {
+    for (int r = r0 + ry; r < r1; r += 4) {
+      const float2 v = *(const float2*)(stats + ((long long)r * C + c) * 2);
+      s1 += (double)v.x; s2 += (double)v.y;
+    }
+  }
+  sm[0][ry][cx] = s1; sm[1][ry][cx] = s2;
+  __syncthreads();
+  if (ry == 0 && c < C) {
+    atomicAdd(partial + 2 * c, (sm[0][0][cx] + sm[0][1][cx]) + (sm[0][2][cx] + sm[0][3][cx]));
+    atomicAdd(partial + 2 * c + 1, (sm[1][0][cx] + sm[1][1][cx]) + (sm[1][2][cx] + sm[1][3][cx]));
+  }
+}
+extern "C" int sg_bn_stats_from_tiles(const float* stats, int nrows, int C, double* partial, sg_stream_t s) {
+  SG_CHECK(stats && partial && nrows > 0 && C > 0, "sg_bn_stats_from_tiles: bad args");
+  SgProfScope prof((hipStream_t)s, (double)nrows * C * 8.0, 4);
+  int gy = (nrows + 255) / 256;
+  if (gy > 64) gy = 64;
+  const int rpb = (nrows + gy - 1) / gy;
+  hipLaunchKernelGGL(k_bn_stats_from_tiles, dim3((C + 63) / 64, gy), dim3(256), 0, (hipStream_t)s, stats, nrows, C, partial, rpb);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
 __global__ void k_bn_finalize(const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd, float* rm, float* rv) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;

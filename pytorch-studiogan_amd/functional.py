@@ -39,6 +39,29 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Batch-norm statistics taken in the producing convolution's epilogue (csrc/conv_v2.h sg_conv_epilogue `stats`): the convolution offers them,
+# the batch norm that runs as the VERY NEXT operator on exactly that tensor takes them (its statistics pass over the activation is then one
+# small reduction over per-tile sums). _SEQ counts convolution / batch-norm forwards; an offer is only good for the operator right behind it.
+_SEQ = [0]
+_STATS_OFFER = [None]      # (seq, data_ptr, shape, per-tile sums [rows][C][2], rows, C)
+_BN_FUSED_STATS = [os.environ.get("SG_BN_FUSED_STATS", "1") != "0"]
+
+
+def _tick():
+    _SEQ[0] += 1
+
+
+def _offer_stats(out, st, rows, C):
+    _STATS_OFFER[0] = (_SEQ[0], out.data_ptr(), tuple(out.shape), st, rows, C)
+
+
+def _take_stats(x):
+    ent, _STATS_OFFER[0] = _STATS_OFFER[0], None
+    if ent is None or ent[0] != _SEQ[0] - 1 or ent[1] != x.data_ptr() or ent[2] != tuple(x.shape) or ent[5] != x.shape[3]:
+        return None
+    return ent[3], ent[4]
+
+
 # ---------------------------------------------------------------------------------------------------------
 # raw launch helpers (also used directly by the kernel-level tests)
 # ---------------------------------------------------------------------------------------------------------
@@ -81,7 +104,7 @@ def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=
     return out
 
 
-def conv2d_skip_raw(x, w_ptr, Cin, Cout, x2, w2_ptr, C2, x2_up=False, pix_flags=0, epi_flags=0, bias=None, bias2=None, alpha=1.0, dry=False):
+def conv2d_skip_raw(x, w_ptr, Cin, Cout, x2, w2_ptr, C2, x2_up=False, pix_flags=0, epi_flags=0, bias=None, bias2=None, alpha=1.0, dry=False, stats=False):
     """[pool]( conv3x3(x; w) + conv1x1(up2?(x2); w2) ) + bias + bias2 in ONE launch (include/sgamd.h sg_conv2d_fwd_skip): the residual block's
     skip convolution as extra K-slices of its last 3x3 launch. dry=True: only ask whether the fused kernel takes the problem.
     Returns the output tensor, or None when the problem is not eligible (the caller then runs the two launches)."""
@@ -93,6 +116,14 @@ def conv2d_skip_raw(x, w_ptr, Cin, Cout, x2, w2_ptr, C2, x2_up=False, pix_flags=
     if L.lib().sg_conv2d_fwd_skip_ok(L.C.byref(sk)) != 1:
         return None
     if dry:
+        return out
+    if stats and not (epi_flags & L.EPI_POOL):
+        # per-tile batch-norm statistics of the result from the epilogue (consumed by BNFn through _offer_stats / _take_stats)
+        rows = L.lib().sg_conv2d_fwd_skip_stat_rows(L.C.byref(sk))
+        st = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+        sk.stats = st.data_ptr()
+        L.call("sg_conv2d_fwd_skip", sk, L.stream())
+        _offer_stats(out, st, rows, Cout)
         return out
     L.call("sg_conv2d_fwd_skip", sk, L.stream())
     return out
@@ -136,7 +167,7 @@ def quad_pack_raw(src_ptr, dst, mode, M, Cs):
 
 
 def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None, alpha=1.0, beta=1.0, dry=False,
-                 x2=None, w2q_ptr=None, bias2=None):
+                 x2=None, w2q_ptr=None, bias2=None, stats=False):
     """The quad forms of a 3x3 / pad-1 convolution next to a 2x resampling (include/sgamd.h sg_conv2d_q). form Q_POOL: x [N,2Hl,2Wl,C] ->
     [N,Hl,Wl,Cout] = avgpool2(conv3x3(x)); form Q_UP: x [N,Hl,Wl,C] -> [N,2Hl,2Wl,Cout] = conv3x3(up2(x)). Returns None when not eligible."""
     N = x.shape[0]
@@ -164,7 +195,14 @@ def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None
     if L.lib().sg_conv2d_q_ok(L.C.byref(d)) != 1:
         return None
     if not dry:
+        st = None
+        if stats:
+            rows = L.lib().sg_conv2d_q_stat_rows(L.C.byref(d))
+            st = torch.empty((rows, Cout, 2), dtype=torch.float32, device=x.device)
+            d.stats = st.data_ptr()
         L.call("sg_conv2d_q", d, L.stream())
+        if st is not None:
+            _offer_stats(out, st, rows, Cout)
     return out
 
 
@@ -291,11 +329,12 @@ class ConvertFn(torch.autograd.Function):
 # convolution
 # ---------------------------------------------------------------------------------------------------------
 class ConvCfg:
-    __slots__ = ("R", "S", "stride", "pad_h", "pad_w", "in_relu", "in_upsample", "out_pool")
+    __slots__ = ("R", "S", "stride", "pad_h", "pad_w", "in_relu", "in_upsample", "out_pool", "stats")
 
-    def __init__(self, R, S, stride=1, pad_h=0, pad_w=0, in_relu=False, in_upsample=False, out_pool=False):
+    def __init__(self, R, S, stride=1, pad_h=0, pad_w=0, in_relu=False, in_upsample=False, out_pool=False, stats=False):
         self.R, self.S, self.stride, self.pad_h, self.pad_w = R, S, stride, pad_h, pad_w
         self.in_relu, self.in_upsample, self.out_pool = in_relu, in_upsample, out_pool
+        self.stats = stats      # a batch norm reads the result next: take its statistics in the epilogue where the kernel can
 
 
 class GradLink:
@@ -340,13 +379,14 @@ def _quad_form(rt, cfg, x):
     return L.Q_POOL if cfg.out_pool else L.Q_UP
 
 
-def _conv_fwd(x, rt, slot, cfg, bias, res=None):
-    """ConvFn's forward launch: [res +] avgpool2?(conv(up2?(relu?(x)))) + bias"""
+def _conv_fwd(x, rt, slot, cfg, bias, res=None, stats=False):
+    """ConvFn's forward launch: [res +] avgpool2?(conv(up2?(relu?(x)))) + bias. stats: also offer the result's batch-norm statistics (quad kernel)"""
     bank = rt.bank()
     Cin = x.shape[3]
     form = _quad_form(rt, cfg, x)
     if form is not None:
-        y = conv2d_q_raw(x, bank.w_quad(slot, rt, form), form, Cin, rt.rows_pad, L.PIX_RELU if cfg.in_relu else 0, 0, bias=bias, res=res)
+        y = conv2d_q_raw(x, bank.w_quad(slot, rt, form), form, Cin, rt.rows_pad, L.PIX_RELU if cfg.in_relu else 0, 0, bias=bias, res=res,
+                         stats=stats and _BN_FUSED_STATS[0] and rt.rows_pad == rt.rows)
         if y is not None:
             return y
     pf = (L.PIX_RELU if cfg.in_relu else 0) | (L.PIX_UPSAMPLE if cfg.in_upsample else 0)
@@ -461,7 +501,8 @@ class ConvFn(torch.autograd.Function):
         if bias is not None and rt.rows_pad != rt.rows:      # padded output channels: the epilogue reads rows_pad bias entries
             bias_k = torch.zeros(rt.rows_pad, dtype=torch.float32, device=x.device)
             bias_k[:rt.rows].copy_(bias.detach())
-        y = _conv_fwd(x, rt, slot, cfg, bias_k, res)
+        _tick()
+        y = _conv_fwd(x, rt, slot, cfg, bias_k, res, stats=cfg.stats)
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
         ctx.bias = bias
@@ -525,6 +566,7 @@ class ConvSkipFn(torch.autograd.Function):
         bank = rt2.bank()
         ctx.link = link
         h, x = _c(h), _c(x)
+        _tick()
         assert cfg2.R == 3 and cfg0.R == 1 and cfg2.out_pool == cfg0.out_pool and cfg2.in_relu == cfg0.in_relu and not cfg2.in_upsample
         pf = L.PIX_RELU if cfg2.in_relu else 0
         ef = L.EPI_POOL if cfg2.out_pool else 0
@@ -537,7 +579,7 @@ class ConvSkipFn(torch.autograd.Function):
         if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
             try:
                 y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
-                                    bias=b2, bias2=b0, alpha=al)
+                                    bias=b2, bias2=b0, alpha=al, stats=cfg2.stats and _BN_FUSED_STATS[0])
             except RuntimeError:
                 y = None         # the launch itself refused (the dry run checks eligibility, not LDS / attribute limits): the two-launch form below
         if y is None and plain and _quad_form(rt2, cfg2, h) == L.Q_POOL and _SKIP_FUSION[0] and rt0.cin_pad % 32 == 0 and not cfg0.in_upsample:
@@ -839,6 +881,8 @@ class BNFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, gain, bias, running_mean, running_var, cfg, *opt):
         x = _c(x)
+        _tick()
+        fused = _take_stats(x) if cfg.batch_stats else None      # statistics the producing convolution took in its epilogue
         ctx.link = opt[0] if opt else None      # optional 7th argument: a GradLink (see ConvSkipFn)
         ctx.nopt = len(opt)
         N, H, W, Cc = x.shape
@@ -852,7 +896,14 @@ class BNFn(torch.autograd.Function):
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
             nc = _comm.native_for(cfg.group) if ws > 1 else None
-            if nc is not None:
+            if fused is not None:
+                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                L.call("sg_bn_stats_from_tiles", fused[0].data_ptr(), fused[1], Cc, L.ptr(partial), L.stream())
+                if ws > 1:
+                    _allreduce_sum(partial, cfg.group)
+                    count *= ws
+                L.call("sg_bn_finalize", L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
+            elif nc is not None:
                 # sync-BN statistics in ONE C-ABI call: partial sums -> RCCL all-reduce -> mean / invstd / running stats, same stream
                 partial = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
                 L.call("sg_bn_stats_sync", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), nc.handle, cfg.eps, cfg.momentum, L.ptr(mean),

@@ -118,13 +118,13 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         self._sg_dgrad_noflip = self.stride[0] != 1     # strided conv: data gradient is a transposed gather (unflipped image)
         self._sg_setup("conv", out_channels, in_channels * kh * kw, in_channels, kh * kw, sn)
 
-    def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None, link=None):
+    def forward_nhwc(self, x, slot=None, in_relu=False, in_upsample=False, out_pool=False, res=None, link=None, stats=False):
         """link: a functional.GradLink shared with the block's tail (conv_skip_nhwc): this convolution's data gradient then also adds the
         gradient the same input receives through the skip path"""
         rt = self._sg_rt
         slot = slot if slot is not None else rt.bank().current
         kh, kw = self.kernel_size
-        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool)
+        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool, stats)
         return F.ConvFn.apply(x, self.master_weight, self.bias, res, rt, slot, cfg, link)
 
     def forward(self, x):
@@ -136,12 +136,12 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         return to_nchw(y)
 
 
-def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False, link=None):
+def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False, link=None, stats=False):
     """Tail of a residual block: [pool](conv_main(relu?(h))) + [pool](conv_skip(up?(relu?(x)))) -- ONE fused launch when the kernel takes the
     shape (functional.ConvSkipFn), the two chained launches otherwise. conv_main: 3x3 / pad 1, conv_skip: 1x1."""
     rt2, rt0 = conv_main._sg_rt, conv_skip._sg_rt
     slot = slot if slot is not None else rt2.bank().current
-    cfg2 = F.ConvCfg(3, 3, 1, 1, 1, in_relu, False, out_pool)
+    cfg2 = F.ConvCfg(3, 3, 1, 1, 1, in_relu, False, out_pool, stats)
     cfg0 = F.ConvCfg(1, 1, 1, 0, 0, in_relu, skip_upsample, out_pool)
     return F.ConvSkipFn.apply(h, x, conv_main.master_weight, conv_main.bias, conv_skip.master_weight, conv_skip.bias, rt2, rt0, slot, cfg2, cfg0, link)
 

@@ -219,3 +219,39 @@ def test_quad_pack_batch_matches_reference(sg):
     torch.cuda.synchronize()
     for j, (mode, M, Cs) in enumerate(specs):
         check(f"quad pack batch item {j} mode {mode}", dsts[j].float().cpu(), refs[j], 4e-3)
+
+
+@pytest.mark.parametrize("kind", ["quad_up", "quad_up_128", "quad_pool", "v4_skip"])
+def test_conv_epilogue_bn_statistics(sg, kind, monkeypatch):
+    """Batch-norm statistics taken in the producing convolution's epilogue (conv_v2.h sg_conv_epilogue `stats`) + sg_bn_stats_from_tiles
+    against the sums of the stored bf16 result (what the separate statistics pass, csrc/norm.hip k_bn_partial_stream, reads back)."""
+    from studiogan_amd import functional as F, _lib as L
+    dt = torch.bfloat16
+    N, Hl, Wl, C, Cout = 3, 8, 16, 64, 96          # J = 384 low-resolution pixels: a full and a partial 256-pixel tile
+    w9 = rnd((Cout, 3, 3, C), dt, 501, 0.1)
+    bias = rnd((Cout,), torch.float32, 502)
+    w9d = _dev(w9)
+    F._STATS_OFFER[0] = None
+    if kind.startswith("quad"):
+        form = L.Q_UP if "up" in kind else L.Q_POOL
+        monkeypatch.setenv("SG_CONV_Q_BJ", "128" if kind.endswith("128") else "256")
+        x = rnd((N, Hl, Wl, C) if form == L.Q_UP else (N, 2 * Hl, 2 * Wl, C), dt, 503)
+        wq = torch.empty(Cout, 16, C, dtype=dt, device="cuda:0")
+        F.quad_pack_raw(w9d.data_ptr(), wq, form, Cout, C)
+        y = F.conv2d_q_raw(_dev(x), wq.data_ptr(), form, C, Cout, 0, 0, bias=_dev(bias), stats=True)
+    else:
+        x = rnd((N, 2 * Hl, 2 * Wl, C), dt, 503)
+        x2 = rnd((N, Hl, Wl, 32), dt, 504)
+        w0 = rnd((Cout, 32), dt, 505, 0.2)
+        w0d = _dev(w0)
+        y = F.conv2d_skip_raw(_dev(x), w9d.data_ptr(), C, Cout, _dev(x2), w0d.data_ptr(), 32, True, 0, 0, bias=_dev(bias), bias2=_dev(bias), stats=True)
+    assert y is not None and F._STATS_OFFER[0] is not None, "no statistics were offered"
+    _, ptr, shape, st, rows, Cc = F._STATS_OFFER[0]
+    assert ptr == y.data_ptr() and Cc == Cout
+    partial = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda:0")
+    L.call("sg_bn_stats_from_tiles", st.data_ptr(), rows, Cout, partial.data_ptr(), L.stream())
+    torch.cuda.synchronize()
+    yd = y.double().cpu().reshape(-1, Cout)
+    got = partial.cpu().reshape(Cout, 2)
+    check(f"epilogue BN statistics {kind}: sum", got[:, 0], yd.sum(0), 1e-5)
+    check(f"epilogue BN statistics {kind}: sum of squares", got[:, 1], (yd * yd).sum(0), 1e-5)
