@@ -122,13 +122,15 @@ typedef struct {
   const void* x2; const void* w2q; const float* bias2;
   int C2, ldx2;
   float* stats;   /* optional: per-tile batch-norm statistics of the result, [sg_conv2d_q_stat_rows()][Cout][2] floats (see sg_conv_skip_desc) */
+  int x2_norelu;  /* 1: SG_PIX_RELU applies to x only, not to the skip input (the first discriminator block: the skip reads the image). With C2 == 8
+                     (the RGB image padded to 8 channels) w2q is [Cout][4][8] = sg_quad_pack_batch mode 5 */
 } sg_convq_desc;
 int sg_conv2d_q_stat_rows(const sg_convq_desc* d);
 int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream);
 int sg_conv2d_q_ok(const sg_convq_desc* d);            /* 1 when sg_conv2d_q takes the problem */
 int sg_quad_pack(int dtype, int mode, const void* src, void* dst, int M, int Cs, sg_stream_t stream);
 /* the same for n images in one launch (items_dev: the table in device memory, items_host: the same table on the host) */
-typedef struct { const void* src; void* dst; int M, Cs, mode, pad_; } sg_quad_item;   /* mode 4: dst[M][Cs] = src[M][Cs] / 4 (the fused skip's filter) */
+typedef struct { const void* src; void* dst; int M, Cs, mode, pad_; } sg_quad_item;   /* mode 4: dst[M][Cs] = src[M][Cs] / 4 (the fused skip's filter); mode 5 (Cs == 8): dst[M][4][8] = src[M][8] / 4, four times */
 int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, const sg_quad_item* items_host, int n, sg_stream_t stream);
 /* weight gradient of the same two forms: dw[co][r][s][c] (the 3x3 gradient image, fp32, accumulated) += alpha * (gradient w.r.t. the
  * quad filter, folded back through the transpose of sg_quad_pack's sums); dbias[co] += sum of dy (optional). POOL: x fine, dy low;

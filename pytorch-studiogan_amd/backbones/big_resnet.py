@@ -170,6 +170,10 @@ class DiscOptBlock(nn.Module):
             h = self.bn1.forward_nhwc(h, relu=True)
             h = self.conv2d2.forward_nhwc(h, slot, out_pool=True)
         else:
+            if self.cpad == 8 and h.dtype == torch.bfloat16:
+                # pool(conv2d2(relu h)) + conv2d0(pool x) = pool(conv2d2(relu h) + conv2d0(x)): pooling is linear, so the skip on the image rides in
+                # the block tail's launch like the other blocks' (functional.ConvSkipFn; the skip input takes no ReLU here)
+                return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, in_relu=True, out_pool=True, skip_relu=False)
             h = self.conv2d2.forward_nhwc(h, slot, in_relu=True, out_pool=True)
         x0 = F.AvgPool2Fn.apply(x)
         if not self.apply_d_sn:

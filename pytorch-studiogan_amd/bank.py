@@ -398,7 +398,7 @@ class WeightBank:
                self.work.numel(), L.stream())
         self._fwd_counter = self.__dict__.get("_fwd_counter", 0) + 1
         slot.fwd_id = self._fwd_counter      # (handle and physical slot share one attribute dict)
-        self._pack_quad(slot, (0, 1, 4))     # the forward quad images this network is known to use (csrc/conv_q.h), one launch
+        self._pack_quad(slot, (0, 1, 4, 5))  # the forward quad images this network is known to use (csrc/conv_q.h), one launch
         self.current = slot
         return slot
 
@@ -442,10 +442,12 @@ class WeightBank:
                 r = self.layers[idx]
                 ent = slot.quad.get((idx, mode))
                 if ent is None:
-                    ent = [torch.empty(r.rows_pad * (r.RS if mode == 4 else 16) * r.cin_pad, dtype=self.dtype, device=self.device), -1]
+                    ent = [torch.empty(r.rows_pad * (r.RS if mode == 4 else (4 if mode == 5 else 16)) * r.cin_pad, dtype=self.dtype, device=self.device), -1]
                     slot.quad[(idx, mode)] = ent
                 it = arr[j]
-                if mode == 4:        # the 1x1 skip filter of a pooled block tail x 1/4
+                if mode == 5:        # the 8-channel (image) skip filter x 1/4, once per parity view
+                    it.src, it.M, it.Cs = self.w_fwd(slot, r), r.rows_pad, 8
+                elif mode == 4:      # the 1x1 skip filter of a pooled block tail x 1/4
                     it.src, it.M, it.Cs = self.w_fwd(slot, r), r.rows_pad, r.RS * r.cin_pad
                 elif mode < 2:
                     it.src, it.M, it.Cs = self.w_fwd(slot, r), r.rows_pad, r.cin_pad

@@ -40,6 +40,8 @@ struct ConvQParams {
   // fused 1x1 skip (SKIP instantiations, POOL form): acc += sum over the four views of conv1x1(relu?(x2_view); w2), w2 = 1/4 of the skip filter
   const bf16_t* x2; const bf16_t* w2; const float* bias2;
   int C2, ldx2, nslice2;
+  int c2x8;               // the skip input has 8 channels (the RGB image): ONE slice whose four 16-byte chunks are the four views; C2 = 32 for the filter
+  int skip_norelu;        // ReLU on load applies to the main input only
   unsigned x2bytes, w2bytes;
   float* stats;           // optional [tilesJ * nph][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue)
 };
@@ -267,14 +269,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
     const unsigned ldx2b = 2u * (unsigned)p.ldx2;
     constexpr int P2B = BJ * 64, NG2 = BJ / 16;
     char* const w2bufs = smem + 2 * P2B;
-    const int n2 = 4 * p.nslice2;
+    const int n2 = p.c2x8 ? 1 : 4 * p.nslice2;
     auto issue2 = [&](int vs2, int slot) {
-      const int v2 = vs2 / p.nslice2, s2 = vs2 - v2 * p.nslice2;
+      // (c2x8: the lane's logical chunk IS the view -- the slice holds view 0 | 1 | 2 | 3 of an 8-channel pixel)
+      const int v2 = p.c2x8 ? lc : vs2 / p.nslice2, s2 = p.c2x8 ? 0 : vs2 - (vs2 / p.nslice2) * p.nslice2;
       const int vadd = (v2 >> 1) * 2 * p.Wl + (v2 & 1);
       for (int g = wave; g < NG2; g += NW) {
         const int pix = j0 + 16 * g + sub;
         const unsigned src = (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd);
-        unsigned off = src * ldx2b + (unsigned)(s2 * 64 + lc * 16);
+        unsigned off = src * ldx2b + (p.c2x8 ? 0u : (unsigned)(s2 * 64 + lc * 16));
         off = (pix < p.J) ? off : 0x80000000u;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx2, (sg_lptr_t)(smem + slot * P2B + g * 1024), 16, (int)off, 0, 0, 0);
       }
@@ -312,7 +315,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
 #pragma unroll
         for (int b = 0; b < TJ; b++) {
           u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
-          if (RELU) v = relu16<bf16_t>(v);
+          if (RELU && !p.skip_norelu) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll

@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* ite
   int it = 0;
   long long blk = blockIdx.x;
   for (; it < n; it++) {
-    const long long per = (long long)items[it].M * (items[it].Cs / V) * (items[it].mode == 4 ? 1 : 16);
+    const long long per = items[it].mode == 5 ? (long long)items[it].M * 4 : (long long)items[it].M * (items[it].Cs / V) * (items[it].mode == 4 ? 1 : 16);
     const long long nb = (per + 255) / 256;
     if (blk < base + nb) break;
     base += nb;
@@ -104,6 +104,15 @@ __global__ __launch_bounds__(256) void k_quad_pack_batch(const sg_quad_item* ite
   const sg_quad_item q = items[it];
   const int cv = q.Cs / V;
   const long long i = (blk - base) * 256 + threadIdx.x;
+  if (q.mode == 5) {           // the 8-channel (RGB) skip filter x 1/4, once per view: [M][8] -> [M][4 views][8] (conv_q.h c2x8); Cs = 8
+    if (i >= (long long)q.M * 4) return;
+    float o[V];
+    unpack16<T>(*(const u32x4*)((const T*)q.src + (i >> 2) * V), o);
+#pragma unroll
+    for (int e = 0; e < V; e++) o[e] *= 0.25f;
+    *(u32x4*)((T*)q.dst + i * V) = pack16<T>(o);
+    return;
+  }
   if (q.mode == 4) {           // the 1x1 skip filter of a pooled block tail, x 1/4 (exact in bf16): [M][Cs] -> [M][Cs]
     if (i >= (long long)q.M * cv) return;
     float o[V];
@@ -146,8 +155,8 @@ extern "C" int sg_quad_pack_batch(int dtype, const sg_quad_item* items_dev, cons
   long long blocks = 0;
   for (int i = 0; i < n; i++) {
     const sg_quad_item& q = items_host[i];
-    SG_CHECK(q.src && q.dst && q.M > 0 && q.Cs > 0 && q.Cs % V == 0 && q.mode >= 0 && q.mode <= 4 && aligned16(q.src) && aligned16(q.dst), "sg_quad_pack_batch: bad item");
-    blocks += ((long long)q.M * (q.Cs / V) * (q.mode == 4 ? 1 : 16) + 255) / 256;
+    SG_CHECK(q.src && q.dst && q.M > 0 && q.Cs > 0 && q.Cs % V == 0 && q.mode >= 0 && q.mode <= 5 && (q.mode != 5 || (q.Cs == 8 && dtype == SG_DTYPE_BF16)) && aligned16(q.src) && aligned16(q.dst), "sg_quad_pack_batch: bad item");
+    blocks += ((q.mode == 5 ? (long long)q.M * 4 : (long long)q.M * (q.Cs / V) * (q.mode == 4 ? 1 : 16)) + 255) / 256;
   }
   hipStream_t st = (hipStream_t)stream;
   if (dtype == SG_DTYPE_BF16) hipLaunchKernelGGL(k_quad_pack_batch<bf16_t>, dim3((unsigned)blocks), dim3(256), 0, st, items_dev, n);
@@ -189,14 +198,17 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
   p.flags = d->pix_flags;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.wgt_off = p.zero_off = p.bias_off = 0;
-  p.x2 = nullptr; p.w2 = nullptr; p.bias2 = nullptr; p.C2 = p.ldx2 = p.nslice2 = 0; p.x2bytes = p.w2bytes = 0;
+  p.x2 = nullptr; p.w2 = nullptr; p.bias2 = nullptr; p.C2 = p.ldx2 = p.nslice2 = 0; p.x2bytes = p.w2bytes = 0; p.c2x8 = p.skip_norelu = 0;
   if (d->x2) {
-    if (d->form != SG_Q_POOL || !d->w2q || d->C2 < 32 || d->C2 % 32 || d->ldx2 % 8 || !aligned16(d->x2) || !aligned16(d->w2q)) return false;
+    const bool c8 = d->C2 == 8;          // the RGB image: one slice = the four views of an 8-channel pixel, filter [Cout][4][8] (sg_quad_pack_batch mode 5)
+    if (d->form != SG_Q_POOL || !d->w2q || (!c8 && (d->C2 < 32 || d->C2 % 32)) || d->ldx2 % 8 || !aligned16(d->x2) || !aligned16(d->w2q)) return false;
     if (d->bias2 && !d->bias) return false;
-    const long long x2bytes = ((4 * J - 1) * d->ldx2 + d->C2) * 2, w2bytes = (long long)d->Cout * d->C2 * 2;
+    const int c2w = c8 ? 32 : d->C2;
+    const long long x2bytes = ((4 * J - 1) * d->ldx2 + d->C2) * 2, w2bytes = (long long)d->Cout * c2w * 2;
     if (x2bytes >= (1ll << 31) || w2bytes >= (1ll << 31)) return false;
     p.x2 = (const bf16_t*)d->x2; p.w2 = (const bf16_t*)d->w2q; p.bias2 = d->bias2;
-    p.C2 = d->C2; p.ldx2 = d->ldx2; p.nslice2 = d->C2 / 32; p.x2bytes = (unsigned)x2bytes; p.w2bytes = (unsigned)w2bytes;
+    p.C2 = c2w; p.ldx2 = d->ldx2; p.nslice2 = c2w / 32; p.x2bytes = (unsigned)x2bytes; p.w2bytes = (unsigned)w2bytes;
+    p.c2x8 = c8 ? 1 : 0; p.skip_norelu = d->x2_norelu ? 1 : 0;
   }
   p.stats = d->stats;
   e.out = d->out; e.out_bstride = 0; e.ldo = d->ldo; e.bias = d->bias;

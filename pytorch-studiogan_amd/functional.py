@@ -167,7 +167,7 @@ def quad_pack_raw(src_ptr, dst, mode, M, Cs):
 
 
 def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None, alpha=1.0, beta=1.0, dry=False,
-                 x2=None, w2q_ptr=None, bias2=None, stats=False):
+                 x2=None, w2q_ptr=None, bias2=None, stats=False, x2_norelu=False):
     """The quad forms of a 3x3 / pad-1 convolution next to a 2x resampling (include/sgamd.h sg_conv2d_q). form Q_POOL: x [N,2Hl,2Wl,C] ->
     [N,Hl,Wl,Cout] = avgpool2(conv3x3(x)); form Q_UP: x [N,Hl,Wl,C] -> [N,2Hl,2Wl,Cout] = conv3x3(up2(x)). Returns None when not eligible."""
     N = x.shape[0]
@@ -192,6 +192,7 @@ def conv2d_q_raw(x, wq_ptr, form, Cin, Cout, pix_flags=0, epi_flags=0, bias=None
     d.ldm = mask.shape[-1] if mask is not None else 0
     if x2 is not None:      # Q_POOL: the block's 1x1 skip convolution in the same launch (x2: fine tensor, w2q: its filter x 1/4)
         d.x2, d.w2q, d.bias2, d.C2, d.ldx2 = L.ptr(x2), w2q_ptr, L.ptr(bias2), x2.shape[3], x2.shape[3]
+        d.x2_norelu = 1 if x2_norelu else 0
     if L.lib().sg_conv2d_q_ok(L.C.byref(d)) != 1:
         return None
     if not dry:
@@ -567,8 +568,10 @@ class ConvSkipFn(torch.autograd.Function):
         ctx.link = link
         h, x = _c(h), _c(x)
         _tick()
-        assert cfg2.R == 3 and cfg0.R == 1 and cfg2.out_pool == cfg0.out_pool and cfg2.in_relu == cfg0.in_relu and not cfg2.in_upsample
+        # (cfg0.in_relu may differ from cfg2.in_relu: the first discriminator block's skip reads the image itself, big_resnet.py:177-192)
+        assert cfg2.R == 3 and cfg0.R == 1 and cfg2.out_pool == cfg0.out_pool and not cfg2.in_upsample and (cfg0.in_relu == cfg2.in_relu or not cfg0.in_relu)
         pf = L.PIX_RELU if cfg2.in_relu else 0
+        same_relu = cfg0.in_relu == cfg2.in_relu
         ef = L.EPI_POOL if cfg2.out_pool else 0
         al = 0.25 if cfg2.out_pool else 1.0
         y = None
@@ -576,19 +579,20 @@ class ConvSkipFn(torch.autograd.Function):
         # measured (tools/skip_bench.py, profiles/r03_skip_bench_c.txt): the fused launch wins from 16 x 16 outputs up (0.01-0.30 ms per block
         # tail at batch 256) and loses 0.04-0.06 ms on the 1536-channel 8 x 8 tails, whose 48 one-tap slices are all stop-and-go
         # (a pooled tail goes through the quad kernel -- 2.25 x fewer MFMAs than the fused 3x3 launch -- and the 1x1 skip adds itself as a residual launch)
-        if plain and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
+        if plain and same_relu and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
             try:
                 y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
                                     bias=b2, bias2=b0, alpha=al, stats=cfg2.stats and _BN_FUSED_STATS[0])
             except RuntimeError:
                 y = None         # the launch itself refused (the dry run checks eligibility, not LDS / attribute limits): the two-launch form below
-        if y is None and plain and _quad_form(rt2, cfg2, h) == L.Q_POOL and _SKIP_FUSION[0] and rt0.cin_pad % 32 == 0 and not cfg0.in_upsample:
-            # pooled tail on the quad kernel with the skip as extra one-tap K-slices of the same launch (conv_q.h SKIP)
+        if y is None and plain and _quad_form(rt2, cfg2, h) == L.Q_POOL and _SKIP_FUSION[0] and (rt0.cin_pad % 32 == 0 or rt0.cin_pad == 8) and not cfg0.in_upsample:
+            # pooled tail on the quad kernel with the skip as extra one-tap K-slices of the same launch (conv_q.h SKIP; an 8-channel skip input --
+            # the image -- is ONE slice holding its four parity views, filter image mode 5)
             y = conv2d_q_raw(h, bank.w_quad(slot, rt2, L.Q_POOL), L.Q_POOL, h.shape[3], rt2.rows, pf, 0, bias=b2,
-                             x2=x, w2q_ptr=bank.w_quad(slot, rt0, 4), bias2=b0)
+                             x2=x, w2q_ptr=bank.w_quad(slot, rt0, 5 if rt0.cin_pad == 8 else 4), bias2=b0, x2_norelu=not same_relu)
         if y is None:
             hh = _conv_fwd(h, rt2, slot, cfg2, b2)
-            pf0 = pf | (L.PIX_UPSAMPLE if cfg0.in_upsample else 0)
+            pf0 = (L.PIX_RELU if cfg0.in_relu else 0) | (L.PIX_UPSAMPLE if cfg0.in_upsample else 0)
             y = conv2d_raw(x, bank.w_fwd(slot, rt0), x.shape[3], rt0.rows_pad, 1, 1, 1, 0, 0, pf0, ef, bias=b0, res=hh, alpha=al)
         ctx.save_for_backward(h, x)
         ctx.rt2, ctx.rt0, ctx.slot, ctx.cfg2, ctx.cfg0 = rt2, rt0, slot, cfg2, cfg0

@@ -136,13 +136,13 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         return to_nchw(y)
 
 
-def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False, link=None, stats=False):
+def conv_skip_nhwc(conv_main, conv_skip, h, x, slot=None, in_relu=False, out_pool=False, skip_upsample=False, link=None, stats=False, skip_relu=None):
     """Tail of a residual block: [pool](conv_main(relu?(h))) + [pool](conv_skip(up?(relu?(x)))) -- ONE fused launch when the kernel takes the
     shape (functional.ConvSkipFn), the two chained launches otherwise. conv_main: 3x3 / pad 1, conv_skip: 1x1."""
     rt2, rt0 = conv_main._sg_rt, conv_skip._sg_rt
     slot = slot if slot is not None else rt2.bank().current
     cfg2 = F.ConvCfg(3, 3, 1, 1, 1, in_relu, False, out_pool, stats)
-    cfg0 = F.ConvCfg(1, 1, 1, 0, 0, in_relu, skip_upsample, out_pool)
+    cfg0 = F.ConvCfg(1, 1, 1, 0, 0, in_relu if skip_relu is None else skip_relu, skip_upsample, out_pool)
     return F.ConvSkipFn.apply(h, x, conv_main.master_weight, conv_main.bias, conv_skip.master_weight, conv_skip.bias, rt2, rt0, slot, cfg2, cfg0, link)
 
 

@@ -164,6 +164,8 @@ SKIP_CASES = [
     (1, 16, 32, 192, 192, 96, True, "256"),
     (1, 16, 32, 192, 192, 96, True, "256db"),
     (2, 8, 64, 96, 96, 32, False, "256db"),
+    (2, 16, 16, 96, 96, 8, True, "256"),          # the first discriminator block: the skip reads the 8-channel image (no ReLU on it): one slice = its four views
+    (3, 4, 8, 64, 64, 8, True, "128"),
 ]
 
 
@@ -182,15 +184,18 @@ def test_conv_q_fused_skip_matches_torch(sg, case, monkeypatch):
     w0 = rnd((Cout, C2), dt, 344, 0.2)
     b2, b0 = rnd((Cout,), torch.float32, 345), rnd((Cout,), torch.float32, 346)
     ref = Q.pool_conv_torch(h.float(), w9.float(), relu) + b2 + b0
-    xx = torch.relu(x.float()) if relu else x.float()
+    img = C2 == 8                                    # ReLU on the main input only; filter image = mode 5 ([Cout][4 views][8] = w0 / 4 four times)
+    xx = torch.relu(x.float()) if (relu and not img) else x.float()
     sk = torch.einsum("nhwc,oc->nhwo", xx, w0.float())
     ref = ref + 0.25 * (sk[:, 0::2, 0::2] + sk[:, 0::2, 1::2] + sk[:, 1::2, 0::2] + sk[:, 1::2, 1::2])
     wq = torch.empty(Cout, 16, C, dtype=dt, device="cuda:0")
     w9d, w0d = _dev(w9), _dev(w0)
     F.quad_pack_raw(w9d.data_ptr(), wq, 0, Cout, C)
     w0q = (w0d.float() * 0.25).to(dt)
+    if img:
+        w0q = w0q.repeat(1, 4).contiguous()
     y = F.conv2d_q_raw(_dev(h), wq.data_ptr(), L.Q_POOL, C, Cout, L.PIX_RELU if relu else 0, 0, bias=_dev(b2),
-                       x2=_dev(x), w2q_ptr=w0q.data_ptr(), bias2=_dev(b0))
+                       x2=_dev(x), w2q_ptr=w0q.data_ptr(), bias2=_dev(b0), x2_norelu=img)
     assert y is not None
     torch.cuda.synchronize()
     check(f"conv_q fused skip {case}", y.float().cpu(), ref, 6e-3)
@@ -200,11 +205,15 @@ def test_quad_pack_batch_matches_reference(sg):
     """every image of a network in one launch (what the weight bank runs behind sg_sn_forward): modes 0-3 and the scaled skip filter (mode 4)"""
     from studiogan_amd import _lib as L
     dt = torch.bfloat16
-    specs = [(0, 96, 64), (1, 64, 96), (2, 32, 192), (3, 96, 32), (4, 192, 96), (0, 64, 32)]
+    specs = [(0, 96, 64), (1, 64, 96), (2, 32, 192), (3, 96, 32), (4, 192, 96), (0, 64, 32), (5, 96, 8)]
     srcs, dsts, refs = [], [], []
     arr = (L.QuadItem * len(specs))()
     for j, (mode, M, Cs) in enumerate(specs):
-        if mode == 4:
+        if mode == 5:
+            w = rnd((M, Cs), dt, 400 + j, 0.3)
+            refs.append((w.double() * 0.25).repeat(1, 4))
+            dst = torch.empty(M, 4 * Cs, dtype=dt, device="cuda:0")
+        elif mode == 4:
             w = rnd((M, Cs), dt, 400 + j, 0.3)
             refs.append(w.double() * 0.25)
             dst = torch.empty(M, Cs, dtype=dt, device="cuda:0")
