@@ -170,7 +170,7 @@ class DiscOptBlock(nn.Module):
             h = self.bn1.forward_nhwc(h, relu=True)
             h = self.conv2d2.forward_nhwc(h, slot, out_pool=True)
         else:
-            if self.cpad == 8 and h.dtype == torch.bfloat16:
+            if self.cpad == 8 and h.dtype == torch.bfloat16 and not x.requires_grad:      # (an image that wants its gradient -- gradient penalty, R1 -- keeps the chain below)
                 # pool(conv2d2(relu h)) + conv2d0(pool x) = pool(conv2d2(relu h) + conv2d0(x)): pooling is linear, so the skip on the image rides in
                 # the block tail's launch like the other blocks' (functional.ConvSkipFn; the skip input takes no ReLU here)
                 return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, in_relu=True, out_pool=True, skip_relu=False)
