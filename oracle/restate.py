@@ -116,6 +116,46 @@ def conv(x, P, B, name, padding, sn_iter=True, E=IDENT, qb_in=True):
     return F.conv2d(E.qb(x) if qb_in else x, E.qw(w), P.get(name + ".bias"), stride=1, padding=padding)
 
 
+# ---- bf16 emulation of the quad kernels (csrc/conv_q.h): the 3x3 convolutions next to a 2x resampling ---------------------------------
+# The HIP path computes avgpool2(conv3x3(x)) as ONE 4x4 / stride-2 convolution and conv3x3(up2(x)) as four 2x2 phase convolutions whose
+# bf16 filter entries are the fp32 SUMS of the bf16 3x3 taps, rounded once more (sg_quad_pack). In exact arithmetic that is the reference's
+# result (tests/test_quad_cpu.py); under Bf16Emu the second rounding is a storage point like any other and is restated here, for exactly the
+# layers the kernels take (functional._quad_form: C % 32 == 0, Cout % 64 == 0 or % 96 == 0). The fp32 restatement (emu off) never comes here.
+def _w(P, name):
+    return P[name + ".weight_orig"] if name + ".weight_orig" in P else P[name + ".weight"]
+
+
+def quad_eligible(w):
+    return w.shape[1] % 32 == 0 and (w.shape[0] % 64 == 0 or w.shape[0] % 96 == 0) and tuple(w.shape[2:]) == (3, 3)
+
+
+def conv_pool_quad(x, P, B, name, sn_iter, E):
+    """E.q-free core of  avg_pool2d(conv3x3(x), 2)  as the kernel computes it: conv4x4 / stride 2 / pad 1 with w'[u][v] = 1/4 sum w[u-i][v-j]"""
+    w = E.qw(weight_of(P, B, name, sn_iter))
+    O_, I_ = w.shape[0], w.shape[1]
+    w4 = F.conv2d(w.reshape(O_ * I_, 1, 3, 3), torch.full((1, 1, 2, 2), 0.25, dtype=w.dtype), padding=1).reshape(O_, I_, 4, 4)
+    y = F.conv2d(E.qb(x), E.qw(w4), None, stride=2, padding=1)
+    b = P.get(name + ".bias")
+    return y if b is None else y + b.view(1, -1, 1, 1)
+
+
+def conv_up_quad(x, P, B, name, sn_iter, E):
+    """conv3x3(nearest_up2(x)) as the kernel computes it: output parity (a, b) = conv2x2(x; R_a w R_b^T), R_0 = [[1,0,0],[0,1,1]], R_1 = [[1,1,0],[0,0,1]]"""
+    w = E.qw(weight_of(P, B, name, sn_iter))
+    R = [torch.tensor([[1., 0., 0.], [0., 1., 1.]], dtype=w.dtype), torch.tensor([[1., 1., 0.], [0., 0., 1.]], dtype=w.dtype)]
+    N, _, H, W = x.shape
+    rows = []
+    for a in (0, 1):
+        cols = []
+        for b in (0, 1):
+            wq = E.qw(torch.einsum("tr,oirs,us->oitu", R[a], w, R[b]))
+            cols.append(F.conv2d(F.pad(x, (1 - b, b, 1 - a, a)), wq))
+        rows.append(torch.stack(cols, dim=-1).reshape(N, -1, H, 2 * W))          # interleave the two column parities
+    y = torch.stack(rows, dim=-2).reshape(N, -1, 2 * H, 2 * W)                       # interleave the two row parities
+    bia = P.get(name + ".bias")
+    return y if bia is None else y + bia.view(1, -1, 1, 1)
+
+
 def conv_strided(x, P, B, name, stride, padding, sn_iter=True, E=IDENT):
     return F.conv2d(E.qb(x), E.qw(weight_of(P, B, name, sn_iter)), P.get(name + ".bias"), stride=stride, padding=padding)
 
@@ -205,8 +245,11 @@ def biggan_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
         pre = f"blocks.{bi}.0"
         x0 = act
         x = E.q(torch.relu(cond_batch_norm(E.qb(act), affines[index], P, B, pre + ".bn1", bn_mode, sn_iter)))
-        x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
-        x = E.q(conv(x, P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
+        if E.emulate and cfg.get("quad_emu", True) and quad_eligible(_w(P, pre + ".conv2d1")):
+            x = E.q(conv_up_quad(E.qb(x), P, B, pre + ".conv2d1", sn_iter, E))
+        else:
+            x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
+            x = E.q(conv(x, P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
         x = E.q(torch.relu(cond_batch_norm(E.qb(x), affines[index], P, B, pre + ".bn2", bn_mode, sn_iter)))
         x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E))
         x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
@@ -236,6 +279,8 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
             if not sn:
                 y = E.q(torch.relu(batch_norm(E.qb(y), P, B, pre + ".bn1", bn_mode)))
                 y = E.q(F.avg_pool2d(conv(y, P, B, pre + ".conv2d2", 1, sn_iter, E), 2))
+            elif E.emulate and cfg.get("quad_emu", True) and quad_eligible(_w(P, pre + ".conv2d2")):
+                y = E.q(conv_pool_quad(torch.relu(y), P, B, pre + ".conv2d2", sn_iter, E))
             else:
                 y = E.q(F.avg_pool2d(conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E), 2))
             x0 = E.q(F.avg_pool2d(E.qb(x0), 2))
@@ -255,9 +300,13 @@ def biggan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
             if not sn:
                 y = E.q(torch.relu(batch_norm(E.qb(y), P, B, pre + ".bn2", bn_mode)))
                 y = conv(y, P, B, pre + ".conv2d2", 1, sn_iter, E)
+            elif down and E.emulate and cfg.get("quad_emu", True) and quad_eligible(_w(P, pre + ".conv2d2")):
+                y = conv_pool_quad(torch.relu(y), P, B, pre + ".conv2d2", sn_iter, E)
             else:
                 y = conv(torch.relu(y), P, B, pre + ".conv2d2", 1, sn_iter, E)
-            if down:
+                if down:
+                    y = F.avg_pool2d(y, 2)
+            if down and not sn:
                 y = F.avg_pool2d(y, 2)
             y = E.q(y)
             if down or mismatch:
@@ -308,9 +357,12 @@ def biggan_deep_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
             x = E.q(torch.relu(cond_batch_norm(E.qb(act), affine, P, B, pre + ".bn1", bn_mode, sn_iter)))
             x = E.q(conv(x, P, B, pre + ".conv2d1", 0, sn_iter, E))
             x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn2", bn_mode, sn_iter)))
-            if up:
-                x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
-            x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E, qb_in=not up))
+            if up and E.emulate and cfg.get("quad_emu", True) and quad_eligible(_w(P, pre + ".conv2d2")):
+                x = E.q(conv_up_quad(E.qb(x), P, B, pre + ".conv2d2", sn_iter, E))
+            else:
+                if up:
+                    x = F.interpolate(E.qb(x), scale_factor=2, mode="nearest")
+                x = E.q(conv(x, P, B, pre + ".conv2d2", 1, sn_iter, E, qb_in=not up))
             x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn3", bn_mode, sn_iter)))
             x = E.q(conv(x, P, B, pre + ".conv2d3", 1, sn_iter, E))
             x = E.q(torch.relu(cond_batch_norm(E.qb(x), affine, P, B, pre + ".bn4", bn_mode, sn_iter)))

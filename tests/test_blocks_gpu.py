@@ -585,21 +585,11 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
 
     if teacher and taps.act:
         # ---- teacher-forced pass: every block on the oracle's own input and upstream gradient ------------------------------------------------
-        from studiogan_amd import functional as SF
-        if which == "G" and full and SF._QUAD[0]:
-            # The upsample + 3x3 layers run through the phase-filter identity (csrc/conv_q.h): their bf16 filter image is the rounded SUM of the
-            # taps that share a source pixel -- one rounding per filter entry, like the oracle's, but not the same one. Inside a generator block
-            # that extra 2e-3 flips more ReLU units behind the cBN than the single-rounding floor model allows for (measured, session r4k:
-            # with SG_QUAD=0 every tensor is within 1.5 x floor; with the quad kernels conv2d1's weight gradient sits at 2.6 x). So: the 3x3
-            # kernels must meet the 1.5 x bound, the quad kernels 3 x -- and are pinned bit-tight against torch in tests/test_quad_gpu.py.
-            SF._QUAD[0] = False
-            try:
-                run_teacher(" (3x3 kernels)", FLOOR_FACTOR)
-            finally:
-                SF._QUAD[0] = True
-            run_teacher("", 2 * FLOOR_FACTOR)
-        else:
-            run_teacher("", FLOOR_FACTOR)
+        # (The emulating oracle restates the quad kernels' filter rounding -- oracle/restate.py conv_pool_quad / conv_up_quad -- so the layers next
+        # to a 2x resampling are modelled at the same storage points as every other layer. Before it did, session r4j / r4k: with SG_QUAD=0 every
+        # generator tensor was within 1.5 x floor, with the quad kernels conv2d1's weight gradient sat at 2.6 x -- the filter-sum rounding flips more
+        # ReLU units behind the cBN than a single-rounding model allows for.)
+        run_teacher("", FLOOR_FACTOR)
         if tfl:
             C.rows.append((which + " teacher-forced WORST oracle-own-floor", max(tfl.values()), float("inf")))
     if report is not None:

@@ -44,3 +44,24 @@ def test_quad_fold_is_transpose_of_pack():
         w = torch.randn(3, 3, 3, 2, generator=g, dtype=torch.float64)
         q = torch.randn(3, 4, 4, 2, generator=g, dtype=torch.float64)
         assert abs(float((Q.quad_pack_ref(w, mode) * q).sum() - (w * Q.quad_fold_ref(q, mode)).sum())) < 1e-10
+
+
+def test_oracle_quad_emulation_is_the_reference_op_without_rounding():
+    """oracle/restate.py conv_pool_quad / conv_up_quad (the bf16-emulating oracle's restatement of the quad kernels' filter rounding) with the
+    rounding switched off are exactly conv3x3 + avg_pool2d / interpolate + conv3x3, values and gradients"""
+    import torch.nn.functional as F_
+    from oracle import restate as O
+    g = torch.Generator().manual_seed(9)
+    w = torch.randn(64, 32, 3, 3, generator=g, dtype=torch.float64).requires_grad_(True)
+    b = torch.randn(64, generator=g, dtype=torch.float64)
+    P = {"c.weight": w, "c.bias": b}
+    assert O.quad_eligible(w)
+    x = torch.randn(2, 32, 8, 8, generator=g, dtype=torch.float64).requires_grad_(True)
+    for fn, ref in ((O.conv_pool_quad, lambda: F_.avg_pool2d(F_.conv2d(x, w, b, padding=1), 2)),
+                    (O.conv_up_quad, lambda: F_.conv2d(F_.interpolate(x, scale_factor=2, mode="nearest"), w, b, padding=1))):
+        y, yr = fn(x, P, {}, "c", False, O.IDENT), ref()
+        assert torch.allclose(y, yr, atol=1e-12)
+        gy = torch.randn(yr.shape, generator=g, dtype=torch.float64)
+        ga = torch.autograd.grad(y, (x, w), gy)
+        gb = torch.autograd.grad(yr, (x, w), gy)
+        assert torch.allclose(ga[0], gb[0], atol=1e-11) and torch.allclose(ga[1], gb[1], atol=1e-10)
