@@ -73,13 +73,19 @@ def per_kernel_table(L, nsteps, peak, pmc=None):
             # kernel templates over the algorithmic bytes; a weight-gradient family includes the split-K reduce launches that follow its kernels
             key = name.split(" ")[0].split("<")[0]
             skip = "SKIP" in name
+            def targs(k):
+                a = k[k.index("<") + 1:k.rindex(">")] if "<" in k and ">" in k else ""
+                return [t.strip() for t in a.split(",")]
+
             def member(k):
                 if key not in k:
                     return False
-                if key == "sg_conv_v4_kernel":
-                    return k.rstrip().endswith("true>") == skip
-                if key == "sg_conv_q_kernel":
-                    return k.rstrip().endswith("true>") == skip
+                if key == "sg_conv_v4_kernel":      # template <NB, RELU, UP, TJW, SKIP>
+                    a = targs(k)
+                    return (len(a) > 4 and a[4] == "true") == skip
+                if key == "sg_conv_q_kernel":       # template <NB, RELU, TJW, SKIP, NPMIN>
+                    a = targs(k)
+                    return (len(a) > 3 and a[3] == "true") == skip
                 if key == "sg_gemm_kernel":
                     return "ConvPix" in k
                 return True

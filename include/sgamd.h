@@ -250,7 +250,7 @@ int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, c
 /* backward, stage 1: per-(n,c) sums of dy' and dy'*xhat where dy' = dy * relu-mask; sums[N][C][2] fp32 (overwritten) */
 int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N, long long HW, int C, const float* mean, const float* invstd,
                      const float* gain, const float* bias, int gb_stride_n, int relu, float* sums, sg_stream_t s);
-/* stage 2: from sums -> dgain/dbias ([N][C] when per-sample else [C], accumulated +=) and the per-channel
+/* stage 2: from sums -> dgain/dbias ([N] rows of pitch gb_stride_n when per-sample else [C], accumulated +=) and the per-channel
  * batch terms chan[C][2] = {sum_n gain*S1, sum_n gain*S2} in fp64 (for the cross-rank all-reduce) */
 int sg_bn_bwd_finalize(const float* sums, int N, int C, const float* gain, int gb_stride_n, float* dgain, float* dbias,
                        double* chan, sg_stream_t s);

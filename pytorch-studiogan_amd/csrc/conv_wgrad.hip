@@ -72,7 +72,7 @@ static V3Plan wgrad_v3_plan(const sg_conv_wgrad_desc* d) {
   if (d->C % 32 || d->ldx % 8 || d->ldg % 8 || !aligned16(d->x) || !aligned16(d->dy)) return s;
   if (d->Cout % 96 == 0) s.NB = 3; else if (d->Cout % 64 == 0) s.NB = 2; else return s;
   const long long K = (long long)d->N * d->Ho * d->Wo;
-  if (K % 64 || (!force && K < 16384) || K >= (1ll << 31)) return s;
+  if (K % 64 || (!force && K < (d->Wo == 4 ? 4096 : 16384)) || K >= (1ll << 31)) return s;      // (4 x 4 layers: 16 pixels per image, batch 256 = 4096)
   if ((long long)d->N * d->xHs * d->xWs * d->ldx * 2 >= (1ll << 31) || (long long)d->N * d->gHs * d->gWs * d->ldg * 2 >= (1ll << 31)) return s;
   s.nci = d->C / 32; s.nco = d->Cout / (32 * s.NB); s.nchunk = (int)(K / 64);
   s.n = 9ll * d->C * d->Cout;

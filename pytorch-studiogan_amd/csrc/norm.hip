@@ -379,9 +379,9 @@ __global__ __launch_bounds__(1024) void k_bn_bwd_finalize(const float* sums, int
       const float s1 = sums[((long long)n * C + c) * 2], s2 = sums[((long long)n * C + c) * 2 + 1];
       const float ga = gain ? gain[(long long)n * gsn + c] : 1.f;
       a0 += (double)ga * s1; a1 += (double)ga * s2;
-      if (gsn) {
-        if (dgain) dgain[(long long)n * C + c] += s2;
-        if (dbias) dbias[(long long)n * C + c] += s1;
+      if (gsn) {     // per-sample gain / bias gradients at the row pitch of gain / bias themselves (gsn == C, or 2 C for the packed [gain | bias] rows of a cBN)
+        if (dgain) dgain[(long long)n * gsn + c] += s2;
+        if (dbias) dbias[(long long)n * gsn + c] += s1;
       } else { g0 += s1; g1 += s2; }
     }
   }

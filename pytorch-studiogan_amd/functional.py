@@ -45,6 +45,7 @@ def _c(t):
 _SEQ = [0]
 _STATS_OFFER = [None]      # (seq, data_ptr, shape, per-tile sums [rows][C][2], rows, C)
 _BN_FUSED_STATS = [os.environ.get("SG_BN_FUSED_STATS", "1") != "0"]
+_CBN_MERGED = [os.environ.get("SG_CBN_MERGED", "1") != "0"]      # gain + bias linears of a conditional batch norm as one GEMM (CbnAffineFn)
 
 
 def _tick():
@@ -797,6 +798,60 @@ class LinearFn(torch.autograd.Function):
         return dx, None, None, None, None, None
 
 
+class CbnAffineFn(torch.autograd.Function):
+    """[1 + gain(y) | bias(y)] of a ConditionalBatchNorm2d (reference src/utils/ops.py:21-27: two (sn)linear layers without bias on the same
+    conditioning vector) as ONE fp32 GEMM over the 2 C rows of the two weight images, which sit back to back in the network's bank: the two
+    linears were ~125 launches of 28-42 us per C3 step (forward, data gradient, weight gradient). Returns the packed [B][2 C] tensor BNFn takes
+    with cfg.packed; falls back to two GEMMs writing the two halves when the images are not adjacent."""
+
+    @staticmethod
+    def forward(ctx, y, wg, wb, rt_g, rt_b, slot, const2):
+        bank = rt_g.bank()
+        y = _c(y.float())
+        B, K = y.shape
+        C = rt_g.rows
+        assert K == rt_g.cols == rt_b.cols and rt_b.rows == C
+        out = torch.empty((B, 2 * C), dtype=torch.float32, device=y.device)
+        pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
+        ctx.adjacent = pb == pg + 4 * C * K
+        if ctx.adjacent:
+            gemm_raw(L.F32, pg, 0, K, y, 0, K, out, 2 * C, 2 * C, B, K, bias=const2)
+        else:
+            gemm_raw(L.F32, pg, 0, K, y, 0, K, out, 2 * C, C, B, K, bias=const2)
+            gemm_raw(L.F32, pb, 0, K, y, 0, K, out.data_ptr() + 4 * C, 2 * C, C, B, K)
+        ctx.save_for_backward(y)
+        ctx.rt_g, ctx.rt_b, ctx.slot = rt_g, rt_b, slot
+        return out
+
+    @staticmethod
+    def backward(ctx, dgb):
+        _first_order_only("CbnAffineFn")
+        (y,) = ctx.saved_tensors
+        rt_g, rt_b, slot = ctx.rt_g, ctx.rt_b, ctx.slot
+        bank = rt_g.bank()
+        dgb = _c(dgb.float())
+        B, K = y.shape
+        C = rt_g.rows
+        pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
+        dg, db = (bank.dwt(slot, rt_g), bank.dwt(slot, rt_b)) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else (None, None)
+        adjacent = ctx.adjacent and (dg is None or db == dg + 4 * C * K)
+        dy = None
+        if ctx.needs_input_grad[0]:
+            dy = torch.empty((B, K), dtype=torch.float32, device=y.device)
+            if adjacent:      # dy[b][k] = sum over the 2 C rows of dgb[b][o] W[o][k]
+                gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, 2 * C)
+            else:
+                gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, C)
+                gemm_raw(L.F32, pb, 1, K, dgb.data_ptr() + 4 * C, 0, 2 * C, dy, K, K, B, C, res=dy, ldr=K)
+        if dg is not None:
+            if adjacent:      # dW[o][k] = sum_b dgb[b][o] y[b][k], o over the 2 C rows
+                gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, 2 * C, B)
+            else:
+                gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, C, B)
+                gemm_raw(L.F32, y, 1, K, dgb.data_ptr() + 4 * C, 1, 2 * C, db, K, K, C, B)
+        return dy, None, None, None, None, None, None
+
+
 class EmbeddingFn(torch.autograd.Function):
     """Plain (non-SN) embedding lookup, e.g. G's shared class embedding (reference src/models/big_resnet.py:98,136)."""
 
@@ -852,10 +907,11 @@ class SNEmbeddingFn(torch.autograd.Function):
 # (conditional) batch norm
 # ---------------------------------------------------------------------------------------------------------
 class BNCfg:
-    __slots__ = ("batch_stats", "track", "eps", "momentum", "relu", "group")
+    __slots__ = ("batch_stats", "track", "eps", "momentum", "relu", "group", "packed")
 
-    def __init__(self, batch_stats, track, eps, momentum, relu, group=None):
+    def __init__(self, batch_stats, track, eps, momentum, relu, group=None, packed=False):
         self.batch_stats, self.track, self.eps, self.momentum, self.relu, self.group = batch_stats, track, eps, momentum, relu, group
+        self.packed = packed      # `gain` is the packed per-sample [N][gain(C) | bias(C)] tensor of a conditional batch norm (CbnAffineFn), `bias` is None
 
 
 def _world(group):
@@ -923,7 +979,12 @@ class BNFn(torch.autograd.Function):
         else:
             L.call("sg_bn_from_running", L.ptr(running_mean), L.ptr(running_var), Cc, cfg.eps, L.ptr(mean), L.ptr(invstd), L.stream())
         gsn = 0
-        if gain is not None:
+        bias_ptr_off = 0
+        if cfg.packed:
+            gain = _c(gain.float())
+            assert bias is None and gain.dim() == 2 and gain.shape[1] == 2 * Cc
+            gsn, bias_ptr_off = 2 * Cc, 4 * Cc
+        elif gain is not None:
             gain = _c(gain.float())
             gsn = Cc if gain.dim() == 2 else 0
         if bias is not None:
@@ -932,7 +993,8 @@ class BNFn(torch.autograd.Function):
             if gain is None:
                 gsn = Cc if bias.dim() == 2 else 0
         y = torch.empty_like(x)
-        L.call("sg_bn_apply", L.dt(x), L.ptr(x), L.ptr(y), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), gsn, 1 if cfg.relu else 0, L.stream())
+        bptr = (L.ptr(gain) + bias_ptr_off) if cfg.packed else L.ptr(bias)
+        L.call("sg_bn_apply", L.dt(x), L.ptr(x), L.ptr(y), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), bptr, gsn, 1 if cfg.relu else 0, L.stream())
         ctx.save_for_backward(x, gain, bias, mean, invstd)
         ctx.cfg, ctx.gsn, ctx.count = cfg, gsn, count
         return y
@@ -954,18 +1016,20 @@ class BNFn(torch.autograd.Function):
         if skip_dx is not None and not ctx.needs_input_grad[0]:
             raise RuntimeError("GradLink: a skip gradient was handed over but this batch norm's input needs no gradient")
         sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
-        L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), gsn,
+        bptr = (L.ptr(gain) + 4 * Cc) if cfg.packed else L.ptr(bias)       # packed cBN rows: [gain(C) | bias(C)], pitch gsn = 2 C
+        L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), bptr, gsn,
                1 if cfg.relu else 0, L.ptr(sums), L.stream())
         chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
         dgain = torch.zeros_like(gain) if (gain is not None and ctx.needs_input_grad[1]) else None
         dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
-        L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), gsn, L.ptr(dgain), L.ptr(dbias), L.ptr(chan), L.stream())
+        dbptr = ((L.ptr(dgain) + 4 * Cc) if dgain is not None else None) if cfg.packed else L.ptr(dbias)
+        L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), gsn, L.ptr(dgain), dbptr, L.ptr(chan), L.stream())
         dx = None
         if ctx.needs_input_grad[0]:
             if cfg.batch_stats and _world(cfg.group) > 1:
                 _allreduce_sum(chan, cfg.group)
             dx = torch.empty_like(x)
-            L.call("sg_bn_bwd_apply_res", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias),
+            L.call("sg_bn_bwd_apply_res", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(dx), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), bptr,
                    gsn, 1 if cfg.relu else 0, L.ptr(chan), ctx.count, 1 if cfg.batch_stats else 0, L.ptr(_c(skip_dx) if skip_dx is not None else None), L.stream())
         return (dx, dgain, dbias, None, None, None) + (None,) * ctx.nopt
 

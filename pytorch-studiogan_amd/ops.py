@@ -214,8 +214,9 @@ class BatchNorm2d(nn.BatchNorm2d):
         mom = 0.0 if self.momentum is None else self.momentum
         return F.BNCfg(batch_stats, track, self.eps, mom, relu, self.sync_group)
 
-    def forward_nhwc(self, x, gain=None, bias=None, relu=False, link=None):
+    def forward_nhwc(self, x, gain=None, bias=None, relu=False, link=None, packed=False):
         cfg = self._cfg(relu)
+        cfg.packed = packed
         if cfg.track and self.num_batches_tracked is not None:
             self.num_batches_tracked.add_(1)
         if gain is None and self.affine:
@@ -237,8 +238,15 @@ class ConditionalBatchNorm2d(nn.Module):
         self.gain = MODULES.g_linear(in_features=in_features, out_features=out_features, bias=False)
         self.bias = MODULES.g_linear(in_features=in_features, out_features=out_features, bias=False)
         self.register_buffer("_ones", torch.ones(out_features), persistent=False)
+        self.register_buffer("_ones2", torch.cat([torch.ones(out_features), torch.zeros(out_features)]), persistent=False)
 
     def forward_nhwc(self, x, y, slot=None, relu=False, link=None):
+        if F._CBN_MERGED[0] and self.gain.bias is None and self.bias.bias is None:
+            # [1 + gain(y) | bias(y)] as one GEMM over the two adjacent weight images (functional.CbnAffineFn); the '1 +' rides in its epilogue bias
+            rt_g, rt_b = self.gain._sg_rt, self.bias._sg_rt
+            slot = slot if slot is not None else rt_g.bank().current
+            gb = F.CbnAffineFn.apply(y, self.gain.master_weight, self.bias.master_weight, rt_g, rt_b, slot, self._ones2)
+            return self.bn.forward_nhwc(x, gb, None, relu, link, packed=True)
         gain = self.gain.forward_rt(y, slot, const_bias=self._ones)  # 1 + gain(y) through the GEMM epilogue bias
         bias = self.bias.forward_rt(y, slot)
         return self.bn.forward_nhwc(x, gain, bias, relu, link)
