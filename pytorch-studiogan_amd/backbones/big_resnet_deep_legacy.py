@@ -41,7 +41,7 @@ class GenBlock(nn.Module):
         h = self.bn1.forward_nhwc(x, affine, slot, relu=True)
         h = self.conv2d1.forward_nhwc(h, slot)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
-        h = self.conv2d2.forward_nhwc(h, slot, in_upsample=self.upsample)
+        h = self.conv2d2.forward_nhwc(h, slot, in_upsample=self.upsample, stats=self.upsample)      # (bn3's statistics from the quad launch's epilogue)
         h = self.bn3.forward_nhwc(h, affine, slot, relu=True)
         h = self.conv2d3.forward_nhwc(h, slot)
         h = self.bn4.forward_nhwc(h, affine, slot, relu=True)

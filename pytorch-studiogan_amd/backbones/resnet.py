@@ -34,10 +34,11 @@ class GenBlock(nn.Module):
     def forward_nhwc(self, x, affine, slot):
         link = F.GradLink()      # x feeds bn1 and the skip: bn1's backward adds the skip's gradient in its own launch
         h = self.bn1.forward_nhwc(x, affine, slot, relu=True, link=link) if self.conditional else self.bn1.forward_nhwc(x, relu=True, link=link)
-        h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True)
+        # (stats=True: a batch norm reads the result next; where the kernel can, its statistics come out of the convolution's epilogue)
+        h = self.conv2d1.forward_nhwc(h, slot, in_upsample=True, stats=True)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True) if self.conditional else self.bn2.forward_nhwc(h, relu=True)
         # conv2d2(h) + conv2d0(up(x)): one launch where the fused kernel takes the shape (bf16; functional.ConvSkipFn), two otherwise
-        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True, link=link)
+        return ops.conv_skip_nhwc(self.conv2d2, self.conv2d0, h, x, slot, skip_upsample=True, link=link, stats=True)
 
 
 class Generator(nn.Module):
