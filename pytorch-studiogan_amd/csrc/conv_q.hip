@@ -238,7 +238,6 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   const double c2 = d->x2 ? (double)d->C2 : 0.0;      // the fused skip stands for a 1x1 convolution over the fine grid
   const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * (16.0 * (double)d->C + 4.0 * c2));
-  // SG_CONV_Q_DB=1: the double-buffered-patch variant (conv_q.h NPMIN; two workgroups per CU) -- A/B switch
   // double-buffered-patch variant (conv_q.h NPMIN; two workgroups per CU). Measured (profiles/r04_quad_bench_l_db.txt): slower than the three
   // single-buffered workgroups everywhere (sum of the C3 layers 4.79 -> 5.07 ms forward, 4.97 -> 5.43 ms data gradient) EXCEPT on the 4 x 4
   // low-resolution grids of the UP form (0.349 -> 0.307 and 0.367 -> 0.318 ms), whose patches are 16 images of 16 pixels and whose slices are
