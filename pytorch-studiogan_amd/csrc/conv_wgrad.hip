@@ -5,6 +5,7 @@
 #include "wgrad_v2.h"
 #include "wgrad_sk.h"
 #include "wgrad_v3.h"
+#include "wgrad_v3l.h"
 
 // ---- thin layers: streaming kernel (wgrad_sk.h). SG_WGRAD_SK=0 disables it. -----------------------------------------------------
 struct SkPlan { bool ok, taps; int NI, NJ, swap, nw; long long n; };
@@ -98,6 +99,8 @@ static int wgrad_v3_launch(const sg_conv_wgrad_desc* d, const V3Plan& s, hipStre
   p.out = d->work; p.split_stride = s.stride;
   p.bias_off = d->dbias ? s.n : -1; p.bias_scale = p.g_up ? 0.25f : 1.f;
   p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
+  // SG_WGRAD_V3_LEAN=1: the lean variant (wgrad_v3l.h) -- A/B switch, read per call; off until it has run on a GPU
+  if (const char* m = getenv("SG_WGRAD_V3_LEAN")) { if (m[0] == '1') return sg_launch_wgrad_v3l(p, s.NB, st); }
   return sg_launch_wgrad_v3(p, s.NB, st);
 }
 

@@ -1,0 +1,164 @@
+"""hipemu driver (TEST INFRASTRUCTURE): builds a translation unit of pytorch-studiogan_amd/csrc for the host against tests/hipemu/include and loads it with
+ctypes. The library exports the SAME C entry points as libsgamd.so for that translation unit (e.g. sg_conv2d_wgrad from conv_wgrad.hip), so a test
+fills the same descriptor the product fills and gets the result the kernel's own index arithmetic produces -- on numpy arrays, without a GPU."""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+SRC = os.path.join(BUILD, "src")
+CXX = "/opt/rocm/lib/llvm/bin/clang++"
+sys.path.insert(0, HERE)
+import translate  # noqa: E402
+
+_vp, _i, _f, _ll = C.c_void_p, C.c_int, C.c_float, C.c_longlong
+
+# field lists: include/sgamd.h (tests/test_host_cpu.py checks the product's copies of these against the header; test_hipemu_cpu.py checks these against the product's)
+WGRAD_FIELDS = [("dtype", _i), ("N", _i), ("xHs", _i), ("xWs", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("gHs", _i), ("gWs", _i),
+                ("Cout", _i), ("ldg", _i), ("g_flags", _i), ("Ho", _i), ("Wo", _i), ("R", _i), ("S", _i), ("stride", _i),
+                ("pad_h", _i), ("pad_w", _i), ("alpha", _f), ("x", _vp), ("dy", _vp), ("dw", _vp), ("alpha_ptr", _vp),
+                ("splits", _i), ("no_tr", _i), ("work", _vp), ("work_floats", _ll), ("dbias", _vp)]
+
+
+class ConvWgradDesc(C.Structure):
+    _fields_ = WGRAD_FIELDS
+
+
+BF16, PIX_RELU, PIX_UPSAMPLE = 1, 1, 2
+
+
+def available():
+    return os.path.exists(CXX)
+
+
+def build(unit, opt="-O1"):
+    """translate csrc, compile <unit>.hip + stubs.cpp for the host; returns the library path (cached on the translated sources' hash)"""
+    translate.translate_tree(SRC)
+    deps = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if f.endswith(".h")] + [os.path.join(SRC, unit + ".hip"),
+            os.path.join(HERE, "stubs.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+    h = hashlib.sha256()
+    for d in deps:
+        with open(d, "rb") as f:
+            h.update(f.read())
+    h.update(opt.encode())
+    lib = os.path.join(BUILD, "libemu_%s_%s.so" % (unit, h.hexdigest()[:12]))
+    if not os.path.exists(lib):
+        for old in os.listdir(BUILD):
+            if old.startswith("libemu_%s_" % unit):
+                os.remove(os.path.join(BUILD, old))
+        cmd = [CXX, "-x", "c++", "-std=c++17", opt, "-fPIC", "-shared", "-I" + os.path.join(HERE, "include"), "-I" + SRC,
+               "-Wno-unknown-attributes", "-Wno-unused-value", os.path.join(SRC, unit + ".hip"), os.path.join(HERE, "stubs.cpp"), "-o", lib + ".tmp"]
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipemu build of %s failed:\n%s" % (unit, r.stdout[-4000:]))
+        os.rename(lib + ".tmp", lib)
+    return lib
+
+
+_libs = {}
+
+
+def load(unit):
+    if unit not in _libs:
+        _libs[unit] = C.CDLL(build(unit))
+        _libs[unit].sg_last_error.restype = C.c_char_p
+    return _libs[unit]
+
+
+def config(lib, dma_late=0, greedy=0, seed=0):
+    lib.hipemu_config(int(dma_late), int(greedy), C.c_uint(seed))
+
+
+def counters(lib):
+    out = (C.c_long * 5)()
+    lib.hipemu_counters(out)
+    return dict(zip(("launches", "blocks", "mfma", "dma_ops", "tr_reads"), list(out)))
+
+
+# ---- bf16 helpers (numpy has no bfloat16: uint16 bit patterns, round to nearest even like torch) -------------------------------------------------
+def to_bf16(a):
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    u = a.view(np.uint32).astype(np.uint64)
+    r = ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)
+    return r
+
+
+def from_bf16(b):
+    return (b.astype(np.uint32) << 16).view(np.float32)
+
+
+def ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def aligned(shape, dtype, align=64):
+    n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+    raw = np.zeros(n + align, dtype=np.uint8)
+    off = (-raw.ctypes.data) % align
+    return raw[off:off + n].view(dtype).reshape(shape)
+
+
+def conv_wgrad(lib, x, dy, Cout, x_flags=0, g_flags=0, alpha=1.0, bias=False, splits=0, env=None):
+    """x: uint16 bf16 [N][xHs][xWs][C], dy: uint16 bf16 [N][gHs][gWs][Cout]; 3x3 / stride 1 / pad 1. Returns (dw fp32 [Cout][3][3][C], dbias or None)
+    through the translation unit's own sg_conv2d_wgrad_plan + sg_conv2d_wgrad (workspace form: the deterministic two-stage reduction)."""
+    N, xHs, xWs, Cin = x.shape
+    _, gHs, gWs, _ = dy.shape
+    up = 2 if (x_flags & PIX_UPSAMPLE) else 1
+    Ho, Wo = xHs * up, xWs * up
+    gup = 2 if (g_flags & PIX_UPSAMPLE) else 1
+    assert (gHs * gup, gWs * gup) == (Ho, Wo)
+    xa = aligned(x.shape, np.uint16); xa[...] = x
+    ga = aligned(dy.shape, np.uint16); ga[...] = dy
+    dw = aligned((Cout, 3, 3, Cin), np.float32)
+    db = aligned((Cout,), np.float32) if bias else None
+    d = ConvWgradDesc(dtype=BF16, N=N, xHs=xHs, xWs=xWs, C=Cin, ldx=Cin, x_flags=x_flags, gHs=gHs, gWs=gWs, Cout=Cout, ldg=Cout, g_flags=g_flags,
+                      Ho=Ho, Wo=Wo, R=3, S=3, stride=1, pad_h=1, pad_w=1, alpha=alpha, x=ptr(xa), dy=ptr(ga), dw=ptr(dw), alpha_ptr=None,
+                      splits=splits, no_tr=0, work=None, work_floats=0, dbias=ptr(db) if bias else None)
+    old = {}
+    for k, v in (env or {}).items():
+        old[k] = os.environ.get(k)
+        os.environ[k] = v
+    try:
+        sp, wf = C.c_int(0), C.c_longlong(0)
+        if lib.sg_conv2d_wgrad_plan(C.byref(d), C.byref(sp), C.byref(wf)) != 0:
+            raise RuntimeError(lib.sg_last_error())
+        work = aligned((max(int(wf.value), 1),), np.float32)
+        d.work, d.work_floats, d.splits = ptr(work), wf.value, sp.value
+        fused = bias and lib.sg_conv2d_wgrad_fuses_bias(C.byref(d)) == 1
+        if bias and not fused:
+            d.dbias = None
+        if lib.sg_conv2d_wgrad(C.byref(d), None) != 0:
+            raise RuntimeError(lib.sg_last_error())
+    finally:
+        for k, v in old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+    return dw, (db if bias and fused else None), sp.value
+
+
+def wgrad_ref(x, dy, x_flags=0, g_flags=0, alpha=1.0):
+    """fp64 restatement of include/sgamd.h's formula for the 3x3 / pad-1 weight gradient on bf16 inputs"""
+    xf = from_bf16(x).astype(np.float64)
+    gf = from_bf16(dy).astype(np.float64)
+    if x_flags & PIX_UPSAMPLE:
+        xf = xf.repeat(2, axis=1).repeat(2, axis=2)
+    if x_flags & PIX_RELU:
+        xf = np.maximum(xf, 0)
+    if g_flags & PIX_UPSAMPLE:
+        gf = gf.repeat(2, axis=1).repeat(2, axis=2)
+    N, H, W, Cin = xf.shape
+    xp = np.zeros((N, H + 2, W + 2, Cin))
+    xp[:, 1:-1, 1:-1] = xf
+    dw = np.zeros((gf.shape[3], 3, 3, Cin))
+    for r in range(3):
+        for s in range(3):
+            dw[:, r, s, :] = np.einsum("nhwk,nhwc->kc", gf, xp[:, r:r + H, s:s + W], optimize=True)
+    db = from_bf16(dy).astype(np.float64).sum(axis=(0, 1, 2))      # over the STORED dy pixels (sgamd.h)
+    return alpha * dw, db

@@ -1,0 +1,470 @@
+// hipemu -- a lane-accurate CPU interpreter for the gfx950 kernels of pytorch-studiogan_amd/csrc, TEST INFRASTRUCTURE ONLY.
+//
+// The kernel sources are compiled for the HOST (x86, amdclang++) against this header instead of the HIP runtime, after tests/hipemu/translate.py
+// has rewritten the constructs a host compiler cannot take (inline gfx950 assembly, address-space casts, `__shared__` declarations). Every
+// thread of a workgroup is a fibre (ucontext); the cross-lane instructions the kernels are built from -- MFMA, the LDS transpose read,
+// LDS-DMA (`buffer_load ... lds`), DPP, shuffles, barriers, `s_waitcnt vmcnt` -- are executed with the semantics MI355X_MICROARCH.md /
+// cdna_hip_programming.md document, per wave, once all live lanes of the wave have arrived. What this buys: the index arithmetic, fragment
+// layouts, staging addresses and result layouts of a kernel are checked on a machine without a GPU, and LDS-DMA completion can be made
+// adversarial (a transfer lands only when a `s_waitcnt vmcnt(n)` / barrier-with-fence forces it, or immediately: HIPEMU_DMA=late|eager) and
+// waves can be scheduled greedily in a seeded order (HIPEMU_SCHED=seed), so missing waits and buffers re-used too early show up as wrong
+// results. What it does not model: timing, bank conflicts, register pressure, the rounding order inside an MFMA (fp32 left-to-right here).
+// The semantics themselves are pinned by running kernels that HAVE passed on the GPU through it (tests/test_hipemu_cpu.py).
+#pragma once
+#include <math.h>
+#include <stddef.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <sys/mman.h>
+#include <ucontext.h>
+
+#include <algorithm>
+#include <deque>
+#include <functional>
+#include <map>
+#include <vector>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+typedef void* hipStream_t;
+typedef int hipError_t;
+enum { hipSuccess = 0 };
+enum { hipFuncAttributeMaxDynamicSharedMemorySize = 8 };
+inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+inline hipError_t hipGetLastError() { return hipSuccess; }
+inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
+
+namespace hipemu {
+
+typedef __attribute__((ext_vector_type(4))) uint32_t e_u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t e_u32x2;
+typedef __attribute__((ext_vector_type(16))) float e_f32x16;
+typedef __attribute__((ext_vector_type(8))) __bf16 e_bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 e_bf16x2;
+typedef __attribute__((ext_vector_type(4))) short e_s16x4;
+
+struct U3 { unsigned x, y, z; };
+struct DmaOp { char* dst; int bytes; uint64_t mask; uint8_t data[64][16]; bool nop; };
+struct Wave;
+struct Wave {
+  int nlive = 0, arrived = 0;
+  unsigned gen = 0;
+  const void* in[64];
+  void* out[64];
+  uint64_t amask = 0;
+  std::function<void(Wave&)> fire;
+  std::deque<DmaOp> dma;
+};
+struct Lane {
+  ucontext_t ctx;
+  char* stack = nullptr;
+  bool done = false;
+  int wave = 0, lane = 0;
+  U3 tid;
+  int wait_kind = 0;      // 0 runnable, 1 wave collective, 2 workgroup barrier
+  unsigned wait_gen = 0;
+};
+struct Block {
+  std::vector<Lane> lanes;
+  std::vector<Wave> waves;
+  int nlive = 0, bar_arrived = 0;
+  unsigned bar_gen = 0;
+  char* lds = nullptr;
+  size_t dyn_size = 0, static_top = 0;
+  std::map<int, size_t> statics;
+  U3 bid;
+};
+struct Config {
+  int dma_late = 0;          // 1: an LDS-DMA transfer lands when a wait forces it; 0: when it is issued
+  int greedy = 0;            // 1: a wave runs until it blocks at a workgroup barrier before the next wave gets a turn
+  unsigned seed = 0;         // wave order permutation
+  long launches = 0, blocks = 0, mfma = 0, dma_ops = 0, tr_reads = 0;
+};
+inline Config g_cfg;
+inline Block* g_blk = nullptr;
+inline Lane* g_cur = nullptr;
+inline ucontext_t g_main;
+inline U3 g_grid, g_bdim;
+inline const std::function<void()>* g_kernel = nullptr;
+inline char* g_lds_arena = nullptr;
+constexpr size_t LDS_BYTES = 160 * 1024;
+constexpr size_t STACK_BYTES = 192 * 1024;
+
+[[noreturn]] inline void die(const char* msg) {
+  fprintf(stderr, "hipemu: %s (block %u,%u thread %u)\n", msg, g_blk ? g_blk->bid.x : 0, g_blk ? g_blk->bid.y : 0, g_cur ? g_cur->tid.x : 0);
+  abort();
+}
+inline void yield_to_main() { swapcontext(&g_cur->ctx, &g_main); }
+
+inline void apply_dma(const DmaOp& op) {
+  if (op.nop) return;
+  for (int l = 0; l < 64; l++)
+    if (op.mask >> l & 1) {
+      char* d = op.dst + (size_t)l * op.bytes;
+      if (d < g_blk->lds || d + op.bytes > g_blk->lds + LDS_BYTES) die("LDS-DMA destination outside the workgroup's LDS");
+      memcpy(d, op.data[l], op.bytes);
+    }
+}
+inline void drain_dma(Wave& w, size_t keep) {
+  while (w.dma.size() > keep) { apply_dma(w.dma.front()); w.dma.pop_front(); }
+}
+
+// a wave-level collective: every live lane of the wave deposits (in, out); the last one to arrive runs `fire` for all of them
+template <class F>
+inline void wave_sync(const void* in, void* out, F fire) {
+  Lane* me = g_cur;
+  Wave& w = g_blk->waves[me->wave];
+  w.in[me->lane] = in; w.out[me->lane] = out; w.amask |= 1ull << me->lane;
+  w.arrived++;
+  if (w.arrived == w.nlive) {
+    fire(w);
+    w.arrived = 0; w.amask = 0; w.gen++; w.fire = nullptr;
+  } else {
+    if (!w.fire) w.fire = [fire](Wave& ww) { fire(ww); };
+    me->wait_kind = 1; me->wait_gen = w.gen;
+    yield_to_main();
+    me->wait_kind = 0;
+  }
+}
+inline void block_barrier() {
+  Lane* me = g_cur;
+  Block& b = *g_blk;
+  b.bar_arrived++;
+  if (b.bar_arrived == b.nlive) { b.bar_arrived = 0; b.bar_gen++; }
+  else { me->wait_kind = 2; me->wait_gen = b.bar_gen; yield_to_main(); me->wait_kind = 0; }
+}
+
+inline void lane_entry() {
+  (*g_kernel)();
+  Lane* me = g_cur;
+  Block& b = *g_blk;
+  Wave& w = b.waves[me->wave];
+  me->done = true;
+  w.nlive--; b.nlive--;
+  if (w.arrived && w.arrived == w.nlive && w.fire) { auto f = w.fire; f(w); w.arrived = 0; w.amask = 0; w.gen++; w.fire = nullptr; }
+  if (w.nlive == 0) drain_dma(w, 0);
+  if (b.bar_arrived && b.bar_arrived == b.nlive) { b.bar_arrived = 0; b.bar_gen++; }
+  // returning resumes uc_link = g_main
+}
+
+inline void configure_from_env() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  if (const char* m = getenv("HIPEMU_DMA")) g_cfg.dma_late = (m[0] == 'l');
+  if (const char* m = getenv("HIPEMU_SCHED")) { g_cfg.greedy = 1; g_cfg.seed = (unsigned)strtoul(m, nullptr, 10); }
+}
+
+inline void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& kernel) {
+  configure_from_env();
+  if (!g_lds_arena) {
+    g_lds_arena = (char*)mmap(nullptr, LDS_BYTES + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_32BIT, -1, 0);
+    if (g_lds_arena == (char*)MAP_FAILED) { perror("mmap"); abort(); }
+    g_lds_arena += 1024;            // LDS address 0 is not where a kernel's image starts in this model: forgetting the base shows
+  }
+  const int nthreads = block.x * block.y * block.z;
+  if (nthreads % 64) { fprintf(stderr, "hipemu: block size %d is not a multiple of 64\n", nthreads); abort(); }
+  if (lds > LDS_BYTES) { fprintf(stderr, "hipemu: %zu B of dynamic LDS\n", lds); abort(); }
+  static std::vector<char*> stacks;
+  while ((int)stacks.size() < nthreads) stacks.push_back((char*)malloc(STACK_BYTES));
+  g_grid = {grid.x, grid.y, grid.z}; g_bdim = {block.x, block.y, block.z};
+  g_kernel = &kernel;
+  g_cfg.launches++;
+  for (unsigned bz = 0; bz < grid.z; bz++)
+    for (unsigned by = 0; by < grid.y; by++)
+      for (unsigned bx = 0; bx < grid.x; bx++) {
+        Block b;
+        b.bid = {bx, by, bz};
+        b.lds = g_lds_arena; b.dyn_size = lds; b.static_top = (lds + 15) & ~(size_t)15;
+        // LDS is NOT cleared between workgroups: a kernel that reads what it never wrote sees the previous workgroup's bytes (first one: 0xCD)
+        if (g_cfg.blocks == 0) memset(g_lds_arena, 0xCD, LDS_BYTES);
+        b.lanes.resize(nthreads); b.waves.resize(nthreads / 64);
+        b.nlive = nthreads;
+        g_blk = &b;
+        for (int t = 0; t < nthreads; t++) {
+          Lane& L = b.lanes[t];
+          L.wave = t / 64; L.lane = t % 64;
+          L.tid = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+          L.stack = stacks[t];
+          getcontext(&L.ctx);
+          L.ctx.uc_stack.ss_sp = L.stack; L.ctx.uc_stack.ss_size = STACK_BYTES; L.ctx.uc_link = &g_main;
+          makecontext(&L.ctx, (void (*)())lane_entry, 0);
+          b.waves[L.wave].nlive++;
+        }
+        std::vector<int> order(b.waves.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        if (g_cfg.greedy) {
+          unsigned s = g_cfg.seed * 2654435761u + bx * 40503u + 12345u;
+          for (size_t i = order.size(); i > 1; i--) { s = s * 1664525u + 1013904223u; std::swap(order[i - 1], order[(s >> 16) % i]); }
+        }
+        int ndone = 0;
+        while (ndone < nthreads) {
+          bool progress = false;
+          for (int wi : order) {
+            bool ran;
+            do {
+              ran = false;
+              for (int l = 0; l < 64; l++) {
+                Lane& L = b.lanes[wi * 64 + l];
+                if (L.done) continue;
+                const bool ok = L.wait_kind == 0 || (L.wait_kind == 1 && b.waves[wi].gen != L.wait_gen) || (L.wait_kind == 2 && b.bar_gen != L.wait_gen);
+                if (!ok) continue;
+                g_cur = &L;
+                swapcontext(&g_main, &L.ctx);
+                if (L.done) ndone++;
+                ran = progress = true;
+              }
+            } while (g_cfg.greedy && ran);
+          }
+          if (!progress) { g_cur = nullptr; die("deadlock: a collective or barrier that not every live lane reaches"); }
+        }
+        g_cfg.blocks++;
+        g_blk = nullptr; g_cur = nullptr;
+      }
+}
+
+// ---- LDS ------------------------------------------------------------------------------------------------------------------------------------
+inline char* dyn_lds() { return g_blk->lds; }
+inline void* static_lds(size_t bytes, int id) {
+  Block& b = *g_blk;
+  auto it = b.statics.find(id);
+  if (it == b.statics.end()) {
+    const size_t off = b.static_top;
+    b.static_top = (off + bytes + 15) & ~(size_t)15;
+    if (b.static_top > LDS_BYTES) die("static LDS overflow");
+    it = b.statics.emplace(id, off).first;
+  }
+  return b.lds + it->second;
+}
+inline unsigned lds_addr(const void* p) { return (unsigned)(uintptr_t)p; }      // the arena sits below 4 GB (MAP_32BIT)
+inline char* lds_ptr(unsigned a) {
+  char* p = (char*)(uintptr_t)a;
+  if (p < g_blk->lds || p + 8 > g_blk->lds + LDS_BYTES) die("LDS address outside the workgroup's LDS");
+  return p;
+}
+
+// ds_read_b64_tr_b16: per 16-lane group, lane t supplies the address of 4 contiguous 16-bit elements M[t][0..3]; lane t receives
+// M[4 k + t / 4][t % 4], k = 0..3 (cdna_hip_programming.md: "column (l & 15) of a 4 x 16 row-major matrix per 16-lane group")
+inline e_s16x4 ds_read_tr16_b64(unsigned addr) {
+  if (addr & 7) die("ds_read_b64_tr_b16 address not 8-byte aligned");
+  e_s16x4 out;
+  wave_sync(&addr, &out, [](Wave& w) {
+    g_cfg.tr_reads++;
+    for (int l = 0; l < 64; l++) {
+      if (!(w.amask >> l & 1)) continue;
+      const int g = l & ~15, t = l & 15;
+      e_s16x4 r;
+      for (int k = 0; k < 4; k++) {
+        const int src = g + 4 * k + t / 4;
+        if (!(w.amask >> src & 1)) die("ds_read_b64_tr_b16 with a partly inactive 16-lane group");
+        const char* p = lds_ptr(*(const unsigned*)w.in[src]);
+        short v; memcpy(&v, p + 2 * (t % 4), 2);
+        r[k] = v;
+      }
+      *(e_s16x4*)w.out[l] = r;
+    }
+  });
+  return out;
+}
+inline e_u32x2 ds_read_tr16_b64_u32x2(unsigned addr) { return __builtin_bit_cast(e_u32x2, ds_read_tr16_b64(addr)); }
+
+// ---- buffer resources, LDS-DMA ---------------------------------------------------------------------------------------------------------------
+struct BufRsrc { const char* base; uint32_t num; };
+inline BufRsrc make_rsrc(const void* p, int /*stride*/, int num, int /*flags*/) { return BufRsrc{(const char*)p, (uint32_t)num}; }
+inline void buf_fetch(const BufRsrc& r, uint32_t off, int bytes, uint8_t* dst) {   // raw buffer: a dword outside [0, num) reads as 0
+  for (int i = 0; i < bytes; i += 4) {
+    const uint32_t o = off + (uint32_t)i;
+    if (o < r.num && o + 4 <= r.num) memcpy(dst + i, r.base + o, 4); else memset(dst + i, 0, 4);
+  }
+}
+struct DmaLaneIn { char* dst; int bytes; uint8_t data[16]; };
+inline void dma_collect(Wave& w) {
+  DmaOp op; op.bytes = 0; op.mask = w.amask; op.dst = nullptr; op.nop = false;
+  for (int l = 0; l < 64; l++) {
+    if (!(w.amask >> l & 1)) continue;
+    const DmaLaneIn* in = (const DmaLaneIn*)w.in[l];
+    if (!op.dst) { op.dst = in->dst; op.bytes = in->bytes; }
+    if (op.dst != in->dst) die("LDS-DMA: the LDS base (M0) differs between lanes of a wave");
+    memcpy(op.data[l], in->data, in->bytes);
+  }
+  g_cfg.dma_ops++;
+  if (g_cfg.dma_late) w.dma.push_back(op); else apply_dma(op);
+}
+// __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds base (wave-uniform), size, voffset, soffset, inst offset, aux):
+// lane l moves `size` bytes from rsrc[voffset + soffset + ioffset] to lds base + ioffset(?) + l * size. (Every call in this tree passes 0, 0.)
+inline void buffer_load_lds(const BufRsrc& r, void* ldsbase, int size, int voff, int soff, int ioff, int /*aux*/) {
+  if (size != 16 && size != 4) die("LDS-DMA size");
+  DmaLaneIn in; in.dst = (char*)ldsbase + ioff; in.bytes = size;
+  buf_fetch(r, (uint32_t)voff + (uint32_t)soff + (uint32_t)ioff, size, in.data);
+  wave_sync(&in, nullptr, dma_collect);
+}
+inline void global_load_lds(const void* g, void* ldsbase, int size, int ioff, int /*aux*/) {
+  DmaLaneIn in; in.dst = (char*)ldsbase + ioff; in.bytes = size;
+  memcpy(in.data, (const char*)g + ioff, size);
+  wave_sync(&in, nullptr, dma_collect);
+}
+inline e_u32x4 buffer_load_b128(const BufRsrc& r, int voff, int soff, int /*aux*/) {
+  e_u32x4 v; buf_fetch(r, (uint32_t)voff + (uint32_t)soff, 16, (uint8_t*)&v);
+  return v;
+}
+inline void buffer_store_b128(e_u32x4 v, const BufRsrc& r, int voff, int soff, int /*aux*/) {
+  const uint32_t o = (uint32_t)voff + (uint32_t)soff;
+  for (int i = 0; i < 4; i++)
+    if (o + 4 * i < r.num && o + 4 * i + 4 <= r.num) memcpy((char*)r.base + o + 4 * i, (const char*)&v + 4 * i, 4);
+}
+// s_waitcnt vmcnt(n): at most n of this wave's vector-memory operations outstanding. Only LDS-DMA is queued (plain loads and stores complete
+// at once here and are not counted: the model keeps MORE transfers pending than the hardware would, never fewer).
+inline void waitcnt_vm(int n) {
+  if (!g_cfg.dma_late) return;
+  wave_sync(&n, nullptr, [](Wave& w) {
+    int n0 = -1;
+    for (int l = 0; l < 64; l++) if (w.amask >> l & 1) { n0 = *(const int*)w.in[l]; break; }
+    drain_dma(w, (size_t)n0);
+  });
+}
+inline void s_barrier() { block_barrier(); }
+inline void syncthreads() { waitcnt_vm(0); block_barrier(); }      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+
+// ---- cross-lane --------------------------------------------------------------------------------------------------------------------------------
+inline int readfirstlane(int v) {
+  int out;
+  wave_sync(&v, &out, [](Wave& w) {
+    int first = 0;
+    for (int l = 0; l < 64; l++) if (w.amask >> l & 1) { first = *(const int*)w.in[l]; break; }
+    for (int l = 0; l < 64; l++) if (w.amask >> l & 1) *(int*)w.out[l] = first;
+  });
+  return out;
+}
+struct ShflIn { uint64_t v; int src; };
+template <class T> inline T shfl_idx(T v, int src) {
+  static_assert(sizeof(T) <= 8, "shuffle payload");
+  ShflIn in; in.v = 0; memcpy(&in.v, &v, sizeof(T)); in.src = src & 63;
+  uint64_t out = 0;
+  wave_sync(&in, &out, [](Wave& w) {
+    uint64_t vals[64];
+    for (int l = 0; l < 64; l++) vals[l] = (w.amask >> l & 1) ? ((const ShflIn*)w.in[l])->v : 0;
+    for (int l = 0; l < 64; l++) if (w.amask >> l & 1) {
+      const int s = ((const ShflIn*)w.in[l])->src;
+      *(uint64_t*)w.out[l] = (w.amask >> s & 1) ? vals[s] : vals[l];      // an inactive source returns the lane's own value
+    }
+  });
+  T r; memcpy(&r, &out, sizeof(T));
+  return r;
+}
+inline int update_dpp(int old, int src, int ctrl, int row_mask, int bank_mask, bool /*bound_ctrl*/) {
+  if (ctrl >= 0x100 || row_mask != 0xF || bank_mask != 0xF) die("update_dpp: only quad_perm with full masks is modelled");
+  const int l = g_cur->lane;
+  (void)old;
+  return shfl_idx(src, (l & ~3) + ((ctrl >> (2 * (l & 3))) & 3));
+}
+
+// ---- matrix cores ------------------------------------------------------------------------------------------------------------------------------
+inline float bf16_bits_to_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float f; memcpy(&f, &u, 4); return f; }
+struct MfmaIn { e_bf16x8 a, b; e_f32x16 c; };
+// v_mfma_f32_32x32x16_bf16: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j]; lane l holds A[l % 32][8 (l / 32) .. + 7], B[8 (l / 32) .. + 7][l % 32],
+// and in register r of C / D: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32.
+inline e_f32x16 mfma_32x32x16_bf16(e_bf16x8 a, e_bf16x8 b, e_f32x16 c) {
+  MfmaIn in{a, b, c};
+  e_f32x16 out;
+  wave_sync(&in, &out, [](Wave& w) {
+    if (w.amask != ~0ull) die("MFMA with inactive lanes");
+    g_cfg.mfma++;
+    static float A[32][16], B[16][32];
+    for (int l = 0; l < 64; l++) {
+      const MfmaIn* in = (const MfmaIn*)w.in[l];
+      uint16_t ab[8], bb[8];
+      memcpy(ab, &in->a, 16); memcpy(bb, &in->b, 16);
+      for (int e = 0; e < 8; e++) { A[l % 32][8 * (l / 32) + e] = bf16_bits_to_f(ab[e]); B[8 * (l / 32) + e][l % 32] = bf16_bits_to_f(bb[e]); }
+    }
+    for (int l = 0; l < 64; l++) {
+      const MfmaIn* in = (const MfmaIn*)w.in[l];
+      e_f32x16 d;
+      const int j = l % 32;
+      for (int r = 0; r < 16; r++) {
+        const int i = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+        float s = in->c[r];
+        for (int k = 0; k < 16; k++) s += A[i][k] * B[k][j];
+        d[r] = s;
+      }
+      *(e_f32x16*)w.out[l] = d;
+    }
+  });
+  return out;
+}
+struct Mfma2In { float a, b; e_f32x16 c; };
+// v_mfma_f32_32x32x2_f32: lane l holds A[l % 32][l / 32] and B[l / 32][l % 32]
+inline e_f32x16 mfma_32x32x2_f32(float a, float b, e_f32x16 c) {
+  Mfma2In in{a, b, c};
+  e_f32x16 out;
+  wave_sync(&in, &out, [](Wave& w) {
+    if (w.amask != ~0ull) die("MFMA with inactive lanes");
+    g_cfg.mfma++;
+    float A[32][2], B[2][32];
+    for (int l = 0; l < 64; l++) { const Mfma2In* in = (const Mfma2In*)w.in[l]; A[l % 32][l / 32] = in->a; B[l / 32][l % 32] = in->b; }
+    for (int l = 0; l < 64; l++) {
+      const Mfma2In* in = (const Mfma2In*)w.in[l];
+      e_f32x16 d;
+      for (int r = 0; r < 16; r++) {
+        const int i = 8 * (r / 4) + 4 * (l / 32) + r % 4;
+        d[r] = in->c[r] + A[i][0] * B[0][l % 32] + A[i][1] * B[1][l % 32];
+      }
+      *(e_f32x16*)w.out[l] = d;
+    }
+  });
+  return out;
+}
+inline float fdot2_bf16(e_bf16x2 a, e_bf16x2 b, float c, bool /*clamp*/) {
+  uint16_t ab[2], bb[2];
+  memcpy(ab, &a, 4); memcpy(bb, &b, 4);
+  return c + bf16_bits_to_f(ab[0]) * bf16_bits_to_f(bb[0]) + bf16_bits_to_f(ab[1]) * bf16_bits_to_f(bb[1]);
+}
+
+}  // namespace hipemu
+
+// ---- the names the kernels use ---------------------------------------------------------------------------------------------------------------------
+#define threadIdx (hipemu::g_cur->tid)
+#define blockIdx (hipemu::g_blk->bid)
+#define blockDim (hipemu::g_bdim)
+#define gridDim (hipemu::g_grid)
+#define hipLaunchKernelGGL(kern, grid, block, lds, st, ...) \
+  hipemu::launch(dim3(grid), dim3(block), (size_t)(lds), [&]() { kern(__VA_ARGS__); })
+
+#define __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, x, y, z) hipemu::mfma_32x32x16_bf16(a, b, c)
+#define __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, x, y, z) hipemu::mfma_32x32x2_f32(a, b, c)
+#define __builtin_amdgcn_make_buffer_rsrc(p, s, n, f) hipemu::make_rsrc(p, s, n, f)
+#define __builtin_amdgcn_raw_ptr_buffer_load_lds hipemu::buffer_load_lds
+#define __builtin_amdgcn_global_load_lds hipemu::global_load_lds
+#define __builtin_amdgcn_raw_buffer_load_b128 hipemu::buffer_load_b128
+#define __builtin_amdgcn_raw_buffer_store_b128 hipemu::buffer_store_b128
+#define __builtin_amdgcn_readfirstlane hipemu::readfirstlane
+#define __builtin_amdgcn_s_barrier hipemu::s_barrier
+#define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu::ds_read_tr16_b64(hipemu::lds_addr(p))
+#define __builtin_amdgcn_exp2f exp2f
+#define __builtin_amdgcn_update_dpp hipemu::update_dpp
+#define __builtin_amdgcn_fdot2_f32_bf16 hipemu::fdot2_bf16
+#define __syncthreads hipemu::syncthreads
+
+inline float __uint_as_float(uint32_t u) { float f; memcpy(&f, &u, 4); return f; }
+inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return u; }
+inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
+inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
+template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::g_cur->lane ^ m); }
+template <class T> inline T __shfl(T v, int s, int = 64) { return hipemu::shfl_idx(v, s); }
+template <class T> inline T __shfl_down(T v, int d, int = 64) { const int s = hipemu::g_cur->lane + d; return hipemu::shfl_idx(v, s < 64 ? s : hipemu::g_cur->lane); }
+template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+inline float __expf(float x) { return expf(x); }
+inline float __fdividef(float a, float b) { return a / b; }
+inline float __frcp_rn(float a) { return 1.f / a; }
+inline float rsqrtf(float a) { return 1.f / sqrtf(a); }
+template <class T> inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }

@@ -485,6 +485,35 @@ def test_wgrad_v3_full_size_layers(sg):
         check(f"wgrad v3 full size {(N, Cin, Cout, H, xf, gf)}", outs["1"], outs["0"], 2e-3)
 
 
+@pytest.mark.skipif(os.environ.get("SG_EXPERIMENTAL") != "1", reason="wgrad_v3l.h has not run on a GPU yet (CPU: tests/test_hipemu_cpu.py); SG_EXPERIMENTAL=1 runs it")
+@pytest.mark.parametrize("case", WV3_CASES)
+def test_wgrad_v3_lean_matches_shipped(sg, case, monkeypatch):
+    """SG_WGRAD_V3_LEAN=1 (csrc/wgrad_v3l.h: ReLU-on-load as a template parameter, bias gradient through v_dot2): the same MFMAs in the same
+    order as the shipped kernel -> dW bit for bit (one split layout), bias gradient to fp32 rounding."""
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, relu, up, pool = case
+    d = torch.device("cuda:0")
+    dt = torch.bfloat16
+    Ho = H * (2 if up else 1)
+    hg = Ho // 2 if pool else Ho
+    x = rnd((N, H, H, Cin), dt, 81).to(d)
+    gy = rnd((N, hg, hg, Cout), dt, 82).to(d)
+    xf = (L.PIX_RELU if relu else 0) | (L.PIX_UPSAMPLE if up else 0)
+    gf = L.PIX_UPSAMPLE if pool else 0
+    monkeypatch.setenv("SG_WGRAD_V3", "force")
+    outs = {}
+    for lean in ("0", "1"):
+        monkeypatch.setenv("SG_WGRAD_V3_LEAN", lean)
+        dw = torch.zeros((Cout, 3, 3, Cin), dtype=torch.float32, device=d)
+        db = torch.zeros((Cout,), dtype=torch.float32, device=d)
+        fused = F.conv2d_wgrad_raw(x, gy, dw.data_ptr(), Cin, Cout, 3, 3, Ho, Ho, 1, 1, 1, xf, gf, alpha=0.5, dbias=db)
+        torch.cuda.synchronize()
+        assert fused
+        outs[lean] = (dw.cpu(), db.cpu())
+    assert torch.equal(outs["0"][0], outs["1"][0]), case
+    check(f"wgrad v3 lean bias gradient {case}", outs["1"][1], outs["0"][1], 1e-5)
+
+
 SKIP_CASES = [
     # N, C (3x3 input), Cout, C2 (skip input), H (output res), relu, pool, up2      -- csrc/conv_v4.h SKIP: conv3x3(h) + conv1x1(up2?(x)) in one launch
     (2, 192, 192, 96, 16, True, True, False),     # DiscBlock 96 -> 192 (quad rows + pooling, ReLU on both inputs), W = 16: image-row parity swizzle

@@ -1,0 +1,123 @@
+"""Lane-accurate CPU runs of the gfx950 kernel SOURCES (tests/hipemu: the csrc translation unit compiled for the host against an interpreter of MFMA /
+ds_read_b64_tr_b16 / LDS-DMA / barriers; see tests/hipemu/include/hip/hip_runtime.h). Two uses:
+
+  * pin the interpreter: kernels that have passed their GPU parity tests (tests/test_conv_v2_gpu.py) must reproduce the fp64 restatement of
+    include/sgamd.h's formula here too, under every DMA-completion / wave-scheduling mode;
+  * check kernels written without GPU time against their GPU-verified predecessors before their first launch (SG_WGRAD_V3_LEAN, ...).
+
+Not a product path and not an oracle of the reference: it executes the product's own kernel code."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "hipemu"))
+import emu  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="host clang++ of the ROCm toolchain not found")
+
+MODES = [dict(dma_late=0, greedy=0, seed=0), dict(dma_late=1, greedy=1, seed=1), dict(dma_late=0, greedy=1, seed=2), dict(dma_late=1, greedy=1, seed=3)]
+# (N, H, W, C, Cout): every chunk shape of wgrad_v3.h (WC = 4 / 8 / 16 / 32 / 64) with both cout tiles (NB = 2: 64, NB = 3: 96 / 192)
+V3_SHAPES = [(4, 4, 4, 32, 64), (8, 4, 4, 64, 96), (2, 8, 8, 32, 64), (1, 8, 8, 64, 192), (1, 16, 16, 32, 96), (2, 32, 32, 32, 64), (1, 64, 64, 32, 64),
+             (1, 64, 128, 32, 96)]
+
+
+@pytest.fixture(scope="module")
+def wg():
+    return emu.load("conv_wgrad")
+
+
+def _data(shape, seed):
+    N, H, W, Cin, Cout = shape
+    rng = np.random.default_rng(seed)
+    return emu.to_bf16(rng.standard_normal((N, H, W, Cin)).astype(np.float32)), emu.to_bf16(rng.standard_normal((N, H, W, Cout)).astype(np.float32))
+
+
+def test_desc_layout_matches_product():
+    import importlib.util
+    here = os.path.dirname(os.path.abspath(__file__))
+    spec = importlib.util.spec_from_file_location("sg_lib_fields", os.path.join(here, "..", "pytorch-studiogan_amd", "_lib.py"))
+    src = open(spec.origin).read()
+    # the product's field list, textually (importing _lib would build / load libsgamd.so)
+    import re
+    m = re.search(r"class ConvWgradDesc\(C.Structure\):\s+_fields_ = \[(.*?)\]\n", src, re.S)
+    names = re.findall(r'\("(\w+)", (_\w+)\)', m.group(1))
+    assert [(n, t) for n, t in names] == [(n, {emu._vp: "_vp", emu._i: "_i", emu._f: "_f", emu._ll: "_ll"}[t]) for n, t in emu.WGRAD_FIELDS]
+
+
+@pytest.mark.parametrize("shape", V3_SHAPES)
+def test_wgrad_v3_pins_interpreter(wg, shape):
+    """the GPU-verified halo weight gradient, as shipped, through the interpreter: fp64 formula within fp32 accumulation noise"""
+    x, dy = _data(shape, 11)
+    for k, mode in enumerate(MODES if shape[0] * shape[1] * shape[2] <= 2048 else MODES[1:2]):
+        emu.config(wg, **mode)
+        c0 = emu.counters(wg)
+        for xf in (0, emu.PIX_RELU):
+            dw, db, sp = emu.conv_wgrad(wg, x, dy, shape[4], x_flags=xf, bias=True, env={"SG_WGRAD_V3": "f", "SG_WGRAD_V3_LEAN": "0"})
+            ref, rb = emu.wgrad_ref(x, dy, x_flags=xf)
+            assert np.abs(dw - ref).max() <= 2e-6 * np.abs(ref).max(), (shape, mode, xf)
+            assert db is not None and np.abs(db - rb).max() <= 2e-6 * np.abs(rb).max()
+        c1 = emu.counters(wg)
+        assert c1["mfma"] > c0["mfma"] and c1["tr_reads"] > c0["tr_reads"] and c1["dma_ops"] > c0["dma_ops"]     # the halo kernel ran, not the GEMM path
+
+
+@pytest.mark.parametrize("shape", V3_SHAPES)
+def test_wgrad_v3_lean_equals_shipped(wg, shape):
+    """wgrad_v3l.h (SG_WGRAD_V3_LEAN=1): same MFMAs in the same order -> dW bit for bit; bias gradient summed in another order -> fp32 rounding"""
+    x, dy = _data(shape, 12)
+    emu.config(wg, dma_late=1, greedy=1, seed=5)
+    for xf in (0, emu.PIX_RELU):
+        a, ab, _ = emu.conv_wgrad(wg, x, dy, shape[4], x_flags=xf, bias=True, alpha=0.5, env={"SG_WGRAD_V3": "f", "SG_WGRAD_V3_LEAN": "0"})
+        b, bb, _ = emu.conv_wgrad(wg, x, dy, shape[4], x_flags=xf, bias=True, alpha=0.5, env={"SG_WGRAD_V3": "f", "SG_WGRAD_V3_LEAN": "1"})
+        assert np.array_equal(a, b), (shape, xf)
+        assert np.abs(ab - bb).max() <= 1e-6 * np.abs(ab).max()
+
+
+def test_wgrad_v3_upsampled_operands(wg):
+    """x read through the nearest-neighbour upsampling (generator conv2d1 without the quad form) and dy read as the pooled gradient (g_up)"""
+    rng = np.random.default_rng(3)
+    N, Hs, Ws, Cin, Cout = 2, 8, 8, 32, 64
+    x = emu.to_bf16(rng.standard_normal((N, Hs, Ws, Cin)).astype(np.float32))
+    dy_full = emu.to_bf16(rng.standard_normal((N, 2 * Hs, 2 * Ws, Cout)).astype(np.float32))
+    dy_low = emu.to_bf16(rng.standard_normal((N, Hs, Ws, Cout)).astype(np.float32))
+    x_full = emu.to_bf16(rng.standard_normal((N, 2 * Hs, 2 * Ws, Cin)).astype(np.float32))
+    emu.config(wg, dma_late=1, greedy=1, seed=9)
+    for lean in ("0", "1"):
+        env = {"SG_WGRAD_V3": "f", "SG_WGRAD_V3_LEAN": lean}
+        dw, db, _ = emu.conv_wgrad(wg, x, dy_full, Cout, x_flags=emu.PIX_UPSAMPLE, bias=True, env=env)
+        ref, rb = emu.wgrad_ref(x, dy_full, x_flags=emu.PIX_UPSAMPLE)
+        assert np.abs(dw - ref).max() <= 2e-6 * np.abs(ref).max() and np.abs(db - rb).max() <= 2e-6 * np.abs(rb).max()
+        dw, db, _ = emu.conv_wgrad(wg, x_full, dy_low, Cout, x_flags=emu.PIX_RELU, g_flags=emu.PIX_UPSAMPLE, bias=True, env=env)
+        ref, rb = emu.wgrad_ref(x_full, dy_low, x_flags=emu.PIX_RELU, g_flags=emu.PIX_UPSAMPLE)
+        assert np.abs(dw - ref).max() <= 2e-6 * np.abs(ref).max()
+        if db is not None:
+            assert np.abs(db - rb).max() <= 2e-6 * np.abs(rb).max()
+
+
+def test_interpreter_catches_a_missing_wait(wg, tmp_path):
+    """the adversarial DMA mode is not decoration: the same kernel with its `s_waitcnt vmcnt(0)` removed must FAIL under late completion"""
+    import translate
+    src = open(os.path.join(translate.CSRC, "wgrad_v3.h")).read()
+    assert 'asm volatile("s_waitcnt vmcnt(0)" ::: "memory");' in src
+    broken = translate.translate(src.replace('asm volatile("s_waitcnt vmcnt(0)" ::: "memory");', ""))
+    assert "waitcnt_vm" not in broken
+    # build a private copy of the translated tree with the broken header
+    import shutil, subprocess
+    d = tmp_path / "src"
+    shutil.copytree(emu.SRC, d)
+    (d / "wgrad_v3.h").write_text(broken)
+    lib = tmp_path / "libbroken.so"
+    subprocess.run([emu.CXX, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(emu.HERE, "include"), "-I" + str(d),
+                    "-Wno-unknown-attributes", "-Wno-unused-value", str(d / "conv_wgrad.hip"), os.path.join(emu.HERE, "stubs.cpp"), "-o", str(lib)], check=True)
+    import ctypes
+    bl = ctypes.CDLL(str(lib))
+    bl.sg_last_error.restype = ctypes.c_char_p
+    x, dy = _data((2, 8, 8, 32, 64), 4)
+    ref, _ = emu.wgrad_ref(x, dy)
+    emu.config(bl, dma_late=0, greedy=0, seed=0)
+    dw, _, _ = emu.conv_wgrad(bl, x, dy, 64, env={"SG_WGRAD_V3": "f"})
+    assert np.abs(dw - ref).max() <= 2e-6 * np.abs(ref).max()          # eager completion hides the bug, like a lucky GPU run
+    emu.config(bl, dma_late=1, greedy=1, seed=1)
+    dw, _, _ = emu.conv_wgrad(bl, x, dy, 64, env={"SG_WGRAD_V3": "f"})
+    assert not np.abs(dw - ref).max() <= 1e-3 * np.abs(ref).max()      # late completion exposes it
