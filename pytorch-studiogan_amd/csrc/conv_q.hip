@@ -9,6 +9,7 @@
 #include "conv_common.h"
 #include "conv_q.h"
 #include "wgrad_q.h"
+#include "wgrad_ql.h"
 
 // ---- filter transforms ---------------------------------------------------------------------------------------------------------------
 // Per dimension: which 3x3 tap indices r feed quad tap ti of parity a. (POOL: w'[u] = (w[u] + w[u-1]) / 2 at u = 2 ti - a + 1;
@@ -366,7 +367,9 @@ extern "C" int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t strea
   p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
   const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)K * 9.0 * (double)d->C, 1);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)K * 16.0 * (double)d->C);
-  const int rc = sg_launch_wgrad_q(p, s.NB, s.S, st);
+  // SG_WGRAD_Q_LEAN=1: the lean variant (wgrad_ql.h) -- A/B switch, read per call; off until it has run on a GPU
+  const char* lean = getenv("SG_WGRAD_Q_LEAN");
+  const int rc = (lean && lean[0] == '1') ? sg_launch_wgrad_ql(p, s.NB, s.S, st) : sg_launch_wgrad_q(p, s.NB, s.S, st);
   if (rc == 0) {
     const bool pl = d->form == SG_Q_POOL;
     const int cb = d->C > 64 ? (d->C + 63) / 64 : 1;

@@ -4,7 +4,8 @@
 // tools/sessions/r5a.sh runs them first). A separate kernel rather than a template flag of sg_wgrad_v3_kernel so that the shipped kernel's
 // code object stays byte-identical (checked with llvm-objdump when this file was added).
 //
-// Same tiling, staging, fragment addresses and result layout as sg_wgrad_v3_kernel. Two changes:
+// Same tiling, staging, fragment addresses and result layout as sg_wgrad_v3_kernel. Three changes:
+//   * the LDS-DMA addresses of a lane's pieces are computed once per workgroup, not once per chunk (see the kernel; plain operands only);
 //   * ReLU-on-load is a template parameter: the layers without one (every generator layer: the ReLU sits in the batch-norm apply) issue no
 //     v_pk_max_i16 at all -- 12 per k-step of 7 MFMAs in the shipped loop, which clamps against -32768 when there is nothing to clamp;
 //   * the bias gradient is summed by the waves that own a seventh product, from the gradient fragment they already hold for it, with one
@@ -101,33 +102,57 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
   const int cpr = WC == 4 ? 1 : p.W / WC;           // chunks per image-row group
   const int cpi = WC == 4 ? 1 : (p.H / RC) * cpr;   // chunks per image (WC == 4: a chunk is four images)
 
+  // ---- LDS-DMA addresses (plain operands only: the launcher keeps x_up / g_up problems on the shipped kernel). The shipped kernel derives
+  // (image, row, column) of every 16-byte piece from its byte offset again for every chunk: divisions by constants and 32-bit multiplies, ~20
+  // vector instructions per piece of which 4-5 run at quarter rate, 6-7 pieces per wave and chunk of 28 MFMAs. The pieces of a lane are the
+  // same for every chunk: their byte offset RELATIVE to the chunk's first pixel and their (row, column) displacement are computed ONCE here;
+  // per chunk a piece costs two adds, two compares and a select.
+  constexpr int NIX = (NPX + 3) / 4;                // x pieces per wave (piece j = wave + 4 i)
+  unsigned xrel[NIX]; int xrc[NIX];         // relative byte offset; (row displacement << 16) | (column displacement & 0xffff)
+#pragma unroll
+  for (int i = 0; i < NIX; i++) {
+    const int j = wave + 4 * i;
+    const int o = j * 1024 + lane * 16;
+    const int pp0 = o >> 6, cb = o & 63;
+    const int kimg = pp0 / (PR * PW), pp = pp0 - kimg * (PR * PW);
+    const int pr = pp / PW, pc = pp - pr * PW;
+    const int dr = pr - 1, dc = pc - 1;
+    xrel[i] = (unsigned)(((kimg * p.H + dr) * p.W + dc) * p.ldx * 2 + cb);
+    const bool inside = (j < NPX) & (kimg < NIMG);
+    xrc[i] = ((inside ? dr : -0x4000) << 16) | (dc & 0xffff);      // (a piece beyond the patch: a row that is never inside [0, H))
+  }
+  unsigned grel[NB];                                // dy pieces: j = wave + 4 i, i < NB (NPG = 4 NB), always inside the tensor
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int o = (wave + 4 * i) * 1024 + lane * 16;
+    const int px = o / GPITCH, cb = o - px * GPITCH;
+    int kimg = 0, cr, cc;
+    if (WC == 4) { kimg = px >> 4; cr = (px >> 2) & 3; cc = px & 3; } else { cr = px / WC; cc = px - cr * WC; }
+    grel[i] = (unsigned)(((kimg * p.H + cr) * p.W + cc) * p.ldg * 2 + cb);
+  }
+
   auto issue = [&](int c, int buf) {
     int n, h0, w0;
     if (WC == 4) { n = 4 * c; h0 = 0; w0 = 0; }
     else { n = c / cpi; const int rem = c - n * cpi; const int rg = rem / cpr, cx = rem - rg * cpr; h0 = rg * RC; w0 = cx * WC; }
     char* base = smem + buf * BUF;
-    for (int j = wave; j < NPX; j += 4) {
-      const int o = j * 1024 + lane * 16;
-      const int pp0 = o >> 6, cb = o & 63;
-      const int kimg = pp0 / (PR * PW), pp = pp0 - kimg * (PR * PW);
-      const int pr = pp / PW, pc = pp - pr * PW;
-      int hh = h0 + pr - 1, ww = w0 + pc - 1;
-      const bool ok = (kimg < NIMG) & ((unsigned)hh < (unsigned)p.H) & ((unsigned)ww < (unsigned)p.W);
-      if (p.x_up) { hh >>= 1; ww >>= 1; }
-      unsigned off = (((unsigned)((n + kimg) * p.xHs + hh) * (unsigned)p.xWs + (unsigned)ww) * (unsigned)p.ldx + (unsigned)ci0) * 2u + (unsigned)cb;
-      off = ok ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(base + j * 1024), 16, (int)off, 0, 0, 0);
+    const unsigned pix0 = (unsigned)(n * p.H + h0) * (unsigned)p.W + (unsigned)w0;       // the chunk's first pixel (wave-uniform: scalar arithmetic)
+    const unsigned bx = pix0 * (unsigned)p.ldx * 2u + (unsigned)ci0 * 2u;
+    const unsigned bg = pix0 * (unsigned)p.ldg * 2u + (unsigned)co0 * 2u;
+#pragma unroll
+    for (int i = 0; i < NIX; i++) {
+      const int j = wave + 4 * i;
+      if (j < NPX) {
+        int rc = xrc[i];
+        asm volatile("" : "+v"(rc));                 // (keeps the unpacking inside the loop: hoisted, it would cost the registers the packing saves)
+        const bool ok = ((unsigned)(h0 + (rc >> 16)) < (unsigned)p.H) & ((unsigned)(w0 + (int)(short)rc) < (unsigned)p.W);
+        const unsigned off = ok ? bx + xrel[i] : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(base + j * 1024), 16, (int)off, 0, 0, 0);
+      }
     }
-    for (int j = wave; j < NPG; j += 4) {
-      const int o = j * 1024 + lane * 16;
-      const int px = o / GPITCH, cb = o - px * GPITCH;
-      int kimg = 0, cr, cc;
-      if (WC == 4) { kimg = px >> 4; cr = (px >> 2) & 3; cc = px & 3; } else { cr = px / WC; cc = px - cr * WC; }
-      int hh = h0 + cr, ww = w0 + cc;
-      if (p.g_up) { hh >>= 1; ww >>= 1; }
-      const unsigned off = (((unsigned)((n + kimg) * p.gHs + hh) * (unsigned)p.gWs + (unsigned)ww) * (unsigned)p.ldg + (unsigned)co0) * 2u + (unsigned)cb;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + GOFF + j * 1024), 16, (int)off, 0, 0, 0);
-    }
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsg, (sg_lptr_t)(base + GOFF + (wave + 4 * i) * 1024), 16, (int)(bg + grel[i]), 0, 0, 0);
   };
 
   // loop-invariant fragment addresses. One transpose read = 4 pixel rows x 16 channels per 16-lane group; lane result: channel
@@ -209,6 +234,7 @@ static inline int sg_launch_wgrad_v3l_r(const WgradV3Params& p, hipStream_t st) 
   return p.x_relu ? sg_launch_wgrad_v3l_t<NB, WC, true>(p, st) : sg_launch_wgrad_v3l_t<NB, WC, false>(p, st);
 }
 static inline int sg_launch_wgrad_v3l(const WgradV3Params& p, int NB, hipStream_t st) {
+  if (p.x_up || p.g_up) return sg_launch_wgrad_v3(p, NB, st);      // operands read through a 2x nearest upsampling: the shipped kernel
   const int wc = p.W >= 64 ? 64 : p.W;
   if (NB == 3) {
     switch (wc) { case 64: return sg_launch_wgrad_v3l_r<3, 64>(p, st); case 32: return sg_launch_wgrad_v3l_r<3, 32>(p, st);

@@ -162,3 +162,103 @@ def wgrad_ref(x, dy, x_flags=0, g_flags=0, alpha=1.0):
             dw[:, r, s, :] = np.einsum("nhwk,nhwc->kc", gf, xp[:, r:r + H, s:s + W], optimize=True)
     db = from_bf16(dy).astype(np.float64).sum(axis=(0, 1, 2))      # over the STORED dy pixels (sgamd.h)
     return alpha * dw, db
+
+
+# ---- quad convolutions (conv_q.hip: sg_quad_pack, sg_conv2d_q, sg_conv2d_q_wgrad) ---------------------------------------------------------------
+CONVQ_FIELDS = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("Cout", _i),
+                ("pix_flags", _i), ("epi_flags", _i), ("alpha", _f), ("beta", _f), ("x", _vp), ("wq", _vp), ("bias", _vp), ("res", _vp),
+                ("mask", _vp), ("out", _vp), ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i),
+                ("x2", _vp), ("w2q", _vp), ("bias2", _vp), ("C2", _i), ("ldx2", _i), ("stats", _vp), ("x2_norelu", _i)]
+CONVQ_WGRAD_FIELDS = [("dtype", _i), ("form", _i), ("N", _i), ("Hl", _i), ("Wl", _i), ("C", _i), ("ldx", _i), ("x_flags", _i), ("Cout", _i),
+                      ("ldg", _i), ("alpha", _f), ("alpha_ptr", _vp), ("x", _vp), ("dy", _vp), ("dw", _vp), ("dbias", _vp), ("work", _vp),
+                      ("work_floats", _ll), ("splits", _i)]
+
+
+class ConvQDesc(C.Structure):
+    _fields_ = CONVQ_FIELDS
+
+
+class ConvQWgradDesc(C.Structure):
+    _fields_ = CONVQ_WGRAD_FIELDS
+
+
+Q_POOL, Q_UP, EPI_RELU = 0, 1, 8
+
+
+class _Env:
+    def __init__(self, env):
+        self.env, self.old = env or {}, {}
+
+    def __enter__(self):
+        for k, v in self.env.items():
+            self.old[k] = os.environ.get(k)
+            os.environ[k] = v
+
+    def __exit__(self, *a):
+        for k, v in self.old.items():
+            if v is None:
+                del os.environ[k]
+            else:
+                os.environ[k] = v
+
+
+def copy_aligned(a):
+    b = aligned(a.shape, a.dtype)
+    b[...] = a
+    return b
+
+
+def quad_pack(lib, w9, mode):
+    """w9: uint16 bf16 [M][3][3][Cs] -> [M][4][4][Cs] (sg_quad_pack)"""
+    M, _, _, Cs = w9.shape
+    src, dst = copy_aligned(w9), aligned((M, 4, 4, Cs), np.uint16)
+    if lib.sg_quad_pack(BF16, mode, ptr(src), ptr(dst), M, Cs, None) != 0:
+        raise RuntimeError(lib.sg_last_error())
+    return dst
+
+
+def conv_q(lib, form, x, wq, Cout, relu_in=False, bias=None, mask=None, res=None, beta=1.0, alpha=1.0, relu_out=False, x2=None, w2q=None, bias2=None,
+           x2_norelu=False, env=None):
+    """x: uint16 bf16 NHWC (POOL: the fine tensor, UP: the low one); returns uint16 bf16 NHWC (POOL: low, UP: fine)"""
+    N, H, W, Cin = x.shape
+    Hl, Wl = (H // 2, W // 2) if form == Q_POOL else (H, W)
+    oshape = (N, Hl, Wl, Cout) if form == Q_POOL else (N, 2 * Hl, 2 * Wl, Cout)
+    xa, wa, out = copy_aligned(x), copy_aligned(wq), aligned(oshape, np.uint16)
+    keep = [xa, wa, out]
+    d = ConvQDesc(dtype=BF16, form=form, N=N, Hl=Hl, Wl=Wl, C=Cin, ldx=Cin, Cout=Cout, pix_flags=PIX_RELU if relu_in else 0,
+                  epi_flags=EPI_RELU if relu_out else 0, alpha=alpha, beta=beta, x=ptr(xa), wq=ptr(wa), out=ptr(out), ldo=Cout, ldr=Cout, ldm=Cout)
+    for name, arr, dt in (("bias", bias, np.float32), ("mask", mask, np.uint16), ("res", res, np.uint16), ("x2", x2, np.uint16), ("w2q", w2q, np.uint16),
+                          ("bias2", bias2, np.float32)):
+        if arr is not None:
+            a = copy_aligned(np.ascontiguousarray(arr, dtype=dt))
+            keep.append(a)
+            setattr(d, name, ptr(a))
+    if x2 is not None:
+        d.C2, d.ldx2, d.x2_norelu = x2.shape[3], x2.shape[3], int(x2_norelu)
+    with _Env(env):
+        if lib.sg_conv2d_q_ok(C.byref(d)) != 1:
+            raise RuntimeError("sg_conv2d_q_ok == 0")
+        if lib.sg_conv2d_q(C.byref(d), None) != 0:
+            raise RuntimeError(lib.sg_last_error())
+    return out
+
+
+def conv_q_wgrad(lib, form, x, dy, relu_in=False, alpha=1.0, bias=False, splits=0, env=None):
+    """returns (dw fp32 [Cout][3][3][C] -- the folded 3x3 gradient, dbias or None, splits)"""
+    N, H, W, Cin = x.shape
+    Cout = dy.shape[3]
+    Hl, Wl = (H // 2, W // 2) if form == Q_POOL else (H, W)
+    xa, ga = copy_aligned(x), copy_aligned(dy)
+    dw = aligned((Cout, 3, 3, Cin), np.float32)
+    db = aligned((Cout,), np.float32) if bias else None
+    d = ConvQWgradDesc(dtype=BF16, form=form, N=N, Hl=Hl, Wl=Wl, C=Cin, ldx=Cin, x_flags=PIX_RELU if relu_in else 0, Cout=Cout, ldg=Cout, alpha=alpha,
+                       x=ptr(xa), dy=ptr(ga), dw=ptr(dw), dbias=ptr(db) if bias else None, splits=splits)
+    with _Env(env):
+        sp, wf = C.c_int(0), C.c_longlong(0)
+        if lib.sg_conv2d_q_wgrad_plan(C.byref(d), C.byref(sp), C.byref(wf)) != 0 or sp.value == 0:
+            raise RuntimeError("sg_conv2d_q_wgrad_plan: not eligible")
+        work = aligned((max(int(wf.value), 1),), np.float32)
+        d.work, d.work_floats, d.splits = ptr(work), wf.value, sp.value
+        if lib.sg_conv2d_q_wgrad(C.byref(d), None) != 0:
+            raise RuntimeError(lib.sg_last_error())
+    return dw, db, sp.value

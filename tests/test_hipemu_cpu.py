@@ -121,3 +121,78 @@ def test_interpreter_catches_a_missing_wait(wg, tmp_path):
     emu.config(bl, dma_late=1, greedy=1, seed=1)
     dw, _, _ = emu.conv_wgrad(bl, x, dy, 64, env={"SG_WGRAD_V3": "f"})
     assert not np.abs(dw - ref).max() <= 1e-3 * np.abs(ref).max()      # late completion exposes it
+
+
+# ---- quad convolutions (conv_q.hip) -------------------------------------------------------------------------------------------------------------------
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+# (N, Hl, Wl, C, Cout) on the LOW-resolution grid: every chunk shape of wgrad_q.h (WC = 4 / 8 / 16 / 32 / 64), S = 1 and 2 slices, NB = 2 and 3
+Q_SHAPES = [(4, 4, 4, 32, 64), (4, 4, 4, 64, 192), (2, 8, 8, 64, 96), (1, 16, 16, 32, 96), (1, 32, 32, 64, 64), (1, 64, 64, 32, 64)]
+
+
+@pytest.fixture(scope="module")
+def cq():
+    return emu.load("conv_q")
+
+
+def _t64(a):
+    import torch
+    return torch.from_numpy(emu.from_bf16(a).astype(np.float64))
+
+
+def _qdata(form, shape, seed):
+    N, Hl, Wl, Cin, Cout = shape
+    rng = np.random.default_rng(seed)
+    xs = (N, 2 * Hl, 2 * Wl, Cin) if form == emu.Q_POOL else (N, Hl, Wl, Cin)
+    gs = (N, Hl, Wl, Cout) if form == emu.Q_POOL else (N, 2 * Hl, 2 * Wl, Cout)
+    return emu.to_bf16(rng.standard_normal(xs).astype(np.float32)), emu.to_bf16(rng.standard_normal(gs).astype(np.float32))
+
+
+@pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
+@pytest.mark.parametrize("shape", Q_SHAPES)
+def test_conv_q_forward_pins_interpreter(cq, form, shape):
+    """the GPU-verified quad forward kernel (LDS-DMA patch + four weight buffers with counted waits, swizzled ds_read_b128 fragments, the staged
+    epilogue with bias / ReLU mask / residual) against tests/quad_ref.py on the kernel's own filter image; sg_quad_pack against its restatement"""
+    import torch
+    import quad_ref as Q
+    N, Hl, Wl, Cin, Cout = shape
+    rng = np.random.default_rng(21)
+    x, _ = _qdata(form, shape, 21)
+    w9 = emu.to_bf16((0.1 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    emu.config(cq, dma_late=1, greedy=1, seed=6)
+    wq = emu.quad_pack(cq, w9, form)
+    wq_ref = Q.quad_pack_ref(_t64(w9), form)
+    assert np.array_equal(wq, emu.to_bf16(wq_ref.numpy().astype(np.float32)))                  # fp32 sums of bf16 taps, rounded once
+    oshape = (N, Hl, Wl, Cout) if form == emu.Q_POOL else (N, 2 * Hl, 2 * Wl, Cout)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    mask = emu.to_bf16(rng.standard_normal(oshape).astype(np.float32))
+    res = emu.to_bf16(rng.standard_normal(oshape).astype(np.float32))
+    for mode in (dict(dma_late=1, greedy=1, seed=6), dict(dma_late=0, greedy=1, seed=7)):
+        emu.config(cq, **mode)
+        for relu in (False, True):
+            out = emu.conv_q(cq, form, x, wq, Cout, relu_in=relu, bias=bias, mask=mask, res=res, alpha=0.5)
+            xx = _t64(x).clamp(min=0) if relu else _t64(x)
+            ref = 0.5 * Q.convq_ref(xx, _t64(wq), form) + torch.from_numpy(bias).double()
+            ref = ref * (_t64(mask) > 0) + _t64(res)
+            got = _t64(out)
+            assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6, (form, shape, relu)     # one bf16 rounding of the result
+
+
+@pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
+@pytest.mark.parametrize("shape", Q_SHAPES)
+def test_wgrad_q_pins_interpreter_and_lean_equals_shipped(cq, form, shape):
+    """shipped sg_wgrad_q_kernel + k_quad_reduce_fold against the fp64 restatement; wgrad_ql.h (SG_WGRAD_Q_LEAN=1: DMA addresses once per workgroup,
+    ReLU as a template parameter, bias gradient through v_dot2) bit for bit against the shipped kernel"""
+    import torch
+    import quad_ref as Q
+    x, dy = _qdata(form, shape, 22)
+    emu.config(cq, dma_late=1, greedy=1, seed=8)
+    for relu in (False, True):
+        a, ab, _ = emu.conv_q_wgrad(cq, form, x, dy, relu_in=relu, bias=True, alpha=0.5, env={"SG_WGRAD_Q": "f", "SG_WGRAD_Q_LEAN": "0"})
+        xx = _t64(x).clamp(min=0) if relu else _t64(x)
+        ref = 0.5 * Q.quad_fold_ref(Q.wgradq_ref(xx, _t64(dy), form), form)
+        rb = _t64(dy).sum((0, 1, 2))
+        assert (torch.from_numpy(a).double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), (form, shape, relu)
+        assert (torch.from_numpy(ab).double() - rb).abs().max().item() <= 2e-6 * rb.abs().max().item()
+        b, bb, _ = emu.conv_q_wgrad(cq, form, x, dy, relu_in=relu, bias=True, alpha=0.5, env={"SG_WGRAD_Q": "f", "SG_WGRAD_Q_LEAN": "1"})
+        assert np.array_equal(a, b), (form, shape, relu)
+        assert np.abs(ab - bb).max() <= 1e-6 * np.abs(ab).max()

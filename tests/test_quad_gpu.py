@@ -2,6 +2,8 @@
 conv3x3(up2(x)) as four 2x2 phase convolutions -- against torch's own conv2d + avg_pool2d / interpolate on the CPU (fp32 accumulation of the
 same bf16 inputs), forward, data gradient and weight gradient, with every fused flag, on shapes that select every chunk geometry of the
 weight-gradient kernel. Replaces src/models/big_resnet.py:28-42 (F.interpolate + conv2d1) and :177-192,221-242 (conv2d2 + average_pooling)."""
+import os
+
 import pytest
 import torch
 
@@ -154,6 +156,31 @@ def test_wgrad_q_matches_autograd(sg, case):
         check(f"wgrad_q {case} splits {splits}", got, dw, 3e-3)
         if with_bias:
             check(f"wgrad_q bias {case} splits {splits}", db.cpu(), dy.float().sum((0, 1, 2)), 2e-3)
+
+
+@pytest.mark.skipif(os.environ.get("SG_EXPERIMENTAL") != "1", reason="wgrad_ql.h has not run on a GPU yet (CPU: tests/test_hipemu_cpu.py); SG_EXPERIMENTAL=1 runs it")
+@pytest.mark.parametrize("case", WG_CASES)
+def test_wgrad_q_lean_matches_shipped(sg, case, monkeypatch):
+    """SG_WGRAD_Q_LEAN=1 (csrc/wgrad_ql.h): the same MFMAs in the same order as the shipped kernel -> the 3x3 gradient bit for bit, the bias gradient to
+    fp32 rounding (summed through v_dot2 on other waves)."""
+    from studiogan_amd import functional as F, _lib as L
+    form, N, Hl, Wl, C, Cout, relu, with_bias = case
+    dt = torch.bfloat16
+    Hx, Wx = (2 * Hl, 2 * Wl) if form == 0 else (Hl, Wl)
+    Hg, Wg = (Hl, Wl) if form == 0 else (2 * Hl, 2 * Wl)
+    x, dy = _dev(rnd((N, Hx, Wx, C), dt, 341)), _dev(rnd((N, Hg, Wg, Cout), dt, 342))
+    outs = {}
+    for lean in ("0", "1"):
+        monkeypatch.setenv("SG_WGRAD_Q_LEAN", lean)
+        for splits in (0, 3):
+            dwd = torch.zeros(Cout, 9, C, dtype=torch.float32, device="cuda:0")
+            db = torch.zeros(Cout, dtype=torch.float32, device="cuda:0")
+            assert F.conv2d_q_wgrad_raw(x, dy, dwd.data_ptr(), form, C, Cout, L.PIX_RELU if relu else 0, alpha=0.5, dbias=db, splits=splits)
+            torch.cuda.synchronize()
+            outs[(lean, splits)] = (dwd.cpu(), db.cpu())
+    for splits in (0, 3):
+        assert torch.equal(outs[("0", splits)][0], outs[("1", splits)][0]), (case, splits)
+        check(f"wgrad_q lean bias {case} splits {splits}", outs[("1", splits)][1], outs[("0", splits)][1], 1e-5)
 
 
 SKIP_CASES = [

@@ -19,6 +19,10 @@ DS_BYTES = {"ds_read_b128": 16, "ds_read_b64": 8, "ds_read_b32": 4, "ds_read2_b6
             "ds_read_b96": 12, "ds_read_u16": 2, "ds_read_u8": 1, "ds_read2st64_b64": 16, "ds_read2st64_b32": 8, "ds_read_b64_tr_b8": 8}
 
 
+# 32-bit integer multiplies issue at a quarter of the vector-ALU rate (16 clk per wave64 instead of 4)
+QUARTER_RATE = ("v_mul_lo_u32", "v_mul_hi_u32", "v_mul_hi_i32", "v_mul_lo_i32", "v_mad_u64_u32", "v_mad_i64_i32")
+
+
 def code_objects(so):
     """the gfx950 members of every clang offload bundle embedded in the shared library"""
     data = open(so, "rb").read()
@@ -87,7 +91,7 @@ def main():
                             if nm and (best is None or addr - tgt > best[1] - best[0]):
                                 best = (tgt, addr)
                 d = meta[name]
-                d.update(mfma=0, ds=0, dsn=0, valu=0, salu=0, vmem=0, ldsdma=0, wait0=0, waits=0, barrier=0, n=0, loop=best is not None)
+                d.update(mfma=0, ds=0, dsn=0, valu=0, qmul=0, salu=0, vmem=0, ldsdma=0, wait0=0, waits=0, barrier=0, n=0, loop=best is not None)
                 for addr, line in ins:
                     if best is not None and not (best[0] <= addr <= best[1]):
                         continue
@@ -104,6 +108,8 @@ def main():
                             d["ldsdma"] += 1
                     elif op.startswith("v_"):
                         d["valu"] += 1
+                        if op.startswith(QUARTER_RATE):
+                            d["qmul"] += 1
                     elif op == "s_waitcnt":
                         d["waits"] += 1
                         if "lgkmcnt(0)" in line:
@@ -117,7 +123,7 @@ def main():
                     rows.append((name, d))
     names = demangle([r[0] for r in rows])
     sel = [s for s in args.match.split(",") if s]
-    print(f"{'vgpr':>4s} {'agpr':>4s} {'w/SIMD':>6s} {'sLDS K':>6s} {'scr B':>5s} {'spill':>5s} | {'MFMA':>5s} {'dsB/MFMA':>8s} {'VALU/MFMA':>9s} {'lgkm0/MFMA':>10s} {'LDS-DMA':>7s} {'barr':>4s} | kernel (* = no MFMA loop found: whole body)")
+    print(f"{'vgpr':>4s} {'agpr':>4s} {'w/SIMD':>6s} {'sLDS K':>6s} {'scr B':>5s} {'spill':>5s} | {'MFMA':>5s} {'dsB/MFMA':>8s} {'VALU/MFMA':>9s} {'qmul':>4s} {'lgkm0/MFMA':>10s} {'LDS-DMA':>7s} {'barr':>4s} | kernel (* = no MFMA loop found: whole body)")
     for (raw, d), nm in sorted(zip(rows, names), key=lambda t: t[1]):
         if sel and not any(s in nm for s in sel):
             continue
@@ -127,7 +133,7 @@ def main():
         occ = min(8, 512 // max(regs, 1))
         mf = max(d["mfma"], 1)
         nm = re.sub(r"\(.*$", "", nm)
-        print(f"{d['vgpr']:4d} {d['agpr']:4d} {occ:6d} {d['lds'] / 1024:6.1f} {d['scratch']:5d} {d['spill']:5d} | {d['mfma']:5d} {d['ds'] / mf:8.0f} {d['valu'] / mf:9.1f} "
+        print(f"{d['vgpr']:4d} {d['agpr']:4d} {occ:6d} {d['lds'] / 1024:6.1f} {d['scratch']:5d} {d['spill']:5d} | {d['mfma']:5d} {d['ds'] / mf:8.0f} {d['valu'] / mf:9.1f} {d['qmul']:4d} "
               f"{d['wait0'] / mf:10.2f} {d['ldsdma']:7d} {d['barrier']:4d} | {nm}{'' if d['loop'] else ' *'}")
 
 
