@@ -233,7 +233,15 @@ def check(rc, name=""):
         raise RuntimeError(f"{name}: {lib().sg_last_error().decode()} (rc={rc})")
 
 
+# Entry points that write parameters / buffers of a network through raw pointers (invisible to torch's version counters): every call moves the
+# epoch the weight bank's frozen-network cache is keyed on (bank.WeightBank.begin_forward).
+_STATE_WRITERS = frozenset(("sg_adam_ema", "sg_ema_lerp", "sg_allreduce_flat"))
+write_epoch = [0]
+
+
 def call(name, *args):
+    if name in _STATE_WRITERS:
+        write_epoch[0] += 1
     rc = getattr(lib(), name)(*args)
     if rc != 0:
         raise RuntimeError(f"{name}: {lib().sg_last_error().decode()} (rc={rc})")
@@ -251,6 +259,11 @@ def dt(t):
     if d == torch.bfloat16:
         return BF16
     raise RuntimeError(f"unsupported dtype {d} (float32 / bfloat16 only)")
+
+
+def require_gpu(dev):
+    if dev.type != "cuda":
+        raise RuntimeError("studiogan_amd modules run on the GPU only (no CPU fallback on the product path)")
 
 
 def ptr(t):

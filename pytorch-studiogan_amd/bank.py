@@ -15,12 +15,14 @@ MI355X-first layout of the *weight side* of the hot path:
 Parameter names/shapes stay exactly the reference's (`weight_orig`, `weight_u`, `weight_v`, `bias`, ...), so
 `state_dict()` / `load_state_dict(strict=True)` interchange with StudioGAN checkpoints (reference src/utils/ckpt.py:38).
 """
+import os
 import weakref
 
 import torch
 
 from . import _lib as L
 
+_EVAL_CACHE = [os.environ.get("SG_EVAL_CACHE", "1") != "0"]   # frozen-network weight-image cache (begin_forward); a list so that tests can flip it
 _ARENA_BY_ID = {}  # id(Parameter) -> (weakref to the Parameter, ParamArena, offset); keyed by identity, never by ==
 
 
@@ -202,8 +204,7 @@ class WeightBank:
                 layers.append(m)
         assert layers, "no weight layers found"
         dev = next(root.parameters()).device
-        if dev.type != "cuda":
-            raise RuntimeError("studiogan_amd modules run on the GPU only (no CPU fallback on the product path)")
+        L.require_gpu(dev)
         self.device = dev
         # 1. flatten parameters / buffers of the whole network (not only weight layers)
         params = list(root.parameters())
@@ -258,6 +259,7 @@ class WeightBank:
         for s in range(nslots):
             self.slots.append(self._new_slot(s))
         self._ring = 0
+        self._fwd_train_epoch = 0           # forwards of this network that ran the power iteration (they move u / v)
         self.current = self.slots[0]
         self._cb_queued = False
         self.es = es
@@ -377,6 +379,19 @@ class WeightBank:
         slot.desc_cache[flags] = ent
         return ent
 
+    def _versioned(self):
+        """the tensors whose torch-side writes invalidate the emitted weight images: every weight-layer parameter and its u / v vectors"""
+        v = self.__dict__.get("_versioned_cache")
+        if v is None:
+            v = []
+            for r in self.layers:
+                m = r.module()
+                v.append(r.param)
+                if r.apply_sn:
+                    v += [m.weight_u, m.weight_v]
+            self._versioned_cache = v
+        return v
+
     def intact(self):
         root = self.root_ref()
         return self.params.intact() and root is not None and self.buffers.intact(root) and get_buffer_arena(root) is self.buffers
@@ -393,6 +408,21 @@ class WeightBank:
         else:
             slot = self.slots[0]
         flags = tuple(bool(r.module().training) for r in self.layers)
+        # A frozen network run without a graph (the evaluation generator of the FID / IS loop, reference src/metrics/features.py:17-65: one forward per
+        # batch of 50 k samples) gets the SAME weight images every time: no power iteration (eval mode), same weights. Slot 0 keeps them until
+        # something writes the parameters or the spectral-norm vectors: our own raw-pointer writers move _lib.write_epoch, torch-side writes
+        # (load_state_dict, an in-place op on a parameter) move the tensors' version counters. SG_EVAL_CACHE=0 re-emits every time.
+        key = None
+        if not need_graph and not any(flags) and _EVAL_CACHE[0]:
+            key = (L.write_epoch[0], sum(p._version for p in self._versioned()), self._fwd_train_epoch)
+            if slot.__dict__.get("emit_key") == key:
+                self.current = slot
+                self.eval_cache_hits = self.__dict__.get("eval_cache_hits", 0) + 1
+                return slot
+        if any(flags):
+            self._fwd_train_epoch += 1          # the power iteration of this forward moves u / v
+        if not need_graph:
+            slot.emit_key = key
         arr, dev_tab = self._desc(slot, flags)
         L.call("sg_sn_forward", self.sgdt, dev_tab.data_ptr(), arr, len(self.layers), self.eps, self.work.data_ptr(),
                self.work.numel(), L.stream())

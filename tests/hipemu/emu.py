@@ -37,10 +37,10 @@ def available():
 
 
 def build(unit, opt="-O1"):
-    """translate csrc, compile <unit>.hip + stubs.cpp for the host; returns the library path (cached on the translated sources' hash)"""
+    """ONE translation unit + stubs.cpp as its own small library (used where a test needs a private, modified copy of a unit); returns the path"""
     translate.translate_tree(SRC)
     deps = [os.path.join(SRC, f) for f in sorted(os.listdir(SRC)) if f.endswith(".h")] + [os.path.join(SRC, unit + ".hip"),
-            os.path.join(HERE, "stubs.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
+            os.path.join(HERE, "stubs.cpp"), os.path.join(HERE, "rt.cpp"), os.path.join(HERE, "include", "hip", "hip_runtime.h")]
     h = hashlib.sha256()
     for d in deps:
         with open(d, "rb") as f:
@@ -51,11 +51,18 @@ def build(unit, opt="-O1"):
         for old in os.listdir(BUILD):
             if old.startswith("libemu_%s_" % unit):
                 os.remove(os.path.join(BUILD, old))
-        cmd = [CXX, "-x", "c++", "-std=c++17", opt, "-fPIC", "-shared", "-I" + os.path.join(HERE, "include"), "-I" + SRC,
-               "-Wno-unknown-attributes", "-Wno-unused-value", os.path.join(SRC, unit + ".hip"), os.path.join(HERE, "stubs.cpp"), "-o", lib + ".tmp"]
-        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
-        if r.returncode != 0:
-            raise RuntimeError("hipemu build of %s failed:\n%s" % (unit, r.stdout[-4000:]))
+        common = [CXX, "-x", "c++", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(HERE, "include"), "-I" + SRC,
+                  "-Wno-unknown-attributes", "-Wno-unused-value"]
+        rt = lib + ".rt.o"            # the interpreter's own loops (MFMA arithmetic): -O3 for the machine this runs on
+        for cmd in (common + ["-O3", "-march=native", "-c", os.path.join(HERE, "rt.cpp"), "-o", rt],
+                    common + [opt, "-c", os.path.join(SRC, unit + ".hip"), "-o", lib + ".o"],
+                    common + [opt, "-c", os.path.join(HERE, "stubs.cpp"), "-o", lib + ".st.o"],
+                    [CXX, "-shared", "-o", lib + ".tmp", lib + ".o", lib + ".st.o", rt]):
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+            if r.returncode != 0:
+                raise RuntimeError("hipemu build of %s failed:\n%s" % (unit, r.stdout[-4000:]))
+        for f in (rt, lib + ".o", lib + ".st.o"):
+            os.remove(f)
         os.rename(lib + ".tmp", lib)
     return lib
 
@@ -63,11 +70,14 @@ def build(unit, opt="-O1"):
 _libs = {}
 
 
-def load(unit):
-    if unit not in _libs:
-        _libs[unit] = C.CDLL(build(unit))
-        _libs[unit].sg_last_error.restype = C.c_char_p
-    return _libs[unit]
+def load(unit=None):
+    """the emulated library. One build serves every test: the WHOLE library (fullemu.build: all translation units in parallel, cached per unit), whose
+    C ABI contains every unit's entry points; `unit` only documents which translation unit a test exercises."""
+    if "full" not in _libs:
+        import fullemu
+        _libs["full"] = C.CDLL(fullemu.build())
+        _libs["full"].sg_last_error.restype = C.c_char_p
+    return _libs["full"]
 
 
 def config(lib, dma_late=0, greedy=0, seed=0):

@@ -2,7 +2,7 @@
 //
 // The kernel sources are compiled for the HOST (x86, amdclang++) against this header instead of the HIP runtime, after tests/hipemu/translate.py
 // has rewritten the constructs a host compiler cannot take (inline gfx950 assembly, address-space casts, `__shared__` declarations). Every
-// thread of a workgroup is a fibre (ucontext); the cross-lane instructions the kernels are built from -- MFMA, the LDS transpose read,
+// thread of a workgroup is a fibre (a hand-written stack switch); the cross-lane instructions the kernels are built from -- MFMA, the LDS transpose read,
 // LDS-DMA (`buffer_load ... lds`), DPP, shuffles, barriers, `s_waitcnt vmcnt` -- are executed with the semantics MI355X_MICROARCH.md /
 // cdna_hip_programming.md document, per wave, once all live lanes of the wave have arrived. What this buys: the index arithmetic, fragment
 // layouts, staging addresses and result layouts of a kernel are checked on a machine without a GPU, and LDS-DMA completion can be made
@@ -18,9 +18,14 @@
 #include <stdlib.h>
 #include <string.h>
 #include <sys/mman.h>
-#include <ucontext.h>
+#include <unistd.h>
 
 #include <algorithm>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
+#include <thread>
+#include <type_traits>
 #include <deque>
 #include <functional>
 #include <map>
@@ -44,6 +49,29 @@ inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess
 inline hipError_t hipGetLastError() { return hipSuccess; }
 inline const char* hipGetErrorString(hipError_t) { return "hipemu"; }
 
+__asm__(R"(
+.text
+.weak hipemu_switch
+.type hipemu_switch,@function
+hipemu_switch:
+  pushq %rbp
+  pushq %rbx
+  pushq %r12
+  pushq %r13
+  pushq %r14
+  pushq %r15
+  movq %rsp, (%rdi)
+  movq (%rsi), %rsp
+  popq %r15
+  popq %r14
+  popq %r13
+  popq %r12
+  popq %rbx
+  popq %rbp
+  ret
+.size hipemu_switch,.-hipemu_switch
+)");
+
 namespace hipemu {
 
 typedef __attribute__((ext_vector_type(4))) uint32_t e_u32x4;
@@ -65,8 +93,12 @@ struct Wave {
   std::function<void(Wave&)> fire;
   std::deque<DmaOp> dma;
 };
+// fibre switch: callee-saved registers + stack pointer (System V x86-64). glibc's swapcontext makes a signal-mask system call per switch (~0.5 us);
+// this is ~10 ns, and a kernel launch is tens of thousands to millions of switches.
+struct Ctx { void* rsp; };
+extern "C" void hipemu_switch(Ctx* from, Ctx* to);
 struct Lane {
-  ucontext_t ctx;
+  Ctx ctx;
   char* stack = nullptr;
   bool done = false;
   int wave = 0, lane = 0;
@@ -84,19 +116,24 @@ struct Block {
   std::map<int, size_t> statics;
   U3 bid;
 };
-struct Config {
+struct Counters { long launches = 0, blocks = 0, mfma = 0, dma_ops = 0, tr_reads = 0; };
+struct Config : Counters {
   int dma_late = 0;          // 1: an LDS-DMA transfer lands when a wait forces it; 0: when it is issued
   int greedy = 0;            // 1: a wave runs until it blocks at a workgroup barrier before the next wave gets a turn
   unsigned seed = 0;         // wave order permutation
-  long launches = 0, blocks = 0, mfma = 0, dma_ops = 0, tr_reads = 0;
+  int threads = 0;           // host threads a launch spreads its workgroups over (0: HIPEMU_THREADS or min(8, cores); 1: sequential, deterministic atomics)
 };
-inline Config g_cfg;
-inline Block* g_blk = nullptr;
-inline Lane* g_cur = nullptr;
-inline ucontext_t g_main;
-inline U3 g_grid, g_bdim;
+inline Config g_cfg;                                  // switches + totals (the per-thread counts are merged in when a launch ends)
+inline std::mutex g_cnt_mutex;
+// per host thread: the workgroup it is running (a fibre never migrates), its scheduler context, its LDS, its counters
+inline thread_local Counters t_cnt;
+inline thread_local Block* g_blk = nullptr;
+inline thread_local Lane* g_cur = nullptr;
+inline thread_local Ctx g_main;
+inline thread_local char* g_lds_arena = nullptr;
+inline thread_local std::vector<char*>* t_stacks = nullptr;
+inline U3 g_grid, g_bdim;                             // per launch (launches do not overlap)
 inline const std::function<void()>* g_kernel = nullptr;
-inline char* g_lds_arena = nullptr;
 constexpr size_t LDS_BYTES = 160 * 1024;
 constexpr size_t STACK_BYTES = 192 * 1024;
 
@@ -104,7 +141,7 @@ constexpr size_t STACK_BYTES = 192 * 1024;
   fprintf(stderr, "hipemu: %s (block %u,%u thread %u)\n", msg, g_blk ? g_blk->bid.x : 0, g_blk ? g_blk->bid.y : 0, g_cur ? g_cur->tid.x : 0);
   abort();
 }
-inline void yield_to_main() { swapcontext(&g_cur->ctx, &g_main); }
+inline void yield_to_main() { hipemu_switch(&g_cur->ctx, &g_main); }
 
 inline void apply_dma(const DmaOp& op) {
   if (op.nop) return;
@@ -154,7 +191,17 @@ inline void lane_entry() {
   if (w.arrived && w.arrived == w.nlive && w.fire) { auto f = w.fire; f(w); w.arrived = 0; w.amask = 0; w.gen++; w.fire = nullptr; }
   if (w.nlive == 0) drain_dma(w, 0);
   if (b.bar_arrived && b.bar_arrived == b.nlive) { b.bar_arrived = 0; b.bar_gen++; }
-  // returning resumes uc_link = g_main
+  hipemu_switch(&me->ctx, &g_main);          // never resumed
+  abort();
+}
+inline void prepare_fibre(Lane& L) {
+  // the first switch into the fibre pops six zeros into the callee-saved registers and returns into lane_entry with the stack 8 mod 16
+  uintptr_t top = ((uintptr_t)L.stack + STACK_BYTES) & ~(uintptr_t)15;
+  void** sp = (void**)(top - 64);
+  sp[6] = (void*)&lane_entry;                // return address at an address = 0 mod 16 (sp + 6 words = top - 16)
+  for (int i = 0; i < 6; i++) sp[i] = nullptr;
+  sp[7] = nullptr;
+  L.ctx.rsp = sp;
 }
 
 inline void configure_from_env() {
@@ -163,74 +210,135 @@ inline void configure_from_env() {
   done = true;
   if (const char* m = getenv("HIPEMU_DMA")) g_cfg.dma_late = (m[0] == 'l');
   if (const char* m = getenv("HIPEMU_SCHED")) { g_cfg.greedy = 1; g_cfg.seed = (unsigned)strtoul(m, nullptr, 10); }
+  if (const char* m = getenv("HIPEMU_THREADS")) g_cfg.threads = atoi(m);
 }
 
-inline void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& kernel) {
-  configure_from_env();
+inline void run_block(unsigned lin, dim3 grid, dim3 block, size_t lds) {
+  const int nthreads = block.x * block.y * block.z;
   if (!g_lds_arena) {
     g_lds_arena = (char*)mmap(nullptr, LDS_BYTES + 4096, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS | MAP_32BIT, -1, 0);
     if (g_lds_arena == (char*)MAP_FAILED) { perror("mmap"); abort(); }
     g_lds_arena += 1024;            // LDS address 0 is not where a kernel's image starts in this model: forgetting the base shows
+    // LDS is NOT cleared between workgroups: a kernel that reads what it never wrote sees the previous workgroup's bytes (first one: 0xCD)
+    memset(g_lds_arena, 0xCD, LDS_BYTES);
   }
+  if (!t_stacks) t_stacks = new std::vector<char*>();
+  while ((int)t_stacks->size() < nthreads) t_stacks->push_back((char*)malloc(STACK_BYTES));
+  const unsigned bx = lin % grid.x, by = (lin / grid.x) % grid.y, bz = lin / (grid.x * grid.y);
+  Block b;
+  b.bid = {bx, by, bz};
+  b.lds = g_lds_arena; b.dyn_size = lds; b.static_top = (lds + 15) & ~(size_t)15;
+  b.lanes.resize(nthreads); b.waves.resize(nthreads / 64);
+  b.nlive = nthreads;
+  g_blk = &b;
+  for (int t = 0; t < nthreads; t++) {
+    Lane& L = b.lanes[t];
+    L.wave = t / 64; L.lane = t % 64;
+    L.tid = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
+    L.stack = (*t_stacks)[t];
+    prepare_fibre(L);
+    b.waves[L.wave].nlive++;
+  }
+  std::vector<int> order(b.waves.size());
+  for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+  if (g_cfg.greedy) {
+    unsigned s = g_cfg.seed * 2654435761u + lin * 40503u + 12345u;
+    for (size_t i = order.size(); i > 1; i--) { s = s * 1664525u + 1013904223u; std::swap(order[i - 1], order[(s >> 16) % i]); }
+  }
+  int ndone = 0;
+  while (ndone < nthreads) {
+    bool progress = false;
+    for (int wi : order) {
+      bool ran;
+      do {
+        ran = false;
+        for (int l = 0; l < 64; l++) {
+          Lane& L = b.lanes[wi * 64 + l];
+          if (L.done) continue;
+          const bool ok = L.wait_kind == 0 || (L.wait_kind == 1 && b.waves[wi].gen != L.wait_gen) || (L.wait_kind == 2 && b.bar_gen != L.wait_gen);
+          if (!ok) continue;
+          g_cur = &L;
+          hipemu_switch(&g_main, &L.ctx);
+          if (L.done) ndone++;
+          ran = progress = true;
+        }
+      } while (g_cfg.greedy && ran);
+    }
+    if (!progress) { g_cur = nullptr; die("deadlock: a collective or barrier that not every live lane reaches"); }
+  }
+  t_cnt.blocks++;
+  g_blk = nullptr; g_cur = nullptr;
+}
+
+// persistent worker threads: run(n, job) executes job on n threads (the caller is one of them) and returns when all are done
+struct Pool {
+  std::mutex m;
+  std::condition_variable cv_work, cv_done;
+  std::vector<std::thread> workers;
+  const std::function<void()>* job = nullptr;
+  unsigned gen = 0; int want = 0, started = 0, finished = 0;
+  bool stop = false;
+  void worker() {
+    unsigned seen = 0;
+    for (;;) {
+      const std::function<void()>* j;
+      {
+        std::unique_lock<std::mutex> g(m);
+        cv_work.wait(g, [&] { return stop || (gen != seen && started < want); });
+        if (stop) return;
+        seen = gen; started++; j = job;
+      }
+      (*j)();
+      { std::lock_guard<std::mutex> g(m); finished++; }
+      cv_done.notify_all();
+    }
+  }
+  void run(int n, const std::function<void()>& f) {
+    while ((int)workers.size() < n - 1) workers.emplace_back([this] { worker(); });
+    { std::lock_guard<std::mutex> g(m); job = &f; want = n - 1; started = 0; finished = 0; gen++; }
+    cv_work.notify_all();
+    f();
+    std::unique_lock<std::mutex> g(m);
+    cv_done.wait(g, [&] { return finished == want; });
+    want = 0;
+  }
+  ~Pool() {
+    { std::lock_guard<std::mutex> g(m); stop = true; }
+    cv_work.notify_all();
+    for (auto& t : workers) t.join();
+  }
+};
+
+inline void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& kernel) {
+  configure_from_env();
   const int nthreads = block.x * block.y * block.z;
   if (nthreads % 64) { fprintf(stderr, "hipemu: block size %d is not a multiple of 64\n", nthreads); abort(); }
   if (lds > LDS_BYTES) { fprintf(stderr, "hipemu: %zu B of dynamic LDS\n", lds); abort(); }
-  static std::vector<char*> stacks;
-  while ((int)stacks.size() < nthreads) stacks.push_back((char*)malloc(STACK_BYTES));
   g_grid = {grid.x, grid.y, grid.z}; g_bdim = {block.x, block.y, block.z};
   g_kernel = &kernel;
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  int T = g_cfg.threads;
+  if (T <= 0) { T = (int)sysconf(_SC_NPROCESSORS_ONLN); if (T > 8) T = 8; if (T < 1) T = 1; }
+  if ((unsigned)T > nblocks) T = (int)nblocks;
+  auto merge = [] {
+    std::lock_guard<std::mutex> g(g_cnt_mutex);
+    g_cfg.blocks += t_cnt.blocks; g_cfg.mfma += t_cnt.mfma; g_cfg.dma_ops += t_cnt.dma_ops; g_cfg.tr_reads += t_cnt.tr_reads;
+    t_cnt = Counters();
+  };
+  if (T <= 1) {
+    for (unsigned b = 0; b < nblocks; b++) run_block(b, grid, block, lds);
+    merge();
+  } else {
+    // workgroups are independent (the kernels' only inter-workgroup traffic is accumulate-style atomics, real atomics here): spread them over a
+    // persistent pool of host threads (each keeps its LDS arena and fibre stacks between launches)
+    static Pool pool;
+    std::atomic<unsigned> next{0};
+    pool.run(T, [&] {
+      for (unsigned b = next.fetch_add(1); b < nblocks; b = next.fetch_add(1)) run_block(b, grid, block, lds);
+      merge();
+    });
+  }
   g_cfg.launches++;
-  for (unsigned bz = 0; bz < grid.z; bz++)
-    for (unsigned by = 0; by < grid.y; by++)
-      for (unsigned bx = 0; bx < grid.x; bx++) {
-        Block b;
-        b.bid = {bx, by, bz};
-        b.lds = g_lds_arena; b.dyn_size = lds; b.static_top = (lds + 15) & ~(size_t)15;
-        // LDS is NOT cleared between workgroups: a kernel that reads what it never wrote sees the previous workgroup's bytes (first one: 0xCD)
-        if (g_cfg.blocks == 0) memset(g_lds_arena, 0xCD, LDS_BYTES);
-        b.lanes.resize(nthreads); b.waves.resize(nthreads / 64);
-        b.nlive = nthreads;
-        g_blk = &b;
-        for (int t = 0; t < nthreads; t++) {
-          Lane& L = b.lanes[t];
-          L.wave = t / 64; L.lane = t % 64;
-          L.tid = {(unsigned)(t % block.x), (unsigned)((t / block.x) % block.y), (unsigned)(t / (block.x * block.y))};
-          L.stack = stacks[t];
-          getcontext(&L.ctx);
-          L.ctx.uc_stack.ss_sp = L.stack; L.ctx.uc_stack.ss_size = STACK_BYTES; L.ctx.uc_link = &g_main;
-          makecontext(&L.ctx, (void (*)())lane_entry, 0);
-          b.waves[L.wave].nlive++;
-        }
-        std::vector<int> order(b.waves.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-        if (g_cfg.greedy) {
-          unsigned s = g_cfg.seed * 2654435761u + bx * 40503u + 12345u;
-          for (size_t i = order.size(); i > 1; i--) { s = s * 1664525u + 1013904223u; std::swap(order[i - 1], order[(s >> 16) % i]); }
-        }
-        int ndone = 0;
-        while (ndone < nthreads) {
-          bool progress = false;
-          for (int wi : order) {
-            bool ran;
-            do {
-              ran = false;
-              for (int l = 0; l < 64; l++) {
-                Lane& L = b.lanes[wi * 64 + l];
-                if (L.done) continue;
-                const bool ok = L.wait_kind == 0 || (L.wait_kind == 1 && b.waves[wi].gen != L.wait_gen) || (L.wait_kind == 2 && b.bar_gen != L.wait_gen);
-                if (!ok) continue;
-                g_cur = &L;
-                swapcontext(&g_main, &L.ctx);
-                if (L.done) ndone++;
-                ran = progress = true;
-              }
-            } while (g_cfg.greedy && ran);
-          }
-          if (!progress) { g_cur = nullptr; die("deadlock: a collective or barrier that not every live lane reaches"); }
-        }
-        g_cfg.blocks++;
-        g_blk = nullptr; g_cur = nullptr;
-      }
 }
 
 // ---- LDS ------------------------------------------------------------------------------------------------------------------------------------
@@ -259,7 +367,7 @@ inline e_s16x4 ds_read_tr16_b64(unsigned addr) {
   if (addr & 7) die("ds_read_b64_tr_b16 address not 8-byte aligned");
   e_s16x4 out;
   wave_sync(&addr, &out, [](Wave& w) {
-    g_cfg.tr_reads++;
+    t_cnt.tr_reads++;
     for (int l = 0; l < 64; l++) {
       if (!(w.amask >> l & 1)) continue;
       const int g = l & ~15, t = l & 15;
@@ -297,7 +405,7 @@ inline void dma_collect(Wave& w) {
     if (op.dst != in->dst) die("LDS-DMA: the LDS base (M0) differs between lanes of a wave");
     memcpy(op.data[l], in->data, in->bytes);
   }
-  g_cfg.dma_ops++;
+  t_cnt.dma_ops++;
   if (g_cfg.dma_late) w.dma.push_back(op); else apply_dma(op);
 }
 // __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc, lds base (wave-uniform), size, voffset, soffset, inst offset, aux):
@@ -373,34 +481,38 @@ inline float bf16_bits_to_f(uint16_t b) { uint32_t u = (uint32_t)b << 16; float 
 struct MfmaIn { e_bf16x8 a, b; e_f32x16 c; };
 // v_mfma_f32_32x32x16_bf16: D[i][j] = C[i][j] + sum_k A[i][k] B[k][j]; lane l holds A[l % 32][8 (l / 32) .. + 7], B[8 (l / 32) .. + 7][l % 32],
 // and in register r of C / D: row 8 (r / 4) + 4 (l / 32) + r % 4, column l % 32.
+void mfma_bf16_fire(Wave& w);                 // defined once, in the translation unit that sets HIPEMU_IMPL (stubs.cpp: built -O3 for this loop)
 inline e_f32x16 mfma_32x32x16_bf16(e_bf16x8 a, e_bf16x8 b, e_f32x16 c) {
   MfmaIn in{a, b, c};
   e_f32x16 out;
-  wave_sync(&in, &out, [](Wave& w) {
-    if (w.amask != ~0ull) die("MFMA with inactive lanes");
-    g_cfg.mfma++;
-    static float A[32][16], B[16][32];
-    for (int l = 0; l < 64; l++) {
-      const MfmaIn* in = (const MfmaIn*)w.in[l];
-      uint16_t ab[8], bb[8];
-      memcpy(ab, &in->a, 16); memcpy(bb, &in->b, 16);
-      for (int e = 0; e < 8; e++) { A[l % 32][8 * (l / 32) + e] = bf16_bits_to_f(ab[e]); B[8 * (l / 32) + e][l % 32] = bf16_bits_to_f(bb[e]); }
-    }
-    for (int l = 0; l < 64; l++) {
-      const MfmaIn* in = (const MfmaIn*)w.in[l];
-      e_f32x16 d;
-      const int j = l % 32;
-      for (int r = 0; r < 16; r++) {
-        const int i = 8 * (r / 4) + 4 * (l / 32) + r % 4;
-        float s = in->c[r];
-        for (int k = 0; k < 16; k++) s += A[i][k] * B[k][j];
-        d[r] = s;
-      }
-      *(e_f32x16*)w.out[l] = d;
-    }
-  });
+  wave_sync(&in, &out, mfma_bf16_fire);
   return out;
 }
+#ifdef HIPEMU_IMPL
+void mfma_bf16_fire(Wave& w) {
+  if (w.amask != ~0ull) die("MFMA with inactive lanes");
+  t_cnt.mfma++;
+  alignas(64) float A[32][16], B[16][32], D[32][32];
+  for (int l = 0; l < 64; l++) {
+    const MfmaIn* in = (const MfmaIn*)w.in[l];
+    uint16_t ab[8], bb[8];
+    memcpy(ab, &in->a, 16); memcpy(bb, &in->b, 16);
+    for (int e = 0; e < 8; e++) { A[l % 32][8 * (l / 32) + e] = bf16_bits_to_f(ab[e]); B[8 * (l / 32) + e][l % 32] = bf16_bits_to_f(bb[e]); }
+    for (int r = 0; r < 16; r++) D[8 * (r / 4) + 4 * (l / 32) + r % 4][l % 32] = in->c[r];
+  }
+  // D[i][j] += A[i][k] B[k][j], k ascending for every (i, j): one fp32 product and one fp32 sum per step (no contraction: -ffp-contract=off)
+  for (int i = 0; i < 32; i++)
+    for (int k = 0; k < 16; k++) {
+      const float a = A[i][k];
+      for (int j = 0; j < 32; j++) D[i][j] += a * B[k][j];
+    }
+  for (int l = 0; l < 64; l++) {
+    e_f32x16 d;
+    for (int r = 0; r < 16; r++) d[r] = D[8 * (r / 4) + 4 * (l / 32) + r % 4][l % 32];
+    *(e_f32x16*)w.out[l] = d;
+  }
+}
+#endif
 struct Mfma2In { float a, b; e_f32x16 c; };
 // v_mfma_f32_32x32x2_f32: lane l holds A[l % 32][l / 32] and B[l / 32][l % 32]
 inline e_f32x16 mfma_32x32x2_f32(float a, float b, e_f32x16 c) {
@@ -408,7 +520,7 @@ inline e_f32x16 mfma_32x32x2_f32(float a, float b, e_f32x16 c) {
   e_f32x16 out;
   wave_sync(&in, &out, [](Wave& w) {
     if (w.amask != ~0ull) die("MFMA with inactive lanes");
-    g_cfg.mfma++;
+    t_cnt.mfma++;
     float A[32][2], B[2][32];
     for (int l = 0; l < 64; l++) { const Mfma2In* in = (const Mfma2In*)w.in[l]; A[l % 32][l / 32] = in->a; B[l / 32][l % 32] = in->b; }
     for (int l = 0; l < 64; l++) {
@@ -462,9 +574,51 @@ inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::g_cur->lane ^ m); }
 template <class T> inline T __shfl(T v, int s, int = 64) { return hipemu::shfl_idx(v, s); }
 template <class T> inline T __shfl_down(T v, int d, int = 64) { const int s = hipemu::g_cur->lane + d; return hipemu::shfl_idx(v, s < 64 ? s : hipemu::g_cur->lane); }
-template <class T> inline T atomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T hipemu_atomic_rmw(T* p, T v, T (*op)(T, T)) {       // compare-and-swap loop on the value's bit pattern (float / double / integers)
+  static_assert(sizeof(T) == 4 || sizeof(T) == 8, "atomic width");
+  typedef typename std::conditional<sizeof(T) == 4, uint32_t, uint64_t>::type U;
+  U* q = (U*)p;
+  U old = __atomic_load_n(q, __ATOMIC_RELAXED);
+  for (;;) {
+    T o; memcpy(&o, &old, sizeof(T));
+    const T n = op(o, v);
+    U nb; memcpy(&nb, &n, sizeof(T));
+    if (__atomic_compare_exchange_n(q, &old, nb, false, __ATOMIC_RELAXED, __ATOMIC_RELAXED)) return o;
+  }
+}
+template <class T> inline T atomicAdd(T* p, T v) { return hipemu_atomic_rmw<T>(p, v, [](T a, T b) { return (T)(a + b); }); }
 inline float __expf(float x) { return expf(x); }
 inline float __fdividef(float a, float b) { return a / b; }
 inline float __frcp_rn(float a) { return 1.f / a; }
 inline float rsqrtf(float a) { return 1.f / sqrtf(a); }
-template <class T> inline T unsafeAtomicAdd(T* p, T v) { T o = *p; *p = o + v; return o; }
+template <class T> inline T unsafeAtomicAdd(T* p, T v) { return atomicAdd(p, v); }
+
+// ---- the rest of the (small) runtime / intrinsic surface the translation units of csrc use -------------------------------------------------------
+typedef struct hipemu_event { int dummy; }* hipEvent_t;
+inline hipError_t hipEventCreate(hipEvent_t* e) { static hipemu_event ev; *e = &ev; return hipSuccess; }
+inline hipError_t hipEventRecord(hipEvent_t, hipStream_t = nullptr) { return hipSuccess; }
+inline hipError_t hipEventElapsedTime(float* ms, hipEvent_t, hipEvent_t) { *ms = 0.f; return hipSuccess; }
+inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t = nullptr) { memset(p, v, n); return hipSuccess; }
+struct float2 { float x, y; };
+struct float4 { float x, y, z, w; };
+inline float2 make_float2(float x, float y) { return float2{x, y}; }
+inline float __fadd_rn(float a, float b) { return a + b; }
+inline float __fsub_rn(float a, float b) { return a - b; }
+inline float __fmul_rn(float a, float b) { return a * b; }
+inline float __fdiv_rn(float a, float b) { return a / b; }
+inline float __logf(float a) { return logf(a); }
+inline long long __double_as_longlong(double d) { long long v; memcpy(&v, &d, 8); return v; }
+inline double __longlong_as_double(long long v) { double d; memcpy(&d, &v, 8); return d; }
+inline int __ffsll(unsigned long long v) { return __builtin_ffsll((long long)v); }
+inline unsigned long long __ballot(int pred) {
+  unsigned long long out = 0;
+  hipemu::wave_sync(&pred, &out, [](hipemu::Wave& w) {
+    unsigned long long m = 0;
+    for (int l = 0; l < 64; l++) if ((w.amask >> l & 1) && *(const int*)w.in[l]) m |= 1ull << l;
+    for (int l = 0; l < 64; l++) if (w.amask >> l & 1) *(unsigned long long*)w.out[l] = m;
+  });
+  return out;
+}
+template <class T> inline T atomicExch(T* p, T v) { return hipemu_atomic_rmw<T>(p, v, [](T, T b) { return b; }); }
+template <class T> inline T atomicMax(T* p, T v) { return hipemu_atomic_rmw<T>(p, v, [](T a, T b) { return b > a ? b : a; }); }
+template <class T> inline T atomicMin(T* p, T v) { return hipemu_atomic_rmw<T>(p, v, [](T a, T b) { return b < a ? b : a; }); }

@@ -1,5 +1,5 @@
-// hipemu harness: the few C-ABI symbols the kernel translation units expect from capi.hip (error string, launch profiler), and the
-// emulator's switches as plain C functions for ctypes.  TEST INFRASTRUCTURE.
+// hipemu harness for ONE translation unit of csrc (TEST INFRASTRUCTURE): the few C-ABI symbols the kernel translation units expect from capi.hip
+// (error string, launch profiler). The whole-library build (fullemu.py) links the real capi.hip instead.
 #include <hip/hip_runtime.h>
 #include <string>
 static std::string g_err;
@@ -9,10 +9,3 @@ extern "C" int sg_prof_begin(hipStream_t, double, int) { return -1; }
 extern "C" void sg_prof_end(hipStream_t, int) {}
 extern "C" void sg_prof_set_executed(int, double) {}
 extern "C" void sg_prof_tag(int, int, double) {}
-extern "C" void hipemu_config(int dma_late, int greedy, unsigned seed) {
-  hipemu::configure_from_env();
-  hipemu::g_cfg.dma_late = dma_late; hipemu::g_cfg.greedy = greedy; hipemu::g_cfg.seed = seed;
-}
-extern "C" void hipemu_counters(long* out) {
-  out[0] = hipemu::g_cfg.launches; out[1] = hipemu::g_cfg.blocks; out[2] = hipemu::g_cfg.mfma; out[3] = hipemu::g_cfg.dma_ops; out[4] = hipemu::g_cfg.tr_reads;
-}

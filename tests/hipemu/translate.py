@@ -121,7 +121,10 @@ def _shared(decl):
     return "; ".join(out)
 
 
-def translate(src):
+def translate(src, base=0):
+    """base: first id of this file's static `__shared__` declarations (ids must not collide between the files of one kernel, and must not depend on
+    what was translated before: the build cache is keyed on the translated text)"""
+    _counter[0] = base
     src = re.sub(r"__attribute__\(\(address_space\(\d+\)\)\)", "", src)
     src = re.sub(r"__attribute__\(\(amdgpu_\w+\([^)]*\)\)\)", "", src)
     # extern __shared__ [attr] T name[];
@@ -161,7 +164,7 @@ def translate_tree(dst):
             continue
         with open(os.path.join(CSRC, fn)) as f:
             src = f.read()
-        text = translate(src).replace('"../../include/sgamd.h"', '"%s"' % os.path.join(REPO, "include", "sgamd.h"))
+        text = translate(src, 1000 * (1 + sorted(os.listdir(CSRC)).index(fn))).replace('"../../include/sgamd.h"', '"%s"' % os.path.join(REPO, "include", "sgamd.h"))
         if fn == "common.h":
             text = text.replace("#pragma once", "#pragma once\n" + PRELUDE, 1)
         path = os.path.join(dst, fn)

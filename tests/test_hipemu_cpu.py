@@ -95,6 +95,7 @@ def test_wgrad_v3_upsampled_operands(wg):
             assert np.abs(db - rb).max() <= 2e-6 * np.abs(rb).max()
 
 
+@pytest.mark.skipif(os.environ.get("SG_EMU_NET") != "1", reason="builds a second, deliberately broken copy of conv_wgrad.hip (~1 min): SG_EMU_NET=1 (last run: profiles/r04_hipemu_nets.txt)")
 def test_interpreter_catches_a_missing_wait(wg, tmp_path):
     """the adversarial DMA mode is not decoration: the same kernel with its `s_waitcnt vmcnt(0)` removed must FAIL under late completion"""
     import translate
@@ -109,7 +110,8 @@ def test_interpreter_catches_a_missing_wait(wg, tmp_path):
     (d / "wgrad_v3.h").write_text(broken)
     lib = tmp_path / "libbroken.so"
     subprocess.run([emu.CXX, "-x", "c++", "-std=c++17", "-O1", "-fPIC", "-shared", "-I" + os.path.join(emu.HERE, "include"), "-I" + str(d),
-                    "-Wno-unknown-attributes", "-Wno-unused-value", str(d / "conv_wgrad.hip"), os.path.join(emu.HERE, "stubs.cpp"), "-o", str(lib)], check=True)
+                    "-Wno-unknown-attributes", "-Wno-unused-value", "-ffp-contract=off", str(d / "conv_wgrad.hip"), os.path.join(emu.HERE, "stubs.cpp"),
+                    os.path.join(emu.HERE, "rt.cpp"), "-o", str(lib)], check=True)
     import ctypes
     bl = ctypes.CDLL(str(lib))
     bl.sg_last_error.restype = ctypes.c_char_p

@@ -1,0 +1,149 @@
+"""Whole training steps of the package on the CPU: its Python layer (autograd functions, weight bank, fused optimiser, worker) drives its real launch
+sequence through libsgamd's own kernel SOURCES, interpreted lane by lane (tests/hipemu/fullemu.py), and the result is held against the golden
+fixtures the real reference wrote (tests/golden/*.npz) -- the same check tests/test_model_gpu.py::test_training_step_vs_golden makes on the GPU, same
+tolerances. What this is for: host-side changes (launch order, fused operands, weight-bank layouts) can be checked at network level without
+GPU time. What it is not: a product path (the package is bound to the interpreter by this test process only) or a performance statement.
+
+One fixture runs by default (an fp32 BigGAN step at width 8: ~10 s after the one-off host build of the library, ~1 min on 8 cores); SG_EMU_NET=1 runs every width-8
+fixture in fp32 (tools/sessions/cpu_emu_nets.sh; last full run: profiles/r04_hipemu_nets.txt)."""
+import os
+import sys
+
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hipemu"))
+sys.path.insert(0, os.path.dirname(HERE))
+import emu  # noqa: E402
+
+pytestmark = pytest.mark.skipif(not emu.available(), reason="host clang++ of the ROCm toolchain not found")
+FULL = os.environ.get("SG_EMU_NET") == "1"
+ALL = ["dcgan32", "sndcgan32", "sngan32", "resgan32", "wgangp32", "sngp32", "bigdeep32", "bigdeepsg32"]
+
+
+@pytest.fixture(autouse=True)
+def _one_torch_thread():
+    # torch's OpenMP workers keep spinning after a parallel region: next to the interpreter's own thread pool they cost a factor of ~7 in wall time
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    yield
+    torch.set_num_threads(n)
+
+
+def _step(name, mixed):
+    import fullemu
+    import test_model_gpu as TM
+    import contextlib
+    import io
+    log = io.StringIO()
+    with fullemu.Installed(dma_late=1, greedy=1, seed=1) as E:
+        c0 = E.counters()
+        try:
+            with contextlib.redirect_stdout(log):          # (the per-tensor report of the comparison: shown only when it fails)
+                TM.step_vs_golden(name, mixed, torch.device("cpu"))
+        except BaseException:
+            print(log.getvalue())
+            raise
+        c1 = E.counters()
+    assert c1["launches"] - c0["launches"] > 100 and c1["mfma"] > c0["mfma"]        # the kernels ran (there is nothing else that could have)
+    return {k: c1[k] - c0[k] for k in c1}
+
+
+def test_emulated_training_step_vs_golden_default():
+    """one fixture in the default CPU suite: an fp32 BigGAN step at width 8 (~700 launches: generic GEMM convolutions forward / data / weight gradient,
+    spectral norm forward + backward, conditional batch norm, self-attention, projection discriminator, hinge loss, fused Adam + EMA), the reference's
+    golden vectors at the fp32 tolerances"""
+    _step("biggan32", False)
+
+
+@pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1 runs every width-8 fixture through the interpreter (minutes)")
+@pytest.mark.parametrize("name", ALL)
+def test_emulated_fp32_training_step_vs_golden(name):
+    _step(name, False)
+
+
+def test_emulated_frozen_network_weight_image_cache():
+    """bank.WeightBank.begin_forward keeps the emitted weight images of a frozen network (eval mode, no graph: the evaluation generator of the FID
+    loop) until something writes its parameters: hits give bit-identical images, a torch-side write (in-place op, load_state_dict), a raw-pointer
+    write (the fused Adam + EMA launch) and a training-mode forward (power iteration) each force a re-emission that equals the uncached one."""
+    import copy
+    import fullemu
+    import test_model_gpu as TM
+    from util import load_golden, sub, hyper
+    from studiogan_amd import bank as B, ops
+    from studiogan_amd.worker import Worker
+    dev = torch.device("cpu")
+    fix, meta = load_golden("biggan32")
+    y = meta["yaml"]
+    with fullemu.Installed(dma_late=1, greedy=1, seed=2) as E:
+        G, D = TM.build_from_yaml(y, False, dev)
+        G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+        D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
+        opt = hyper(y)
+        w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+                   d_updates_per_step=1, apply_g_ema=True, g_ema_decay=0.9, g_ema_start=0, apply_gp=opt["apply_gp"], gp_lambda=opt["gp_lambda"])
+        ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+        z, lab = ins["z0"], ins["fl0"]
+        Ge = w.Gen_ema
+        Ge.eval()
+        _, bank = ops._root_and_bank(Ge)
+
+        def run(cache=True):
+            B._EVAL_CACHE[0] = cache
+            try:
+                with torch.no_grad():
+                    Ge(z, lab, eval=True)
+                s0 = bank.slots[0]      # what the cache keeps: the emitted operand images of the no-graph slot (the width-8 generator's tanh output is saturated)
+                return torch.cat([s0.img.float().flatten(), s0.f32.flatten()]).clone()
+            finally:
+                B._EVAL_CACHE[0] = True
+
+        def same(u, v):      # two emissions of the same weights: equal up to the order of the fp32 atomics in the spectral-norm reductions
+            ok = torch.allclose(u, v, rtol=1e-5, atol=2e-6, equal_nan=True)        # (padding the emission never writes may hold anything)
+            if not ok:
+                d = (u - v).abs()
+                print("emissions differ: max", d.max().item(), "at", d.argmax().item(), u[d.argmax()].item(), v[d.argmax()].item(), "n", (d > 2e-6).sum().item())
+            return ok
+
+        def hits():
+            return bank.__dict__.get("eval_cache_hits", 0)
+        a = run()
+        h0, l0 = hits(), E.counters()["launches"]
+        b = run()
+        l1 = E.counters()["launches"]
+        c = run()
+        l2 = E.counters()["launches"]
+        assert hits() == h0 + 2 and torch.equal(a, b) and torch.equal(a, c)
+        assert l2 - l1 == l1 - l0                                         # (steady state: the same launches per cached forward)
+        ref = run(cache=False)
+        l3 = E.counters()["launches"]
+        assert same(ref, a) and (l3 - l2) > (l2 - l1)              # the uncached forward issues the spectral-norm / packing launches on top
+        # 1. torch-side write
+        p = next(q for n, q in Ge.named_parameters() if n.endswith("weight_orig") or n.endswith(".weight"))
+        with torch.no_grad():
+            p.add_(0.05 * torch.randn(p.shape, generator=torch.Generator().manual_seed(5)))
+        h = hits()
+        d = run()
+        assert hits() == h and not torch.equal(d, a) and same(d, run(cache=False))
+        # 2. raw-pointer write: one generator update moves G and, inside the same launch, the EMA copy
+        w.train_generator(0, [(ins["z1"], ins["fl1"])])
+        Ge.eval()                                     # (the worker leaves its networks in training mode)
+        h = hits()
+        e = run()
+        assert hits() == h and not torch.equal(e, d) and same(e, run(cache=False))
+        e2 = run()                                    # (the uncached emission above left the slot unkeyed: this one re-emits and keys it)
+        assert same(e2, e) and torch.equal(run(), e2) and hits() == h + 1
+        # 3. load_state_dict
+        Ge.load_state_dict(copy.deepcopy(G.state_dict()), strict=True)
+        h = hits()
+        f = run()
+        assert hits() == h and not torch.equal(f, e) and same(f, run(cache=False))
+        # 4. a training-mode forward of the same network runs the power iteration (u / v move): the next frozen forward re-emits
+        Ge.train()
+        with torch.no_grad():
+            Ge(z, lab)
+        Ge.eval()
+        h = hits()
+        g2 = run()
+        assert hits() == h and same(g2, run(cache=False))

@@ -43,9 +43,10 @@ def test_training_step_vs_golden(sg, name, mixed):
     step_vs_golden(name, mixed)
 
 
-def step_vs_golden(name, mixed):
+def step_vs_golden(name, mixed, dev=None):
+    """dev: the GPU, or the CPU when the package is bound to the emulated library (tests/test_hipemu_net_cpu.py)"""
     from studiogan_amd.worker import Worker
-    dev = torch.device("cuda:0")
+    dev = dev or torch.device("cuda:0")
     fix, meta = load_golden(name)
     cond = load_cond(name) if not mixed else {}      # fp32: measured conditioning of the reference chain (bf16 has its own, larger, rounding noise)
     nz = lambda k: cond.get("chain/" + k)

@@ -1,0 +1,30 @@
+#!/bin/bash
+# round-5 GPU session A (FIRST GPU minutes of the round): the kernels written in round 4 without GPU time -- wgrad_v3l.h / wgrad_ql.h ("lean" weight
+# gradients: LDS-DMA addresses once per workgroup, ReLU as a template parameter, bias gradient through v_dot2; CPU: tests/test_hipemu_cpu.py,
+# bit-identical to the shipped kernels under the interpreter). 1. parity on the GPU (opt-in tests), 2. layer tables A/B, 3. step A/B.
+# Decision rule: a switch becomes the default when its layer table is faster on the same box and the step is not slower.
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+O=gpurun_out/r5a
+mkdir -p $O
+( time SG_EXPERIMENTAL=1 timeout 400 python -m pytest tests/test_conv_v2_gpu.py tests/test_quad_gpu.py -q -p no:cacheprovider --maxfail=10 -k "lean" 2>&1 | tail -8 ) > $O/pytest_lean.txt 2>&1
+cat $O/pytest_lean.txt | cut -c1-250
+for f in 0 1; do
+  ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 | grep -i "wgrad\|average\|avg" ) > $O/conv_bench_v3lean$f.txt 2>&1
+  ( SG_WGRAD_Q_LEAN=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_qlean$f.txt 2>&1
+  tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
+done
+for f in 0 1; do
+  ( SG_WGRAD_V3_LEAN=$f SG_WGRAD_Q_LEAN=$f timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --fid-samples 0 ) > $O/bench_lean$f.json 2> $O/bench_lean$f.err
+  python - <<PY
+import json
+try:
+    j=json.loads([l for l in open("$O/bench_lean$f.json") if l.startswith("{")][-1])
+    r=j["roofline"]
+    pk=r["per_kernel"]
+    print("LEAN=$f", j["value"], "img/s", j["ms_per_step"], "ms; conv ms", r["conv_ms_per_step"], {k: (v["ms_per_step"], v["executed_tflops"]) for k, v in pk.items() if "wgrad" in k}, "losses", j["last_step_losses"])
+except Exception as e:
+    print("failed", e)
+PY
+  tail -2 $O/bench_lean$f.err | cut -c1-200
+done
