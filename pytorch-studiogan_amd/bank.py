@@ -414,7 +414,7 @@ class WeightBank:
         # (load_state_dict, an in-place op on a parameter) move the tensors' version counters. SG_EVAL_CACHE=0 re-emits every time.
         key = None
         if not need_graph and not any(flags) and _EVAL_CACHE[0]:
-            key = (L.write_epoch[0], sum(p._version for p in self._versioned()), self._fwd_train_epoch)
+            key = (L.write_epoch[0], sum(p._version for p in self._versioned()), self.params.data._version, self.buffers.data._version, self._fwd_train_epoch)
             if slot.__dict__.get("emit_key") == key:
                 self.current = slot
                 self.eval_cache_hits = self.__dict__.get("eval_cache_hits", 0) + 1
