@@ -228,7 +228,7 @@ inline void run_block(unsigned lin, dim3 grid, dim3 block, size_t lds) {
   Block b;
   b.bid = {bx, by, bz};
   b.lds = g_lds_arena; b.dyn_size = lds; b.static_top = (lds + 15) & ~(size_t)15;
-  b.lanes.resize(nthreads); b.waves.resize(nthreads / 64);
+  b.lanes.resize(nthreads); b.waves.resize((nthreads + 63) / 64);        // (a partial last wave: its missing lanes never exist)
   b.nlive = nthreads;
   g_blk = &b;
   for (int t = 0; t < nthreads; t++) {
@@ -252,7 +252,7 @@ inline void run_block(unsigned lin, dim3 grid, dim3 block, size_t lds) {
       bool ran;
       do {
         ran = false;
-        for (int l = 0; l < 64; l++) {
+        for (int l = 0; l < 64 && wi * 64 + l < nthreads; l++) {
           Lane& L = b.lanes[wi * 64 + l];
           if (L.done) continue;
           const bool ok = L.wait_kind == 0 || (L.wait_kind == 1 && b.waves[wi].gen != L.wait_gen) || (L.wait_kind == 2 && b.bar_gen != L.wait_gen);
@@ -312,7 +312,6 @@ struct Pool {
 inline void launch(dim3 grid, dim3 block, size_t lds, const std::function<void()>& kernel) {
   configure_from_env();
   const int nthreads = block.x * block.y * block.z;
-  if (nthreads % 64) { fprintf(stderr, "hipemu: block size %d is not a multiple of 64\n", nthreads); abort(); }
   if (lds > LDS_BYTES) { fprintf(stderr, "hipemu: %zu B of dynamic LDS\n", lds); abort(); }
   g_grid = {grid.x, grid.y, grid.z}; g_bdim = {block.x, block.y, block.z};
   g_kernel = &kernel;
@@ -440,6 +439,9 @@ inline void waitcnt_vm(int n) {
     drain_dma(w, (size_t)n0);
   });
 }
+// the lanes of a wave are independent fibres between collectives; the hardware executes them in lockstep. Where a kernel passes data between the lanes of ONE
+// wave through LDS without a workgroup barrier (conv_sk.h's wave-private epilogue tile), its explicit `s_waitcnt lgkmcnt` is the re-alignment point.
+inline void wave_lockstep() { int z = 0; wave_sync(&z, nullptr, [](Wave&) {}); }
 inline void s_barrier() { block_barrier(); }
 inline void syncthreads() { waitcnt_vm(0); block_barrier(); }      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
 

@@ -3,7 +3,10 @@ compiler can build the kernels against tests/hipemu/include/hip/hip_runtime.h. N
 arithmetic and their launchers are compiled as they stand; only these constructs change form
 
     asm volatile("s_waitcnt vmcnt(N)" ...)                  -> hipemu::waitcnt_vm(N)           (drains the wave's queued LDS-DMA transfers)
-    asm volatile("s_waitcnt lgkmcnt(..)" ...), asm("" ...)  -> nothing                          (LDS reads complete at once in the model)
+    asm volatile("s_waitcnt lgkmcnt(..)" ...)               -> hipemu::wave_lockstep()          (LDS accesses complete at once in the model, but the lanes of a
+                                                               wave are fibres: where a kernel exchanges data between lanes through LDS and
+                                                               relies on the SIMD's lockstep, its explicit wait is where the fibres re-align)
+    asm volatile("" ...)                                    -> nothing
     asm volatile("ds_read_b64_tr_b16 %0, %1 [offset:..]")   -> hipemu transpose read            (a wave-level collective)
     __attribute__((address_space(N))), amdgpu_* attributes  -> dropped                          (LDS lives below 4 GB: a pointer IS its address)
     extern __shared__ T name[];                             -> T* name = workgroup's dynamic LDS
@@ -93,7 +96,7 @@ def _asm(stmt):
     if m:
         return "hipemu::waitcnt_vm(%s)" % (ops[int(m.group(2))] if m.group(1) else m.group(2))
     if re.match(r"s_waitcnt lgkmcnt\(", t):
-        return "((void)0)"
+        return "hipemu::wave_lockstep()"
     m = re.match(r"ds_read_b64_tr_b16 %0, %1(?: offset:(%?)(\d+))?$", t)
     if m:
         off = "0" if m.group(2) is None else (ops[int(m.group(2))] if m.group(1) else m.group(2))

@@ -396,7 +396,7 @@ FLOOR_EPS = 1e-5       # relative weight perturbation of the oracle's own noise-
 FLOOR_FACTOR = 1.5
 
 
-def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floor=None, shared_objective=False, teacher=None):
+def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floor=None, shared_objective=False, teacher=None, dev=None):
     """bf16 mode against the oracle run with `Bf16Emu` (oracle/restate.py): the same bf16 rounding at the same storage points
     (activations, activation gradients, weight images), fp32 everywhere else. Per operator the model is exact to 3e-5
     (conv / BN forward + backward) and 8e-3 (attention backward) -- tools/diag_bf16.py, measured on MI355X; over a whole
@@ -419,7 +419,7 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
     input and upstream gradient (ops.block_boundary), so nothing compounds across blocks and no ReLU-mask flip of an earlier block reaches a later
     one: every block output, every block-input gradient and every weight gradient must agree to 1e-2 relative-L2 -- a 10-50 % error in one
     weight-gradient kernel, invisible under the whole-network floor of the generators, fails here."""
-    dev = torch.device("cuda:0")
+    dev = dev or torch.device("cuda:0")     # (the CPU when the package is bound to the interpreted library: tests/test_hipemu_net_cpu.py)
     fix, meta = load_golden(name)
     y = meta["yaml"]
     ocfg = dict(MG.oracle_cfg(y), emu=O.Bf16Emu)
@@ -501,14 +501,14 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
         gadv = torch.tensor([0.3, -1.0, 0.7, 0.5, -0.2, 0.9, -0.6, 0.1]).repeat((xd.shape[0] + 7) // 8)[:xd.shape[0]]
         out = D(xd, lab.to(dev))
         (out["adv_output"] * gadv.to(dev)).sum().backward()
-        torch.cuda.synchronize()
+        (torch.cuda.synchronize() if dev.type == "cuda" else None)
         C.check("D adv", out["adv_output"], ref["D adv"], tol("D adv", 2e-2), l2=full)
         C.check("D h", out["h"], ref["D h"], tol("D h", 2e-2), l2=full)
         C.check("D dx", xd.grad, ref["D dx"], tol("D dx", tg), l2=True)
     else:
         img = G(fix["in/z0"].to(dev), fix["in/fl0"].to(dev))
         (img * gimg.to(dev)).sum().backward()
-        torch.cuda.synchronize()
+        (torch.cuda.synchronize() if dev.type == "cuda" else None)
         C.check("G img", img, ref["G img"], tol("G img", 2e-2), l2=full)
     gmax = max(float(v.grad.abs().max()) for v in leaves.values())
     num = den = 0.0
@@ -565,7 +565,7 @@ def bf16_vs_emulating_oracle(name, which, report=None, batch=None, tg=None, floo
             roots = [tf.out[b] for b in order] + [final]
             grads = [to_dev(taps.act[b].grad) for b in order] + [gfinal.to(final.dtype) if final.dtype != gfinal.dtype else gfinal]
             torch.autograd.backward(roots, grads)
-            torch.cuda.synchronize()
+            (torch.cuda.synchronize() if dev.type == "cuda" else None)
         finally:
             net.__dict__.pop("_sg_teacher", None)
         back = lambda t: t.detach().float().permute(0, 3, 1, 2)

@@ -147,3 +147,51 @@ def test_emulated_frozen_network_weight_image_cache():
         h = hits()
         g2 = run()
         assert hits() == h and same(g2, run(cache=False))
+
+
+# ---- the FAST kernels at full width (SG_EMU_NET=1: 1-3 min each) ------------------------------------------------------------------------------------------
+FORCE = ("SG_CONV_V4", "SG_CONV_V3", "SG_CONV_V2", "SG_CONV_SK", "SG_CONV_RS", "SG_CONV_RS96", "SG_WGRAD_BJ256", "SG_WGRAD_V3")
+
+
+@pytest.fixture
+def forced_fast_kernels(monkeypatch):
+    """what tests/test_fullwidth_gpu.py::forced does: the kernels bench.py runs at batch 256 take the fixtures' small batches too"""
+    for k in FORCE:
+        monkeypatch.setenv(k, "force")
+
+
+@pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: BigGAN-128 at FULL width (batch 4) through the interpreter, ~3 min")
+@pytest.mark.parametrize("lean", ["0", "1"])
+def test_emulated_fullwidth_bf16_step_vs_golden(forced_fast_kernels, monkeypatch, lean):
+    """the benchmarked network (BASELINE config 3: BigGAN, ImageNet-128 widths) with the benchmarked kernels -- conv_q / conv_v4 / conv_v3 / conv_sk /
+    conv_rs forward and data gradient, wgrad_v3 / wgrad_q / wgrad_sk / wgrad_v2, flash attention, epilogue BN statistics: 901 launches, 52 M MFMAs --
+    one bf16 training step against the reference's golden vectors. lean = 1: with the round-4 weight-gradient kernels that have not run on a GPU."""
+    monkeypatch.setenv("SG_WGRAD_V3_LEAN", lean)
+    monkeypatch.setenv("SG_WGRAD_Q_LEAN", lean)
+    c = _step("biggan128w", True)
+    assert c["dma_ops"] > 1e6 and c["tr_reads"] > 1e6          # the LDS-DMA / transpose-read kernels ran (the width-8 fixtures never reach them)
+
+
+@pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: teacher-forced block test of BigGAN-128 at full width through the interpreter, 1-2 min each")
+@pytest.mark.parametrize("which", ["D", "G"])
+def test_emulated_fullwidth_teacher_forced_blocks_with_lean_kernels(forced_fast_kernels, monkeypatch, which):
+    """tests/test_blocks_gpu.py::bf16_vs_emulating_oracle on the interpreter with SG_WGRAD_V3_LEAN = SG_WGRAD_Q_LEAN = 1: every block of the full-width
+    network on the bf16-emulating oracle's input and upstream gradient -- block output, input gradient and every weight gradient to 1e-2 relative L2
+    (discriminator: flat; generator: max(1e-2, 1.5 x measured floor)). The tight network-level bound on the lean weight-gradient kernels."""
+    import contextlib
+    import io
+    import fullemu
+    import test_blocks_gpu as TB
+    monkeypatch.setenv("SG_WGRAD_V3_LEAN", "1")
+    monkeypatch.setenv("SG_WGRAD_Q_LEAN", "1")
+    rows, log = [], io.StringIO()
+    with fullemu.Installed(dma_late=1, greedy=1, seed=1):
+        try:
+            with contextlib.redirect_stdout(log):
+                TB.bf16_vs_emulating_oracle("biggan128w", which, report=rows, dev=torch.device("cpu"))
+        except BaseException:
+            print(log.getvalue()[-6000:])
+            raise
+    worst = max((e for n, e, t in rows if "teacher-forced grad" in n), default=0.0)
+    print(f"{which}: worst teacher-forced weight-gradient error {worst:.3e} over {len(rows)} compared tensors")
+    assert rows and worst < 1e-2 * (1 if which == "D" else 3)
