@@ -28,3 +28,12 @@ except Exception as e:
 PY
   tail -2 $O/bench_lean$f.err | cut -c1-200
 done
+# 4. FID leg (bf16 Inception): conv_v2 for InceptionV3's 128 / 160-cout 1x7 / 7x1 layers (SG_CONV_V2_MIN_TILES / SG_CONV_V2_PAD_TILES), and the
+#    frozen-network weight-image cache (tools/fid_leg.py runs G.eval(): SG_EVAL_CACHE=0 is the round-4 behaviour)
+( timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval.txt 2>&1; cat $O/pytest_eval.txt | cut -c1-200
+for cfg in "SG_EVAL_CACHE=0" "SG_EVAL_CACHE=1" "SG_EVAL_CACHE=1 SG_CONV_V2_MIN_TILES=128" "SG_EVAL_CACHE=1 SG_CONV_V2_MIN_TILES=128 SG_CONV_V2_PAD_TILES=1"; do
+  tag=$(echo "$cfg" | tr ' =' '__')
+  ( env $cfg timeout 300 python tools/fid_leg.py --samples 10240 --dtype bf16 ) > $O/fid_$tag.json 2> $O/fid_$tag.err
+  echo "$cfg: $(grep -o '"value": [0-9.]*' $O/fid_$tag.json | head -1)"; tail -1 $O/fid_$tag.err | cut -c1-200
+done
+( SG_CONV_V2_MIN_TILES=128 SG_CONV_V2_PAD_TILES=1 timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval_v2.txt 2>&1; cat $O/pytest_eval_v2.txt | cut -c1-200
