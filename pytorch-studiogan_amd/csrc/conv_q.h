@@ -63,9 +63,16 @@ struct ConvQParams {
 // barrier that ends tap t needs the weights of tap t + 1 only: vmcnt(n_p + 2 n_w) behind taps 0-2 (leaves P' and two weight tiles in flight),
 // vmcnt(2 n_w) behind tap 3 (P' and W0' have landed). NPMIN = the smallest number of patch pieces a wave issues (compile-time immediate;
 // waves with one piece more only wait a little earlier than they must).
+//
+// NPMIN < 0 ("LA3", round 4, written without GPU time: SG_CONV_Q_LA3=1, default off): the single-buffered loop (three workgroups per CU) with the weights
+// THREE taps ahead instead of two. If the per-tap wait is the weight tile's DMA latency (a tap is 12 MFMAs per wave = 384 clk of its matrix pipe; a tile
+// requested two taps earlier has ~2 x 1152 clk at full rate to arrive), one more tap of lookahead costs nothing: the fourth buffer is free as soon as the
+// barrier that ends the previous tap has been passed. The double-buffered variant above already runs three ahead but pays for its second patch with
+// a workgroup per CU. Checked on the CPU interpreter (late DMA completion, seeded wave order): tests/test_hipemu_cpu.py.
 template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 : 3, NPMIN ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
   constexpr bool DB = NPMIN > 0;
+  constexpr bool LA3 = NPMIN < 0;           // single-buffered patch, weights THREE taps ahead (see above)
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -175,7 +182,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
   patch_slice(view, 0);
   weight_tile(0, view, 0, 0);
   weight_tile(1, view, 0, 1);
-  if (DB) weight_tile(2, view, 0, 2);
+  if (DB || LA3) weight_tile(2, view, 0, 2);
   __syncthreads();
   for (int vs = 0; vs < nvs; vs++) {
     const bool next_slice = vs + 1 < nvs;
@@ -190,8 +197,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
-      const bool issue = (t + 2 < 4) || next_slice;
-      if constexpr (DB) {
+      const bool issue = LA3 ? (t == 0 || next_slice) : ((t + 2 < 4) || next_slice);
+      if constexpr (LA3) {
+        // buffer (t + 3) % 4 = (t - 1) % 4 was read during the previous tap, and every wave is past the barrier that ended it
+        if (t == 0) weight_tile(3, view, s, 3);
+        else if (next_slice) weight_tile(t - 1, nview, ns, t - 1);
+      } else if constexpr (DB) {
         if (t == 0) {
           weight_tile(3, view, s, 3);
           if (next_slice) patch_slice(nview, ns, ((vs + 1) & 1) * p.patchb);
@@ -252,6 +263,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN ? 2 :
         __syncthreads();
         patch_slice(nview, ns);
         __syncthreads();
+      } else if constexpr (LA3) {
+        // the weights of tap t + 1 must have landed; behind them at most the tiles of taps t + 2 and t + 3 are in flight (n_w pieces each per wave)
+        if (next_slice || t == 0) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
+        else if (t == 1) { if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
       } else {
         if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -371,6 +388,7 @@ static inline int sg_launch_conv_qr(ConvQParams p, const Epilogue<bf16_t>& e, hi
 template <int NB, bool SKIP, bool RELU>
 static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
   if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
+  if (db == 2) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -1>(p, e, st);      // LA3
   if (db) {       // double-buffered patch: the smallest per-wave piece count is a compile-time immediate of the counted waits
     const int npmin = (p.npx >> 4) >> 2;
     if (npmin == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 4>(p, e, st);

@@ -198,3 +198,31 @@ def test_wgrad_q_pins_interpreter_and_lean_equals_shipped(cq, form, shape):
         b, bb, _ = emu.conv_q_wgrad(cq, form, x, dy, relu_in=relu, bias=True, alpha=0.5, env={"SG_WGRAD_Q": "f", "SG_WGRAD_Q_LEAN": "1"})
         assert np.array_equal(a, b), (form, shape, relu)
         assert np.abs(ab - bb).max() <= 1e-6 * np.abs(ab).max()
+
+
+@pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 96), (1, 32, 32, 96, 192), (1, 16, 64, 32, 64)])
+def test_conv_q_la3_equals_default(cq, form, shape):
+    """SG_CONV_Q_LA3=1 (conv_q.h NPMIN < 0: weights three taps ahead in the single-buffered loop): same MFMAs, same order -> the same bf16 output bit
+    for bit as the shipped loop, under late DMA completion (the counted waits and the buffer re-use are what changed) and several wave orders; with
+    the fused 1x1 skip of the POOL form too."""
+    N, Hl, Wl, Cin, Cout = shape
+    rng = np.random.default_rng(31)
+    x, _ = _qdata(form, shape, 31)
+    w9 = emu.to_bf16((0.1 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    wq = emu.quad_pack(cq, w9, form)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    kw = {}
+    if form == emu.Q_POOL:
+        kw = dict(x2=emu.to_bf16(rng.standard_normal((N, 2 * Hl, 2 * Wl, 32)).astype(np.float32)), w2q=emu.to_bf16((0.1 * rng.standard_normal((Cout, 32))).astype(np.float32)),
+                  bias2=rng.standard_normal(Cout).astype(np.float32))
+    outs = {}
+    for la in ("0", "1"):
+        for seed in (1, 2, 3):
+            emu.config(cq, dma_late=1, greedy=1, seed=seed)
+            c0 = emu.counters(cq)
+            outs[(la, seed)] = emu.conv_q(cq, form, x, wq, Cout, relu_in=True, bias=bias, env={"SG_CONV_Q_LA3": la, "SG_CONV_Q_BJ": "256", "SG_CONV_Q_DB": "0"}, **kw).copy()
+            assert emu.counters(cq)["dma_ops"] > c0["dma_ops"]
+    ref = outs[("0", 1)]
+    for k, v in outs.items():
+        assert np.array_equal(v, ref), k

@@ -28,6 +28,11 @@ except Exception as e:
 PY
   tail -2 $O/bench_lean$f.err | cut -c1-200
 done
+# 3b. conv_q.h with the weights three taps ahead (SG_CONV_Q_LA3=1; CPU: bit-identical to the shipped loop under the interpreter)
+( SG_CONV_Q_LA3=1 timeout 300 python -m pytest tests/test_quad_gpu.py -q -p no:cacheprovider -k "conv_q and not wgrad" 2>&1 | tail -3 ) > $O/pytest_la3.txt 2>&1; cat $O/pytest_la3.txt | cut -c1-200
+for f in 0 1; do
+  ( SG_CONV_Q_LA3=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
+done
 # 4. FID leg (bf16 Inception): conv_v2 for InceptionV3's 128 / 160-cout 1x7 / 7x1 layers (SG_CONV_V2_MIN_TILES / SG_CONV_V2_PAD_TILES), and the
 #    frozen-network weight-image cache (tools/fid_leg.py runs G.eval(): SG_EVAL_CACHE=0 is the round-4 behaviour)
 ( timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval.txt 2>&1; cat $O/pytest_eval.txt | cut -c1-200
