@@ -272,3 +272,42 @@ def conv_q_wgrad(lib, form, x, dy, relu_in=False, alpha=1.0, bias=False, splits=
         if lib.sg_conv2d_q_wgrad(C.byref(d), None) != 0:
             raise RuntimeError(lib.sg_last_error())
     return dw, db, sp.value
+
+
+# ---- plain convolution forward / data gradient (conv.hip sg_conv2d_fwd and the engines behind it) --------------------------------------------------------
+CONV_FWD_FIELDS = [("dtype", _i), ("N", _i), ("Hs", _i), ("Ws", _i), ("C", _i), ("ldx", _i), ("Ho", _i), ("Wo", _i), ("Cout", _i),
+                   ("R", _i), ("S", _i), ("stride", _i), ("pad_h", _i), ("pad_w", _i), ("pix_flags", _i), ("epi_flags", _i),
+                   ("alpha", _f), ("beta", _f), ("x", _vp), ("w", _vp), ("bias", _vp), ("res", _vp), ("mask", _vp), ("out", _vp),
+                   ("alpha_ptr", _vp), ("ldo", _i), ("ldr", _i), ("ldm", _i)]
+
+
+class ConvFwdDesc(C.Structure):
+    _fields_ = CONV_FWD_FIELDS
+
+
+PIX_QUAD, EPI_POOL = 4, 4
+
+
+def conv_fwd(lib, x, w, R, S, pad, relu_in=False, up=False, pool=False, bias=None, mask=None, res=None, alpha=1.0, beta=1.0, relu_out=False, env=None):
+    """x: uint16 bf16 [N][Hs][Ws][C]; w: uint16 bf16 [Cout][R][S][C]; stride 1. pool: 2x2 average pooling in the epilogue (the kernel then wants its
+    pixels in quad order: SG_PIX_QUAD). Returns uint16 bf16 NHWC through sg_conv2d_fwd -- whichever engine takes the problem (see the SG_CONV_* switches)."""
+    N, Hs, Ws, Cin = x.shape
+    Cout = w.shape[0]
+    u = 2 if up else 1
+    Ho, Wo = Hs * u + 2 * pad - R + 1, Ws * u + 2 * pad - S + 1
+    oshape = (N, Ho // 2, Wo // 2, Cout) if pool else (N, Ho, Wo, Cout)
+    xa, wa, out = copy_aligned(x), copy_aligned(w), aligned(oshape, np.uint16)
+    keep = [xa, wa, out]
+    pf = (PIX_RELU if relu_in else 0) | (PIX_UPSAMPLE if up else 0) | (PIX_QUAD if pool else 0)
+    ef = (EPI_POOL if pool else 0) | (EPI_RELU if relu_out else 0)
+    d = ConvFwdDesc(dtype=BF16, N=N, Hs=Hs, Ws=Ws, C=Cin, ldx=Cin, Ho=Ho, Wo=Wo, Cout=Cout, R=R, S=S, stride=1, pad_h=pad, pad_w=pad, pix_flags=pf, epi_flags=ef,
+                    alpha=alpha, beta=beta, x=ptr(xa), w=ptr(wa), out=ptr(out), ldo=Cout, ldr=Cout, ldm=Cout)
+    for name, arr, dt in (("bias", bias, np.float32), ("mask", mask, np.uint16), ("res", res, np.uint16)):
+        if arr is not None:
+            a = copy_aligned(np.ascontiguousarray(arr, dtype=dt))
+            keep.append(a)
+            setattr(d, name, ptr(a))
+    with _Env(env):
+        if lib.sg_conv2d_fwd(C.byref(d), None) != 0:
+            raise RuntimeError(lib.sg_last_error())
+    return out

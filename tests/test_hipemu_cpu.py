@@ -226,3 +226,50 @@ def test_conv_q_la3_equals_default(cq, form, shape):
     ref = outs[("0", 1)]
     for k, v in outs.items():
         assert np.array_equal(v, ref), k
+
+
+# ---- conv_v4.h (3x3 halo kernel of the <= 384-channel layers) -----------------------------------------------------------------------------------------------
+V4_CASES = [
+    # N, H, C, Cout, relu_in, up, pool
+    (2, 16, 64, 96, True, False, False),        # NB = 3, two channel slices (ring of four buffers: slice 1 starts at buffer 1)
+    (1, 32, 96, 64, False, False, False),       # NB = 2, three slices
+    (2, 16, 64, 192, True, False, True),        # quad row order + pooling epilogue, two cout tiles
+    (2, 8, 96, 96, True, True, False),          # nearest x2 upsampling on load
+    (1, 16, 32, 96, False, False, False),       # ONE slice: the tail waits of the last slice from tap 0 on
+]
+
+
+@pytest.mark.parametrize("case", V4_CASES)
+def test_conv_v4_pins_interpreter_and_la3_equals_default(cq, case):
+    """the GPU-verified halo kernel against torch on the same bf16 inputs; SG_CONV_V4_LA3=1 (four weight buffers, three taps ahead: conv_v4.h NWB = 4)
+    bit for bit against it under late DMA completion and three wave orders"""
+    import torch
+    import torch.nn.functional as TF
+    N, H, Cin, Cout, relu, up, pool = case
+    rng = np.random.default_rng(41)
+    x = emu.to_bf16(rng.standard_normal((N, H, H, Cin)).astype(np.float32))
+    w = emu.to_bf16((0.1 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    env = {"SG_CONV_V4": "force", "SG_CONV_V3": "0", "SG_QUAD": "0", "SG_CONV_RS": "0"}
+    xr = _t64(x).permute(0, 3, 1, 2)
+    if relu:
+        xr = xr.clamp(min=0)
+    if up:
+        xr = TF.interpolate(xr, scale_factor=2, mode="nearest")
+    ref = TF.conv2d(xr, _t64(w).permute(0, 3, 1, 2), None, padding=1)
+    if pool:
+        ref = TF.avg_pool2d(ref, 2)
+    ref = ref + torch.from_numpy(bias).double()[None, :, None, None]
+    ref = ref.permute(0, 2, 3, 1)
+    outs = {}
+    for la in ("0", "1"):
+        for seed in (1, 2, 3):
+            emu.config(cq, dma_late=1, greedy=1, seed=seed)
+            c0 = emu.counters(cq)
+            outs[(la, seed)] = emu.conv_fwd(cq, x, w, 3, 3, 1, relu_in=relu, up=up, pool=pool, bias=bias, alpha=0.25 if pool else 1.0,      # (the pooling epilogue SUMS the quad)
+                                            env=dict(env, SG_CONV_V4_LA3=la)).copy()
+            assert emu.counters(cq)["dma_ops"] > c0["dma_ops"]
+    got = _t64(outs[("0", 1)])
+    assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6, case
+    for k, v in outs.items():
+        assert np.array_equal(v, outs[("0", 1)]), (case, k)

@@ -33,6 +33,17 @@ done
 for f in 0 1; do
   ( SG_CONV_Q_LA3=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
 done
+# 3c. conv_v4.h with four weight buffers / three taps ahead (SG_CONV_V4_LA3=1) where three workgroups still fit a CU
+( SG_CONV_V4_LA3=1 timeout 300 python -m pytest tests/test_conv_v2_gpu.py -q -p no:cacheprovider -k "conv_v4 or fused_skip" 2>&1 | tail -3 ) > $O/pytest_v4la3.txt 2>&1; cat $O/pytest_v4la3.txt | cut -c1-200
+for f in 0 1; do
+  ( SG_CONV_V4_LA3=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 | grep -v wgrad ) > $O/conv_bench_v4la3_$f.txt 2>&1; tail -12 $O/conv_bench_v4la3_$f.txt | cut -c1-200
+done
+# 3d. everything that won its layer table, together: step A/B (edit the list)
+for cfg in "SG_NOOP=1" "SG_WGRAD_V3_LEAN=1 SG_WGRAD_Q_LEAN=1 SG_CONV_Q_LA3=1 SG_CONV_V4_LA3=1"; do
+  tag=$(echo "$cfg" | tr ' =' '__' | cut -c1-40)
+  ( env $cfg timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --fid-samples 0 ) > $O/bench_all_$tag.json 2> $O/bench_all_$tag.err
+  echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' $O/bench_all_$tag.json | head -1) $(grep -o '"conv_ms_per_step": [0-9.]*' $O/bench_all_$tag.json | head -1)"
+done
 # 4. FID leg (bf16 Inception): conv_v2 for InceptionV3's 128 / 160-cout 1x7 / 7x1 layers (SG_CONV_V2_MIN_TILES / SG_CONV_V2_PAD_TILES), and the
 #    frozen-network weight-image cache (tools/fid_leg.py runs G.eval(): SG_EVAL_CACHE=0 is the round-4 behaviour)
 ( timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval.txt 2>&1; cat $O/pytest_eval.txt | cut -c1-200
