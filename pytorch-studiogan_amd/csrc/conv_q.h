@@ -64,7 +64,11 @@ struct ConvQParams {
 // vmcnt(2 n_w) behind tap 3 (P' and W0' have landed). NPMIN = the smallest number of patch pieces a wave issues (compile-time immediate;
 // waves with one piece more only wait a little earlier than they must).
 //
-// NPMIN < 0 ("LA3", round 4, written without GPU time: SG_CONV_Q_LA3=1, default off): the single-buffered loop (three workgroups per CU) with the weights
+// NPMIN == -2 ("PAIR", round 4, written without GPU time: SG_CONV_Q_LA3=2, default off): the four taps of a slice as two PAIRS -- a pair's two weight tiles are
+// requested one pair ahead (the same 24 MFMAs per wave of distance as the shipped two-taps-ahead scheme) and the workgroup synchronises once per pair
+// instead of once per tap: half the barriers and half the counted waits, every wait a plain vmcnt(0). Against LA3 this separates "the barriers cost" from
+// "the tile's latency costs" in one A/B.
+// NPMIN == -1 ("LA3", round 4, written without GPU time: SG_CONV_Q_LA3=1, default off): the single-buffered loop (three workgroups per CU) with the weights
 // THREE taps ahead instead of two. If the per-tap wait is the weight tile's DMA latency (a tap is 12 MFMAs per wave = 384 clk of its matrix pipe; a tile
 // requested two taps earlier has ~2 x 1152 clk at full rate to arrive), one more tap of lookahead costs nothing: the fourth buffer is free as soon as the
 // barrier that ends the previous tap has been passed. The double-buffered variant above already runs three ahead but pays for its second patch with
@@ -72,7 +76,8 @@ struct ConvQParams {
 template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
   constexpr bool DB = NPMIN > 0;
-  constexpr bool LA3 = NPMIN < 0;           // single-buffered patch, weights THREE taps ahead (see above)
+  constexpr bool LA3 = NPMIN == -1;         // single-buffered patch, weights THREE taps ahead (see above)
+  constexpr bool PAIR = NPMIN == -2;        // single-buffered patch, taps in PAIRS: one barrier per two taps (see above)
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -182,7 +187,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
   patch_slice(view, 0);
   weight_tile(0, view, 0, 0);
   weight_tile(1, view, 0, 1);
-  if (DB || LA3) weight_tile(2, view, 0, 2);
+  if (DB || LA3) weight_tile(2, view, 0, 2);       // (PAIR: taps 2, 3 are requested at the first tap of the loop)
   __syncthreads();
   for (int vs = 0; vs < nvs; vs++) {
     const bool next_slice = vs + 1 < nvs;
@@ -198,7 +203,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
     for (int t = 0; t < 4; t++) {
       // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
       const bool issue = LA3 ? (t == 0 || next_slice) : ((t + 2 < 4) || next_slice);
-      if constexpr (LA3) {
+      if constexpr (PAIR) {
+        // buffers 2, 3 were read during the previous slice's second pair, buffers 0, 1 during this slice's first pair: every wave is past the barrier since
+        if (t == 0) { weight_tile(2, view, s, 2); weight_tile(3, view, s, 3); }
+        else if (t == 2 && next_slice) { weight_tile(0, nview, ns, 0); weight_tile(1, nview, ns, 1); }
+      } else if constexpr (LA3) {
         // buffer (t + 3) % 4 = (t - 1) % 4 was read during the previous tap, and every wave is past the barrier that ended it
         if (t == 0) weight_tile(3, view, s, 3);
         else if (next_slice) weight_tile(t - 1, nview, ns, t - 1);
@@ -263,6 +272,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
         __syncthreads();
         patch_slice(nview, ns);
         __syncthreads();
+      } else if constexpr (PAIR) {
+        // no barrier inside a pair; behind a pair everything in flight is the next pair's two tiles
+        if (t == 1 || t == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
       } else if constexpr (LA3) {
         // the weights of tap t + 1 must have landed; behind them at most the tiles of taps t + 2 and t + 3 are in flight (n_w pieces each per wave)
         if (next_slice || t == 0) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
@@ -389,6 +401,7 @@ template <int NB, bool SKIP, bool RELU>
 static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
   if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
   if (db == 2) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -1>(p, e, st);      // LA3
+  if (db == 3) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -2>(p, e, st);      // PAIR
   if (db) {       // double-buffered patch: the smallest per-wave piece count is a compile-time immediate of the counted waits
     const int npmin = (p.npx >> 4) >> 2;
     if (npmin == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 4>(p, e, st);
