@@ -10,7 +10,7 @@ mkdir -p $O
 ( time SG_EXPERIMENTAL=1 timeout 400 python -m pytest tests/test_conv_v2_gpu.py tests/test_quad_gpu.py -q -p no:cacheprovider --maxfail=10 -k "lean" 2>&1 | tail -8 ) > $O/pytest_lean.txt 2>&1
 cat $O/pytest_lean.txt | cut -c1-250
 for f in 0 1; do
-  ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 | grep -i "wgrad\|average\|avg" ) > $O/conv_bench_v3lean$f.txt 2>&1
+  ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v3lean$f.txt 2>&1
   ( SG_WGRAD_Q_LEAN=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_qlean$f.txt 2>&1
   tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
 done
@@ -36,7 +36,7 @@ done
 # 3c. conv_v4.h with four weight buffers / three taps ahead (SG_CONV_V4_LA3=1) where three workgroups still fit a CU
 ( SG_CONV_V4_LA3=1 timeout 300 python -m pytest tests/test_conv_v2_gpu.py -q -p no:cacheprovider -k "conv_v4 or fused_skip" 2>&1 | tail -3 ) > $O/pytest_v4la3.txt 2>&1; cat $O/pytest_v4la3.txt | cut -c1-200
 for f in 0 1; do
-  ( SG_CONV_V4_LA3=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 | grep -v wgrad ) > $O/conv_bench_v4la3_$f.txt 2>&1; tail -12 $O/conv_bench_v4la3_$f.txt | cut -c1-200
+  ( SG_CONV_V4_LA3=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v4la3_$f.txt 2>&1; tail -12 $O/conv_bench_v4la3_$f.txt | cut -c1-200
 done
 # 3d. everything that won its layer table, together: step A/B (edit the list)
 for cfg in "SG_NOOP=1" "SG_WGRAD_V3_LEAN=1 SG_WGRAD_Q_LEAN=1 SG_CONV_Q_LA3=1 SG_CONV_V4_LA3=1"; do
