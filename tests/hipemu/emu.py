@@ -113,7 +113,7 @@ def aligned(shape, dtype, align=64):
     return raw[off:off + n].view(dtype).reshape(shape)
 
 
-def conv_wgrad(lib, x, dy, Cout, x_flags=0, g_flags=0, alpha=1.0, bias=False, splits=0, env=None):
+def conv_wgrad(lib, x, dy, Cout, x_flags=0, g_flags=0, alpha=1.0, bias=False, splits=0, env=None, R=3, pad=1):
     """x: uint16 bf16 [N][xHs][xWs][C], dy: uint16 bf16 [N][gHs][gWs][Cout]; 3x3 / stride 1 / pad 1. Returns (dw fp32 [Cout][3][3][C], dbias or None)
     through the translation unit's own sg_conv2d_wgrad_plan + sg_conv2d_wgrad (workspace form: the deterministic two-stage reduction)."""
     N, xHs, xWs, Cin = x.shape
@@ -124,10 +124,10 @@ def conv_wgrad(lib, x, dy, Cout, x_flags=0, g_flags=0, alpha=1.0, bias=False, sp
     assert (gHs * gup, gWs * gup) == (Ho, Wo)
     xa = aligned(x.shape, np.uint16); xa[...] = x
     ga = aligned(dy.shape, np.uint16); ga[...] = dy
-    dw = aligned((Cout, 3, 3, Cin), np.float32)
+    dw = aligned((Cout, R, R, Cin), np.float32)
     db = aligned((Cout,), np.float32) if bias else None
     d = ConvWgradDesc(dtype=BF16, N=N, xHs=xHs, xWs=xWs, C=Cin, ldx=Cin, x_flags=x_flags, gHs=gHs, gWs=gWs, Cout=Cout, ldg=Cout, g_flags=g_flags,
-                      Ho=Ho, Wo=Wo, R=3, S=3, stride=1, pad_h=1, pad_w=1, alpha=alpha, x=ptr(xa), dy=ptr(ga), dw=ptr(dw), alpha_ptr=None,
+                      Ho=Ho, Wo=Wo, R=R, S=R, stride=1, pad_h=pad, pad_w=pad, alpha=alpha, x=ptr(xa), dy=ptr(ga), dw=ptr(dw), alpha_ptr=None,
                       splits=splits, no_tr=0, work=None, work_floats=0, dbias=ptr(db) if bias else None)
     old = {}
     for k, v in (env or {}).items():
@@ -153,7 +153,7 @@ def conv_wgrad(lib, x, dy, Cout, x_flags=0, g_flags=0, alpha=1.0, bias=False, sp
     return dw, (db if bias and fused else None), sp.value
 
 
-def wgrad_ref(x, dy, x_flags=0, g_flags=0, alpha=1.0):
+def wgrad_ref(x, dy, x_flags=0, g_flags=0, alpha=1.0, R=3, pad=1):
     """fp64 restatement of include/sgamd.h's formula for the 3x3 / pad-1 weight gradient on bf16 inputs"""
     xf = from_bf16(x).astype(np.float64)
     gf = from_bf16(dy).astype(np.float64)
@@ -164,11 +164,11 @@ def wgrad_ref(x, dy, x_flags=0, g_flags=0, alpha=1.0):
     if g_flags & PIX_UPSAMPLE:
         gf = gf.repeat(2, axis=1).repeat(2, axis=2)
     N, H, W, Cin = xf.shape
-    xp = np.zeros((N, H + 2, W + 2, Cin))
-    xp[:, 1:-1, 1:-1] = xf
-    dw = np.zeros((gf.shape[3], 3, 3, Cin))
-    for r in range(3):
-        for s in range(3):
+    xp = np.zeros((N, H + 2 * pad, W + 2 * pad, Cin))
+    xp[:, pad:pad + H, pad:pad + W] = xf
+    dw = np.zeros((gf.shape[3], R, R, Cin))
+    for r in range(R):
+        for s in range(R):
             dw[:, r, s, :] = np.einsum("nhwk,nhwc->kc", gf, xp[:, r:r + H, s:s + W], optimize=True)
     db = from_bf16(dy).astype(np.float64).sum(axis=(0, 1, 2))      # over the STORED dy pixels (sgamd.h)
     return alpha * dw, db

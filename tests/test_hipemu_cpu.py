@@ -273,3 +273,68 @@ def test_conv_v4_pins_interpreter_and_la3_equals_default(cq, case):
     assert (got - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6, case
     for k, v in outs.items():
         assert np.array_equal(v, outs[("0", 1)]), (case, k)
+
+
+# ---- the other forward engines behind sg_conv2d_fwd, pinned for later edits ---------------------------------------------------------------------------------
+ENGINE_CASES = [
+    # name, env, (N, H, C, Cout, R, pad, relu_in, up, pool)
+    ("conv_v3 deep layer", {"SG_CONV_V3": "force", "SG_CONV_V4": "0", "SG_QUAD": "0"}, (2, 8, 512, 192, 3, 1, True, False, False)),
+    ("conv_v3 pooled", {"SG_CONV_V3": "force", "SG_CONV_V4": "0", "SG_QUAD": "0"}, (2, 8, 416, 96, 3, 1, True, False, True)),
+    ("conv_sk 1x1", {"SG_CONV_SK": "force"}, (2, 16, 96, 48, 1, 0, False, False, False)),
+    ("conv_sk 1x1 upsampled, ReLU", {"SG_CONV_SK": "force"}, (2, 8, 192, 96, 1, 0, True, True, False)),
+    ("conv_sk stem 3x3 on 8 channels", {"SG_CONV_SK": "force", "SG_CONV_RS": "0"}, (2, 32, 8, 96, 3, 1, False, False, False)),
+    ("conv_rs RGB layer (8 padded couts, 128-wide rows)", {"SG_CONV_RS": "force", "SG_CONV_RS96": "0"}, (1, 128, 96, 8, 3, 1, True, False, False)),
+    ("conv_rs96 row streaming 96 -> 96", {"SG_CONV_RS": "force", "SG_CONV_RS96": "force"}, (1, 128, 96, 96, 3, 1, False, False, False)),
+    ("conv_v2 tile kernel, 5x5", {"SG_CONV_V2": "force", "SG_CONV_V3": "0", "SG_CONV_V4": "0"}, (2, 16, 24, 96, 5, 2, False, False, False)),
+    ("generic engine (everything off)", {"SG_CONV_V2": "0", "SG_CONV_V3": "0", "SG_CONV_V4": "0", "SG_CONV_SK": "0", "SG_CONV_RS": "0", "SG_QUAD": "0"},
+     (2, 8, 40, 24, 3, 1, True, False, False)),
+]
+
+
+@pytest.mark.parametrize("case", ENGINE_CASES, ids=[c[0] for c in ENGINE_CASES])
+def test_forward_engines_pin_interpreter(cq, case):
+    """every forward / data-gradient engine of sg_conv2d_fwd against torch on the same bf16 inputs (one bf16 rounding of the result), under late DMA
+    completion and a seeded wave order: the regression net for edits made without GPU time"""
+    import torch
+    import torch.nn.functional as TF
+    name, env, (N, H, Cin, Cout, R, pad, relu, up, pool) = case
+    rng = np.random.default_rng(51)
+    x = emu.to_bf16(rng.standard_normal((N, H, H, Cin)).astype(np.float32))
+    w = emu.to_bf16((0.1 * rng.standard_normal((Cout, R, R, Cin))).astype(np.float32))
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    xr = _t64(x).permute(0, 3, 1, 2)
+    if relu:
+        xr = xr.clamp(min=0)
+    if up:
+        xr = TF.interpolate(xr, scale_factor=2, mode="nearest")
+    ref = TF.conv2d(xr, _t64(w).permute(0, 3, 1, 2), None, padding=pad)
+    if pool:
+        ref = TF.avg_pool2d(ref, 2)
+    ref = (ref + torch.from_numpy(bias).double()[None, :, None, None]).permute(0, 2, 3, 1)
+    for seed in (1, 2):
+        emu.config(cq, dma_late=1, greedy=1, seed=seed)
+        out = emu.conv_fwd(cq, x, w, R, R, pad, relu_in=relu, up=up, pool=pool, bias=bias, alpha=0.25 if pool else 1.0, env=env)
+        assert (_t64(out) - ref).abs().max().item() <= 2 ** -8 * ref.abs().max().item() + 1e-6, (name, seed)
+
+
+WGRAD_ENGINE_CASES = [
+    # name, env, (N, H, C, Cout, R, pad, relu)
+    ("wgrad_sk 1x1", {"SG_WGRAD_SK": "1", "SG_WGRAD_V3": "0"}, (2, 16, 96, 48, 1, 0, True)),
+    ("wgrad_sk stem 3x3 on 8 channels", {"SG_WGRAD_SK": "1", "SG_WGRAD_V3": "0"}, (2, 32, 8, 96, 3, 1, False)),
+    ("wgrad_v2 tile kernel", {"SG_CONV_V2": "force", "SG_WGRAD_V3": "0", "SG_WGRAD_SK": "0"}, (2, 16, 64, 128, 3, 1, True)),
+    ("generic engine", {"SG_CONV_V2": "0", "SG_WGRAD_V3": "0", "SG_WGRAD_SK": "0"}, (2, 8, 40, 24, 3, 1, False)),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_ENGINE_CASES, ids=[c[0] for c in WGRAD_ENGINE_CASES])
+def test_wgrad_engines_pin_interpreter(wg, case):
+    """the other weight-gradient engines of sg_conv2d_wgrad (streaming thin-layer kernel, LDS-DMA tile kernel, generic contraction) against the fp64 formula"""
+    name, env, (N, H, Cin, Cout, R, pad, relu) = case
+    rng = np.random.default_rng(61)
+    x = emu.to_bf16(rng.standard_normal((N, H, H, Cin)).astype(np.float32))
+    dy = emu.to_bf16(rng.standard_normal((N, H, H, Cout)).astype(np.float32))
+    xf = emu.PIX_RELU if relu else 0
+    emu.config(wg, dma_late=1, greedy=1, seed=4)
+    dw, _, _ = emu.conv_wgrad(wg, x, dy, Cout, x_flags=xf, env=env, R=R, pad=pad)
+    ref, _ = emu.wgrad_ref(x, dy, x_flags=xf, R=R, pad=pad)
+    assert np.abs(dw - ref).max() <= 3e-6 * np.abs(ref).max(), name
