@@ -105,6 +105,10 @@ struct Lane {
   U3 tid;
   int wait_kind = 0;      // 0 runnable, 1 wave collective, 2 workgroup barrier
   unsigned wait_gen = 0;
+  // results of inline-assembly LDS reads (ds_read_b64_tr_b16) that have been issued but not waited for: the destination holds poison until a
+  // `s_waitcnt lgkmcnt(n)` leaves at most n of them outstanding (LDS operations of a wave return in order)
+  struct PendingRead { void* dst; unsigned char val[8]; };
+  std::deque<PendingRead> pending;
 };
 struct Block {
   std::vector<Lane> lanes;
@@ -441,9 +445,21 @@ inline void waitcnt_vm(int n) {
 }
 // the lanes of a wave are independent fibres between collectives; the hardware executes them in lockstep. Where a kernel passes data between the lanes of ONE
 // wave through LDS without a workgroup barrier (conv_sk.h's wave-private epilogue tile), its explicit `s_waitcnt lgkmcnt` is the re-alignment point.
-inline void wave_lockstep() { int z = 0; wave_sync(&z, nullptr, [](Wave&) {}); }
+inline void complete_reads(Lane* me, size_t keep) {
+  while (me->pending.size() > keep) { memcpy(me->pending.front().dst, me->pending.front().val, 8); me->pending.pop_front(); }
+}
+// s_waitcnt lgkmcnt(n): at most n of this lane's issued LDS reads stay outstanding; the fibres of the wave re-align
+inline void wave_lockstep(int n = 0) { complete_reads(g_cur, (size_t)n); int z = 0; wave_sync(&z, nullptr, [](Wave&) {}); }
+// an inline-assembly transpose read: the value is fetched now (LDS contents at issue time), the destination gets it at the wait
+template <class T> inline void tr_read_deferred(T& dst, unsigned addr) {
+  static_assert(sizeof(T) == 8, "ds_read_b64_tr_b16 destination");
+  const e_s16x4 v = ds_read_tr16_b64(addr);
+  Lane::PendingRead pr; pr.dst = &dst; memcpy(pr.val, &v, 8);
+  g_cur->pending.push_back(pr);
+  memset(&dst, 0xFF, 8);           // poison (two bf16 NaN pairs per dword): using the register before the wait shows
+}
 inline void s_barrier() { block_barrier(); }
-inline void syncthreads() { waitcnt_vm(0); block_barrier(); }      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
+inline void syncthreads() { complete_reads(g_cur, 0); waitcnt_vm(0); block_barrier(); }      // __syncthreads() = s_waitcnt vmcnt(0) lgkmcnt(0) + s_barrier
 
 // ---- cross-lane --------------------------------------------------------------------------------------------------------------------------------
 inline int readfirstlane(int v) {

@@ -95,8 +95,9 @@ def _asm(stmt):
     m = re.match(r"s_waitcnt vmcnt\((%?)(\d+)\)$", t)
     if m:
         return "hipemu::waitcnt_vm(%s)" % (ops[int(m.group(2))] if m.group(1) else m.group(2))
-    if re.match(r"s_waitcnt lgkmcnt\(", t):
-        return "hipemu::wave_lockstep()"
+    m = re.match(r"s_waitcnt lgkmcnt\((%?)(\d+)\)$", t)
+    if m:
+        return "hipemu::wave_lockstep(%s)" % (ops[int(m.group(2))] if m.group(1) else m.group(2))
     m = re.match(r"ds_read_b64_tr_b16 %0, %1(?: offset:(%?)(\d+))?$", t)
     if m:
         off = "0" if m.group(2) is None else (ops[int(m.group(2))] if m.group(1) else m.group(2))
@@ -156,7 +157,7 @@ def translate(src, base=0):
 
 PRELUDE = """// generated by tests/hipemu/translate.py -- do not edit
 #include <hip/hip_runtime.h>
-template <class T> static inline void hipemu_tr_assign(T& dst, unsigned addr) { dst = __builtin_bit_cast(T, hipemu::ds_read_tr16_b64(addr)); }
+template <class T> static inline void hipemu_tr_assign(T& dst, unsigned addr) { hipemu::tr_read_deferred(dst, addr); }
 """
 
 
