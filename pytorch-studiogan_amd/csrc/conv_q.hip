@@ -372,7 +372,7 @@ extern "C" int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t strea
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)K * 16.0 * (double)d->C);
   // SG_WGRAD_Q_LEAN=1: the lean variant (wgrad_ql.h) -- A/B switch, read per call; off until it has run on a GPU
   const char* lean = getenv("SG_WGRAD_Q_LEAN");
-  const int rc = (lean && lean[0] == '1') ? sg_launch_wgrad_ql(p, s.NB, s.S, st) : sg_launch_wgrad_q(p, s.NB, s.S, st);
+  const int rc = (lean && (lean[0] == '1' || lean[0] == '2')) ? sg_launch_wgrad_ql(p, s.NB, s.S, st, lean[0] == '2') : sg_launch_wgrad_q(p, s.NB, s.S, st);      // 2: + the register pipeline
   if (rc == 0) {
     const bool pl = d->form == SG_Q_POOL;
     const int cb = d->C > 64 ? (d->C + 63) / 64 : 1;

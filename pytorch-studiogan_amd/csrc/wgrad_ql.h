@@ -16,26 +16,30 @@
 
 typedef __bf16 wql_bf2 __attribute__((ext_vector_type(2)));
 
-template <int NB, int WC, int S, int KS, bool RELU>
-__device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
+// fragments of one k-step (16 pixels): S activation fragments (one per slice) and NB gradient fragments, each as two transpose reads
+template <int NB, int S> struct WqlFrags { u32x2 al[S], ah[S], bl[NB], bh[NB]; };
+template <int NB, int WC, int S, int KS>
+__device__ __forceinline__ void wql_issue(unsigned a0, unsigned b0, WqlFrags<NB, S>& f) {      // 2 (S + NB) transpose reads, no wait
   constexpr int NIMG = WC == 4 ? 4 : 1, RC = 64 / WC, RCI = RC / NIMG, PW = WC + 1, PPI = (RCI + 1) * PW;
   constexpr int XB = ((NIMG * PPI * 64 + 1023) / 1024) * 1024;                 // one slice plane of the patch
   constexpr int GPITCH = NB * 64;
   constexpr int KX = WC == 4 ? KS * PPI * 64 : (((KS * 16) / WC) * PW + ((KS * 16) % WC)) * 64;
   constexpr int A2 = WC == 4 ? PW * 64 : 256;                                  // the second half of the fragment: + 4 pixels (WC == 4: the next image row)
   constexpr int KG = KS * 16 * GPITCH;
-  u32x2 al[S], ah[S], bl[NB], bh[NB];
-  wq_tr_read<KX>(a0, al[0]); wq_tr_read<KX + A2>(a0, ah[0]);
-  if constexpr (S == 2) { wq_tr_read<KX + XB>(a0, al[1]); wq_tr_read<KX + XB + A2>(a0, ah[1]); }
-  wq_tr_read<KG>(b0, bl[0]); wq_tr_read<KG + 4 * GPITCH>(b0, bh[0]);
-  wq_tr_read<KG + 64>(b0, bl[1]); wq_tr_read<KG + 64 + 4 * GPITCH>(b0, bh[1]);
-  if constexpr (NB == 3) { wq_tr_read<KG + 128>(b0, bl[2]); wq_tr_read<KG + 128 + 4 * GPITCH>(b0, bh[2]); }
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wq_tr_read<KX>(a0, f.al[0]); wq_tr_read<KX + A2>(a0, f.ah[0]);
+  if constexpr (S == 2) { wq_tr_read<KX + XB>(a0, f.al[1]); wq_tr_read<KX + XB + A2>(a0, f.ah[1]); }
+  wq_tr_read<KG>(b0, f.bl[0]); wq_tr_read<KG + 4 * GPITCH>(b0, f.bh[0]);
+  wq_tr_read<KG + 64>(b0, f.bl[1]); wq_tr_read<KG + 64 + 4 * GPITCH>(b0, f.bh[1]);
+  if constexpr (NB == 3) { wq_tr_read<KG + 128>(b0, f.bl[2]); wq_tr_read<KG + 128 + 4 * GPITCH>(b0, f.bh[2]); }
+}
+// the S NB MFMAs of a k-step from fragments that HAVE landed (the caller's s_waitcnt lgkmcnt covers them)
+template <int NB, int S, bool RELU>
+__device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int cblk, float& csum) {
   bf16x8_t af[S], bf[NB];
 #pragma unroll
   for (int s = 0; s < S; s++) {
-    asm volatile("" : "+v"(al[s]), "+v"(ah[s]));
-    u32x4 v = {al[s][0], al[s][1], ah[s][0], ah[s][1]};
+    asm volatile("" : "+v"(f.al[s]), "+v"(f.ah[s]));          // (the registers are used behind the wait, not before it)
+    u32x4 v = {f.al[s][0], f.al[s][1], f.ah[s][0], f.ah[s][1]};
     if constexpr (RELU) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -49,8 +53,8 @@ __device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0,
   }
 #pragma unroll
   for (int b = 0; b < NB; b++) {
-    asm volatile("" : "+v"(bl[b]), "+v"(bh[b]));
-    u32x4 v = {bl[b][0], bl[b][1], bh[b][0], bh[b][1]};
+    asm volatile("" : "+v"(f.bl[b]), "+v"(f.bh[b]));
+    u32x4 v = {f.bl[b][0], f.bl[b][1], f.bh[b][0], f.bh[b][1]};
     bf[b] = __builtin_bit_cast(bf16x8_t, v);
   }
   // bias gradient: cout block cblk (= this wave's index, or -1) from the fragment already in registers: this lane's 8 pixels of cout (lane & 31)
@@ -70,10 +74,38 @@ __device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0,
     for (int b = 0; b < NB; b++)
       acc[s * NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf[b], acc[s * NB + b], 0, 0, 0);
 }
+template <int NB, int WC, int S, int KS, bool RELU>
+__device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
+  WqlFrags<NB, S> f;
+  wql_issue<NB, WC, S, KS>(a0, b0, f);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wql_consume<NB, S, RELU>(acc, f, cblk, csum);
+}
+// PIPE: the four k-steps of a chunk as a two-deep register pipeline -- the reads of k-step s + 1 are in flight while the MFMAs of k-step s issue; the
+// counted wait leaves exactly those 2 (S + NB) reads outstanding (LDS operations of a wave return in order). One exposed LDS round trip per chunk
+// instead of four; 2 (S + NB) more registers (wgrad_v2.h has run such a pipeline since round 2).
+template <int NB, int WC, int S, bool RELU>
+__device__ __forceinline__ void wql_chunk_pipelined(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
+  constexpr int NR = 2 * (S + NB);
+  static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
+  WqlFrags<NB, S> f0, f1;
+  wql_issue<NB, WC, S, 0>(a0, b0, f0);
+  wql_issue<NB, WC, S, 1>(a0, b0, f1);
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
+  wql_issue<NB, WC, S, 2>(a0, b0, f0);
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
+  wql_issue<NB, WC, S, 3>(a0, b0, f1);
+  asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
+}
 
 // NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in low-resolution pixels (64, 32, 16, 8: 64 / WC whole image rows; 4: four
 // whole 4 x 4 images), S = 32-channel input slices per workgroup (1 or 2)
-template <int NB, int WC, int S, bool RELU>
+template <int NB, int WC, int S, bool RELU, bool PIPE = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sg_wgrad_ql_kernel(WgradQParams p) {
   constexpr int NIMG = WC == 4 ? 4 : 1;             // images per chunk
   constexpr int RC = 64 / WC, RCI = RC / NIMG;      // chunk rows, rows per image part
@@ -194,10 +226,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();                   // chunk c has landed everywhere; every wave is done with the other buffer
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
-    wql_kstep<NB, WC, S, 0, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-    wql_kstep<NB, WC, S, 1, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-    wql_kstep<NB, WC, S, 2, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-    wql_kstep<NB, WC, S, 3, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+    if constexpr (PIPE) {
+      wql_chunk_pipelined<NB, WC, S, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+    } else {
+      wql_kstep<NB, WC, S, 0, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+      wql_kstep<NB, WC, S, 1, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+      wql_kstep<NB, WC, S, 2, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+      wql_kstep<NB, WC, S, 3, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+    }
     buf ^= 1;
   }
 
@@ -224,36 +260,37 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int NB, int WC, int S, bool RELU>
+template <int NB, int WC, int S, bool RELU, bool PIPE>
 static inline int sg_launch_wgrad_ql_t(const WgradQParams& p, hipStream_t st) {
   constexpr int NIMG = WC == 4 ? 4 : 1, RCI = (64 / WC) / NIMG, PPI = (RCI + 1) * (WC + 1);
   constexpr int XB = ((NIMG * PPI * 64 + 1023) / 1024) * 1024;
   constexpr int LDS = 2 * (S * XB + 64 * NB * 64);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_wgrad_ql_kernel<NB, WC, S, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_wgrad_ql_kernel<NB, WC, S, RELU, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_wgrad_ql_kernel<NB, WC, S, RELU>), dim3(4 * p.nci * p.nco * p.splits), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((sg_wgrad_ql_kernel<NB, WC, S, RELU, PIPE>), dim3(4 * p.nci * p.nco * p.splits), dim3(256), LDS, st, p);
   return 0;
 }
-template <int NB, int S, bool RELU>
+template <int NB, int S, bool RELU, bool PIPE>
 static inline int sg_launch_wgrad_ql_s(const WgradQParams& p, hipStream_t st) {
   const int wc = p.W >= 64 ? 64 : p.W;
   switch (wc) {
-    case 64: return sg_launch_wgrad_ql_t<NB, 64, S, RELU>(p, st);
-    case 32: return sg_launch_wgrad_ql_t<NB, 32, S, RELU>(p, st);
-    case 16: return sg_launch_wgrad_ql_t<NB, 16, S, RELU>(p, st);
-    case 8: return sg_launch_wgrad_ql_t<NB, 8, S, RELU>(p, st);
-    case 4: return sg_launch_wgrad_ql_t<NB, 4, S, RELU>(p, st);
+    case 64: return sg_launch_wgrad_ql_t<NB, 64, S, RELU, PIPE>(p, st);
+    case 32: return sg_launch_wgrad_ql_t<NB, 32, S, RELU, PIPE>(p, st);
+    case 16: return sg_launch_wgrad_ql_t<NB, 16, S, RELU, PIPE>(p, st);
+    case 8: return sg_launch_wgrad_ql_t<NB, 8, S, RELU, PIPE>(p, st);
+    case 4: return sg_launch_wgrad_ql_t<NB, 4, S, RELU, PIPE>(p, st);
   }
   return -1;
 }
-template <bool RELU>
+template <bool RELU, bool PIPE>
 static inline int sg_launch_wgrad_ql_r(const WgradQParams& p, int NB, int S, hipStream_t st) {
-  if (NB == 3) return S == 2 ? sg_launch_wgrad_ql_s<3, 2, RELU>(p, st) : sg_launch_wgrad_ql_s<3, 1, RELU>(p, st);
-  return S == 2 ? sg_launch_wgrad_ql_s<2, 2, RELU>(p, st) : sg_launch_wgrad_ql_s<2, 1, RELU>(p, st);
+  if (NB == 3) return S == 2 ? sg_launch_wgrad_ql_s<3, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<3, 1, RELU, PIPE>(p, st);
+  return S == 2 ? sg_launch_wgrad_ql_s<2, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<2, 1, RELU, PIPE>(p, st);
 }
-static inline int sg_launch_wgrad_ql(const WgradQParams& p, int NB, int S, hipStream_t st) {
-  return p.x_relu ? sg_launch_wgrad_ql_r<true>(p, NB, S, st) : sg_launch_wgrad_ql_r<false>(p, NB, S, st);
+static inline int sg_launch_wgrad_ql(const WgradQParams& p, int NB, int S, hipStream_t st, bool pipe = false) {
+  if (pipe) return p.x_relu ? sg_launch_wgrad_ql_r<true, true>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, true>(p, NB, S, st);
+  return p.x_relu ? sg_launch_wgrad_ql_r<true, false>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, false>(p, NB, S, st);
 }

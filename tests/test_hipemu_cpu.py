@@ -195,9 +195,10 @@ def test_wgrad_q_pins_interpreter_and_lean_equals_shipped(cq, form, shape):
         rb = _t64(dy).sum((0, 1, 2))
         assert (torch.from_numpy(a).double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item(), (form, shape, relu)
         assert (torch.from_numpy(ab).double() - rb).abs().max().item() <= 2e-6 * rb.abs().max().item()
-        b, bb, _ = emu.conv_q_wgrad(cq, form, x, dy, relu_in=relu, bias=True, alpha=0.5, env={"SG_WGRAD_Q": "f", "SG_WGRAD_Q_LEAN": "1"})
-        assert np.array_equal(a, b), (form, shape, relu)
-        assert np.abs(ab - bb).max() <= 1e-6 * np.abs(ab).max()
+        for lean in ("1", "2"):          # 2: + the two-deep register pipeline over the k-steps of a chunk (counted lgkmcnt waits)
+            b, bb, _ = emu.conv_q_wgrad(cq, form, x, dy, relu_in=relu, bias=True, alpha=0.5, env={"SG_WGRAD_Q": "f", "SG_WGRAD_Q_LEAN": lean})
+            assert np.array_equal(a, b), (form, shape, relu, lean)
+            assert np.abs(ab - bb).max() <= 1e-6 * np.abs(ab).max()
 
 
 @pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])

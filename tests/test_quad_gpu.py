@@ -170,7 +170,7 @@ def test_wgrad_q_lean_matches_shipped(sg, case, monkeypatch):
     Hg, Wg = (Hl, Wl) if form == 0 else (2 * Hl, 2 * Wl)
     x, dy = _dev(rnd((N, Hx, Wx, C), dt, 341)), _dev(rnd((N, Hg, Wg, Cout), dt, 342))
     outs = {}
-    for lean in ("0", "1"):
+    for lean in ("0", "1", "2"):          # 2: lean + the two-deep register pipeline over the k-steps of a chunk
         monkeypatch.setenv("SG_WGRAD_Q_LEAN", lean)
         for splits in (0, 3):
             dwd = torch.zeros(Cout, 9, C, dtype=torch.float32, device="cuda:0")
@@ -179,8 +179,9 @@ def test_wgrad_q_lean_matches_shipped(sg, case, monkeypatch):
             torch.cuda.synchronize()
             outs[(lean, splits)] = (dwd.cpu(), db.cpu())
     for splits in (0, 3):
-        assert torch.equal(outs[("0", splits)][0], outs[("1", splits)][0]), (case, splits)
-        check(f"wgrad_q lean bias {case} splits {splits}", outs[("1", splits)][1], outs[("0", splits)][1], 1e-5)
+        for lean in ("1", "2"):
+            assert torch.equal(outs[("0", splits)][0], outs[(lean, splits)][0]), (case, splits, lean)
+            check(f"wgrad_q lean={lean} bias {case} splits {splits}", outs[(lean, splits)][1], outs[("0", splits)][1], 1e-5)
 
 
 SKIP_CASES = [

@@ -9,10 +9,10 @@ O=gpurun_out/r5a
 mkdir -p $O
 ( time SG_EXPERIMENTAL=1 timeout 400 python -m pytest tests/test_conv_v2_gpu.py tests/test_quad_gpu.py -q -p no:cacheprovider --maxfail=10 -k "lean" 2>&1 | tail -8 ) > $O/pytest_lean.txt 2>&1
 cat $O/pytest_lean.txt | cut -c1-250
-for f in 0 1; do
-  ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v3lean$f.txt 2>&1
+for f in 0 1 2; do      # wgrad_q: 1 = lean, 2 = lean + register pipeline over the k-steps (wgrad_v3 has 0 / 1 only)
+  [ $f -lt 2 ] && ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v3lean$f.txt 2>&1
   ( SG_WGRAD_Q_LEAN=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_qlean$f.txt 2>&1
-  tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
+  [ $f -lt 2 ] && tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
 done
 for f in 0 1; do
   ( SG_WGRAD_V3_LEAN=$f SG_WGRAD_Q_LEAN=$f timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --fid-samples 0 ) > $O/bench_lean$f.json 2> $O/bench_lean$f.err
