@@ -22,7 +22,7 @@ import torch
 
 from . import _lib as L
 
-_EVAL_CACHE = [os.environ.get("SG_EVAL_CACHE", "1") != "0"]   # frozen-network weight-image cache (begin_forward); a list so that tests can flip it
+_EVAL_CACHE = [os.environ.get("SG_EVAL_CACHE", "0") == "1"]   # frozen-network weight-image cache (begin_forward), opt-in; a list so that tests can flip it
 _ARENA_BY_ID = {}  # id(Parameter) -> (weakref to the Parameter, ParamArena, offset); keyed by identity, never by ==
 
 
@@ -411,7 +411,8 @@ class WeightBank:
         # A frozen network run without a graph (the evaluation generator of the FID / IS loop, reference src/metrics/features.py:17-65: one forward per
         # batch of 50 k samples) gets the SAME weight images every time: no power iteration (eval mode), same weights. Slot 0 keeps them until
         # something writes the parameters or the spectral-norm vectors: our own raw-pointer writers move _lib.write_epoch, torch-side writes
-        # (load_state_dict, an in-place op on a parameter) move the tensors' version counters. SG_EVAL_CACHE=0 re-emits every time.
+        # (load_state_dict, an in-place op on a parameter) move the tensors' version counters. What NEITHER sees is an in-place write through
+        # `param.data` (a detached alias with its own version counter): the cache is therefore OPT-IN (SG_EVAL_CACHE=1) for loops that own their network.
         key = None
         if not need_graph and not any(flags) and _EVAL_CACHE[0]:
             key = (L.write_epoch[0], sum(p._version for p in self._versioned()), self.params.data._version, self.buffers.data._version, self._fwd_train_epoch)

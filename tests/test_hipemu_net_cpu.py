@@ -90,14 +90,14 @@ def test_emulated_frozen_network_weight_image_cache():
         _, bank = ops._root_and_bank(Ge)
 
         def run(cache=True):
-            B._EVAL_CACHE[0] = cache
+            B._EVAL_CACHE[0] = cache                  # (opt-in in the package: SG_EVAL_CACHE=1)
             try:
                 with torch.no_grad():
                     Ge(z, lab, eval=True)
                 s0 = bank.slots[0]      # what the cache keeps: the emitted operand images of the no-graph slot (the width-8 generator's tanh output is saturated)
                 return torch.cat([s0.img.float().flatten(), s0.f32.flatten()]).clone()
             finally:
-                B._EVAL_CACHE[0] = True
+                B._EVAL_CACHE[0] = False
 
         def same(u, v):      # two emissions of the same weights: equal up to the order of the fp32 atomics in the spectral-norm reductions
             ok = torch.allclose(u, v, rtol=1e-5, atol=2e-6, equal_nan=True)        # (padding the emission never writes may hold anything)

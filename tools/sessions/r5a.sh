@@ -45,7 +45,7 @@ for cfg in "SG_NOOP=1" "SG_WGRAD_V3_LEAN=1 SG_WGRAD_Q_LEAN=1 SG_CONV_Q_LA3=1 SG_
   echo "$cfg: $(grep -o '"ms_per_step": [0-9.]*' $O/bench_all_$tag.json | head -1) $(grep -o '"conv_ms_per_step": [0-9.]*' $O/bench_all_$tag.json | head -1)"
 done
 # 4. FID leg (bf16 Inception): conv_v2 for InceptionV3's 128 / 160-cout 1x7 / 7x1 layers (SG_CONV_V2_MIN_TILES / SG_CONV_V2_PAD_TILES), and the
-#    frozen-network weight-image cache (tools/fid_leg.py runs G.eval(): SG_EVAL_CACHE=0 is the round-4 behaviour)
+#    frozen-network weight-image cache (tools/fid_leg.py runs G.eval(): SG_EVAL_CACHE=1 opts in, 0 is the round-4 behaviour)
 ( timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval.txt 2>&1; cat $O/pytest_eval.txt | cut -c1-200
 for cfg in "SG_EVAL_CACHE=0" "SG_EVAL_CACHE=1" "SG_EVAL_CACHE=1 SG_CONV_V2_MIN_TILES=128" "SG_EVAL_CACHE=1 SG_CONV_V2_MIN_TILES=128 SG_CONV_V2_PAD_TILES=1"; do
   tag=$(echo "$cfg" | tr ' =' '__')
