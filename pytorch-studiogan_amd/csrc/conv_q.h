@@ -22,6 +22,7 @@
 //     with counted waits (conv_v4.h's scheme; four buffers because a slice has four taps).
 // Tile = 256 low-resolution pixels x 32 NB couts, 4 waves, <= 53 KB of LDS: three workgroups per CU.
 #pragma once
+#include <type_traits>
 #include "conv_v2.h"
 
 struct ConvQParams {
@@ -45,6 +46,8 @@ struct ConvQParams {
   unsigned x2bytes, w2bytes;
   float* stats;           // optional [tilesJ * nph][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue)
 };
+// the LA3 / PAIR instantiations take one more argument (the shipped instantiations keep their kernel-argument layout, hence their code, as it was)
+struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 
 // TJW = 32-pixel blocks per wave: 2 (tile of 256 low-resolution pixels) or 1 (128: twice the workgroups for the layers whose whole low-resolution
 // grid is a few thousand positions -- the 1536-channel 8 x 8 -> 4 x 4 tail has 256 tiles of 256 x 96 at batch 256, one per CU where three fit)
@@ -74,7 +77,7 @@ struct ConvQParams {
 // barrier that ends the previous tap has been passed. The double-buffered variant above already runs three ahead but pays for its second patch with
 // a workgroup per CU. Checked on the CPU interpreter (late DMA completion, seeded wave order): tests/test_hipemu_cpu.py.
 template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
   constexpr bool DB = NPMIN > 0;
   constexpr bool LA3 = NPMIN == -1;         // single-buffered patch, weights THREE taps ahead (see above)
   constexpr bool PAIR = NPMIN == -2;        // single-buffered patch, taps in PAIRS: one barrier per two taps (see above)
@@ -249,11 +252,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
           if (RELU) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
+        if constexpr (LA3 || PAIR) SG_PRIO_UP(p.prio);
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+        if constexpr (LA3 || PAIR) SG_PRIO_DOWN(p.prio);
       }
       if constexpr (DB) {
         // counted waits (see the kernel comment): n_w = 2 for the waves that issue two weight pieces per tap, else 1
@@ -383,8 +388,11 @@ static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, bool db, int
   return body + 128 + BI * 4;
 }
 template <int NB, bool RELU, int TJW, bool SKIP, int NPMIN>
-static inline int sg_launch_conv_qr(ConvQParams p, const Epilogue<bf16_t>& e, hipStream_t st) {
+static inline int sg_launch_conv_qr(const ConvQParams& p0, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BI = 32 * NB, BJ = 128 * TJW;
+  typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p;
+  static_cast<ConvQParams&>(p) = p0;
+  if constexpr (NPMIN < 0) p.prio = sg_mfma_prio_env();
   p.patchb = p.npx * 64;
   const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, NPMIN > 0, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;

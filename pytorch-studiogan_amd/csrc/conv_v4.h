@@ -20,6 +20,7 @@
 //     computes while another loads its patch or stores its tile). One barrier (4 waves) per tap = per 4 NB MFMAs of a wave.
 // Row bookkeeping (raster / quad order, nearest x2 upsample on load, image-border masks) is conv_v3.h's; epilogue: sg_conv_epilogue.
 #pragma once
+#include <type_traits>
 #include "conv_v2.h"
 
 struct ConvV4Params {
@@ -41,6 +42,8 @@ struct ConvV4Params {
   unsigned x2bytes, w2bytes;
   float* stats;           // optional [tilesJ][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue), 256-pixel tiles only
 };
+// the NWB = 4 instantiations take one more argument (the shipped instantiations keep their kernel-argument layout, hence their code, as it was)
+struct ConvV4ParamsP : ConvV4Params { int prio; };  // prio: SG_MFMA_PRIO
 
 // TJW = 32-pixel blocks per wave: 2 (tile 256 pixels, 6 accumulator blocks per wave for NB = 3, three workgroups per CU) or 4 (tile 512 pixels,
 // 12 accumulator blocks: 7 fragment reads per 12 MFMAs instead of 5 per 6, two workgroups per CU; the staged epilogue runs in two halves)
@@ -57,7 +60,7 @@ struct ConvV4Params {
 // earlier, a third tap of lookahead hides more of it at the price of one more 2 NB KB buffer -- taken only where the operand area still fits under
 // the staged epilogue (W <= 64 for NB = 3), so that three workgroups keep sharing a CU. The buffer of tap g (counted across slices) is g % 4.
 template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int NWB = 3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(typename std::conditional<(NWB == 4), ConvV4ParamsP, ConvV4Params>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   static_assert(!SKIP || (!UP && TJW == 2), "the fused skip is built for the plain 256-pixel tile");
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
@@ -231,11 +234,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
           if (RELU) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
+        if constexpr (NWB == 4) SG_PRIO_UP(p.prio);
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+        if constexpr (NWB == 4) SG_PRIO_DOWN(p.prio);
       }
       if (t == 8 && next_slice) {
         // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
@@ -371,7 +376,10 @@ static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, i
   return body + 128 + BI * 4;
 }
 template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int NWB = 3>
-static inline int sg_launch_conv_v4n(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
+static inline int sg_launch_conv_v4n(const ConvV4Params& p0, const Epilogue<bf16_t>& e, hipStream_t st) {
+  typename std::conditional<(NWB == 4), ConvV4ParamsP, ConvV4Params>::type p;
+  static_cast<ConvV4Params&>(p) = p0;
+  if constexpr (NWB == 4) p.prio = sg_mfma_prio_env();
   const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0, NWB);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;

@@ -15,6 +15,7 @@
 #include "wgrad_q.h"
 
 typedef __bf16 wql_bf2 __attribute__((ext_vector_type(2)));
+struct WgradQLParams : WgradQParams { int prio; };       // prio: SG_MFMA_PRIO (the shipped kernel keeps its argument layout)
 
 // fragments of one k-step (16 pixels): S activation fragments (one per slice) and NB gradient fragments, each as two transpose reads
 template <int NB, int S> struct WqlFrags { u32x2 al[S], ah[S], bl[NB], bh[NB]; };
@@ -34,7 +35,7 @@ __device__ __forceinline__ void wql_issue(unsigned a0, unsigned b0, WqlFrags<NB,
 }
 // the S NB MFMAs of a k-step from fragments that HAVE landed (the caller's s_waitcnt lgkmcnt covers them)
 template <int NB, int S, bool RELU>
-__device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int cblk, float& csum) {
+__device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int cblk, float& csum, int prio) {
   bf16x8_t af[S], bf[NB];
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -68,45 +69,47 @@ __device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int
         csum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wql_bf2, gq), __builtin_bit_cast(wql_bf2, 0x3f803f80u), csum, false);
       }
     }
+  SG_PRIO_UP(prio);
 #pragma unroll
   for (int s = 0; s < S; s++)
 #pragma unroll
     for (int b = 0; b < NB; b++)
       acc[s * NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf[b], acc[s * NB + b], 0, 0, 0);
+  SG_PRIO_DOWN(prio);
 }
 template <int NB, int WC, int S, int KS, bool RELU>
-__device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
+__device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum, int prio) {
   WqlFrags<NB, S> f;
   wql_issue<NB, WC, S, KS>(a0, b0, f);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  wql_consume<NB, S, RELU>(acc, f, cblk, csum);
+  wql_consume<NB, S, RELU>(acc, f, cblk, csum, prio);
 }
 // PIPE: the four k-steps of a chunk as a two-deep register pipeline -- the reads of k-step s + 1 are in flight while the MFMAs of k-step s issue; the
 // counted wait leaves exactly those 2 (S + NB) reads outstanding (LDS operations of a wave return in order). One exposed LDS round trip per chunk
 // instead of four; 2 (S + NB) more registers (wgrad_v2.h has run such a pipeline since round 2).
 template <int NB, int WC, int S, bool RELU>
-__device__ __forceinline__ void wql_chunk_pipelined(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
+__device__ __forceinline__ void wql_chunk_pipelined(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum, int prio) {
   constexpr int NR = 2 * (S + NB);
   static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
   WqlFrags<NB, S> f0, f1;
   wql_issue<NB, WC, S, 0>(a0, b0, f0);
   wql_issue<NB, WC, S, 1>(a0, b0, f1);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum, prio);
   wql_issue<NB, WC, S, 2>(a0, b0, f0);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum, prio);
   wql_issue<NB, WC, S, 3>(a0, b0, f1);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum, prio);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum, prio);
 }
 
 // NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in low-resolution pixels (64, 32, 16, 8: 64 / WC whole image rows; 4: four
 // whole 4 x 4 images), S = 32-channel input slices per workgroup (1 or 2)
 template <int NB, int WC, int S, bool RELU, bool PIPE = false>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sg_wgrad_ql_kernel(WgradQParams p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sg_wgrad_ql_kernel(WgradQLParams p) {
   constexpr int NIMG = WC == 4 ? 4 : 1;             // images per chunk
   constexpr int RC = 64 / WC, RCI = RC / NIMG;      // chunk rows, rows per image part
   constexpr int PW = WC + 1, PR = RCI + 1;          // patch extent (per image part) in pixels
@@ -227,12 +230,12 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
     if constexpr (PIPE) {
-      wql_chunk_pipelined<NB, WC, S, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+      wql_chunk_pipelined<NB, WC, S, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
     } else {
-      wql_kstep<NB, WC, S, 0, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-      wql_kstep<NB, WC, S, 1, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-      wql_kstep<NB, WC, S, 2, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
-      wql_kstep<NB, WC, S, 3, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
+      wql_kstep<NB, WC, S, 0, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
+      wql_kstep<NB, WC, S, 1, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
+      wql_kstep<NB, WC, S, 2, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
+      wql_kstep<NB, WC, S, 3, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
     }
     buf ^= 1;
   }
@@ -261,7 +264,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
 }
 
 template <int NB, int WC, int S, bool RELU, bool PIPE>
-static inline int sg_launch_wgrad_ql_t(const WgradQParams& p, hipStream_t st) {
+static inline int sg_launch_wgrad_ql_t(const WgradQLParams& p, hipStream_t st) {
   constexpr int NIMG = WC == 4 ? 4 : 1, RCI = (64 / WC) / NIMG, PPI = (RCI + 1) * (WC + 1);
   constexpr int XB = ((NIMG * PPI * 64 + 1023) / 1024) * 1024;
   constexpr int LDS = 2 * (S * XB + 64 * NB * 64);
@@ -274,7 +277,7 @@ static inline int sg_launch_wgrad_ql_t(const WgradQParams& p, hipStream_t st) {
   return 0;
 }
 template <int NB, int S, bool RELU, bool PIPE>
-static inline int sg_launch_wgrad_ql_s(const WgradQParams& p, hipStream_t st) {
+static inline int sg_launch_wgrad_ql_s(const WgradQLParams& p, hipStream_t st) {
   const int wc = p.W >= 64 ? 64 : p.W;
   switch (wc) {
     case 64: return sg_launch_wgrad_ql_t<NB, 64, S, RELU, PIPE>(p, st);
@@ -286,11 +289,14 @@ static inline int sg_launch_wgrad_ql_s(const WgradQParams& p, hipStream_t st) {
   return -1;
 }
 template <bool RELU, bool PIPE>
-static inline int sg_launch_wgrad_ql_r(const WgradQParams& p, int NB, int S, hipStream_t st) {
+static inline int sg_launch_wgrad_ql_r(const WgradQLParams& p, int NB, int S, hipStream_t st) {
   if (NB == 3) return S == 2 ? sg_launch_wgrad_ql_s<3, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<3, 1, RELU, PIPE>(p, st);
   return S == 2 ? sg_launch_wgrad_ql_s<2, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<2, 1, RELU, PIPE>(p, st);
 }
-static inline int sg_launch_wgrad_ql(const WgradQParams& p, int NB, int S, hipStream_t st, bool pipe = false) {
+static inline int sg_launch_wgrad_ql(const WgradQParams& p0, int NB, int S, hipStream_t st, bool pipe = false) {
+  WgradQLParams p;
+  static_cast<WgradQParams&>(p) = p0;
+  p.prio = sg_mfma_prio_env();
   if (pipe) return p.x_relu ? sg_launch_wgrad_ql_r<true, true>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, true>(p, NB, S, st);
   return p.x_relu ? sg_launch_wgrad_ql_r<true, false>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, false>(p, NB, S, st);
 }

@@ -16,10 +16,11 @@
 #include "wgrad_v3.h"
 
 typedef __bf16 w3l_bf2 __attribute__((ext_vector_type(2)));
+struct WgradV3LParams : WgradV3Params { int prio; };     // prio: SG_MFMA_PRIO (the shipped kernel keeps its argument layout)
 
 // one k-step (16 pixels) of a chunk, as w3_kstep: 2 NB + 1 MFMAs from 3 activation fragments (taps t0, t1, 8) and NB + 1 gradient fragments
 template <int NB, int WC, int KS, bool RELU>
-__device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, bool extra, float& csum, bool do_csum) {
+__device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, bool extra, float& csum, bool do_csum, int prio) {
   constexpr int PW = WC + 2, GPITCH = NB * 64;
   // patch byte offset of pixels KS * 16 .. of the chunk raster. WC == 4 (round 4): a chunk is FOUR whole 4 x 4 images, each with its own 6 x 6
   // halo patch; a 16-pixel k-step is one image, and the second half of a fragment (+ 4 pixels) is the next image row
@@ -66,16 +67,18 @@ __device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1,
       csum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(w3l_bf2, gq), __builtin_bit_cast(w3l_bf2, 0x3f803f80u), csum, false);
     }
   }
+  SG_PRIO_UP(prio);
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b], acc[b], 0, 0, 0);
     acc[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b], acc[NB + b], 0, 0, 0);
   }
   if (extra) acc[2 * NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], xf, acc[2 * NB], 0, 0, 0);
+  SG_PRIO_DOWN(prio);
 }
 
 template <int NB, int WC, bool RELU>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_wgrad_v3l_kernel(WgradV3Params p) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void sg_wgrad_v3l_kernel(WgradV3LParams p) {
   constexpr int NIMG = WC == 4 ? 4 : 1;             // images per chunk (WC == 4: four whole 4 x 4 images)
   constexpr int RC = 64 / WC / NIMG;                // image rows per chunk (per image part)
   constexpr int PW = WC + 2, PR = RC + 2;           // patch extent in pixels (per image part)
@@ -189,10 +192,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_s_barrier();                   // chunk c has landed everywhere; every wave is done with the other buffer
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
-    w3l_kstep<NB, WC, 0, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
-    w3l_kstep<NB, WC, 1, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
-    w3l_kstep<NB, WC, 2, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
-    w3l_kstep<NB, WC, 3, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
+    w3l_kstep<NB, WC, 0, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
+    w3l_kstep<NB, WC, 1, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
+    w3l_kstep<NB, WC, 2, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
+    w3l_kstep<NB, WC, 3, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
     buf ^= 1;
   }
 
@@ -218,7 +221,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 }
 
 template <int NB, int WC, bool RELU>
-static inline int sg_launch_wgrad_v3l_t(const WgradV3Params& p, hipStream_t st) {
+static inline int sg_launch_wgrad_v3l_t(const WgradV3LParams& p, hipStream_t st) {
   constexpr int NIMG = WC == 4 ? 4 : 1, RC = 64 / WC / NIMG, XB = NIMG * (RC + 2) * (WC + 2) * 64;
   constexpr int LDS = 2 * (((XB + 1023) / 1024) * 1024 + 64 * NB * 64);
   static bool attr_done = false;
@@ -230,11 +233,14 @@ static inline int sg_launch_wgrad_v3l_t(const WgradV3Params& p, hipStream_t st) 
   return 0;
 }
 template <int NB, int WC>
-static inline int sg_launch_wgrad_v3l_r(const WgradV3Params& p, hipStream_t st) {
+static inline int sg_launch_wgrad_v3l_r(const WgradV3LParams& p, hipStream_t st) {
   return p.x_relu ? sg_launch_wgrad_v3l_t<NB, WC, true>(p, st) : sg_launch_wgrad_v3l_t<NB, WC, false>(p, st);
 }
-static inline int sg_launch_wgrad_v3l(const WgradV3Params& p, int NB, hipStream_t st) {
-  if (p.x_up || p.g_up) return sg_launch_wgrad_v3(p, NB, st);      // operands read through a 2x nearest upsampling: the shipped kernel
+static inline int sg_launch_wgrad_v3l(const WgradV3Params& p0, int NB, hipStream_t st) {
+  if (p0.x_up || p0.g_up) return sg_launch_wgrad_v3(p0, NB, st);      // operands read through a 2x nearest upsampling: the shipped kernel
+  WgradV3LParams p;
+  static_cast<WgradV3Params&>(p) = p0;
+  p.prio = sg_mfma_prio_env();
   const int wc = p.W >= 64 ? 64 : p.W;
   if (NB == 3) {
     switch (wc) { case 64: return sg_launch_wgrad_v3l_r<3, 64>(p, st); case 32: return sg_launch_wgrad_v3l_r<3, 32>(p, st);

@@ -579,6 +579,7 @@ inline float fdot2_bf16(e_bf16x2 a, e_bf16x2 b, float c, bool /*clamp*/) {
 #define __builtin_amdgcn_readfirstlane hipemu::readfirstlane
 #define __builtin_amdgcn_s_barrier hipemu::s_barrier
 #define __builtin_amdgcn_sched_barrier(x) ((void)0)
+#define __builtin_amdgcn_s_setprio(x) ((void)0)        // a scheduling hint: no effect on results
 #define __builtin_amdgcn_ds_read_tr16_b64_v4i16(p) hipemu::ds_read_tr16_b64(hipemu::lds_addr(p))
 #define __builtin_amdgcn_exp2f exp2f
 #define __builtin_amdgcn_update_dpp hipemu::update_dpp

@@ -9,10 +9,11 @@ O=gpurun_out/r5a
 mkdir -p $O
 ( time SG_EXPERIMENTAL=1 timeout 400 python -m pytest tests/test_conv_v2_gpu.py tests/test_quad_gpu.py -q -p no:cacheprovider --maxfail=10 -k "lean" 2>&1 | tail -8 ) > $O/pytest_lean.txt 2>&1
 cat $O/pytest_lean.txt | cut -c1-250
-for f in 0 1 2; do      # wgrad_q: 1 = lean, 2 = lean + register pipeline over the k-steps (wgrad_v3 has 0 / 1 only)
-  [ $f -lt 2 ] && ( SG_WGRAD_V3_LEAN=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v3lean$f.txt 2>&1
-  ( SG_WGRAD_Q_LEAN=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_qlean$f.txt 2>&1
-  [ $f -lt 2 ] && tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
+for f in 0 1 2 1p 2p; do      # wgrad_q: 1 = lean, 2 = lean + register pipeline over the k-steps (wgrad_v3 has 0 / 1 only); p = + SG_MFMA_PRIO=1 (s_setprio around the MFMA clusters)
+  pr=0; case $f in *p) pr=1;; esac; l=${f%p}
+  [ $l -lt 2 ] && ( SG_MFMA_PRIO=$pr SG_WGRAD_V3_LEAN=$l timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v3lean$f.txt 2>&1
+  ( SG_MFMA_PRIO=$pr SG_WGRAD_Q_LEAN=$l timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_qlean$f.txt 2>&1
+  [ $l -lt 2 ] && tail -4 $O/conv_bench_v3lean$f.txt | cut -c1-200; tail -6 $O/quad_bench_qlean$f.txt | cut -c1-200
 done
 for f in 0 1; do
   ( SG_WGRAD_V3_LEAN=$f SG_WGRAD_Q_LEAN=$f timeout 400 python bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extras --fid-samples 0 ) > $O/bench_lean$f.json 2> $O/bench_lean$f.err
@@ -30,13 +31,15 @@ PY
 done
 # 3b. conv_q.h with the weights three taps ahead (SG_CONV_Q_LA3=1; CPU: bit-identical to the shipped loop under the interpreter)
 for f in 1 2; do ( SG_CONV_Q_LA3=$f timeout 300 python -m pytest tests/test_quad_gpu.py -q -p no:cacheprovider -k "conv_q and not wgrad" 2>&1 | tail -3 ) > $O/pytest_la3_$f.txt 2>&1; cat $O/pytest_la3_$f.txt | cut -c1-200; done
-for f in 0 1 2; do      # 0: shipped loop, 1: weights three taps ahead, 2: taps in pairs (one barrier per pair)
-  ( SG_CONV_Q_LA3=$f timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
+for f in 0 1 2 1p 2p; do      # 0: shipped loop, 1: weights three taps ahead, 2: taps in pairs (one barrier per pair); p = + SG_MFMA_PRIO=1
+  pr=0; case $f in *p) pr=1;; esac
+  ( SG_MFMA_PRIO=$pr SG_CONV_Q_LA3=${f%p} timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
 done
 # 3c. conv_v4.h with four weight buffers / three taps ahead (SG_CONV_V4_LA3=1) where three workgroups still fit a CU
 ( SG_CONV_V4_LA3=1 timeout 300 python -m pytest tests/test_conv_v2_gpu.py -q -p no:cacheprovider -k "conv_v4 or fused_skip" 2>&1 | tail -3 ) > $O/pytest_v4la3.txt 2>&1; cat $O/pytest_v4la3.txt | cut -c1-200
-for f in 0 1; do
-  ( SG_CONV_V4_LA3=$f timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v4la3_$f.txt 2>&1; tail -12 $O/conv_bench_v4la3_$f.txt | cut -c1-200
+for f in 0 1 1p; do
+  pr=0; case $f in *p) pr=1;; esac
+  ( SG_MFMA_PRIO=$pr SG_CONV_V4_LA3=${f%p} timeout 300 python tools/conv_bench.py --batch 256 2>&1 ) > $O/conv_bench_v4la3_$f.txt 2>&1; tail -12 $O/conv_bench_v4la3_$f.txt | cut -c1-200
 done
 # 3d. everything that won its layer table, together: step A/B (edit the list)
 for cfg in "SG_NOOP=1" "SG_WGRAD_V3_LEAN=1 SG_WGRAD_Q_LEAN=1 SG_CONV_Q_LA3=1 SG_CONV_V4_LA3=1"; do
