@@ -2,6 +2,7 @@
 # round-5 GPU session A (FIRST GPU minutes of the round): the kernels written in round 4 without GPU time -- wgrad_v3l.h / wgrad_ql.h ("lean" weight
 # gradients: LDS-DMA addresses once per workgroup, ReLU as a template parameter, bias gradient through v_dot2; CPU: tests/test_hipemu_cpu.py,
 # bit-identical to the shipped kernels under the interpreter). 1. parity on the GPU (opt-in tests), 2. layer tables A/B, 3. step A/B.
+# ~45 GPU-minutes as written: split it (sections 1-3 | 3b-3d | 4) if the budget asks for it.
 # Decision rule: a switch becomes the default when its layer table is faster on the same box and the step is not slower.
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
