@@ -67,6 +67,9 @@ struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 // vmcnt(2 n_w) behind tap 3 (P' and W0' have landed). NPMIN = the smallest number of patch pieces a wave issues (compile-time immediate;
 // waves with one piece more only wait a little earlier than they must).
 //
+// NPMIN == -3 ("HALO1", round 4, written without GPU time: SG_CONV_Q_LA3=3, default off): the shipped loop with a patch of BJ + Wl + 16 pixels instead of BJ + 2 Wl + 16 --
+// the four taps of a view reach to one side only (wgrad_q.h already stages its patches that way). 16 % fewer patch bytes at Wl = 64 (8 % of everything the kernel
+// stages), nothing else changes: the cleanest test of whether the LDS-DMA ingest rate (10-11 B / clk / CU in every halo kernel of this tree) is what bounds them.
 // NPMIN == -2 ("PAIR", round 4, written without GPU time: SG_CONV_Q_LA3=2, default off): the four taps of a slice as two PAIRS -- a pair's two weight tiles are
 // requested one pair ahead (the same 24 MFMAs per wave of distance as the shipped two-taps-ahead scheme) and the workgroup synchronises once per pair
 // instead of once per tap: half the barriers and half the counted waits, every wait a plain vmcnt(0). Against LA3 this separates "the barriers cost" from
@@ -81,6 +84,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
   constexpr bool DB = NPMIN > 0;
   constexpr bool LA3 = NPMIN == -1;         // single-buffered patch, weights THREE taps ahead (see above)
   constexpr bool PAIR = NPMIN == -2;        // single-buffered patch, taps in PAIRS: one barrier per two taps (see above)
+  constexpr bool HALO1 = NPMIN == -3;       // the shipped loop with a ONE-sided patch halo (see above)
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -126,8 +130,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
   const int pix0 = P0 + 16 * wave + sub;
   auto patch_slice = [&](int view, int s, int pbase = 0) {
     const int vadd = pool ? ((view >> 1) * 2 * p.Wl + (view & 1)) : 0;
+    // HALO1: the four taps of a view reach to ONE side (row offsets {-ea, 1 - ea} of the low-resolution grid): its patch starts ea rows, not one row, above the tile
+    const int vsh = HALO1 ? (1 - (pool ? (view >> 1) : 1 - (view >> 1))) * p.Wl : 0;
     for (int g = wave; g < ngroups; g += NW) {
-      const int pix = pix0 + 16 * (g - wave);
+      const int pix = pix0 + vsh + 16 * (g - wave);
       // POOL: view pixel -> fine pixel; out-of-range low-resolution indices (tile halo beyond the tensor) read zeros
       const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
       unsigned off = src * ldxb + (unsigned)(s * 64 + lc * 16);
@@ -163,7 +169,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
           if ((unsigned)(ho - 1 + rr) < (unsigned)(1 << p.hlog) && (unsigned)(wo - 1 + ss) < (unsigned)p.Wl) m |= 1u << (rr * 3 + ss);
     }
     qval[b] = m;
-    rb[b] = row - P0;
+    rb[b] = HALO1 ? row - (j0 - 8) : row - P0;                         // (HALO1: relative to the tile; the view's row shift cancels against its tap origin)
   }
   // weight fragment addresses: row = cout a * 32 + frow, chunk (ks * 2 + fhi) ^ (row >> 2 & 3); ks = 1 is the address ^ 32
   unsigned wa[TI];
@@ -200,7 +206,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
     // tap origin of this view on the low-resolution grid
     const int ea = pool ? (view >> 1) : 1 - (view >> 1);
     const int eb = pool ? (view & 1) : 1 - (view & 1);
-    const int org = -ea * p.Wl - eb;                                 // patch-row displacement of tap (0, 0)
+    const int org = HALO1 ? -eb : -ea * p.Wl - eb;                   // patch-row displacement of tap (0, 0)
     const int vbit0 = (1 - ea) * 3 + (1 - eb);                       // validity bit of tap (0, 0)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
@@ -393,6 +399,7 @@ static inline int sg_launch_conv_qr(const ConvQParams& p0, const Epilogue<bf16_t
   typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p;
   static_cast<ConvQParams&>(p) = p0;
   if constexpr (NPMIN < 0) p.prio = sg_mfma_prio_env();
+  if constexpr (NPMIN == -3) p.npx = ((p.bj + p.Wl + 16) + 15) & ~15;      // one-sided halo
   p.patchb = p.npx * 64;
   const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, NPMIN > 0, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;
@@ -410,6 +417,7 @@ static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>
   if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
   if (db == 2) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -1>(p, e, st);      // LA3
   if (db == 3) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -2>(p, e, st);      // PAIR
+  if (db == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -3>(p, e, st);      // HALO1
   if (db) {       // double-buffered patch: the smallest per-wave piece count is a compile-time immediate of the counted waits
     const int npmin = (p.npx >> 4) >> 2;
     if (npmin == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 4>(p, e, st);

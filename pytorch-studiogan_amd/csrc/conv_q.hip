@@ -247,7 +247,7 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   int db_mode = ev_db ? (ev_db[0] == '1' ? 1 : 0) : ((d->Wl == 4 && d->form == SG_Q_UP) ? 1 : 0);
   // SG_CONV_Q_LA3=1 (A/B switch, not run on a GPU yet): weights three taps ahead in the single-buffered loop (conv_q.h NPMIN < 0) wherever the
   // double-buffered variant is not the choice
-  if (const char* la = getenv("SG_CONV_Q_LA3")) { if (db_mode == 0) db_mode = la[0] == '1' ? 2 : (la[0] == '2' ? 3 : 0); }      // 2: the PAIR loop
+  if (const char* la = getenv("SG_CONV_Q_LA3")) { if (db_mode == 0) db_mode = la[0] == '1' ? 2 : (la[0] == '2' ? 3 : (la[0] == '3' ? 4 : 0)); }      // 2: the PAIR loop, 3: one-sided patch halo
   const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, db_mode, st) : sg_launch_conv_q<2>(p, e, db_mode, st);
   {
     // algorithmic HBM bytes: input (+ skip input), quad filter(s), result (+ mask / residual), bf16

@@ -202,7 +202,7 @@ def test_wgrad_q_pins_interpreter_and_lean_equals_shipped(cq, form, shape):
 
 
 @pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
-@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 96), (1, 32, 32, 96, 192), (1, 16, 64, 32, 64)])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64, 96), (1, 32, 32, 96, 192), (1, 16, 64, 32, 64), (3, 8, 8, 64, 96)])      # (the last: one ragged tile)
 def test_conv_q_la3_equals_default(cq, form, shape):
     """SG_CONV_Q_LA3=1 / 2 (conv_q.h NPMIN = -1: weights three taps ahead in the single-buffered loop; -2: taps in pairs, one barrier per pair): same MFMAs, same order -> the same bf16 output bit
     for bit as the shipped loop, under late DMA completion (the counted waits and the buffer re-use are what changed) and several wave orders; with
@@ -218,7 +218,7 @@ def test_conv_q_la3_equals_default(cq, form, shape):
         kw = dict(x2=emu.to_bf16(rng.standard_normal((N, 2 * Hl, 2 * Wl, 32)).astype(np.float32)), w2q=emu.to_bf16((0.1 * rng.standard_normal((Cout, 32))).astype(np.float32)),
                   bias2=rng.standard_normal(Cout).astype(np.float32))
     outs = {}
-    for la in ("0", "1", "2"):          # shipped loop, LA3, PAIR
+    for la in ("0", "1", "2", "3"):     # shipped loop, LA3, PAIR, one-sided patch halo
         for seed in (1, 2, 3):
             emu.config(cq, dma_late=1, greedy=1, seed=seed)
             c0 = emu.counters(cq)

@@ -198,11 +198,11 @@ def test_emulated_fullwidth_teacher_forced_blocks_with_lean_kernels(forced_fast_
 
 
 @pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: every full-width fixture through the interpreter with every round-4 switch on, 0.5-4 min each")
-@pytest.mark.parametrize("qla", ["1", "2"])
+@pytest.mark.parametrize("qla", ["1", "2", "3"])
 @pytest.mark.parametrize("name", ["sngan32w", "wgangp128w", "bigdeep128w", "biggan128w"])
 def test_emulated_fullwidth_bf16_step_all_round4_switches(forced_fast_kernels, monkeypatch, name, qla):
     """the four full-width fixtures (C2 SNGAN, C5 WGAN-GP ResNet-128 with its double backward, C4 BigGAN-deep-128, C3 BigGAN-128) with EVERY kernel variant that
-    has not run on a GPU yet switched on at once: lean weight gradients, conv_q weights three taps ahead (qla = 1) or taps in pairs (qla = 2), conv_v4 with
+    has not run on a GPU yet switched on at once: lean weight gradients, conv_q weights three taps ahead (qla = 1), taps in pairs (qla = 2) or one-sided patch halo (qla = 3), conv_v4 with
     four weight buffers. Golden vectors of the reference at the bf16 tolerances of tests/test_fullwidth_gpu.py."""
     for k, v in (("SG_WGRAD_V3_LEAN", "1"), ("SG_WGRAD_Q_LEAN", "1"), ("SG_CONV_Q_LA3", qla), ("SG_CONV_V4_LA3", "1")):
         monkeypatch.setenv(k, v)

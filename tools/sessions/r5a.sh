@@ -31,8 +31,8 @@ PY
   tail -2 $O/bench_lean$f.err | cut -c1-200
 done
 # 3b. conv_q.h with the weights three taps ahead (SG_CONV_Q_LA3=1; CPU: bit-identical to the shipped loop under the interpreter)
-for f in 1 2; do ( SG_CONV_Q_LA3=$f timeout 300 python -m pytest tests/test_quad_gpu.py -q -p no:cacheprovider -k "conv_q and not wgrad" 2>&1 | tail -3 ) > $O/pytest_la3_$f.txt 2>&1; cat $O/pytest_la3_$f.txt | cut -c1-200; done
-for f in 0 1 2 1p 2p; do      # 0: shipped loop, 1: weights three taps ahead, 2: taps in pairs (one barrier per pair); p = + SG_MFMA_PRIO=1
+for f in 1 2 3; do ( SG_CONV_Q_LA3=$f timeout 300 python -m pytest tests/test_quad_gpu.py -q -p no:cacheprovider -k "conv_q and not wgrad" 2>&1 | tail -3 ) > $O/pytest_la3_$f.txt 2>&1; cat $O/pytest_la3_$f.txt | cut -c1-200; done
+for f in 0 3 1 2 1p 2p; do      # 0: shipped loop, 3: one-sided patch halo (-8 % staged bytes: the LDS-DMA-ingest test), 1: weights three taps ahead, 2: taps in pairs (one barrier per pair); p = + SG_MFMA_PRIO=1
   pr=0; case $f in *p) pr=1;; esac
   ( SG_MFMA_PRIO=$pr SG_CONV_Q_LA3=${f%p} timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
 done
