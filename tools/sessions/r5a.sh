@@ -57,3 +57,11 @@ for cfg in "SG_EVAL_CACHE=0" "SG_EVAL_CACHE=1" "SG_EVAL_CACHE=1 SG_CONV_V2_MIN_T
   echo "$cfg: $(grep -o '"value": [0-9.]*' $O/fid_$tag.json | head -1)"; tail -1 $O/fid_$tag.err | cut -c1-200
 done
 ( SG_CONV_V2_MIN_TILES=128 SG_CONV_V2_PAD_TILES=1 timeout 300 python -m pytest tests/test_eval_gpu.py -q -p no:cacheprovider 2>&1 | tail -3 ) > $O/pytest_eval_v2.txt 2>&1; cat $O/pytest_eval_v2.txt | cut -c1-200
+# 5. counters that tell the vector pipe from the LDS-DMA ingest (separate passes, --kernel-trace only: MI355X_MICROARCH.md's recipe): weight-gradient layer tables,
+#    shipped vs lean -- SQ_ACTIVE_INST_VALU / SQ_WAVE_CYCLES falls with the lean kernels whatever happens to the time; SQ_VALU_MFMA_BUSY_CYCLES per clock is the verdict
+R=$(pwd)
+for f in 0 1; do
+  ( cd /tmp && SG_WGRAD_V3_LEAN=$f SG_WGRAD_Q_LEAN=$f timeout 300 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU --kernel-trace -d $R/$O/pmc_lean$f -o pmc --output-format csv -- python $R/tools/quad_bench.py --batch 256 ) > $O/pmc_lean$f.log 2>&1
+  python tools/pmc_summary.py $(ls $O/pmc_lean$f/*/*counter_collection.csv $O/pmc_lean$f/*counter_collection.csv 2>/dev/null | head -1) > $O/sq_counters_lean$f.txt 2> $O/sq_counters_lean$f.err
+  grep -i "wgrad" $O/sq_counters_lean$f.txt | cut -c1-220 | head -8
+done
