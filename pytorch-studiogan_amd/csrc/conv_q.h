@@ -49,6 +49,10 @@ struct ConvQParams {
 // the LA3 / PAIR instantiations take one more argument (the shipped instantiations keep their kernel-argument layout, hence their code, as it was)
 struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 
+// TJW = 4 (round 4, written without GPU time: SG_CONV_Q_BJ=512, default off): 512-pixel tiles -- 12 accumulator blocks per wave, two workgroups per CU, the result staged
+// in two halves like conv_v4.h's 512-pixel tile. A weight tile then serves twice the pixels: 62-66 KB staged per 384 MFMAs instead of 45-50 per 192 (-35 % per
+// MFMA). conv_v4.h's own 512-pixel tile ran no faster than its 256-pixel one in round 2; whether conv_q, with its four-tap slices, differs is for the A/B
+// that HALO1 opens (does the time follow the staged bytes?). Not with the fused skip.
 // TJW = 32-pixel blocks per wave: 2 (tile of 256 low-resolution pixels) or 1 (128: twice the workgroups for the layers whose whole low-resolution
 // grid is a few thousand positions -- the 1536-channel 8 x 8 -> 4 x 4 tail has 256 tiles of 256 x 96 at batch 256, one per CU where three fit)
 //
@@ -80,7 +84,7 @@ struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 // barrier that ends the previous tap has been passed. The double-buffered variant above already runs three ahead but pays for its second patch with
 // a workgroup per CU. Checked on the CPU interpreter (late DMA completion, seeded wave order): tests/test_hipemu_cpu.py.
 template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 || TJW == 4) ? 2 : 3, (NPMIN > 0 || TJW == 4) ? 2 : 3))) void sg_conv_q_kernel(typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
   constexpr bool DB = NPMIN > 0;
   constexpr bool LA3 = NPMIN == -1;         // single-buffered patch, weights THREE taps ahead (see above)
   constexpr bool PAIR = NPMIN == -2;        // single-buffered patch, taps in PAIRS: one barrier per two taps (see above)
@@ -370,7 +374,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
-  if (pool) {
+  if constexpr (TJW == 4) {
+    // 512-pixel tile, 256-row staging area (conv_v4.h's scheme): waves 0, 1 then waves 2, 3; the statistics rows are those of the 256-pixel tiling
+    float* const st1 = (j0 + 256 < p.J) ? p.stats : nullptr;
+    if (pool) {
+      sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2, 0, 0, p.stats, p.I, 2 * tJ);
+      sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2, 0, 0, st1, p.I, 2 * tJ + 1);
+    } else {
+      const int vadd = (ph >> 1) * 2 * p.Wl + (ph & 1);
+      sg_conv_epilogue<BI, 256, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2, p.wlog, vadd, p.stats, p.I, (2 * tJ) * nph + ph);
+      sg_conv_epilogue<BI, 256, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2, p.wlog, vadd, st1, p.I, (2 * tJ + 1) * nph + ph);
+    }
+  } else if (pool) {
     sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
   } else {
     // UP: output / mask / residual rows go through the view of this workgroup's phase
@@ -384,7 +399,7 @@ static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, bool db, int
   const int BI = 32 * NB;
   const int woff = npx * 64 * (db ? 2 : 1);
   const int ops = woff + 4 * BI * 64;
-  const int stage = BJ * (BI * 2 + 16);
+  const int stage = (BJ > 256 ? 256 : BJ) * (BI * 2 + 16);      // (512-pixel tiles stage their result in two halves)
   const int skp = skip ? 2 * BJ * 64 + 2 * BI * 64 : 0;      // two staging slots of the fused skip (patch + weights each)
   int body = ops > stage ? ops : stage;
   if (skp > body) body = skp;
@@ -415,6 +430,7 @@ static inline int sg_launch_conv_qr(const ConvQParams& p0, const Epilogue<bf16_t
 template <int NB, bool SKIP, bool RELU>
 static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
   if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
+  if constexpr (!SKIP) { if (p.bj == 512) return db == 4 ? sg_launch_conv_qr<NB, RELU, 4, false, -3>(p, e, st) : sg_launch_conv_qr<NB, RELU, 4, false, 0>(p, e, st); }
   if (db == 2) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -1>(p, e, st);      // LA3
   if (db == 3) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -2>(p, e, st);      // PAIR
   if (db == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -3>(p, e, st);      // HALO1

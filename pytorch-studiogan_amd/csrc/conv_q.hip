@@ -193,7 +193,7 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
     const int nph = d->form == SG_Q_POOL ? 1 : 4;
     const long long tiles256 = (long long)(d->Cout / (32 * NB)) * ((J + 255) / 256) * nph;
     p.bj = tiles256 < 512 ? 128 : 256;
-    if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; }
+    if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; else if (bj[0] == '5' && !d->x2 && (tiles256 >= 1024 || bj[1] == 'f')) p.bj = 512; }      // 512 (5f: whatever the tile count, tests): A/B switch, not run on a GPU yet
   }
   p.npx = ((p.bj + 2 * d->Wl + 16) + 15) & ~15;
   p.flags = d->pix_flags;
@@ -228,7 +228,8 @@ extern "C" int sg_conv2d_q_stat_rows(const sg_convq_desc* d) {
   if (!d || !d->x || !d->wq || !d->out) return 0;
   ConvQParams p; Epilogue<bf16_t> e; int NB;
   if (!convq_plan(d, p, e, NB)) return 0;
-  return ((p.J + p.bj - 1) / p.bj) * (d->form == SG_Q_POOL ? 1 : 4);
+  const int sbj = p.bj > 256 ? 256 : p.bj;          // (512-pixel tiles write the statistics rows of the 256-pixel tiling)
+  return ((p.J + sbj - 1) / sbj) * (d->form == SG_Q_POOL ? 1 : 4);
 }
 extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   SG_CHECK(d && d->x && d->wq && d->out, "sg_conv2d_q: null pointer");

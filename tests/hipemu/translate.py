@@ -130,7 +130,15 @@ def translate(src, base=0):
     what was translated before: the build cache is keyed on the translated text)"""
     _counter[0] = base
     src = re.sub(r"__attribute__\(\(address_space\(\d+\)\)\)", "", src)
-    src = re.sub(r"__attribute__\(\(amdgpu_\w+\([^)]*\)\)\)", "", src)
+    # __attribute__((amdgpu_...(...))) -- balanced: the arguments may hold parenthesised expressions
+    out, i = "", 0
+    for m in re.finditer(r"__attribute__\s*\(\(\s*amdgpu_\w+", src):
+        if m.start() < i:
+            continue
+        j = _balanced(src, src.index("(", m.start()))
+        out += src[i:m.start()]
+        i = j
+    src = out + src[i:]
     # extern __shared__ [attr] T name[];
     src = re.sub(r"extern\s+__shared__\s+(?:__attribute__\(\(aligned\(\d+\)\)\)\s*)?(\w+)\s+(\w+)\s*\[\s*\]\s*;",
                  r"\1* \2 = (\1*)hipemu::dyn_lds();", src)

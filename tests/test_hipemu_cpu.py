@@ -339,3 +339,33 @@ def test_wgrad_engines_pin_interpreter(wg, case):
     dw, _, _ = emu.conv_wgrad(wg, x, dy, Cout, x_flags=xf, env=env, R=R, pad=pad)
     ref, _ = emu.wgrad_ref(x, dy, x_flags=xf, R=R, pad=pad)
     assert np.abs(dw - ref).max() <= 3e-6 * np.abs(ref).max(), name
+
+
+@pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
+@pytest.mark.parametrize("shape", [(2, 16, 32, 64, 96), (3, 16, 16, 32, 64), (1, 32, 32, 96, 192)])      # (the second: 768 positions = one full and one half tile)
+def test_conv_q_512_pixel_tile_equals_default(cq, form, shape):
+    """SG_CONV_Q_BJ=512 (conv_q.h TJW = 4: 12 accumulator blocks per wave, result staged in two halves), alone and with the one-sided halo: the same bf16 output bit for
+    bit as the 256-pixel tile, with bias + ReLU mask + residual in the epilogue"""
+    N, Hl, Wl, Cin, Cout = shape
+    rng = np.random.default_rng(71)
+    x, _ = _qdata(form, shape, 71)
+    w9 = emu.to_bf16((0.1 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    wq = emu.quad_pack(cq, w9, form)
+    oshape = (N, Hl, Wl, Cout) if form == emu.Q_POOL else (N, 2 * Hl, 2 * Wl, Cout)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    mask = emu.to_bf16(rng.standard_normal(oshape).astype(np.float32))
+    res = emu.to_bf16(rng.standard_normal(oshape).astype(np.float32))
+    outs = {}
+    for tag, env in (("256", {"SG_CONV_Q_BJ": "256"}), ("512", {"SG_CONV_Q_BJ": "5f"}), ("512+halo1", {"SG_CONV_Q_BJ": "5f", "SG_CONV_Q_LA3": "3"})):
+        for seed in (1, 2):
+            emu.config(cq, dma_late=1, greedy=1, seed=seed)
+            c0 = emu.counters(cq)
+            outs[(tag, seed)] = emu.conv_q(cq, form, x, wq, Cout, relu_in=True, bias=bias, mask=mask, res=res, alpha=0.5, env=dict(env, SG_CONV_Q_DB="0")).copy()
+            blocks = emu.counters(cq)["blocks"] - c0["blocks"]
+            if seed == 1:
+                outs[(tag, "blocks")] = blocks
+    assert outs[("512", "blocks")] < outs[("256", "blocks")]          # the 512-pixel instantiation ran
+    ref = outs[("256", 1)]
+    for k, v in outs.items():
+        if k[1] != "blocks":
+            assert np.array_equal(v, ref), k

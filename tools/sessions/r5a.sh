@@ -36,6 +36,12 @@ for f in 0 3 1 2 1p 2p; do      # 0: shipped loop, 3: one-sided patch halo (-8 %
   pr=0; case $f in *p) pr=1;; esac
   ( SG_MFMA_PRIO=$pr SG_CONV_Q_LA3=${f%p} timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_la3_$f.txt 2>&1; tail -6 $O/quad_bench_la3_$f.txt | cut -c1-200
 done
+# 3b'. conv_q.h with 512-pixel tiles (SG_CONV_Q_BJ=512: -35 % staged bytes per MFMA at two workgroups per CU), alone and with the one-sided halo
+( SG_CONV_Q_BJ=5f timeout 300 python -m pytest tests/test_quad_gpu.py -q -p no:cacheprovider -k "conv_q and not wgrad" 2>&1 | tail -3 ) > $O/pytest_bj512.txt 2>&1; cat $O/pytest_bj512.txt | cut -c1-200
+for cfg in "SG_CONV_Q_BJ=512" "SG_CONV_Q_BJ=512 SG_CONV_Q_LA3=3"; do
+  tag=$(echo "$cfg" | tr ' =' '__')
+  ( env $cfg timeout 300 python tools/quad_bench.py --batch 256 2>&1 ) > $O/quad_bench_$tag.txt 2>&1; tail -6 $O/quad_bench_$tag.txt | cut -c1-200
+done
 # 3c. conv_v4.h with four weight buffers / three taps ahead (SG_CONV_V4_LA3=1) where three workgroups still fit a CU
 ( SG_CONV_V4_LA3=1 timeout 300 python -m pytest tests/test_conv_v2_gpu.py -q -p no:cacheprovider -k "conv_v4 or fused_skip" 2>&1 | tail -3 ) > $O/pytest_v4la3.txt 2>&1; cat $O/pytest_v4la3.txt | cut -c1-200
 for f in 0 1 1p; do
