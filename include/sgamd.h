@@ -344,6 +344,9 @@ int sg_masked_sum_hw(int dtype, const void* t, const void* x, float* out, int B,
 int sg_attn_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
 /* fused forward of the attention core: O = softmax(theta phi^T) g per image in one launch (probabilities stored only when P != NULL) */
 int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg);
+/* the P == NULL form streams keys and values in 256-key chunks: no bound on HW4 (16384 queries x 4096 keys of BigGAN-deep-256's D,
+ * reference models/big_resnet_deep_legacy.py:80-95); sg_attn_fwd_fused accepts P == NULL whenever this returns 1 */
+int sg_attn_fwd_flash_ok(int B, int HW, int HW4, int Dp, int Cg);
 int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, float* O32, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s);
 /* fused backward of the attention core: dtheta, dphi, dg from theta / phi / g / dO / lse with P and dS recomputed on the fly (two launches:
  * query side + key side); delta = fp32 scratch [B][HW]. O32 = the unrounded fp32 copy of the forward output [B][HW][Cg] that

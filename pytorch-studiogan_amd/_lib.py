@@ -148,6 +148,7 @@ _PROTOS = {
     "sg_bn_bwd2_apply": [_i, _vp, _vp, _vp, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _vp, C.c_double, _i, _vp],
     "sg_attn_fused_ok": [_i, _i, _i, _i, _i],
     "sg_attn_fwd_fused_ok": [_i, _i, _i, _i, _i],
+    "sg_attn_fwd_flash_ok": [_i, _i, _i, _i, _i],
     "sg_attn_fwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_attn_bwd_fused_ok": [_i, _i, _i, _i, _i],
     "sg_attn_bwd_fused": [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp],

@@ -576,11 +576,18 @@ extern "C" int sg_attn_fwd_fused_ok(int B, int HW, int HW4, int Dp, int Cg) {
   const int ncg = (Cg + 31) / 32;
   return (at_ok(B, HW, HW4, Dp) && Cg % 8 == 0 && Cg >= 8 && Cg <= 128 && HW4 * 64 + ncg * 16384 <= 160 * 1024) ? 1 : 0;
 }
+// the P == NULL form of sg_attn_fwd_fused (k_attn_fwd_flash) streams keys AND values in 256-key chunks: (1 + ncg) * 16 KiB of LDS whatever HW4 is
+// (BigGAN-deep-256's discriminator attends over 128 x 128 = 16384 queries x 4096 keys: reference src/models/big_resnet_deep_legacy.py:80-95)
+extern "C" int sg_attn_fwd_flash_ok(int B, int HW, int HW4, int Dp, int Cg) {
+  return (at_ok(B, HW, HW4, Dp) && Cg % 8 == 0 && Cg >= 8 && Cg <= 128) ? 1 : 0;
+}
 // O = softmax(theta phi^T) g in one launch; P == NULL: the probabilities are not stored (no backward will ask for them)
 extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void* g, void* P, float* lse, void* O, float* O32, int B, int HW, int HW4, int Dp, int Cg, sg_stream_t s) {
   SG_CHECK(theta && phi && g && lse && O, "sg_attn_fwd_fused: null");
   SG_CHECK(!(P && O32), "sg_attn_fwd_fused: the fp32 copy of O belongs to the path that does not store P");
-  SG_CHECK(sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1, "sg_attn_fwd_fused: unsupported shape");
+  static const bool two_pass = [] { const char* e = getenv("SG_ATTN_FLASH"); return e && e[0] == '0'; }();    // A/B switch: the first fused forward
+  const bool flash = !P && !(two_pass && !O32);
+  SG_CHECK((flash ? sg_attn_fwd_flash_ok(B, HW, HW4, Dp, Cg) : sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg)) == 1, "sg_attn_fwd_fused: unsupported shape");
   const int ncg = (Cg + 31) / 32;
   const int lds = HW4 * 64 + ncg * 16384;
   SgProfScope prof((hipStream_t)s, (double)B * HW * ((P ? (double)HW4 * 2.0 : 0.0) + (Dp + Cg) * 2.0 + 4.0) + (double)B * HW4 * (Dp + Cg) * 2.0, 5);
@@ -598,9 +605,8 @@ extern "C" int sg_attn_fwd_fused(const void* theta, const void* phi, const void*
     if (!done) { SG_CHECK(hipFuncSetAttribute((const void*)k_attn_fwd_flash<N>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) == hipSuccess, "sg_attn_fwd_fused: LDS attribute"); done = true; } \
     hipLaunchKernelGGL((k_attn_fwd_flash<N>), grid, blk, (1 + N) * 16384, st, (const bf16_t*)theta, (const bf16_t*)phi, (const bf16_t*)g, lse, (bf16_t*)O, O32, HW, HW4, Dp, Cg); \
   }
-  static const bool two_pass = [] { const char* e = getenv("SG_ATTN_FLASH"); return e && e[0] == '0'; }();    // A/B switch: the first fused forward
   if (P) { if (ncg == 1) ATF_LAUNCH(1, true) else if (ncg == 2) ATF_LAUNCH(2, true) else if (ncg == 3) ATF_LAUNCH(3, true) else ATF_LAUNCH(4, true) }
-  else if (two_pass && !O32) { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
+  else if (!flash) { if (ncg == 1) ATF_LAUNCH(1, false) else if (ncg == 2) ATF_LAUNCH(2, false) else if (ncg == 3) ATF_LAUNCH(3, false) else ATF_LAUNCH(4, false) }
   else { if (ncg == 1) ATL_LAUNCH(1) else if (ncg == 2) ATL_LAUNCH(2) else if (ncg == 3) ATL_LAUNCH(3) else ATL_LAUNCH(4) }
 #undef ATL_LAUNCH
 #undef ATF_LAUNCH

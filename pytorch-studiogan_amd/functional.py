@@ -1229,13 +1229,18 @@ class AttnCoreFn(torch.autograd.Function):
         L.call("sg_maxpool2_fwd", sd, L.ptr(phi_full), Dp, L.ptr(phi), Dp, L.ptr(idx_phi), B, H, W, Dp, L.stream())
         L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
         fused = T == torch.bfloat16 and L.lib().sg_attn_fused_ok(B, HW, HW4, Dp, Cg) == 1
-        fused_fwd = fused and L.lib().sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
+        # the bf16 probabilities are written only when a backward can come that needs them (they feed dg = P^T dO): never for the no-grad generator
+        # forwards of the discriminator update, nor when the backward recomputes them itself (sg_attn_bwd_fused: no P and no dS in HBM at all)
+        need_p = any(ctx.needs_input_grad) and L.lib().sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) != 1
+        if need_p:
+            fused_fwd = fused and L.lib().sg_attn_fwd_fused_ok(B, HW, HW4, Dp, Cg) == 1
+        else:
+            # keys and values streamed in 256-key chunks: no bound on the number of keys (16384 x 4096 scores per image in BigGAN-deep-256's D,
+            # reference src/models/big_resnet_deep_legacy.py:80-95, never exist in HBM)
+            fused_fwd = T == torch.bfloat16 and L.lib().sg_attn_fwd_flash_ok(B, HW, HW4, Dp, Cg) == 1
         lse = o32 = None
         if fused_fwd:
-            # one launch: scores, softmax and the product with the pooled values; the bf16 probabilities are written only when a backward
-            # can come (they feed dg = P^T dO), never for the no-grad generator forwards of the discriminator update
-            # ... nor when the backward recomputes them itself (sg_attn_bwd_fused: no P and no dS in HBM at all)
-            need_p = any(ctx.needs_input_grad) and L.lib().sg_attn_bwd_fused_ok(B, HW, HW4, Dp, Cg) != 1
+            # one launch: scores, softmax and the product with the pooled values
             P = torch.empty((B, HW, HW4), dtype=T, device=dev) if need_p else None
             lse = torch.empty((B, HW), dtype=torch.float32, device=dev)
             o = torch.empty((B, H, W, Cg), dtype=T, device=dev)

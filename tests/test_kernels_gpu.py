@@ -339,13 +339,22 @@ def test_softmax_pool_misc(sg, dtype):
 
 
 @pytest.mark.parametrize("dtype", DT)
-@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 4, 16), (3, 32, 32, 24, 24, 96), (2, 32, 32, 16, 12, 48), (2, 64, 32, 32, 32, 40)])
-def test_attention_core(sg, dtype, shape):
+@pytest.mark.parametrize("shape", [(2, 8, 8, 8, 4, 16), (3, 32, 32, 24, 24, 96), (2, 32, 32, 16, 12, 48), (2, 64, 32, 32, 32, 40), (1, 128, 128, 32, 32, 128)])
+def test_attention_core(sg, dtype, shape, monkeypatch):
     """AttnCoreFn = maxpool + QK^T + softmax + PV and its backward vs the reference formulation (utils/ops.py:83-100).
-    The 32x32 / 64x32 shapes take the fused score kernels of csrc/attn.hip in bf16 (G: 24 -> 96 channels, D: 12(16) -> 48)."""
-    from studiogan_amd import functional as F
+    The 32x32 / 64x32 shapes take the fused score kernels of csrc/attn.hip in bf16 (G: 24 -> 96 channels, D: 12(16) -> 48); the 128 x 128 one is
+    BigGAN-deep-256's discriminator attention (16384 queries x 4096 keys, 32 -> 128 channels; reference src/models/big_resnet_deep_legacy.py:80-95):
+    keys and values streamed through LDS, forward and both backward kernels -- no score matrix in HBM."""
+    from studiogan_amd import functional as F, _lib as L
     d = dev()
     B, H, W, Dp, Dv, Cg = shape
+    if H * W > 8192:
+        if dtype == torch.float32:
+            pytest.skip("the 16384-query shape is the bf16 streaming path's case")
+        assert L.lib().sg_attn_fwd_flash_ok(B, H * W, H * W // 4, Dp, Cg) == 1 and L.lib().sg_attn_bwd_fused_ok(B, H * W, H * W // 4, Dp, Cg) == 1
+        calls = []
+        orig = L.call
+        monkeypatch.setattr(L, "call", lambda name, *a: (calls.append(name), orig(name, *a))[1])
     tol = 5e-4 if dtype == torch.float32 else 3e-2
     th = rnd((B, Dp, H, W), dtype, 61, 0.5); th[:, Dv:] = 0
     ph = rnd((B, Dp, H, W), dtype, 62, 0.5); ph[:, Dv:] = 0
@@ -366,6 +375,8 @@ def test_attention_core(sg, dtype, shape):
     check("attn dtheta", nchw(thd.grad.float().cpu())[:, :Dv], thr.grad[:, :Dv], tol)
     check("attn dphi", nchw(phd.grad.float().cpu())[:, :Dv], phr.grad[:, :Dv], tol)
     check("attn dg", nchw(gd.grad.float().cpu()), gr.grad, tol)
+    if H * W > 8192:
+        assert "sg_attn_fwd_fused" in calls and "sg_attn_bwd_fused" in calls and "sg_gemm" not in calls and "sg_softmax_rows" not in calls, calls
 
 
 def test_head_losses_embedding(sg):
