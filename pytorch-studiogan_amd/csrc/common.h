@@ -13,13 +13,11 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(4))) short s16x4;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-// SG_MFMA_PRIO=1 (A/B switch of the round-4 kernel variants that have not run on a GPU yet; read per launch): `s_setprio 1` around their MFMA clusters. Three
-// workgroups share a CU in different phases (one in its MFMA cluster while another issues LDS-DMA / waits at its barrier): the case in which the hint keeps the
-// matrix pipe fed (cdna_hip_programming.md T5: +21-25 % on a phase-split GEMM, ~0 on a lockstep one). A kernel argument, not a template parameter: scalar branch.
-#include <stdlib.h>
-static inline int sg_mfma_prio_env() { const char* e = getenv("SG_MFMA_PRIO"); return (e && e[0] == '1') ? 1 : 0; }
-#define SG_PRIO_UP(flag) do { if (flag) __builtin_amdgcn_s_setprio(1); } while (0)
-#define SG_PRIO_DOWN(flag) do { if (flag) __builtin_amdgcn_s_setprio(0); } while (0)
+// `s_setprio 1` around the MFMA clusters of the lean weight-gradient kernels (wgrad_ql.h, wgrad_v3l.h): their workgroups share a CU in different phases (one in
+// its MFMA cluster while another issues its LDS-DMA or sits at its barrier), the structure cdna_hip_programming.md T5 prices the hint for. Measured in round 5
+// (same box, profiles/r05_variant_ab_layer_tables_b.txt): -1.0 % / -1.7 % on the two weight-gradient layer tables, -0.7 ms on the C3 step: always on.
+#define SG_PRIO_UP() __builtin_amdgcn_s_setprio(1)
+#define SG_PRIO_DOWN() __builtin_amdgcn_s_setprio(0)
 
 #define SG_DTYPE_F32 0
 #define SG_DTYPE_BF16 1

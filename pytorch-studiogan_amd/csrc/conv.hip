@@ -52,17 +52,12 @@ template <> bool conv_fwd_v2_try<bf16_t>(const sg_conv_fwd_desc* d, const Epilog
     // no candidate divides the cout count (InceptionV3: 32 / 48 / 64 / 160 / 224 / 320 / 448 couts): take the one that pads least -- the kernel
     // zero-fills weight rows >= I and its epilogue stores only the 16-byte chunks that exist. Up to 50 % padding still beats the generic
     // engine these layers ran on (17 % of the FID leg at ~150 us per launch, profiles/r02_fid_leg_kerneltrace.txt).
-    // SG_CONV_V2_PAD_TILES=1 (A/B switch, round 4, not measured yet): among the candidates that pad equally take the one with MORE tiles -- 160 couts pad
-    // to 192 with the 192-wide tile (145 tiles at 17 x 17, batch 128: under the tile-count floor below, so the layer ran on the generic engine) and
-    // with the 96-wide one (290 tiles): InceptionV3's c7 = 160 1x7 / 7x1 layers (reference src/metrics/inception_net.py:135-249).
-    const char* pt = getenv("SG_CONV_V2_PAD_TILES");
-    const bool more_tiles = pt && pt[0] == '1';
     int best_pad = 0;
     for (int c = 0; c < 3; c++) {
       const int padded = ((I + cands[c] - 1) / cands[c]) * cands[c];
       if (2 * padded > 3 * I) continue;
       const int tiles = (padded / cands[c]) * tj;
-      if (!best || padded < best_pad || (more_tiles && padded == best_pad && tiles > best_tiles)) { best = cands[c]; best_pad = padded; best_tiles = tiles; }
+      if (!best || padded < best_pad) { best = cands[c]; best_pad = padded; best_tiles = tiles; }
     }
   }
   // tile-count floor: below it the chip is too empty for this kernel's one workgroup per CU. SG_CONV_V2_MIN_TILES=<n> moves it (A/B switch: 128-cout

@@ -46,13 +46,7 @@ struct ConvQParams {
   unsigned x2bytes, w2bytes;
   float* stats;           // optional [tilesJ * nph][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue)
 };
-// the LA3 / PAIR instantiations take one more argument (the shipped instantiations keep their kernel-argument layout, hence their code, as it was)
-struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 
-// TJW = 4 (round 4, written without GPU time: SG_CONV_Q_BJ=512, default off): 512-pixel tiles -- 12 accumulator blocks per wave, two workgroups per CU, the result staged
-// in two halves like conv_v4.h's 512-pixel tile. A weight tile then serves twice the pixels: 62-66 KB staged per 384 MFMAs instead of 45-50 per 192 (-35 % per
-// MFMA). conv_v4.h's own 512-pixel tile ran no faster than its 256-pixel one in round 2; whether conv_q, with its four-tap slices, differs is for the A/B
-// that HALO1 opens (does the time follow the staged bytes?). Not with the fused skip.
 // TJW = 32-pixel blocks per wave: 2 (tile of 256 low-resolution pixels) or 1 (128: twice the workgroups for the layers whose whole low-resolution
 // grid is a few thousand positions -- the 1536-channel 8 x 8 -> 4 x 4 tail has 256 tiles of 256 x 96 at batch 256, one per CU where three fit)
 //
@@ -71,24 +65,13 @@ struct ConvQParamsP : ConvQParams { int prio; };    // prio: SG_MFMA_PRIO
 // vmcnt(2 n_w) behind tap 3 (P' and W0' have landed). NPMIN = the smallest number of patch pieces a wave issues (compile-time immediate;
 // waves with one piece more only wait a little earlier than they must).
 //
-// NPMIN == -3 ("HALO1", round 4, written without GPU time: SG_CONV_Q_LA3=3, default off): the shipped loop with a patch of BJ + Wl + 16 pixels instead of BJ + 2 Wl + 16 --
-// the four taps of a view reach to one side only (wgrad_q.h already stages its patches that way). 16 % fewer patch bytes at Wl = 64 (8 % of everything the kernel
-// stages), nothing else changes: the cleanest test of whether the LDS-DMA ingest rate (10-11 B / clk / CU in every halo kernel of this tree) is what bounds them.
-// NPMIN == -2 ("PAIR", round 4, written without GPU time: SG_CONV_Q_LA3=2, default off): the four taps of a slice as two PAIRS -- a pair's two weight tiles are
-// requested one pair ahead (the same 24 MFMAs per wave of distance as the shipped two-taps-ahead scheme) and the workgroup synchronises once per pair
-// instead of once per tap: half the barriers and half the counted waits, every wait a plain vmcnt(0). Against LA3 this separates "the barriers cost" from
-// "the tile's latency costs" in one A/B.
-// NPMIN == -1 ("LA3", round 4, written without GPU time: SG_CONV_Q_LA3=1, default off): the single-buffered loop (three workgroups per CU) with the weights
-// THREE taps ahead instead of two. If the per-tap wait is the weight tile's DMA latency (a tap is 12 MFMAs per wave = 384 clk of its matrix pipe; a tile
-// requested two taps earlier has ~2 x 1152 clk at full rate to arrive), one more tap of lookahead costs nothing: the fourth buffer is free as soon as the
-// barrier that ends the previous tap has been passed. The double-buffered variant above already runs three ahead but pays for its second patch with
-// a workgroup per CU. Checked on the CPU interpreter (late DMA completion, seeded wave order): tests/test_hipemu_cpu.py.
+// Measured and removed in round 5 (profiles/r05_variant_ab_layer_tables_b.txt, same box, the ten quad layers of C3): weights three taps ahead in the
+// single-buffered loop (+1.2 %), the four taps of a slice as two pairs with one barrier per pair (+-0), a one-sided patch halo (-8 % staged bytes: -0.7 %,
+// inside the box noise, 0 on the step), 512-pixel tiles at two workgroups per CU (+3.4 % / +7.4 %). Neither the weight tile's latency, nor the barrier
+// count, nor the bytes staged per MFMA bound this loop.
 template <int NB, bool RELU, int TJW = 2, bool SKIP = false, int NPMIN = 0>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 || TJW == 4) ? 2 : 3, (NPMIN > 0 || TJW == 4) ? 2 : 3))) void sg_conv_q_kernel(typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ? 2 : 3, NPMIN > 0 ? 2 : 3))) void sg_conv_q_kernel(ConvQParams p, Epilogue<bf16_t> epi, int tilesI, int tilesJ, int nph) {
   constexpr bool DB = NPMIN > 0;
-  constexpr bool LA3 = NPMIN == -1;         // single-buffered patch, weights THREE taps ahead (see above)
-  constexpr bool PAIR = NPMIN == -2;        // single-buffered patch, taps in PAIRS: one barrier per two taps (see above)
-  constexpr bool HALO1 = NPMIN == -3;       // the shipped loop with a ONE-sided patch halo (see above)
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -134,10 +117,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
   const int pix0 = P0 + 16 * wave + sub;
   auto patch_slice = [&](int view, int s, int pbase = 0) {
     const int vadd = pool ? ((view >> 1) * 2 * p.Wl + (view & 1)) : 0;
-    // HALO1: the four taps of a view reach to ONE side (row offsets {-ea, 1 - ea} of the low-resolution grid): its patch starts ea rows, not one row, above the tile
-    const int vsh = HALO1 ? (1 - (pool ? (view >> 1) : 1 - (view >> 1))) * p.Wl : 0;
     for (int g = wave; g < ngroups; g += NW) {
-      const int pix = pix0 + vsh + 16 * (g - wave);
+      const int pix = pix0 + 16 * (g - wave);
       // POOL: view pixel -> fine pixel; out-of-range low-resolution indices (tile halo beyond the tensor) read zeros
       const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
       unsigned off = src * ldxb + (unsigned)(s * 64 + lc * 16);
@@ -173,7 +154,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
           if ((unsigned)(ho - 1 + rr) < (unsigned)(1 << p.hlog) && (unsigned)(wo - 1 + ss) < (unsigned)p.Wl) m |= 1u << (rr * 3 + ss);
     }
     qval[b] = m;
-    rb[b] = HALO1 ? row - (j0 - 8) : row - P0;                         // (HALO1: relative to the tile; the view's row shift cancels against its tap origin)
+    rb[b] = row - P0;
   }
   // weight fragment addresses: row = cout a * 32 + frow, chunk (ks * 2 + fhi) ^ (row >> 2 & 3); ks = 1 is the address ^ 32
   unsigned wa[TI];
@@ -200,7 +181,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
   patch_slice(view, 0);
   weight_tile(0, view, 0, 0);
   weight_tile(1, view, 0, 1);
-  if (DB || LA3) weight_tile(2, view, 0, 2);       // (PAIR: taps 2, 3 are requested at the first tap of the loop)
+  if (DB) weight_tile(2, view, 0, 2);
   __syncthreads();
   for (int vs = 0; vs < nvs; vs++) {
     const bool next_slice = vs + 1 < nvs;
@@ -210,21 +191,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
     // tap origin of this view on the low-resolution grid
     const int ea = pool ? (view >> 1) : 1 - (view >> 1);
     const int eb = pool ? (view & 1) : 1 - (view & 1);
-    const int org = HALO1 ? -eb : -ea * p.Wl - eb;                   // patch-row displacement of tap (0, 0)
+    const int org = -ea * p.Wl - eb;                                 // patch-row displacement of tap (0, 0)
     const int vbit0 = (1 - ea) * 3 + (1 - eb);                       // validity bit of tap (0, 0)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
-      const bool issue = LA3 ? (t == 0 || next_slice) : ((t + 2 < 4) || next_slice);
-      if constexpr (PAIR) {
-        // buffers 2, 3 were read during the previous slice's second pair, buffers 0, 1 during this slice's first pair: every wave is past the barrier since
-        if (t == 0) { weight_tile(2, view, s, 2); weight_tile(3, view, s, 3); }
-        else if (t == 2 && next_slice) { weight_tile(0, nview, ns, 0); weight_tile(1, nview, ns, 1); }
-      } else if constexpr (LA3) {
-        // buffer (t + 3) % 4 = (t - 1) % 4 was read during the previous tap, and every wave is past the barrier that ended it
-        if (t == 0) weight_tile(3, view, s, 3);
-        else if (next_slice) weight_tile(t - 1, nview, ns, t - 1);
-      } else if constexpr (DB) {
+      const bool issue = (t + 2 < 4) || next_slice;
+      if constexpr (DB) {
         if (t == 0) {
           weight_tile(3, view, s, 3);
           if (next_slice) patch_slice(nview, ns, ((vs + 1) & 1) * p.patchb);
@@ -262,13 +235,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
           if (RELU) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
-        if constexpr (LA3 || PAIR) SG_PRIO_UP(p.prio);
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
-        if constexpr (LA3 || PAIR) SG_PRIO_DOWN(p.prio);
       }
       if constexpr (DB) {
         // counted waits (see the kernel comment): n_w = 2 for the waves that issue two weight pieces per tap, else 1
@@ -287,15 +258,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
         __syncthreads();
         patch_slice(nview, ns);
         __syncthreads();
-      } else if constexpr (PAIR) {
-        // no barrier inside a pair; behind a pair everything in flight is the next pair's two tiles
-        if (t == 1 || t == 3) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); }
-      } else if constexpr (LA3) {
-        // the weights of tap t + 1 must have landed; behind them at most the tiles of taps t + 2 and t + 3 are in flight (n_w pieces each per wave)
-        if (next_slice || t == 0) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else if (t == 1) { if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
       } else {
         if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -374,18 +336,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu((NPMIN > 0 
 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
-  if constexpr (TJW == 4) {
-    // 512-pixel tile, 256-row staging area (conv_v4.h's scheme): waves 0, 1 then waves 2, 3; the statistics rows are those of the 256-pixel tiling
-    float* const st1 = (j0 + 256 < p.J) ? p.stats : nullptr;
-    if (pool) {
-      sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2, 0, 0, p.stats, p.I, 2 * tJ);
-      sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2, 0, 0, st1, p.I, 2 * tJ + 1);
-    } else {
-      const int vadd = (ph >> 1) * 2 * p.Wl + (ph & 1);
-      sg_conv_epilogue<BI, 256, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2, p.wlog, vadd, p.stats, p.I, (2 * tJ) * nph + ph);
-      sg_conv_epilogue<BI, 256, NW, TI, TJ, true>(acc, smem, sbias, epi, i0, j0 + 256, 0, wj0 - 256, al, wave >= 2, p.wlog, vadd, st1, p.I, (2 * tJ + 1) * nph + ph);
-    }
-  } else if (pool) {
+  if (pool) {
     sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
   } else {
     // UP: output / mask / residual rows go through the view of this workgroup's phase
@@ -399,7 +350,7 @@ static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, bool db, int
   const int BI = 32 * NB;
   const int woff = npx * 64 * (db ? 2 : 1);
   const int ops = woff + 4 * BI * 64;
-  const int stage = (BJ > 256 ? 256 : BJ) * (BI * 2 + 16);      // (512-pixel tiles stage their result in two halves)
+  const int stage = BJ * (BI * 2 + 16);
   const int skp = skip ? 2 * BJ * 64 + 2 * BI * 64 : 0;      // two staging slots of the fused skip (patch + weights each)
   int body = ops > stage ? ops : stage;
   if (skp > body) body = skp;
@@ -411,10 +362,7 @@ static inline int sg_conv_q_lds(int NB, int BJ, int npx, bool skip, bool db, int
 template <int NB, bool RELU, int TJW, bool SKIP, int NPMIN>
 static inline int sg_launch_conv_qr(const ConvQParams& p0, const Epilogue<bf16_t>& e, hipStream_t st) {
   constexpr int BI = 32 * NB, BJ = 128 * TJW;
-  typename std::conditional<(NPMIN < 0), ConvQParamsP, ConvQParams>::type p;
-  static_cast<ConvQParams&>(p) = p0;
-  if constexpr (NPMIN < 0) p.prio = sg_mfma_prio_env();
-  if constexpr (NPMIN == -3) p.npx = ((p.bj + p.Wl + 16) + 15) & ~15;      // one-sided halo
+  ConvQParams p = p0;
   p.patchb = p.npx * 64;
   const int lds = sg_conv_q_lds(NB, BJ, p.npx, SKIP, NPMIN > 0, &p.wgt_off, &p.zero_off, &p.bias_off);
   if (lds > 80 * 1024) return -1;
@@ -430,10 +378,6 @@ static inline int sg_launch_conv_qr(const ConvQParams& p0, const Epilogue<bf16_t
 template <int NB, bool SKIP, bool RELU>
 static inline int sg_launch_conv_qd(const ConvQParams& p, const Epilogue<bf16_t>& e, int db, hipStream_t st) {
   if (p.bj == 128) return sg_launch_conv_qr<NB, RELU, 1, SKIP, 0>(p, e, st);
-  if constexpr (!SKIP) { if (p.bj == 512) return db == 4 ? sg_launch_conv_qr<NB, RELU, 4, false, -3>(p, e, st) : sg_launch_conv_qr<NB, RELU, 4, false, 0>(p, e, st); }
-  if (db == 2) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -1>(p, e, st);      // LA3
-  if (db == 3) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -2>(p, e, st);      // PAIR
-  if (db == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, -3>(p, e, st);      // HALO1
   if (db) {       // double-buffered patch: the smallest per-wave piece count is a compile-time immediate of the counted waits
     const int npmin = (p.npx >> 4) >> 2;
     if (npmin == 4) return sg_launch_conv_qr<NB, RELU, 2, SKIP, 4>(p, e, st);

@@ -193,7 +193,7 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
     const int nph = d->form == SG_Q_POOL ? 1 : 4;
     const long long tiles256 = (long long)(d->Cout / (32 * NB)) * ((J + 255) / 256) * nph;
     p.bj = tiles256 < 512 ? 128 : 256;
-    if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; else if (bj[0] == '5' && !d->x2 && (tiles256 >= 1024 || bj[1] == 'f')) p.bj = 512; }      // 512 (5f: whatever the tile count, tests): A/B switch, not run on a GPU yet
+    if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; }
   }
   p.npx = ((p.bj + 2 * d->Wl + 16) + 15) & ~15;
   p.flags = d->pix_flags;
@@ -246,9 +246,6 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   // pure weight streaming: default on there only. SG_CONV_Q_DB=1 / 0 forces it on / off (read per call: the tests switch it).
   const char* ev_db = getenv("SG_CONV_Q_DB");
   int db_mode = ev_db ? (ev_db[0] == '1' ? 1 : 0) : ((d->Wl == 4 && d->form == SG_Q_UP) ? 1 : 0);
-  // SG_CONV_Q_LA3=1 (A/B switch, not run on a GPU yet): weights three taps ahead in the single-buffered loop (conv_q.h NPMIN < 0) wherever the
-  // double-buffered variant is not the choice
-  if (const char* la = getenv("SG_CONV_Q_LA3")) { if (db_mode == 0) db_mode = la[0] == '1' ? 2 : (la[0] == '2' ? 3 : (la[0] == '3' ? 4 : 0)); }      // 2: the PAIR loop, 3: one-sided patch halo
   const int rc = NB == 3 ? sg_launch_conv_q<3>(p, e, db_mode, st) : sg_launch_conv_q<2>(p, e, db_mode, st);
   {
     // algorithmic HBM bytes: input (+ skip input), quad filter(s), result (+ mask / residual), bf16
@@ -371,9 +368,10 @@ extern "C" int sg_conv2d_q_wgrad(const sg_convq_wgrad_desc* d, sg_stream_t strea
   p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
   const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)K * 9.0 * (double)d->C, 1);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)K * 16.0 * (double)d->C);
-  // SG_WGRAD_Q_LEAN=1: the lean variant (wgrad_ql.h) -- A/B switch, read per call; off until it has run on a GPU
+  // the lean kernel (wgrad_ql.h; round 5, same box: the ten quad layers of C3 6.29 -> 5.00 ms, profiles/r05_variant_ab_layer_tables_b.txt).
+  // SG_WGRAD_Q_LEAN=0 (read per call) selects the round-4 kernel it replaced: the bit-identity reference of tests/test_quad_gpu.py
   const char* lean = getenv("SG_WGRAD_Q_LEAN");
-  const int rc = (lean && (lean[0] == '1' || lean[0] == '2')) ? sg_launch_wgrad_ql(p, s.NB, s.S, st, lean[0] == '2') : sg_launch_wgrad_q(p, s.NB, s.S, st);      // 2: + the register pipeline
+  const int rc = (lean && lean[0] == '0') ? sg_launch_wgrad_q(p, s.NB, s.S, st) : sg_launch_wgrad_ql(p, s.NB, s.S, st);
   if (rc == 0) {
     const bool pl = d->form == SG_Q_POOL;
     const int cb = d->C > 64 ? (d->C + 63) / 64 : 1;

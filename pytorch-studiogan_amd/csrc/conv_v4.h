@@ -42,8 +42,6 @@ struct ConvV4Params {
   unsigned x2bytes, w2bytes;
   float* stats;           // optional [tilesJ][I][2]: per-tile batch-norm statistics of the result (sg_conv_epilogue), 256-pixel tiles only
 };
-// the NWB = 4 instantiations take one more argument (the shipped instantiations keep their kernel-argument layout, hence their code, as it was)
-struct ConvV4ParamsP : ConvV4Params { int prio; };  // prio: SG_MFMA_PRIO
 
 // TJW = 32-pixel blocks per wave: 2 (tile 256 pixels, 6 accumulator blocks per wave for NB = 3, three workgroups per CU) or 4 (tile 512 pixels,
 // 12 accumulator blocks: 7 fragment reads per 12 MFMAs instead of 5 per 6, two workgroups per CU; the staged epilogue runs in two halves)
@@ -55,12 +53,10 @@ struct ConvV4ParamsP : ConvV4Params { int prio; };  // prio: SG_MFMA_PRIO
 // pixels (no halo) is staged there (one source pixel per 2 x 2 outputs with up2) next to its 32 NB x 32 weights. This removes the skip's
 // launch, its read-modify-write of the block output and the 1x1 kernel's tile overheads.
 //
-// NWB = 4 ("LA3", round 4, written without GPU time: SG_CONV_V4_LA3=1, default off): FOUR weight buffers, weights THREE taps ahead. A tap is 4 NB MFMAs
-// per wave (384 clk of its matrix pipe for NB = 3); if the counted wait in front of a tap's barrier is the DMA latency of a tile requested two taps
-// earlier, a third tap of lookahead hides more of it at the price of one more 2 NB KB buffer -- taken only where the operand area still fits under
-// the staged epilogue (W <= 64 for NB = 3), so that three workgroups keep sharing a CU. The buffer of tap g (counted across slices) is g % 4.
-template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int NWB = 3>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(typename std::conditional<(NWB == 4), ConvV4ParamsP, ConvV4Params>::type p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
+// Measured and removed in round 5 (profiles/r05_variant_ab_layer_tables_b.txt): a fourth weight buffer with the tiles three taps ahead -- +1.0 % on the layer
+// table: the counted wait in front of a tap's barrier is not the weight tile's latency.
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   static_assert(!SKIP || (!UP && TJW == 2), "the fused skip is built for the plain 256-pixel tile");
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
@@ -180,24 +176,21 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   // two pieces per tap, the others one.
   const int nslice = p.nslice;
   const bool two = wave + NW < NWP;                                  // this wave issues two weight pieces per tap
-  constexpr int LA = NWB - 1;                                        // taps of lookahead
-  static_assert(NWB == 3 || NWB == 4, "three or four weight buffers");
+  constexpr int LA = 2;                                              // taps of lookahead (three weight buffers)
   patch_slice(0);
   weight_tile(0, 0, 0);
   weight_tile(1, 0, 1);
-  if (NWB == 4) weight_tile(2, 0, 2);
   __syncthreads();
   for (int s = 0; s < nslice; s++) {
     const bool next_slice = s + 1 < nslice;
-    const int g0 = NWB == 4 ? (s * 9) & 3 : 0;                       // buffer of this slice's tap 0 (9 % 3 == 0: the three-buffer ring restarts every slice)
 #pragma unroll
     for (int t = 0; t < 9; t++) {
-      // weights LA taps ahead: buffer (g + LA) % NWB = (g - 1) % NWB was read during the previous tap, every wave is past its barrier
+      // weights LA taps ahead: buffer (t + LA) % 3 = (t - 1) % 3 was read during the previous tap, every wave is past its barrier (9 % 3 == 0: the ring restarts every slice)
       const bool issue = (t + LA < 9) || next_slice;
-      const int ibuf = NWB == 4 ? (g0 + t + LA) & 3 : (t + LA) % 3;
+      const int ibuf = (t + LA) % 3;
       if (t + LA < 9) weight_tile(ibuf, s, t + LA);
       else if (next_slice) weight_tile(ibuf, s + 1, t + LA - 9);
-      const char* ps = pbufs + (NWB == 4 ? (g0 + t) & 3 : t % 3) * PB;
+      const char* ps = pbufs + (t % 3) * PB;
       const int tr = t / 3, ts = t % 3;                          // compile-time after unrolling
       unsigned qa[TJ];
 #pragma unroll
@@ -234,13 +227,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
           if (RELU) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
-        if constexpr (NWB == 4) SG_PRIO_UP(p.prio);
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
-        if constexpr (NWB == 4) SG_PRIO_DOWN(p.prio);
       }
       if (t == 8 && next_slice) {
         // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
@@ -248,13 +239,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
         __syncthreads();
         patch_slice(s + 1);
         __syncthreads();
-      } else if constexpr (NWB == 4) {
-        // the weights of tap t + 1 must have landed; behind them the tiles of taps t + 2 and t + 3 are in flight where those taps exist
-        const bool e2 = (t + 2 < 9) || next_slice, e3 = (t + 3 < 9) || next_slice;
-        if (e2 && e3) { if (two) asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); }
-        else if (e2) { if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); }
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
       } else {
         if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
@@ -363,11 +347,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
 }
 
 // LDS need (bytes) of a configuration
-static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off, int skip_patch_bytes = 0, int nwb = 3) {
+static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, int* bias_off, int skip_patch_bytes = 0) {
   const int BI = 32 * NB;
   // (a fused skip stages its own patches at the start of the operand area: the weight buffers must lie behind them too)
   const int woff = npx * 64 > skip_patch_bytes ? npx * 64 : skip_patch_bytes;
-  const int ops = woff + nwb * BI * 64;
+  const int ops = woff + 3 * BI * 64;
   const int stage = 256 * (BI * 2 + 16);
   const int body = ops > stage ? ops : stage;
   if (wgt_off) *wgt_off = woff;
@@ -375,34 +359,19 @@ static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, i
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int NWB = 3>
-static inline int sg_launch_conv_v4n(const ConvV4Params& p0, const Epilogue<bf16_t>& e, hipStream_t st) {
-  typename std::conditional<(NWB == 4), ConvV4ParamsP, ConvV4Params>::type p;
-  static_cast<ConvV4Params&>(p) = p0;
-  if constexpr (NWB == 4) p.prio = sg_mfma_prio_env();
-  const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0, NWB);
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
+static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
+  const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP, NWB>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
   const int BI = 32 * NB, BJ = 128 * TJW;
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP, NWB>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
   return 0;
-}
-template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
-static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
-  if constexpr (TJW == 2) {
-    // SG_CONV_V4_LA3=1 (A/B switch, not run on a GPU yet): four weight buffers / three taps of lookahead where three workgroups still fit a CU
-    const char* la = getenv("SG_CONV_V4_LA3");
-    if (la && la[0] == '1') {
-      const int lds4 = sg_conv_v4_lds(NB, p.npx, nullptr, nullptr, nullptr, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0, 4);
-      if (3 * lds4 <= 160 * 1024) return sg_launch_conv_v4n<NB, RELU, UP, TJW, SKIP, 4>(p, e, st);
-    }
-  }
-  return sg_launch_conv_v4n<NB, RELU, UP, TJW, SKIP, 3>(p, e, st);
 }
 template <int NB>
 static inline int sg_launch_conv_v4_skip(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {

@@ -99,9 +99,11 @@ static int wgrad_v3_launch(const sg_conv_wgrad_desc* d, const V3Plan& s, hipStre
   p.out = d->work; p.split_stride = s.stride;
   p.bias_off = d->dbias ? s.n : -1; p.bias_scale = p.g_up ? 0.25f : 1.f;
   p.alpha = d->alpha; p.alpha_ptr = d->alpha_ptr;
-  // SG_WGRAD_V3_LEAN=1: the lean variant (wgrad_v3l.h) -- A/B switch, read per call; off until it has run on a GPU
-  if (const char* m = getenv("SG_WGRAD_V3_LEAN")) { if (m[0] == '1') return sg_launch_wgrad_v3l(p, s.NB, st); }
-  return sg_launch_wgrad_v3(p, s.NB, st);
+  // the lean kernel (wgrad_v3l.h; round 5, same box: the wgrad_v3 layers of C3 -8..-12 %, profiles/r05_variant_ab_layer_tables_b.txt); it hands problems whose
+  // operands are read through a 2x upsampling to wgrad_v3.h's kernel. SG_WGRAD_V3_LEAN=0 (read per call): that kernel everywhere (the bit-identity reference of
+  // tests/test_conv_v2_gpu.py)
+  if (const char* m = getenv("SG_WGRAD_V3_LEAN")) { if (m[0] == '0') return sg_launch_wgrad_v3(p, s.NB, st); }
+  return sg_launch_wgrad_v3l(p, s.NB, st);
 }
 
 // tile configuration and split-K plan of the weight gradient (shared by the launcher and sg_conv2d_wgrad_plan)

@@ -1,7 +1,8 @@
-// wgrad_ql.h -- "lean" variant of the quad weight-gradient kernel (wgrad_q.h), the twin of wgrad_v3l.h. Written in round 4 WITHOUT GPU time from the
-// static instruction mix of the shipped loop (tools/isa_mix.py: 9.5 vector-ALU instructions per MFMA): NOT run on a GPU yet, off by default,
-// SG_WGRAD_Q_LEAN=1 selects it. Checked lane by lane on the CPU against the shipped kernel (tests/test_hipemu_cpu.py: same MFMAs in the same
-// order -> dq bit for bit); tests/test_quad_gpu.py has the opt-in GPU case. A separate kernel so that the shipped code objects stay as they are.
+// wgrad_ql.h -- the quad weight-gradient kernel (the "lean" rewrite of wgrad_q.h's loop, the twin of wgrad_v3l.h). Written in round 4 without GPU time from
+// the static instruction mix of the round-4 loop (tools/isa_mix.py: 9.5 vector-ALU instructions per MFMA), checked lane by lane on the CPU interpreter against it
+// (tests/test_hipemu_cpu.py: same MFMAs in the same order -> dq bit for bit); first GPU run in round 5 (profiles/r05_variant_ab_layer_tables_b.txt, same box):
+// the ten quad layers of C3 6.29 -> 5.00 ms (-20 %), bit-identical on the GPU too (tests/test_quad_gpu.py). The default since; SG_WGRAD_Q_LEAN=0 selects
+// wgrad_q.h's kernel (the reference of that test).
 //
 // Same tiling, staging, fragment addresses and result layout as sg_wgrad_q_kernel. Three changes:
 //   * the LDS-DMA addresses of a lane's pieces are computed once per workgroup, not once per chunk (see the kernel): the shipped loop spends
@@ -15,7 +16,7 @@
 #include "wgrad_q.h"
 
 typedef __bf16 wql_bf2 __attribute__((ext_vector_type(2)));
-struct WgradQLParams : WgradQParams { int prio; };       // prio: SG_MFMA_PRIO (the shipped kernel keeps its argument layout)
+typedef WgradQParams WgradQLParams;
 
 // fragments of one k-step (16 pixels): S activation fragments (one per slice) and NB gradient fragments, each as two transpose reads
 template <int NB, int S> struct WqlFrags { u32x2 al[S], ah[S], bl[NB], bh[NB]; };
@@ -35,7 +36,7 @@ __device__ __forceinline__ void wql_issue(unsigned a0, unsigned b0, WqlFrags<NB,
 }
 // the S NB MFMAs of a k-step from fragments that HAVE landed (the caller's s_waitcnt lgkmcnt covers them)
 template <int NB, int S, bool RELU>
-__device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int cblk, float& csum, int prio) {
+__device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int cblk, float& csum) {
   bf16x8_t af[S], bf[NB];
 #pragma unroll
   for (int s = 0; s < S; s++) {
@@ -69,46 +70,39 @@ __device__ __forceinline__ void wql_consume(f32x16* acc, WqlFrags<NB, S>& f, int
         csum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(wql_bf2, gq), __builtin_bit_cast(wql_bf2, 0x3f803f80u), csum, false);
       }
     }
-  SG_PRIO_UP(prio);
+  SG_PRIO_UP();
 #pragma unroll
   for (int s = 0; s < S; s++)
 #pragma unroll
     for (int b = 0; b < NB; b++)
       acc[s * NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[s], bf[b], acc[s * NB + b], 0, 0, 0);
-  SG_PRIO_DOWN(prio);
+  SG_PRIO_DOWN();
 }
-template <int NB, int WC, int S, int KS, bool RELU>
-__device__ __forceinline__ void wql_kstep(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum, int prio) {
-  WqlFrags<NB, S> f;
-  wql_issue<NB, WC, S, KS>(a0, b0, f);
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  wql_consume<NB, S, RELU>(acc, f, cblk, csum, prio);
-}
-// PIPE: the four k-steps of a chunk as a two-deep register pipeline -- the reads of k-step s + 1 are in flight while the MFMAs of k-step s issue; the
+// The four k-steps of a chunk as a two-deep register pipeline -- the reads of k-step s + 1 are in flight while the MFMAs of k-step s issue; the
 // counted wait leaves exactly those 2 (S + NB) reads outstanding (LDS operations of a wave return in order). One exposed LDS round trip per chunk
 // instead of four; 2 (S + NB) more registers (wgrad_v2.h has run such a pipeline since round 2).
 template <int NB, int WC, int S, bool RELU>
-__device__ __forceinline__ void wql_chunk_pipelined(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum, int prio) {
+__device__ __forceinline__ void wql_chunk_pipelined(f32x16* acc, unsigned a0, unsigned b0, int cblk, float& csum) {
   constexpr int NR = 2 * (S + NB);
   static_assert(NR <= 15, "lgkmcnt is a 4-bit counter");
   WqlFrags<NB, S> f0, f1;
   wql_issue<NB, WC, S, 0>(a0, b0, f0);
   wql_issue<NB, WC, S, 1>(a0, b0, f1);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f0, cblk, csum, prio);
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
   wql_issue<NB, WC, S, 2>(a0, b0, f0);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f1, cblk, csum, prio);
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
   wql_issue<NB, WC, S, 3>(a0, b0, f1);
   asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(NR) : "memory");
-  wql_consume<NB, S, RELU>(acc, f0, cblk, csum, prio);
+  wql_consume<NB, S, RELU>(acc, f0, cblk, csum);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  wql_consume<NB, S, RELU>(acc, f1, cblk, csum, prio);
+  wql_consume<NB, S, RELU>(acc, f1, cblk, csum);
 }
 
 // NB = 32-wide cout blocks per tile (2 or 3), WC = chunk width in low-resolution pixels (64, 32, 16, 8: 64 / WC whole image rows; 4: four
 // whole 4 x 4 images), S = 32-channel input slices per workgroup (1 or 2)
-template <int NB, int WC, int S, bool RELU, bool PIPE = false>
+template <int NB, int WC, int S, bool RELU>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void sg_wgrad_ql_kernel(WgradQLParams p) {
   constexpr int NIMG = WC == 4 ? 4 : 1;             // images per chunk
   constexpr int RC = 64 / WC, RCI = RC / NIMG;      // chunk rows, rows per image part
@@ -229,14 +223,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
     __builtin_amdgcn_s_barrier();                   // chunk c has landed everywhere; every wave is done with the other buffer
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
-    if constexpr (PIPE) {
-      wql_chunk_pipelined<NB, WC, S, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
-    } else {
-      wql_kstep<NB, WC, S, 0, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
-      wql_kstep<NB, WC, S, 1, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
-      wql_kstep<NB, WC, S, 2, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
-      wql_kstep<NB, WC, S, 3, RELU>(acc, a0 + bo, b0 + bo, cblk, csum, p.prio);
-    }
+    wql_chunk_pipelined<NB, WC, S, RELU>(acc, a0 + bo, b0 + bo, cblk, csum);
     buf ^= 1;
   }
 
@@ -263,40 +250,36 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) voi
   }
 }
 
-template <int NB, int WC, int S, bool RELU, bool PIPE>
+template <int NB, int WC, int S, bool RELU>
 static inline int sg_launch_wgrad_ql_t(const WgradQLParams& p, hipStream_t st) {
   constexpr int NIMG = WC == 4 ? 4 : 1, RCI = (64 / WC) / NIMG, PPI = (RCI + 1) * (WC + 1);
   constexpr int XB = ((NIMG * PPI * 64 + 1023) / 1024) * 1024;
   constexpr int LDS = 2 * (S * XB + 64 * NB * 64);
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_wgrad_ql_kernel<NB, WC, S, RELU, PIPE>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_wgrad_ql_kernel<NB, WC, S, RELU>, hipFuncAttributeMaxDynamicSharedMemorySize, LDS) != hipSuccess) return -1;
     attr_done = true;
   }
-  hipLaunchKernelGGL((sg_wgrad_ql_kernel<NB, WC, S, RELU, PIPE>), dim3(4 * p.nci * p.nco * p.splits), dim3(256), LDS, st, p);
+  hipLaunchKernelGGL((sg_wgrad_ql_kernel<NB, WC, S, RELU>), dim3(4 * p.nci * p.nco * p.splits), dim3(256), LDS, st, p);
   return 0;
 }
-template <int NB, int S, bool RELU, bool PIPE>
+template <int NB, int S, bool RELU>
 static inline int sg_launch_wgrad_ql_s(const WgradQLParams& p, hipStream_t st) {
   const int wc = p.W >= 64 ? 64 : p.W;
   switch (wc) {
-    case 64: return sg_launch_wgrad_ql_t<NB, 64, S, RELU, PIPE>(p, st);
-    case 32: return sg_launch_wgrad_ql_t<NB, 32, S, RELU, PIPE>(p, st);
-    case 16: return sg_launch_wgrad_ql_t<NB, 16, S, RELU, PIPE>(p, st);
-    case 8: return sg_launch_wgrad_ql_t<NB, 8, S, RELU, PIPE>(p, st);
-    case 4: return sg_launch_wgrad_ql_t<NB, 4, S, RELU, PIPE>(p, st);
+    case 64: return sg_launch_wgrad_ql_t<NB, 64, S, RELU>(p, st);
+    case 32: return sg_launch_wgrad_ql_t<NB, 32, S, RELU>(p, st);
+    case 16: return sg_launch_wgrad_ql_t<NB, 16, S, RELU>(p, st);
+    case 8: return sg_launch_wgrad_ql_t<NB, 8, S, RELU>(p, st);
+    case 4: return sg_launch_wgrad_ql_t<NB, 4, S, RELU>(p, st);
   }
   return -1;
 }
-template <bool RELU, bool PIPE>
+template <bool RELU>
 static inline int sg_launch_wgrad_ql_r(const WgradQLParams& p, int NB, int S, hipStream_t st) {
-  if (NB == 3) return S == 2 ? sg_launch_wgrad_ql_s<3, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<3, 1, RELU, PIPE>(p, st);
-  return S == 2 ? sg_launch_wgrad_ql_s<2, 2, RELU, PIPE>(p, st) : sg_launch_wgrad_ql_s<2, 1, RELU, PIPE>(p, st);
+  if (NB == 3) return S == 2 ? sg_launch_wgrad_ql_s<3, 2, RELU>(p, st) : sg_launch_wgrad_ql_s<3, 1, RELU>(p, st);
+  return S == 2 ? sg_launch_wgrad_ql_s<2, 2, RELU>(p, st) : sg_launch_wgrad_ql_s<2, 1, RELU>(p, st);
 }
-static inline int sg_launch_wgrad_ql(const WgradQParams& p0, int NB, int S, hipStream_t st, bool pipe = false) {
-  WgradQLParams p;
-  static_cast<WgradQParams&>(p) = p0;
-  p.prio = sg_mfma_prio_env();
-  if (pipe) return p.x_relu ? sg_launch_wgrad_ql_r<true, true>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, true>(p, NB, S, st);
-  return p.x_relu ? sg_launch_wgrad_ql_r<true, false>(p, NB, S, st) : sg_launch_wgrad_ql_r<false, false>(p, NB, S, st);
+static inline int sg_launch_wgrad_ql(const WgradQParams& p, int NB, int S, hipStream_t st) {
+  return p.x_relu ? sg_launch_wgrad_ql_r<true>(p, NB, S, st) : sg_launch_wgrad_ql_r<false>(p, NB, S, st);
 }

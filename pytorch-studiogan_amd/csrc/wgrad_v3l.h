@@ -1,8 +1,7 @@
-// wgrad_v3l.h -- "lean" variant of the halo weight-gradient kernel (wgrad_v3.h). Written at the end of round 4 WITHOUT GPU time, from the
-// static instruction mix of the shipped loop (tools/isa_mix.py, profiles/r04_isa_mix.txt: 9.5 vector-ALU instructions per MFMA, both sides of
-// its branches counted): NOT run yet, off by default, SG_WGRAD_V3_LEAN=1 selects it (tests/test_conv_v2_gpu.py has the opt-in parity cases;
-// tools/sessions/r5a.sh runs them first). A separate kernel rather than a template flag of sg_wgrad_v3_kernel so that the shipped kernel's
-// code object stays byte-identical (checked with llvm-objdump when this file was added).
+// wgrad_v3l.h -- the halo weight-gradient kernel for plain operands (the "lean" rewrite of wgrad_v3.h's loop). Written at the end of round 4 without GPU time,
+// from the static instruction mix of that loop (tools/isa_mix.py, profiles/r04_isa_mix.txt: 9.5 vector-ALU instructions per MFMA), checked on the CPU interpreter
+// (tests/test_hipemu_cpu.py); first GPU run in round 5 (profiles/r05_variant_ab_layer_tables_b.txt, same box): the wgrad_v3 layers of C3 -8..-12 %, dW bit-identical
+// (tests/test_conv_v2_gpu.py). The default since; SG_WGRAD_V3_LEAN=0 selects wgrad_v3.h's kernel everywhere (it still serves the upsampled operands).
 //
 // Same tiling, staging, fragment addresses and result layout as sg_wgrad_v3_kernel. Three changes:
 //   * the LDS-DMA addresses of a lane's pieces are computed once per workgroup, not once per chunk (see the kernel; plain operands only);
@@ -16,11 +15,11 @@
 #include "wgrad_v3.h"
 
 typedef __bf16 w3l_bf2 __attribute__((ext_vector_type(2)));
-struct WgradV3LParams : WgradV3Params { int prio; };     // prio: SG_MFMA_PRIO (the shipped kernel keeps its argument layout)
+typedef WgradV3Params WgradV3LParams;
 
 // one k-step (16 pixels) of a chunk, as w3_kstep: 2 NB + 1 MFMAs from 3 activation fragments (taps t0, t1, 8) and NB + 1 gradient fragments
 template <int NB, int WC, int KS, bool RELU>
-__device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, bool extra, float& csum, bool do_csum, int prio) {
+__device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1, unsigned a2, unsigned b0, unsigned bx, bool extra, float& csum, bool do_csum) {
   constexpr int PW = WC + 2, GPITCH = NB * 64;
   // patch byte offset of pixels KS * 16 .. of the chunk raster. WC == 4 (round 4): a chunk is FOUR whole 4 x 4 images, each with its own 6 x 6
   // halo patch; a 16-pixel k-step is one image, and the second half of a fragment (+ 4 pixels) is the next image row
@@ -67,14 +66,14 @@ __device__ __forceinline__ void w3l_kstep(f32x16* acc, unsigned a0, unsigned a1,
       csum = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(w3l_bf2, gq), __builtin_bit_cast(w3l_bf2, 0x3f803f80u), csum, false);
     }
   }
-  SG_PRIO_UP(prio);
+  SG_PRIO_UP();
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     acc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[b], acc[b], 0, 0, 0);
     acc[NB + b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[b], acc[NB + b], 0, 0, 0);
   }
   if (extra) acc[2 * NB] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2], xf, acc[2 * NB], 0, 0, 0);
-  SG_PRIO_DOWN(prio);
+  SG_PRIO_DOWN();
 }
 
 template <int NB, int WC, bool RELU>
@@ -192,10 +191,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
     __builtin_amdgcn_s_barrier();                   // chunk c has landed everywhere; every wave is done with the other buffer
     if (c + p.splits < p.nchunk) issue(c + p.splits, buf ^ 1);
     const unsigned bo = (unsigned)(buf * BUF);
-    w3l_kstep<NB, WC, 0, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
-    w3l_kstep<NB, WC, 1, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
-    w3l_kstep<NB, WC, 2, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
-    w3l_kstep<NB, WC, 3, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum, p.prio);
+    w3l_kstep<NB, WC, 0, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
+    w3l_kstep<NB, WC, 1, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
+    w3l_kstep<NB, WC, 2, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
+    w3l_kstep<NB, WC, 3, RELU>(acc, a0 + bo, a1 + bo, a2 + bo, b0 + bo, bx + bo, extra, csum, do_csum);
     buf ^= 1;
   }
 
@@ -238,9 +237,7 @@ static inline int sg_launch_wgrad_v3l_r(const WgradV3LParams& p, hipStream_t st)
 }
 static inline int sg_launch_wgrad_v3l(const WgradV3Params& p0, int NB, hipStream_t st) {
   if (p0.x_up || p0.g_up) return sg_launch_wgrad_v3(p0, NB, st);      // operands read through a 2x nearest upsampling: the shipped kernel
-  WgradV3LParams p;
-  static_cast<WgradV3Params&>(p) = p0;
-  p.prio = sg_mfma_prio_env();
+  const WgradV3LParams& p = p0;
   const int wc = p.W >= 64 ? 64 : p.W;
   if (NB == 3) {
     switch (wc) { case 64: return sg_launch_wgrad_v3l_r<3, 64>(p, st); case 32: return sg_launch_wgrad_v3l_r<3, 32>(p, st);

@@ -485,11 +485,10 @@ def test_wgrad_v3_full_size_layers(sg):
         check(f"wgrad v3 full size {(N, Cin, Cout, H, xf, gf)}", outs["1"], outs["0"], 2e-3)
 
 
-@pytest.mark.skipif(os.environ.get("SG_EXPERIMENTAL") != "1", reason="wgrad_v3l.h has not run on a GPU yet (CPU: tests/test_hipemu_cpu.py); SG_EXPERIMENTAL=1 runs it")
 @pytest.mark.parametrize("case", WV3_CASES)
-def test_wgrad_v3_lean_matches_shipped(sg, case, monkeypatch):
-    """SG_WGRAD_V3_LEAN=1 (csrc/wgrad_v3l.h: ReLU-on-load as a template parameter, bias gradient through v_dot2): the same MFMAs in the same
-    order as the shipped kernel -> dW bit for bit (one split layout), bias gradient to fp32 rounding."""
+def test_wgrad_v3_lean_matches_round4_kernel(sg, case, monkeypatch):
+    """csrc/wgrad_v3l.h (the default since round 5: ReLU-on-load as a template parameter, bias gradient through v_dot2) against the round-4 kernel
+    (SG_WGRAD_V3_LEAN=0, csrc/wgrad_v3.h): the same MFMAs in the same order -> dW bit for bit (one split layout), bias gradient to fp32 rounding."""
     from studiogan_amd import functional as F, _lib as L
     N, Cin, Cout, H, relu, up, pool = case
     d = torch.device("cuda:0")

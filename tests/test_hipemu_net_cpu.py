@@ -165,7 +165,7 @@ def forced_fast_kernels(monkeypatch):
 def test_emulated_fullwidth_bf16_step_vs_golden(forced_fast_kernels, monkeypatch, lean):
     """the benchmarked network (BASELINE config 3: BigGAN, ImageNet-128 widths) with the benchmarked kernels -- conv_q / conv_v4 / conv_v3 / conv_sk /
     conv_rs forward and data gradient, wgrad_v3 / wgrad_q / wgrad_sk / wgrad_v2, flash attention, epilogue BN statistics: 901 launches, 52 M MFMAs --
-    one bf16 training step against the reference's golden vectors. lean = 1: with the round-4 weight-gradient kernels that have not run on a GPU."""
+    one bf16 training step against the reference's golden vectors. lean = 1: the default weight-gradient kernels (wgrad_v3l.h / wgrad_ql.h), 0: the round-4 ones."""
     monkeypatch.setenv("SG_WGRAD_V3_LEAN", lean)
     monkeypatch.setenv("SG_WGRAD_Q_LEAN", lean)
     c = _step("biggan128w", True)
@@ -175,7 +175,7 @@ def test_emulated_fullwidth_bf16_step_vs_golden(forced_fast_kernels, monkeypatch
 @pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: teacher-forced block test of BigGAN-128 at full width through the interpreter, 1-2 min each")
 @pytest.mark.parametrize("which", ["D", "G"])
 def test_emulated_fullwidth_teacher_forced_blocks_with_lean_kernels(forced_fast_kernels, monkeypatch, which):
-    """tests/test_blocks_gpu.py::bf16_vs_emulating_oracle on the interpreter with SG_WGRAD_V3_LEAN = SG_WGRAD_Q_LEAN = 1: every block of the full-width
+    """tests/test_blocks_gpu.py::bf16_vs_emulating_oracle on the interpreter with the lean weight-gradient kernels (the default since round 5): every block of the full-width
     network on the bf16-emulating oracle's input and upstream gradient -- block output, input gradient and every weight gradient to 1e-2 relative L2
     (discriminator: flat; generator: max(1e-2, 1.5 x measured floor)). The tight network-level bound on the lean weight-gradient kernels."""
     import contextlib
@@ -197,13 +197,9 @@ def test_emulated_fullwidth_teacher_forced_blocks_with_lean_kernels(forced_fast_
     assert rows and worst < 1e-2 * (1 if which == "D" else 3)
 
 
-@pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: every full-width fixture through the interpreter with every round-4 switch on, 0.5-4 min each")
-@pytest.mark.parametrize("qla", ["1", "2", "3"])
+@pytest.mark.skipif(not FULL, reason="SG_EMU_NET=1: every full-width fixture through the interpreter, 0.5-4 min each")
 @pytest.mark.parametrize("name", ["sngan32w", "wgangp128w", "bigdeep128w", "biggan128w"])
-def test_emulated_fullwidth_bf16_step_all_round4_switches(forced_fast_kernels, monkeypatch, name, qla):
-    """the four full-width fixtures (C2 SNGAN, C5 WGAN-GP ResNet-128 with its double backward, C4 BigGAN-deep-128, C3 BigGAN-128) with EVERY kernel variant that
-    has not run on a GPU yet switched on at once: lean weight gradients, conv_q weights three taps ahead (qla = 1), taps in pairs (qla = 2) or one-sided patch halo (qla = 3), conv_v4 with
-    four weight buffers. Golden vectors of the reference at the bf16 tolerances of tests/test_fullwidth_gpu.py."""
-    for k, v in (("SG_WGRAD_V3_LEAN", "1"), ("SG_WGRAD_Q_LEAN", "1"), ("SG_CONV_Q_LA3", qla), ("SG_CONV_V4_LA3", "1")):
-        monkeypatch.setenv(k, v)
+def test_emulated_fullwidth_bf16_step_every_fixture(forced_fast_kernels, monkeypatch, name):
+    """the four full-width fixtures (C2 SNGAN, C5 WGAN-GP ResNet-128 with its double backward, C4 BigGAN-deep-128, C3 BigGAN-128) with the fast kernels forced:
+    golden vectors of the reference at the bf16 tolerances of tests/test_fullwidth_gpu.py."""
     _step(name, True)
