@@ -52,6 +52,28 @@ ENGINES = ["other", "sg_conv_sk_kernel", "sg_conv_rs_kernel / sg_conv_rs96_kerne
            "sg_wgrad_v2_kernel", "sg_gemm_kernel<wgrad>", "sg_wgrad_q_kernel"]
 
 
+def peak_for(mixed):
+    return PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources this library was built from: the PMC summaries under profiles/ carry the same figure
+    (tools/pmc_traffic.py), so the line can say whether its byte counts were taken on THIS code (the GPU box has no .git to ask)"""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "pytorch-studiogan_amd", "csrc")
+    for f in sorted(glob.glob(os.path.join(d, "*.h")) + glob.glob(os.path.join(d, "*.hip"))):
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()[:16]
+
+
+# rocprof names of the kernels behind a profiler tag (the lean weight-gradient kernels kept their tags)
+TAG_KERNELS = {"sg_wgrad_q_kernel": ("sg_wgrad_q_kernel", "sg_wgrad_ql_kernel"), "sg_wgrad_v3_kernel": ("sg_wgrad_v3_kernel", "sg_wgrad_v3l_kernel"),
+               "sg_conv_rs_kernel": ("sg_conv_rs_kernel", "sg_conv_rs96_kernel")}
+
+
 def per_kernel_table(L, nsteps, peak, pmc=None):
     """roofline.per_kernel: the convolution engine's launches of the timed region by kernel family (hipEvent time per launch, recorded on the launch
     stream by libsgamd.so): launches / step, ms / step, algorithmic and executed TFLOP/s, fraction of the MFMA peak, algorithmic HBM bytes per launch,
@@ -66,7 +88,7 @@ def per_kernel_table(L, nsteps, peak, pmc=None):
             continue
         r = {"launches_per_step": round(cnt / nsteps, 1), "ms_per_step": round(ms / nsteps, 3),
              "tflops": round(fl / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, "frac": round(fl / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else None,
-             "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 1) if ms > 0 else None,
+             "executed_tflops": round(ex / (ms * 1e-3) / 1e12, 1) if ms > 0 else None, "executed_frac": round(ex / (ms * 1e-3) / 1e12 / peak, 4) if ms > 0 else None,
              "algorithmic_MB_per_launch": round(by / cnt / 1e6, 1), "algorithmic_GBps": round(by / (ms * 1e-3) / 1e9, 1) if ms > 0 else None}
         if pmc:
             # measured HBM bytes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command, tools/pmc_traffic.py) of the family's
@@ -78,7 +100,7 @@ def per_kernel_table(L, nsteps, peak, pmc=None):
                 return [t.strip() for t in a.split(",")]
 
             def member(k):
-                if key not in k:
+                if not any(kk + "<" in k or k.endswith(kk) for kk in TAG_KERNELS.get(key, (key,))):
                     return False
                 if key == "sg_conv_v4_kernel":      # template <NB, RELU, UP, TJW, SKIP>
                     a = targs(k)
@@ -487,10 +509,13 @@ def main():
     assert d_last > 1e-2, f"discriminator saturated in the timed region (d_loss {d_last}): the measured step would multiply zero gradients"
     fake_chk = w.last_g[0]
     assert bool(torch.isfinite(fake_chk).all()) and float(fake_chk.abs().max()) <= 1.0, "generator images of the last step are not finite / not in [-1, 1]"
-    pmc_tab, pmc_src = None, None
+    # PMC byte counts need their own rocprofv3 passes: the committed summary of those passes over this same command (tools/pmc_traffic.py). The
+    # summary carries the hash of the kernel sources it was taken on; a summary of OTHER sources is reported as stale, never silently used as current
+    pmc_tab, pmc_src, pmc_sha, cur_sha = None, None, None, csrc_sha16()
     try:
-        pmc_name = next(n for n in ("r04_conv_hbm_traffic_pmc.json",) if os.path.exists(os.path.join(ROOT, "profiles", n)))
-        pmc_tab = json.load(open(os.path.join(ROOT, "profiles", pmc_name))).get("per_kernel")
+        pmc_name = next(n for n in ("r05_conv_hbm_traffic_pmc.json", "r04_conv_hbm_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        pj = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
+        pmc_tab, pmc_sha = pj.get("per_kernel"), pj.get("csrc_sha16")
         pmc_src = "profiles/" + pmc_name
     except Exception:
         pass
@@ -529,15 +554,16 @@ def main():
         fwd_ms = e0.elapsed_time(e1) / it
         conv_only_ms = pd[1] / it
         pk = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
+        alg_tf = pd[2] / it / (conv_only_ms * 1e-3) / 1e12 if conv_only_ms > 0 else None
+        exe_tf = pd4[3] / it / (conv_only_ms * 1e-3) / 1e12 if conv_only_ms > 0 else None
         dfwd = {"what": "BigGAN-128 D forward at batch %d (SN power iteration + weight packing included in forward_ms)" % args.batch,
-                "forward_ms": round(fwd_ms, 3), "forward_tflops": round(21.673 * args.batch / fwd_ms, 1),
+                # algorithmic = the reference's op graph (3x3 convolution + AvgPool2d as written in src/models/big_resnet.py:177-242) = SURVEY 8(d) / the north-star
+                # target's accounting; executed = the MFMAs issued: the pooled block tails run as 4x4 / stride-2 convolutions with the pre-summed filter (csrc/conv_q.h)
+                "conv_stack_frac_of_peak": round(alg_tf / pk, 4) if alg_tf else None,
+                "conv_stack_executed_frac_of_peak": round(exe_tf / pk, 4) if exe_tf else None,
                 "conv_stack_ms": round(conv_only_ms, 3), "conv_launches": int(pd[0] / it),
-                "conv_stack_tflops": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
-                "conv_stack_frac_of_peak": round(pd[2] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None, "peak_tflops": pk,
-                # algorithmic = the reference's op graph (3x3 convolution + AvgPool2d as written in src/models/big_resnet.py:177-242); the pooled
-                # block tails run as 4x4 / stride-2 convolutions with the pre-summed filter (csrc/conv_q.h): 16/36 of those MACs are executed
-                "conv_stack_executed_tflops": round(pd4[3] / it / (conv_only_ms * 1e-3) / 1e12, 1) if conv_only_ms > 0 else None,
-                "conv_stack_executed_frac_of_peak": round(pd4[3] / it / (conv_only_ms * 1e-3) / 1e12 / pk, 4) if conv_only_ms > 0 else None,
+                "conv_stack_tflops": round(alg_tf, 1) if alg_tf else None, "conv_stack_executed_tflops": round(exe_tf, 1) if exe_tf else None, "peak_tflops": pk,
+                "forward_ms": round(fwd_ms, 3), "forward_tflops": round(21.673 * args.batch / fwd_ms, 1),
                 "per_kernel": dfwd_kernels}
     # ---- HBM-bound kernel families of the step: algorithmic bytes / hipEvent time per family over two more steps --------
     hbm = None
@@ -588,7 +614,13 @@ def main():
                # algorithmic work per sample: G forward 42.24 GFLOP + InceptionV3 at 299^2 11.4 GFLOP
                "roofline_bf16": {"bound": "mfma", "gflop_per_sample": 53.64, "achieved": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3, 1), "unit": "TFLOP/s",
                                  "peak": 2500.0, "frac": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3 / 2500.0, 4),
-                                 "kernel_trace": "profiles/r03_fid_leg_kerneltrace.txt (tools/fid_leg.py, traced at the round-3 code state)"},
+                                 "kernel_trace": "profiles/r05_fid_leg_kerneltrace.txt (tools/fid_leg.py under rocprofv3 --kernel-trace --stats)"},
+               # the headline value's own roofline: G_ema runs in bf16 (42.24 GFLOP per sample on the bf16 MFMA), InceptionV3 in fp32 (11.4 GFLOP per sample on the
+               # fp32 MFMA, 157.3 TFLOP/s): the time each half would need at its peak, summed, over the measured time per sample
+               "roofline_f32": {"bound": "mfma", "gflop_per_sample_bf16_generator": 42.24, "gflop_per_sample_f32_inception": 11.4,
+                                "inception_f32_tflops_if_it_took_all_the_time": round(fid["f32"]["samples_per_sec"] * 11.4 / 1e3, 1), "peak_f32": 157.3,
+                                "frac": round(fid["f32"]["samples_per_sec"] * (42.24 / 2500.0e3 + 11.4 / 157.3e3), 4),
+                                "frac_note": "sum over the two halves of (FLOPs per sample / that dtype's MFMA peak) / measured seconds per sample"},
                "weights": "seeded random (pretrained FID Inception weights are not available offline)"}
     if rank != 0:
         if world > 1:
@@ -604,17 +636,30 @@ def main():
     conv_flop = prof[2] + prof[5]
     achieved = conv_flop / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     peak = PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS
-    # HBM bytes per conv launch: PMC counters need their own rocprofv3 passes, so the figure is the committed summary of
-    # those passes over this same command (tools/pmc_traffic.py), not something this process can sample live
     traffic, traffic_src = None, None
     try:
-        tname = next(n for n in ("r04_conv_hbm_traffic_pmc.json", "r03_conv_hbm_traffic_pmc.json", "r02_conv_hbm_traffic_pmc.json", "r01_conv_hbm_traffic_pmc_v2.json")
-                     if os.path.exists(os.path.join(ROOT, "profiles", n)))
-        tj = json.load(open(os.path.join(ROOT, "profiles", tname)))
-        if args.workload == "biggan128" and mixed and args.batch == 256:
-            traffic, traffic_src = tj["hbm_bytes_per_launch"], f"profiles/{tname} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
+        if pmc_src and args.workload == "biggan128" and mixed and args.batch == 256:
+            traffic = pj["hbm_bytes_per_launch"]
+            traffic_src = f"{pmc_src} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes, read side x2)"
     except Exception:
         pass
+    # the dominant kernel: sg_conv_q_kernel with and without the fused skip are ONE kernel template (two profiler tags)
+    dominant = None
+    if per_kernel:
+        fam = {}
+        for k, v in per_kernel.items():
+            fam.setdefault(k.split("<")[0].strip(), []).append(v)
+        dname, rows = max(fam.items(), key=lambda kv: sum(r["ms_per_step"] for r in kv[1]))
+        dms = sum(r["ms_per_step"] for r in rows)
+        dn = sum(r["launches_per_step"] for r in rows)
+        dalg = sum((r["tflops"] or 0.0) * r["ms_per_step"] for r in rows) / dms if dms > 0 else 0.0
+        dex = sum((r["executed_tflops"] or 0.0) * r["ms_per_step"] for r in rows) / dms if dms > 0 else 0.0
+        dab = sum(r["algorithmic_MB_per_launch"] * r["launches_per_step"] for r in rows)
+        dpb = sum(r.get("pmc_MB_per_launch", 0.0) * r["launches_per_step"] for r in rows) if all("pmc_MB_per_launch" in r for r in rows) else None
+        dominant = {"kernel": dname + (" (plain + fused-skip instantiations)" if len(rows) > 1 else ""), "ms_per_step": round(dms, 3), "launches_per_step": round(dn, 1),
+                    "frac": round(dalg / peak_for(mixed), 4), "executed_frac": round(dex / peak_for(mixed), 4), "tflops": round(dalg, 1), "executed_tflops": round(dex, 1),
+                    "algorithmic_MB_per_launch": round(dab / dn, 1) if dn else None,
+                    "pmc_bytes_over_algorithmic": round(dpb / dab, 3) if (dpb and dab) else None}
     out = {
         "metric": "images/sec (G+D step) BigGAN ImageNet-128 bs256",
         "value": round(value, 3), "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -631,14 +676,21 @@ def main():
                    # time the compute stream spent waiting for collectives (sync-BN all-reduces run on it; waits on the gradient reductions in
                    # FusedAdam.step), max over ranks: hipEvent pairs around every such point (studiogan_amd.comm.exposed)
                    "exposed_comm_ms_per_step": None if exposed_comm_ms is None else round(exposed_comm_ms / args.steps, 3)},
+        # frac = SURVEY 8(d)'s accounting (ALGORITHMIC FLOPs of the reference's op graph / time); executed_frac = the MFMAs actually issued / time (the
+        # hardware-utilisation figure: the convolutions next to a 2x resampling run through the exact pooled / phase-filter identity of csrc/conv_q.h and
+        # execute 16/36 of the algorithmic MACs). Both lead the object; every per-kernel row carries both.
         "roofline": {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
-                     "kernel": "convolution engine (family; per_kernel has the members, dominant_kernel the largest): sg_conv_q_kernel / sg_wgrad_q_kernel (3x3 next to a 2x resampling as 4x4-stride-2 / four 2x2 phase convolutions) / sg_conv_v4_kernel (3x3 halo, <= 384 channels, G tails with the 1x1 skip fused) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers) / sg_conv_v2_kernel / sg_wgrad_v3_kernel / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel",
                      "executed_tflops": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12, 2) if conv_ms > 0 else None,
                      "executed_frac": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms > 0 else None,
-                     "achieved_note": "achieved = ALGORITHMIC FLOPs of the reference's op graph (3x3 convolutions over the fine grid) / hipEvent time; the convolutions next to "
-                                      "a 2x resampling run through the exact pooled / phase-filter identity (csrc/conv_q.h) and execute 16/36 of them: executed_* counts the MFMAs issued",
-                     "dominant_kernel": max(per_kernel.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if per_kernel else None,
+                     "frac_basis": "frac: algorithmic FLOPs of the reference's op graph (3x3 convolutions over the fine grid) / hipEvent time = SURVEY 8(d); "
+                                   "executed_frac: MFMAs issued / the same time = matrix-pipe utilisation (quad launches execute 16/36 of the algorithmic MACs)",
+                     "dominant_kernel": dominant,
+                     "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
+                     "pmc_csrc_sha16": pmc_sha, "csrc_sha16": cur_sha,
+                     "pmc_stale": None if pmc_src is None else (pmc_sha != cur_sha),
+                     "pmc_note": "traffic and every pmc_* figure come from the committed PMC summary named in traffic_source (counters need their own rocprofv3 passes); "
+                                 "pmc_stale = that summary was taken on other kernel sources than this run's (csrc hashes differ or the summary predates the hash)",
+                     "kernel": "convolution engine (family; per_kernel has the members, dominant_kernel the largest): sg_conv_q_kernel / sg_wgrad_ql_kernel (3x3 next to a 2x resampling as 4x4-stride-2 / four 2x2 phase convolutions) / sg_conv_v4_kernel (3x3 halo, <= 384 channels, G tails with the 1x1 skip fused) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers) / sg_conv_v2_kernel / sg_wgrad_v3l_kernel / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel",
                      "per_kernel": per_kernel, "per_kernel_pmc_source": pmc_src,
                      "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),

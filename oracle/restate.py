@@ -530,19 +530,22 @@ def resnet_generator(z, label, P, B, cfg, bn_mode="track", sn_iter=True):
         x = E.qb(x)
         return cond_batch_norm(x, aff, P, B, name, bn_mode, sn_iter) if cond else batch_norm(x, P, B, name, bn_mode)
 
-    act = E.q(linear(z, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4)
+    act = _tap(cfg, -1, E.q(linear(z, P, B, "linear0", sn_iter)).view(-1, g_in[0], 4, 4))
     bi = 0
     for index in range(len(g_in)):
         pre = f"blocks.{bi}.0"
         x0 = act
         x = E.q(torch.relu(bn(act, pre + ".bn1")))
-        x = E.q(conv(F.interpolate(E.qb(x), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
+        if E.emulate and cfg.get("quad_emu", True) and quad_eligible(_w(P, pre + ".conv2d1")):
+            x = E.q(conv_up_quad(E.qb(x), P, B, pre + ".conv2d1", sn_iter, E))      # (the HIP path's storage points: csrc/conv_q.h rounds the phase filters once more)
+        else:
+            x = E.q(conv(F.interpolate(E.qb(x), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d1", 1, sn_iter, E, qb_in=False))
         x = E.q(conv(E.q(torch.relu(bn(x, pre + ".bn2"))), P, B, pre + ".conv2d2", 1, sn_iter, E))
         x0 = conv(F.interpolate(E.qb(x0), scale_factor=2, mode="nearest"), P, B, pre + ".conv2d0", 0, sn_iter, E, qb_in=False)
-        act = E.q(x + x0)
+        act = _tap(cfg, bi, E.q(x + x0))
         bi += 1
         if cfg.get("apply_attn", False) and (index + 1) in cfg["attn_g_loc"]:
-            act = self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E)
+            act = _tap(cfg, bi, self_attention(act, P, B, f"blocks.{bi}.0", sn_iter, E))
             bi += 1
     act = E.q(torch.relu(batch_norm(E.qb(act), P, B, "bn4", bn_mode)))
     return torch.tanh(E.q(conv(act, P, B, "conv2d5", 1, sn_iter, E)))

@@ -12,6 +12,8 @@ import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libsgamd.so")
+if os.environ.get("SG_LIBSGAMD"):      # same-box A/B of two builds of the library (tools/sessions/*.sh); never set by the package, the tests or bench.py
+    LIB_PATH = os.path.abspath(os.environ["SG_LIBSGAMD"])
 CSRC = os.path.join(_HERE, "csrc")
 
 F32, BF16, F64 = 0, 1, 2

@@ -99,6 +99,7 @@ class Generator(nn.Module):
             affines = TF.one_hot(label, num_classes=self.num_classes).to(torch.float32)
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
+        act = ops.block_boundary(self, -1, act)
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
         for bi, blocklist in enumerate(self.blocks):
             for block in blocklist:
@@ -106,6 +107,7 @@ class Generator(nn.Module):
                     act = block.forward_nhwc(act, slot)
                 else:
                     act = block.forward_nhwc(act, affines, slot)
+            act = ops.block_boundary(self, bi, act)
             if nxt is not None:
                 act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
         act = self.bn4.forward_nhwc(act, relu=True)

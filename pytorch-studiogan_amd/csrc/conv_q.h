@@ -112,27 +112,50 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
   const int wmask = p.Wl - 1;
 
   // ---- patch DMA: groups of 16 consecutive low-resolution pixels, group g = wave + 4 i ---------------------------------------------
+  // Round 5 ("lean" forward loop, after the weight-gradient kernels): what a lane's LDS-DMA pieces read is the same for every slice of a view up to the
+  // slice's channel offset, which is wave-uniform -- the per-lane byte offsets (with their bounds decision folded in) are computed once per VIEW and held in
+  // registers (pvo), the slice offset rides in the instruction's scalar offset. The loop this replaces re-derived (pixel -> fine pixel -> byte offset, one
+  // 64-bit multiply-add each) for every piece of every slice: ~8 vector instructions per piece, one of them quarter-rate, 6-7 pieces per wave and slice of 48 MFMAs.
   const int P0 = j0 - p.Wl - 8;                                      // raster index of patch row 0
   const int ngroups = p.npx >> 4;
   const int pix0 = P0 + 16 * wave + sub;
-  auto patch_slice = [&](int view, int s, int pbase = 0) {
+  constexpr int MAXPG = 7;                                           // pieces per wave held in registers: (BJ + 2 Wl + 16) / 64 rounded up for Wl <= 64
+  unsigned pvo[MAXPG];
+  int pview = 0;
+  auto patch_offset = [&](int view, int i) -> unsigned {
     const int vadd = pool ? ((view >> 1) * 2 * p.Wl + (view & 1)) : 0;
-    for (int g = wave; g < ngroups; g += NW) {
-      const int pix = pix0 + 16 * (g - wave);
-      // POOL: view pixel -> fine pixel; out-of-range low-resolution indices (tile halo beyond the tensor) read zeros
-      const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
-      unsigned off = src * ldxb + (unsigned)(s * 64 + lc * 16);
-      off = ((unsigned)pix < (unsigned)p.J) ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + pbase + g * 1024), 16, (int)off, 0, 0, 0);
-    }
+    const int pix = pix0 + 64 * i;
+    // POOL: view pixel -> fine pixel; out-of-range low-resolution indices (tile halo beyond the tensor) read zeros
+    const unsigned src = pool ? (unsigned)(((pix >> p.wlog) << (p.wlog + 2)) + ((pix & wmask) << 1) + vadd) : (unsigned)pix;
+    return ((unsigned)pix < (unsigned)p.J) ? src * ldxb + (unsigned)(lc * 16) : 0x80000000u;
   };
-  // ---- weight DMA: BI rows x 32 channels of (view, slice s, tap t) ------------------------------------------------------------------
+  auto patch_offsets = [&](int view) {
+    pview = view;
+#pragma unroll
+    for (int i = 0; i < MAXPG; i++) pvo[i] = patch_offset(view, i);
+  };
+  auto patch_slice = [&](int s, int pbase = 0) {
+#pragma unroll
+    for (int i = 0; i < MAXPG; i++) {
+      const int g = wave + NW * i;
+      if (g < ngroups) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + pbase + g * 1024), 16, (int)pvo[i], s * 64, 0, 0);
+    }
+    for (int g = wave + NW * MAXPG; g < ngroups; g += NW)            // (Wl = 128 only: the eighth and ninth piece, offsets on the fly)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + pbase + g * 1024), 16, (int)patch_offset(pview, (g - wave) / NW), s * 64, 0, 0);
+  };
+  // ---- weight DMA: BI rows x 32 channels of (view, slice s, tap t): per-lane row offsets once per workgroup, (view, tap, slice) through the scalar offset ----
+  unsigned wvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = i0 + 16 * (wave + NW * i) + sub;
+    wvo[i] = (row < p.I) ? ((unsigned)row * (unsigned)p.K + (unsigned)(lc * 8)) * 2u : 0x80000000u;
+  }
   auto weight_tile = [&](int buf, int view, int s, int t) {
-    for (int g = wave; g < NWP; g += NW) {
-      const int row = i0 + 16 * g + sub;
-      unsigned off = ((unsigned)row * (unsigned)p.K + (unsigned)((view * 4 + t) * p.C + s * 32 + lc * 8)) * 2u;
-      off = (row < p.I) ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)off, 0, 0, 0);
+    const int so = ((view * 4 + t) * p.C + s * 32) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int g = wave + NW * i;
+      if (g < NWP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)wvo[i], so, 0, 0);
     }
   };
 
@@ -178,7 +201,29 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
   const int nvs = nv * nslice;
   const bool two = wave + NW < NWP;                                  // this wave issues two weight pieces per tap
   int view = pool ? 0 : ph, s = 0;
-  patch_slice(view, 0);
+  // patch fragment addresses of the four taps of a view (k-step 1 is the address ^ 32): they depend on the view's tap origin only -- computed once per
+  // view instead of once per tap (10 vector instructions per 32-pixel block and tap in the loop this replaces). Invalid taps (image border) read the zero line.
+  unsigned qat[4][TJ];
+  auto tap_addresses = [&](int view) {
+    const int ea = pool ? (view >> 1) : 1 - (view >> 1);
+    const int eb = pool ? (view & 1) : 1 - (view & 1);
+    const int org = -ea * p.Wl - eb;                                 // patch-row displacement of tap (0, 0)
+    const int vbit0 = (1 - ea) * 3 + (1 - eb);                       // validity bit of tap (0, 0)
+#pragma unroll
+    for (int t = 0; t < 4; t++) {
+      const int ti = t >> 1, tj = t & 1;
+#pragma unroll
+      for (int b = 0; b < TJ; b++) {
+        const int row = rb[b] + org + ti * p.Wl + tj;
+        unsigned a = ((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4);
+        a = ((qval[b] >> (vbit0 + ti * 3 + tj)) & 1u) ? a : (unsigned)p.zero_off;
+        qat[t][b] = a;
+      }
+    }
+  };
+  patch_offsets(view);
+  tap_addresses(view);
+  patch_slice(0);
   weight_tile(0, view, 0, 0);
   weight_tile(1, view, 0, 1);
   if (DB) weight_tile(2, view, 0, 2);
@@ -188,11 +233,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
     const unsigned pb = DB ? (unsigned)((vs & 1) * p.patchb) : 0u;
     int nview = view, ns = s + 1;
     if (ns == nslice) { ns = 0; nview = view + 1; }
-    // tap origin of this view on the low-resolution grid
-    const int ea = pool ? (view >> 1) : 1 - (view >> 1);
-    const int eb = pool ? (view & 1) : 1 - (view & 1);
-    const int org = -ea * p.Wl - eb;                                 // patch-row displacement of tap (0, 0)
-    const int vbit0 = (1 - ea) * 3 + (1 - eb);                       // validity bit of tap (0, 0)
 #pragma unroll
     for (int t = 0; t < 4; t++) {
       // weights of the tap after next: buffer (t + 2) % 4 was last read two taps ago, every wave is past two barriers since
@@ -200,7 +240,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
       if constexpr (DB) {
         if (t == 0) {
           weight_tile(3, view, s, 3);
-          if (next_slice) patch_slice(nview, ns, ((vs + 1) & 1) * p.patchb);
+          if (next_slice) {
+            if (ns == 0) patch_offsets(nview);       // (POOL form: the next slice belongs to the next view)
+            patch_slice(ns, ((vs + 1) & 1) * p.patchb);
+          }
         } else if (next_slice) {
           weight_tile(t - 1, nview, ns, t - 1);
         }
@@ -209,18 +252,6 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
         else if (next_slice) weight_tile(t - 2, nview, ns, t - 2);
       }
       const char* ps = pbufs + t * PB;
-      const int ti = t >> 1, tj = t & 1;                           // compile-time after unrolling
-      unsigned qa[TJ];
-#pragma unroll
-      for (int b = 0; b < TJ; b++) {
-        int row = rb[b] + org;
-        asm volatile("" : "+v"(row));
-        if (ti) row += p.Wl;
-        if (tj) row += 1;
-        unsigned a = pb + (((unsigned)row << 6) | ((unsigned)((fhi ^ (row >> 2)) & 3) << 4));
-        a = ((qval[b] >> (vbit0 + ti * 3 + tj)) & 1u) ? a : (unsigned)p.zero_off;
-        qa[b] = a;
-      }
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
         bf16x8_t pf[TI], qf[TJ];
@@ -231,7 +262,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
         }
 #pragma unroll
         for (int b = 0; b < TJ; b++) {
-          u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
+          unsigned qaddr = qat[t][b] ^ (unsigned)(ks * 32);
+          if constexpr (DB) qaddr += (qaddr < (unsigned)p.zero_off) ? pb : 0u;      // (the zero line is not double-buffered)
+          u32x4 v = *(const u32x4*)(smem + qaddr);
           if (RELU) v = relu16<bf16_t>(v);
           qf[b] = __builtin_bit_cast(bf16x8_t, v);
         }
@@ -252,11 +285,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
           else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();
+        if (t == 3 && next_slice && ns == 0) tap_addresses(nview);
       } else if (t == 3 && next_slice) {
         // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
         // workgroup; the other two workgroups of the CU keep the matrix pipe busy)
         __syncthreads();
-        patch_slice(nview, ns);
+        if (ns == 0) { patch_offsets(nview); tap_addresses(nview); }      // (POOL form: the next slice belongs to the next view)
+        patch_slice(ns);
         __syncthreads();
       } else {
         if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

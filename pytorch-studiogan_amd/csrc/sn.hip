@@ -301,23 +301,45 @@ template <typename T> static void sn_pack_launch(const sg_sn_layer* layers_dev, 
   }
 }
 
-extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s) {
-  SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_forward: bad args");
+// layers [i0, i1) of a table: the launch sequence of one forward (power iteration, sigma, operand images)
+template <typename T> static void sn_forward_range(const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, hipStream_t st) {
   int max_rows = 1, max_cols = 1, max_rows_out = 1; long long max_elems = 1; bool any_sn = false, any_pi = false;
   for (int i = 0; i < n; i++) {
     const sg_sn_layer& l = layers_host[i];
-    SG_CHECK(l.w && l.sigma && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_forward: bad layer");
-    if (l.apply_sn) {
-      SG_CHECK(l.u && l.v, "sg_sn_forward: SN layer without u/v");
-      SG_CHECK(l.work_off >= 0 && l.work_off + (long long)SN_SPLITS * l.cols + l.rows <= work_floats, "sg_sn_forward: workspace too small");
-      any_sn = true; if (l.do_power_iter) any_pi = true;
-    }
+    if (l.apply_sn) { any_sn = true; if (l.do_power_iter) any_pi = true; }
     if (l.rows > max_rows) max_rows = l.rows;
     if (l.cols > max_cols) max_cols = l.cols;
     const int ro = l.rows_pad > l.rows ? l.rows_pad : l.rows;
     if (ro > max_rows_out) max_rows_out = ro;
     const long long e = (long long)ro * l.cols;
     if (e > max_elems) max_elems = e;
+  }
+  if (any_pi) {
+    hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 1023) / 1024, SN_SPLITS, n), dim3(256), 0, st, layers_dev, work);
+    hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  }
+  if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, n), dim3(256), 0, st, layers_dev, work);
+  hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  sn_pack_launch<T>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
+}
+// SG_SN_CHUNK_MB=<n> (default 96; 0 = the whole table at once): the table is walked in runs of consecutive layers of <= n MB of fp32 weights, each run through
+// its whole launch sequence before the next starts. A forward reads every weight three to four times (W^T u, W v, the two packing passes); with the whole
+// table per launch (350 MB for BigGAN's D) each pass streams from HBM, with runs that fit the 256 MB Infinity Cache the later passes of a run find its
+// weights on the die (MI355X_MICROARCH.md, Infinity Cache). More launches (5-6 per run), same arithmetic, same results: every reduction is per layer.
+static long long sn_chunk_bytes() {
+  static const long long v = [] { const char* e = getenv("SG_SN_CHUNK_MB"); const long long mb = e ? atoll(e) : 96; return mb <= 0 ? (1ll << 60) : mb * (1ll << 20); }();
+  return v;
+}
+extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s) {
+  SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_forward: bad args");
+  SG_CHECK(dtype == SG_DTYPE_F32 || dtype == SG_DTYPE_BF16, "sg_sn_forward: bad dtype");
+  for (int i = 0; i < n; i++) {
+    const sg_sn_layer& l = layers_host[i];
+    SG_CHECK(l.w && l.sigma && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_forward: bad layer");
+    if (l.apply_sn) {
+      SG_CHECK(l.u && l.v, "sg_sn_forward: SN layer without u/v");
+      SG_CHECK(l.work_off >= 0 && l.work_off + (long long)SN_SPLITS * l.cols + l.rows <= work_floats, "sg_sn_forward: workspace too small");
+    }
   }
   hipStream_t st = (hipStream_t)s;
   double bytes = 0.0;      // algorithmic: W^T u and W v read the fp32 weight once each, the pack reads it again and writes the operand images
@@ -327,15 +349,14 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
     bytes += e * (4.0 * ((l.apply_sn && l.do_power_iter ? 1 : 0) + (l.apply_sn ? 1 : 0) + 1) + (l.w_fwd ? es : 0.0) + (l.w_dgrad ? es : 0.0) + (l.w_f32 ? 4.0 : 0.0));
   }
   SgProfScope prof(st, bytes, 3);
-  if (any_pi) {
-    hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 1023) / 1024, SN_SPLITS, n), dim3(256), 0, st, layers_dev, work);
-    hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  const long long chunk = sn_chunk_bytes();
+  for (int i0 = 0; i0 < n;) {
+    int i1 = i0; long long b = 0;
+    while (i1 < n && (i1 == i0 || b + 4ll * layers_host[i1].rows * layers_host[i1].cols <= chunk)) { b += 4ll * layers_host[i1].rows * layers_host[i1].cols; i1++; }
+    if (dtype == SG_DTYPE_F32) sn_forward_range<float>(layers_dev + i0, layers_host + i0, i1 - i0, eps, work, st);
+    else sn_forward_range<bf16_t>(layers_dev + i0, layers_host + i0, i1 - i0, eps, work, st);
+    i0 = i1;
   }
-  if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, n), dim3(256), 0, st, layers_dev, work);
-  hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
-  if (dtype == SG_DTYPE_F32) sn_pack_launch<float>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
-  else if (dtype == SG_DTYPE_BF16) sn_pack_launch<bf16_t>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
-  else { sg_set_error("sg_sn_forward: bad dtype"); return -1; }
   SG_LAUNCH_CHECK();
   return 0;
 }
@@ -500,31 +521,42 @@ __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, con
 extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s) {
   SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_backward: bad args");
   SG_CHECK((long long)n * SNB_BLOCKS <= work_floats, "sg_sn_backward: workspace too small");
-  long long max_elems = 1; bool any_sn = false;
   for (int i = 0; i < n; i++) {
     const sg_sn_bwd_layer& l = layers_host[i];
     SG_CHECK(l.dwt && l.dw && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_backward: bad layer");
-    if (l.apply_sn) { SG_CHECK(l.w && l.u && l.v && l.sigma, "sg_sn_backward: SN layer without state"); any_sn = true; }
-    const long long e = (long long)l.rows * l.cols;
-    if (e > max_elems) max_elems = e;
+    if (l.apply_sn) SG_CHECK(l.w && l.u && l.v && l.sigma, "sg_sn_backward: SN layer without state");
   }
   hipStream_t st = (hipStream_t)s;
   double bytes = 0.0;      // dot: dWt + W; apply: dWt + read-modify-write of dW
   for (int i = 0; i < n; i++) bytes += (double)layers_host[i].rows * layers_host[i].cols * 4.0 * ((layers_host[i].apply_sn ? 2 : 0) + 3);
   SgProfScope prof(st, bytes, 3);
-  bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false;
-  for (int i = 0; i < n; i++) {
-    const sg_sn_bwd_layer& l = layers_host[i];
-    if (snb_row_ok(l)) { any_row = true; if (l.apply_sn) any_row_sn = true; }
-    else { any_old = true; if (l.apply_sn) any_old_sn = true; }
+  // runs of consecutive layers whose gradient scratch fits the Infinity Cache (see sg_sn_forward): the apply pass of a run re-reads the dWt its dot pass has
+  // just streamed. The block partials of <dWt, W> are indexed by the layer's position inside its run: one run at a time on the stream, no overlap.
+  const long long chunk = sn_chunk_bytes();
+  for (int i0 = 0; i0 < n;) {
+    int i1 = i0; long long b = 0;
+    while (i1 < n && (i1 == i0 || b + 4ll * layers_host[i1].rows * layers_host[i1].cols <= chunk)) { b += 4ll * layers_host[i1].rows * layers_host[i1].cols; i1++; }
+    const sg_sn_bwd_layer* ld = layers_dev + i0;
+    const sg_sn_bwd_layer* lh = layers_host + i0;
+    const int m = i1 - i0;
+    long long max_elems = 1;
+    bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false;
+    for (int i = 0; i < m; i++) {
+      const sg_sn_bwd_layer& l = lh[i];
+      const long long e = (long long)l.rows * l.cols;
+      if (e > max_elems) max_elems = e;
+      if (snb_row_ok(l)) { any_row = true; if (l.apply_sn) any_row_sn = true; }
+      else { any_old = true; if (l.apply_sn) any_old_sn = true; }
+    }
+    if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
+    if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
+    if (any_old) {
+      long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+      hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, m), dim3(256), 0, st, ld, (const float*)work);
+    }
+    if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
+    i0 = i1;
   }
-  if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
-  if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
-  if (any_old) {
-    long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
-    hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work);
-  }
-  if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, n), dim3(256), 0, st, layers_dev, work);
   SG_LAUNCH_CHECK();
   return 0;
 }

@@ -41,11 +41,16 @@ def to_nchw(y):
     return y.permute(0, 3, 1, 2)
 
 
+BLOCK_HOOKS = [False]      # flipped by tests/test_blocks_gpu.py while a teacher is installed: the forward of a network carries no per-block lookup otherwise
+
+
 def block_boundary(net, bi, act):
-    """Block boundary `bi` of a backbone's forward (-1: in front of the first block). A no-op unless a test installed a teacher on the network
-    (`net._sg_teacher`, tests/test_blocks_gpu.py TeacherForcing): then the activation is handed to it -- it records the block's output and may
-    return the tensor the NEXT block is to read instead (teacher forcing: every block sees the emulating oracle's input and upstream gradient,
-    nothing compounds across blocks)."""
+    """Block boundary `bi` of a backbone's forward (-1: in front of the first block). The identity unless a test has switched BLOCK_HOOKS on AND installed a
+    teacher on the network (`net._sg_teacher`, tests/test_blocks_gpu.py TeacherForcing): then the activation is handed to it -- it records the block's output
+    and may return the tensor the NEXT block is to read instead (teacher forcing: every block sees the emulating oracle's input and upstream gradient, nothing
+    compounds across blocks)."""
+    if not BLOCK_HOOKS[0]:
+        return act
     tf = net.__dict__.get("_sg_teacher")
     return act if tf is None else tf(bi, act)
 

@@ -7,11 +7,14 @@ Units / corrections (MI355X_MICROARCH.md §HBM): FETCH_SIZE and WRITE_SIZE are i
 bytes of a wide coalesced read stream (TCC_EA0_RDREQ tallied at 64 B for 128-B requests), so the read side is doubled."""
 import csv
 import json
+import os
 import re
 import sys
 
-CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_conv_rs96_kernel|sg_conv_q_kernel|sg_wgrad_q_kernel|k_quad_reduce_fold|"
-                  r"sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+CONV = re.compile(r"sg_conv_v2_kernel|sg_conv_v3_kernel|sg_conv_v4_kernel|sg_conv_sk_kernel|sg_conv_rs_kernel|sg_conv_rs96_kernel|sg_conv_q_kernel|sg_wgrad_q_kernel|sg_wgrad_ql_kernel|k_quad_reduce_fold|"
+                  r"sg_wgrad_v2_kernel|sg_wgrad_v3_kernel|sg_wgrad_v3l_kernel|sg_wgrad_sk_kernel|k_splitk_reduce|sg_gemm_kernel<.*ConvPix")
 
 
 def collect(path, counter):
@@ -25,6 +28,12 @@ def collect(path, counter):
             a[0] += 1
             a[1] += float(r["Counter_Value"])
     return per
+
+
+def csrc_sha():
+    """hash of the kernel sources the traced library was built from (bench.py compares it with its own: a summary of other sources is reported as stale)"""
+    import bench
+    return bench.csrc_sha16()
 
 
 def main():
@@ -44,7 +53,7 @@ def main():
     print(json.dumps({"kernel_family": "convolution engine (sg_conv_v4 / sg_conv_v3 / sg_conv_v2 / sg_conv_sk / sg_conv_rs / sg_wgrad_v3 / sg_wgrad_v2 / sg_wgrad_sk / sg_gemm_kernel<ConvPix*>)", "launches": tot_n,
                       "hbm_bytes_per_launch": round(tot_b / max(tot_n, 1)), "read_side_doubled": True,
                       "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes) over bench.py --steps 2 --warmup 1 --no-extras --fid-samples 0 --no-cpu-baseline; launches = sg_conv2d_fwd / sg_conv2d_wgrad calls (a weight-gradient launch includes its split-K reduce)",
-                      "per_kernel": rows}, indent=1))
+                      "csrc_sha16": csrc_sha(), "per_kernel": rows}, indent=1))
 
 
 if __name__ == "__main__":
