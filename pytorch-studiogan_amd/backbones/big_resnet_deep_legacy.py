@@ -38,15 +38,17 @@ class GenBlock(nn.Module):
         self.conv2d4 = MODULES.g_conv2d(in_channels=self.hidden_channels, out_channels=self.out_channels, kernel_size=1, stride=1, padding=0)
 
     def forward_nhwc(self, x, affine, slot):
-        h = self.bn1.forward_nhwc(x, affine, slot, relu=True)
+        # x feeds bn1 and the channel-slice skip: bn1's backward adds the skip's gradient in its own launch (functional.GradLink)
+        link = F.GradLink() if (F._GRAD_LINK[0] and torch.is_grad_enabled() and x.requires_grad) else None
+        h = self.bn1.forward_nhwc(x, affine, slot, relu=True, link=link)
         h = self.conv2d1.forward_nhwc(h, slot)
         h = self.bn2.forward_nhwc(h, affine, slot, relu=True)
         h = self.conv2d2.forward_nhwc(h, slot, in_upsample=self.upsample, stats=self.upsample)      # (bn3's statistics from the quad launch's epilogue)
         h = self.bn3.forward_nhwc(h, affine, slot, relu=True)
         h = self.conv2d3.forward_nhwc(h, slot)
         h = self.bn4.forward_nhwc(h, affine, slot, relu=True)
-        if self.upsample or self.in_channels != self.out_channels:
-            x0 = F.SliceUpFn.apply(x, self.out_channels, 2 if self.upsample else 1)
+        if self.upsample or self.in_channels != self.out_channels or link is not None:
+            x0 = F.SliceUpFn.apply(x, self.out_channels, 2 if self.upsample else 1, link)
         else:
             x0 = x
         return self.conv2d4.forward_nhwc(h, slot, res=x0)
@@ -150,10 +152,12 @@ class DiscBlock(nn.Module):
 
     def forward_nhwc(self, x, slot):
         # nn.ReLU(inplace=True) on the block input also rewrites the skip tensor (same storage): x0 = relu(x)
-        h = self.conv2d1.forward_nhwc(x, slot, in_relu=True)
+        # x feeds conv2d1 and the skip: conv2d1's data-gradient launch takes the skip's (masked) gradient as its residual (functional.GradLink)
+        link = F.GradLink() if (F._GRAD_LINK[0] and torch.is_grad_enabled() and x.requires_grad) else None
+        h = self.conv2d1.forward_nhwc(x, slot, in_relu=True, link=link)
         h = self.conv2d2.forward_nhwc(h, slot, in_relu=True)
         h = self.conv2d3.forward_nhwc(h, slot, in_relu=True)
-        x0 = F.ReluFn.apply(x)
+        x0 = F.ReluFn.apply(x, link)
         if self.downsample:
             x0 = F.AvgPool2Fn.apply(x0)
         if self.learnable_sc:

@@ -15,6 +15,7 @@ MI355X-first layout of the *weight side* of the hot path:
 Parameter names/shapes stay exactly the reference's (`weight_orig`, `weight_u`, `weight_v`, `bias`, ...), so
 `state_dict()` / `load_state_dict(strict=True)` interchange with StudioGAN checkpoints (reference src/utils/ckpt.py:38).
 """
+import ctypes
 import os
 import weakref
 
@@ -253,7 +254,7 @@ class WeightBank:
             r.param_off = arena_of(r.param)[1]        # position of the master weight in the flat arena (exchange ranges)
             m._sg_rt = r
             self.layers.append(r)
-        self.work = torch.zeros(max(work, self.SNB_BLOCKS * len(layers)) + 64, device=dev, dtype=torch.float32)
+        self.work = torch.zeros(max(work, 4096 * len(layers)) + 64, device=dev, dtype=torch.float32)      # (4096: csrc/sn.hip SNB_MAX, the ceiling of SG_SNB_BLOCKS)
         self._sizes = (img_elems, f32_elems, dwt_elems, uv_elems)
         self.slots = []
         for s in range(nslots):
@@ -349,15 +350,23 @@ class WeightBank:
 
     # -- forward ------------------------------------------------------------------------------------------
     def _desc(self, slot, flags):
+        """-> (host table, device table, groups): the layers in table order = convolutions first, then linear / embedding layers; groups = [(first, count)] of
+        the two runs. sg_sn_forward sizes its launches by the largest layer of the table it is given: one [24576 x 20] linear layer (a generator's linear0) in
+        a table of [1536 x 13824] convolutions made k_sn_pack_dgrad a grid of 1.7 M workgroups, 97 % of them empty (869 us per generator forward, round 5:
+        tools/sn_bench.py) -- each kind gets its own call."""
         ent = slot.desc_cache.get(flags)
         if ent is not None:
             return ent
         n = len(self.layers)
         arr = (L.SnLayer * n)()
         es = self.es
-        for r, pi in zip(self.layers, flags):
+        order = [r for r in self.layers if r.kind == "conv"] + [r for r in self.layers if r.kind != "conv"]
+        nconv = sum(1 for r in self.layers if r.kind == "conv")
+        pi_of = {r.index: pi for r, pi in zip(self.layers, flags)}
+        for pos, r in enumerate(order):
+            pi = pi_of[r.index]
             m = r.module()
-            d = arr[r.index]
+            d = arr[pos]
             d.w = r.param.data_ptr()
             if r.apply_sn:
                 d.u, d.v = m.weight_u.data_ptr(), m.weight_v.data_ptr()
@@ -375,7 +384,14 @@ class WeightBank:
             d.trans, d.dgrad_noflip = r.trans, r.noflip
             d.Cin_pad = r.cin_pad
         dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
-        ent = (arr, dev_tab)
+        groups = [g for g in ((0, nconv), (nconv, n - nconv)) if g[1] > 0]
+        if len(groups) == 2:
+            # (a second call costs ~30 us of launches: taken only when a linear / embedding layer would inflate the convolutions' grids -- BigGAN's generator;
+            # its discriminator's [1000 x 1536] embedding and [1 x 1536] linear sit inside the convolutions' extent and stay in their table)
+            cr, cc = max(r.rows for r in order[:nconv]), max(r.cols for r in order[:nconv])
+            if all(r.rows <= cr and r.cols <= cc for r in order[nconv:]):
+                groups = [(0, n)]
+        ent = (arr, dev_tab, groups)
         slot.desc_cache[flags] = ent
         return ent
 
@@ -424,9 +440,11 @@ class WeightBank:
             self._fwd_train_epoch += 1          # the power iteration of this forward moves u / v
         if not need_graph:
             slot.emit_key = key
-        arr, dev_tab = self._desc(slot, flags)
-        L.call("sg_sn_forward", self.sgdt, dev_tab.data_ptr(), arr, len(self.layers), self.eps, self.work.data_ptr(),
-               self.work.numel(), L.stream())
+        arr, dev_tab, groups = self._desc(slot, flags)
+        esz = ctypes.sizeof(L.SnLayer)
+        for first, count in groups:
+            L.call("sg_sn_forward", self.sgdt, dev_tab.data_ptr() + first * esz, ctypes.cast(ctypes.addressof(arr) + first * esz, ctypes.POINTER(L.SnLayer)), count, self.eps, self.work.data_ptr(),
+                   self.work.numel(), L.stream())
         self._fwd_counter = self.__dict__.get("_fwd_counter", 0) + 1
         slot.fwd_id = self._fwd_counter      # (handle and physical slot share one attribute dict)
         self._pack_quad(slot, (0, 1, 4, 5))  # the forward quad images this network is known to use (csrc/conv_q.h), one launch

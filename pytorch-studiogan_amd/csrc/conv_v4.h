@@ -57,7 +57,8 @@ struct ConvV4Params {
 // table: the counted wait in front of a tap's barrier is not the weight tile's latency.
 template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
-  static_assert(!SKIP || (!UP && TJW == 2), "the fused skip is built for the plain 256-pixel tile");
+  static_assert(TJW == 2, "256-pixel tiles (the 512-pixel instantiation was measured no faster and removed in round 5)");
+  static_assert(!SKIP || !UP, "the fused skip is built for the plain tile");
   constexpr int BI = 32 * NB, BJ = 128 * TJW, NW = 4, TI = NB, TJ = TJW;
   constexpr int PB = BI * 64;                  // one weight tile (BI couts x 32 channels)
   constexpr int NWP = BI / 16;                 // weight DMA pieces per tap (16 rows each): 6 or 4
@@ -96,22 +97,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   const int P0 = (UP ? (j0 >> 2) : j0) - p.W - 8;                    // raster index of patch row 0
   const int ngroups = p.npx >> 4;
   const int pix0 = P0 + 16 * wave + sub;
-  auto patch_slice = [&](int s) {
-    for (int g = wave; g < ngroups; g += NW) {
-      const int pix = pix0 + 16 * (g - wave);
-      const int lce = lc ^ ((pix >> p.psh) & p.pm2);
-      unsigned off = (unsigned)pix * ldx2 + (unsigned)(s * 64 + lce * 16);
-      off = ((unsigned)pix < (unsigned)p.npix_src) ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)off, 0, 0, 0);
-    }
+  // (round 5, as conv_q.h: what a lane's LDS-DMA pieces read differs from slice to slice by a wave-uniform channel offset only -- the per-lane byte offsets,
+  // bounds decision included, are computed once per workgroup and the slice / tap offset rides in the instruction's scalar offset; the loop this replaces
+  // re-derived ~8 vector instructions per piece, one of them a quarter-rate multiply, for each of the 6-11 pieces of a slice)
+  constexpr int MAXPG = 7;                           // pieces per wave held in registers: (BJ + 2 W + 16) / 64 rounded up for W <= 64
+  unsigned pvo[MAXPG];
+  auto patch_offset = [&](int i) -> unsigned {
+    const int pix = pix0 + 64 * i;
+    const int lce = lc ^ ((pix >> p.psh) & p.pm2);
+    return ((unsigned)pix < (unsigned)p.npix_src) ? (unsigned)pix * ldx2 + (unsigned)(lce * 16) : 0x80000000u;
   };
-  // ---- weight DMA: BI rows x 32 channels of (slice s, tap t) ----------------------------------------------------------------------
+#pragma unroll
+  for (int i = 0; i < MAXPG; i++) pvo[i] = patch_offset(i);
+  auto patch_slice = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < MAXPG; i++) {
+      const int g = wave + NW * i;
+      if (g < ngroups) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)pvo[i], s * 64, 0, 0);
+    }
+    for (int g = wave + NW * MAXPG; g < ngroups; g += NW)            // (wider images only: offsets on the fly)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsx, (sg_lptr_t)(smem + g * 1024), 16, (int)patch_offset((g - wave) / NW), s * 64, 0, 0);
+  };
+  // ---- weight DMA: BI rows x 32 channels of (slice s, tap t): per-lane row offsets once per workgroup ---------------------------------
+  unsigned wvo[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int row = i0 + 16 * (wave + NW * i) + sub;
+    wvo[i] = (row < p.I) ? ((unsigned)row * (unsigned)p.K + (unsigned)(lc * 8)) * 2u : 0x80000000u;
+  }
   auto weight_tile = [&](int buf, int s, int t) {
-    for (int g = wave; g < NWP; g += NW) {
-      const int row = i0 + 16 * g + sub;
-      unsigned off = ((unsigned)row * (unsigned)p.K + (unsigned)(t * p.C + s * 32 + lc * 8)) * 2u;
-      off = (row < p.I) ? off : 0x80000000u;
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)off, 0, 0, 0);
+    const int so = (t * p.C + s * 32) * 2;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const int g = wave + NW * i;
+      if (g < NWP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rsw, (sg_lptr_t)(pbufs + buf * PB + g * 1024), 16, (int)wvo[i], so, 0, 0);
     }
   };
 

@@ -37,12 +37,11 @@ bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc*
   if (e.res && ((e.flags & SG_EPI_RES_F32) || (e.ldr & 7) || !aligned16(e.res))) return false;
   int NB;
   if (I % 96 == 0) NB = 3; else if (I % 64 == 0) NB = 2; else return false;
-  // SG_CONV_V4_BJ=512: the 512-pixel tile (12 accumulator blocks per wave, two workgroups per CU) where the shape allows it (A/B switch)
-  const char* bj = getenv("SG_CONV_V4_BJ");
-  int BJ = (bj && bj[0] == '5' && !sk) ? 512 : 256;
-  if (BJ == 512 && (J % 512 || ((quad || up) && (512 % (2 * d->Wo))))) BJ = 256;
+  // (a 512-pixel tile -- 12 accumulator blocks per wave, two workgroups per CU -- ran no faster than this one in round 2, profiles/r02_conv_layer_table_v4_bj512_q.txt,
+  // and again on conv_q.h in round 5: removed)
+  const int BJ = 256;
   const int tiles = (I / (32 * NB)) * ((J + BJ - 1) / BJ);
-  if (!force && tiles < (BJ == 512 ? 512 : 768)) return false;   // one full wave of workgroups (two / three per CU)
+  if (!force && tiles < 768) return false;   // one full wave of workgroups (three per CU)
   if ((quad || up || (sk && sk->x2_up)) && (BJ % (2 * d->Wo))) return false;         // the tile must cover whole pairs of image rows
   if (J % d->Wo) return false;
   if (dry) return true;
@@ -72,8 +71,5 @@ bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc*
     p.x2bytes = (unsigned)x2bytes; p.w2bytes = (unsigned)w2bytes;
     return (NB == 3 ? sg_launch_conv_v4_skip<3>(p, e, st) : sg_launch_conv_v4_skip<2>(p, e, st)) == 0;
   }
-  int rc;
-  if (BJ == 512) rc = NB == 3 ? sg_launch_conv_v4<3, 4>(p, e, st) : sg_launch_conv_v4<2, 4>(p, e, st);
-  else rc = NB == 3 ? sg_launch_conv_v4<3, 2>(p, e, st) : sg_launch_conv_v4<2, 2>(p, e, st);
-  return rc == 0;
+  return (NB == 3 ? sg_launch_conv_v4<3, 2>(p, e, st) : sg_launch_conv_v4<2, 2>(p, e, st)) == 0;
 }

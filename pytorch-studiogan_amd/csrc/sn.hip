@@ -290,11 +290,17 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(con
 }
 template <typename T> static void sn_pack_launch(const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, int max_rows_out, int max_rows, int max_cols, long long max_elems, hipStream_t st) {
   bool any_dg = false;
-  for (int i = 0; i < n; i++) if (layers_host[i].w_dgrad) any_dg = true;
+  int dg_rows = 1, dg_cols = 1;      // the data-gradient images' launch is sized by the layers that HAVE one
+  for (int i = 0; i < n; i++)
+    if (layers_host[i].w_dgrad) {
+      any_dg = true;
+      if (layers_host[i].rows > dg_rows) dg_rows = layers_host[i].rows;
+      if (layers_host[i].cols > dg_cols) dg_cols = layers_host[i].cols;
+    }
   if ((size_t)max_cols * sizeof(T) <= 60 * 1024) {
     int gx = max_rows_out; if (gx > 2048) gx = 2048;
     hipLaunchKernelGGL(k_sn_pack_rows<T>, dim3(gx, n), dim3(256), (size_t)max_cols * sizeof(T), st, layers_dev);
-    if (any_dg) hipLaunchKernelGGL(k_sn_pack_dgrad<T>, dim3((max_cols + 127) / 128, (max_rows + 63) / 64, n), dim3(256), 0, st, layers_dev);
+    if (any_dg) hipLaunchKernelGGL(k_sn_pack_dgrad<T>, dim3((dg_cols + 127) / 128, (dg_rows + 63) / 64, n), dim3(256), 0, st, layers_dev);
   } else {
     long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
     hipLaunchKernelGGL(k_sn_pack<T>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
@@ -322,14 +328,11 @@ template <typename T> static void sn_forward_range(const sg_sn_layer* layers_dev
   hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
   sn_pack_launch<T>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
 }
-// SG_SN_CHUNK_MB=<n> (default 96; 0 = the whole table at once): the table is walked in runs of consecutive layers of <= n MB of fp32 weights, each run through
-// its whole launch sequence before the next starts. A forward reads every weight three to four times (W^T u, W v, the two packing passes); with the whole
-// table per launch (350 MB for BigGAN's D) each pass streams from HBM, with runs that fit the 256 MB Infinity Cache the later passes of a run find its
-// weights on the die (MI355X_MICROARCH.md, Infinity Cache). More launches (5-6 per run), same arithmetic, same results: every reduction is per layer.
-static long long sn_chunk_bytes() {
-  static const long long v = [] { const char* e = getenv("SG_SN_CHUNK_MB"); const long long mb = e ? atoll(e) : 96; return mb <= 0 ? (1ll << 60) : mb * (1ll << 20); }();
-  return v;
-}
+// (Round 5, measured and removed: walking the table in runs of layers that fit the 256 MB Infinity Cache, each run through its whole launch sequence, so that the
+// later passes of a run would find its weights on the die -- SLOWER on the D table, forward 430 -> 512 us and backward 588 -> 1177 us: the extra launches cost
+// more than the cache returns. What does pay is keeping layers of very different shapes out of one launch: the grids are sized by the largest layer of the
+// table, and one [24576 x 20] linear layer next to [1536 x 13824] convolutions turned k_sn_pack_dgrad into 1.7 M workgroups, all but 50 k of them empty
+// (generator forward 869 us): bank.py hands the convolutions and the linear / embedding layers over as separate tables.)
 extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s) {
   SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_forward: bad args");
   SG_CHECK(dtype == SG_DTYPE_F32 || dtype == SG_DTYPE_BF16, "sg_sn_forward: bad dtype");
@@ -349,20 +352,15 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
     bytes += e * (4.0 * ((l.apply_sn && l.do_power_iter ? 1 : 0) + (l.apply_sn ? 1 : 0) + 1) + (l.w_fwd ? es : 0.0) + (l.w_dgrad ? es : 0.0) + (l.w_f32 ? 4.0 : 0.0));
   }
   SgProfScope prof(st, bytes, 3);
-  const long long chunk = sn_chunk_bytes();
-  for (int i0 = 0; i0 < n;) {
-    int i1 = i0; long long b = 0;
-    while (i1 < n && (i1 == i0 || b + 4ll * layers_host[i1].rows * layers_host[i1].cols <= chunk)) { b += 4ll * layers_host[i1].rows * layers_host[i1].cols; i1++; }
-    if (dtype == SG_DTYPE_F32) sn_forward_range<float>(layers_dev + i0, layers_host + i0, i1 - i0, eps, work, st);
-    else sn_forward_range<bf16_t>(layers_dev + i0, layers_host + i0, i1 - i0, eps, work, st);
-    i0 = i1;
-  }
+  if (dtype == SG_DTYPE_F32) sn_forward_range<float>(layers_dev, layers_host, n, eps, work, st);
+  else sn_forward_range<bf16_t>(layers_dev, layers_host, n, eps, work, st);
   SG_LAUNCH_CHECK();
   return 0;
 }
 
 // ---- backward: dW = (dWt - <dWt, W/sigma> u v^T) / sigma --------------------------------------------------
-#define SNB_BLOCKS 512     // block partials of <dWt, W> per layer (64 blocks left 3/4 of the chip idle on the big layers: 0.97 TB/s)
+#define SNB_BLOCKS 512     // block partials of <dWt, W> per layer (64 blocks left 3/4 of the chip idle on the big layers: 0.97 TB/s); SG_SNB_BLOCKS=<n> (<= SNB_MAX, A/B switch)
+#define SNB_MAX 4096
 __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int o, int k) {
   if (l.natural == 1) return (long long)o * l.cols + k;
   const int c = k / l.RS, rs = k - c * l.RS;
@@ -388,7 +386,7 @@ __host__ __device__ __forceinline__ bool snb_row_ok(const sg_sn_bwd_layer& l) {
   return (cp % 4 == 0) && ((reinterpret_cast<uintptr_t>(l.dwt) & 15) == 0) && l.RS <= 16;
 }
 // grid (SNB_BLOCKS, layers); APPLY = false: block partials of <dWt, W> into work; true: dw += (dWt - coef u v^T) / sigma
-template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg_sn_bwd_layer* L, float* work) {
+template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg_sn_bwd_layer* L, float* work, int nb) {
   __shared__ __attribute__((aligned(16))) float tile[16 * SNB_ST];
   __shared__ float sm[4];
   __shared__ float coef_sm;
@@ -400,7 +398,7 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg
     sig = l.sigma[0];
     if (threadIdx.x < 64) {      // fixed-order sum of the block partials (every block computes the same value)
       float t = 0.f;
-      for (int b = threadIdx.x; b < SNB_BLOCKS; b += 64) t += work[(long long)blockIdx.y * SNB_BLOCKS + b];
+      for (int b = threadIdx.x; b < nb; b += 64) t += work[(long long)blockIdx.y * nb + b];
       t = wave_sum(t);
       if (threadIdx.x == 0) coef_sm = t;
     }
@@ -462,11 +460,11 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg
   }
   if (!APPLY) {
     acc = block_sum_256(acc, sm);
-    if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
+    if (threadIdx.x == 0) work[(long long)blockIdx.y * nb + blockIdx.x] = acc;
   }
 }
 // grid (SNB_BLOCKS, layers): block partials of <dWt, W>
-__global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float* work) {
+__global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float* work, int nb) {
   __shared__ float sm[4];
   const sg_sn_bwd_layer l = L[blockIdx.y];
   if (!l.apply_sn || snb_row_ok(l)) return;
@@ -475,22 +473,22 @@ __global__ __launch_bounds__(256) void k_snb_dot(const sg_sn_bwd_layer* L, float
   const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
   if (l.natural == 0 && cp == l.Cin) {
     // walk dwt in ITS order ([o][rs][c], contiguous reads of the big scratch) and gather w ([o][c][rs], L2-friendly 9-float strides)
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += nb * 256ll) {
       const int o = (int)(i / l.cols), j = (int)(i % l.cols);
       const int rs = j / l.Cin, c = j - rs * l.Cin;
       acc += l.dwt[i] * l.w[sn_widx(l, o, c * l.RS + rs)];
     }
   } else {
-    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += SNB_BLOCKS * 256ll) {
+    for (long long i = blockIdx.x * 256ll + threadIdx.x; i < total; i += nb * 256ll) {
       const int o = (int)(i / l.cols), k = (int)(i % l.cols);
       acc += l.dwt[snb_src_index(l, o, k)] * l.w[sn_widx(l, o, k)];
     }
   }
   acc = block_sum_256(acc, sm);
-  if (threadIdx.x == 0) work[(long long)blockIdx.y * SNB_BLOCKS + blockIdx.x] = acc;
+  if (threadIdx.x == 0) work[(long long)blockIdx.y * nb + blockIdx.x] = acc;
 }
 // grid (tiles, layers)
-__global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, const float* work) {
+__global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, const float* work, int nb) {
   const sg_sn_bwd_layer l = L[blockIdx.y];
   if (snb_row_ok(l)) return;
   const long long total = (long long)l.rows * l.cols;
@@ -502,7 +500,7 @@ __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, con
     __shared__ float coef_sm;
     if (threadIdx.x < 64) {
       float t = 0.f;
-      for (int b = threadIdx.x; b < SNB_BLOCKS; b += 64) t += work[(long long)blockIdx.y * SNB_BLOCKS + b];
+      for (int b = threadIdx.x; b < nb; b += 64) t += work[(long long)blockIdx.y * nb + b];
       t = wave_sum(t);
       if (threadIdx.x == 0) coef_sm = t;
     }
@@ -520,7 +518,10 @@ __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, con
 }
 extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s) {
   SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_backward: bad args");
-  SG_CHECK((long long)n * SNB_BLOCKS <= work_floats, "sg_sn_backward: workspace too small");
+  static const int nb_env = [] { const char* e = getenv("SG_SNB_BLOCKS"); const int v = e ? atoi(e) : SNB_BLOCKS; return v < 64 ? 64 : (v > SNB_MAX ? SNB_MAX : v); }();
+  int nb = nb_env;
+  while (nb > SNB_BLOCKS && (long long)n * nb > work_floats) nb >>= 1;
+  SG_CHECK((long long)n * nb <= work_floats, "sg_sn_backward: workspace too small");
   for (int i = 0; i < n; i++) {
     const sg_sn_bwd_layer& l = layers_host[i];
     SG_CHECK(l.dwt && l.dw && l.rows > 0 && l.cols > 0 && l.RS > 0 && l.Cin * l.RS == l.cols, "sg_sn_backward: bad layer");
@@ -530,33 +531,22 @@ extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd
   double bytes = 0.0;      // dot: dWt + W; apply: dWt + read-modify-write of dW
   for (int i = 0; i < n; i++) bytes += (double)layers_host[i].rows * layers_host[i].cols * 4.0 * ((layers_host[i].apply_sn ? 2 : 0) + 3);
   SgProfScope prof(st, bytes, 3);
-  // runs of consecutive layers whose gradient scratch fits the Infinity Cache (see sg_sn_forward): the apply pass of a run re-reads the dWt its dot pass has
-  // just streamed. The block partials of <dWt, W> are indexed by the layer's position inside its run: one run at a time on the stream, no overlap.
-  const long long chunk = sn_chunk_bytes();
-  for (int i0 = 0; i0 < n;) {
-    int i1 = i0; long long b = 0;
-    while (i1 < n && (i1 == i0 || b + 4ll * layers_host[i1].rows * layers_host[i1].cols <= chunk)) { b += 4ll * layers_host[i1].rows * layers_host[i1].cols; i1++; }
-    const sg_sn_bwd_layer* ld = layers_dev + i0;
-    const sg_sn_bwd_layer* lh = layers_host + i0;
-    const int m = i1 - i0;
-    long long max_elems = 1;
-    bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false;
-    for (int i = 0; i < m; i++) {
-      const sg_sn_bwd_layer& l = lh[i];
-      const long long e = (long long)l.rows * l.cols;
-      if (e > max_elems) max_elems = e;
-      if (snb_row_ok(l)) { any_row = true; if (l.apply_sn) any_row_sn = true; }
-      else { any_old = true; if (l.apply_sn) any_old_sn = true; }
-    }
-    if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
-    if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
-    if (any_old) {
-      long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
-      hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, m), dim3(256), 0, st, ld, (const float*)work);
-    }
-    if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(SNB_BLOCKS, m), dim3(256), 0, st, ld, work);
-    i0 = i1;
+  long long max_elems = 1;
+  bool any_row = false, any_old = false, any_old_sn = false, any_row_sn = false;
+  for (int i = 0; i < n; i++) {
+    const sg_sn_bwd_layer& l = layers_host[i];
+    const long long e = (long long)l.rows * l.cols;
+    if (e > max_elems) max_elems = e;
+    if (snb_row_ok(l)) { any_row = true; if (l.apply_sn) any_row_sn = true; }
+    else { any_old = true; if (l.apply_sn) any_old_sn = true; }
   }
+  if (any_old_sn) hipLaunchKernelGGL(k_snb_dot, dim3(nb, n), dim3(256), 0, st, layers_dev, work, nb);
+  if (any_row && any_row_sn) hipLaunchKernelGGL(k_snb_rows<false>, dim3(nb, n), dim3(256), 0, st, layers_dev, work, nb);
+  if (any_old) {
+    long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
+    hipLaunchKernelGGL(k_snb_apply, dim3((int)tiles, n), dim3(256), 0, st, layers_dev, (const float*)work, nb);
+  }
+  if (any_row) hipLaunchKernelGGL(k_snb_rows<true>, dim3(nb, n), dim3(256), 0, st, layers_dev, work, nb);
   SG_LAUNCH_CHECK();
   return 0;
 }

@@ -53,12 +53,14 @@ def _tick():
 
 
 def _offer_stats(out, st, rows, C):
-    _STATS_OFFER[0] = (_SEQ[0], out.data_ptr(), tuple(out.shape), st, rows, C)
+    # (the tensor's version counter rides along: an in-place write to the convolution's output between the two operators -- noise injection, a hook --
+    # invalidates the offer instead of handing the batch norm statistics of what the tensor no longer holds)
+    _STATS_OFFER[0] = (_SEQ[0], out.data_ptr(), tuple(out.shape), st, rows, C, out._version)
 
 
 def _take_stats(x):
     ent, _STATS_OFFER[0] = _STATS_OFFER[0], None
-    if ent is None or ent[0] != _SEQ[0] - 1 or ent[1] != x.data_ptr() or ent[2] != tuple(x.shape) or ent[5] != x.shape[3]:
+    if ent is None or ent[0] != _SEQ[0] - 1 or ent[1] != x.data_ptr() or ent[2] != tuple(x.shape) or ent[5] != x.shape[3] or ent[6] != x._version:
         return None
     return ent[3], ent[4]
 
@@ -660,15 +662,19 @@ _SKIP_FUSION = [{"0": False, "all": "all"}.get(os.environ.get("SG_SKIP_FUSION", 
 
 class SliceUpFn(torch.autograd.Function):
     """y = nearest_up(x[..., :C]) (up in {1, 2}): the channel-slice skip of a BigGAN-deep generator block
-    (reference src/models/big_resnet_deep_legacy.py:53-56,74-75)."""
+    (reference src/models/big_resnet_deep_legacy.py:53-56,74-75). link: a GradLink shared with the block's first operator (its bn1 reads the same x): the
+    skip's gradient is stashed there and added inside that operator's backward launch instead of by a separate elementwise add."""
 
     @staticmethod
-    def forward(ctx, x, C, up):
+    def forward(ctx, x, C, up, link=None):
         x = _c(x)
         N, Hs, Ws, ld = x.shape
+        ctx.dims = (N, Hs, Ws, ld, C, up)
+        ctx.link = link
+        if C == ld and up == 1:          # the whole tensor at its own resolution: the identity skip of a non-resampling block (no launch)
+            return x.view_as(x)
         y = torch.empty((N, Hs * up, Ws * up, C), dtype=x.dtype, device=x.device)
         L.call("sg_slice_up_fwd", L.dt(x), L.ptr(x), L.ptr(y), N, Hs, Ws, ld, C, up, L.stream())
-        ctx.dims = (N, Hs, Ws, ld, C, up)
         return y
 
     @staticmethod
@@ -676,9 +682,14 @@ class SliceUpFn(torch.autograd.Function):
         _first_order_only("SliceUpFn")
         N, Hs, Ws, ld, C, up = ctx.dims
         dy = _c(dy)
-        dx = torch.empty((N, Hs, Ws, ld), dtype=dy.dtype, device=dy.device)
-        L.call("sg_slice_up_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Hs, Ws, ld, C, up, L.stream())
-        return dx, None, None
+        if C == ld and up == 1:
+            dx = dy
+        else:
+            dx = torch.empty((N, Hs, Ws, ld), dtype=dy.dtype, device=dy.device)
+            L.call("sg_slice_up_bwd", L.dt(dy), L.ptr(dy), L.ptr(dx), N, Hs, Ws, ld, C, up, L.stream())
+        if ctx.link is not None and _GRAD_LINK[0]:
+            ctx.link.dx, dx = dx, None
+        return dx, None, None, None
 
 
 class CatConvFn(torch.autograd.Function):
@@ -1171,20 +1182,28 @@ class MaskFn(torch.autograd.Function):
 
 
 class ReluFn(torch.autograd.Function):
-    """standalone ReLU (only where no neighbouring launch can absorb it): y = x * (x > 0)."""
+    """standalone ReLU (only where no neighbouring launch can absorb it): y = x * (x > 0). link: a GradLink shared with another reader of the same x whose
+    backward runs later (the first convolution of a BigGAN-deep discriminator block): the masked gradient is stashed there and rides as the residual of that
+    convolution's data-gradient launch."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, link=None):
         x = _c(x)
         y = torch.empty_like(x)
         L.call("sg_relu_mask", L.dt(x), L.ptr(x), L.ptr(x), L.ptr(y), x.numel(), L.stream())
         ctx.save_for_backward(x)
+        ctx.link = link
         return y
 
     @staticmethod
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
-        return MaskFn.apply(dy, x) if torch.is_grad_enabled() else _mask(dy, x)
+        if torch.is_grad_enabled():
+            return MaskFn.apply(dy, x), None
+        dx = _mask(dy, x)
+        if ctx.link is not None and _GRAD_LINK[0]:
+            ctx.link.dx, dx = dx, None
+        return dx, None
 
 
 class AddReluFn(torch.autograd.Function):

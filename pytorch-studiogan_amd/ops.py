@@ -129,7 +129,8 @@ class Conv2d(_WeightLayerMixin, nn.Conv2d):
         rt = self._sg_rt
         slot = slot if slot is not None else rt.bank().current
         kh, kw = self.kernel_size
-        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool, stats)
+        # (stats: only a batch norm in batch-statistics mode takes the offer; a frozen network -- eval mode, the FID loop's generator -- reads running statistics)
+        cfg = F.ConvCfg(kh, kw, self.stride[0], self.padding[0], self.padding[1], in_relu, in_upsample, out_pool, stats and self.training)
         return F.ConvFn.apply(x, self.master_weight, self.bias, res, rt, slot, cfg, link)
 
     def forward(self, x):
