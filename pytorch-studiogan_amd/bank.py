@@ -254,7 +254,7 @@ class WeightBank:
             r.param_off = arena_of(r.param)[1]        # position of the master weight in the flat arena (exchange ranges)
             m._sg_rt = r
             self.layers.append(r)
-        self.work = torch.zeros(max(work, 4096 * len(layers)) + 64, device=dev, dtype=torch.float32)      # (4096: csrc/sn.hip SNB_MAX, the ceiling of SG_SNB_BLOCKS)
+        self.work = torch.zeros(max(work, self.SNB_BLOCKS * len(layers)) + 64, device=dev, dtype=torch.float32)
         self._sizes = (img_elems, f32_elems, dwt_elems, uv_elems)
         self.slots = []
         for s in range(nslots):

@@ -19,6 +19,16 @@
 #include "common.h"
 #include "../../include/sgamd.h"
 
+// Inner-loop unrolling of the streaming kernels (k_attn_fwd_flash pass 2, k_attn_bwd_q, k_attn_bwd_k): left to the compiler these loops were unrolled
+// eight times and their fragment loads hoisted -- 276 registers for k_attn_fwd_flash<3>, 324 / 432 for k_attn_bwd_k<2> / <3>: ONE wave per SIMD under kernels whose
+// MFMA -> exp -> pack -> MFMA chains have nothing but other waves to hide behind (round 5, tools/isa_mix.py).
+#ifndef AT_UNROLL
+#define AT_UNROLL 1
+#endif
+// workgroups per CU the staging areas allow ((1 + NCG) * 16 KiB each): the register budget is set to match
+#ifndef AT_WAVES
+#define AT_WAVES(NCG) ((NCG) <= 2 ? 3 : 2)
+#endif
 typedef __attribute__((address_space(1))) const void* at_gptr_t;
 typedef __attribute__((address_space(3))) void* at_lptr_t;
 typedef __bf16 at_bf16x8 __attribute__((ext_vector_type(8)));
@@ -238,7 +248,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(const bf16_t* theta, con
 // running row maximum (16 v_max per block), pass 2 forms p = exp2(s log2e - m log2e) (one fma + one v_exp), accumulates the row sum and
 // O' = sum p V with the unnormalised bf16 p as the MFMA operand, and O = O' / l at the end (m is the true maximum, so no rescaling).
 template <int NCG>
-__global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O, float* O32,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NCG), AT_WAVES(NCG)))) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O, float* O32,
                                                         int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
   constexpr float LOG2E = 1.4426950408889634f;
@@ -282,6 +292,7 @@ __global__ __launch_bounds__(256) void k_attn_fwd_flash(const bf16_t* theta, con
 #pragma unroll
     for (int cg = 0; cg < NCG; cg++) at_stage<4>(vimg + cg * KC * 64, g + ((long long)b * HW4 + k0) * Cg, KC, Cg, cg * 32, Cg, wave, lane);
     __syncthreads();
+#pragma unroll AT_UNROLL
     for (int kc = 0; kc < KC / 32; kc++) {
       at_f32x16 s;
 #pragma unroll
@@ -386,7 +397,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_ds_bwd(const bf
 // O comes as the UNROUNDED fp32 copy the forward keeps for this purpose: with the bf16 output the error of dtheta against fp64 grew from
 // ~2e-2 to 4.4e-2 on the near-uniform softmax of tests/test_kernels_gpu.py::test_attention_core (session F), because dS = P (dP - delta)
 // subtracts nearly equal numbers there.
-template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* Oin,
+template <int NCG> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NCG), AT_WAVES(NCG)))) void k_attn_bwd_q(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* Oin,
                                                                         const float* lse, float* delta_out, bf16_t* dtheta, int HW, int HW4, int Dp, int Cg) {
   constexpr int KC = 256;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
@@ -431,6 +442,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf1
 #pragma unroll
       for (int cg = 0; cg < NCG; cg++) at_stage<4>(vimg + cg * KC * 64, g + ((long long)b * HW4 + k0) * Cg, KC, Cg, cg * 32, Cg, wave, lane);
       __syncthreads();
+#pragma unroll AT_UNROLL
       for (int kb = 0; kb < KC / 32; kb++) {
         at_f32x16 s, dp;
 #pragma unroll
@@ -476,7 +488,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_q(const bf1
 // orientation of the query-side kernels: scores = theta (rows) x phi (columns)). Query-side operands (theta, dO; lse, delta) are staged by
 // LDS-DMA in chunks of 256 queries; they feed the score / dP products as k-contiguous fragments and the two accumulating products as
 // transposed fragments of the same images. No P and no dS ever exist in HBM.
-template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_k(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse,
+template <int NCG> __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NCG), AT_WAVES(NCG)))) void k_attn_bwd_k(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, const bf16_t* dO, const float* lse,
                                                                         const float* delta, bf16_t* dphi, bf16_t* dg, int HW, int HW4, int Dp, int Cg) {
   constexpr int QC = 256;
   extern __shared__ __attribute__((aligned(16))) char at_smem[];
@@ -510,6 +522,7 @@ template <int NCG> __global__ __launch_bounds__(256) void k_attn_bwd_k(const bf1
     for (int cg = 0; cg < NCG; cg++) at_stage<4>(oimg + cg * QC * 64, dO + ((long long)b * HW + q0) * Cg, QC, Cg, cg * 32, Cg, wave, lane);
     if (tid < QC) { st[tid] = lse[(long long)b * HW + q0 + tid] * 1.4426950408889634f; dl[tid] = delta[(long long)b * HW + q0 + tid]; }
     __syncthreads();
+#pragma unroll AT_UNROLL
     for (int qb = 0; qb < QC / 32; qb++) {
       at_f32x16 s, dp;
 #pragma unroll

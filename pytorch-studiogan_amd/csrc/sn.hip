@@ -359,8 +359,8 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
 }
 
 // ---- backward: dW = (dWt - <dWt, W/sigma> u v^T) / sigma --------------------------------------------------
-#define SNB_BLOCKS 512     // block partials of <dWt, W> per layer (64 blocks left 3/4 of the chip idle on the big layers: 0.97 TB/s); SG_SNB_BLOCKS=<n> (<= SNB_MAX, A/B switch)
-#define SNB_MAX 4096
+#define SNB_BLOCKS 512     // block partials of <dWt, W> per layer (64 blocks left 3/4 of the chip idle on the big layers: 0.97 TB/s; round 5, tools/sn_bench.py: 1024 / 2048 / 4096
+                           // are SLOWER -- D backward 576 / 585 / 728 / 1145 us -- every block re-sums the partials and the per-item staging gets shorter)
 __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int o, int k) {
   if (l.natural == 1) return (long long)o * l.cols + k;
   const int c = k / l.RS, rs = k - c * l.RS;
@@ -518,9 +518,7 @@ __global__ __launch_bounds__(256) void k_snb_apply(const sg_sn_bwd_layer* L, con
 }
 extern "C" int sg_sn_backward(const sg_sn_bwd_layer* layers_dev, const sg_sn_bwd_layer* layers_host, int n, float* work, long long work_floats, sg_stream_t s) {
   SG_CHECK(layers_dev && layers_host && n > 0 && work, "sg_sn_backward: bad args");
-  static const int nb_env = [] { const char* e = getenv("SG_SNB_BLOCKS"); const int v = e ? atoi(e) : SNB_BLOCKS; return v < 64 ? 64 : (v > SNB_MAX ? SNB_MAX : v); }();
-  int nb = nb_env;
-  while (nb > SNB_BLOCKS && (long long)n * nb > work_floats) nb >>= 1;
+  const int nb = SNB_BLOCKS;
   SG_CHECK((long long)n * nb <= work_floats, "sg_sn_backward: workspace too small");
   for (int i = 0; i < n; i++) {
     const sg_sn_bwd_layer& l = layers_host[i];

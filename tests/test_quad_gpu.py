@@ -282,8 +282,8 @@ def test_conv_epilogue_bn_statistics(sg, kind, monkeypatch):
         w0d = _dev(w0)
         y = F.conv2d_skip_raw(_dev(x), w9d.data_ptr(), C, Cout, _dev(x2), w0d.data_ptr(), 32, True, 0, 0, bias=_dev(bias), bias2=_dev(bias), stats=True)
     assert y is not None and F._STATS_OFFER[0] is not None, "no statistics were offered"
-    _, ptr, shape, st, rows, Cc = F._STATS_OFFER[0]
-    assert ptr == y.data_ptr() and Cc == Cout
+    _, ptr, shape, st, rows, Cc, ver = F._STATS_OFFER[0]
+    assert ptr == y.data_ptr() and Cc == Cout and ver == y._version
     partial = torch.zeros(2 * Cout, dtype=torch.float64, device="cuda:0")
     L.call("sg_bn_stats_from_tiles", st.data_ptr(), rows, Cout, partial.data_ptr(), L.stream())
     torch.cuda.synchronize()
@@ -291,3 +291,7 @@ def test_conv_epilogue_bn_statistics(sg, kind, monkeypatch):
     got = partial.cpu().reshape(Cout, 2)
     check(f"epilogue BN statistics {kind}: sum", got[:, 0], yd.sum(0), 1e-5)
     check(f"epilogue BN statistics {kind}: sum of squares", got[:, 1], (yd * yd).sum(0), 1e-5)
+    # the offer is good for the untouched tensor only: an in-place write between the convolution and its batch norm withdraws it
+    F._SEQ[0] = F._STATS_OFFER[0][0] + 1          # (the batch norm would be the very next operator)
+    y.add_(1.0)
+    assert F._take_stats(y) is None, "a stale statistics offer was taken after an in-place write to the tensor"
