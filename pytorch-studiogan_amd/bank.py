@@ -484,6 +484,13 @@ class WeightBank:
         keys = tuple(k for k in keys if not (k in slot.quad and slot.quad[k][1] == slot.fwd_id))
         if not keys or (keys[0][1] in (2, 3) and slot.dwt is None):
             return
+        if len(keys) > 64:          # sg_quad_pack_batch takes at most 64 items per launch (a deep / high-resolution backbone: ADVICE r4)
+            for i in range(0, len(keys), 64):
+                self._pack_quad_keys(slot, keys[i:i + 64])
+            return
+        self._pack_quad_keys(slot, keys)
+
+    def _pack_quad_keys(self, slot, keys):
         tab = slot.quad_tab.get(keys)
         if tab is None:
             arr = (L.QuadItem * len(keys))()

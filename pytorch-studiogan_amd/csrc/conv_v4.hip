@@ -44,6 +44,12 @@ bool sg_conv_fwd_v4_skip_try(const sg_conv_fwd_desc* d, const sg_conv_skip_desc*
   if (!force && tiles < 768) return false;   // one full wave of workgroups (three per CU)
   if ((quad || up || (sk && sk->x2_up)) && (BJ % (2 * d->Wo))) return false;         // the tile must cover whole pairs of image rows
   if (J % d->Wo) return false;
+  {
+    // the launcher's own limit, asked here so that a dry run is authoritative (the caller no longer swallows a launch failure): operand area + staged epilogue
+    // of one workgroup within 80 KiB
+    const int npx = (((up ? BJ / 4 : BJ) + 2 * d->Ws + 16) + 15) & ~15;
+    if (sg_conv_v4_lds(NB, npx, nullptr, nullptr, nullptr, sk ? (sk->x2_up ? 3 * 64 * 64 : 2 * 256 * 64) : 0) > 80 * 1024) return false;
+  }
   if (dry) return true;
   ConvV4Params p;
   p.x = (const bf16_t*)d->x; p.w = (const bf16_t*)d->w;

@@ -583,11 +583,10 @@ class ConvSkipFn(torch.autograd.Function):
         # tail at batch 256) and loses 0.04-0.06 ms on the 1536-channel 8 x 8 tails, whose 48 one-tap slices are all stop-and-go
         # (a pooled tail goes through the quad kernel -- 2.25 x fewer MFMAs than the fused 3x3 launch -- and the 1x1 skip adds itself as a residual launch)
         if plain and same_relu and h.dtype == torch.bfloat16 and _SKIP_FUSION[0] and (h.shape[1] >= 16 or _SKIP_FUSION[0] == "all") and _quad_form(rt2, cfg2, h) is None:
-            try:
-                y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
-                                    bias=b2, bias2=b0, alpha=al, stats=cfg2.stats and _BN_FUSED_STATS[0])
-            except RuntimeError:
-                y = None         # the launch itself refused (the dry run checks eligibility, not LDS / attribute limits): the two-launch form below
+            # (None: the kernel does not take the shape -- sg_conv2d_fwd_skip_ok includes the launcher's LDS limit -- and the two-launch form below runs;
+            # a launch that fails after that is a real fault and propagates)
+            y = conv2d_skip_raw(h, bank.w_fwd(slot, rt2), h.shape[3], rt2.rows, x, bank.w_fwd(slot, rt0), x.shape[3], cfg0.in_upsample, pf, ef,
+                                bias=b2, bias2=b0, alpha=al, stats=cfg2.stats and _BN_FUSED_STATS[0])
         if y is None and plain and _quad_form(rt2, cfg2, h) == L.Q_POOL and _SKIP_FUSION[0] and (rt0.cin_pad % 32 == 0 or rt0.cin_pad == 8) and not cfg0.in_upsample:
             # pooled tail on the quad kernel with the skip as extra one-tap K-slices of the same launch (conv_q.h SKIP; an 8-channel skip input --
             # the image -- is ONE slice holding its four parity views, filter image mode 5)
@@ -844,8 +843,11 @@ class CbnAffineFn(torch.autograd.Function):
         B, K = y.shape
         C = rt_g.rows
         pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
-        dg, db = (bank.dwt(slot, rt_g), bank.dwt(slot, rt_b)) if (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]) else (None, None)
-        adjacent = ctx.adjacent and (dg is None or db == dg + 4 * C * K)
+        # (a frozen half -- only one of the two weights requires a gradient -- gets none: the merged 2 C-row GEMM is taken when BOTH want theirs)
+        dg = bank.dwt(slot, rt_g) if ctx.needs_input_grad[1] else None
+        db = bank.dwt(slot, rt_b) if ctx.needs_input_grad[2] else None
+        both = dg is not None and db is not None
+        adjacent = ctx.adjacent and (not both or db == dg + 4 * C * K)
         dy = None
         if ctx.needs_input_grad[0]:
             dy = torch.empty((B, K), dtype=torch.float32, device=y.device)
@@ -854,11 +856,12 @@ class CbnAffineFn(torch.autograd.Function):
             else:
                 gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, C)
                 gemm_raw(L.F32, pb, 1, K, dgb.data_ptr() + 4 * C, 0, 2 * C, dy, K, K, B, C, res=dy, ldr=K)
-        if dg is not None:
-            if adjacent:      # dW[o][k] = sum_b dgb[b][o] y[b][k], o over the 2 C rows
-                gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, 2 * C, B)
-            else:
+        if both and adjacent:      # dW[o][k] = sum_b dgb[b][o] y[b][k], o over the 2 C rows
+            gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, 2 * C, B)
+        else:
+            if dg is not None:
                 gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, C, B)
+            if db is not None:
                 gemm_raw(L.F32, y, 1, K, dgb.data_ptr() + 4 * C, 1, 2 * C, db, K, K, C, B)
         return dy, None, None, None, None, None, None
 
