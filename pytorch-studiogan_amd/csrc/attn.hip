@@ -240,13 +240,19 @@ __global__ __launch_bounds__(256) void k_attn_fwd_fused(const bf16_t* theta, con
     }
 }
 
-// ---- fused forward when nothing stores P: max pass + one unnormalised pass ------------------------------------------------------------------
-// k_attn_fwd_fused<., false> was measured at 811 us on D's attention (B 256, 4096 queries x 1024 keys, 48 channels; session D trace):
-// 96 KiB of LDS = one workgroup = ONE wave per SIMD, so every MFMA -> exp -> pack -> MFMA chain ran exposed, and its first pass paid
-// 17 v_exp per 32 x 32 block only to get the row sums (v_exp is quarter rate: 16 of them cost as much as 8 MFMAs).
-// Here both passes walk the keys in 256-key chunks (LDS (1 + NCG) * 16 KiB: three workgroups per CU for NCG = 2), pass 1 keeps only the
-// running row maximum (16 v_max per block), pass 2 forms p = exp2(s log2e - m log2e) (one fma + one v_exp), accumulates the row sum and
-// O' = sum p V with the unnormalised bf16 p as the MFMA operand, and O = O' / l at the end (m is the true maximum, so no rescaling).
+// ---- fused forward when nothing stores P: ONE pass over the keys, running maximum with a deferred rescale ------------------------------------------------
+// History. k_attn_fwd_fused<., false> (whole key image in LDS, two exp passes): 811 us on D's attention (B 256, 4096 queries x 1024 keys, 48 channels). Round 2:
+// keys and values streamed in 256-key chunks (LDS (1 + NCG) * 16 KiB), pass 1 = running row maximum only (scores + 16 v_max per block), pass 2 = p = exp2(s log2e -
+// m log2e), row sum and O' = sum p V with the unnormalised bf16 p as the MFMA operand, O = O' / l. Round 5: the maximum pass is gone. The running maximum m of a
+// query is only RAISED when a block's maximum exceeds it by more than AT_THR (then l and the O' accumulators of that query are rescaled by exp(m_old - m_new), as in
+// online softmax); below the threshold the stale m is kept and p = exp(s - m) <= e^AT_THR simply carries a common factor that cancels in O' / l and in
+// lse = m + log l. bf16 p has fp32's exponent range, l and O' accumulate in fp32: nothing is lost to the factor. With a threshold the rescale runs once per query
+// (at the first block) instead of on almost every block for some query of the wave; what is saved per 32-key block is the first pass's two score MFMAs, its two
+// fragment reads and its 16 v_max, and per chunk one key staging and two barriers.
+// m is kept equal in the two lane halves of a query (they hold disjoint keys of the block, and the second product contracts over both halves' probabilities).
+#ifndef AT_THR
+#define AT_THR 8.0f
+#endif
 template <int NCG>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NCG), AT_WAVES(NCG)))) void k_attn_fwd_flash(const bf16_t* theta, const bf16_t* phi, const bf16_t* g, float* lse, bf16_t* O, float* O32,
                                                         int HW, int HW4, int Dp, int Cg) {
@@ -262,24 +268,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NC
   const long long qrow = (long long)b * HW + q;
   const at_bf16x8 qf0 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 8 * h, Dp));
   const at_bf16x8 qf1 = __builtin_bit_cast(at_bf16x8, at_gfrag(theta, qrow, Dp, 16 + 8 * h, Dp));
-  float m = -3.0e38f;
-  for (int k0 = 0; k0 < HW4; k0 += KC) {
-    __syncthreads();
-    at_stage<4>(kimg, phi + ((long long)b * HW4 + k0) * Dp, KC, Dp, 0, Dp, wave, lane);
-    __syncthreads();
-#pragma unroll 2
-    for (int kb = 0; kb < KC / 32; kb++) {
-      at_f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; r++) s[r] = 0.f;
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 0, lane), qf0, s, 0, 0, 0);
-      s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kb, 1, lane), qf1, s, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 16; r++) m = fmaxf(m, s[r]);
-    }
-  }
-  m = at_half_max(m);
-  const float m2 = m * LOG2E;
+  float m = -3.0e38f;          // running reference maximum of this query (natural-log units), equal in both lane halves
+  float m2 = m * LOG2E;
   float l = 0.f;
   at_f32x16 o[NCG];
 #pragma unroll
@@ -299,6 +289,20 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NC
       for (int r = 0; r < 16; r++) s[r] = 0.f;
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kc, 0, lane), qf0, s, 0, 0, 0);
       s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(at_frag(kimg, kc, 1, lane), qf1, s, 0, 0, 0);
+      float bm = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; r++) bm = fmaxf(bm, s[r]);
+      bm = at_half_max(bm);
+      if (bm > m + AT_THR) {                                      // (the first block always: m starts at -3e38)
+        const float alpha = __builtin_amdgcn_exp2f((m - bm) * LOG2E);
+        l *= alpha;
+#pragma unroll
+        for (int cg = 0; cg < NCG; cg++)
+#pragma unroll
+          for (int r = 0; r < 16; r++) o[cg][r] *= alpha;
+        m = bm;
+        m2 = m * LOG2E;
+      }
       float p[16];
 #pragma unroll
       for (int r = 0; r < 16; r++) { p[r] = __builtin_amdgcn_exp2f(__builtin_fmaf(s[r], LOG2E, -m2)); l += p[r]; }
@@ -316,7 +320,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(AT_WAVES(NC
   }
   l = at_half_sum(l);
   // (the MFMA contracts over the key slots of BOTH lane halves, so o[] is already complete for the channels this lane holds; only the
-  // row sum and the row maximum are per half and need the exchange)
+  // row sum is per half and needs the exchange -- the reference maximum is common to both halves by construction)
   const float inv = 1.f / l;
   if (h == 0) lse[qrow] = m + __logf(l);
   bf16_t* orow = O + qrow * Cg;

@@ -379,6 +379,30 @@ def test_attention_core(sg, dtype, shape, monkeypatch):
         assert "sg_attn_fwd_fused" in calls and "sg_attn_bwd_fused" in calls and "sg_gemm" not in calls and "sg_softmax_rows" not in calls, calls
 
 
+@pytest.mark.parametrize("shape", [(2, 32, 16, 48, 0.5), (1, 32, 32, 96, 3.0), (1, 64, 32, 40, 6.0)])
+def test_attention_flash_single_pass_deferred_rescale(sg, shape):
+    """k_attn_fwd_flash (round 5: ONE pass over the keys, the running maximum raised -- and l / O' rescaled -- only when a block exceeds it by more than e^8):
+    score ranges from +-8 to +-2400 with a few much larger keys late in the sequence, so that the rescale fires in the middle of the pass; output against the
+    fp64 softmax of the reference formulation (utils/ops.py:83-100)."""
+    from studiogan_amd import functional as F
+    B, H, Dp, Cg, scale = shape
+    g0 = torch.Generator().manual_seed(7)
+    th = (scale * torch.randn(B, H, H, Dp, generator=g0)).to(torch.bfloat16)
+    ph = (scale * torch.randn(B, H, H, Dp, generator=g0)).to(torch.bfloat16)
+    g = torch.randn(B, H, H, Cg, generator=g0).to(torch.bfloat16)
+    ph[:, H - 2, H - 3] *= 4.0
+    d = dev()
+    with torch.no_grad():
+        o = F.AttnCoreFn.apply(th.to(d), ph.to(d), g.to(d))
+    torch.cuda.synchronize()
+    t = th.double().reshape(B, H * H, Dp)
+    p = TF.max_pool2d(ph.double().permute(0, 3, 1, 2), 2, 2).reshape(B, Dp, -1)
+    gg = TF.max_pool2d(g.double().permute(0, 3, 1, 2), 2, 2).reshape(B, Cg, -1)
+    ref = torch.bmm(torch.softmax(torch.bmm(t, p), -1), gg.permute(0, 2, 1)).reshape(B, H, H, Cg)
+    assert bool(torch.isfinite(o).all())
+    check(f"single-pass flash attention {shape}", o.float().cpu(), ref, 1e-2)
+
+
 def test_head_losses_embedding(sg):
     from studiogan_amd import functional as F, _lib as L
     d = dev()
