@@ -252,6 +252,30 @@ def gemm_raw(dtype, p, p_form, ldp, q, q_form, ldq, out, ldo, I, J, K, batch=1, 
     L.call("sg_gemm", d, L.stream())
 
 
+_DGRAD_SPLITK = [os.environ.get("SG_DGRAD_SPLITK", "1") != "0"]      # SG_DGRAD_SPLITK=0: one launch, one serial contraction per output tile (A/B runs)
+
+
+def gemm_dgrad_rows(w_ptr, dy, dx, B, K, O):
+    """dx[b][k] = sum_o dy[b][o] W[o][k] for a (sn)linear layer's [O][K] fp32 weight image (fp32): the contraction runs over the layer's OUTPUT width, the result
+    is only [B][K]. At BigGAN's conditional batch norms (K = 148, B = 256, O = 2 C up to 3072) the plain launch is FOUR workgroups walking 3072 contraction steps each:
+    270 us (tools/cbn_gemm_bench.py, profiles/r05_cbn_gemm_bench.txt; forward and weight gradient of the same layer: 23 / 30 us) -- 1.3 ms per generator backward.
+    Here the contraction is cut into S slices that run as the S batches of ONE launch (batch strides = slice offsets along the contraction) into [S][B][K] partial
+    results, summed in a fixed order by one small reduction: no atomics, bit-reproducible."""
+    S = 1
+    tiles = ((K + 127) // 128) * ((B + 127) // 128)          # output tiles of the plain launch
+    if _DGRAD_SPLITK[0] and tiles < 64:
+        while S < 32 and tiles * S < 256 and O % (2 * S) == 0 and O // (2 * S) >= 96:
+            S *= 2
+    if S == 1:
+        gemm_raw(L.F32, w_ptr, 1, K, dy, 0, dy.shape[1] if torch.is_tensor(dy) else O, dx, K, K, B, O)
+        return dx
+    ldq = dy.shape[1]
+    ws = torch.empty((S, B, K), dtype=torch.float32, device=dx.device)
+    gemm_raw(L.F32, w_ptr, 1, K, dy, 0, ldq, ws, K, K, B, O // S, batch=S, p_bs=(O // S) * K, q_bs=O // S, out_bs=B * K)
+    torch.sum(ws, dim=0, out=dx)
+    return dx
+
+
 # ---------------------------------------------------------------------------------------------------------
 # layout at the reference's NCHW fp32 boundary
 # ---------------------------------------------------------------------------------------------------------
@@ -798,7 +822,7 @@ class LinearFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty((B, K), dtype=torch.float32, device=x.device)
             # dx[b][k] = sum_o dy[b][o] W[o][k] : P(i=k, red=o) = W stored [o][k] -> row-contiguous form
-            gemm_raw(L.F32, bank.w_f32(slot, rt), 1, K, dy, 0, O, dx, K, K, B, O)
+            gemm_dgrad_rows(bank.w_f32(slot, rt), dy, dx, B, K, O)
         if ctx.needs_input_grad[1]:
             # dW[o][k] = sum_b dy[b][o] x[b][k]
             gemm_raw(L.F32, x, 1, K, dy, 1, O, bank.dwt(slot, rt), K, K, O, B)
@@ -852,7 +876,7 @@ class CbnAffineFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dy = torch.empty((B, K), dtype=torch.float32, device=y.device)
             if adjacent:      # dy[b][k] = sum over the 2 C rows of dgb[b][o] W[o][k]
-                gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, 2 * C)
+                gemm_dgrad_rows(pg, dgb, dy, B, K, 2 * C)
             else:
                 gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, C)
                 gemm_raw(L.F32, pb, 1, K, dgb.data_ptr() + 4 * C, 0, 2 * C, dy, K, K, B, C, res=dy, ldr=K)
