@@ -459,6 +459,45 @@ int sg_filtered_lrelu(int dtype, const void* x, const float* fu, const float* fd
                       int fu_n, int fd_n, int up, int down, int px0, int px1, int py0, int py1, float gain, float slope, float clamp,
                       int flip_filter, sg_stream_t s);
 
+/* ---- differentiable augmentations in front of the discriminator and the consistency regularisers' loss -----------------------
+ * sg_augment_fwd: y = cutout(translate(flip(contrast(saturation(brightness(x)))))) on fp32 NCHW image batches in ONE gather pass (one more partial-sum
+ * pass when SG_AUG_CONTRAST is set). Replaces the per-operator chains of the reference's
+ *   utils/diffaug.py:47-95  rand_brightness / rand_saturation / rand_contrast / rand_translation (zero fill) / rand_cutout
+ *                           (cfgs.AUG.series_augment, config.py:586-587; called at worker.py:276-278,549-550)
+ *   utils/cr.py:24-48       random_flip / random_translation over F.pad(mode='reflect')  (cfgs.AUG.parallel_augment, worker.py:326-354)
+ * with the random draws made by the caller (the host mirrors draw them with the reference's own calls, in the reference's order):
+ *   color [N][3] fp32 : brightness offset (rand - 0.5), saturation factor (rand * 2), contrast factor (rand + 0.5)
+ *   geom  [N][5] int32: row shift, column shift (out[i][j] = in[i + shift_r][j + shift_c]), cutout centre row, cutout centre column (the reference's
+ *                       offset_x / offset_y: the window is [centre - cut/2, centre - cut/2 + cut) with its indices CLAMPED into the image), flip flag
+ * Operators are selected by `ops` and always applied in the order above; a policy in another order is several calls. |shift| < the axis length; with
+ * SG_AUG_TRANSLATE_REFLECT |shift| <= max_t < min(H, W) (F.pad's own limit). x and y must not alias. work: sg_augment_work_floats(d) floats of scratch
+ * (contrast only; may be NULL otherwise). sg_augment_bwd: dx = d<dy, y>/dx, the transposed gather (every source pixel collects its at most 3 x 3
+ * images: no atomics, bit-identical between runs). Both are linear in their tensor argument up to the brightness offset, so second-order passes
+ * (R1 / gradient penalties through an augmented batch) are sg_augment_fwd without SG_AUG_BRIGHTNESS on the incoming cotangent. */
+#define SG_AUG_BRIGHTNESS 1
+#define SG_AUG_SATURATION 2
+#define SG_AUG_CONTRAST 4
+#define SG_AUG_FLIP 8
+#define SG_AUG_TRANSLATE 16          /* zero fill outside the image (diffaug.py:61-76) */
+#define SG_AUG_TRANSLATE_REFLECT 32  /* reflect padding, no edge repeat (cr.py:33-48) */
+#define SG_AUG_CUTOUT 64
+typedef struct {
+  int N, C, H, W;        /* fp32 [N][C][H][W], 1 <= C <= 4 */
+  int ops;               /* SG_AUG_* */
+  int cut_h, cut_w;      /* cutout window (SG_AUG_CUTOUT) */
+  int max_t;             /* bound of |shift| (SG_AUG_TRANSLATE_REFLECT) */
+  const float* color;    /* [N][3] or NULL when no colour operator is selected */
+  const int* geom;       /* [N][5] or NULL when no geometric operator is selected */
+} sg_aug_desc;
+int sg_augment_work_floats(const sg_aug_desc* d);
+int sg_augment_fwd(const sg_aug_desc* d, const float* x, float* y, float* work, sg_stream_t s);
+int sg_augment_bwd(const sg_aug_desc* d, const float* dy, float* dx, float* work, sg_stream_t s);
+/* torch.nn.MSELoss(reduction='mean') between two fp32 tensors of n elements (the reference's `l2_loss`, worker.py:116,329-361,603): loss[0] = mean (a - b)^2
+ * by a fixed-order two-level sum (work: sg_mse_work_floats() floats); sg_mse_bwd: da = gout[0] * 2 (a - b) / n, db = -da (either may be NULL). */
+int sg_mse_work_floats(void);
+int sg_mse_fwd(const float* a, const float* b, long long n, float* work, float* loss, sg_stream_t s);
+int sg_mse_bwd(const float* a, const float* b, const float* gout, long long n, float* da, float* db, sg_stream_t s);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,96 @@
+"""Golden vectors of the image augmentations written by the REAL reference's own functions (reference src/utils/diffaug.py apply_diffaug,
+src/utils/cr.py apply_cr_aug, torch.nn.MSELoss as src/worker.py:116 builds it), imported on CPU through oracle/ref_import.py under a seeded
+generator, and the pin of the restatement oracle/aug_ref.py (draws as arguments) against them. Output: tests/golden/aug.npz.
+
+    python -m oracle.make_golden_aug           (authoring container only: needs /root/reference)
+TEST INFRASTRUCTURE."""
+import importlib
+import os
+
+import numpy as np
+import torch
+
+from . import aug_ref as AR
+from . import ref_import
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "aug.npz")
+
+DIFFAUG_CASES = [   # (tag, shape, policy)
+    ("full32", (4, 3, 32, 32), "color,translation,cutout"), ("full_rect", (3, 3, 16, 24), "color,translation,cutout"),
+    ("odd", (2, 3, 7, 9), "color,translation,cutout"), ("gray", (3, 1, 8, 8), "color,translation,cutout"),
+    ("geo", (4, 3, 16, 16), "translation,cutout"), ("color", (4, 3, 12, 12), "color"), ("cut_first", (3, 3, 16, 16), "cutout,color"),
+    ("trans", (5, 3, 8, 8), "translation"), ("twice", (2, 3, 16, 16), "translation,translation,cutout,cutout"), ("two_ch", (2, 2, 6, 10), "color,cutout"),
+]
+CR_CASES = [        # (tag, shape, flip, translation)
+    ("both32", (6, 3, 32, 32), True, True), ("flip", (5, 3, 8, 12), True, False), ("trans_rect", (4, 3, 16, 24), False, True), ("odd", (3, 3, 9, 17), True, True),
+]
+MSE_CASES = [("logits", (64,)), ("embed", (16, 48)), ("images", (4, 3, 32, 32))]
+
+
+def _rand(shape, seed, scale=0.8):
+    return (scale * torch.randn(shape, generator=torch.Generator().manual_seed(seed))).float()
+
+
+def main():
+    assert ref_import.available(), "needs the reference checkout"
+    ref_import._prepare()
+    RD = importlib.import_module("utils.diffaug")
+    RC = importlib.import_module("utils.cr")
+    out, worst = {}, 0.0
+    for i, (tag, shape, policy) in enumerate(DIFFAUG_CASES):
+        x = _rand(shape, 1000 + i).clamp(-1, 1).requires_grad_(True)
+        gy, gg = _rand(shape, 2000 + i, 1.0), _rand(shape, 3000 + i, 1.0)
+        torch.manual_seed(4000 + i)
+        draws = AR.draw_diffaug(shape, policy)
+        torch.manual_seed(4000 + i)
+        y = RD.apply_diffaug(x, policy)                       # the reference, drawing the same numbers from the same generator state
+        dx = torch.autograd.grad(y, x, gy)[0]
+        mine = AR.diffaug(x, policy, draws)
+        assert torch.equal(mine, y), (tag, float((mine - y).abs().max()))
+        worst = max(worst, float((torch.autograd.grad(mine, x, gy)[0] - dx).abs().max()))     # (autograd sums the mean's cotangents in another order)
+        # second order (what R1 through an augmented batch needs): u -> d/dgy <A^T gy, u> = A u, the linear part of the map
+        gyv = gy.clone().requires_grad_(True)
+        dxv = torch.autograd.grad(RD_apply_seeded(RD, x, policy, 4000 + i), x, gyv, create_graph=True)[0]
+        lin = torch.autograd.grad(dxv, gyv, gg)[0]
+        p = f"diffaug/{tag}/"
+        out[p + "x"], out[p + "gy"], out[p + "gg"] = x.detach().numpy(), gy.numpy(), gg.numpy()
+        for k, d in enumerate(draws):
+            out[p + f"draw{k}"] = d.numpy()
+        out[p + "y"], out[p + "dx"], out[p + "lin"] = y.detach().numpy(), dx.numpy(), lin.numpy()
+    for i, (tag, shape, flip, trans) in enumerate(CR_CASES):
+        x = _rand(shape, 5000 + i).clamp(-1, 1).requires_grad_(True)
+        gy = _rand(shape, 6000 + i, 1.0)
+        torch.manual_seed(7000 + i)
+        coin, tx, ty = AR.draw_cr(shape, flip, trans)
+        torch.manual_seed(7000 + i)
+        y = RC.apply_cr_aug(x, flip=flip, translation=trans)
+        dx = torch.autograd.grad(y, x, gy)[0]
+        mine = AR.cr_aug(x, coin, tx, ty)
+        assert torch.equal(mine, y), tag
+        worst = max(worst, float((torch.autograd.grad(mine, x, gy)[0] - dx).abs().max()))
+        p = f"cr/{tag}/"
+        out[p + "x"], out[p + "gy"], out[p + "y"], out[p + "dx"] = x.detach().numpy(), gy.numpy(), y.detach().numpy(), dx.numpy()
+        if flip:
+            out[p + "coin"] = coin.numpy()
+        if trans:
+            out[p + "tx"], out[p + "ty"] = tx.numpy(), ty.numpy()
+    l2 = torch.nn.MSELoss()                                   # reference src/worker.py:116
+    for i, (tag, shape) in enumerate(MSE_CASES):
+        a, b = _rand(shape, 8000 + i).requires_grad_(True), _rand(shape, 8100 + i).requires_grad_(True)
+        loss = l2(a, b)
+        da, db = torch.autograd.grad(loss, [a, b], torch.tensor(0.7))
+        worst = max(worst, float((AR.mse(a, b) - loss).detach().abs()))
+        p = f"mse/{tag}/"
+        out[p + "a"], out[p + "b"], out[p + "loss"], out[p + "da"], out[p + "db"] = a.detach().numpy(), b.detach().numpy(), loss.detach().numpy(), da.numpy(), db.numpy()
+    assert worst <= 1e-6, worst
+    np.savez_compressed(OUT, **out)
+    print("wrote", OUT, "restatement bit-identical to the reference on", len(DIFFAUG_CASES) + len(CR_CASES), "augmentation cases (outputs); gradients / mse worst", worst)
+
+
+def RD_apply_seeded(RD, x, policy, seed):
+    torch.manual_seed(seed)
+    return RD.apply_diffaug(x, policy)
+
+
+if __name__ == "__main__":
+    main()

@@ -920,3 +920,61 @@ def d_side_loss(dis_fn, P, B, cfg, real, real_labels, fake, fake_labels, loss_ki
         elif aux == "ADC":
             loss = loss + hp["cond_lambda"] * cond_loss(mtd, fd, hp["temperature"], hp["m_p"])
     return loss, rd, fd
+
+
+# ---------------------------------------------------------------------------------------------------------
+# DiffAugment + consistency regularisers around the discriminator (worker.py:236-365,541-603)
+# ---------------------------------------------------------------------------------------------------------
+def _consistency(a, b, mtd):
+    """torch.nn.MSELoss between the two views' logits (+ class logits for AC, embeddings for 2C / D2D-CE): worker.py:329-335,344-353,358-364"""
+    loss = ((a["adv_output"] - b["adv_output"]) ** 2).mean()
+    if mtd == "AC":
+        loss = loss + ((a["cls_output"] - b["cls_output"]) ** 2).mean()
+    elif mtd in ("2C", "D2DCE"):
+        loss = loss + ((a["embed"] - b["embed"]) ** 2).mean()
+    return loss
+
+
+def d_consistency_loss(gen_fn, dis_fn, GP, GB, P, B, cfg, real, real_labels, z, fake_labels, loss_kind, hp, draws, z_eps=None):
+    """The discriminator-side loss of one micro-batch with DiffAugment in front of the discriminator and the consistency regularisers behind it
+    (src/worker.py:236-365), in the reference's order of generator / discriminator forwards (the spectral-norm vectors advance with each):
+    G(z), [G(z + eps)] (utils/sample.py:162-176), D(series(real)), D(series(fake)), [CR: D(parallel(real))], [bCR: D(parallel(real)), D(parallel(fake))],
+    [zCR: D(G(z + eps))]. hp: diffaug_policy (or None), cr_lambda / (real_lambda, fake_lambda) / d_lambda (each None = off). draws: the random
+    numbers of each augmentation call in consumption order ("series_real", "series_fake": oracle/aug_ref.draw_diffaug lists; "prl_real", "prl_fake":
+    draw_cr triples). Returns (loss, fake images)."""
+    from . import aug_ref as AR
+    mtd = cfg.get("d_cond_mtd", "W/O")
+    with torch.no_grad():
+        fake = gen_fn(z, fake_labels, GP, GB, bn_mode="untrack")
+        fake_eps = gen_fn(z_eps, fake_labels, GP, GB, bn_mode="untrack") if z_eps is not None else None
+    series = (lambda x, d: AR.diffaug(x, hp["diffaug_policy"], d)) if hp.get("diffaug_policy") else (lambda x, d: x)
+
+    def heads(x, lab):
+        adv, h = dis_fn(x, lab, P, B)
+        return d_heads(adv, h, lab, P, B, cfg, False)
+    rd = heads(series(real, draws.get("series_real")), real_labels)
+    fd = heads(series(fake, draws.get("series_fake")), fake_labels)
+    loss = d_loss(loss_kind, rd["adv_output"], fd["adv_output"])
+    if hp.get("cr_lambda") is not None:
+        loss = loss + hp["cr_lambda"] * _consistency(rd, heads(AR.cr_aug(real, *draws["prl_real"]), real_labels), mtd)
+    if hp.get("bcr_lambdas") is not None:
+        real_prl, fake_prl = AR.cr_aug(real, *draws["prl_real"]), AR.cr_aug(fake, *draws["prl_fake"])
+        rp = heads(real_prl, real_labels)
+        fp = heads(fake_prl, fake_labels)
+        loss = loss + hp["bcr_lambdas"][0] * _consistency(rd, rp, mtd) + hp["bcr_lambdas"][1] * _consistency(fd, fp, mtd)
+    if hp.get("d_lambda") is not None:
+        loss = loss + hp["d_lambda"] * _consistency(fd, heads(fake_eps, fake_labels), mtd)
+    return loss, fake
+
+
+def g_consistency_loss(gen_fn, dis_fn, GP, GB, DP, DB, cfg, z, fake_labels, loss_kind, hp, draws, z_eps=None):
+    """The generator-side loss (src/worker.py:520-603): G(z), [G(z + eps)], D(series(fake)), adversarial loss - g_lambda * MSE(G(z), G(z + eps))."""
+    from . import aug_ref as AR
+    fake = gen_fn(z, fake_labels, GP, GB, bn_mode="track")
+    fake_eps = gen_fn(z_eps, fake_labels, GP, GB, bn_mode="track") if z_eps is not None else None
+    x = AR.diffaug(fake, hp["diffaug_policy"], draws["series_fake"]) if hp.get("diffaug_policy") else fake
+    adv, _ = dis_fn(x, fake_labels, DP, DB)
+    loss = g_loss(loss_kind, adv)
+    if hp.get("g_lambda") is not None:
+        loss = loss - hp["g_lambda"] * ((fake - fake_eps) ** 2).mean()
+    return loss, fake

@@ -77,6 +77,12 @@ class SnBwdLayer(C.Structure):
                 ("Cin", _i), ("RS", _i), ("natural", _i), ("apply_sn", _i), ("trans", _i), ("Cin_pad", _i)]
 
 
+class AugDesc(C.Structure):
+    _fields_ = [("N", _i), ("C", _i), ("H", _i), ("W", _i), ("ops", _i), ("cut_h", _i), ("cut_w", _i), ("max_t", _i), ("color", _vp), ("geom", _vp)]
+
+
+AUG_BRIGHTNESS, AUG_SATURATION, AUG_CONTRAST, AUG_FLIP, AUG_TRANSLATE, AUG_TRANSLATE_REFLECT, AUG_CUTOUT = 1, 2, 4, 8, 16, 32, 64
+
 _lib = None
 
 
@@ -204,6 +210,12 @@ _PROTOS = {
     "sg_bias_act": [_i, _vp, _vp, _vp, _vp, _vp, _vp, _ll, _ll, _i, _i, _i, _f, _f, _f, _vp],
     "sg_upfirdn2d": [_i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _vp],
     "sg_filtered_lrelu": [_i, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _i, _f, _f, _f, _i, _vp],
+    "sg_augment_work_floats": [C.POINTER(AugDesc)],       # returns a count (call through lib(), not call())
+    "sg_augment_fwd": [C.POINTER(AugDesc), _vp, _vp, _vp, _vp],
+    "sg_augment_bwd": [C.POINTER(AugDesc), _vp, _vp, _vp, _vp],
+    "sg_mse_work_floats": [],                              # returns a count
+    "sg_mse_fwd": [_vp, _vp, _ll, _vp, _vp, _vp],
+    "sg_mse_bwd": [_vp, _vp, _vp, _ll, _vp, _vp, _vp],
 }
 
 

@@ -1801,3 +1801,87 @@ class GatherColsFn(torch.autograd.Function):
         dz = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
         L.call("sg_scatter_cols", L.ptr(g), L.ptr(label), ctx.shape[0], ctx.shape[1], L.ptr(dz), L.stream())
         return dz, None
+
+
+# ---------------------------------------------------------------------------------------------------------
+# differentiable augmentations in front of the discriminator (csrc/aug/augment.hip)
+# ---------------------------------------------------------------------------------------------------------
+class AugSpec:
+    """One sg_augment call: operator bits (applied in the kernel's fixed order), the per-image draws and the window sizes."""
+
+    __slots__ = ("ops", "color", "geom", "cut_h", "cut_w", "max_t")
+
+    def __init__(self, ops, color=None, geom=None, cut_h=0, cut_w=0, max_t=0):
+        self.ops, self.color, self.geom, self.cut_h, self.cut_w, self.max_t = ops, color, geom, cut_h, cut_w, max_t
+
+
+def _augment_launch(entry, spec, t, ops):
+    import ctypes as C
+    if t.dim() != 4 or not 1 <= t.shape[1] <= 4:
+        raise RuntimeError("augment: expected an image batch [N, C <= 4, H, W]")
+    if t.dtype != torch.float32:
+        raise RuntimeError("augment: images cross the generator / discriminator boundary in fp32 (got %s)" % t.dtype)
+    t = _c(t)
+    N, Cc, H, W = t.shape
+    for name, tab, width, dt_ in (("color", spec.color, 3, torch.float32), ("geom", spec.geom, 5, torch.int32)):
+        if tab is not None and (tab.dtype != dt_ or tuple(tab.shape) != (N, width) or not tab.is_contiguous()):
+            raise RuntimeError("augment: the %s table must be a contiguous [%d, %d] %s tensor" % (name, N, width, dt_))
+    out = torch.empty_like(t)
+    d = L.AugDesc(N, Cc, H, W, ops, spec.cut_h, spec.cut_w, spec.max_t, L.ptr(spec.color), L.ptr(spec.geom))
+    work = torch.empty(L.lib().sg_augment_work_floats(C.byref(d)), dtype=torch.float32, device=t.device) if ops & L.AUG_CONTRAST else None
+    L.call(entry, C.byref(d), L.ptr(t), L.ptr(out), L.ptr(work), L.stream())
+    return out
+
+
+class AugmentFn(torch.autograd.Function):
+    """y = cutout(translate(flip(contrast(saturation(brightness(x)))))) in one gather pass (sg_augment_fwd; reference src/utils/diffaug.py:47-95,
+    src/utils/cr.py:24-48). linear=True drops the brightness offset: the map applied to a cotangent in a create_graph pass."""
+
+    @staticmethod
+    def forward(ctx, x, spec, linear=False):
+        ctx.spec = spec
+        return _augment_launch("sg_augment_fwd", spec, x, spec.ops & ~L.AUG_BRIGHTNESS if linear else spec.ops)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return AugmentBwdFn.apply(dy, ctx.spec), None, None
+
+
+class AugmentBwdFn(torch.autograd.Function):
+    """dx = A^T dy for the linear part A of AugmentFn (sg_augment_bwd: the transposed gather); its own backward is A again, so R1 / gradient penalties
+    through an augmented batch (reference src/worker.py:276-278 with :410-412) differentiate twice."""
+
+    @staticmethod
+    def forward(ctx, dy, spec):
+        ctx.spec = spec
+        return _augment_launch("sg_augment_bwd", spec, dy, spec.ops)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        return AugmentFn.apply(ddx, ctx.spec, True), None
+
+
+class MseFn(torch.autograd.Function):
+    """torch.nn.MSELoss() of two fp32 tensors (the reference's l2_loss, src/worker.py:116): fixed-order sum forward, one elementwise launch backward."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        if a.shape != b.shape:
+            raise RuntimeError("l2_loss: shapes differ (%s vs %s)" % (tuple(a.shape), tuple(b.shape)))
+        a, b = _c(a.float()), _c(b.float())
+        work = torch.empty(L.lib().sg_mse_work_floats(), dtype=torch.float32, device=a.device)
+        loss = torch.empty(1, dtype=torch.float32, device=a.device)
+        L.call("sg_mse_fwd", L.ptr(a), L.ptr(b), a.numel(), L.ptr(work), L.ptr(loss), L.stream())
+        ctx.save_for_backward(a, b)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        _first_order_only("MseFn")
+        a, b = ctx.saved_tensors
+        g = _c(g.float().reshape(1))
+        da = torch.empty_like(a) if ctx.needs_input_grad[0] else None
+        db = torch.empty_like(b) if ctx.needs_input_grad[1] else None
+        if da is not None or db is not None:
+            L.call("sg_mse_bwd", L.ptr(a), L.ptr(b), L.ptr(g), a.numel(), L.ptr(da), L.ptr(db), L.stream())
+        return da, db

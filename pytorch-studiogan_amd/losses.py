@@ -131,6 +131,12 @@ def cal_r1_reg(adv_output, images, device):
     return F.GradPenaltyFn.apply(grad_dout, 1)
 
 
+def l2_loss(a, b):
+    """torch.nn.MSELoss() as the reference's worker builds it (src/worker.py:116): the consistency terms of CR / bCR / zCR
+    (src/worker.py:326-361) and the generator's latent-consistency repulsion (:601-603)."""
+    return F.MseFn.apply(a, b)
+
+
 def adjust_k(current_k, topk_gamma, inf_k):
     """reference src/utils/losses.py:364-366."""
     current_k = max(current_k * topk_gamma, inf_k)

@@ -1,7 +1,8 @@
 """Training-step driver with the structure of the reference's WORKER (reference src/worker.py:213-497
 train_discriminator, :502-681 train_generator, loop body src/loader.py:392-405), minus everything §8 marks out of scope
-(augmentation, logging, checkpointing, StyleGAN paths). bench.py, __graft_entry__.smoke() and the step-parity tests run
-this; on a StudioGAN checkout the unmodified reference worker drives the same modules through the backbone seam
+(ADA / APA / SimCLR augmentation, logging, checkpointing, StyleGAN paths). DiffAugment and the consistency regularisers
+(CR, bCR, zCR) are in: studiogan_amd.diffaug / .cr in the roles of cfgs.AUG.series_augment / parallel_augment.
+bench.py, __graft_entry__.smoke() and the step-parity tests run this; on a StudioGAN checkout the unmodified reference worker drives the same modules through the backbone seam
 (INTEGRATION.md).
 """
 import copy
@@ -69,8 +70,17 @@ class Worker:
                  apply_r1_reg=False, r1_lambda=10.0, apply_maxgp=False, maxgp_lambda=1.0, apply_dra=False, dra_lambda=10.0,
                  apply_lecam=False, lecam_lambda=0.3, lecam_ema_start_iter=1000, lecam_ema_decay=0.99,
                  d_cond_mtd="W/O", aux_cls_type="W/O", cond_lambda=1.0, temperature=1.0, m_p=1.0, tac_dis_lambda=1.0, tac_gen_lambda=1.0,
-                 mh_lambda=1.0):
+                 mh_lambda=1.0, apply_diffaug=False, diffaug_type="diffaug", apply_cr=False, cr_aug_type="cr", cr_lambda=10.0,
+                 apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0):
         self.Gen, self.Dis = Gen, Dis
+        # augmentations in front of the discriminator (reference src/config.py:582-626): series_augment runs on every real / fake batch
+        # (src/worker.py:276-278,549-550), parallel_augment makes the second view of the consistency regularisers (:326-354)
+        self.series_augment = self._augmenter(diffaug_type, "diffaug_type") if apply_diffaug else (lambda x: x)
+        self.apply_cr, self.cr_lambda = apply_cr, cr_lambda
+        self.apply_bcr, self.real_lambda, self.fake_lambda = apply_bcr, real_lambda, fake_lambda
+        self.apply_zcr, self.radius, self.g_lambda, self.d_lambda = apply_zcr, radius, g_lambda, d_lambda
+        assert not (apply_cr and apply_bcr), "CR and bCR share cfgs.AUG.parallel_augment: one of them (reference src/config.py:596-626)"
+        self.parallel_augment = self._augmenter(cr_aug_type if apply_cr else bcr_aug_type, "cr_aug_type / bcr_aug_type") if (apply_cr or apply_bcr) else None
         self.apply_dra, self.dra_lambda = apply_dra, dra_lambda
         self.apply_lecam, self.lecam_lambda, self.lecam_ema_start_iter = apply_lecam, lecam_lambda, lecam_ema_start_iter
         self.lecam_ema = ops.LeCamEMA(decay=lecam_ema_decay, start_iter=lecam_ema_start_iter) if apply_lecam else None   # src/worker.py:139-140
@@ -123,6 +133,38 @@ class Worker:
             self.ema = Ema(source=Gen, target=self.Gen_ema, decay=g_ema_decay, start_iter=g_ema_start)
         self.group = group
 
+    @staticmethod
+    def _augmenter(kind, what):
+        from . import diffaug, cr
+        if kind == "diffaug":
+            return diffaug.apply_diffaug                      # src/config.py:586-587,605-606,619-620
+        if kind in ("cr", "bcr"):
+            return cr.apply_cr_aug                            # src/config.py:584-585,603-604,617-618
+        raise NotImplementedError(f"{what} = {kind}: SimCLR / BYOL / ADA augmentation pipelines are outside the hot path (SURVEY.md §8f)")
+
+    def _consistency(self, a, b):
+        """l2 between the two views' logits, plus their class logits (AC) or embeddings (2C / D2D-CE): src/worker.py:329-335,344-353,358-364"""
+        loss = sg_losses.l2_loss(a["adv_output"], b["adv_output"])
+        if self.d_cond_mtd == "AC":
+            loss = loss + sg_losses.l2_loss(a["cls_output"], b["cls_output"])
+        elif self.d_cond_mtd in ("2C", "D2DCE"):
+            loss = loss + sg_losses.l2_loss(a["embed"], b["embed"])
+        return loss
+
+    def _sample(self, injected, k):
+        """(zs, fake_labels, zs_eps): reference src/utils/sample.py:69-88 -- zs_eps = zs + radius * N(0, I) when the latent consistency term is on.
+        injected entries are (z, y) or (z, y, z_eps)."""
+        if injected is not None:
+            ent = injected[k]
+            zs, ys = ent[0], ent[1]
+            eps = ent[2] if len(ent) > 2 else None
+        else:
+            zs, ys = sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+            eps = None
+        if self.apply_zcr and eps is None:
+            eps = zs + self.radius * torch.randn(zs.shape[0], self.z_dim, device=zs.device)
+        return zs, ys, (eps if self.apply_zcr else None)
+
     # -- src/worker.py:213-497 ------------------------------------------------------------------------------------
     def train_discriminator(self, current_step, real_batches, injected=None):
         """real_batches: list (n_d * acml) of (images NCHW fp32 in [-1,1], labels). injected: optional list of (z, y)."""
@@ -136,13 +178,16 @@ class Worker:
             self.d_optimizer.zero_grad()
             for micro in range(self.acml):
                 real_images, real_labels = real_batches[k]
-                zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+                zs, fake_labels, zs_eps = self._sample(injected, k)
                 k += 1
                 fake_images = self.Gen(zs, fake_labels)
+                fake_images_eps = self.Gen(zs_eps, fake_labels) if zs_eps is not None else None      # src/utils/sample.py:162-176
                 if self.apply_r1_reg:    # src/worker.py:260-261
                     real_images = real_images.detach().requires_grad_(True)
-                real_dict = self.Dis(real_images, real_labels)
-                fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
+                real_images_ = self.series_augment(real_images)          # src/worker.py:276-278
+                fake_images_ = self.series_augment(fake_images)
+                real_dict = self.Dis(real_images_, real_labels)
+                fake_dict = self.Dis(fake_images_, fake_labels, adc_fake=self.adc_fake)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
                 if self.adv_loss == "MH":          # src/worker.py:300-302
                     dis_acml_loss = self.d_loss(DDP=self.group is not None, **real_dict)
@@ -159,6 +204,19 @@ class Worker:
                         dis_acml_loss = dis_acml_loss + self.tac_dis_lambda * self.cond_loss_mi(**fake_dict)
                     elif self.aux_cls_type == "ADC":
                         dis_acml_loss = dis_acml_loss + self.cond_lambda * self.cond_loss(**fake_dict)
+                if self.apply_cr:        # src/worker.py:325-336: the real batch's second view must score like the first
+                    real_prl_dict = self.Dis(self.parallel_augment(real_images), real_labels)
+                    dis_acml_loss = dis_acml_loss + self.cr_lambda * self._consistency(real_dict, real_prl_dict)
+                if self.apply_bcr:       # src/worker.py:339-354: balanced CR (ICRGAN), real and fake batch
+                    real_prl_images = self.parallel_augment(real_images)
+                    fake_prl_images = self.parallel_augment(fake_images)
+                    real_prl_dict = self.Dis(real_prl_images, real_labels)
+                    fake_prl_dict = self.Dis(fake_prl_images, fake_labels, adc_fake=self.adc_fake)
+                    dis_acml_loss = dis_acml_loss + self.real_lambda * self._consistency(real_dict, real_prl_dict) \
+                        + self.fake_lambda * self._consistency(fake_dict, fake_prl_dict)
+                if self.apply_zcr:       # src/worker.py:357-365: latent CR, D's side: G(z) and G(z + eps) score alike
+                    fake_eps_dict = self.Dis(fake_images_eps, fake_labels, adc_fake=self.adc_fake)
+                    dis_acml_loss = dis_acml_loss + self.d_lambda * self._consistency(fake_dict, fake_eps_dict)
                 if self.apply_gp:   # src/worker.py:369-375
                     gp_loss = sg_losses.cal_grad_penalty(real_images=real_images, real_labels=real_labels, fake_images=fake_images,
                                                          discriminator=self.Dis, device=self.device)
@@ -200,10 +258,12 @@ class Worker:
         for _ in range(self.n_g):
             self.g_optimizer.zero_grad()
             for micro in range(self.acml):
-                zs, fake_labels = injected[k] if injected is not None else sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+                zs, fake_labels, zs_eps = self._sample(injected, k)
                 k += 1
                 fake_images = self.Gen(zs, fake_labels)
-                fake_dict = self.Dis(fake_images, fake_labels)
+                fake_images_eps = self.Gen(zs_eps, fake_labels) if zs_eps is not None else None
+                fake_images_ = self.series_augment(fake_images)          # src/worker.py:549-550
+                fake_dict = self.Dis(fake_images_, fake_labels)
                 self.last_g = (fake_images.detach(), fake_dict["adv_output"].detach())
                 if self.apply_topk:      # src/worker.py:565-566
                     fake_dict["adv_output"] = sg_losses.topk_values(fake_dict["adv_output"], int(self.topk))
@@ -216,8 +276,10 @@ class Worker:
                     if self.aux_cls_type == "TAC":
                         gen_acml_loss = gen_acml_loss - self.tac_gen_lambda * self.cond_loss_mi(**fake_dict)      # src/worker.py:579
                     elif self.aux_cls_type == "ADC":
-                        adc_fake_dict = self.Dis(fake_images, fake_labels, adc_fake=self.adc_fake)
+                        adc_fake_dict = self.Dis(fake_images_, fake_labels, adc_fake=self.adc_fake)       # (the augmented batch: src/worker.py:583)
                         gen_acml_loss = gen_acml_loss - self.cond_lambda * self.cond_loss(**adc_fake_dict)
+                if self.apply_zcr:       # src/worker.py:601-603: G's side of the latent CR pushes G(z) and G(z + eps) apart
+                    gen_acml_loss = gen_acml_loss - self.g_lambda * sg_losses.l2_loss(fake_images, fake_images_eps)
                 gen_acml_loss = gen_acml_loss / self.acml
                 if self._xchg and micro == self.acml - 1:
                     self.g_optimizer.arm_exchange(self.group)

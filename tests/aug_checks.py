@@ -1,0 +1,253 @@
+"""Checks of the augmentation / l2-loss host mirrors (studiogan_amd.diffaug, .cr, losses.l2_loss) against the vectors the reference wrote
+(tests/golden/aug.npz, oracle/make_golden_aug.py), written once for both places they run: the GPU (tests/test_aug_gpu.py) and the kernel sources on
+the CPU interpreter (tests/test_aug_cpu.py under hipemu.fullemu.Installed). fp32 throughout; tolerance 2e-6 of the expected tensor's range where the
+contrast mean's summation order enters, exact equality where it does not."""
+import os
+
+import numpy as np
+import torch
+
+from util import check
+from oracle import aug_ref as AR
+from oracle import make_golden_aug as MGA
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "aug.npz")
+TOL = 2e-6
+
+
+def _t(z, k):
+    return torch.from_numpy(z[k]) if k in z.files else None
+
+
+def _replay(draws):
+    """torch.rand / torch.randint / FloatTensor.uniform_ stand-ins that hand out the recorded draws in order (shape-checked): the host mirrors then
+    consume exactly what the reference consumed when it wrote the fixture, whatever generator the device has"""
+    it = iter(draws)
+
+    def nxt(shape, dev):
+        d = next(it)
+        assert tuple(d.shape) == tuple(shape), (tuple(d.shape), tuple(shape))
+        return d.to(dev)
+    return nxt
+
+
+class Replayed:
+    def __init__(self, draws):
+        self.nxt = _replay(draws)
+
+    def __enter__(self):
+        self.saved = (torch.rand, torch.randint, torch.FloatTensor)
+        nxt = self.nxt
+
+        def rand(*size, dtype=None, device=None, **kw):
+            return nxt(size, device)
+
+        def randint(low, high, size=None, device=None, **kw):
+            return nxt(size, device)
+
+        class FT:
+            def __init__(self, *size):
+                self.size = size
+
+            def uniform_(self, a, b):
+                return nxt(self.size, "cpu")
+        torch.rand, torch.randint, torch.FloatTensor = rand, randint, FT
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randint, torch.FloatTensor = self.saved
+
+
+def diffaug_case(case, dev):
+    """output, gradient and the second-order (linear) term of apply_diffaug against the reference's vectors"""
+    from studiogan_amd import diffaug as DA
+    tag, shape, policy = case
+    z = np.load(GOLD)
+    p = f"diffaug/{tag}/"
+    draws = []
+    while p + f"draw{len(draws)}" in z.files:
+        draws.append(_t(z, p + f"draw{len(draws)}"))
+    x = _t(z, p + "x").to(dev).requires_grad_(True)
+    with Replayed(draws):
+        y = DA.apply_diffaug(x, policy)
+    exact = "color" not in policy          # no contrast mean: same fp32 operations in the same order as the reference
+    if exact:
+        assert torch.equal(y.detach().cpu(), _t(z, p + "y")), tag
+    check(f"diffaug {tag} y", y, _t(z, p + "y"), TOL)
+    gy = _t(z, p + "gy").to(dev).requires_grad_(True)
+    (dx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+    check(f"diffaug {tag} dx", dx, _t(z, p + "dx"), TOL)
+    (lin,) = torch.autograd.grad(dx, gy, _t(z, p + "gg").to(dev))
+    check(f"diffaug {tag} second order", lin, _t(z, p + "lin"), TOL)
+    # channels-last entry (diffaug.py:37-44)
+    with Replayed(draws):
+        y2 = DA.apply_diffaug(x.detach().permute(0, 2, 3, 1).contiguous(), policy, channels_first=False)
+    assert y2.shape == (shape[0], shape[2], shape[3], shape[1]) and y2.is_contiguous()
+    assert torch.equal(y2.permute(0, 3, 1, 2), y.detach())
+
+
+def cr_case(case, dev):
+    from studiogan_amd import cr as CR
+    tag, shape, flip, trans = case
+    z = np.load(GOLD)
+    p = f"cr/{tag}/"
+    draws = ([_t(z, p + "coin")] if flip else []) + ([_t(z, p + "tx"), _t(z, p + "ty")] if trans else [])
+    x = _t(z, p + "x").to(dev).requires_grad_(True)
+    with Replayed(draws):
+        y = CR.apply_cr_aug(x, flip=flip, translation=trans)
+    assert torch.equal(y.detach().cpu(), _t(z, p + "y")), tag            # a pure gather: bit for bit
+    (dx,) = torch.autograd.grad(y, x, _t(z, p + "gy").to(dev))
+    check(f"cr {tag} dx", dx, _t(z, p + "dx"), TOL)
+
+
+def mse_case(case, dev):
+    from studiogan_amd import losses
+    tag, shape = case
+    z = np.load(GOLD)
+    p = f"mse/{tag}/"
+    a, b = _t(z, p + "a").to(dev).requires_grad_(True), _t(z, p + "b").to(dev).requires_grad_(True)
+    loss = losses.l2_loss(a, b)
+    assert loss.dim() == 0
+    assert abs(float(loss.detach()) - float(z[p + "loss"])) <= 2e-6 * abs(float(z[p + "loss"])), tag
+    da, db = torch.autograd.grad(loss, [a, b], torch.tensor(0.7, device=dev))
+    check(f"mse {tag} da", da, _t(z, p + "da"), TOL)
+    check(f"mse {tag} db", db, _t(z, p + "db"), TOL)
+    (da_only,) = torch.autograd.grad(losses.l2_loss(a, b.detach()), a, torch.tensor(0.7, device=dev))     # one-sided (detached partner, worker.py:603)
+    assert torch.equal(da_only, da)
+
+
+def adjoint_and_linearity(shape, ops_policy, dev, seed=0):
+    """size-independent properties (run at the benchmark's image sizes on the GPU): <A u, v> == <u, A^T v> for the linear part A (ties the backward kernel
+    to the forward one), A(a u1 + b u2) == a A u1 + b A u2, and y(x) - A x == the brightness offset pushed through the rest of the chain"""
+    from studiogan_amd import functional as F
+    from studiogan_amd import _lib as L
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = shape
+    u, u2, v = (torch.randn(shape, generator=g).to(dev) for _ in range(3))
+    color = torch.stack([torch.rand(N, generator=g) - 0.5, torch.rand(N, generator=g) * 2, torch.rand(N, generator=g) + 0.5], 1).to(dev)
+    mt = max(H // 8, 1)
+    geom = torch.stack([torch.randint(-mt, mt + 1, (N,), generator=g), torch.randint(-mt, mt + 1, (N,), generator=g), torch.randint(0, H, (N,), generator=g),
+                        torch.randint(0, W, (N,), generator=g), torch.randint(0, 2, (N,), generator=g)], 1).to(torch.int32).to(dev)
+    spec = F.AugSpec(ops_policy, color, geom, (H + 1) // 2, (W + 1) // 2, mt)
+    Au = F.AugmentFn.apply(u, spec, True)
+    Atv = F.AugmentBwdFn.apply(v, spec)
+    lhs, rhs = float((Au.double() * v.double()).sum()), float((u.double() * Atv.double()).sum())
+    scale = float(Au.double().norm() * v.double().norm()) + 1e-30
+    assert abs(lhs - rhs) <= 1e-6 * scale, (lhs, rhs, scale)
+    comb = F.AugmentFn.apply(0.75 * u - 1.5 * u2, spec, True)
+    check("augment linearity", comb, 0.75 * Au - 1.5 * F.AugmentFn.apply(u2, spec, True), 5e-6)
+    if ops_policy & L.AUG_BRIGHTNESS:
+        off = F.AugmentFn.apply(u, spec) - Au                     # the offset b pushed through saturation / contrast (identity on a constant image), then the geometry
+        ones = F.AugmentFn.apply(torch.ones_like(u), F.AugSpec(ops_policy & ~(L.AUG_BRIGHTNESS | L.AUG_SATURATION | L.AUG_CONTRAST), None, geom, spec.cut_h, spec.cut_w, mt), True) \
+            if ops_policy & ~(L.AUG_BRIGHTNESS | L.AUG_SATURATION | L.AUG_CONTRAST) else torch.ones_like(u)
+        check("augment brightness offset", off, ones * color[:, 0].reshape(N, 1, 1, 1), 5e-6)
+    return Au
+
+
+def oracle_spec_case(shape, ops, dev, seed=0):
+    """sg_augment with explicit tables against the restatement's operators composed in the kernel's fixed order (any operator subset, both translation kinds)"""
+    from studiogan_amd import functional as F
+    from studiogan_amd import _lib as L
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = shape
+    x = (torch.rand(shape, generator=g) * 2 - 1)
+    gy = torch.randn(shape, generator=g)
+    b, s, c = torch.rand(N, generator=g) - 0.5, torch.rand(N, generator=g) * 2, torch.rand(N, generator=g) + 0.5
+    mt = max(min(H, W) // 8, 1)
+    tx, ty = torch.randint(-mt, mt + 1, (N,), generator=g), torch.randint(-mt, mt + 1, (N,), generator=g)
+    ch, cw = (H + 1) // 2, (W + 1) // 2
+    cx, cy = torch.randint(0, H + (1 - ch % 2), (N,), generator=g), torch.randint(0, W + (1 - cw % 2), (N,), generator=g)
+    fl = torch.randint(0, 2, (N,), generator=g)
+    xr = x.clone().requires_grad_(True)
+    e = xr
+    if ops & L.AUG_BRIGHTNESS:
+        e = AR.brightness(e, b)
+    if ops & L.AUG_SATURATION:
+        e = AR.saturation(e, s)
+    if ops & L.AUG_CONTRAST:
+        e = AR.contrast(e, c)
+    if ops & L.AUG_FLIP:
+        e = AR.cr_flip(e, fl)
+    if ops & L.AUG_TRANSLATE:
+        e = AR.translation(e, tx, ty)
+    if ops & L.AUG_TRANSLATE_REFLECT:
+        e = AR.cr_translation(e, tx, ty)
+    if ops & L.AUG_CUTOUT:
+        e = AR.cutout(e, cx, cy, ch, cw)
+    (edx,) = torch.autograd.grad(e, xr, gy)
+    color = torch.stack([b, s, c], 1).to(dev)
+    geom = torch.stack([tx, ty, cx, cy, fl], 1).to(torch.int32).to(dev)
+    xd = x.to(dev).requires_grad_(True)
+    y = F.AugmentFn.apply(xd, F.AugSpec(ops, color, geom, ch, cw, mt))
+    check(f"augment ops={ops} {shape} y", y, e, TOL)
+    (dx,) = torch.autograd.grad(y, xd, gy.to(dev))
+    check(f"augment ops={ops} {shape} dx", dx, edx, TOL)
+
+
+DIFFAUG_CASES, CR_CASES, MSE_CASES = MGA.DIFFAUG_CASES, MGA.CR_CASES, MGA.MSE_CASES
+
+
+# ---- the worker's discriminator / generator update with DiffAugment + CR / bCR / zCR against the reference's vectors -------------------------------------
+def consistency_case(tag, dev):
+    """studiogan_amd.worker.Worker with apply_diffaug / apply_cr / apply_bcr / apply_zcr on the networks and inputs of tests/golden/<config>.npz, fed the
+    recorded draws: loss value and every parameter gradient of one discriminator update and one generator update against what the REAL reference's
+    models + utils/diffaug.py + utils/cr.py + MSELoss produced when combined as src/worker.py:236-365,520-603 (tests/golden/consistency.npz,
+    oracle/make_golden_consistency.py). fp32; tolerances of tests/test_model_gpu.py::step_vs_golden."""
+    import json
+    from util import load_golden, sub, hyper, Collector, GOLDEN
+    from test_model_gpu import build_from_yaml
+    from studiogan_amd.worker import Worker
+    z = np.load(os.path.join(GOLDEN, "consistency.npz"))
+    meta_c = json.load(open(os.path.join(GOLDEN, "consistency.json")))[tag]
+    hp = meta_c["hp"]
+    fix, meta = load_golden(meta_c["config"])
+    y = meta["yaml"]
+    G, D = build_from_yaml(y, False, dev)
+    G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+    D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
+    opt = hyper(y)
+    bcr = hp.get("bcr_lambdas")
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+               d_updates_per_step=1, apply_diffaug=bool(hp.get("diffaug_policy")), apply_cr=hp.get("cr_lambda") is not None, cr_lambda=hp.get("cr_lambda", 0.0),
+               apply_bcr=bcr is not None, real_lambda=(bcr or [0, 0])[0], fake_lambda=(bcr or [0, 0])[1], apply_zcr=hp.get("d_lambda") is not None,
+               radius=hp.get("radius", 0.0), g_lambda=hp.get("g_lambda", 0.0), d_lambda=hp.get("d_lambda", 0.0))
+    if hp.get("diffaug_policy"):
+        from studiogan_amd import diffaug as DA
+        w.series_augment = lambda x: DA.apply_diffaug(x, hp["diffaug_policy"])
+    ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+    p = tag + "/"
+
+    def draws_of(prefix, names):
+        out = []
+        for name in names:
+            i = 0
+            while i < 8:
+                k = f"{p}{prefix}/{name}/{i}"
+                if k in z.files:
+                    out.append(torch.from_numpy(z[k]))
+                i += 1
+        return out
+    C = Collector()
+    zed = torch.from_numpy(z[p + "z_eps_d"]).to(dev) if p + "z_eps_d" in z.files else None
+    with Replayed(draws_of("draw_d", ["series_real", "series_fake", "prl_real", "prl_fake"])):
+        d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"]) + ((zed,) if zed is not None else ())])
+    C.check("d_loss", d_loss, torch.from_numpy(z[p + "d_loss"]), 2e-4)
+    dmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "D_grad/"))
+    for k, prm in D.named_parameters():
+        C.check("D_grad/" + k, prm.grad, torch.from_numpy(z[p + "D_grad/" + k]), 1e-3, floor=1e-2 * dmax)
+    # the generator side of the fixture was taken on the networks as the discriminator side's FORWARDS left them (no optimiser step in between):
+    # put the discriminator's weights back, keep the spectral-norm vectors / batch-norm statistics where the update's forwards left them
+    with torch.no_grad():
+        for k, prm in D.named_parameters():
+            prm.copy_(fix["D_init/" + k].to(dev))
+    zeg = torch.from_numpy(z[p + "z_eps_g"]).to(dev) if p + "z_eps_g" in z.files else None
+    with Replayed(draws_of("draw_g", ["series_fake"])):
+        g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"]) + ((zeg,) if zeg is not None else ())])
+    C.check("g_loss", g_loss, torch.from_numpy(z[p + "g_loss"]), 1e-3)
+    gmx = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "G_grad/"))
+    for k, prm in G.named_parameters():
+        C.check("G_grad/" + k, prm.grad, torch.from_numpy(z[p + "G_grad/" + k]), 2e-2, floor=1e-2 * gmx)
+    C.finish()
+
+
+CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug"]

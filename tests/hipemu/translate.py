@@ -169,14 +169,25 @@ template <class T> static inline void hipemu_tr_assign(T& dst, unsigned addr) { 
 """
 
 
+def source_files():
+    """(name in the flat translated tree, path): csrc/*.{h,hip} and the units of csrc/aug/ (augmentation kernels)"""
+    out = [(fn, os.path.join(CSRC, fn)) for fn in sorted(os.listdir(CSRC)) if fn.endswith(".h") or fn.endswith(".hip")]
+    aug = os.path.join(CSRC, "aug")
+    if os.path.isdir(aug):
+        out += [(fn, os.path.join(aug, fn)) for fn in sorted(os.listdir(aug)) if fn.endswith(".h") or fn.endswith(".hip")]
+    return out
+
+
 def translate_tree(dst):
     os.makedirs(dst, exist_ok=True)
-    for fn in sorted(os.listdir(CSRC)):
-        if not (fn.endswith(".h") or fn.endswith(".hip")):
-            continue
-        with open(os.path.join(CSRC, fn)) as f:
+    files = source_files()
+    assert len(set(n for n, _ in files)) == len(files), "file names must be unique across csrc/ and csrc/aug/"
+    hdr = os.path.join(REPO, "include", "sgamd.h")
+    for k, (fn, src_path) in enumerate(files):
+        with open(src_path) as f:
             src = f.read()
-        text = translate(src, 1000 * (1 + sorted(os.listdir(CSRC)).index(fn))).replace('"../../include/sgamd.h"', '"%s"' % os.path.join(REPO, "include", "sgamd.h"))
+        text = translate(src, 1000 * (1 + k))
+        text = text.replace('"../../../include/sgamd.h"', '"%s"' % hdr).replace('"../../include/sgamd.h"', '"%s"' % hdr).replace('"../common.h"', '"common.h"')
         if fn == "common.h":
             text = text.replace("#pragma once", "#pragma once\n" + PRELUDE, 1)
         path = os.path.join(dst, fn)

@@ -1,0 +1,211 @@
+"""CPU: the augmentation oracle (oracle/aug_ref.py) against the vectors the reference's own apply_diffaug / apply_cr_aug / MSELoss wrote
+(tests/golden/aug.npz), the regeneration of those vectors from the reference when it is present, the host mirrors' argument behaviour, and the kernel
+SOURCES of csrc/aug/augment.hip run lane by lane on the CPU interpreter (tests/hipemu) through the product's own Python layer against the same vectors --
+the checks tests/test_aug_gpu.py makes on the GPU."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, "hipemu"))
+import emu  # noqa: E402
+import aug_checks as AC  # noqa: E402
+from oracle import aug_ref as AR  # noqa: E402
+from oracle import make_golden_aug as MGA  # noqa: E402
+from oracle import ref_import  # noqa: E402
+
+_NT = torch.get_num_threads()      # (the interpreter fixture below pins torch to one thread for the module: reference-side runs put the default back)
+needs_emu = pytest.mark.skipif(not emu.available(), reason="host clang++ of the ROCm toolchain not found")
+
+
+def test_aug_oracle_reproduces_the_reference_vectors():
+    z = np.load(AC.GOLD)
+    for tag, shape, policy in MGA.DIFFAUG_CASES:
+        p = f"diffaug/{tag}/"
+        draws = []
+        while p + f"draw{len(draws)}" in z.files:
+            draws.append(AC._t(z, p + f"draw{len(draws)}"))
+        x = AC._t(z, p + "x").requires_grad_(True)
+        y = AR.diffaug(x, policy, draws)
+        assert torch.equal(y.detach(), AC._t(z, p + "y")), tag
+        gy = AC._t(z, p + "gy").requires_grad_(True)
+        (dx,) = torch.autograd.grad(y, x, gy, create_graph=True)
+        assert float((dx.detach() - AC._t(z, p + "dx")).abs().max()) <= 1e-6, tag
+        (lin,) = torch.autograd.grad(dx, gy, AC._t(z, p + "gg"))
+        assert float((lin - AC._t(z, p + "lin")).abs().max()) <= 1e-6, tag
+    for tag, shape, flip, trans in MGA.CR_CASES:
+        p = f"cr/{tag}/"
+        x = AC._t(z, p + "x").requires_grad_(True)
+        y = AR.cr_aug(x, AC._t(z, p + "coin"), AC._t(z, p + "tx"), AC._t(z, p + "ty"))
+        assert torch.equal(y.detach(), AC._t(z, p + "y")), tag
+        assert float((torch.autograd.grad(y, x, AC._t(z, p + "gy"))[0] - AC._t(z, p + "dx")).abs().max()) <= 1e-6, tag
+    for tag, shape in MGA.MSE_CASES:
+        p = f"mse/{tag}/"
+        assert abs(float(AR.mse(AC._t(z, p + "a"), AC._t(z, p + "b"))) - float(z[p + "loss"])) <= 1e-7
+
+
+def test_aug_draw_order_matches_the_reference_consumption():
+    """draw_diffaug / draw_cr (what the host mirrors call) leave the generator in the state the reference's functions leave it in"""
+    if not ref_import.available():
+        pytest.skip("the reference checkout is only present in the authoring container")
+    import importlib
+    ref_import._prepare()
+    RD, RC = importlib.import_module("utils.diffaug"), importlib.import_module("utils.cr")
+    x = torch.randn(3, 3, 16, 16)
+    for policy in ("color,translation,cutout", "cutout,translation", "color"):
+        torch.manual_seed(5)
+        RD.apply_diffaug(x, policy)
+        a = torch.rand(4)
+        torch.manual_seed(5)
+        AR.draw_diffaug(x.shape, policy)
+        assert torch.equal(a, torch.rand(4)), policy
+    torch.manual_seed(6)
+    RC.apply_cr_aug(x)
+    a = torch.rand(4)
+    torch.manual_seed(6)
+    AR.draw_cr(x.shape)
+    assert torch.equal(a, torch.rand(4))
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_aug_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
+    out = tmp_path / "aug.npz"
+    monkeypatch.setattr(MGA, "OUT", str(out))
+    MGA.main()
+    a, b = np.load(AC.GOLD), np.load(out)
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+
+
+def test_aug_host_mirrors_refuse_the_cpu_and_bad_arguments():
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import diffaug, cr, losses
+    x = torch.randn(2, 3, 8, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        diffaug.apply_diffaug(x)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        cr.apply_cr_aug(x)
+    with pytest.raises(RuntimeError, match="GPU tensor"):
+        losses.l2_loss(x, x)
+    assert diffaug.apply_diffaug(x, policy="") is x and cr.apply_cr_aug(x, flip=False, translation=False) is x       # diffaug.py:36, cr.py:18
+
+
+# ---- the kernel sources on the interpreter ---------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def installed():
+    import fullemu
+    n = torch.get_num_threads()
+    torch.set_num_threads(1)
+    with fullemu.Installed(dma_late=1, greedy=1, seed=3) as E:
+        yield E
+    torch.set_num_threads(n)
+
+
+@needs_emu
+@pytest.mark.parametrize("case", AC.DIFFAUG_CASES, ids=[c[0] for c in AC.DIFFAUG_CASES])
+def test_emulated_diffaug_matches_reference_vectors(installed, case):
+    c0 = installed.counters()["launches"]
+    AC.diffaug_case(case, torch.device("cpu"))
+    assert installed.counters()["launches"] > c0
+
+
+@needs_emu
+@pytest.mark.parametrize("case", AC.CR_CASES, ids=[c[0] for c in AC.CR_CASES])
+def test_emulated_cr_aug_matches_reference_vectors(installed, case):
+    AC.cr_case(case, torch.device("cpu"))
+
+
+@needs_emu
+@pytest.mark.parametrize("case", AC.MSE_CASES, ids=[c[0] for c in AC.MSE_CASES])
+def test_emulated_l2_loss_matches_reference_vectors(installed, case):
+    AC.mse_case(case, torch.device("cpu"))
+
+
+@needs_emu
+def test_emulated_augment_operator_subsets_and_properties(installed):
+    from studiogan_amd import _lib as L
+    dev = torch.device("cpu")
+    every = [L.AUG_BRIGHTNESS, L.AUG_SATURATION, L.AUG_CONTRAST, L.AUG_FLIP, L.AUG_CUTOUT]
+    k = 0
+    for tr in (0, L.AUG_TRANSLATE, L.AUG_TRANSLATE_REFLECT):
+        for sub in range(1 << len(every)):
+            ops = tr | sum(b for i, b in enumerate(every) if sub >> i & 1)
+            if ops and (sub % 3 == k % 3):            # a third of the 96 subsets per translation kind, rotating: every operator pair meets
+                AC.oracle_spec_case((2, 3, 8, 12) if k % 2 else (3, 3, 9, 7), ops, dev, seed=k)
+            k += 1
+    allz = L.AUG_BRIGHTNESS | L.AUG_SATURATION | L.AUG_CONTRAST | L.AUG_FLIP | L.AUG_CUTOUT
+    AC.adjoint_and_linearity((3, 3, 16, 16), allz | L.AUG_TRANSLATE, dev, 1)
+    AC.adjoint_and_linearity((2, 3, 10, 14), allz | L.AUG_TRANSLATE_REFLECT, dev, 2)
+    AC.adjoint_and_linearity((2, 1, 8, 8), L.AUG_CONTRAST | L.AUG_TRANSLATE_REFLECT, dev, 3)
+
+
+@needs_emu
+@pytest.mark.parametrize("tag", AC.CONSISTENCY_CASES)
+def test_emulated_worker_update_with_diffaug_and_consistency_regularisers(installed, tag):
+    """the worker's discriminator and generator update with DiffAugment + bCR + zCR (BigGAN), CR and DiffAugment alone (SNGAN) through the interpreted
+    kernel sources: loss and every gradient against the REAL reference's (tests/golden/consistency.npz)"""
+    AC.consistency_case(tag, torch.device("cpu"))
+
+
+def test_consistency_oracle_reproduces_the_reference_vectors():
+    """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
+    import json
+    from util import load_golden, sub, GOLDEN
+    from oracle import restate as O, make_golden as MG
+    z = np.load(os.path.join(GOLDEN, "consistency.npz"))
+    meta_c = json.load(open(os.path.join(GOLDEN, "consistency.json")))
+    for tag, m in meta_c.items():
+        hp = m["hp"]
+        fix, meta = load_golden(m["config"])
+        y = meta["yaml"]
+        ocfg = MG.oracle_cfg(y)
+        gen_fn, dis_fn = O.model_fns(ocfg)
+
+        def split(pre, names):
+            st = sub(fix, pre)
+            P = {k: st[k].clone() for k in names}
+            return P, {k: v.clone() for k, v in st.items() if k not in P}
+        GP, GB = split("G_init/", [k[len(tag) + 8:] for k in z.files if k.startswith(tag + "/G_grad/")])
+        DP, DB = split("D_init/", [k[len(tag) + 8:] for k in z.files if k.startswith(tag + "/D_grad/")])
+        p = tag + "/"
+
+        def lst(prefix, name):
+            return [torch.from_numpy(z[f"{p}{prefix}/{name}/{i}"]) if f"{p}{prefix}/{name}/{i}" in z.files else None for i in range(8)]
+        draws = {}
+        if hp.get("diffaug_policy"):
+            draws["series_real"] = [t for t in lst("draw_d", "series_real") if t is not None]
+            draws["series_fake"] = [t for t in lst("draw_d", "series_fake") if t is not None]
+        for name in ("prl_real", "prl_fake"):
+            if f"{p}draw_d/{name}/0" in z.files:
+                draws[name] = lst("draw_d", name)[:3]
+        ins = sub(fix, "in/")
+        zed = torch.from_numpy(z[p + "z_eps_d"]) if p + "z_eps_d" in z.files else None
+        leaves = O._leaves(DP)
+        loss, _ = O.d_consistency_loss(gen_fn, dis_fn, GP, GB, leaves, DB, ocfg, ins["real0"], ins["rl0"], ins["z0"], ins["fl0"], y["LOSS"]["adv_loss"], hp, draws, zed)
+        loss.backward()
+        assert abs(float(loss.detach()) - float(z[p + "d_loss"])) <= 1e-5 * abs(float(z[p + "d_loss"])), tag
+        gmax = max(float(np.abs(z[p + "D_grad/" + k]).max()) for k in leaves)
+        for k, v in leaves.items():
+            assert float((v.grad - torch.from_numpy(z[p + "D_grad/" + k])).abs().max()) <= 1e-4 * gmax, (tag, k)      # (torch's own CPU sums move by 2.5e-5 with the thread count)
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_consistency_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
+    from oracle import make_golden_consistency as MGC
+    monkeypatch.setattr(MGC, "OUT", str(tmp_path / "consistency"))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    import shutil
+    from util import GOLDEN
+    for name in ("biggan32", "sngan32"):
+        shutil.copy(os.path.join(GOLDEN, name + ".npz"), tmp_path / (name + ".npz"))
+    MGC.main()
+    a, b = np.load(os.path.join(GOLDEN, "consistency.npz")), np.load(tmp_path / "consistency.npz")
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    torch.set_num_threads(nt)
