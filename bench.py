@@ -59,7 +59,7 @@ def peak_for(mixed):
 def csrc_sha16():
     """sha256 (first 16 hex digits) over csrc/*.{h,hip} -- the sources of every kernel the benchmarked configurations launch (the step, the extras, the
     FID leg): the PMC summaries under profiles/ carry the same figure (tools/pmc_traffic.py), so the line can say whether its byte counts were taken
-    on THIS code (the GPU box has no .git to ask). csrc/aug/ (augmentations in front of the discriminator: no benchmarked configuration uses them) is not
+    on THIS code (the GPU box has no .git to ask). csrc/ext/ (augmentations in front of the discriminator: no benchmarked configuration uses them) is not
     part of it."""
     import glob
     import hashlib

@@ -497,6 +497,14 @@ int sg_augment_bwd(const sg_aug_desc* d, const float* dy, float* dx, float* work
 int sg_mse_work_floats(void);
 int sg_mse_fwd(const float* a, const float* b, long long n, float* work, float* loss, sg_stream_t s);
 int sg_mse_bwd(const float* a, const float* b, const float* gout, long long n, float* da, float* db, sg_stream_t s);
+/* Least-squares adversarial loss (reference utils/losses.py:216-223 d_ls / g_ls): loss[0] = mean(0.5 (real - 1)^2 + 0.5 fake^2) resp. mean(0.5 (fake - 1)^2)
+ * with the gradient w.r.t. the logits from the same launch (sg_loss_d / sg_loss_g cover hinge, wasserstein, vanilla = logistic). */
+int sg_loss_ls_d(const float* real, const float* fake, int B, float* loss, float* d_real, float* d_fake, sg_stream_t s);
+int sg_loss_ls_g(const float* fake, int B, float* loss, float* d_fake, sg_stream_t s);
+/* Feature matching (reference utils/losses.py:254-259, worker.py:588-596): loss[0] = mean_c |mean_b fake_h[b][c] - mean_b real_h[b][c]| on [B][C] fp32
+ * features, d_fake = its gradient w.r.t. fake_h (real_h is detached by the caller). work: sg_fm_work_floats(C) floats. */
+int sg_fm_work_floats(int C);
+int sg_fm_loss(const float* real_h, const float* fake_h, int B, int C, float* work, float* loss, float* d_fake, sg_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -25,6 +25,8 @@ CR_CASES = [        # (tag, shape, flip, translation)
     ("both32", (6, 3, 32, 32), True, True), ("flip", (5, 3, 8, 12), True, False), ("trans_rect", (4, 3, 16, 24), False, True), ("odd", (3, 3, 9, 17), True, True),
 ]
 MSE_CASES = [("logits", (64,)), ("embed", (16, 48)), ("images", (4, 3, 32, 32))]
+LOSS_KINDS = ["least_square", "logistic", "vanilla"]           # (vanilla rides along: the logistic mirror is the vanilla kernel)
+FM_CASES = [("narrow", (4, 16)), ("wide", (64, 1536)), ("ragged", (7, 300))]
 
 
 def _rand(shape, seed, scale=0.8):
@@ -82,6 +84,26 @@ def main():
         worst = max(worst, float((AR.mse(a, b) - loss).detach().abs()))
         p = f"mse/{tag}/"
         out[p + "a"], out[p + "b"], out[p + "loss"], out[p + "da"], out[p + "db"] = a.detach().numpy(), b.detach().numpy(), loss.detach().numpy(), da.numpy(), db.numpy()
+    RL = importlib.import_module("utils.losses")
+    from . import restate as O
+    for i, kind in enumerate(LOSS_KINDS):                     # src/utils/losses.py:197-223 through the names src/config.py:411-433 binds
+        r, f = _rand((37,), 9000 + i, 1.5).requires_grad_(True), _rand((37,), 9100 + i, 1.5).requires_grad_(True)
+        short = {"least_square": "ls"}.get(kind, kind)
+        dl = getattr(RL, "d_" + short)(r, f, DDP=False)
+        dr, df = torch.autograd.grad(dl, [r, f], torch.tensor(1.3))
+        gl = getattr(RL, "g_" + short)(f, DDP=False)
+        (gf,) = torch.autograd.grad(gl, f, torch.tensor(1.3))
+        worst = max(worst, float((O.d_loss(kind, r, f) - dl).detach().abs()), float((O.g_loss(kind, f) - gl).detach().abs()))
+        p = f"loss/{kind}/"
+        out[p + "real"], out[p + "fake"] = r.detach().numpy(), f.detach().numpy()
+        out[p + "d"], out[p + "d_dreal"], out[p + "d_dfake"], out[p + "g"], out[p + "g_dfake"] = dl.detach().numpy(), dr.numpy(), df.numpy(), gl.detach().numpy(), gf.numpy()
+    for i, (tag, shape) in enumerate(FM_CASES):               # src/utils/losses.py:254-259
+        hr, hf = _rand(shape, 9200 + i), _rand(shape, 9300 + i).requires_grad_(True)
+        fm = RL.feature_matching_loss(hr, hf)
+        (dh,) = torch.autograd.grad(fm, hf, torch.tensor(0.9))
+        worst = max(worst, float((O.feature_matching(hr, hf) - fm).detach().abs()))
+        p = f"fm/{tag}/"
+        out[p + "real"], out[p + "fake"], out[p + "loss"], out[p + "dfake"] = hr.numpy(), hf.detach().numpy(), fm.detach().numpy(), dh.numpy()
     assert worst <= 1e-6, worst
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "restatement bit-identical to the reference on", len(DIFFAUG_CASES) + len(CR_CASES), "augmentation cases (outputs); gradients / mse worst", worst)

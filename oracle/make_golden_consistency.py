@@ -26,6 +26,8 @@ CASES = {     # tag -> (configuration of oracle/make_golden.py, hyper-parameters
     "biggan32_diffaug_bcr_zcr": ("biggan32", dict(diffaug_policy="color,translation,cutout", bcr_lambdas=(10.0, 10.0), d_lambda=20.0, g_lambda=0.5, radius=0.05)),
     "sngan32_cr": ("sngan32", dict(cr_lambda=10.0)),
     "sngan32_diffaug": ("sngan32", dict(diffaug_policy="translation,cutout")),
+    # least-squares adversarial loss (configs/CIFAR10/LSGAN.yaml) + feature matching in the generator update (LOSS.apply_fm of configs/*/MHGAN.yaml) behind DiffAugment
+    "sngan32_ls_fm_diffaug": ("sngan32", dict(adv_loss="least_square", fm_lambda=1.0, diffaug_policy="translation,cutout")),
 }
 AUG_SEED = 31337
 
@@ -74,6 +76,7 @@ def reference_d_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, RC, misc):
 
 
 def reference_g_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, misc):
+    ref_losses = importlib.import_module("utils.losses")
     l2 = torch.nn.MSELoss()
     misc.make_GAN_trainable(Gen, None, Dis)
     misc.toggle_grad(Dis, False)
@@ -85,7 +88,12 @@ def reference_g_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, misc):
     fake_eps = Gen(z_eps, fl) if z_eps is not None else None
     torch.manual_seed(AUG_SEED + 1)
     fake_ = RD.apply_diffaug(fake, hp["diffaug_policy"]) if hp.get("diffaug_policy") else fake          # worker.py:549-550
-    loss = cfgs.LOSS.g_loss(Dis(fake_, fl)["adv_output"], DDP=False)
+    fake_dict = Dis(fake_, fl)
+    loss = cfgs.LOSS.g_loss(fake_dict["adv_output"], DDP=False)
+    if hp.get("fm_lambda") is not None:                                                   # worker.py:588-596
+        real_ = RD.apply_diffaug(ins["real1"], hp["diffaug_policy"]) if hp.get("diffaug_policy") else ins["real1"]
+        real_dict = Dis(real_, ins["rl1"])
+        loss = loss + hp["fm_lambda"] * ref_losses.feature_matching_loss(real_dict["h"].detach(), fake_dict["h"])
     if hp.get("g_lambda") is not None:                                                    # worker.py:601-603
         loss = loss + hp["g_lambda"] * (-1 * l2(fake, fake_eps))
     loss.backward()
@@ -101,6 +109,8 @@ def main():
     for tag, (cfg_name, hp) in CASES.items():
         c = MG.CONFIGS[cfg_name]
         y = c["yaml"]
+        if hp.get("adv_loss"):
+            y = dict(y, LOSS=dict(y.get("LOSS", {}), adv_loss=hp["adv_loss"]))
         cfgs = RI.load_cfgs(y)
         cfgs.define_losses()
         torch.manual_seed(c["seed"])
@@ -144,6 +154,10 @@ def main():
         # ---- generator side (the networks have advanced by the discriminator side's forwards on both implementations) -------------
         torch.manual_seed(AUG_SEED + 1)
         draws_g = {"series_fake": AR.draw_diffaug(shape, hp["diffaug_policy"])} if hp.get("diffaug_policy") else {}
+        if hp.get("fm_lambda") is not None:
+            if hp.get("diffaug_policy"):
+                draws_g["series_real_fm"] = AR.draw_diffaug(shape, hp["diffaug_policy"])
+            hp = dict(hp, _fm_real=(ins["real1"], ins["rl1"]))
         g_loss, g_grads, fake1 = reference_g_side(cfgs, Gen, Dis, ins, hp, ze_g, RD, misc)
         gl = O._leaves(GP)
         og_loss, og_fake = O.g_consistency_loss(gen_fn, dis_fn, gl, GB, DP, DB, ocfg, ins["z1"], ins["fl1"], y["LOSS"]["adv_loss"], hp, draws_g, ze_g)
@@ -156,11 +170,12 @@ def main():
         fix[p + "g_loss"] = g_loss
         for k, v in g_grads.items():
             fix[p + "G_grad/" + k] = v
-        for i, t in enumerate(draws_g.get("series_fake", [])):
-            fix[p + f"draw_g/series_fake/{i}"] = t
+        for name in ("series_fake", "series_real_fm"):
+            for i, t in enumerate(draws_g.get(name, [])):
+                fix[p + f"draw_g/{name}/{i}"] = t
         if ze_g is not None:
             fix[p + "z_eps_g"] = ze_g
-        meta[tag] = {"config": cfg_name, "hp": hp}
+        meta[tag] = {"config": cfg_name, "hp": {k: v for k, v in hp.items() if not k.startswith("_")}}
     np.savez_compressed(OUT + ".npz", **{k: v.detach().cpu().numpy() for k, v in fix.items()})
     json.dump(meta, open(OUT + ".json", "w"), indent=1)
     print("wrote", OUT + ".npz", os.path.getsize(OUT + ".npz") // 1024, "KiB")

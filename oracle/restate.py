@@ -606,6 +606,11 @@ def dcgan_discriminator(x, label, P, B, cfg, bn_mode="track", sn_iter=True):
 # ---------------------------------------------------------------------------------------------------------
 # losses (utils/losses.py:197-239) / gradient penalty (utils/losses.py:268-275,301-316)
 # ---------------------------------------------------------------------------------------------------------
+def feature_matching(real_h, fake_h):
+    """utils/losses.py:254-259"""
+    return torch.mean(torch.abs(torch.mean(fake_h, 0) - torch.mean(real_h, 0)))
+
+
 def d_loss(kind, real, fake):
     if kind == "hinge":
         return torch.mean(F.relu(1. - real)) + torch.mean(F.relu(1. + fake))
@@ -613,14 +618,20 @@ def d_loss(kind, real, fake):
         return torch.mean(fake - real)
     if kind == "vanilla":
         return torch.mean(F.softplus(-real)) + torch.mean(F.softplus(fake))
+    if kind == "logistic":           # utils/losses.py:207-209
+        return (F.softplus(-real) + F.softplus(fake)).mean()
+    if kind == "least_square":       # utils/losses.py:216-218
+        return (0.5 * (real - torch.ones_like(real)) ** 2 + 0.5 * fake ** 2).mean()
     raise ValueError(kind)
 
 
 def g_loss(kind, fake):
     if kind in ("hinge", "wasserstein"):
         return -torch.mean(fake)
-    if kind == "vanilla":
+    if kind in ("vanilla", "logistic"):
         return torch.mean(F.softplus(-fake))
+    if kind == "least_square":       # utils/losses.py:221-223
+        return (0.5 * (fake - torch.ones_like(fake)) ** 2).mean()
     raise ValueError(kind)
 
 
@@ -973,8 +984,13 @@ def g_consistency_loss(gen_fn, dis_fn, GP, GB, DP, DB, cfg, z, fake_labels, loss
     fake = gen_fn(z, fake_labels, GP, GB, bn_mode="track")
     fake_eps = gen_fn(z_eps, fake_labels, GP, GB, bn_mode="track") if z_eps is not None else None
     x = AR.diffaug(fake, hp["diffaug_policy"], draws["series_fake"]) if hp.get("diffaug_policy") else fake
-    adv, _ = dis_fn(x, fake_labels, DP, DB)
+    adv, h = dis_fn(x, fake_labels, DP, DB)
     loss = g_loss(loss_kind, adv)
+    if hp.get("fm_lambda") is not None:      # worker.py:588-596: a real batch through the (series-augmented) discriminator, its pooled features detached
+        real, real_labels = hp["_fm_real"]
+        xr = AR.diffaug(real, hp["diffaug_policy"], draws["series_real_fm"]) if hp.get("diffaug_policy") else real
+        _, h_r = dis_fn(xr, real_labels, DP, DB)
+        loss = loss + hp["fm_lambda"] * feature_matching(h_r.detach(), h)
     if hp.get("g_lambda") is not None:
         loss = loss - hp["g_lambda"] * ((fake - fake_eps) ** 2).mean()
     return loss, fake

@@ -216,6 +216,10 @@ _PROTOS = {
     "sg_mse_work_floats": [],                              # returns a count
     "sg_mse_fwd": [_vp, _vp, _ll, _vp, _vp, _vp],
     "sg_mse_bwd": [_vp, _vp, _vp, _ll, _vp, _vp, _vp],
+    "sg_loss_ls_d": [_vp, _vp, _i, _vp, _vp, _vp, _vp],
+    "sg_loss_ls_g": [_vp, _i, _vp, _vp, _vp],
+    "sg_fm_work_floats": [_i],                             # returns a count
+    "sg_fm_loss": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
 }
 
 

@@ -1,6 +1,6 @@
 """The consistency-regularisation augmentation with the reference's name and signature (reference src/utils/cr.py:13-48; cfgs.AUG.parallel_augment
 of src/config.py:600-604,614-618; called at src/worker.py:326-354): per-image horizontal flip with probability 1/2, then an integer translation of
-up to 1/8 of the image over a reflect-padded copy. One sg_augment launch (csrc/aug/augment.hip) instead of clone + masked flip + pad + index grid +
+up to 1/8 of the image over a reflect-padded copy. One sg_augment launch (csrc/ext/augment.hip) instead of clone + masked flip + pad + index grid +
 gather; the draws are the reference's own calls in its order (the flip coin on the CPU generator, the shifts on the device)."""
 import torch
 

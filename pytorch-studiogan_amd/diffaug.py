@@ -3,7 +3,7 @@ cfgs.AUG.series_augment by src/config.py:586-587 and as the CR / bCR `parallel_a
 in front of every discriminator forward, src/worker.py:276-278,549-550).
 
 The reference runs each operator as its own chain of torch kernels (and materialises an int64 index grid per translation / cutout). Here the
-operators of a policy are gathered into sg_augment calls (csrc/aug/augment.hip: ONE gather pass per call, one extra partial-sum pass for the
+operators of a policy are gathered into sg_augment calls (csrc/ext/augment.hip: ONE gather pass per call, one extra partial-sum pass for the
 contrast mean); the per-image random draws are made exactly as the reference makes them -- same torch calls, same order, same device -- so a
 seeded run consumes the generator's stream identically. Differentiable to second order (functional.AugmentFn / AugmentBwdFn).
 """

@@ -1632,7 +1632,10 @@ class DLossFn(torch.autograd.Function):
         B = real.numel()
         loss = torch.empty(1, dtype=torch.float32, device=real.device)
         dr, df = torch.empty_like(real), torch.empty_like(fake)
-        L.call("sg_loss_d", kind, L.ptr(real), L.ptr(fake), B, L.ptr(loss), L.ptr(dr), L.ptr(df), L.stream())
+        if kind == 3:      # least squares (csrc/ext/losses.hip)
+            L.call("sg_loss_ls_d", L.ptr(real), L.ptr(fake), B, L.ptr(loss), L.ptr(dr), L.ptr(df), L.stream())
+        else:
+            L.call("sg_loss_d", kind, L.ptr(real), L.ptr(fake), B, L.ptr(loss), L.ptr(dr), L.ptr(df), L.stream())
         ctx.save_for_backward(dr, df)
         return loss[0]
 
@@ -1648,7 +1651,10 @@ class GLossFn(torch.autograd.Function):
         fake = _c(fake.float())
         loss = torch.empty(1, dtype=torch.float32, device=fake.device)
         df = torch.empty_like(fake)
-        L.call("sg_loss_g", kind, L.ptr(fake), fake.numel(), L.ptr(loss), L.ptr(df), L.stream())
+        if kind == 3:
+            L.call("sg_loss_ls_g", L.ptr(fake), fake.numel(), L.ptr(loss), L.ptr(df), L.stream())
+        else:
+            L.call("sg_loss_g", kind, L.ptr(fake), fake.numel(), L.ptr(loss), L.ptr(df), L.stream())
         ctx.save_for_backward(df)
         return loss[0]
 
@@ -1804,7 +1810,7 @@ class GatherColsFn(torch.autograd.Function):
 
 
 # ---------------------------------------------------------------------------------------------------------
-# differentiable augmentations in front of the discriminator (csrc/aug/augment.hip)
+# differentiable augmentations in front of the discriminator (csrc/ext/augment.hip)
 # ---------------------------------------------------------------------------------------------------------
 class AugSpec:
     """One sg_augment call: operator bits (applied in the kernel's fixed order), the per-image draws and the window sizes."""
@@ -1885,3 +1891,26 @@ class MseFn(torch.autograd.Function):
         if da is not None or db is not None:
             L.call("sg_mse_bwd", L.ptr(a), L.ptr(b), L.ptr(g), a.numel(), L.ptr(da), L.ptr(db), L.stream())
         return da, db
+
+
+class FeatureMatchingFn(torch.autograd.Function):
+    """mean_c |mean_b fake_h[b, c] - mean_b real_h[b, c]| (reference src/utils/losses.py:254-259); gradient w.r.t. fake_h only (the worker detaches
+    the real features, src/worker.py:594)."""
+
+    @staticmethod
+    def forward(ctx, real_h, fake_h):
+        if real_h.dim() != 2 or real_h.shape != fake_h.shape:
+            raise RuntimeError("feature_matching_loss: expected two [B, C] feature tensors of one shape")
+        real_h, fake_h = _c(real_h.detach().float()), _c(fake_h.float())
+        B, Cc = fake_h.shape
+        work = torch.empty(L.lib().sg_fm_work_floats(Cc), dtype=torch.float32, device=fake_h.device)
+        loss = torch.empty(1, dtype=torch.float32, device=fake_h.device)
+        df = torch.empty_like(fake_h)
+        L.call("sg_fm_loss", L.ptr(real_h), L.ptr(fake_h), B, Cc, L.ptr(work), L.ptr(loss), L.ptr(df), L.stream())
+        ctx.save_for_backward(df)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (df,) = ctx.saved_tensors
+        return None, df * g

@@ -32,6 +32,30 @@ def g_vanilla(d_logit_fake, DDP=False):
     return F.GLossFn.apply(d_logit_fake, 2)
 
 
+def d_logistic(d_logit_real, d_logit_fake, DDP=False):
+    """reference src/utils/losses.py:207-209: mean(softplus(-r) + softplus(f)) -- the vanilla loss with the two means taken as one"""
+    return F.DLossFn.apply(d_logit_real, d_logit_fake, 2)
+
+
+def g_logistic(d_logit_fake, DDP=False):
+    return F.GLossFn.apply(d_logit_fake, 2)
+
+
+def d_ls(d_logit_real, d_logit_fake, DDP=False):
+    """reference src/utils/losses.py:216-218 (LSGAN)"""
+    return F.DLossFn.apply(d_logit_real, d_logit_fake, 3)
+
+
+def g_ls(d_logit_fake, DDP=False):
+    """reference src/utils/losses.py:221-223"""
+    return F.GLossFn.apply(d_logit_fake, 3)
+
+
+def feature_matching_loss(real_embed, fake_embed):
+    """reference src/utils/losses.py:254-259 (LOSS.apply_fm, src/worker.py:588-596)"""
+    return F.FeatureMatchingFn.apply(real_embed, fake_embed)
+
+
 class GatherLayer(autograd.Function):
     """All-gather with a backward pass, reference src/utils/losses.py:19-37 (used under DDP by the LeCam regulariser,
     src/worker.py:396-399, and the contrastive heads): forward returns the rank-ordered concatenation of every rank's tensor
@@ -63,8 +87,9 @@ def gather_logits(x, group=None):
     return GatherLayer.apply(x, group)
 
 
-G_LOSSES = {"vanilla": g_vanilla, "hinge": g_hinge, "wasserstein": g_wasserstein}
-D_LOSSES = {"vanilla": d_vanilla, "hinge": d_hinge, "wasserstein": d_wasserstein}
+# reference src/config.py:411-433 (define_losses): the names LOSS.adv_loss takes
+G_LOSSES = {"vanilla": g_vanilla, "logistic": g_logistic, "least_square": g_ls, "hinge": g_hinge, "wasserstein": g_wasserstein}
+D_LOSSES = {"vanilla": d_vanilla, "logistic": d_logistic, "least_square": d_ls, "hinge": d_hinge, "wasserstein": d_wasserstein}
 
 
 def cal_deriv(inputs, outputs, device):

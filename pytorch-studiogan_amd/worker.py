@@ -71,8 +71,10 @@ class Worker:
                  apply_lecam=False, lecam_lambda=0.3, lecam_ema_start_iter=1000, lecam_ema_decay=0.99,
                  d_cond_mtd="W/O", aux_cls_type="W/O", cond_lambda=1.0, temperature=1.0, m_p=1.0, tac_dis_lambda=1.0, tac_gen_lambda=1.0,
                  mh_lambda=1.0, apply_diffaug=False, diffaug_type="diffaug", apply_cr=False, cr_aug_type="cr", cr_lambda=10.0,
-                 apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0):
+                 apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0,
+                 apply_fm=False, fm_lambda=1.0):
         self.Gen, self.Dis = Gen, Dis
+        self.apply_fm, self.fm_lambda = apply_fm, fm_lambda          # feature matching in the generator update (src/worker.py:588-596)
         # augmentations in front of the discriminator (reference src/config.py:582-626): series_augment runs on every real / fake batch
         # (src/worker.py:276-278,549-550), parallel_augment makes the second view of the consistency regularisers (:326-354)
         self.series_augment = self._augmenter(diffaug_type, "diffaug_type") if apply_diffaug else (lambda x: x)
@@ -248,7 +250,9 @@ class Worker:
         return dis_acml_loss
 
     # -- src/worker.py:502-681 ------------------------------------------------------------------------------------
-    def train_generator(self, current_step, injected=None):
+    def train_generator(self, current_step, injected=None, real_batches=None):
+        """real_batches: list (n_g * acml) of (images, labels), only read by the feature-matching term (LOSS.apply_fm samples a real batch per micro-step,
+        src/worker.py:589-591)"""
         make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
         toggle_grad(self.Dis, False)
         toggle_grad(self.Gen, True)
@@ -278,6 +282,10 @@ class Worker:
                     elif self.aux_cls_type == "ADC":
                         adc_fake_dict = self.Dis(fake_images_, fake_labels, adc_fake=self.adc_fake)       # (the augmented batch: src/worker.py:583)
                         gen_acml_loss = gen_acml_loss - self.cond_lambda * self.cond_loss(**adc_fake_dict)
+                if self.apply_fm:        # src/worker.py:588-596: pooled features of a real batch (detached) against the fake batch's
+                    real_images, real_labels = real_batches[k - 1]
+                    real_dict = self.Dis(self.series_augment(real_images), real_labels)
+                    gen_acml_loss = gen_acml_loss + self.fm_lambda * sg_losses.feature_matching_loss(real_dict["h"].detach(), fake_dict["h"])
                 if self.apply_zcr:       # src/worker.py:601-603: G's side of the latent CR pushes G(z) and G(z + eps) apart
                     gen_acml_loss = gen_acml_loss - self.g_lambda * sg_losses.l2_loss(fake_images, fake_images_eps)
                 gen_acml_loss = gen_acml_loss / self.acml
@@ -297,5 +305,5 @@ class Worker:
     # -- src/loader.py:392-405 ------------------------------------------------------------------------------------
     def step(self, current_step, real_batches, injected_d=None, injected_g=None):
         d = self.train_discriminator(current_step, real_batches, injected_d)
-        g = self.train_generator(current_step, injected_g)
+        g = self.train_generator(current_step, injected_g, real_batches if self.apply_fm else None)
         return d, g

@@ -207,10 +207,11 @@ def consistency_case(tag, dev):
     D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
     opt = hyper(y)
     bcr = hp.get("bcr_lambdas")
-    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], hp.get("adv_loss", opt["adv_loss"]), opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
                d_updates_per_step=1, apply_diffaug=bool(hp.get("diffaug_policy")), apply_cr=hp.get("cr_lambda") is not None, cr_lambda=hp.get("cr_lambda", 0.0),
                apply_bcr=bcr is not None, real_lambda=(bcr or [0, 0])[0], fake_lambda=(bcr or [0, 0])[1], apply_zcr=hp.get("d_lambda") is not None,
-               radius=hp.get("radius", 0.0), g_lambda=hp.get("g_lambda", 0.0), d_lambda=hp.get("d_lambda", 0.0))
+               radius=hp.get("radius", 0.0), g_lambda=hp.get("g_lambda", 0.0), d_lambda=hp.get("d_lambda", 0.0),
+               apply_fm=hp.get("fm_lambda") is not None, fm_lambda=hp.get("fm_lambda", 0.0))
     if hp.get("diffaug_policy"):
         from studiogan_amd import diffaug as DA
         w.series_augment = lambda x: DA.apply_diffaug(x, hp["diffaug_policy"])
@@ -241,8 +242,8 @@ def consistency_case(tag, dev):
         for k, prm in D.named_parameters():
             prm.copy_(fix["D_init/" + k].to(dev))
     zeg = torch.from_numpy(z[p + "z_eps_g"]).to(dev) if p + "z_eps_g" in z.files else None
-    with Replayed(draws_of("draw_g", ["series_fake"])):
-        g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"]) + ((zeg,) if zeg is not None else ())])
+    with Replayed(draws_of("draw_g", ["series_fake", "series_real_fm"])):
+        g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"]) + ((zeg,) if zeg is not None else ())], real_batches=[(ins["real1"], ins["rl1"])])
     C.check("g_loss", g_loss, torch.from_numpy(z[p + "g_loss"]), 1e-3)
     gmx = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "G_grad/"))
     for k, prm in G.named_parameters():
@@ -250,4 +251,39 @@ def consistency_case(tag, dev):
     C.finish()
 
 
-CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug"]
+CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug", "sngan32_ls_fm_diffaug"]
+
+
+def loss_case(kind, dev):
+    """least-squares / logistic (/ vanilla) adversarial losses: value and gradients against the reference's functions (utils/losses.py:197-223)"""
+    from studiogan_amd import losses
+    z = np.load(GOLD)
+    p = f"loss/{kind}/"
+    r, f = _t(z, p + "real").to(dev).requires_grad_(True), _t(z, p + "fake").to(dev).requires_grad_(True)
+    dl = losses.D_LOSSES[kind](r, f, DDP=False)
+    dr, df = torch.autograd.grad(dl, [r, f], torch.tensor(1.3, device=dev))
+    gl = losses.G_LOSSES[kind](f, DDP=False)
+    (gf,) = torch.autograd.grad(gl, f, torch.tensor(1.3, device=dev))
+    for name, a, b in (("d", dl, "d"), ("d dreal", dr, "d_dreal"), ("d dfake", df, "d_dfake"), ("g", gl, "g"), ("g dfake", gf, "g_dfake")):
+        check(f"{kind} {name}", a.reshape(-1), _t(z, p + b).reshape(-1), 3e-6)
+
+
+def fm_case(case, dev):
+    from studiogan_amd import losses
+    tag, shape = case
+    z = np.load(GOLD)
+    p = f"fm/{tag}/"
+    hr, hf = _t(z, p + "real").to(dev).requires_grad_(True), _t(z, p + "fake").to(dev).requires_grad_(True)
+    fm = losses.feature_matching_loss(hr.detach(), hf)
+    (dh,) = torch.autograd.grad(fm, hf, torch.tensor(0.9, device=dev))
+    check(f"fm {tag}", fm.reshape(-1), _t(z, p + "loss").reshape(-1), 3e-6)
+    # the gradient is sign(column difference) / (B C): the signs agree wherever the difference is not within rounding distance of 0
+    exp = _t(z, p + "dfake")
+    flipped = (torch.sign(dh.detach().cpu()) != torch.sign(exp)).any(0)
+    diff = (_t(z, p + "fake").mean(0) - _t(z, p + "real").mean(0)).abs()
+    assert not bool(flipped.any()) or float(diff[flipped].max()) <= 1e-6, tag
+    keep = ~flipped
+    check(f"fm {tag} dfake", dh.detach().cpu()[:, keep], exp[:, keep], 1e-6)
+
+
+LOSS_KINDS, FM_CASES = MGA.LOSS_KINDS, MGA.FM_CASES

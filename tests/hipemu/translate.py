@@ -170,9 +170,9 @@ template <class T> static inline void hipemu_tr_assign(T& dst, unsigned addr) { 
 
 
 def source_files():
-    """(name in the flat translated tree, path): csrc/*.{h,hip} and the units of csrc/aug/ (augmentation kernels)"""
+    """(name in the flat translated tree, path): csrc/*.{h,hip} and the units of csrc/ext/"""
     out = [(fn, os.path.join(CSRC, fn)) for fn in sorted(os.listdir(CSRC)) if fn.endswith(".h") or fn.endswith(".hip")]
-    aug = os.path.join(CSRC, "aug")
+    aug = os.path.join(CSRC, "ext")
     if os.path.isdir(aug):
         out += [(fn, os.path.join(aug, fn)) for fn in sorted(os.listdir(aug)) if fn.endswith(".h") or fn.endswith(".hip")]
     return out
@@ -181,7 +181,7 @@ def source_files():
 def translate_tree(dst):
     os.makedirs(dst, exist_ok=True)
     files = source_files()
-    assert len(set(n for n, _ in files)) == len(files), "file names must be unique across csrc/ and csrc/aug/"
+    assert len(set(n for n, _ in files)) == len(files), "file names must be unique across csrc/ and csrc/ext/"
     hdr = os.path.join(REPO, "include", "sgamd.h")
     for k, (fn, src_path) in enumerate(files):
         with open(src_path) as f:

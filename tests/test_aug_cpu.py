@@ -1,6 +1,6 @@
 """CPU: the augmentation oracle (oracle/aug_ref.py) against the vectors the reference's own apply_diffaug / apply_cr_aug / MSELoss wrote
 (tests/golden/aug.npz), the regeneration of those vectors from the reference when it is present, the host mirrors' argument behaviour, and the kernel
-SOURCES of csrc/aug/augment.hip run lane by lane on the CPU interpreter (tests/hipemu) through the product's own Python layer against the same vectors --
+SOURCES of csrc/ext/augment.hip run lane by lane on the CPU interpreter (tests/hipemu) through the product's own Python layer against the same vectors --
 the checks tests/test_aug_gpu.py makes on the GPU."""
 import os
 import sys
@@ -126,6 +126,14 @@ def test_emulated_l2_loss_matches_reference_vectors(installed, case):
 
 
 @needs_emu
+def test_emulated_further_losses_match_reference_vectors(installed):
+    for kind in AC.LOSS_KINDS:
+        AC.loss_case(kind, torch.device("cpu"))
+    for case in AC.FM_CASES:
+        AC.fm_case(case, torch.device("cpu"))
+
+
+@needs_emu
 def test_emulated_augment_operator_subsets_and_properties(installed):
     from studiogan_amd import _lib as L
     dev = torch.device("cpu")
@@ -185,7 +193,7 @@ def test_consistency_oracle_reproduces_the_reference_vectors():
         ins = sub(fix, "in/")
         zed = torch.from_numpy(z[p + "z_eps_d"]) if p + "z_eps_d" in z.files else None
         leaves = O._leaves(DP)
-        loss, _ = O.d_consistency_loss(gen_fn, dis_fn, GP, GB, leaves, DB, ocfg, ins["real0"], ins["rl0"], ins["z0"], ins["fl0"], y["LOSS"]["adv_loss"], hp, draws, zed)
+        loss, _ = O.d_consistency_loss(gen_fn, dis_fn, GP, GB, leaves, DB, ocfg, ins["real0"], ins["rl0"], ins["z0"], ins["fl0"], hp.get("adv_loss", y["LOSS"]["adv_loss"]), hp, draws, zed)
         loss.backward()
         assert abs(float(loss.detach()) - float(z[p + "d_loss"])) <= 1e-5 * abs(float(z[p + "d_loss"])), tag
         gmax = max(float(np.abs(z[p + "D_grad/" + k]).max()) for k in leaves)

@@ -1,4 +1,4 @@
-"""GPU: the differentiable augmentations and the l2 loss (csrc/aug/augment.hip behind studiogan_amd.diffaug / .cr / losses.l2_loss)
+"""GPU: the differentiable augmentations and the l2 loss (csrc/ext/augment.hip behind studiogan_amd.diffaug / .cr / losses.l2_loss)
   * against the vectors the reference's own apply_diffaug / apply_cr_aug / MSELoss wrote under a seeded generator (tests/golden/aug.npz): outputs
     (bit for bit where no contrast mean enters), gradients and the second-order term an R1 penalty through an augmented batch needs;
   * every operator subset against oracle/aug_ref.py (pinned bit-identically to the reference) in the kernel's fixed order, both translation kinds;
@@ -28,6 +28,16 @@ def test_cr_aug_matches_reference_vectors(sg, case):
 @pytest.mark.parametrize("case", AC.MSE_CASES, ids=[c[0] for c in AC.MSE_CASES])
 def test_l2_loss_matches_reference_vectors(sg, case):
     AC.mse_case(case, DEV)
+
+
+@pytest.mark.parametrize("kind", AC.LOSS_KINDS)
+def test_least_squares_and_logistic_losses_match_reference_vectors(sg, kind):
+    AC.loss_case(kind, DEV)
+
+
+@pytest.mark.parametrize("case", AC.FM_CASES, ids=[c[0] for c in AC.FM_CASES])
+def test_feature_matching_loss_matches_reference_vectors(sg, case):
+    AC.fm_case(case, DEV)
 
 
 def test_augment_operator_subsets_vs_oracle(sg):
