@@ -26,7 +26,9 @@ def timed(fn, reps=50):
 
 def main():
     dev = torch.device("cuda:0")
-    for shape in ((256, 3, 128, 128), (256, 3, 32, 32), (64, 3, 256, 256)):
+    # (the first shape is measured twice: the first timed loop of a fresh process shows ~0.8 ms per call of host-side one-off cost -- the kernel trace of the same
+    #  run has no k_aug_* launch above 24 us, profiles/r05_augment_kerneltrace_k.txt)
+    for shape in ((256, 3, 128, 128), (256, 3, 128, 128), (256, 3, 32, 32), (64, 3, 256, 256)):
         N, C, H, W = shape
         n = N * C * H * W
         x = torch.rand(shape, device=dev) * 2 - 1
