@@ -505,6 +505,14 @@ int sg_loss_ls_g(const float* fake, int B, float* loss, float* d_fake, sg_stream
  * features, d_fake = its gradient w.r.t. fake_h (real_h is detached by the caller). work: sg_fm_work_floats(C) floats. */
 int sg_fm_work_floats(int C);
 int sg_fm_loss(const float* real_h, const float* fake_h, int B, int C, float* work, float* loss, float* d_fake, sg_stream_t s);
+/* Adjoints the create_graph pass through SelfAttention needs next to the first-order entry points (R1 / gradient penalties on a discriminator with
+ * attention: reference utils/losses.py:301-316,355-361 through utils/ops.py:83-103):
+ *   sg_maxpool2_gather    y[q][c] = x[2x2 window of q][idx[q][c]][c]: the pooling with the argmax of sg_maxpool2_fwd held fixed (adjoint of sg_maxpool2_bwd)
+ *   sg_softmax_rows_bwd2  gP = u * (dP - <P, dP>) - dP * <u, P> per row: d/dP of sg_softmax_rows_bwd's dS = P * (dP - <P, dP>), contracted with u (fp32)
+ *   sg_scale_by_ptr       y = sigma[0] * x with sigma on the device (SelfAttention's output gain) */
+int sg_maxpool2_gather(int dtype, const void* x, int ldx, const uint8_t* idx, void* y, int ldy, int N, int H, int W, int C, sg_stream_t s);
+int sg_softmax_rows_bwd2(const float* P, const float* dP, const float* u, float* gP, long long rows, int cols, sg_stream_t s);
+int sg_scale_by_ptr(int dtype, const void* x, const float* sigma, void* y, long long n, sg_stream_t s);
 
 #ifdef __cplusplus
 }

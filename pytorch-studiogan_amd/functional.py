@@ -18,7 +18,7 @@ def _first_order_only(name):
     """Functions without a differentiable backward refuse create_graph=True instead of silently cutting the graph."""
     if torch.is_grad_enabled():
         raise NotImplementedError(name + ": second-order gradients (create_graph=True) are implemented for the discriminator's "
-                                         "conv / BN / pooling / head path only (WGAN-GP)")
+                                         "conv / BN / pooling / self-attention / head path only (gradient penalties, R1)")
 
 
 def _param_grad_wanted(*params):
@@ -346,7 +346,8 @@ class ConvertFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        _first_order_only("ConvertFn")
+        if torch.is_grad_enabled():          # a create_graph pass: the conversion is linear, its adjoint is the conversion back
+            return ConvertFn.apply(dy, ctx.src), None
         dy = _c(dy)
         dx = torch.empty(dy.shape, dtype=ctx.src, device=dy.device)
         L.call("sg_convert", L.dt(dy), L.dt(ctx.src), L.ptr(dy), L.ptr(dx), dy.numel(), L.stream())
@@ -475,7 +476,6 @@ class ConvDgradFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, dy, x, weight, rt, slot, cfg):
         dy = _c(dy)
-        assert rt.rows_pad == rt.rows, "padded output channels are not supported on the second-order path"
         ctx.save_for_backward(dy, x)
         ctx.rt, ctx.slot, ctx.cfg = rt, slot, cfg
         return _conv_dgrad(dy, x, rt, slot, cfg)
@@ -497,10 +497,11 @@ class ConvDgradFn(torch.autograd.Function):
         pool = cfg.out_pool
         g_dy = None
         if ctx.needs_input_grad[0]:
-            g_dy = conv2d_raw(t, bank.w_fwd(slot, rt), Cin, rt.rows, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w,
+            # (rows_pad: the zero rows of a padded weight image -- theta / phi of SelfAttention, the RGB layer -- ride along as in the first-order launches)
+            g_dy = conv2d_raw(t, bank.w_fwd(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, cfg.stride, cfg.pad_h, cfg.pad_w,
                               L.PIX_UPSAMPLE if cfg.in_upsample else 0, L.EPI_POOL if pool else 0, alpha=0.25 if pool else 1.0)
         if ctx.needs_input_grad[2]:
-            conv2d_wgrad_raw(t, dy, bank.dwt(slot, rt), Cin, rt.rows, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w,
+            conv2d_wgrad_raw(t, dy, bank.dwt(slot, rt), Cin, rt.rows_pad, cfg.R, cfg.S, Ho, Wo, cfg.stride, cfg.pad_h, cfg.pad_w,
                              L.PIX_UPSAMPLE if cfg.in_upsample else 0, L.PIX_UPSAMPLE if pool else 0, alpha=0.25 if pool else 1.0)
         return g_dy, None, None, None, None, None
 
@@ -1257,23 +1258,194 @@ class AddReluFn(torch.autograd.Function):
 # ---------------------------------------------------------------------------------------------------------
 # self-attention core (reference src/utils/ops.py:83-103)
 # ---------------------------------------------------------------------------------------------------------
-class AttnCoreFn(torch.autograd.Function):
-    """o = softmax(theta . maxpool(phi)^T) . maxpool(g)   per image; theta/phi: [B,H,W,Dp], g: [B,H,W,Cg]."""
+class MaxPool2Fn(torch.autograd.Function):
+    """2x2 max pooling of an NHWC tensor -> [B, H/2 * W/2, C] (reference src/utils/ops.py:86,91: nn.MaxPool2d(2) on phi and g of SelfAttention). Its own autograd
+    node since round 5 (the same two launches as before, when it sat inside the attention core's node) so that a create_graph pass can differentiate it: the
+    backward is the scatter by the saved argmax, linear in dy, whose adjoint is the gather by the same argmax."""
 
     @staticmethod
-    def forward(ctx, theta, phi_full, g_full):
-        theta, phi_full, g_full = _c(theta), _c(phi_full), _c(g_full)
+    def forward(ctx, x):
+        x = _c(x)
+        B, H, W, Cc = x.shape
+        y = torch.empty((B, (H // 2) * (W // 2), Cc), dtype=x.dtype, device=x.device)
+        idx = torch.empty((B, (H // 2) * (W // 2), Cc), dtype=torch.uint8, device=x.device)
+        L.call("sg_maxpool2_fwd", L.dt(x), L.ptr(x), Cc, L.ptr(y), Cc, L.ptr(idx), B, H, W, Cc, L.stream())
+        ctx.save_for_backward(idx)
+        ctx.dims = (B, H, W, Cc)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (idx,) = ctx.saved_tensors
+        if torch.is_grad_enabled():
+            return MaxPool2BwdFn.apply(dy, idx, ctx.dims)
+        return _maxpool2_bwd(dy, idx, ctx.dims)
+
+
+def _maxpool2_bwd(dy, idx, dims):
+    B, H, W, Cc = dims
+    dy = _c(dy)
+    dx = torch.empty((B, H, W, Cc), dtype=dy.dtype, device=dy.device)
+    L.call("sg_maxpool2_bwd", L.dt(dy), L.ptr(dy), Cc, L.ptr(idx), L.ptr(dx), Cc, B, H, W, Cc, L.stream())
+    return dx
+
+
+class MaxPool2BwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, idx, dims):
+        ctx.save_for_backward(idx)
+        ctx.dims = dims
+        return _maxpool2_bwd(dy, idx, dims)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (idx,) = ctx.saved_tensors
+        B, H, W, Cc = ctx.dims
+        ddx = _c(ddx)
+        y = torch.empty((B, (H // 2) * (W // 2), Cc), dtype=ddx.dtype, device=ddx.device)
+        L.call("sg_maxpool2_gather", L.dt(ddx), L.ptr(ddx), Cc, L.ptr(idx), L.ptr(y), Cc, B, H, W, Cc, L.stream())
+        return y, None, None
+
+
+class BmmFn(torch.autograd.Function):
+    """C[b] = op(A[b]) op(B[b]) in exact fp32 on the MFMA engine (op = transpose when ta / tb); closed under differentiation (its gradients are BmmFn calls):
+    the matrix products of the create_graph pass through SelfAttention (reference src/utils/ops.py:93,100 torch.bmm, differentiated twice by autograd)."""
+
+    @staticmethod
+    def forward(ctx, A, Bm, ta, tb):
+        A, Bm = _c(A), _c(Bm)
+        if A.dtype != torch.float32 or Bm.dtype != torch.float32 or A.dim() != 3 or Bm.dim() != 3 or A.shape[0] != Bm.shape[0]:
+            raise RuntimeError("BmmFn: two fp32 [batch, rows, cols] tensors expected")
+        nb = A.shape[0]
+        M, K = (A.shape[2], A.shape[1]) if ta else (A.shape[1], A.shape[2])
+        K2, N = (Bm.shape[2], Bm.shape[1]) if tb else (Bm.shape[1], Bm.shape[2])
+        if K != K2:
+            raise RuntimeError("BmmFn: inner dimensions differ")
+        out = torch.empty((nb, M, N), dtype=torch.float32, device=A.device)
+        # OUT[j][i] = sum_k P(i, k) Q(j, k): P = op(B) seen from its column index (form 1 = [K][N] storage), Q = op(A) (form 0 = [M][K] storage)
+        gemm_raw(L.F32, Bm, 0 if tb else 1, Bm.shape[2], A, 1 if ta else 0, A.shape[2], out, N, N, M, K, batch=nb,
+                 p_bs=Bm.shape[1] * Bm.shape[2], q_bs=A.shape[1] * A.shape[2], out_bs=M * N)
+        ctx.save_for_backward(A, Bm)
+        ctx.t = (ta, tb)
+        return out
+
+    @staticmethod
+    def backward(ctx, dC):
+        A, Bm = ctx.saved_tensors
+        ta, tb = ctx.t
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = BmmFn.apply(Bm, dC, tb, True) if ta else BmmFn.apply(dC, Bm, False, not tb)
+        if ctx.needs_input_grad[1]:
+            dB = BmmFn.apply(dC, A, True, ta) if tb else BmmFn.apply(A, dC, not ta, False)
+        return dA, dB, None, None
+
+
+class SoftmaxRowsFn(torch.autograd.Function):
+    """P = softmax over the last dimension (fp32), differentiable twice: dS = P * (dP - <P, dP>) (SoftmaxRowsBwdFn), whose own gradients are the same map
+    applied to the incoming cotangent (the Jacobian diag(P) - P P^T is symmetric) and sg_softmax_rows_bwd2 for the dependence on P."""
+
+    @staticmethod
+    def forward(ctx, S):
+        S = _c(S)
+        P = torch.empty_like(S)
+        L.call("sg_softmax_rows", L.F32, L.ptr(S), L.ptr(P), S.numel() // S.shape[-1], S.shape[-1], L.stream())
+        ctx.save_for_backward(P)
+        return P
+
+    @staticmethod
+    def backward(ctx, dP):
+        (P,) = ctx.saved_tensors
+        return SoftmaxRowsBwdFn.apply(P, dP)
+
+
+class SoftmaxRowsBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, P, dP):
+        P, dP = _c(P), _c(dP)
+        dS = torch.empty_like(P)
+        L.call("sg_softmax_rows_bwd", L.F32, L.ptr(P), L.ptr(dP), L.ptr(dS), P.numel() // P.shape[-1], P.shape[-1], L.stream())
+        ctx.save_for_backward(P, dP)
+        return dS
+
+    @staticmethod
+    def backward(ctx, u):
+        _first_order_only("SoftmaxRowsBwdFn")        # (third order: not a path of the reference's regularisers)
+        P, dP = ctx.saved_tensors
+        u = _c(u)
+        rows, cols = P.numel() // P.shape[-1], P.shape[-1]
+        gP = gdP = None
+        if ctx.needs_input_grad[0]:
+            gP = torch.empty_like(P)
+            L.call("sg_softmax_rows_bwd2", L.ptr(P), L.ptr(dP), L.ptr(u), L.ptr(gP), rows, cols, L.stream())
+        if ctx.needs_input_grad[1]:
+            gdP = torch.empty_like(P)
+            L.call("sg_softmax_rows_bwd", L.F32, L.ptr(P), L.ptr(u), L.ptr(gdP), rows, cols, L.stream())
+        return gP, gdP
+
+
+class ScalePtrFn(torch.autograd.Function):
+    """y = sigma[0] * x with sigma a one-element fp32 device tensor (SelfAttention's learnt output gain, reference src/utils/ops.py:81,103) as a differentiable
+    operator of both: dx = sigma * dy (itself again), dsigma = <dy, x> (accumulated into the parameter's gradient like every parameter gradient here)."""
+
+    @staticmethod
+    def forward(ctx, x, sigma):
+        x = _c(x)
+        y = torch.empty_like(x)
+        L.call("sg_scale_by_ptr", L.dt(x), L.ptr(x), L.ptr(sigma), L.ptr(y), x.numel(), L.stream())
+        ctx.save_for_backward(x, sigma)
+        ctx.sigma_param = sigma
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, sigma = ctx.saved_tensors
+        dx = None
+        if torch.is_grad_enabled():
+            if _param_grad_wanted(ctx.sigma_param):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP / R1 path)")
+            return (ScalePtrFn.apply(dy, sigma) if ctx.needs_input_grad[0] else None), None
+        dy = _c(dy)
+        if ctx.needs_input_grad[1]:
+            g = ensure_grad(ctx.sigma_param)
+            L.call("sg_dot", L.dt(dy), L.ptr(dy), L.ptr(x), dy.numel(), L.ptr(g), 1.0, None, L.stream())
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(dy)
+            L.call("sg_scale_by_ptr", L.dt(dy), L.ptr(dy), L.ptr(sigma), L.ptr(dx), dy.numel(), L.stream())
+        return dx, None
+
+
+class AttnCoreFn:
+    """o = softmax(theta . maxpool(phi)^T) . maxpool(g) per image; theta / phi: [B,H,W,Dp], g: [B,H,W,Cg] (reference src/utils/ops.py:83-101): the two poolings
+    and the attention proper as three autograd nodes (the launches are those of the single node this replaced)."""
+
+    @staticmethod
+    def apply(theta, phi_full, g_full):
+        return AttnPooledFn.apply(theta, MaxPool2Fn.apply(phi_full), MaxPool2Fn.apply(g_full))
+
+
+def _attn_reference_graph(theta, phi, g, dims):
+    """the attention core from differentiable fp32 primitives (scores and probabilities materialised): what a create_graph backward differentiates"""
+    B, H, W, Dp, Cg = dims
+    T = theta.dtype
+    th = ConvertFn.apply(theta, torch.float32).reshape(B, H * W, Dp)
+    ph, gg = ConvertFn.apply(phi, torch.float32), ConvertFn.apply(g, torch.float32)
+    P = SoftmaxRowsFn.apply(BmmFn.apply(th, ph, False, True))
+    o = BmmFn.apply(P, gg, False, False).reshape(B, H, W, Cg)
+    return ConvertFn.apply(o, T)
+
+
+class AttnPooledFn(torch.autograd.Function):
+    """the attention core on pooled keys / values: theta [B,H,W,Dp], phi [B,HW/4,Dp], g [B,HW/4,Cg] -> o [B,H,W,Cg]"""
+
+    @staticmethod
+    def forward(ctx, theta, phi, g):
+        theta, phi, g = _c(theta), _c(phi), _c(g)
         B, H, W, Dp = theta.shape
-        Cg = g_full.shape[3]
+        Cg = g.shape[2]
         HW, HW4 = H * W, (H // 2) * (W // 2)
         dev, T = theta.device, theta.dtype
         sd = L.dt(T)
-        phi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
-        g = torch.empty((B, HW4, Cg), dtype=T, device=dev)
-        idx_phi = torch.empty((B, HW4, Dp), dtype=torch.uint8, device=dev)
-        idx_g = torch.empty((B, HW4, Cg), dtype=torch.uint8, device=dev)
-        L.call("sg_maxpool2_fwd", sd, L.ptr(phi_full), Dp, L.ptr(phi), Dp, L.ptr(idx_phi), B, H, W, Dp, L.stream())
-        L.call("sg_maxpool2_fwd", sd, L.ptr(g_full), Cg, L.ptr(g), Cg, L.ptr(idx_g), B, H, W, Cg, L.stream())
         fused = T == torch.bfloat16 and L.lib().sg_attn_fused_ok(B, HW, HW4, Dp, Cg) == 1
         # the bf16 probabilities are written only when a backward can come that needs them (they feed dg = P^T dO): never for the no-grad generator
         # forwards of the discriminator update, nor when the backward recomputes them itself (sg_attn_bwd_fused: no P and no dS in HBM at all)
@@ -1308,15 +1480,21 @@ class AttnCoreFn(torch.autograd.Function):
             o = torch.empty((B, H, W, Cg), dtype=T, device=dev)
             # o[q][c] = sum_k P[q][k] g[k][c]
             gemm_raw(sd, g, 1, Cg, P, 0, HW4, o, Cg, Cg, HW, HW4, batch=B, p_bs=HW4 * Cg, q_bs=HW * HW4, out_bs=HW * Cg)
-        ctx.save_for_backward(theta, phi, g, idx_phi, idx_g, P, lse, o32)
+        ctx.save_for_backward(theta, phi, g, P, lse, o32)
         ctx.dims = (B, H, W, Dp, Cg)
         return o
 
     @staticmethod
     def backward(ctx, do):
-        _first_order_only("AttnCoreFn")
-        theta, phi, g, idx_phi, idx_g, P, lse, o32 = ctx.saved_tensors
+        theta, phi, g, P, lse, o32 = ctx.saved_tensors
         B, H, W, Dp, Cg = ctx.dims
+        if torch.is_grad_enabled():
+            # create_graph=True (R1 / gradient penalties through a discriminator with attention): re-evaluate the block from differentiable primitives on the saved
+            # inputs (which carry their graph) and let autograd take the first-order gradient of THAT with a graph of its own
+            with torch.enable_grad():
+                ins = [t for t, need in zip((theta, phi, g), ctx.needs_input_grad) if need]
+                grads = list(torch.autograd.grad(_attn_reference_graph(theta, phi, g, ctx.dims), ins, do, create_graph=True)) if ins else []
+            return tuple(grads.pop(0) if need else None for need in ctx.needs_input_grad)
         HW, HW4 = H * W, (H // 2) * (W // 2)
         do = _c(do)
         dev, T = do.device, do.dtype
@@ -1331,11 +1509,7 @@ class AttnCoreFn(torch.autograd.Function):
             dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
             L.call("sg_attn_bwd_fused", L.ptr(theta), L.ptr(phi), L.ptr(g), L.ptr(do), L.ptr(o32), L.ptr(lse), L.ptr(delta), L.ptr(dtheta), L.ptr(dphi),
                    L.ptr(dg), B, HW, HW4, Dp, Cg, L.stream())
-            dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
-            dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)
-            L.call("sg_maxpool2_bwd", sd, L.ptr(dphi), Dp, L.ptr(idx_phi), L.ptr(dphi_full), Dp, B, H, W, Dp, L.stream())
-            L.call("sg_maxpool2_bwd", sd, L.ptr(dg), Cg, L.ptr(idx_g), L.ptr(dg_full), Cg, B, H, W, Cg, L.stream())
-            return dtheta, dphi_full, dg_full
+            return dtheta, dphi, dg
         # dg[k][c] = sum_q P[q][k] do[q][c]
         dg = torch.empty((B, HW4, Cg), dtype=T, device=dev)
         gemm_raw(sd, do, 1, Cg, P, 1, HW4, dg, Cg, Cg, HW4, HW, batch=B, p_bs=HW * Cg, q_bs=HW * HW4, out_bs=HW4 * Cg)
@@ -1355,11 +1529,7 @@ class AttnCoreFn(torch.autograd.Function):
         # dphi[k][d] = sum_q dS[q][k] theta[q][d]
         dphi = torch.empty((B, HW4, Dp), dtype=T, device=dev)
         gemm_raw(sd, theta, 1, Dp, dS, 1, HW4, dphi, Dp, Dp, HW4, HW, batch=B, p_bs=HW * Dp, q_bs=HW * HW4, out_bs=HW4 * Dp)
-        dphi_full = torch.empty((B, H, W, Dp), dtype=T, device=dev)
-        dg_full = torch.empty((B, H, W, Cg), dtype=T, device=dev)
-        L.call("sg_maxpool2_bwd", sd, L.ptr(dphi), Dp, L.ptr(idx_phi), L.ptr(dphi_full), Dp, B, H, W, Dp, L.stream())
-        L.call("sg_maxpool2_bwd", sd, L.ptr(dg), Cg, L.ptr(idx_g), L.ptr(dg_full), Cg, B, H, W, Cg, L.stream())
-        return dtheta, dphi_full, dg_full
+        return dtheta, dphi, dg
 
 
 class AttnOutFn(torch.autograd.Function):
@@ -1374,13 +1544,19 @@ class AttnOutFn(torch.autograd.Function):
         ctx.save_for_backward(o, sigma)
         ctx.rt, ctx.slot = rt, slot
         ctx.sigma_param = sigma
+        ctx.weight = weight      # the master parameter: only handed on to ConvDgradFn so the second-order graph reaches it
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        _first_order_only("AttnOutFn")
         o, sigma = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
+        if torch.is_grad_enabled():
+            # create_graph=True: dx = dy and do = sigma * F_W^T(dy) as differentiable operators of dy (and, through ConvDgradFn / ScalePtrFn, of W and sigma)
+            if _param_grad_wanted(ctx.weight, ctx.sigma_param):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP / R1 path)")
+            do = ScalePtrFn.apply(ConvDgradFn.apply(dy, o, ctx.weight, rt, slot, ConvCfg(1, 1)), ctx.sigma_param) if ctx.needs_input_grad[1] else None
+            return (dy if ctx.needs_input_grad[0] else None), do, None, None, None, None, None
         bank = rt.bank()
         dy = _c(dy)
         N, H, W, Cc = dy.shape

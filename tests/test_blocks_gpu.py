@@ -243,13 +243,19 @@ def test_gradient_penalty_double_backward(sg, name, mixed):
 
 
 @pytest.mark.parametrize("kind", ["r1", "maxgp"])
-@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "sngan32"])
+@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "sngan32", "biggan32"])
 def test_r1_and_maxgp_double_backward(sg, name, kind):
     """R1 (reference utils/losses.py:355-361, taken through the SAME real-batch forward that feeds the adversarial loss,
     src/worker.py:260-261,410-412) and the max-gradient penalty (:338-352): value and gradient w.r.t. every discriminator
-    parameter against torch autograd's double backward over the CPU oracle (fp32)."""
+    parameter against torch autograd's double backward over the CPU oracle (fp32). biggan32: through SelfAttention (spectral-normed theta / phi / g /
+    output convolutions, max-pooling, softmax, the learnt gain sigma = 0.6) -- the create_graph pass re-evaluates the block from differentiable primitives
+    (functional.AttnPooledFn.backward)."""
+    r1_maxgp_case(name, kind, torch.device("cuda:0"))
+
+
+def r1_maxgp_case(name, kind, dev):
+    """dev: the GPU, or the CPU when the package is bound to the interpreted library (tests/test_aug_cpu.py)"""
     from studiogan_amd import losses as SL
-    dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
     y = meta["yaml"]
     ocfg = MG.oracle_cfg(y)
@@ -278,7 +284,8 @@ def test_r1_and_maxgp_double_backward(sg, name, kind):
         torch.manual_seed(meta["seed"] + MG.GP_SEED)
         r = SL.cal_maxgrad_penalty(real.to(dev), lab.to(dev), fake.to(dev), D, dev)
         r.backward()
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     C = Collector()
     C.check(kind + " penalty", r, r_o, 5e-4)
     gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)

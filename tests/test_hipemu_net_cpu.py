@@ -203,3 +203,16 @@ def test_emulated_fullwidth_bf16_step_every_fixture(forced_fast_kernels, monkeyp
     """the four full-width fixtures (C2 SNGAN, C5 WGAN-GP ResNet-128 with its double backward, C4 BigGAN-deep-128, C3 BigGAN-128) with the fast kernels forced:
     golden vectors of the reference at the bf16 tolerances of tests/test_fullwidth_gpu.py."""
     _step(name, True)
+
+
+@pytest.mark.parametrize("kind", ["r1", "maxgp"])
+def test_emulated_second_order_through_attention(kind):
+    """R1 / max-gradient penalty on the BigGAN discriminator (SelfAttention with sigma = 0.6; reference utils/losses.py:338-361 through utils/ops.py:83-103): the
+    create_graph pass through the attention block (functional.AttnPooledFn / AttnOutFn / MaxPool2Fn with BmmFn, SoftmaxRowsFn, ScalePtrFn and the csrc/ext
+    adjoints) against torch autograd's double backward over the CPU oracle -- penalty and every parameter gradient (tests/test_blocks_gpu.py r1_maxgp_case)"""
+    import fullemu
+    import test_blocks_gpu as TB
+    with fullemu.Installed(dma_late=1, greedy=1, seed=4) as E:
+        c0 = E.counters()
+        TB.r1_maxgp_case("biggan32", kind, torch.device("cpu"))
+        assert E.counters()["launches"] - c0["launches"] > 100
