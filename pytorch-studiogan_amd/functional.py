@@ -732,13 +732,18 @@ class CatConvFn(torch.autograd.Function):
         conv2d_raw(x, bank.w_fwd(slot, rt), Cin, Cc, 1, 1, bias=bias, out=out, out_coff=Cin)
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.bias = rt, slot, bias
+        ctx.weight = weight      # the master parameter: only handed on to CatConvDgradFn so the second-order graph reaches it
         return out
 
     @staticmethod
     def backward(ctx, dy):
-        _first_order_only("CatConvFn")
         (x,) = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
+        if torch.is_grad_enabled():
+            # create_graph=True (R1 / gradient penalties on a BigGAN-deep discriminator): the data gradient as a differentiable operator
+            if _param_grad_wanted(ctx.weight, ctx.bias):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (WGAN-GP / R1 path)")
+            return (CatConvDgradFn.apply(dy, ctx.weight, rt, slot, x.shape[3]) if ctx.needs_input_grad[0] else None), None, None, None, None
         bank = rt.bank()
         dy = _c(dy)
         N, H, W, Cin = x.shape
@@ -753,6 +758,37 @@ class CatConvFn(torch.autograd.Function):
             g = ensure_grad(ctx.bias)
             L.call("sg_colsum", L.dt(dy), L.ptr(dy) + Cin * dy.element_size(), ld, None, 0, N * H * W, Cc, L.ptr(g), 1.0, L.stream())
         return dx, None, None, None, None
+
+
+class CatConvDgradFn(torch.autograd.Function):
+    """dx = dy[..., :Cin] + W^T dy[..., Cin:]: CatConvFn's data gradient as a differentiable operator (second-order pass). Linear in dy and in W:
+        d/d(dy) = cat([t, conv1x1(t; W)])   -- CatConvFn's forward launches again, without the bias
+        d/dW    = wgrad(t, dy[..., Cin:])    -- the forward's weight-gradient launch with x := t"""
+
+    @staticmethod
+    def forward(ctx, dy, weight, rt, slot, Cin):
+        dy = _c(dy)
+        ctx.save_for_backward(dy)
+        ctx.rt, ctx.slot, ctx.Cin = rt, slot, Cin
+        Cc = rt.rows
+        return conv2d_raw(dy, rt.bank().w_dgrad(slot, rt), Cc, Cin, 1, 1, res=dy, ldx=Cin + Cc, x_coff=Cin)
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (dy,) = ctx.saved_tensors
+        rt, slot, Cin = ctx.rt, ctx.slot, ctx.Cin
+        bank = rt.bank()
+        t = _c(ddx)
+        N, H, W, _ = t.shape
+        Cc = rt.rows
+        g_dy = None
+        if ctx.needs_input_grad[0]:
+            g_dy = torch.empty((N, H, W, Cin + Cc), dtype=t.dtype, device=t.device)
+            L.call("sg_copy_channels", L.dt(t), L.ptr(t), Cin, L.ptr(g_dy), Cin + Cc, N * H * W, Cin, L.stream())
+            conv2d_raw(t, bank.w_fwd(slot, rt), Cin, Cc, 1, 1, out=g_dy, out_coff=Cin)
+        if ctx.needs_input_grad[1]:
+            conv2d_wgrad_raw(t, dy, bank.dwt(slot, rt), Cin, Cc, 1, 1, H, W, ldg=Cin + Cc, dy_coff=Cin)
+        return g_dy, None, None, None, None
 
 
 class ConvTransposeFn(torch.autograd.Function):

@@ -200,13 +200,16 @@ def generator_fwd_bwd(name, mixed, bn_mode):
 
 
 @pytest.mark.parametrize("mixed", [False, True])
-@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "resgan32", "sngan32", "dcgan32", "sndcgan32"])
+@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "resgan32", "sngan32", "dcgan32", "sndcgan32", "biggan32"])
 def test_gradient_penalty_double_backward(sg, name, mixed):
     """WGAN-GP penalty (reference utils/losses.py:301-316) and its gradient w.r.t. every discriminator parameter -- the
     double backward through conv (stride 1 / 2, fused ReLU / pooling), batch norm with batch statistics, pooling, the
-    projection head and spectral norm -- against torch autograd's own double backward over the CPU oracle."""
+    projection head, spectral norm and (biggan32) self-attention -- against torch autograd's own double backward over the CPU oracle."""
+    gradient_penalty_case(name, mixed, torch.device("cuda:0"))
+
+
+def gradient_penalty_case(name, mixed, dev):
     from studiogan_amd import losses as SL
-    dev = torch.device("cuda:0")
     fix, meta = load_golden(name)
     y = meta["yaml"]
     ocfg = MG.oracle_cfg(y)
@@ -226,7 +229,8 @@ def test_gradient_penalty_double_backward(sg, name, mixed):
     torch.manual_seed(meta["seed"] + MG.GP_SEED)
     gp = SL.cal_grad_penalty(real.to(dev), lab.to(dev), fake.to(dev), D, dev)
     gp.backward()
-    torch.cuda.synchronize()
+    if dev.type == "cuda":
+        torch.cuda.synchronize()
     C = Collector()
     wide = bool(meta.get("compact"))
     t = 5e-4 if not mixed else 5e-2
@@ -243,13 +247,14 @@ def test_gradient_penalty_double_backward(sg, name, mixed):
 
 
 @pytest.mark.parametrize("kind", ["r1", "maxgp"])
-@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "sngan32", "biggan32"])
+@pytest.mark.parametrize("name", ["wgangp32", "sngp32", "sngan32", "biggan32", "bigdeep32", "bigdeepsg32", "sndcgan32", "resgan32"])
 def test_r1_and_maxgp_double_backward(sg, name, kind):
     """R1 (reference utils/losses.py:355-361, taken through the SAME real-batch forward that feeds the adversarial loss,
     src/worker.py:260-261,410-412) and the max-gradient penalty (:338-352): value and gradient w.r.t. every discriminator
     parameter against torch autograd's double backward over the CPU oracle (fp32). biggan32: through SelfAttention (spectral-normed theta / phi / g /
     output convolutions, max-pooling, softmax, the learnt gain sigma = 0.6) -- the create_graph pass re-evaluates the block from differentiable primitives
-    (functional.AttnPooledFn.backward)."""
+    (functional.AttnPooledFn.backward); bigdeep32 / bigdeepsg32: attention + the bottleneck blocks' channel-concat skip (functional.CatConvDgradFn);
+    sndcgan32: strided 4x4 convolutions under spectral norm; resgan32: batch norm in the discriminator."""
     r1_maxgp_case(name, kind, torch.device("cuda:0"))
 
 

@@ -205,8 +205,8 @@ def test_emulated_fullwidth_bf16_step_every_fixture(forced_fast_kernels, monkeyp
     _step(name, True)
 
 
-@pytest.mark.parametrize("kind", ["r1", "maxgp"])
-def test_emulated_second_order_through_attention(kind):
+@pytest.mark.parametrize("name,kind", [("biggan32", "r1"), ("biggan32", "maxgp"), ("bigdeep32", "r1")])
+def test_emulated_second_order_through_attention(name, kind):
     """R1 / max-gradient penalty on the BigGAN discriminator (SelfAttention with sigma = 0.6; reference utils/losses.py:338-361 through utils/ops.py:83-103): the
     create_graph pass through the attention block (functional.AttnPooledFn / AttnOutFn / MaxPool2Fn with BmmFn, SoftmaxRowsFn, ScalePtrFn and the csrc/ext
     adjoints) against torch autograd's double backward over the CPU oracle -- penalty and every parameter gradient (tests/test_blocks_gpu.py r1_maxgp_case)"""
@@ -214,5 +214,5 @@ def test_emulated_second_order_through_attention(kind):
     import test_blocks_gpu as TB
     with fullemu.Installed(dma_late=1, greedy=1, seed=4) as E:
         c0 = E.counters()
-        TB.r1_maxgp_case("biggan32", kind, torch.device("cpu"))
+        TB.r1_maxgp_case(name, kind, torch.device("cpu"))      # (bigdeep32: + the bottleneck blocks' channel-concat skip, functional.CatConvDgradFn)
         assert E.counters()["launches"] - c0["launches"] > 100
