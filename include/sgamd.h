@@ -513,6 +513,12 @@ int sg_fm_loss(const float* real_h, const float* fake_h, int B, int C, float* wo
 int sg_maxpool2_gather(int dtype, const void* x, int ldx, const uint8_t* idx, void* y, int ldy, int N, int H, int W, int C, sg_stream_t s);
 int sg_softmax_rows_bwd2(const float* P, const float* dP, const float* u, float* gP, long long rows, int cols, sg_stream_t s);
 int sg_scale_by_ptr(int dtype, const void* x, const float* sigma, void* y, long long n, sg_stream_t s);
+/* Weight clipping (reference worker.py:489-492, LOSS.apply_wc): p[i] = clamp(p[i], lo, hi) over a flat fp32 parameter buffer, one pass.
+ * Adaptive pseudo augmentation (reference utils/apa_aug.py:10-21): out[n] = flag[n] ? a[n] : b[n] for N rows of `row` floats (a = fake, b = real images).
+ * The ADA / APA heuristic's accumulator (worker.py:285-289,478-481): acc[0] += sum_b sign(logit[b]), acc[1] += B, without a host round trip. */
+int sg_clamp_flat(float* p, long long n, float lo, float hi, sg_stream_t s);
+int sg_select_rows(const uint8_t* flag, const float* a, const float* b, float* out, int N, long long row, sg_stream_t s);
+int sg_sign_count(const float* logit, int B, float* acc, sg_stream_t s);
 
 #ifdef __cplusplus
 }

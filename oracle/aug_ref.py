@@ -9,6 +9,7 @@ Restates (all paths relative to /root/reference/src):
   utils/diffaug.py:79-95   rand_cutout         x * mask, mask = 0 on the (clamped) window around (cx, cy)
   utils/cr.py:24-31        random_flip         images with coin < p mirrored along the width
   utils/cr.py:33-48        random_translation  out[i][j] = reflect-padded x at [i + tx][j + ty]
+  utils/apa_aug.py:10-21   apply_apa_aug       fake where the per-image draw < p, else real
 Pinned against the reference's own functions under a seeded generator by oracle/make_golden_aug.py (bit-identical; see tests/test_aug_cpu.py).
 Plain torch on CPU, differentiable through autograd to any order (that is how the gradient and second-order vectors of the fixture are made)."""
 import torch
@@ -129,6 +130,11 @@ def cr_aug(x, coin, tx, ty):
     if tx is not None:
         x = cr_translation(x, tx.reshape(-1), ty.reshape(-1))
     return x.contiguous()
+
+
+def apa(real, fake, coin, p):
+    """utils/apa_aug.py:10-21: the real image of a slot is replaced by the fake one where the uniform draw is below p"""
+    return torch.where((coin < p).reshape(-1, 1, 1, 1), fake, real)
 
 
 def mse(a, b):

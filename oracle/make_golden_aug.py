@@ -104,6 +104,16 @@ def main():
         worst = max(worst, float((O.feature_matching(hr, hf) - fm).detach().abs()))
         p = f"fm/{tag}/"
         out[p + "real"], out[p + "fake"], out[p + "loss"], out[p + "dfake"] = hr.numpy(), hf.detach().numpy(), fm.detach().numpy(), dh.numpy()
+    RA = importlib.import_module("utils.apa_aug")              # src/utils/apa_aug.py:10-21
+    for i, pr in enumerate((0.0, 0.5, 1.0)):
+        real, fake = _rand((6, 3, 8, 8), 9400 + i), _rand((6, 3, 8, 8), 9500 + i)
+        torch.manual_seed(9600 + i)
+        coin = torch.rand([6, 1, 1, 1])
+        torch.manual_seed(9600 + i)
+        y = RA.apply_apa_aug(real, fake, pr, "cpu")
+        assert torch.equal(AR.apa(real, fake, coin, pr), y), pr
+        p = f"apa/{i}/"
+        out[p + "real"], out[p + "fake"], out[p + "coin"], out[p + "p"], out[p + "y"] = real.numpy(), fake.numpy(), coin.numpy(), np.float32(pr), y.numpy()
     assert worst <= 1e-6, worst
     np.savez_compressed(OUT, **out)
     print("wrote", OUT, "restatement bit-identical to the reference on", len(DIFFAUG_CASES) + len(CR_CASES), "augmentation cases (outputs); gradients / mse worst", worst)

@@ -28,6 +28,8 @@ CASES = {     # tag -> (configuration of oracle/make_golden.py, hyper-parameters
     "sngan32_diffaug": ("sngan32", dict(diffaug_policy="translation,cutout")),
     # least-squares adversarial loss (configs/CIFAR10/LSGAN.yaml) + feature matching in the generator update (LOSS.apply_fm of configs/*/MHGAN.yaml) behind DiffAugment
     "sngan32_ls_fm_diffaug": ("sngan32", dict(adv_loss="least_square", fm_lambda=1.0, diffaug_policy="translation,cutout")),
+    # adaptive pseudo augmentation at p = 0.5 (configs/CIFAR10/SNGAN-APA.yaml) + weight clipping after the discriminator's optimiser step (configs/CIFAR10/WGAN-WC.yaml: 0.01)
+    "sngan32_apa_wc": ("sngan32", dict(apa_p=0.5, wc_bound=0.01, adv_loss="wasserstein")),
 }
 AUG_SEED = 31337
 
@@ -35,6 +37,8 @@ AUG_SEED = 31337
 def draw_all(hp, shape):
     """the generator's draws in the order the reference worker's discriminator step consumes them (series(real), series(fake), then the parallel views)"""
     d = {}
+    if hp.get("apa_p") is not None:
+        d["apa"] = [torch.rand([shape[0], 1, 1, 1])]
     if hp.get("diffaug_policy"):
         d["series_real"] = AR.draw_diffaug(shape, hp["diffaug_policy"])
         d["series_fake"] = AR.draw_diffaug(shape, hp["diffaug_policy"])
@@ -58,6 +62,8 @@ def reference_d_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, RC, misc):
     fake = Gen(ins["z0"], fl)                                                             # utils/sample.py:162
     fake_eps = Gen(z_eps, fl) if z_eps is not None else None                              # utils/sample.py:176
     torch.manual_seed(AUG_SEED)
+    if hp.get("apa_p") is not None:                                                       # worker.py:273-274
+        real = importlib.import_module("utils.apa_aug").apply_apa_aug(real, fake.detach(), hp["apa_p"], "cpu")
     real_, fake_ = series(real), series(fake)                                             # worker.py:277-278
     rd, fd = Dis(real_, rl), Dis(fake_, fl)
     loss = cfgs.LOSS.d_loss(rd["adv_output"], fd["adv_output"], DDP=False)
@@ -72,7 +78,19 @@ def reference_d_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, RC, misc):
         fe = Dis(fake_eps, fl)
         loss = loss + hp["d_lambda"] * l2(fd["adv_output"], fe["adv_output"])
     loss.backward()
-    return loss.detach().clone(), {k: p.grad.detach().clone() for k, p in Dis.named_parameters()}, fake.detach().clone()
+    grads = {k: p.grad.detach().clone() for k, p in Dis.named_parameters()}
+    after = None
+    if hp.get("wc_bound") is not None:                                                    # worker.py:440-443,489-492: optimiser step, then the clip
+        before = {k: p.detach().clone() for k, p in Dis.named_parameters()}
+        cfgs.define_optimizer(Gen, Dis)
+        cfgs.OPTIMIZATION.d_optimizer.step()
+        for p in Dis.parameters():
+            p.data.clamp_(-hp["wc_bound"], hp["wc_bound"])
+        after = {k: p.detach().clone() for k, p in Dis.named_parameters()}
+        with torch.no_grad():                                                             # (the generator side of the fixture is taken on the un-stepped weights)
+            for k, p in Dis.named_parameters():
+                p.copy_(before[k])
+    return loss.detach().clone(), grads, fake.detach().clone(), after
 
 
 def reference_g_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, misc):
@@ -130,7 +148,10 @@ def main():
         # ---- discriminator side -------------------------------------------------------------------------------------------------
         torch.manual_seed(AUG_SEED)
         draws = draw_all(hp, shape)
-        d_loss, d_grads, fake0 = reference_d_side(cfgs, Gen, Dis, ins, hp, ze_d, RD, RC, misc)
+        d_loss, d_grads, fake0, d_after = reference_d_side(cfgs, Gen, Dis, ins, hp, ze_d, RD, RC, misc)
+        if d_after is not None:
+            for k, v in d_after.items():
+                fix[tag + "/D_after/" + k] = v
         gen_fn, dis_fn = O.model_fns(ocfg)
         leaves = O._leaves(DP)
         o_loss, o_fake = O.d_consistency_loss(gen_fn, dis_fn, GP, GB, leaves, DB, ocfg, ins["real0"], ins["rl0"], ins["z0"], ins["fl0"],

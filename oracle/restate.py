@@ -959,6 +959,8 @@ def d_consistency_loss(gen_fn, dis_fn, GP, GB, P, B, cfg, real, real_labels, z, 
         fake = gen_fn(z, fake_labels, GP, GB, bn_mode="untrack")
         fake_eps = gen_fn(z_eps, fake_labels, GP, GB, bn_mode="untrack") if z_eps is not None else None
     series = (lambda x, d: AR.diffaug(x, hp["diffaug_policy"], d)) if hp.get("diffaug_policy") else (lambda x, d: x)
+    if hp.get("apa_p") is not None:          # worker.py:273-274
+        real = AR.apa(real, fake, draws["apa"][0], hp["apa_p"])
 
     def heads(x, lab):
         adv, h = dis_fn(x, lab, P, B)

@@ -223,6 +223,9 @@ _PROTOS = {
     "sg_maxpool2_gather": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_softmax_rows_bwd2": [_vp, _vp, _vp, _vp, _ll, _i, _vp],
     "sg_scale_by_ptr": [_i, _vp, _vp, _vp, _ll, _vp],
+    "sg_clamp_flat": [_vp, _ll, _f, _f, _vp],
+    "sg_select_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
+    "sg_sign_count": [_vp, _i, _vp, _vp],
 }
 
 
@@ -257,7 +260,7 @@ def check(rc, name=""):
 
 # Entry points that write parameters / buffers of a network through raw pointers (invisible to torch's version counters): every call moves the
 # epoch the weight bank's frozen-network cache is keyed on (bank.WeightBank.begin_forward).
-_STATE_WRITERS = frozenset(("sg_adam_ema", "sg_ema_lerp", "sg_allreduce_flat"))
+_STATE_WRITERS = frozenset(("sg_adam_ema", "sg_ema_lerp", "sg_allreduce_flat", "sg_clamp_flat"))
 write_epoch = [0]
 
 

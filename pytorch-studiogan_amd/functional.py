@@ -2126,3 +2126,25 @@ class FeatureMatchingFn(torch.autograd.Function):
     def backward(ctx, g):
         (df,) = ctx.saved_tensors
         return None, df * g
+
+
+def select_rows(flag, a, b):
+    """out[n] = a[n] if flag[n] else b[n] for fp32 tensors of one shape (adaptive pseudo augmentation, reference src/utils/apa_aug.py:14-21). No gradient:
+    the reference hands it the detached fake batch and the real batch (src/worker.py:274)."""
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("select_rows: two fp32 tensors of one shape expected")
+    a, b = _c(a.detach()), _c(b.detach())
+    f = _c(flag.to(torch.uint8))
+    N = a.shape[0]
+    if f.numel() != N:
+        raise RuntimeError("select_rows: one flag per row expected")
+    out = torch.empty_like(a)
+    L.call("sg_select_rows", L.ptr(f), L.ptr(a), L.ptr(b), L.ptr(out), N, a.numel() // N, L.stream())
+    return out
+
+
+def sign_count_(acc, logits):
+    """acc[0] += sum sign(logits), acc[1] += len(logits) on the device (the ADA / APA heuristic's accumulator, reference src/worker.py:285-289)."""
+    lg = _c(logits.detach().float().reshape(-1))
+    L.call("sg_sign_count", L.ptr(lg), lg.numel(), L.ptr(acc), L.stream())
+    return acc

@@ -272,6 +272,12 @@ class FusedAdam(torch.optim.Optimizer):
         self._t = steps.pop() if steps else 0
         self.state.clear()
 
+    @torch.no_grad()
+    def clamp_(self, bound):
+        """Weight clipping of every parameter of the network to [-bound, bound] (reference src/worker.py:489-492) as one pass over the parameter arena."""
+        a = self._state()
+        L.call("sg_clamp_flat", a.data.data_ptr(), a.numel, -float(bound), float(bound), L.stream())
+
     def zero_grad(self, set_to_none=False):
         a = self._state()
         if self._plan is not None:

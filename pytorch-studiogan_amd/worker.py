@@ -72,8 +72,14 @@ class Worker:
                  d_cond_mtd="W/O", aux_cls_type="W/O", cond_lambda=1.0, temperature=1.0, m_p=1.0, tac_dis_lambda=1.0, tac_gen_lambda=1.0,
                  mh_lambda=1.0, apply_diffaug=False, diffaug_type="diffaug", apply_cr=False, cr_aug_type="cr", cr_lambda=10.0,
                  apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0,
-                 apply_fm=False, fm_lambda=1.0):
+                 apply_fm=False, fm_lambda=1.0, apply_wc=False, wc_bound=0.01,
+                 apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4):
         self.Gen, self.Dis = Gen, Dis
+        self.apply_wc, self.wc_bound = apply_wc, wc_bound              # weight clipping after every discriminator update (src/worker.py:489-492)
+        # adaptive pseudo augmentation (src/worker.py:82,127-134,273-274,285-289,478-487): real images swapped for fakes with probability aa_p, which follows
+        # the sign statistic of the real logits towards aa_target
+        self.apply_apa, self.aa_p, self.aa_target, self.aa_kimg, self.aa_interval = apply_apa, float(apa_initial_augment_p), apa_target, apa_kimg, apa_interval
+        self.dis_sign_real = torch.zeros(2, dtype=torch.float32, device=next(Gen.parameters()).device) if apply_apa else None
         self.apply_fm, self.fm_lambda = apply_fm, fm_lambda          # feature matching in the generator update (src/worker.py:588-596)
         # augmentations in front of the discriminator (reference src/config.py:582-626): series_augment runs on every real / fake batch
         # (src/worker.py:276-278,549-550), parallel_augment makes the second view of the consistency regularisers (:326-354)
@@ -186,11 +192,17 @@ class Worker:
                 fake_images_eps = self.Gen(zs_eps, fake_labels) if zs_eps is not None else None      # src/utils/sample.py:162-176
                 if self.apply_r1_reg:    # src/worker.py:260-261
                     real_images = real_images.detach().requires_grad_(True)
+                if self.apply_apa:       # src/worker.py:273-274
+                    from . import apa_aug
+                    real_images = apa_aug.apply_apa_aug(real_images, fake_images.detach(), self.aa_p, self.device)
                 real_images_ = self.series_augment(real_images)          # src/worker.py:276-278
                 fake_images_ = self.series_augment(fake_images)
                 real_dict = self.Dis(real_images_, real_labels)
                 fake_dict = self.Dis(fake_images_, fake_labels, adc_fake=self.adc_fake)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
+                if self.apply_apa:       # src/worker.py:285-289 (the sum stays on the device until the heuristic reads it)
+                    from . import functional as _F
+                    _F.sign_count_(self.dis_sign_real, real_dict["adv_output"])
                 if self.adv_loss == "MH":          # src/worker.py:300-302
                     dis_acml_loss = self.d_loss(DDP=self.group is not None, **real_dict)
                     dis_acml_loss = dis_acml_loss + self.d_loss(fake_dict["adv_output"], self.lossy, DDP=self.group is not None)
@@ -247,6 +259,18 @@ class Worker:
                 dis_acml_loss.backward()
                 dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
             self.d_optimizer.step(group=self.group)
+            if self.apply_apa and self.aa_target is not None and current_step % self.aa_interval == 0:      # src/worker.py:478-487
+                import numpy as _np
+                import torch.distributed as _dist
+                if self.group is not None:
+                    _dist.all_reduce(self.dis_sign_real, op=_dist.ReduceOp.SUM, group=self.group)
+                s_sum, s_cnt = (float(v) for v in self.dis_sign_real.tolist())
+                heuristic = s_sum / s_cnt
+                adjust = float(_np.sign(heuristic - self.aa_target)) * s_cnt / (self.aa_kimg * 1000)
+                self.aa_p = min(1.0, max(self.aa_p + adjust, 0.0))
+                self.dis_sign_real.zero_()
+            if self.apply_wc:            # src/worker.py:489-492
+                self.d_optimizer.clamp_(self.wc_bound)
         return dis_acml_loss
 
     # -- src/worker.py:502-681 ------------------------------------------------------------------------------------

@@ -40,6 +40,8 @@ class Replayed:
         nxt = self.nxt
 
         def rand(*size, dtype=None, device=None, **kw):
+            if len(size) == 1 and isinstance(size[0], (list, tuple)):
+                size = tuple(size[0])
             return nxt(size, device)
 
         def randint(low, high, size=None, device=None, **kw):
@@ -211,7 +213,9 @@ def consistency_case(tag, dev):
                d_updates_per_step=1, apply_diffaug=bool(hp.get("diffaug_policy")), apply_cr=hp.get("cr_lambda") is not None, cr_lambda=hp.get("cr_lambda", 0.0),
                apply_bcr=bcr is not None, real_lambda=(bcr or [0, 0])[0], fake_lambda=(bcr or [0, 0])[1], apply_zcr=hp.get("d_lambda") is not None,
                radius=hp.get("radius", 0.0), g_lambda=hp.get("g_lambda", 0.0), d_lambda=hp.get("d_lambda", 0.0),
-               apply_fm=hp.get("fm_lambda") is not None, fm_lambda=hp.get("fm_lambda", 0.0))
+               apply_fm=hp.get("fm_lambda") is not None, fm_lambda=hp.get("fm_lambda", 0.0),
+               apply_apa=hp.get("apa_p") is not None, apa_initial_augment_p=hp.get("apa_p", 0.0), apa_target=None,
+               apply_wc=hp.get("wc_bound") is not None, wc_bound=hp.get("wc_bound", 0.0))
     if hp.get("diffaug_policy"):
         from studiogan_amd import diffaug as DA
         w.series_augment = lambda x: DA.apply_diffaug(x, hp["diffaug_policy"])
@@ -230,12 +234,18 @@ def consistency_case(tag, dev):
         return out
     C = Collector()
     zed = torch.from_numpy(z[p + "z_eps_d"]).to(dev) if p + "z_eps_d" in z.files else None
-    with Replayed(draws_of("draw_d", ["series_real", "series_fake", "prl_real", "prl_fake"])):
+    with Replayed(draws_of("draw_d", ["apa", "series_real", "series_fake", "prl_real", "prl_fake"])):
         d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"]) + ((zed,) if zed is not None else ())])
     C.check("d_loss", d_loss, torch.from_numpy(z[p + "d_loss"]), 2e-4)
     dmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "D_grad/"))
     for k, prm in D.named_parameters():
         C.check("D_grad/" + k, prm.grad, torch.from_numpy(z[p + "D_grad/" + k]), 1e-3, floor=1e-2 * dmax)
+    if hp.get("wc_bound") is not None:
+        # after Adam + the clip (src/worker.py:440-443,489-492): inside the band an element whose gradient is rounding noise may land one lr-kick apart
+        b = hp["wc_bound"]
+        for k, prm in D.named_parameters():
+            assert float(prm.detach().abs().max()) <= b, k
+            C.check("D_after/" + k, prm, torch.from_numpy(z[p + "D_after/" + k]), 1e-3, abs_ok=2.5 * opt["d_lr"])
     # the generator side of the fixture was taken on the networks as the discriminator side's FORWARDS left them (no optimiser step in between):
     # put the discriminator's weights back, keep the spectral-norm vectors / batch-norm statistics where the update's forwards left them
     with torch.no_grad():
@@ -251,7 +261,36 @@ def consistency_case(tag, dev):
     C.finish()
 
 
-CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug", "sngan32_ls_fm_diffaug"]
+CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug", "sngan32_ls_fm_diffaug", "sngan32_apa_wc"]
+
+
+def apa_case(i, dev):
+    """apply_apa_aug against the reference's output under the same draw (bit for bit: a select), and the accumulator of the heuristic"""
+    from studiogan_amd import apa_aug, functional as F
+    z = np.load(GOLD)
+    p = f"apa/{i}/"
+    real, fake = _t(z, p + "real").to(dev), _t(z, p + "fake").to(dev)
+    with Replayed([_t(z, p + "coin")]):
+        y = apa_aug.apply_apa_aug(real, fake, float(z[p + "p"]), dev)
+    assert torch.equal(y.cpu(), _t(z, p + "y")), i
+    acc = torch.zeros(2, dtype=torch.float32, device=dev)
+    lg = torch.tensor([0.5, -1.0, 0.0, 2.0, -0.1, 3.0, 1e-9], device=dev)
+    F.sign_count_(acc, lg)
+    F.sign_count_(acc, lg[:3])
+    assert acc.tolist() == [float(torch.sign(lg).sum() + torch.sign(lg[:3]).sum()), 10.0]
+
+
+def clamp_case(dev):
+    """FusedAdam.clamp_ == p.data.clamp_(-b, b) on every parameter (reference src/worker.py:489-492), odd sizes included"""
+    from studiogan_amd.optim import FusedAdam
+    g = torch.Generator().manual_seed(5)
+    ps = [torch.nn.Parameter((torch.randn(shape, generator=g) * 0.05).to(dev)) for shape in ((7,), (3, 5, 3, 3), (1,), (129, 33))]
+    ref = [q.detach().clone().clamp_(-0.03, 0.03) for q in ps]
+    opt = FusedAdam(ps, lr=1e-3)
+    opt.zero_grad()
+    opt.clamp_(0.03)
+    for q, r in zip(ps, ref):
+        assert torch.equal(q.detach(), r)
 
 
 def loss_case(kind, dev):

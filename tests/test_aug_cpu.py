@@ -134,6 +134,13 @@ def test_emulated_further_losses_match_reference_vectors(installed):
 
 
 @needs_emu
+def test_emulated_apa_select_and_weight_clipping(installed):
+    for i in range(3):
+        AC.apa_case(i, torch.device("cpu"))
+    AC.clamp_case(torch.device("cpu"))
+
+
+@needs_emu
 def test_emulated_augment_operator_subsets_and_properties(installed):
     from studiogan_amd import _lib as L
     dev = torch.device("cpu")
@@ -190,6 +197,8 @@ def test_consistency_oracle_reproduces_the_reference_vectors():
         for name in ("prl_real", "prl_fake"):
             if f"{p}draw_d/{name}/0" in z.files:
                 draws[name] = lst("draw_d", name)[:3]
+        if f"{p}draw_d/apa/0" in z.files:
+            draws["apa"] = lst("draw_d", "apa")[:1]
         ins = sub(fix, "in/")
         zed = torch.from_numpy(z[p + "z_eps_d"]) if p + "z_eps_d" in z.files else None
         leaves = O._leaves(DP)

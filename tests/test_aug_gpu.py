@@ -40,6 +40,12 @@ def test_feature_matching_loss_matches_reference_vectors(sg, case):
     AC.fm_case(case, DEV)
 
 
+def test_apa_select_and_weight_clipping(sg):
+    for i in range(3):
+        AC.apa_case(i, DEV)
+    AC.clamp_case(DEV)
+
+
 def test_augment_operator_subsets_vs_oracle(sg):
     from studiogan_amd import _lib as L
     every = [L.AUG_BRIGHTNESS, L.AUG_SATURATION, L.AUG_CONTRAST, L.AUG_FLIP, L.AUG_CUTOUT]
