@@ -326,3 +326,44 @@ def fm_case(case, dev):
 
 
 LOSS_KINDS, FM_CASES = MGA.LOSS_KINDS, MGA.FM_CASES
+
+
+def r1_through_diffaug_case(name, dev):
+    """R1 on a real batch that reaches the discriminator THROUGH DiffAugment (reference src/worker.py:260-261,276-279,410-412 with src/utils/losses.py:355-361;
+    the StyleGAN2-DiffAug family's combination): the create_graph pass runs through functional.AugmentFn / AugmentBwdFn inside the network's graph. Penalty and
+    every parameter gradient against torch autograd's double backward over the oracle fed the same draws (fp32)."""
+    from util import load_golden, sub, Collector
+    from test_model_gpu import build_from_yaml
+    from test_blocks_gpu import _split, _perturb
+    from oracle import restate as O, make_golden as MG
+    from studiogan_amd import losses as SL, diffaug as DA
+    policy = "color,translation,cutout"
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    ocfg = MG.oracle_cfg(y)
+    P, B = _split(sub(fix, "D_init/"))
+    _perturb(P, 9)
+    _, D = build_from_yaml(y, False, dev)
+    D.load_state_dict({**{k: v.to(dev) for k, v in P.items()}, **{k: v.to(dev) for k, v in B.items()}}, strict=True)
+    D.train()
+    real, lab = fix["in/real0"].clone(), fix["in/rl0"]
+    torch.manual_seed(77)
+    draws = AR.draw_diffaug(tuple(real.shape), policy)
+    dis = O.model_fns(ocfg)[1]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+    r_o, adv_o = O.r1_reg(lambda x, l, Pp, Bb: dis(AR.diffaug(x, policy, draws), l, Pp, Bb), real, lab, leaves, B)
+    (10.0 * r_o + torch.mean(torch.relu(1.0 - adv_o))).backward()
+    for prm in D.parameters():
+        prm.grad = None
+    xr = real.to(dev).requires_grad_(True)
+    with Replayed(draws):
+        out = D(DA.apply_diffaug(xr, policy), lab.to(dev))
+    r = SL.cal_r1_reg(adv_output=out["adv_output"], images=xr, device=dev)
+    (10.0 * r + SL.d_hinge(out["adv_output"], torch.full_like(out["adv_output"].detach(), -5.0))).backward()
+    C = Collector()
+    C.check("r1 through diffaug: penalty", r, r_o, 5e-4)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, prm in D.named_parameters():
+        go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        C.check("r1 through diffaug: grad " + k, prm.grad if prm.grad is not None else torch.zeros_like(prm), go, 1e-3, floor=1e-2 * gmax)
+    C.finish()

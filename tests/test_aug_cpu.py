@@ -166,6 +166,11 @@ def test_emulated_worker_update_with_diffaug_and_consistency_regularisers(instal
     AC.consistency_case(tag, torch.device("cpu"))
 
 
+@needs_emu
+def test_emulated_r1_through_diffaug(installed):
+    AC.r1_through_diffaug_case("biggan32", torch.device("cpu"))
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json

@@ -120,3 +120,8 @@ def test_worker_update_with_diffaug_and_consistency_regularisers(sg, tag):
     one generator update against the REAL reference's models + utils/diffaug.py + utils/cr.py + MSELoss combined as src/worker.py:236-365,520-603
     (tests/golden/consistency.npz)"""
     AC.consistency_case(tag, DEV)
+
+
+@pytest.mark.parametrize("name", ["biggan32", "sngan32"])
+def test_r1_through_diffaug(sg, name):
+    AC.r1_through_diffaug_case(name, DEV)
