@@ -519,6 +519,18 @@ int sg_scale_by_ptr(int dtype, const void* x, const float* sigma, void* y, long 
 int sg_clamp_flat(float* p, long long n, float lo, float hi, sg_stream_t s);
 int sg_select_rows(const uint8_t* flag, const float* a, const float* b, float* out, int N, long long row, sg_stream_t s);
 int sg_sign_count(const float* logit, int B, float* acc, sg_stream_t s);
+/* Image-side operators of the adaptive discriminator augmentation pipeline (reference utils/ada_aug.py:178-353; the per-image 3 x 3 / 4 x 4 transforms are
+ * composed by the host mirror from the reference's draws), fp32 NCHW, each with its exact gather-form adjoint:
+ *   sg_reflect_pad2d_fwd / _bwd   F.pad(mode='reflect') of `planes` [H][W] images by (l, r, t, b) < the image size (ada_aug.py:265)
+ *   sg_affine_sample_fwd / _bwd   F.affine_grid(theta [N][2][3], align_corners=False) + grid_sample(bilinear, zeros) in one pass: x [N][C][Hi][Wi] ->
+ *                                 y [N][C][Ho][Wo] (ada_aug.py:276-277); _bwd: dx from dy (gradient w.r.t. the image; theta is a draw, not a parameter)
+ *   sg_color_affine               y = M[:, :, :3] x + M[:, :, 3] per image, M [N][3][4] (transpose = 1: the adjoint M[:, :, :3]^T dy); C == 1: y = x * M[n][0][0] + M[n][0][3]
+ *                                 (ada_aug.py:339-347) */
+int sg_reflect_pad2d_fwd(const float* x, float* y, int planes, int H, int W, int l, int r, int t, int b, sg_stream_t s);
+int sg_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, int l, int r, int t, int b, sg_stream_t s);
+int sg_affine_sample_fwd(const float* x, const float* theta, float* y, int N, int C, int Hi, int Wi, int Ho, int Wo, sg_stream_t s);
+int sg_affine_sample_bwd(const float* dy, const float* theta, float* dx, int N, int C, int Hi, int Wi, int Ho, int Wo, sg_stream_t s);
+int sg_color_affine(const float* x, const float* M, float* y, int N, int C, int HW, int transpose, sg_stream_t s);
 
 #ifdef __cplusplus
 }

@@ -30,6 +30,9 @@ CASES = {     # tag -> (configuration of oracle/make_golden.py, hyper-parameters
     "sngan32_ls_fm_diffaug": ("sngan32", dict(adv_loss="least_square", fm_lambda=1.0, diffaug_policy="translation,cutout")),
     # adaptive pseudo augmentation at p = 0.5 (configs/CIFAR10/SNGAN-APA.yaml) + weight clipping after the discriminator's optimiser step (configs/CIFAR10/WGAN-WC.yaml: 0.01)
     "sngan32_apa_wc": ("sngan32", dict(apa_p=0.5, wc_bound=0.01, adv_loss="wasserstein")),
+    # adaptive discriminator augmentation, 'bgc' pipeline at p = 0.8 (configs/CIFAR10/SNGAN-ADA.yaml). No restatement of the pipeline exists: the fixture carries
+    # the draws the reference's AdaAugment made (recorded at torch.rand / torch.randn) and the product is held against the reference directly
+    "sngan32_ada": ("sngan32", dict(ada_type="bgc", ada_p=0.8)),
 }
 AUG_SEED = 31337
 
@@ -53,6 +56,8 @@ def draw_all(hp, shape):
 def reference_d_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, RC, misc):
     l2 = torch.nn.MSELoss()                                                              # src/worker.py:116
     series = (lambda x: RD.apply_diffaug(x, hp["diffaug_policy"])) if hp.get("diffaug_policy") else (lambda x: x)      # config.py:586-587 / misc.identity
+    if hp.get("_ada") is not None:
+        series = hp["_ada"]                                                               # config.py:590-591
     misc.make_GAN_trainable(Gen, None, Dis)
     misc.toggle_grad(Gen, False)
     misc.toggle_grad(Dis, True)
@@ -106,6 +111,8 @@ def reference_g_side(cfgs, Gen, Dis, ins, hp, z_eps, RD, misc):
     fake_eps = Gen(z_eps, fl) if z_eps is not None else None
     torch.manual_seed(AUG_SEED + 1)
     fake_ = RD.apply_diffaug(fake, hp["diffaug_policy"]) if hp.get("diffaug_policy") else fake          # worker.py:549-550
+    if hp.get("_ada") is not None:
+        fake_ = hp["_ada"](fake)
     fake_dict = Dis(fake_, fl)
     loss = cfgs.LOSS.g_loss(fake_dict["adv_output"], DDP=False)
     if hp.get("fm_lambda") is not None:                                                   # worker.py:588-596
@@ -148,6 +155,30 @@ def main():
         # ---- discriminator side -------------------------------------------------------------------------------------------------
         torch.manual_seed(AUG_SEED)
         draws = draw_all(hp, shape)
+        ada = hp.get("ada_type")
+        if ada:
+            from . import make_golden_ada as MGD
+            RAda = importlib.import_module("utils.ada_aug")
+            mod = RAda.AdaAugment(**MGD.PIPES[ada]).train().requires_grad_(False)
+            mod.p.copy_(torch.as_tensor(hp["ada_p"]))
+            hp = dict(hp, _ada=mod)
+            with MGD.Recorded() as rec:
+                d_loss, d_grads, fake0, d_after = reference_d_side(cfgs, Gen, Dis, ins, hp, ze_d, RD, RC, misc)
+            for i, t in enumerate(rec.draws):
+                fix[p + f"draw_d/ada/{i:03d}"] = t
+            fix[p + "d_loss"] = d_loss
+            for k, v in d_grads.items():
+                fix[p + "D_grad/" + k] = v
+            with MGD.Recorded() as rec:
+                g_loss, g_grads, fake1 = reference_g_side(cfgs, Gen, Dis, ins, hp, ze_g, RD, misc)
+            for i, t in enumerate(rec.draws):
+                fix[p + f"draw_g/ada/{i:03d}"] = t
+            fix[p + "g_loss"] = g_loss
+            for k, v in g_grads.items():
+                fix[p + "G_grad/" + k] = v
+            print(f"{tag:28s} reference only: D loss {float(d_loss):.8e}, G loss {float(g_loss):.8e}")
+            meta[tag] = {"config": cfg_name, "hp": {k: v for k, v in hp.items() if not k.startswith("_")}}
+            continue
         d_loss, d_grads, fake0, d_after = reference_d_side(cfgs, Gen, Dis, ins, hp, ze_d, RD, RC, misc)
         if d_after is not None:
             for k, v in d_after.items():

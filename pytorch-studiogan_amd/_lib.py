@@ -226,6 +226,11 @@ _PROTOS = {
     "sg_clamp_flat": [_vp, _ll, _f, _f, _vp],
     "sg_select_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
     "sg_sign_count": [_vp, _i, _vp, _vp],
+    "sg_reflect_pad2d_fwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_reflect_pad2d_bwd": [_vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_affine_sample_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_affine_sample_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_color_affine": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
 }
 
 

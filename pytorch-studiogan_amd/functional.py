@@ -2148,3 +2148,111 @@ def sign_count_(acc, logits):
     lg = _c(logits.detach().float().reshape(-1))
     L.call("sg_sign_count", L.ptr(lg), lg.numel(), L.ptr(acc), L.stream())
     return acc
+
+
+# ---------------------------------------------------------------------------------------------------------
+# adaptive discriminator augmentation: image-side operators (csrc/ext/ada.hip)
+# ---------------------------------------------------------------------------------------------------------
+def _f32_image(t, what):
+    if t.dim() != 4 or t.dtype != torch.float32:
+        raise RuntimeError(what + ": an fp32 [N, C, H, W] image batch expected")
+    return _c(t)
+
+
+class ReflectPad2dFn(torch.autograd.Function):
+    """F.pad(x, [l, r, t, b], mode='reflect') (reference src/utils/ada_aug.py:265); backward = fold of the mirrored margins (gather form), its adjoint the pad again"""
+
+    @staticmethod
+    def forward(ctx, x, l, r, t, b):
+        x = _f32_image(x, "reflect_pad2d")
+        N, Cc, H, W = x.shape
+        ctx.m = (l, r, t, b)
+        y = torch.empty((N, Cc, H + t + b, W + l + r), dtype=torch.float32, device=x.device)
+        L.call("sg_reflect_pad2d_fwd", L.ptr(x), L.ptr(y), N * Cc, H, W, l, r, t, b, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ReflectPad2dBwdFn.apply(dy, *ctx.m), None, None, None, None
+
+
+class ReflectPad2dBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, l, r, t, b):
+        dy = _f32_image(dy, "reflect_pad2d backward")
+        N, Cc, Ho, Wo = dy.shape
+        ctx.m = (l, r, t, b)
+        dx = torch.empty((N, Cc, Ho - t - b, Wo - l - r), dtype=torch.float32, device=dy.device)
+        L.call("sg_reflect_pad2d_bwd", L.ptr(dy), L.ptr(dx), N * Cc, Ho - t - b, Wo - l - r, l, r, t, b, L.stream())
+        return dx
+
+    @staticmethod
+    def backward(ctx, ddx):
+        return ReflectPad2dFn.apply(ddx, *ctx.m), None, None, None, None
+
+
+class AffineSampleFn(torch.autograd.Function):
+    """grid_sample(x, affine_grid(theta, [N, C, Ho, Wo], align_corners=False)) with bilinear interpolation and zero padding (reference
+    src/utils/ada_aug.py:276-277) in one pass; theta [N, 2, 3] is a draw (no gradient). Linear in x: backward and its adjoint are the two kernels."""
+
+    @staticmethod
+    def forward(ctx, x, theta, Ho, Wo):
+        x = _f32_image(x, "affine_sample")
+        theta = _c(theta.detach().float())
+        N, Cc, Hi, Wi = x.shape
+        if tuple(theta.shape) != (N, 2, 3):
+            raise RuntimeError("affine_sample: theta must be [N, 2, 3]")
+        ctx.save_for_backward(theta)
+        ctx.dims = (Hi, Wi, Ho, Wo)
+        y = torch.empty((N, Cc, Ho, Wo), dtype=torch.float32, device=x.device)
+        L.call("sg_affine_sample_fwd", L.ptr(x), L.ptr(theta), L.ptr(y), N, Cc, Hi, Wi, Ho, Wo, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (theta,) = ctx.saved_tensors
+        return AffineSampleBwdFn.apply(dy, theta, *ctx.dims), None, None, None
+
+
+class AffineSampleBwdFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, dy, theta, Hi, Wi, Ho, Wo):
+        dy = _f32_image(dy, "affine_sample backward")
+        N, Cc = dy.shape[0], dy.shape[1]
+        ctx.save_for_backward(theta)
+        ctx.dims = (Ho, Wo)
+        dx = torch.empty((N, Cc, Hi, Wi), dtype=torch.float32, device=dy.device)
+        L.call("sg_affine_sample_bwd", L.ptr(dy), L.ptr(theta), L.ptr(dx), N, Cc, Hi, Wi, Ho, Wo, L.stream())
+        return dx
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (theta,) = ctx.saved_tensors
+        return AffineSampleFn.apply(ddx, theta, *ctx.dims), None, None, None, None, None
+
+
+class ColorAffineFn(torch.autograd.Function):
+    """y = M[:, :, :3] x + M[:, :, 3] per image (M [N, 3, 4]; one-plane images: y = x * M[n, 0, 0] + M[n, 0, 3]); reference src/utils/ada_aug.py:339-347.
+    linear=True: without the offset column (the map applied to a cotangent)."""
+
+    @staticmethod
+    def forward(ctx, x, M, transpose=False):
+        x = _f32_image(x, "color_affine")
+        M = _c(M.detach().float())
+        N, Cc, H, W = x.shape
+        if tuple(M.shape) != (N, 3, 4):
+            raise RuntimeError("color_affine: M must be [N, 3, 4]")
+        ctx.save_for_backward(M)
+        ctx.transpose = transpose
+        y = torch.empty_like(x)
+        L.call("sg_color_affine", L.ptr(x), L.ptr(M), L.ptr(y), N, Cc, H * W, 1 if transpose else 0, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (M,) = ctx.saved_tensors
+        if ctx.transpose:      # the adjoint of the adjoint: the linear part again (offset-free)
+            M0 = M.clone()
+            M0[:, :, 3] = 0
+            return ColorAffineFn.apply(dy, M0, False), None, None
+        return ColorAffineFn.apply(dy, M, True), None, None

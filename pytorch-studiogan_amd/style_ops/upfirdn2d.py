@@ -68,8 +68,7 @@ def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=Fals
 
 def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain):
     """one sg_upfirdn2d launch; x: dense NCHW fp32 / bf16 on the GPU; f2d: [fh][fw] fp32"""
-    if not x.is_cuda:
-        raise RuntimeError("upfirdn2d: the HIP kernels need a GPU tensor (no CPU fallback on the product path)")
+    L.require_gpu(x.device)          # the HIP kernels need a GPU tensor: no CPU fallback on the product path
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise RuntimeError(f"upfirdn2d: float32 / bfloat16 only, got {x.dtype}")
     x = x.contiguous()

@@ -73,17 +73,29 @@ class Worker:
                  mh_lambda=1.0, apply_diffaug=False, diffaug_type="diffaug", apply_cr=False, cr_aug_type="cr", cr_lambda=10.0,
                  apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0,
                  apply_fm=False, fm_lambda=1.0, apply_wc=False, wc_bound=0.01,
-                 apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4):
+                 apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4,
+                 apply_ada=False, ada_aug_type="bgc", ada_initial_augment_p=0.0, ada_target=0.6, ada_kimg=500, ada_interval=4):
         self.Gen, self.Dis = Gen, Dis
         self.apply_wc, self.wc_bound = apply_wc, wc_bound              # weight clipping after every discriminator update (src/worker.py:489-492)
         # adaptive pseudo augmentation (src/worker.py:82,127-134,273-274,285-289,478-487): real images swapped for fakes with probability aa_p, which follows
         # the sign statistic of the real logits towards aa_target
         self.apply_apa, self.aa_p, self.aa_target, self.aa_kimg, self.aa_interval = apply_apa, float(apa_initial_augment_p), apa_target, apa_kimg, apa_interval
-        self.dis_sign_real = torch.zeros(2, dtype=torch.float32, device=next(Gen.parameters()).device) if apply_apa else None
+        self.dis_sign_real = torch.zeros(2, dtype=torch.float32, device=next(Gen.parameters()).device) if (apply_apa or apply_ada) else None
         self.apply_fm, self.fm_lambda = apply_fm, fm_lambda          # feature matching in the generator update (src/worker.py:588-596)
         # augmentations in front of the discriminator (reference src/config.py:582-626): series_augment runs on every real / fake batch
         # (src/worker.py:276-278,549-550), parallel_augment makes the second view of the consistency regularisers (:326-354)
         self.series_augment = self._augmenter(diffaug_type, "diffaug_type") if apply_diffaug else (lambda x: x)
+        # adaptive discriminator augmentation (src/config.py:590-591, src/worker.py:127-134): the series augmentation is the AdaAugment pipeline, its strength p
+        # follows the same heuristic
+        self.apply_ada = apply_ada
+        assert not (apply_ada and apply_diffaug), "AUG.apply_ada and AUG.apply_diffaug both set cfgs.AUG.series_augment: one of them (reference src/config.py:582-594)"
+        if apply_ada:
+            from . import ada_aug
+            if ada_aug_type not in ada_aug.AUGPIPE:
+                raise NotImplementedError(f"ada_aug_type = {ada_aug_type}")
+            self.series_augment = ada_aug.AdaAugment(**ada_aug.AUGPIPE[ada_aug_type]).train().to(next(Gen.parameters()).device).requires_grad_(False)
+            self.aa_p, self.aa_target, self.aa_kimg, self.aa_interval = float(ada_initial_augment_p), ada_target, ada_kimg, ada_interval
+            self.series_augment.p.copy_(torch.as_tensor(self.aa_p))
         self.apply_cr, self.cr_lambda = apply_cr, cr_lambda
         self.apply_bcr, self.real_lambda, self.fake_lambda = apply_bcr, real_lambda, fake_lambda
         self.apply_zcr, self.radius, self.g_lambda, self.d_lambda = apply_zcr, radius, g_lambda, d_lambda
@@ -200,7 +212,7 @@ class Worker:
                 real_dict = self.Dis(real_images_, real_labels)
                 fake_dict = self.Dis(fake_images_, fake_labels, adc_fake=self.adc_fake)
                 self.last_d = (fake_images.detach(), real_dict["adv_output"].detach(), fake_dict["adv_output"].detach())
-                if self.apply_apa:       # src/worker.py:285-289 (the sum stays on the device until the heuristic reads it)
+                if self.apply_apa or self.apply_ada:       # src/worker.py:285-289 (the sum stays on the device until the heuristic reads it)
                     from . import functional as _F
                     _F.sign_count_(self.dis_sign_real, real_dict["adv_output"])
                 if self.adv_loss == "MH":          # src/worker.py:300-302
@@ -259,7 +271,7 @@ class Worker:
                 dis_acml_loss.backward()
                 dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
             self.d_optimizer.step(group=self.group)
-            if self.apply_apa and self.aa_target is not None and current_step % self.aa_interval == 0:      # src/worker.py:478-487
+            if (self.apply_apa or self.apply_ada) and self.aa_target is not None and current_step % self.aa_interval == 0:      # src/worker.py:478-487
                 import numpy as _np
                 import torch.distributed as _dist
                 if self.group is not None:
@@ -268,6 +280,8 @@ class Worker:
                 heuristic = s_sum / s_cnt
                 adjust = float(_np.sign(heuristic - self.aa_target)) * s_cnt / (self.aa_kimg * 1000)
                 self.aa_p = min(1.0, max(self.aa_p + adjust, 0.0))
+                if self.apply_ada:
+                    self.series_augment.p.copy_(torch.as_tensor(self.aa_p))
                 self.dis_sign_real.zero_()
             if self.apply_wc:            # src/worker.py:489-492
                 self.d_optimizer.clamp_(self.wc_bound)

@@ -22,7 +22,7 @@ def _t(z, k):
 def _replay(draws):
     """torch.rand / torch.randint / FloatTensor.uniform_ stand-ins that hand out the recorded draws in order (shape-checked): the host mirrors then
     consume exactly what the reference consumed when it wrote the fixture, whatever generator the device has"""
-    it = iter(draws)
+    it = draws if hasattr(draws, "__next__") else iter(draws)
 
     def nxt(shape, dev):
         d = next(it)
@@ -33,10 +33,11 @@ def _replay(draws):
 
 class Replayed:
     def __init__(self, draws):
-        self.nxt = _replay(draws)
+        self.it = iter(draws)
+        self.nxt = _replay(self.it)
 
     def __enter__(self):
-        self.saved = (torch.rand, torch.randint, torch.FloatTensor)
+        self.saved = (torch.rand, torch.randint, torch.FloatTensor, torch.randn)
         nxt = self.nxt
 
         def rand(*size, dtype=None, device=None, **kw):
@@ -53,11 +54,11 @@ class Replayed:
 
             def uniform_(self, a, b):
                 return nxt(self.size, "cpu")
-        torch.rand, torch.randint, torch.FloatTensor = rand, randint, FT
+        torch.rand, torch.randint, torch.FloatTensor, torch.randn = rand, randint, FT, rand
         return self
 
     def __exit__(self, *a):
-        torch.rand, torch.randint, torch.FloatTensor = self.saved
+        torch.rand, torch.randint, torch.FloatTensor, torch.randn = self.saved
 
 
 def diffaug_case(case, dev):
@@ -215,7 +216,8 @@ def consistency_case(tag, dev):
                radius=hp.get("radius", 0.0), g_lambda=hp.get("g_lambda", 0.0), d_lambda=hp.get("d_lambda", 0.0),
                apply_fm=hp.get("fm_lambda") is not None, fm_lambda=hp.get("fm_lambda", 0.0),
                apply_apa=hp.get("apa_p") is not None, apa_initial_augment_p=hp.get("apa_p", 0.0), apa_target=None,
-               apply_wc=hp.get("wc_bound") is not None, wc_bound=hp.get("wc_bound", 0.0))
+               apply_wc=hp.get("wc_bound") is not None, wc_bound=hp.get("wc_bound", 0.0),
+               apply_ada=hp.get("ada_type") is not None, ada_aug_type=hp.get("ada_type", "bgc"), ada_initial_augment_p=hp.get("ada_p", 0.0), ada_target=None)
     if hp.get("diffaug_policy"):
         from studiogan_amd import diffaug as DA
         w.series_augment = lambda x: DA.apply_diffaug(x, hp["diffaug_policy"])
@@ -225,16 +227,13 @@ def consistency_case(tag, dev):
     def draws_of(prefix, names):
         out = []
         for name in names:
-            i = 0
-            while i < 8:
-                k = f"{p}{prefix}/{name}/{i}"
-                if k in z.files:
-                    out.append(torch.from_numpy(z[k]))
-                i += 1
+            pre = f"{p}{prefix}/{name}/"
+            keys = sorted((k for k in z.files if k.startswith(pre)), key=lambda k: int(k[len(pre):]))
+            out += [torch.from_numpy(z[k]) for k in keys]
         return out
     C = Collector()
     zed = torch.from_numpy(z[p + "z_eps_d"]).to(dev) if p + "z_eps_d" in z.files else None
-    with Replayed(draws_of("draw_d", ["apa", "series_real", "series_fake", "prl_real", "prl_fake"])):
+    with Replayed(draws_of("draw_d", ["apa", "series_real", "series_fake", "prl_real", "prl_fake", "ada"])):
         d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"]) + ((zed,) if zed is not None else ())])
     C.check("d_loss", d_loss, torch.from_numpy(z[p + "d_loss"]), 2e-4)
     dmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "D_grad/"))
@@ -252,7 +251,7 @@ def consistency_case(tag, dev):
         for k, prm in D.named_parameters():
             prm.copy_(fix["D_init/" + k].to(dev))
     zeg = torch.from_numpy(z[p + "z_eps_g"]).to(dev) if p + "z_eps_g" in z.files else None
-    with Replayed(draws_of("draw_g", ["series_fake", "series_real_fm"])):
+    with Replayed(draws_of("draw_g", ["series_fake", "series_real_fm", "ada"])):
         g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"]) + ((zeg,) if zeg is not None else ())], real_batches=[(ins["real1"], ins["rl1"])])
     C.check("g_loss", g_loss, torch.from_numpy(z[p + "g_loss"]), 1e-3)
     gmx = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith(p + "G_grad/"))
@@ -261,7 +260,7 @@ def consistency_case(tag, dev):
     C.finish()
 
 
-CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug", "sngan32_ls_fm_diffaug", "sngan32_apa_wc"]
+CONSISTENCY_CASES = ["biggan32_diffaug_bcr_zcr", "sngan32_cr", "sngan32_diffaug", "sngan32_ls_fm_diffaug", "sngan32_apa_wc", "sngan32_ada"]
 
 
 def apa_case(i, dev):
@@ -367,3 +366,65 @@ def r1_through_diffaug_case(name, dev):
         go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
         C.check("r1 through diffaug: grad " + k, prm.grad if prm.grad is not None else torch.zeros_like(prm), go, 1e-3, floor=1e-2 * gmax)
     C.finish()
+
+
+# ---- adaptive discriminator augmentation against the reference's own outputs (tests/golden/ada.npz, oracle/make_golden_ada.py) ------------------------------
+ADA_GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ada.npz")
+
+
+def ada_case(case, dev):
+    """studiogan_amd.ada_aug.AdaAugment fed the draws the REAL reference's AdaAugment made: output and image gradient (fp32; 2e-5 of the tensor's range: the
+    reference's grid coordinates come out of a batched matmul, the kernel's out of three fused multiply-adds)"""
+    from oracle import make_golden_ada as MGD
+    from studiogan_amd import ada_aug
+    tag, pipe, shape, pr = case
+    z = np.load(ADA_GOLD)
+    pre = f"{tag}/"
+    draws = []
+    while pre + f"draw{len(draws)}" in z.files:
+        draws.append(_t(z, pre + f"draw{len(draws)}"))
+    aug = ada_aug.AdaAugment(**MGD.PIPES[pipe]).to(dev)
+    aug.p.copy_(torch.as_tensor(pr))
+    x = _t(z, pre + "x").to(dev).requires_grad_(True)
+    with Replayed(draws) as R:
+        y = aug(x)
+    assert next(R.it, None) is None, "the mirror consumed fewer draws than the reference made"
+    check(f"ada {tag} y", y, _t(z, pre + "y"), 2e-5)
+    if float(np.abs(z[pre + "dx"]).max()) > 0:
+        (dx,) = torch.autograd.grad(y, x, _t(z, pre + "gy").to(dev))
+        check(f"ada {tag} dx", dx, _t(z, pre + "dx"), 2e-5)
+
+
+def ada_adjoint_case(shape, dev, seed=0):
+    """the three image-side operators against their adjoints at any size: <A u, v> == <u, A^T v> for reflect padding, the affine resampling (random
+    rotations / scalings / shifts) and the colour matrix; run-to-run bit-identity of the gather-form backward"""
+    from studiogan_amd import functional as F
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = shape
+
+    def adj(fn, bfn, u, v):
+        Au, Atv = fn(u), bfn(v)
+        lhs, rhs = float((Au.double() * v.double()).sum()), float((u.double() * Atv.double()).sum())
+        scale = float(Au.double().norm() * v.double().norm()) + 1e-30
+        assert abs(lhs - rhs) <= 2e-6 * scale, (lhs, rhs, scale)
+        assert torch.equal(Atv, bfn(v))
+    u = torch.randn(shape, generator=g).to(dev)
+    l, r, t, b = min(5, W - 1), min(2, W - 1), min(3, H - 1), min(H - 1, 7)
+    adj(lambda a: F.ReflectPad2dFn.apply(a, l, r, t, b), lambda a: F.ReflectPad2dBwdFn.apply(a, l, r, t, b), u,
+        torch.randn((N, C, H + t + b, W + l + r), generator=g).to(dev))
+    ang = (torch.rand(N, generator=g) * 2 - 1) * 3.14159
+    sx, sy = torch.exp2(torch.randn(N, generator=g) * 0.3), torch.exp2(torch.randn(N, generator=g) * 0.3)
+    theta = torch.stack([torch.stack([sx * torch.cos(ang), -sy * torch.sin(ang), torch.randn(N, generator=g) * 0.2], 1),
+                         torch.stack([sx * torch.sin(ang), sy * torch.cos(ang), torch.randn(N, generator=g) * 0.2], 1)], 1).to(dev)
+    Ho, Wo = H + 6, W + 4
+    adj(lambda a: F.AffineSampleFn.apply(a, theta, Ho, Wo), lambda a: F.AffineSampleBwdFn.apply(a, theta, H, W, Ho, Wo), u,
+        torch.randn((N, C, Ho, Wo), generator=g).to(dev))
+    # the resampling against torch's own affine_grid + grid_sample on the CPU
+    ref = torch.nn.functional.grid_sample(u.cpu(), torch.nn.functional.affine_grid(theta.cpu(), [N, C, Ho, Wo], align_corners=False), mode="bilinear",
+                                          padding_mode="zeros", align_corners=False)
+    check("affine_sample vs torch grid_sample", F.AffineSampleFn.apply(u, theta, Ho, Wo), ref, 2e-5)
+    if C in (1, 3):
+        M = torch.randn(N, 3, 4, generator=g).to(dev)
+        M0 = M.clone()
+        M0[:, :, 3] = 0
+        adj(lambda a: F.ColorAffineFn.apply(a, M0), lambda a: F.ColorAffineFn.apply(a, M, True), u, torch.randn(shape, generator=g).to(dev))

@@ -171,6 +171,15 @@ def test_emulated_r1_through_diffaug(installed):
     AC.r1_through_diffaug_case("biggan32", torch.device("cpu"))
 
 
+@needs_emu
+def test_emulated_ada_pipeline_matches_reference_vectors(installed):
+    from oracle import make_golden_ada as MGD
+    for case in MGD.CASES:
+        AC.ada_case(case, torch.device("cpu"))
+    AC.ada_adjoint_case((2, 3, 12, 10), torch.device("cpu"), 1)
+    AC.ada_adjoint_case((3, 1, 9, 16), torch.device("cpu"), 2)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json
@@ -180,6 +189,8 @@ def test_consistency_oracle_reproduces_the_reference_vectors():
     meta_c = json.load(open(os.path.join(GOLDEN, "consistency.json")))
     for tag, m in meta_c.items():
         hp = m["hp"]
+        if hp.get("ada_type"):
+            continue          # (no restatement of the ADA pipeline: the product is held against the reference's vectors directly)
         fix, meta = load_golden(m["config"])
         y = meta["yaml"]
         ocfg = MG.oracle_cfg(y)

@@ -125,3 +125,28 @@ def test_worker_update_with_diffaug_and_consistency_regularisers(sg, tag):
 @pytest.mark.parametrize("name", ["biggan32", "sngan32"])
 def test_r1_through_diffaug(sg, name):
     AC.r1_through_diffaug_case(name, DEV)
+
+
+def test_ada_pipeline_matches_reference_vectors(sg):
+    """studiogan_amd.ada_aug.AdaAugment ('blit', 'geom', 'color', 'bgc'; RGB and one-channel images) fed the draws the REAL reference's AdaAugment made:
+    output and image gradient (tests/golden/ada.npz)"""
+    from oracle import make_golden_ada as MGD
+    for case in MGD.CASES:
+        AC.ada_case(case, DEV)
+
+
+def test_ada_operators_adjoint_at_benchmark_size(sg):
+    AC.ada_adjoint_case((64, 3, 128, 128), DEV, 1)
+    AC.ada_adjoint_case((256, 3, 32, 32), DEV, 2)
+    AC.ada_adjoint_case((8, 1, 33, 47), DEV, 3)
+    from studiogan_amd import ada_aug
+    with pytest.raises(NotImplementedError):
+        ada_aug.AdaAugment(imgfilter=1)
+    aug = ada_aug.AdaAugment(**ada_aug.AUGPIPE["bgc"]).to(DEV)
+    aug.p.copy_(torch.as_tensor(0.6))
+    x = torch.rand(256, 3, 128, 128, device=DEV) * 2 - 1
+    torch.manual_seed(5)
+    a = aug(x)
+    torch.manual_seed(5)
+    b = aug(x)
+    assert a.shape == x.shape and torch.equal(a, b) and bool(torch.isfinite(a).all())

@@ -54,6 +54,14 @@ def main():
             y = torch.rand_like(x)
             tm = timed(lambda: losses.l2_loss(x, y))
         print(f"{'apply_diffaug (draws + tables + launch)':42s} {th:8.1f} us    apply_cr_aug {tc:8.1f} us    l2_loss {tm:8.1f} us = {n * 8 / tm / 1e3:7.1f} GB/s")
+        from studiogan_amd import ada_aug
+        aug = ada_aug.AdaAugment(**ada_aug.AUGPIPE["bgc"]).to(dev)
+        aug.p.copy_(torch.as_tensor(0.6))
+        with torch.no_grad():
+            ta = timed(lambda: aug(x), reps=20)
+        xg = x.clone().requires_grad_(True)
+        tab = timed(lambda: torch.autograd.grad(aug(xg).sum(), xg), reps=20)
+        print(f"{'AdaAugment bgc, p = 0.6 (whole module)':42s} fwd {ta:8.1f} us    fwd + bwd {tab:8.1f} us")
 
 
 if __name__ == "__main__":
