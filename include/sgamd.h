@@ -531,6 +531,12 @@ int sg_reflect_pad2d_bwd(const float* dy, float* dx, int planes, int H, int W, i
 int sg_affine_sample_fwd(const float* x, const float* theta, float* y, int N, int C, int Hi, int Wi, int Ho, int Wo, sg_stream_t s);
 int sg_affine_sample_bwd(const float* dy, const float* theta, float* dx, int N, int C, int Hi, int Wi, int Ho, int Wo, sg_stream_t s);
 int sg_color_affine(const float* x, const float* M, float* y, int N, int C, int HW, int transpose, sg_stream_t s);
+/*   sg_fir_reflect                one axis (0: along a row, 1: along a column) of the per-image separable amplification filter over the reflect-padded image
+ *                                 (ada_aug.py:352-389): y = sum_t taps[n][t] x[reflect(pos + t - T/2)], T odd; transpose = 1: its adjoint
+ *   sg_ada_noise_cutout           y = (x + noise * sigma[n]) * cutout-mask(cut[n] = centre x, centre y, size x, size y in image fractions) (ada_aug.py:393-416);
+ *                                 noise / sigma or cut may be NULL; the adjoint is the call without noise */
+int sg_fir_reflect(const float* x, const float* taps, float* y, int N, int C, int H, int W, int T, int axis, int transpose, sg_stream_t s);
+int sg_ada_noise_cutout(const float* x, const float* noise, const float* sigma, const float* cut, float* y, int N, int C, int H, int W, sg_stream_t s);
 
 #ifdef __cplusplus
 }

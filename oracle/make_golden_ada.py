@@ -20,10 +20,15 @@ PIPES = {      # reference src/config.py ada_augpipe
     "blit": dict(xflip=1, rotate90=1, xint=1), "geom": dict(scale=1, rotate=1, aniso=1, xfrac=1),
     "color": dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
     "bgc": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
+    "filter": dict(imgfilter=1), "noise": dict(noise=1), "cutout": dict(cutout=1),
+    "bgcfnc": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1, imgfilter=1, noise=1,
+                   cutout=1),
 }
 CASES = [      # (tag, pipe, shape, p)
     ("bgc32", "bgc", (4, 3, 32, 32), 0.8), ("bgc_rect", "bgc", (3, 3, 16, 24), 1.0), ("blit16", "blit", (4, 3, 16, 16), 1.0), ("geom16", "geom", (4, 3, 16, 16), 0.9),
     ("color8", "color", (5, 3, 8, 8), 0.8), ("gray", "bgc", (3, 1, 16, 16), 1.0), ("off", "bgc", (2, 3, 8, 8), 0.0),
+    ("filter32", "filter", (3, 3, 32, 32), 1.0), ("filter_rect", "filter", (2, 1, 24, 40), 0.8), ("noise8", "noise", (4, 3, 8, 8), 0.9),
+    ("cutout16", "cutout", (5, 3, 16, 16), 0.9), ("bgcfnc32", "bgcfnc", (3, 3, 32, 32), 0.9),
 ]
 
 

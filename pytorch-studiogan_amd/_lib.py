@@ -231,6 +231,8 @@ _PROTOS = {
     "sg_affine_sample_fwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sg_affine_sample_bwd": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _vp],
     "sg_color_affine": [_vp, _vp, _vp, _i, _i, _i, _i, _vp],
+    "sg_fir_reflect": [_vp, _vp, _vp, _i, _i, _i, _i, _i, _i, _i, _vp],
+    "sg_ada_noise_cutout": [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp],
 }
 
 

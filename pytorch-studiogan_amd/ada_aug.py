@@ -2,8 +2,9 @@
 AdaAugment; built by src/config.py:590-591 from the `ada_augpipe` table and used as cfgs.AUG.series_augment, its strength `p` driven by the overfitting
 heuristic of src/worker.py:478-487). The pipelines the non-StyleGAN configurations use are mirrored: pixel blitting (x-flip, 90-degree rotations, integer
 translation), general geometric transformations (isotropic / anisotropic scaling, pre- and post-rotation, fractional translation), colour transformations
-(brightness, contrast, luma flip, hue rotation, saturation): 'blit', 'geom', 'color', 'bg', 'bgc' -- what configs/*/{BigGAN,SNGAN,ReACGAN}-ADA.yaml use.
-Image-space filtering, additive noise and cutout ('filter', 'noise', 'cutout', 'bgcf', ...) raise NotImplementedError.
+(brightness, contrast, luma flip, hue rotation, saturation), image-space filtering (a per-image 4-band amplification filter), additive noise and cutout: every
+entry of the reference's `ada_augpipe` table ('blit', 'geom', 'color', 'filter', 'noise', 'cutout', 'bg', 'bgc', 'bgcf', 'bgcfn', 'bgcfnc'); the non-StyleGAN
+configurations (configs/*/{BigGAN,SNGAN,ReACGAN}-ADA.yaml) use 'bgc'.
 
 What the reference does with ~25 tiny launches per draw is kept as it is -- the per-image 3 x 3 / 4 x 4 matrices are composed with torch on [N]-sized tensors,
 by the reference's own draw calls in the reference's order -- and everything that touches image bytes runs in libsgamd.so: reflect padding, 2x up-sampling
@@ -21,11 +22,17 @@ from .style_ops import upfirdn2d
 _SYM6 = [0.015404109327027373, 0.0034907120842174702, -0.11799011114819057, -0.048311742585633, 0.4910559419267466, 0.787641141030194, 0.3379294217276218,
          -0.07263752278646252, -0.021060292512300564, 0.04472490177066578, 0.0017677118642428036, -0.007800708325034148]      # ada_aug.py:37 (the geometric low-pass)
 
+_SYM2 = [-0.12940952255092145, 0.22414386804185735, 0.836516303737469, 0.48296291314469025]      # ada_aug.py:33
+
 AUGPIPE = {      # reference src/config.py: ada_augpipe
     "blit": dict(xflip=1, rotate90=1, xint=1), "geom": dict(scale=1, rotate=1, aniso=1, xfrac=1),
     "color": dict(brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1), "filter": dict(imgfilter=1), "noise": dict(noise=1), "cutout": dict(cutout=1),
     "bg": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1),
     "bgc": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1),
+    "bgcf": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1, imgfilter=1),
+    "bgcfn": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1, imgfilter=1, noise=1),
+    "bgcfnc": dict(xflip=1, rotate90=1, xint=1, scale=1, rotate=1, aniso=1, xfrac=1, brightness=1, contrast=1, lumaflip=1, hue=1, saturation=1, imgfilter=1, noise=1,
+                   cutout=1),
 }
 
 
@@ -66,10 +73,20 @@ class AdaAugment(torch.nn.Module):
                          saturation_std=saturation_std, imgfilter=imgfilter, imgfilter_std=imgfilter_std, noise=noise, cutout=cutout, noise_std=noise_std,
                          cutout_size=cutout_size).items():
             setattr(self, k, float(v))
-        if self.imgfilter > 0 or self.noise > 0 or self.cutout > 0:
-            raise NotImplementedError("AdaAugment: image-space filtering, additive noise and cutout ('filter', 'noise', 'cutout', 'bgcf', ...) are not "
-                                      "mirrored: the non-StyleGAN configurations use 'bgc' (SURVEY.md §8f)")
+        self.imgfilter_bands = list(imgfilter_bands)
         self.register_buffer("Hz_geom", upfirdn2d.setup_filter(_SYM6))
+        # filter bank of the image-space filtering (ada_aug.py:166-176): four octave bands built from the sym2 wavelet
+        import scipy.signal
+        Hz_lo = np.asarray(_SYM2)
+        Hz_hi = Hz_lo * ((-1) ** np.arange(Hz_lo.size))
+        Hz_lo2 = np.convolve(Hz_lo, Hz_lo[::-1]) / 2
+        Hz_hi2 = np.convolve(Hz_hi, Hz_hi[::-1]) / 2
+        Hz_fbank = np.eye(4, 1)
+        for i in range(1, Hz_fbank.shape[0]):
+            Hz_fbank = np.dstack([Hz_fbank, np.zeros_like(Hz_fbank)]).reshape(Hz_fbank.shape[0], -1)[:, :-1]
+            Hz_fbank = scipy.signal.convolve(Hz_fbank, [Hz_lo2])
+            Hz_fbank[i, (Hz_fbank.shape[1] - Hz_hi2.size) // 2: (Hz_fbank.shape[1] + Hz_hi2.size) // 2] += Hz_hi2
+        self.register_buffer("Hz_fbank", torch.as_tensor(Hz_fbank, dtype=torch.float32))
 
     # ---- parameter selection: the reference's draws, in its order (ada_aug.py:187-262,284-325) --------------------------------------------------------
     def _geometry(self, B, width, height, dev):
@@ -190,4 +207,30 @@ class AdaAugment(torch.nn.Module):
             else:
                 raise ValueError("Image must be RGB (3 channels) or L (1 channel)")
             images = F.ColorAffineFn.apply(images, M.contiguous())
+        if self.imgfilter > 0:                                         # ada_aug.py:352-389
+            num_bands = self.Hz_fbank.shape[0]
+            assert len(self.imgfilter_bands) == num_bands
+            expected_power = torch.as_tensor(np.array([10, 1, 1, 1]) / 13, dtype=torch.float32, device=dev)
+            g = torch.ones([B, num_bands], device=dev)
+            for i, band_strength in enumerate(self.imgfilter_bands):
+                t_i = torch.exp2(torch.randn([B], device=dev) * self.imgfilter_std)
+                t_i = torch.where(torch.rand([B], device=dev) < self.imgfilter * self.p * band_strength, t_i, torch.ones_like(t_i))
+                t = torch.ones([B, num_bands], device=dev)
+                t[:, i] = t_i
+                t = t / (expected_power * t.square()).sum(dim=-1, keepdims=True).sqrt()
+                g = g * t
+            Hz_prime = (g.unsqueeze(-1) * self.Hz_fbank.unsqueeze(0)).sum(1)      # g @ Hz_fbank: [B, taps]
+            images = F.FirReflectFn.apply(F.FirReflectFn.apply(images, Hz_prime, 0), Hz_prime, 1)
+        noise = sigma = cut = None
+        if self.noise > 0:                                             # ada_aug.py:393-399
+            sigma = torch.randn([B, 1, 1, 1], device=dev).abs() * self.noise_std
+            sigma = torch.where(torch.rand([B, 1, 1, 1], device=dev) < self.noise * self.p, sigma, torch.zeros_like(sigma))
+            noise = torch.randn([B, Cc, height, width], device=dev)
+        if self.cutout > 0:                                            # ada_aug.py:402-416
+            size = torch.full([B, 2, 1, 1, 1], self.cutout_size, device=dev)
+            size = torch.where(torch.rand([B, 1, 1, 1, 1], device=dev) < self.cutout * self.p, size, torch.zeros_like(size))
+            center = torch.rand([B, 2, 1, 1, 1], device=dev)
+            cut = torch.cat([center.reshape(B, 2), size.reshape(B, 2)], dim=1)
+        if noise is not None or cut is not None:
+            images = F.NoiseCutoutFn.apply(images, noise, sigma, cut)
         return images

@@ -185,3 +185,74 @@ extern "C" int sg_color_affine(const float* x, const float* M, float* y, int N, 
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- image-space filtering, additive noise, cutout (ada_aug.py:352-416) --------------------------------------------------------------------------------------
+// sg_fir_reflect: y[n][c][..] = sum_t taps[n][t] x[n][c][reflect(pos + t - T/2)] along one axis (axis 0: columns, 1: rows) -- one of the two passes of the per-image
+// separable amplification filter over a reflect-padded image (conv2d is a correlation: no tap flip). transpose = 1: the adjoint (each source sample gathers from its
+// direct and mirrored positions).
+__global__ __launch_bounds__(256) void k_fir_reflect(const float* x, const float* taps, float* y, int C, int H, int W, int T, int axis, int transpose) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const float* w = taps + (long long)n * T;
+  const int p = T / 2, Lax = axis ? H : W, stride = axis ? W : 1;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < C * HW; i += gridDim.x * 256) {
+    const int c = i / HW, r = i - c * HW;
+    const int row = r / W, col = r - row * W;
+    const int pos = axis ? row : col;
+    const float* line = x + ((long long)(n * C + c) * H + (axis ? 0 : row)) * W + (axis ? col : 0);
+    float a = 0.f;
+    if (!transpose) {
+      for (int t = 0; t < T; t++) a += w[t] * line[(long long)ada_reflect(pos + t - p, Lax) * stride];
+    } else {
+      // sources k (padded coordinate) that read this sample: k = pos, -pos, 2 (L - 1) - pos; output index j = k - t + p
+      int ks[3], nk = 0;
+      ks[nk++] = pos;
+      if (pos > 0) ks[nk++] = -pos;
+      if (pos < Lax - 1) ks[nk++] = 2 * (Lax - 1) - pos;
+      for (int u = 0; u < nk; u++)
+        for (int t = 0; t < T; t++) {
+          const int j = ks[u] - t + p;
+          if (j >= 0 && j < Lax && ks[u] >= -p && ks[u] <= Lax - 1 + p) a += w[t] * line[(long long)j * stride];
+        }
+    }
+    y[((long long)(n * C + c) * H + row) * W + col] = a;
+  }
+}
+extern "C" int sg_fir_reflect(const float* x, const float* taps, float* y, int N, int C, int H, int W, int T, int axis, int transpose, sg_stream_t s) {
+  SG_CHECK(x && taps && y && x != y && N > 0 && C > 0 && H > 0 && W > 0 && T > 0 && (T & 1) && (axis == 0 || axis == 1), "sg_fir_reflect: bad args (odd tap count)");
+  SG_CHECK(T / 2 < (axis ? H : W), "sg_fir_reflect: the reflect padding (T / 2) must be smaller than the image");
+  int bx = (C * H * W + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_fir_reflect, dim3(bx, N), dim3(256), 0, (hipStream_t)s, x, taps, y, C, H, W, T, axis, transpose);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+// y = (x + noise * sigma[n]) * mask_n; mask_n(i, j) = 0 inside the cutout rectangle |(j + 0.5) / W - cut[n][0]| < cut[n][2] / 2 and |(i + 0.5) / H - cut[n][1]| < cut[n][3] / 2
+// (ada_aug.py:393-416). noise / sigma and cut may be NULL (that operator off); the adjoint is the same call with noise = NULL.
+__global__ __launch_bounds__(256) void k_noise_cutout(const float* x, const float* noise, const float* sigma, const float* cut, float* y, int C, int H, int W) {
+  const int n = blockIdx.y;
+  const int HW = H * W;
+  const float sg = sigma ? sigma[n] : 0.f;
+  float cx = 0.f, cy = 0.f, hx = -1.f, hy = -1.f;
+  if (cut) { cx = cut[4 * n]; cy = cut[4 * n + 1]; hx = __fdiv_rn(cut[4 * n + 2], 2.f); hy = __fdiv_rn(cut[4 * n + 3], 2.f); }
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < C * HW; i += gridDim.x * 256) {
+    const int r = i % HW, row = r / W, col = r - row * W;
+    const long long o = (long long)n * C * HW + i;
+    float v = x[o];
+    if (noise) v = __fadd_rn(v, __fmul_rn(noise[o], sg));
+    if (cut) {
+      const bool keep_x = fabsf(__fsub_rn(__fdiv_rn((float)col + 0.5f, (float)W), cx)) >= hx;
+      const bool keep_y = fabsf(__fsub_rn(__fdiv_rn((float)row + 0.5f, (float)H), cy)) >= hy;
+      if (!(keep_x || keep_y)) v = __fmul_rn(v, 0.f);
+    }
+    y[o] = v;
+  }
+}
+extern "C" int sg_ada_noise_cutout(const float* x, const float* noise, const float* sigma, const float* cut, float* y, int N, int C, int H, int W, sg_stream_t s) {
+  SG_CHECK(x && y && N > 0 && C > 0 && H > 0 && W > 0 && (!noise == !sigma), "sg_ada_noise_cutout: bad args (noise and sigma come together)");
+  int bx = (C * H * W + 255) / 256;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(k_noise_cutout, dim3(bx, N), dim3(256), 0, (hipStream_t)s, x, noise, sigma, cut, y, C, H, W);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

@@ -2256,3 +2256,50 @@ class ColorAffineFn(torch.autograd.Function):
             M0[:, :, 3] = 0
             return ColorAffineFn.apply(dy, M0, False), None, None
         return ColorAffineFn.apply(dy, M, True), None, None
+
+
+class FirReflectFn(torch.autograd.Function):
+    """one axis of ADA's per-image separable amplification filter over the reflect-padded image (reference src/utils/ada_aug.py:383-388: F.pad(mode='reflect') +
+    grouped conv2d with one filter per image); taps [N, T] are derived from draws (no gradient). transpose=True: the adjoint; each is the other's backward."""
+
+    @staticmethod
+    def forward(ctx, x, taps, axis, transpose=False):
+        x = _f32_image(x, "fir_reflect")
+        taps = _c(taps.detach().float())
+        N, Cc, H, W = x.shape
+        if taps.dim() != 2 or taps.shape[0] != N:
+            raise RuntimeError("fir_reflect: taps must be [N, T]")
+        ctx.save_for_backward(taps)
+        ctx.axis, ctx.transpose = axis, transpose
+        y = torch.empty_like(x)
+        L.call("sg_fir_reflect", L.ptr(x), L.ptr(taps), L.ptr(y), N, Cc, H, W, taps.shape[1], axis, 1 if transpose else 0, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (taps,) = ctx.saved_tensors
+        return FirReflectFn.apply(dy, taps, ctx.axis, not ctx.transpose), None, None, None
+
+
+class NoiseCutoutFn(torch.autograd.Function):
+    """y = (x + noise * sigma[n]) * cutout mask (reference src/utils/ada_aug.py:393-416); noise [N,C,H,W] / sigma [N] and cut [N,4] are draws. Linear in x up to the
+    noise term: the backward is the mask alone."""
+
+    @staticmethod
+    def forward(ctx, x, noise, sigma, cut):
+        x = _f32_image(x, "noise_cutout")
+        N, Cc, H, W = x.shape
+        noise = _c(noise.detach().float()) if noise is not None else None
+        sigma = _c(sigma.detach().float().reshape(N)) if sigma is not None else None
+        cut = _c(cut.detach().float().reshape(N, 4)) if cut is not None else None
+        ctx.save_for_backward(cut)
+        y = torch.empty_like(x)
+        L.call("sg_ada_noise_cutout", L.ptr(x), L.ptr(noise), L.ptr(sigma), L.ptr(cut), L.ptr(y), N, Cc, H, W, L.stream())
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (cut,) = ctx.saved_tensors
+        if cut is None:
+            return dy, None, None, None
+        return NoiseCutoutFn.apply(dy, None, None, cut), None, None, None

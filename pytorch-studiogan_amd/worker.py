@@ -63,6 +63,16 @@ def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
     return zs, ys
 
 
+def adapt_aa_p(aa_p, sign_sum, count, aa_target, aa_kimg):
+    """The ADA / APA overfitting heuristic (reference src/worker.py:478-482): the mean sign of the real logits over the interval is pushed towards aa_target by
+    moving the augmentation probability count / (aa_kimg * 1000) up or down, clipped to [0, 1]. sign_sum / count: the accumulated (and, under data
+    parallelism, all-reduced) statistic of functional.sign_count_."""
+    import numpy as np
+    heuristic = sign_sum / count
+    adjust = float(np.sign(heuristic - aa_target)) * count / (aa_kimg * 1000)
+    return min(1.0, max(aa_p + adjust, 0.0))
+
+
 class Worker:
     def __init__(self, Gen, Dis, z_dim, num_classes, batch_size, adv_loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999,
                  d_updates_per_step=5, g_updates_per_step=1, acml_steps=1, apply_g_ema=False, g_ema_decay=0.9999, g_ema_start=0,
@@ -272,14 +282,11 @@ class Worker:
                 dis_acml_loss = dis_acml_loss.detach()     # drop the graph now: its weight-bank slots become reusable (bank._free_graph_slot)
             self.d_optimizer.step(group=self.group)
             if (self.apply_apa or self.apply_ada) and self.aa_target is not None and current_step % self.aa_interval == 0:      # src/worker.py:478-487
-                import numpy as _np
                 import torch.distributed as _dist
                 if self.group is not None:
                     _dist.all_reduce(self.dis_sign_real, op=_dist.ReduceOp.SUM, group=self.group)
                 s_sum, s_cnt = (float(v) for v in self.dis_sign_real.tolist())
-                heuristic = s_sum / s_cnt
-                adjust = float(_np.sign(heuristic - self.aa_target)) * s_cnt / (self.aa_kimg * 1000)
-                self.aa_p = min(1.0, max(self.aa_p + adjust, 0.0))
+                self.aa_p = adapt_aa_p(self.aa_p, s_sum, s_cnt, self.aa_target, self.aa_kimg)
                 if self.apply_ada:
                     self.series_augment.p.copy_(torch.as_tensor(self.aa_p))
                 self.dis_sign_real.zero_()

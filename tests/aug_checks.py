@@ -428,3 +428,28 @@ def ada_adjoint_case(shape, dev, seed=0):
         M0 = M.clone()
         M0[:, :, 3] = 0
         adj(lambda a: F.ColorAffineFn.apply(a, M0), lambda a: F.ColorAffineFn.apply(a, M, True), u, torch.randn(shape, generator=g).to(dev))
+
+
+def ada_filter_adjoint_case(shape, dev, seed=0):
+    """sg_fir_reflect (both axes) and the cutout mask against their adjoints: <A u, v> == <u, A^T v>; the filter against F.pad(mode='reflect') + a grouped conv1d on the CPU"""
+    from studiogan_amd import functional as F
+    g = torch.Generator().manual_seed(seed)
+    N, C, H, W = shape
+    T = 43 if min(H, W) > 21 else 2 * ((min(H, W) - 1) // 2) - 1
+    taps = torch.randn(N, T, generator=g) * 0.2
+    u, v = torch.randn(shape, generator=g), torch.randn(shape, generator=g)
+    for axis in (0, 1):
+        Au = F.FirReflectFn.apply(u.to(dev), taps.to(dev), axis)
+        Atv = F.FirReflectFn.apply(v.to(dev), taps.to(dev), axis, True)
+        lhs, rhs = float((Au.double().cpu() * v.double()).sum()), float((u.double() * Atv.double().cpu()).sum())
+        assert abs(lhs - rhs) <= 2e-6 * float(Au.double().norm() * v.double().norm() + 1e-30), (axis, lhs, rhs)
+        p = T // 2
+        pad = [p, p, 0, 0] if axis == 0 else [0, 0, p, p]
+        xp = torch.nn.functional.pad(u.reshape(1, N * C, H, W), pad, mode="reflect")
+        w = taps.repeat_interleave(C, 0).reshape(N * C, 1, 1, T) if axis == 0 else taps.repeat_interleave(C, 0).reshape(N * C, 1, T, 1)
+        ref = torch.nn.functional.conv2d(xp, w, groups=N * C).reshape(N, C, H, W)
+        check(f"fir_reflect axis {axis} vs torch", Au, ref, 5e-6)
+    cut = torch.cat([torch.rand(N, 2, generator=g), torch.full((N, 2), 0.5)], 1)
+    Au = F.NoiseCutoutFn.apply(u.to(dev), None, None, cut.to(dev))
+    Atv = F.NoiseCutoutFn.apply(v.to(dev), None, None, cut.to(dev))
+    assert abs(float((Au.double().cpu() * v.double()).sum()) - float((u.double() * Atv.double().cpu()).sum())) <= 1e-6 * float(u.double().norm() * v.double().norm())

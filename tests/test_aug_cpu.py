@@ -94,6 +94,22 @@ def test_aug_host_mirrors_refuse_the_cpu_and_bad_arguments():
     assert diffaug.apply_diffaug(x, policy="") is x and cr.apply_cr_aug(x, flip=False, translation=False) is x       # diffaug.py:36, cr.py:18
 
 
+def test_ada_apa_heuristic_matches_the_reference_formula():
+    """worker.adapt_aa_p against the reference's lines (src/worker.py:478-482) evaluated literally with its tensor arithmetic"""
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd.worker import adapt_aa_p
+    rng = np.random.default_rng(0)
+    for _ in range(200):
+        aa_p, target, kimg = float(rng.uniform(0, 1)), float(rng.choice([0.6, 0.5, 0.9])), float(rng.choice([100, 500]))
+        cnt = float(rng.choice([64, 256, 1024]) * rng.integers(1, 9))
+        ssum = float(rng.integers(-int(cnt), int(cnt) + 1))
+        dis_sign_real = torch.tensor((ssum, cnt))
+        heuristic = (dis_sign_real[0] / dis_sign_real[1]).item()
+        adjust = np.sign(heuristic - target) * (dis_sign_real[1].item()) / (kimg * 1000)
+        ref = min(torch.as_tensor(1.), max(aa_p + adjust, torch.as_tensor(0.)))
+        assert abs(adapt_aa_p(aa_p, ssum, cnt, target, kimg) - float(ref)) <= 1e-7
+
+
 # ---- the kernel sources on the interpreter ---------------------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def installed():
@@ -178,6 +194,8 @@ def test_emulated_ada_pipeline_matches_reference_vectors(installed):
         AC.ada_case(case, torch.device("cpu"))
     AC.ada_adjoint_case((2, 3, 12, 10), torch.device("cpu"), 1)
     AC.ada_adjoint_case((3, 1, 9, 16), torch.device("cpu"), 2)
+    AC.ada_filter_adjoint_case((2, 3, 24, 26), torch.device("cpu"), 3)
+    AC.ada_filter_adjoint_case((2, 1, 9, 12), torch.device("cpu"), 4)
 
 
 def test_consistency_oracle_reproduces_the_reference_vectors():

@@ -131,7 +131,7 @@ def test_ada_pipeline_matches_reference_vectors(sg):
     """studiogan_amd.ada_aug.AdaAugment ('blit', 'geom', 'color', 'bgc'; RGB and one-channel images) fed the draws the REAL reference's AdaAugment made:
     output and image gradient (tests/golden/ada.npz)"""
     from oracle import make_golden_ada as MGD
-    for case in MGD.CASES:
+    for case in MGD.CASES[:7]:      # (the image-space filtering / noise / cutout cases: tests/test_wide_ada_gpu.py)
         AC.ada_case(case, DEV)
 
 
@@ -140,8 +140,6 @@ def test_ada_operators_adjoint_at_benchmark_size(sg):
     AC.ada_adjoint_case((256, 3, 32, 32), DEV, 2)
     AC.ada_adjoint_case((8, 1, 33, 47), DEV, 3)
     from studiogan_amd import ada_aug
-    with pytest.raises(NotImplementedError):
-        ada_aug.AdaAugment(imgfilter=1)
     aug = ada_aug.AdaAugment(**ada_aug.AUGPIPE["bgc"]).to(DEV)
     aug.p.copy_(torch.as_tensor(0.6))
     x = torch.rand(256, 3, 128, 128, device=DEV) * 2 - 1
