@@ -505,6 +505,11 @@ int sg_loss_ls_g(const float* fake, int B, float* loss, float* d_fake, sg_stream
  * features, d_fake = its gradient w.r.t. fake_h (real_h is detached by the caller). work: sg_fm_work_floats(C) floats. */
 int sg_fm_work_floats(int C);
 int sg_fm_loss(const float* real_h, const float* fake_h, int B, int C, float* work, float* loss, float* d_fake, sg_stream_t s);
+/* InfoGAN's Q heads (reference models/big_resnet.py:337-344,373-377; utils/losses.py:369-375 normal_nll_loss; worker.py:607-618): y = exp(x) and its backward
+ * dx = dy * y (the variance head); loss[0] = -mean_b sum_k [-0.5 log(2 pi var + 1e-6) - (x - mu)^2 / (2 var + 1e-6)] over [B][K] fp32 with d loss / d mu, d var. */
+int sg_exp_fwd(const float* x, float* y, long long n, sg_stream_t s);
+int sg_exp_bwd(const float* dy, const float* y, float* dx, long long n, sg_stream_t s);
+int sg_normal_nll(const float* x, const float* mu, const float* var, int B, int K, float* loss, float* dmu, float* dvar, sg_stream_t s);
 /* Adjoints the create_graph pass through SelfAttention needs next to the first-order entry points (R1 / gradient penalties on a discriminator with
  * attention: reference utils/losses.py:301-316,355-361 through utils/ops.py:83-103):
  *   sg_maxpool2_gather    y[q][c] = x[2x2 window of q][idx[q][c]][c]: the pooling with the argmax of sg_maxpool2_fwd held fixed (adjoint of sg_maxpool2_bwd)

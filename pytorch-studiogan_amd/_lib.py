@@ -220,6 +220,9 @@ _PROTOS = {
     "sg_loss_ls_g": [_vp, _i, _vp, _vp, _vp],
     "sg_fm_work_floats": [_i],                             # returns a count
     "sg_fm_loss": [_vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
+    "sg_exp_fwd": [_vp, _vp, _ll, _vp],
+    "sg_exp_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "sg_normal_nll": [_vp, _vp, _vp, _i, _i, _vp, _vp, _vp, _vp],
     "sg_maxpool2_gather": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_softmax_rows_bwd2": [_vp, _vp, _vp, _vp, _ll, _i, _vp],
     "sg_scale_by_ptr": [_i, _vp, _vp, _vp, _ll, _vp],

@@ -87,8 +87,23 @@ class Generator(nn.Module):
         self.chunk_size = z_dim // (self.num_blocks + 1)
         self.affine_input_dim = self.chunk_size
         assert self.z_dim % (self.num_blocks + 1) == 0, "z_dim should be divided by the number of blocks"
-        if getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("InfoGAN heads are outside the benchmarked hot path (SURVEY.md §8f)")
+        # InfoGAN: the codes ride behind z (reference src/utils/sample.py:113-118) and enter either through a mixing linear layer in front of the z chunks
+        # ("concat") or as one more conditioning vector of every conditional batch norm ("cBN") -- src/models/big_resnet.py:81-92,125-130
+        self.info_type = getattr(MODEL, "info_type", "N/A")
+        self.g_info_injection = getattr(MODEL, "g_info_injection", "N/A")
+        info_dim = 0
+        if self.info_type in ("discrete", "both"):
+            info_dim += MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c
+        if self.info_type in ("continuous", "both"):
+            info_dim += MODEL.info_num_conti_c
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                self.info_mix_linear = MODULES.g_linear(in_features=self.z_dim + info_dim, out_features=self.z_dim, bias=True)
+            elif self.g_info_injection == "cBN":
+                self.affine_input_dim += self.g_shared_dim
+                self.info_proj_linear = MODULES.g_linear(in_features=info_dim, out_features=self.g_shared_dim, bias=True)
+            else:
+                raise NotImplementedError(f"g_info_injection = {self.g_info_injection}")
 
         self.linear0 = MODULES.g_linear(in_features=self.chunk_size, out_features=self.in_dims[0] * self.bottom * self.bottom, bias=True)
         if self.g_cond_mtd != "W/O":
@@ -115,9 +130,15 @@ class Generator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, z, shared_label))
+        affine_list = []
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                z = self.info_mix_linear.forward_rt(z, slot)
+            else:
+                z, z_info = z[:, :self.z_dim], z[:, self.z_dim:]
+                affine_list.append(self.info_proj_linear.forward_rt(z_info, slot))
         zs = torch.split(z, self.chunk_size, 1)
         z0 = zs[0]
-        affine_list = []
         if self.g_cond_mtd != "W/O":
             if shared_label is None:
                 shared_label = self.shared(label)
@@ -284,5 +305,6 @@ class Discriminator(nn.Module):
             if nxt is not None:
                 h = bank.mark(h, nxt[bi])          # data parallelism: the backward's return to this point releases the gradients behind it
             h = ops.block_boundary(self, bi, h)
+        hw = h.shape[1] * h.shape[2]
         h = F.ReluSumFn.apply(h)
-        return apply_heads(self, h, label, slot, adc_fake)
+        return apply_heads(self, h, label, slot, adc_fake, hw=hw)

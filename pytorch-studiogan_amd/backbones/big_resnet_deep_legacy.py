@@ -237,5 +237,6 @@ class Discriminator(nn.Module):
             if nxt is not None:
                 h = bank.mark(h, nxt[bi])          # data parallelism: the backward's return to this point releases the gradients behind it
             h = ops.block_boundary(self, bi, h)
+        hw = h.shape[1] * h.shape[2]
         h = F.ReluSumFn.apply(h)
-        return apply_heads(self, h, label, slot, adc_fake)
+        return apply_heads(self, h, label, slot, adc_fake, hw=hw)

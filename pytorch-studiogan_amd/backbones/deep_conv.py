@@ -50,9 +50,22 @@ class Generator(nn.Module):
         self.mixed_precision = mixed_precision
         self.MODEL = MODEL
         self.affine_input_dim = 0
-        if getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("InfoGAN heads are outside the benchmarked hot path (SURVEY.md §8f)")
+        # InfoGAN (reference src/models/deep_conv.py:56-68,101-106; configs/CIFAR10/DCGAN-Info.yaml)
+        self.info_type = getattr(MODEL, "info_type", "N/A")
         self.g_info_injection = getattr(MODEL, "g_info_injection", "N/A")
+        info_dim = 0
+        if self.info_type in ("discrete", "both"):
+            info_dim += MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c
+        if self.info_type in ("continuous", "both"):
+            info_dim += MODEL.info_num_conti_c
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                self.info_mix_linear = MODULES.g_linear(in_features=self.z_dim + info_dim, out_features=self.z_dim, bias=True)
+            elif self.g_info_injection == "cBN":
+                self.affine_input_dim += self.z_dim
+                self.info_proj_linear = MODULES.g_linear(in_features=info_dim, out_features=self.z_dim, bias=True)
+            else:
+                raise NotImplementedError(f"g_info_injection = {self.g_info_injection}")
         if self.g_cond_mtd != "W/O" and self.g_cond_mtd == "cBN":
             self.affine_input_dim += self.num_classes
         self.linear0 = MODULES.g_linear(in_features=self.z_dim, out_features=self.in_dims[0] * 4 * 4, bias=True)
@@ -73,9 +86,16 @@ class Generator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, z))
-        affines = None
+        affine_list = []
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                z = self.info_mix_linear.forward_rt(z, slot)
+            else:
+                z, z_info = z[:, :self.z_dim], z[:, self.z_dim:]
+                affine_list.append(self.info_proj_linear.forward_rt(z_info, slot))
         if self.g_cond_mtd != "W/O":
-            affines = TF.one_hot(label, num_classes=self.num_classes).to(torch.float32)
+            affine_list.append(TF.one_hot(label, num_classes=self.num_classes).to(torch.float32))
+        affines = torch.cat(affine_list, 1) if len(affine_list) > 0 else None
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], 4, 4), dtype)
         for blocklist in self.blocks:
@@ -157,9 +177,9 @@ class Discriminator(nn.Module):
                     pending_relu = self.apply_d_sn
         if self.apply_d_sn:
             h = self.conv1.forward_nhwc(h, slot, in_relu=pending_relu)
-            h = F.ReluSumFn.apply(h)
         else:
             h = self.conv1.forward_nhwc(h, slot)
             h = self.bn1.forward_nhwc(h)
-            h = F.ReluSumFn.apply(h)
-        return apply_heads(self, h, label, slot, adc_fake)
+        hw = h.shape[1] * h.shape[2]
+        h = F.ReluSumFn.apply(h)
+        return apply_heads(self, h, label, slot, adc_fake, hw=hw)

@@ -13,8 +13,13 @@ HEADS = ("W/O", "PD", "AC", "2C", "D2DCE", "MH", "MD")
 def build_heads(self, MODULES, feat_dim, d_cond_mtd, aux_cls_type, d_embed_dim, num_classes, MODEL):
     if d_cond_mtd not in HEADS or aux_cls_type not in ("W/O", "N/A", "TAC", "ADC"):
         raise NotImplementedError(f"d_cond_mtd {d_cond_mtd} / aux_cls_type {aux_cls_type}")
-    if getattr(MODEL, "info_type", "N/A") != "N/A":
-        raise NotImplementedError("InfoGAN heads are outside the hot path (SURVEY.md §8f)")
+    # Q head network of InfoGAN (reference src/models/big_resnet.py:337-344; parameters owned by the GENERATOR's optimiser, src/config.py:501-512)
+    info_type = getattr(MODEL, "info_type", "N/A")
+    if info_type in ("discrete", "both"):
+        self.info_discrete_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c, bias=False)
+    if info_type in ("continuous", "both"):
+        self.info_conti_mu_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
+        self.info_conti_var_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
     if d_cond_mtd == "MH":
         self.linear1 = MODULES.d_linear(in_features=feat_dim, out_features=1 + num_classes, bias=True)
     elif d_cond_mtd == "MD":
@@ -46,10 +51,29 @@ def _embed(module, label, slot):
     return F.EmbeddingFn.apply(module.weight, label.reshape(-1))
 
 
-def apply_heads(self, h, label, slot, adc_fake=False):
-    """h: [B, C] = sum_hw relu(features). Returns the reference's 12-key dictionary."""
+INFO_PARAMS = ("info_discrete_linear", "info_conti_mu_linear", "info_conti_var_linear")      # reference src/config.py:346 MISC.info_params
+
+
+def apply_heads(self, h, label, slot, adc_fake=False, hw=None):
+    """h: [B, C] = sum_hw relu(features); hw: the number of positions summed (the Q heads read the MEAN feature, big_resnet.py:374-377).
+    Returns the reference's 12-key dictionary."""
     mtd, aux = self.d_cond_mtd, self.aux_cls_type
     embed = proxy = cls_output = mi_embed = mi_proxy = mi_cls_output = None
+    info_discrete_c_logits = info_conti_mu = info_conti_var = None
+    info_type = getattr(self.MODEL, "info_type", "N/A")
+    if info_type != "N/A":
+        if hw is None:
+            raise RuntimeError("apply_heads: the Q heads need the number of pooled positions (hw)")
+        inv = getattr(self, "_sg_info_inv", None)
+        if inv is None or inv.device != h.device or float(inv) != 1.0 / hw:
+            inv = torch.full((1,), 1.0 / hw, dtype=torch.float32, device=h.device)
+            self.__dict__["_sg_info_inv"] = inv
+        hm = F.ScalePtrFn.apply(h, inv)                          # h / (bottom_h * bottom_w)
+        if info_type in ("discrete", "both"):
+            info_discrete_c_logits = self.info_discrete_linear.forward_rt(hm, slot)
+        if info_type in ("continuous", "both"):
+            info_conti_mu = self.info_conti_mu_linear.forward_rt(hm, slot)
+            info_conti_var = F.ExpFn.apply(self.info_conti_var_linear.forward_rt(hm, slot))
     if mtd in ("W/O", "PD"):
         pd = mtd == "PD"
         adv_output = F.PDHeadFn.apply(h, self.linear1.master_weight, self.linear1.bias, self.embedding.master_weight if pd else None,
@@ -79,4 +103,4 @@ def apply_heads(self, h, label, slot, adc_fake=False):
                 mi_embed, mi_proxy = F.RowNormalizeFn.apply(mi_embed, 1e-12), F.RowNormalizeFn.apply(mi_proxy, 1e-12)
     return {"h": h, "adv_output": adv_output, "embed": embed, "proxy": proxy, "cls_output": cls_output, "label": label,
             "mi_embed": mi_embed, "mi_proxy": mi_proxy, "mi_cls_output": mi_cls_output,
-            "info_discrete_c_logits": None, "info_conti_mu": None, "info_conti_var": None}
+            "info_discrete_c_logits": info_discrete_c_logits, "info_conti_mu": info_conti_mu, "info_conti_var": info_conti_var}

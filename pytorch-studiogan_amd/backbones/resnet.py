@@ -69,9 +69,22 @@ class Generator(nn.Module):
         self.bottom = 4
         self.num_blocks = len(self.in_dims)
         self.affine_input_dim = 0
-        if getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("InfoGAN heads are outside the benchmarked hot path (SURVEY.md §8f)")
+        # InfoGAN (reference src/models/resnet.py:95-107,142-147): codes behind z, through a mixing layer ("concat") or as conditioning of the block norms ("cBN")
+        self.info_type = getattr(MODEL, "info_type", "N/A")
         self.g_info_injection = getattr(MODEL, "g_info_injection", "N/A")
+        info_dim = 0
+        if self.info_type in ("discrete", "both"):
+            info_dim += MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c
+        if self.info_type in ("continuous", "both"):
+            info_dim += MODEL.info_num_conti_c
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                self.info_mix_linear = MODULES.g_linear(in_features=self.z_dim + info_dim, out_features=self.z_dim, bias=True)
+            elif self.g_info_injection == "cBN":
+                self.affine_input_dim += self.z_dim
+                self.info_proj_linear = MODULES.g_linear(in_features=info_dim, out_features=self.z_dim, bias=True)
+            else:
+                raise NotImplementedError(f"g_info_injection = {self.g_info_injection}")
         self.linear0 = MODULES.g_linear(in_features=self.z_dim, out_features=self.in_dims[0] * self.bottom * self.bottom, bias=True)
         if self.g_cond_mtd != "W/O" and self.g_cond_mtd == "cBN":
             self.affine_input_dim += self.num_classes
@@ -94,9 +107,16 @@ class Generator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, z))
-        affines = None
+        affine_list = []
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                z = self.info_mix_linear.forward_rt(z, slot)
+            else:
+                z, z_info = z[:, :self.z_dim], z[:, self.z_dim:]
+                affine_list.append(self.info_proj_linear.forward_rt(z_info, slot))
         if self.g_cond_mtd != "W/O":
-            affines = TF.one_hot(label, num_classes=self.num_classes).to(torch.float32)
+            affine_list.append(TF.one_hot(label, num_classes=self.num_classes).to(torch.float32))
+        affines = torch.cat(affine_list, 1) if len(affine_list) > 0 else None
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
         act = ops.block_boundary(self, -1, act)

@@ -80,3 +80,49 @@ extern "C" int sg_fm_loss(const float* real_h, const float* fake_h, int B, int C
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- InfoGAN's Q-head losses (reference src/models/big_resnet.py:337-344,373-377, src/utils/losses.py:369-375, src/worker.py:607-618) -------------------------
+// sg_exp_fwd / _bwd: the continuous code's variance head, var = exp(linear(h)); dx = dy * y.
+// sg_normal_nll: nll = -mean_b sum_k [ -0.5 log(2 pi var + 1e-6) - (x - mu)^2 / (2 var + 1e-6) ] with the gradients w.r.t. mu and var from the same launch.
+__global__ __launch_bounds__(256) void k_exp_fwd(const float* x, float* y, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) y[i] = expf(x[i]);
+}
+__global__ __launch_bounds__(256) void k_exp_bwd(const float* dy, const float* y, float* dx, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) dx[i] = dy[i] * y[i];
+}
+extern "C" int sg_exp_fwd(const float* x, float* y, long long n, sg_stream_t s) {
+  SG_CHECK(x && y && n > 0, "sg_exp_fwd: bad args");
+  long long b = (n + 255) / 256; if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(k_exp_fwd, dim3((int)b), dim3(256), 0, (hipStream_t)s, x, y, n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int sg_exp_bwd(const float* dy, const float* y, float* dx, long long n, sg_stream_t s) {
+  SG_CHECK(dy && y && dx && n > 0, "sg_exp_bwd: bad args");
+  long long b = (n + 255) / 256; if (b > 4096) b = 4096;
+  hipLaunchKernelGGL(k_exp_bwd, dim3((int)b), dim3(256), 0, (hipStream_t)s, dy, y, dx, n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+__global__ __launch_bounds__(256) void k_normal_nll(const float* x, const float* mu, const float* var, int B, int K, float* loss, float* dmu, float* dvar) {
+  __shared__ float sm[4];
+  const float TWO_PI = 6.283185307179586f;
+  const int n = B * K;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float d = x[i] - mu[i], v = var[i];
+    const float a = v * TWO_PI + 1e-6f, b2 = v * 2.f + 1e-6f;
+    acc += -0.5f * logf(a) - d * d / b2;
+    // d nll / d mu = -(1/B) d logli / d mu,  d logli / d mu = 2 d / b2;  d logli / d var = -0.5 * 2 pi / a + 2 d^2 / b2^2
+    dmu[i] = -(2.f * d / b2) / (float)B;
+    dvar[i] = -(-0.5f * TWO_PI / a + 2.f * d * d / (b2 * b2)) / (float)B;
+  }
+  acc = block_sum_256(acc, sm);
+  if (threadIdx.x == 0) loss[0] = -acc / (float)B;
+}
+extern "C" int sg_normal_nll(const float* x, const float* mu, const float* var, int B, int K, float* loss, float* dmu, float* dvar, sg_stream_t s) {
+  SG_CHECK(x && mu && var && loss && dmu && dvar && B > 0 && K > 0, "sg_normal_nll: bad args");
+  hipLaunchKernelGGL(k_normal_nll, dim3(1), dim3(256), 0, (hipStream_t)s, x, mu, var, B, K, loss, dmu, dvar);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

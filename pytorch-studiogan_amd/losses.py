@@ -51,6 +51,11 @@ def g_ls(d_logit_fake, DDP=False):
     return F.GLossFn.apply(d_logit_fake, 3)
 
 
+def normal_nll_loss(x, mu, var):
+    """reference src/utils/losses.py:369-375 (InfoGAN's continuous codes)"""
+    return F.NormalNllFn.apply(x, mu, var)
+
+
 def feature_matching_loss(real_embed, fake_embed):
     """reference src/utils/losses.py:254-259 (LOSS.apply_fm, src/worker.py:588-596)"""
     return F.FeatureMatchingFn.apply(real_embed, fake_embed)

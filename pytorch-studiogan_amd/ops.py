@@ -393,7 +393,7 @@ def adopt(root, compute_dtype):
 class Modules:
     """Drop-in for `cfgs.MODULES` (reference src/config.py:435-495) built from the same MODEL flags."""
 
-    def __init__(self, apply_g_sn=False, apply_d_sn=False, g_cond_mtd="W/O", backbone="big_resnet", g_act_fn="ReLU", d_act_fn="ReLU"):
+    def __init__(self, apply_g_sn=False, apply_d_sn=False, g_cond_mtd="W/O", backbone="big_resnet", g_act_fn="ReLU", d_act_fn="ReLU", g_info_injection="N/A"):
         self.g_conv2d = snconv2d if apply_g_sn else conv2d
         self.g_deconv2d = sndeconv2d if apply_g_sn else deconv2d
         self.d_deconv2d = sndeconv2d if apply_d_sn else deconv2d
@@ -402,7 +402,7 @@ class Modules:
         self.d_conv2d = snconv2d if apply_d_sn else conv2d
         self.d_linear = snlinear if apply_d_sn else linear
         self.d_embedding = sn_embedding if apply_d_sn else embedding
-        if g_cond_mtd == "cBN" or backbone == "big_resnet":
+        if g_cond_mtd == "cBN" or g_info_injection == "cBN" or backbone == "big_resnet":      # src/config.py:458
             self.g_bn = ConditionalBatchNorm2d
         else:
             self.g_bn = batchnorm_2d

@@ -412,3 +412,35 @@ class Ema:
         sa, ta = self.source_arena(), self.target_arena()
         L.call("sg_ema_lerp", sa.data.data_ptr(), ta.data.data_ptr(), sa.numel, decay, L.stream())
         self.update_buffers(decay)
+
+
+class SmallAdam:
+    """torch.optim.Adam semantics for a HANDFUL of parameters that live inside another network's arena (InfoGAN's Q heads: they sit in the discriminator module and
+    are trained in the generator update with the generator's optimiser settings, reference src/config.py:501-512): one sg_adam_ema launch per parameter on its own
+    data / gradient views, moments of its own, one step count. The gradients are whatever the kernels accumulated into p.grad (views of the owning arena)."""
+
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.0):
+        self.params = [p for p in params]
+        assert self.params, "SmallAdam: no parameters"
+        self.lr, self.betas, self.eps, self.weight_decay = lr, tuple(betas), eps, weight_decay
+        self._m = [torch.zeros_like(p, dtype=torch.float32).reshape(-1) for p in self.params]
+        self._v = [torch.zeros_like(p, dtype=torch.float32).reshape(-1) for p in self.params]
+        self._t = 0
+
+    def zero_grad(self):
+        for p in self.params:
+            if p.grad is not None:
+                p.grad.zero_()
+
+    @torch.no_grad()
+    def step(self, group=None):
+        world = dist.get_world_size(group) if (group is not None and dist.is_available() and dist.is_initialized()) else 1
+        self._t += 1
+        for p, m, v in zip(self.params, self._m, self._v):
+            if p.grad is None:
+                continue
+            assert p.is_contiguous() and p.grad.is_contiguous() and p.dtype == torch.float32
+            if world > 1:
+                dist.all_reduce(p.grad, op=dist.ReduceOp.SUM, group=group)
+            L.call("sg_adam_ema", p.data_ptr(), p.grad.data_ptr(), m.data_ptr(), v.data_ptr(), None, p.numel(), self.lr, self.betas[0], self.betas[1], self.eps,
+                   self.weight_decay, self._t, 0.0, 1.0 / world, L.stream())

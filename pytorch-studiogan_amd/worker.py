@@ -84,8 +84,13 @@ class Worker:
                  apply_bcr=False, bcr_aug_type="bcr", real_lambda=10.0, fake_lambda=10.0, apply_zcr=False, radius=0.05, g_lambda=0.5, d_lambda=20.0,
                  apply_fm=False, fm_lambda=1.0, apply_wc=False, wc_bound=0.01,
                  apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4,
-                 apply_ada=False, ada_aug_type="bgc", ada_initial_augment_p=0.0, ada_target=0.6, ada_kimg=500, ada_interval=4):
+                 apply_ada=False, ada_aug_type="bgc", ada_initial_augment_p=0.0, ada_target=0.6, ada_kimg=500, ada_interval=4,
+                 info_type="N/A", info_num_discrete_c=0, info_dim_discrete_c=0, info_num_conti_c=0, infoGAN_loss_discrete_lambda=1.0,
+                 infoGAN_loss_conti_lambda=1.0):
         self.Gen, self.Dis = Gen, Dis
+        # InfoGAN (reference src/worker.py:220-224,508-512,607-618; src/utils/sample.py:113-118; src/config.py:501-512)
+        self.info_type, self.info_num_discrete_c, self.info_dim_discrete_c, self.info_num_conti_c = info_type, info_num_discrete_c, info_dim_discrete_c, info_num_conti_c
+        self.info_discrete_lambda, self.info_conti_lambda = infoGAN_loss_discrete_lambda, infoGAN_loss_conti_lambda
         self.apply_wc, self.wc_bound = apply_wc, wc_bound              # weight clipping after every discriminator update (src/worker.py:489-492)
         # adaptive pseudo augmentation (src/worker.py:82,127-134,273-274,285-289,478-487): real images swapped for fakes with probability aa_p, which follows
         # the sign statistic of the real logits towards aa_target
@@ -148,6 +153,16 @@ class Worker:
             sync_replicas(Dis, group)
         self.g_optimizer = FusedAdam(Gen.parameters(), lr=g_lr, betas=(beta1, beta2), eps=1e-6)
         self.d_optimizer = FusedAdam(Dis.parameters(), lr=d_lr, betas=(beta1, beta2), eps=1e-6)
+        # the Q heads live in the discriminator module but are trained by the GENERATOR's optimiser settings in the generator update (src/config.py:501-512):
+        # a small Adam of their own with the generator's hyper-parameters and step count. The discriminator's fused Adam still walks over them, with gradients
+        # that are exactly zero in its updates (they do not require grad there) and moments that therefore stay zero: an exact no-op.
+        self.info_modules, self.info_optimizer = [], None
+        if info_type != "N/A":
+            from .backbones.heads import INFO_PARAMS
+            from .optim import SmallAdam
+            self.info_modules = [getattr(Dis, n) for n in INFO_PARAMS if hasattr(Dis, n)]
+            assert self.info_modules, "info_type is set but the discriminator has no Q heads (build it with MODEL.info_type)"
+            self.info_optimizer = SmallAdam([p for m in self.info_modules for p in m.parameters()], lr=g_lr, betas=(beta1, beta2), eps=1e-6)
         import os as _os
         self._xchg = group is not None or _os.environ.get("SG_EXCHANGE_SELFTEST") == "1"
         if self._xchg:
@@ -184,15 +199,30 @@ class Worker:
     def _sample(self, injected, k):
         """(zs, fake_labels, zs_eps): reference src/utils/sample.py:69-88 -- zs_eps = zs + radius * N(0, I) when the latent consistency term is on.
         injected entries are (z, y) or (z, y, z_eps)."""
+        info = None
         if injected is not None:
             ent = injected[k]
             zs, ys = ent[0], ent[1]
             eps = ent[2] if len(ent) > 2 else None
+            info = ent[3] if len(ent) > 3 else None
         else:
             zs, ys = sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
             eps = None
         if self.apply_zcr and eps is None:
             eps = zs + self.radius * torch.randn(zs.shape[0], self.z_dim, device=zs.device)
+        self.info_codes = (None, None)
+        if self.info_type != "N/A":          # src/utils/sample.py:113-118: the codes ride behind z
+            B = zs.shape[0]
+            disc, conti = info if info is not None else (None, None)
+            if self.info_type in ("discrete", "both"):
+                if disc is None:
+                    disc = torch.randint(self.info_dim_discrete_c, (B, self.info_num_discrete_c), device=zs.device)
+                zs = torch.cat((zs, torch.nn.functional.one_hot(disc, self.info_dim_discrete_c).view(B, -1)), dim=1)
+            if self.info_type in ("continuous", "both"):
+                if conti is None:
+                    conti = torch.rand(B, self.info_num_conti_c, device=zs.device) * 2 - 1
+                zs = torch.cat((zs, conti), dim=1)
+            self.info_codes = (disc, conti)
         return zs, ys, (eps if self.apply_zcr else None)
 
     # -- src/worker.py:213-497 ------------------------------------------------------------------------------------
@@ -201,6 +231,8 @@ class Worker:
         make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
         toggle_grad(self.Gen, False)
         toggle_grad(self.Dis, True)
+        for m in self.info_modules:          # src/worker.py:220-224: the Q heads are not the discriminator's to train
+            toggle_grad(m, False)
         self.Gen.apply(untrack_bn_statistics)
         k = 0
         dis_acml_loss = None
@@ -301,11 +333,15 @@ class Worker:
         make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
         toggle_grad(self.Dis, False)
         toggle_grad(self.Gen, True)
+        for m in self.info_modules:          # src/worker.py:508-512
+            toggle_grad(m, True)
         self.Gen.apply(track_bn_statistics)
         k = 0
         gen_acml_loss = None
         for _ in range(self.n_g):
             self.g_optimizer.zero_grad()
+            if self.info_optimizer is not None:
+                self.info_optimizer.zero_grad()
             for micro in range(self.acml):
                 zs, fake_labels, zs_eps = self._sample(injected, k)
                 k += 1
@@ -331,6 +367,18 @@ class Worker:
                     real_images, real_labels = real_batches[k - 1]
                     real_dict = self.Dis(self.series_augment(real_images), real_labels)
                     gen_acml_loss = gen_acml_loss + self.fm_lambda * sg_losses.feature_matching_loss(real_dict["h"].detach(), fake_dict["h"])
+                if self.info_type in ("discrete", "both"):      # src/worker.py:607-615
+                    dim, disc = self.info_dim_discrete_c, self.info_codes[0]
+                    info_discrete_loss = None
+                    for c in range(self.info_num_discrete_c):
+                        term = sg_losses.CrossEntropyLoss()(fake_dict["info_discrete_c_logits"][:, c * dim: dim * (c + 1)], disc[:, c])
+                        info_discrete_loss = term if info_discrete_loss is None else info_discrete_loss + term
+                    self.info_discrete_loss = info_discrete_loss.detach()
+                    gen_acml_loss = gen_acml_loss + self.info_discrete_lambda * info_discrete_loss
+                if self.info_type in ("continuous", "both"):    # src/worker.py:616-618
+                    info_conti_loss = sg_losses.normal_nll_loss(self.info_codes[1], fake_dict["info_conti_mu"], fake_dict["info_conti_var"])
+                    self.info_conti_loss = info_conti_loss.detach()
+                    gen_acml_loss = gen_acml_loss + self.info_conti_lambda * info_conti_loss
                 if self.apply_zcr:       # src/worker.py:601-603: G's side of the latent CR pushes G(z) and G(z + eps) apart
                     gen_acml_loss = gen_acml_loss - self.g_lambda * sg_losses.l2_loss(fake_images, fake_images_eps)
                 gen_acml_loss = gen_acml_loss / self.acml
@@ -340,6 +388,8 @@ class Worker:
                 gen_acml_loss = gen_acml_loss.detach()
             # Adam and the EMA of the generator copy (src/worker.py:630-634,675-676) in one launch
             self.g_optimizer.step(ema=self.ema, iteration=current_step, group=self.group)
+            if self.info_optimizer is not None:
+                self.info_optimizer.step(group=self.group)
         return gen_acml_loss
 
     def adjust_topk(self):

@@ -453,3 +453,90 @@ def ada_filter_adjoint_case(shape, dev, seed=0):
     Au = F.NoiseCutoutFn.apply(u.to(dev), None, None, cut.to(dev))
     Atv = F.NoiseCutoutFn.apply(v.to(dev), None, None, cut.to(dev))
     assert abs(float((Au.double().cpu() * v.double()).sum()) - float((u.double() * Atv.double().cpu()).sum())) <= 1e-6 * float(u.double().norm() * v.double().norm())
+
+
+# ---- InfoGAN against the reference's vectors (tests/golden/info.npz, oracle/make_golden_info.py) -----------------------------------------------------------
+INFO_CASES = ["biggan32_info_cbn", "sngan32_info_concat", "sngan32_info_cbn", "dcgan32_info_cbn"]
+
+
+def info_case(tag, dev):
+    """studiogan_amd.worker.Worker(info_type=...) on the reference's InfoGAN networks (generator code injection "cBN" / "concat", discriminator Q heads): the
+    discriminator update (loss, every gradient, the Q heads untouched by its optimiser step), the generator update (adversarial + information loss, the gradients
+    of every generator parameter AND of the Q heads) and the Q heads after their Adam step with the generator's settings, against the REAL reference (fp32)."""
+    import importlib
+    import json
+    import types
+    from util import Collector, GOLDEN, hyper
+    from studiogan_amd import ops
+    from studiogan_amd.worker import Worker
+    z = np.load(os.path.join(GOLDEN, "info.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "info.json")))[tag]
+    y, B = meta["yaml"], meta["batch"]
+    M, Dt = y["MODEL"], y["DATA"]
+    MODEL = types.SimpleNamespace(info_type=M["info_type"], g_info_injection=M["g_info_injection"], info_num_discrete_c=M.get("info_num_discrete_c", "N/A"),
+                                  info_dim_discrete_c=M.get("info_dim_discrete_c", "N/A"), info_num_conti_c=M.get("info_num_conti_c", "N/A"))
+    bb = importlib.import_module("studiogan_amd.backbones." + M.get("backbone", "resnet"))
+    MOD = ops.Modules(apply_g_sn=M.get("apply_g_sn", False), apply_d_sn=M.get("apply_d_sn", False), g_cond_mtd=M.get("g_cond_mtd", "W/O"),
+                      backbone=M.get("backbone", "resnet"), g_info_injection=M["g_info_injection"])
+    G = bb.Generator(M.get("z_dim", 128), M.get("g_shared_dim", "N/A"), Dt["img_size"], M.get("g_conv_dim", 64), M.get("apply_attn", False),
+                     M.get("attn_g_loc", ["N/A"]), M.get("g_cond_mtd", "W/O"), Dt["num_classes"], "ortho", M.get("g_depth", "N/A"), False, MOD, MODEL).to(dev)
+    D = bb.Discriminator(Dt["img_size"], M.get("d_conv_dim", 64), M.get("apply_d_sn", False), M.get("apply_attn", False), M.get("attn_d_loc", ["N/A"]),
+                         M.get("d_cond_mtd", "W/O"), M.get("aux_cls_type", "W/O"), M.get("d_embed_dim", "N/A"), M.get("normalize_d_embed", False),
+                         Dt["num_classes"], "ortho", M.get("d_depth", "N/A"), False, MOD, MODEL).to(dev)
+    p = tag + "/"
+    compact = bool(meta.get("compact"))
+    if compact:          # initial state by formula (oracle/make_golden.py formula_state), large expected tensors as samples + norm
+        from oracle import make_golden as MG
+        G.load_state_dict({k: v.to(dev) for k, v in MG.formula_state({k: list(v.shape) for k, v in G.state_dict().items()}, meta["seeds"][0]).items()}, strict=True)
+        D.load_state_dict({k: v.to(dev) for k, v in MG.formula_state({k: list(v.shape) for k, v in D.state_dict().items()}, meta["seeds"][1]).items()}, strict=True)
+    else:
+        G.load_state_dict({k[len(p) + 7:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith(p + "G_init/")}, strict=True)
+        D.load_state_dict({k[len(p) + 7:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith(p + "D_init/")}, strict=True)
+    d_init = {k: v.detach().clone() for k, v in D.named_parameters()}
+
+    def exp(key):
+        """expected tensor, or (samples, norm) of a large one in a compact fixture"""
+        if key in z.files:
+            return torch.from_numpy(z[key])
+        from util import Sampled
+        return Sampled(torch.from_numpy(z[key + "#s"]), torch.tensor([0.0, float(z[key + "#n"][0])], dtype=torch.float64))
+
+    def amax(key):
+        return float(np.abs(z[key] if key in z.files else z[key + "#s"]).max())
+    opt = hyper(y)
+    Ls = y.get("LOSS", {})
+    w = Worker(G, D, opt["z_dim"], Dt["num_classes"], B, opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"], d_updates_per_step=1,
+               info_type=M["info_type"], info_num_discrete_c=M.get("info_num_discrete_c", 0), info_dim_discrete_c=M.get("info_dim_discrete_c", 0),
+               info_num_conti_c=M.get("info_num_conti_c", 0), infoGAN_loss_discrete_lambda=Ls.get("infoGAN_loss_discrete_lambda", 1.0),
+               infoGAN_loss_conti_lambda=Ls.get("infoGAN_loss_conti_lambda", 1.0))
+    ins = {k[len(p) + 3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith(p + "in/")}
+
+    def codes(side):
+        return tuple(torch.from_numpy(z[p + f"code_{side}_{kind}"]).to(dev) if p + f"code_{side}_{kind}" in z.files else None for kind in ("disc", "conti"))
+    C = Collector()
+    info_names = [k for k, _ in D.named_parameters() if k.startswith("info_")]
+    assert info_names
+    d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"], None, codes("d"))])
+    C.check("d_loss", d_loss, torch.from_numpy(z[p + "d_loss"]), 2e-4)
+    wide = compact           # full widths: ~1e6 ReLU units per layer, a handful within fp32 rounding of 0 -> l2 metric (tests/test_model_gpu.py)
+    dmax = max(amax(p + "D_grad/" + k) for k, _ in D.named_parameters())
+    for k, prm in D.named_parameters():
+        C.check("D_grad/" + k, prm.grad if prm.grad is not None else torch.zeros_like(prm), exp(p + "D_grad/" + k), 3e-3 if wide else 1e-3, floor=1e-2 * dmax, l2=wide)
+        if k in info_names:          # the Q heads are not the discriminator optimiser's to move (src/config.py:509-517): bit for bit where they were
+            assert torch.equal(prm.detach(), d_init[k]), k
+    # the generator side of the fixture ran on the discriminator AFTER its optimiser step: Adam's sign noise on near-zero gradients aside, take the reference's
+    if not compact:
+        with torch.no_grad():
+            for k, prm in D.named_parameters():
+                prm.copy_(torch.from_numpy(z[p + "D_after_d/" + k]).to(dev))
+    g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"], None, codes("g"))])
+    C.check("g_loss", g_loss, torch.from_numpy(z[p + "g_loss"]), 5e-3 if wide else 1e-3)
+    gmx = max(amax(p + "G_grad/" + k) for k, _ in G.named_parameters())
+    for k, prm in G.named_parameters():
+        C.check("G_grad/" + k, prm.grad, exp(p + "G_grad/" + k), 5e-2 if wide else 2e-2, floor=1e-2 * gmx, l2=wide)      # (wide: on OUR discriminator after its Adam step; measured 3e-3)
+    for k, prm in D.named_parameters():
+        if k in info_names:
+            e = exp(p + "Q_grad/" + k)
+            C.check("Q_grad/" + k, prm.grad, e, 2e-2 if wide else 1e-3, floor=1e-3 * amax(p + "Q_grad/" + k), l2=wide)
+            C.check("Q_after_g/" + k, prm, exp(p + "Q_after_g/" + k), 1e-3, abs_ok=2.5 * opt["g_lr"])
+    C.finish()

@@ -198,6 +198,31 @@ def test_emulated_ada_pipeline_matches_reference_vectors(installed):
     AC.ada_filter_adjoint_case((2, 1, 9, 12), torch.device("cpu"), 4)
 
 
+@needs_emu
+@pytest.mark.parametrize("tag", AC.INFO_CASES)
+def test_emulated_infogan_updates_match_reference_vectors(installed, tag):
+    """InfoGAN: generator code injection ("cBN" / "concat"), the discriminator's Q heads, the information losses and the Q heads' Adam with the generator's
+    settings, through the interpreted kernel sources against the REAL reference (tests/golden/info.npz)"""
+    if tag in ("sngan32_info_cbn", "dcgan32_info_cbn") and os.environ.get("SG_EMU_NET") != "1":
+        pytest.skip("SG_EMU_NET=1 runs the remaining InfoGAN fixtures through the interpreter (full-width DCGAN: ~40 s)")
+    AC.info_case(tag, torch.device("cpu"))
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_info_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
+    from oracle import make_golden_info as MGI
+    from util import GOLDEN
+    monkeypatch.setattr(MGI, "OUT", str(tmp_path / "info"))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    MGI.main()
+    a, b = np.load(os.path.join(GOLDEN, "info.npz")), np.load(tmp_path / "info.npz")
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    torch.set_num_threads(nt)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json
