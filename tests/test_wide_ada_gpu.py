@@ -1,8 +1,8 @@
 """GPU: the remaining stages of the ADA pipeline -- image-space filtering (per-image 4-band amplification filter over the reflect-padded image), additive noise,
 cutout ('filter', 'noise', 'cutout', 'bgcfnc' of the reference's ada_augpipe; csrc/ext/ada.hip sg_fir_reflect / sg_ada_noise_cutout) -- fed the draws the REAL
 reference's AdaAugment made, against its output and image gradient (tests/golden/ada.npz), and the operators against their adjoints at the benchmark's image size.
-These kernels were written after the round's GPU minutes were spent: their first GPU run is the driver's (they pass on the CPU interpreter,
-tests/test_aug_cpu.py::test_emulated_ada_pipeline_matches_reference_vectors); the file sorts last for that reason."""
+Written when the round's GPU minutes were nearly spent: green on the CPU interpreter first (tests/test_aug_cpu.py::test_emulated_ada_pipeline_matches_reference_vectors),
+then on the GPU in the round's last seconds (profiles/r05_pytest_wide_r.txt)."""
 import pytest
 import torch
 

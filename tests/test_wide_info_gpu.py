@@ -2,8 +2,8 @@
 models/resnet.py:95-107, models/deep_conv.py:56-68), the discriminators' Q heads (models/big_resnet.py:337-344,373-377), the information losses and toggling of
 src/worker.py:220-224,508-512,607-618 and the Q heads' Adam with the generator's settings (src/config.py:499-517), against vectors the REAL reference wrote
 (tests/golden/info.npz, oracle/make_golden_info.py): loss and every gradient of one discriminator and one generator update, the Q heads after the step.
-Written after the round's GPU minutes were spent: green on the CPU interpreter (tests/test_aug_cpu.py::test_emulated_infogan_updates_match_reference_vectors),
-first GPU run = the driver's; the file sorts last for that reason."""
+Written when the round's GPU minutes were nearly spent: green on the CPU interpreter first (tests/test_aug_cpu.py::test_emulated_infogan_updates_match_reference_vectors),
+then on the GPU in the round's last seconds (profiles/r05_pytest_wide_r.txt)."""
 import pytest
 import torch
 
