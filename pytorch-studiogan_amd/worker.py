@@ -14,10 +14,21 @@ from . import ops
 from .optim import FusedAdam, Ema, sync_replicas
 
 
-def toggle_grad(model, grad):
-    """reference src/utils/misc.py:190-216 (num_freeze_layers = -1)."""
-    for p in model.parameters():
-        p.requires_grad = grad
+def toggle_grad(model, grad, num_freeze_layers=-1):
+    """reference src/utils/misc.py:190-216. num_freeze_layers = N >= 0 (RUN.freezeD, src/worker.py:219): every parameter trainable except those of the first N
+    entries of `model.blocks` (fine-tuning with the discriminator's early blocks frozen; the weight bank folds gradients of the trainable layers only)."""
+    if num_freeze_layers == -1:
+        for p in model.parameters():
+            p.requires_grad = grad
+        return
+    assert grad, "cannot freeze the model when grad is False"
+    if hasattr(model, "in_dims"):
+        assert num_freeze_layers < len(model.in_dims), f"cannot freeze the {num_freeze_layers}th block > total {len(model.in_dims)} blocks."
+    for name, p in model.named_parameters():
+        p.requires_grad = True
+        for layer in range(num_freeze_layers):
+            if "blocks.{layer}".format(layer=layer) in name:
+                p.requires_grad = False
 
 
 def untrack_bn_statistics(m):
@@ -86,8 +97,9 @@ class Worker:
                  apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4,
                  apply_ada=False, ada_aug_type="bgc", ada_initial_augment_p=0.0, ada_target=0.6, ada_kimg=500, ada_interval=4,
                  info_type="N/A", info_num_discrete_c=0, info_dim_discrete_c=0, info_num_conti_c=0, infoGAN_loss_discrete_lambda=1.0,
-                 infoGAN_loss_conti_lambda=1.0):
+                 infoGAN_loss_conti_lambda=1.0, freezeD=-1):
         self.Gen, self.Dis = Gen, Dis
+        self.freezeD = freezeD          # RUN.freezeD (src/worker.py:219): the discriminator's first blocks stay fixed
         # InfoGAN (reference src/worker.py:220-224,508-512,607-618; src/utils/sample.py:113-118; src/config.py:501-512)
         self.info_type, self.info_num_discrete_c, self.info_dim_discrete_c, self.info_num_conti_c = info_type, info_num_discrete_c, info_dim_discrete_c, info_num_conti_c
         self.info_discrete_lambda, self.info_conti_lambda = infoGAN_loss_discrete_lambda, infoGAN_loss_conti_lambda
@@ -230,7 +242,7 @@ class Worker:
         """real_batches: list (n_d * acml) of (images NCHW fp32 in [-1,1], labels). injected: optional list of (z, y)."""
         make_GAN_trainable(self.Gen, self.Gen_ema, self.Dis)
         toggle_grad(self.Gen, False)
-        toggle_grad(self.Dis, True)
+        toggle_grad(self.Dis, True, self.freezeD)
         for m in self.info_modules:          # src/worker.py:220-224: the Q heads are not the discriminator's to train
             toggle_grad(m, False)
         self.Gen.apply(untrack_bn_statistics)

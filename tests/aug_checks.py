@@ -540,3 +540,37 @@ def info_case(tag, dev):
             C.check("Q_grad/" + k, prm.grad, e, 2e-2 if wide else 1e-3, floor=1e-3 * amax(p + "Q_grad/" + k), l2=wide)
             C.check("Q_after_g/" + k, prm, exp(p + "Q_after_g/" + k), 1e-3, abs_ok=2.5 * opt["g_lr"])
     C.finish()
+
+
+def freeze_d_case(name, dev, n_freeze=2):
+    """RUN.freezeD = N (reference src/utils/misc.py:190-216, src/worker.py:219): the first N discriminator blocks receive no gradient and do not move; the loss and
+    the gradients of every other parameter are those of the unfrozen update (the forward is the same): against the golden vectors of tests/golden/<name>.npz"""
+    from util import load_golden, sub, hyper, Collector
+    from test_model_gpu import build_from_yaml
+    from studiogan_amd.worker import Worker
+    fix, meta = load_golden(name)
+    y = meta["yaml"]
+    G, D = build_from_yaml(y, False, dev)
+    G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+    D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"], opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+               d_updates_per_step=1, freezeD=n_freeze)
+    ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+    exp = sub(fix, "exp/")
+    before = {k: v.detach().clone() for k, v in D.named_parameters()}
+    d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"])])
+    C = Collector()
+    C.check("d_loss0", d_loss, exp["d_loss0"], 2e-4)
+    dmax = max(float(v.abs().max()) for k, v in exp.items() if k.startswith("D_grad0/"))
+    frozen = 0
+    for k, prm in D.named_parameters():
+        if any(f"blocks.{i}." in k for i in range(n_freeze)):
+            frozen += 1
+            assert not prm.requires_grad and torch.equal(prm.detach(), before[k]), k
+            assert prm.grad is None or float(prm.grad.abs().max()) == 0.0, k
+        else:
+            C.check("D_grad0/" + k, prm.grad, exp["D_grad0/" + k], 1e-3, floor=1e-2 * dmax)
+            assert not torch.equal(prm.detach(), before[k]) or float(exp["D_grad0/" + k].abs().max()) == 0.0, k
+    assert frozen > 0
+    C.finish()

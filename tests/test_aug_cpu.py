@@ -223,6 +223,11 @@ def test_info_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch
     torch.set_num_threads(nt)
 
 
+@needs_emu
+def test_emulated_freeze_d(installed):
+    AC.freeze_d_case("sngan32", torch.device("cpu"), 2)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json

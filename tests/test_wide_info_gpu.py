@@ -15,3 +15,9 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("tag", AC.INFO_CASES)
 def test_infogan_updates_match_reference_vectors(sg, tag):
     AC.info_case(tag, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("name", ["sngan32", "biggan32"])
+def test_freeze_d(sg, name):
+    """RUN.freezeD (reference src/utils/misc.py:190-216): frozen blocks untouched, the rest as in the unfrozen update's golden vectors"""
+    AC.freeze_d_case(name, torch.device("cuda:0"), 2)
