@@ -518,6 +518,10 @@ int sg_normal_nll(const float* x, const float* mu, const float* var, int B, int 
 int sg_maxpool2_gather(int dtype, const void* x, int ldx, const uint8_t* idx, void* y, int ldy, int N, int H, int W, int C, sg_stream_t s);
 int sg_softmax_rows_bwd2(const float* P, const float* dP, const float* u, float* gP, long long rows, int cols, sg_stream_t s);
 int sg_scale_by_ptr(int dtype, const void* x, const float* sigma, void* y, long long n, sg_stream_t s);
+/* tanh of the generator's output in a create_graph pass (latent optimisation, reference utils/losses.py:278-298): t = dy * (1 - y^2) and its derivative with
+ * respect to y contracted with g: out = -2 g dy y (fp32) */
+int sg_tanh_bwd(const float* dy, const float* y, float* t, long long n, sg_stream_t s);
+int sg_tanh_bwd2(const float* g, const float* dy, const float* y, float* out, long long n, sg_stream_t s);
 /* Weight clipping (reference worker.py:489-492, LOSS.apply_wc): p[i] = clamp(p[i], lo, hi) over a flat fp32 parameter buffer, one pass.
  * Adaptive pseudo augmentation (reference utils/apa_aug.py:10-21): out[n] = flag[n] ? a[n] : b[n] for N rows of `row` floats (a = fake, b = real images).
  * The ADA / APA heuristic's accumulator (worker.py:285-289,478-481): acc[0] += sum_b sign(logit[b]), acc[1] += B, without a host round trip. */

@@ -226,6 +226,8 @@ _PROTOS = {
     "sg_maxpool2_gather": [_i, _vp, _i, _vp, _vp, _i, _i, _i, _i, _i, _vp],
     "sg_softmax_rows_bwd2": [_vp, _vp, _vp, _vp, _ll, _i, _vp],
     "sg_scale_by_ptr": [_i, _vp, _vp, _vp, _ll, _vp],
+    "sg_tanh_bwd": [_vp, _vp, _vp, _ll, _vp],
+    "sg_tanh_bwd2": [_vp, _vp, _vp, _vp, _ll, _vp],
     "sg_clamp_flat": [_vp, _ll, _f, _f, _vp],
     "sg_select_rows": [_vp, _vp, _vp, _vp, _i, _ll, _vp],
     "sg_sign_count": [_vp, _i, _vp, _vp],

@@ -71,3 +71,26 @@ extern "C" int sg_scale_by_ptr(int dtype, const void* x, const float* sigma, voi
   SG_LAUNCH_CHECK();
   return 0;
 }
+
+// ---- tanh of the generator's output image in a create_graph pass (latent optimisation, reference src/utils/losses.py:278-298: the gradient of D(G(z)) with
+// respect to z is itself differentiated) -- fp32 NCHW:  sg_tanh_bwd  t = dy * (1 - y^2)      sg_tanh_bwd2  out = -2 g dy y  (d t / d y contracted with g)
+__global__ __launch_bounds__(256) void k_tanh_bwd(const float* dy, const float* y, float* t, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) { const float v = y[i]; t[i] = dy[i] * (1.f - v * v); }
+}
+__global__ __launch_bounds__(256) void k_tanh_bwd2(const float* g, const float* dy, const float* y, float* out, long long n) {
+  for (long long i = blockIdx.x * 256ll + threadIdx.x; i < n; i += (long long)gridDim.x * 256) out[i] = -2.f * g[i] * dy[i] * y[i];
+}
+extern "C" int sg_tanh_bwd(const float* dy, const float* y, float* t, long long n, sg_stream_t s) {
+  SG_CHECK(dy && y && t && n > 0, "sg_tanh_bwd: bad args");
+  long long b = (n + 255) / 256; if (b > 16384) b = 16384;
+  hipLaunchKernelGGL(k_tanh_bwd, dim3((int)b), dim3(256), 0, (hipStream_t)s, dy, y, t, n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int sg_tanh_bwd2(const float* g, const float* dy, const float* y, float* out, long long n, sg_stream_t s) {
+  SG_CHECK(g && dy && y && out && n > 0, "sg_tanh_bwd2: bad args");
+  long long b = (n + 255) / 256; if (b > 16384) b = 16384;
+  hipLaunchKernelGGL(k_tanh_bwd2, dim3((int)b), dim3(256), 0, (hipStream_t)s, g, dy, y, out, n);
+  SG_LAUNCH_CHECK();
+  return 0;
+}

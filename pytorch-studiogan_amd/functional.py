@@ -325,7 +325,9 @@ class NhwcToNchwFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, dy):
-        _first_order_only("NhwcToNchwFn")
+        if torch.is_grad_enabled():        # create_graph=True (latent optimisation: d D(G(z)) / dz is differentiated again): stay on differentiable operators
+            t = TanhGradFn.apply(dy, ctx.saved_tensors[0]) if ctx.apply_tanh else dy
+            return NchwToNhwcFn.apply(t, ctx.in_dtype, ctx.ld), None, None
         dy = _c(dy.float())
         N, Cc, H, W = dy.shape
         y = ctx.saved_tensors[0] if ctx.apply_tanh else None
@@ -333,6 +335,32 @@ class NhwcToNchwFn(torch.autograd.Function):
         dx = (torch.zeros if ld > Cc else torch.empty)((N, H, W, ld), dtype=ctx.in_dtype, device=dy.device)
         L.call("sg_nchw_grad_to_nhwc", L.dt(ctx.in_dtype), L.ptr(dy), L.ptr(y), L.ptr(dx), N, Cc, H, W, ld, 1 if ctx.apply_tanh else 0, L.stream())
         return dx, None, None
+
+
+class TanhGradFn(torch.autograd.Function):
+    """t = dy * (1 - y^2) with y = tanh(x) the forward's OUTPUT (so its gradient re-enters the producing node): the tanh backward as a differentiable operator"""
+
+    @staticmethod
+    def forward(ctx, dy, y):
+        dy, y = _c(dy.float()), _c(y.float())
+        t = torch.empty_like(dy)
+        L.call("sg_tanh_bwd", L.ptr(dy), L.ptr(y), L.ptr(t), dy.numel(), L.stream())
+        ctx.save_for_backward(dy, y)
+        return t
+
+    @staticmethod
+    def backward(ctx, g):
+        _first_order_only("TanhGradFn")
+        dy, y = ctx.saved_tensors
+        g = _c(g.float())
+        g_dy = g_y = None
+        if ctx.needs_input_grad[0]:
+            g_dy = torch.empty_like(g)
+            L.call("sg_tanh_bwd", L.ptr(g), L.ptr(y), L.ptr(g_dy), g.numel(), L.stream())
+        if ctx.needs_input_grad[1]:
+            g_y = torch.empty_like(g)
+            L.call("sg_tanh_bwd2", L.ptr(g), L.ptr(dy), L.ptr(y), L.ptr(g_y), g.numel(), L.stream())
+        return g_dy, g_y
 
 
 class ConvertFn(torch.autograd.Function):
@@ -844,13 +872,17 @@ class LinearFn(torch.autograd.Function):
         gemm_raw(L.F32, bank.w_f32(slot, rt), 0, K, x, 0, K, y, rt.rows, rt.rows, B, K, bias=b)
         ctx.save_for_backward(x)
         ctx.rt, ctx.slot, ctx.bias = rt, slot, bias
+        ctx.weight = weight      # the master parameter: only handed on to LinearDgradFn so the second-order graph reaches it
         return y
 
     @staticmethod
     def backward(ctx, dy):
-        _first_order_only("LinearFn")
         (x,) = ctx.saved_tensors
         rt, slot = ctx.rt, ctx.slot
+        if torch.is_grad_enabled():      # create_graph=True: the data gradient as a differentiable operator; parameter gradients of this first pass are not wanted
+            if _param_grad_wanted(ctx.weight, ctx.bias):
+                raise NotImplementedError("create_graph=True is supported for input gradients only (gradient penalties, latent optimisation)")
+            return (LinearDgradFn.apply(dy, ctx.weight, rt, slot) if ctx.needs_input_grad[0] else None), None, None, None, None, None
         bank = rt.bank()
         dy = _c(dy.float())
         B, K = x.shape
@@ -861,12 +893,47 @@ class LinearFn(torch.autograd.Function):
             # dx[b][k] = sum_o dy[b][o] W[o][k] : P(i=k, red=o) = W stored [o][k] -> row-contiguous form
             gemm_dgrad_rows(bank.w_f32(slot, rt), dy, dx, B, K, O)
         if ctx.needs_input_grad[1]:
-            # dW[o][k] = sum_b dy[b][o] x[b][k]
-            gemm_raw(L.F32, x, 1, K, dy, 1, O, bank.dwt(slot, rt), K, K, O, B)
+            # dW[o][k] += sum_b dy[b][o] x[b][k]  (accumulated into the slot's zero-initialised scratch: in a pass that follows a create_graph pass through
+            # the same forward -- latent optimisation -- LinearDgradFn.backward has already put its share there)
+            dw = bank.dwt(slot, rt)
+            gemm_raw(L.F32, x, 1, K, dy, 1, O, dw, K, K, O, B, res=dw, ldr=K)
         if ctx.bias is not None and ctx.needs_input_grad[2]:
             g = ensure_grad(ctx.bias)
             L.call("sg_colsum", L.F32, L.ptr(dy), O, None, 0, B, O, L.ptr(g), 1.0, L.stream())
         return dx, None, None, None, None, None
+
+
+class LinearDgradFn(torch.autograd.Function):
+    """dx = dy W_sn: LinearFn's data gradient as a differentiable operator (second-order pass through a generator: latent optimisation, reference
+    src/utils/losses.py:278-298). Linear in dy and in W: d/d(dy) = t W_sn^T (the forward without bias), d/dW = dy^T t into the bank's scratch."""
+
+    @staticmethod
+    def forward(ctx, dy, weight, rt, slot):
+        dy = _c(dy.float())
+        B, O = dy.shape
+        assert O == rt.rows
+        ctx.save_for_backward(dy)
+        ctx.rt, ctx.slot = rt, slot
+        dx = torch.empty((B, rt.cols), dtype=torch.float32, device=dy.device)
+        gemm_dgrad_rows(rt.bank().w_f32(slot, rt), dy, dx, B, rt.cols, O)
+        return dx
+
+    @staticmethod
+    def backward(ctx, ddx):
+        (dy,) = ctx.saved_tensors
+        rt, slot = ctx.rt, ctx.slot
+        bank = rt.bank()
+        t = _c(ddx.float())
+        B, K = t.shape
+        O = rt.rows
+        g_dy = None
+        if ctx.needs_input_grad[0]:
+            g_dy = torch.empty((B, O), dtype=torch.float32, device=t.device)
+            gemm_raw(L.F32, bank.w_f32(slot, rt), 0, K, t, 0, K, g_dy, O, O, B, K)
+        if ctx.needs_input_grad[1]:
+            dw = bank.dwt(slot, rt)
+            gemm_raw(L.F32, t, 1, K, dy, 1, O, dw, K, K, O, B, res=dw, ldr=K)      # dW[o][k] += sum_b dy[b][o] t[b][k]
+        return g_dy, None, None, None
 
 
 class CbnAffineFn(torch.autograd.Function):

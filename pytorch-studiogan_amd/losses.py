@@ -51,6 +51,26 @@ def g_ls(d_logit_fake, DDP=False):
     return F.GLossFn.apply(d_logit_fake, 3)
 
 
+def latent_optimise(zs, fake_labels, generator, discriminator, batch_size, lo_rate, lo_steps, lo_alpha, lo_beta, eval, cal_trsp_cost, device):
+    """Latent optimisation of LOGAN, reference src/utils/losses.py:278-298 (called from src/utils/sample.py:123-135 when LOSS.apply_lo): one natural-gradient-like
+    step of z along d D(G(z)) / dz, taken WITH a graph (cal_deriv: create_graph=True) so that the transport cost and the images of the moved latents back-propagate
+    through it -- the create_graph pass runs through the generator's and the discriminator's differentiable data-gradient operators (functional.LinearDgradFn,
+    ConvDgradFn, BNBwdFn, TanhGradFn, ...). The arithmetic on the [B, z_dim] latents is torch's, as in the reference. Like the reference, the function returns from
+    inside its loop: one step is taken whatever lo_steps says (>= 2)."""
+    for step in range(lo_steps - 1):
+        drop_mask = (torch.FloatTensor(batch_size, 1).uniform_() > 1 - lo_rate).to(device)
+        zs = zs.detach().requires_grad_(True)
+        fake_images = generator(zs, fake_labels, eval=eval)
+        fake_dict = discriminator(fake_images, fake_labels, eval=eval)
+        z_grads = cal_deriv(inputs=zs, outputs=fake_dict["adv_output"], device=device)
+        z_grads_norm = torch.unsqueeze((z_grads.norm(2, dim=1) ** 2), dim=1)
+        delta_z = lo_alpha * z_grads / (lo_beta + z_grads_norm)
+        zs = torch.clamp(zs + drop_mask * delta_z, -1.0, 1.0)
+        trsf_cost = (delta_z.norm(2, dim=1) ** 2).mean() if cal_trsp_cost else None
+        return zs, trsf_cost
+    return zs, None
+
+
 def normal_nll_loss(x, mu, var):
     """reference src/utils/losses.py:369-375 (InfoGAN's continuous codes)"""
     return F.NormalNllFn.apply(x, mu, var)

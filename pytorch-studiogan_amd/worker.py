@@ -97,8 +97,13 @@ class Worker:
                  apply_apa=False, apa_initial_augment_p=0.0, apa_target=0.6, apa_kimg=500, apa_interval=4,
                  apply_ada=False, ada_aug_type="bgc", ada_initial_augment_p=0.0, ada_target=0.6, ada_kimg=500, ada_interval=4,
                  info_type="N/A", info_num_discrete_c=0, info_dim_discrete_c=0, info_num_conti_c=0, infoGAN_loss_discrete_lambda=1.0,
-                 infoGAN_loss_conti_lambda=1.0, freezeD=-1):
+                 infoGAN_loss_conti_lambda=1.0, freezeD=-1, apply_lo=False, lo_rate=0.8, lo_steps4train=2, lo_alpha=0.9, lo_beta=0.1, lo_lambda=0.1,
+                 z_prior="gaussian"):
         self.Gen, self.Dis = Gen, Dis
+        # latent optimisation (LOGAN; reference src/utils/sample.py:123-135, src/worker.py:319-321,598-599): z takes one step along d D(G(z)) / dz before the
+        # images are generated; the transport cost of that step joins both losses
+        self.apply_lo, self.lo_rate, self.lo_steps, self.lo_alpha, self.lo_beta, self.lo_lambda = apply_lo, lo_rate, lo_steps4train, lo_alpha, lo_beta, lo_lambda
+        self.z_prior = z_prior
         self.freezeD = freezeD          # RUN.freezeD (src/worker.py:219): the discriminator's first blocks stay fixed
         # InfoGAN (reference src/worker.py:220-224,508-512,607-618; src/utils/sample.py:113-118; src/config.py:501-512)
         self.info_type, self.info_num_discrete_c, self.info_dim_discrete_c, self.info_num_conti_c = info_type, info_num_discrete_c, info_dim_discrete_c, info_num_conti_c
@@ -183,7 +188,7 @@ class Worker:
             self.g_optimizer.attach(Gen)
             self.d_optimizer.attach(Dis)
         # update procedures with a create_graph pass inside keep the whole exchange in step()
-        self._plain_d_update = not (apply_gp or apply_r1_reg or apply_maxgp or apply_dra)
+        self._plain_d_update = not (apply_gp or apply_r1_reg or apply_maxgp or apply_dra or apply_lo)
         self.Gen_ema, self.ema = None, None
         if apply_g_ema:
             self.Gen_ema = copy.deepcopy(Gen)
@@ -219,6 +224,10 @@ class Worker:
             info = ent[3] if len(ent) > 3 else None
         else:
             zs, ys = sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
+            if self.z_prior == "uniform":          # src/utils/sample.py:75-76 (drawn on the CPU generator like the reference)
+                zs = torch.FloatTensor(self.batch_size, self.z_dim).uniform_(-1.0, 1.0).to(self.device)
+            elif self.z_prior != "gaussian":
+                raise NotImplementedError(self.z_prior)
             eps = None
         if self.apply_zcr and eps is None:
             eps = zs + self.radius * torch.randn(zs.shape[0], self.z_dim, device=zs.device)
@@ -235,6 +244,11 @@ class Worker:
                     conti = torch.rand(B, self.info_num_conti_c, device=zs.device) * 2 - 1
                 zs = torch.cat((zs, conti), dim=1)
             self.info_codes = (disc, conti)
+        self.trsp_cost = None
+        if self.apply_lo:                    # src/utils/sample.py:123-135
+            zs, self.trsp_cost = sg_losses.latent_optimise(zs=zs, fake_labels=ys, generator=self.Gen, discriminator=self.Dis, batch_size=zs.shape[0],
+                                                           lo_rate=self.lo_rate, lo_steps=self.lo_steps, lo_alpha=self.lo_alpha, lo_beta=self.lo_beta, eval=False,
+                                                           cal_trsp_cost=True, device=self.device)
         return zs, ys, (eps if self.apply_zcr else None)
 
     # -- src/worker.py:213-497 ------------------------------------------------------------------------------------
@@ -284,6 +298,8 @@ class Worker:
                         dis_acml_loss = dis_acml_loss + self.tac_dis_lambda * self.cond_loss_mi(**fake_dict)
                     elif self.aux_cls_type == "ADC":
                         dis_acml_loss = dis_acml_loss + self.cond_lambda * self.cond_loss(**fake_dict)
+                if self.apply_lo:        # src/worker.py:319-321
+                    dis_acml_loss = dis_acml_loss + self.lo_lambda * self.trsp_cost
                 if self.apply_cr:        # src/worker.py:325-336: the real batch's second view must score like the first
                     real_prl_dict = self.Dis(self.parallel_augment(real_images), real_labels)
                     dis_acml_loss = dis_acml_loss + self.cr_lambda * self._consistency(real_dict, real_prl_dict)
@@ -379,6 +395,8 @@ class Worker:
                     real_images, real_labels = real_batches[k - 1]
                     real_dict = self.Dis(self.series_augment(real_images), real_labels)
                     gen_acml_loss = gen_acml_loss + self.fm_lambda * sg_losses.feature_matching_loss(real_dict["h"].detach(), fake_dict["h"])
+                if self.apply_lo:        # src/worker.py:598-599
+                    gen_acml_loss = gen_acml_loss + self.lo_lambda * self.trsp_cost
                 if self.info_type in ("discrete", "both"):      # src/worker.py:607-615
                     dim, disc = self.info_dim_discrete_c, self.info_codes[0]
                     info_discrete_loss = None
@@ -394,7 +412,7 @@ class Worker:
                 if self.apply_zcr:       # src/worker.py:601-603: G's side of the latent CR pushes G(z) and G(z + eps) apart
                     gen_acml_loss = gen_acml_loss - self.g_lambda * sg_losses.l2_loss(fake_images, fake_images_eps)
                 gen_acml_loss = gen_acml_loss / self.acml
-                if self._xchg and micro == self.acml - 1:
+                if self._xchg and not self.apply_lo and micro == self.acml - 1:      # (a create_graph pass inside the update keeps the whole exchange in step())
                     self.g_optimizer.arm_exchange(self.group)
                 gen_acml_loss.backward()
                 gen_acml_loss = gen_acml_loss.detach()

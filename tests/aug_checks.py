@@ -52,7 +52,7 @@ class Replayed:
             def __init__(self, *size):
                 self.size = size
 
-            def uniform_(self, a, b):
+            def uniform_(self, a=0.0, b=1.0):
                 return nxt(self.size, "cpu")
         torch.rand, torch.randint, torch.FloatTensor, torch.randn = rand, randint, FT, rand
         return self
@@ -573,4 +573,55 @@ def freeze_d_case(name, dev, n_freeze=2):
             C.check("D_grad0/" + k, prm.grad, exp["D_grad0/" + k], 1e-3, floor=1e-2 * dmax)
             assert not torch.equal(prm.detach(), before[k]) or float(exp["D_grad0/" + k].abs().max()) == 0.0, k
     assert frozen > 0
+    C.finish()
+
+
+# ---- LOGAN's latent optimisation against the reference's vectors (tests/golden/logan.npz, oracle/make_golden_logan.py) ----------------------------------------
+def logan_case(dev):
+    """studiogan_amd.worker.Worker(apply_lo=True): one discriminator and one generator update of the LOGAN configuration (unconditional ResNet generator with batch
+    norm, spectral-norm discriminator, uniform prior) whose losses back-propagate THROUGH d D(G(z)) / dz -- the create_graph pass runs through the generator's
+    differentiable data-gradient operators (LinearDgradFn, ConvDgradFn, BNBwdFn, TanhGradFn) and the discriminator's: moved latents, transport cost, loss and every
+    gradient against the REAL reference's double backward (fp32)."""
+    import importlib
+    import json
+    import types
+    from util import Collector, GOLDEN, hyper
+    from studiogan_amd import ops
+    from studiogan_amd.worker import Worker
+    z = np.load(os.path.join(GOLDEN, "logan.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "logan.json")))
+    y = meta["yaml"]
+    M, Dt, Ls = y["MODEL"], y["DATA"], y["LOSS"]
+    MODEL = types.SimpleNamespace(info_type="N/A", g_info_injection="N/A")
+    bb = importlib.import_module("studiogan_amd.backbones.resnet")
+    MOD = ops.Modules(apply_g_sn=False, apply_d_sn=True, g_cond_mtd="W/O", backbone="resnet")
+    G = bb.Generator(M["z_dim"], "N/A", Dt["img_size"], M["g_conv_dim"], False, ["N/A"], "W/O", Dt["num_classes"], "ortho", "N/A", False, MOD, MODEL).to(dev)
+    D = bb.Discriminator(Dt["img_size"], M["d_conv_dim"], True, False, ["N/A"], "W/O", "W/O", "N/A", False, Dt["num_classes"], "ortho", "N/A", False, MOD, MODEL).to(dev)
+    G.load_state_dict({k[7:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("G_init/")}, strict=True)
+    D.load_state_dict({k[7:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("D_init/")}, strict=True)
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], Dt["num_classes"], y["OPTIMIZATION"]["batch_size"], "hinge", opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+               d_updates_per_step=1, apply_lo=True, lo_rate=Ls["lo_rate"], lo_steps4train=Ls["lo_steps4train"], lo_alpha=Ls["lo_alpha"], lo_beta=Ls["lo_beta"],
+               lo_lambda=Ls["lo_lambda"], z_prior="uniform")
+    ins = {k[3:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith("in/")}
+    d_init = {k: v.detach().clone() for k, v in D.named_parameters()}
+    C = Collector()
+    s0, s1 = meta["mask_seeds"]
+    with Replayed([torch.from_numpy(z[f"mask_draw/{s0}"])]):
+        d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"])])
+    C.check("d transport cost", w.trsp_cost, torch.from_numpy(z["d_trsp_cost"]), 2e-4)
+    C.check("d_loss", d_loss, torch.from_numpy(z["d_loss"]), 2e-4)
+    dmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("D_grad/"))
+    for k, prm in D.named_parameters():
+        C.check("D_grad/" + k, prm.grad, torch.from_numpy(z["D_grad/" + k]), 1e-3, floor=1e-2 * dmax)
+    with torch.no_grad():           # the generator side of the fixture ran on the un-stepped discriminator
+        for k, prm in D.named_parameters():
+            prm.copy_(d_init[k])
+    with Replayed([torch.from_numpy(z[f"mask_draw/{s1}"])]):
+        g_loss = w.train_generator(0, [(ins["z1"], ins["fl1"])])
+    C.check("g transport cost", w.trsp_cost, torch.from_numpy(z["g_trsp_cost"]), 1e-3)
+    C.check("g_loss", g_loss, torch.from_numpy(z["g_loss"]), 1e-3)
+    gmx = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("G_grad/"))
+    for k, prm in G.named_parameters():
+        C.check("G_grad/" + k, prm.grad, torch.from_numpy(z["G_grad/" + k]), 2e-2, floor=1e-2 * gmx)
     C.finish()

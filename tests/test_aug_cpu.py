@@ -228,6 +228,28 @@ def test_emulated_freeze_d(installed):
     AC.freeze_d_case("sngan32", torch.device("cpu"), 2)
 
 
+@needs_emu
+def test_emulated_logan_latent_optimisation(installed):
+    """LOGAN: both updates back-propagate through d D(G(z)) / dz (the create_graph pass through the GENERATOR: LinearDgradFn, ConvDgradFn with the fused upsampling,
+    batch-norm double backward, TanhGradFn) against the REAL reference's double backward (tests/golden/logan.npz)"""
+    AC.logan_case(torch.device("cpu"))
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_logan_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
+    from oracle import make_golden_logan as MGL
+    from util import GOLDEN
+    monkeypatch.setattr(MGL, "OUT", str(tmp_path / "logan"))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    MGL.main()
+    a, b = np.load(os.path.join(GOLDEN, "logan.npz")), np.load(tmp_path / "logan.npz")
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    torch.set_num_threads(nt)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json

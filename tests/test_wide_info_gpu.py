@@ -21,3 +21,9 @@ def test_infogan_updates_match_reference_vectors(sg, tag):
 def test_freeze_d(sg, name):
     """RUN.freezeD (reference src/utils/misc.py:190-216): frozen blocks untouched, the rest as in the unfrozen update's golden vectors"""
     AC.freeze_d_case(name, torch.device("cuda:0"), 2)
+
+
+def test_logan_latent_optimisation(sg):
+    """LOGAN (reference configs/CIFAR10/LOGAN.yaml; src/utils/losses.py:278-298): written after the round's last GPU second -- green on the CPU interpreter
+    (tests/test_aug_cpu.py::test_emulated_logan_latent_optimisation), first GPU run = the driver's"""
+    AC.logan_case(torch.device("cuda:0"))
