@@ -29,6 +29,9 @@ CASES = {
     # the configuration files' own setting: one 10-way code through the conditional batch norms of the ResNet generator (configs/CIFAR10/SNGAN-Info.yaml)
     "sngan32_info_cbn": dict(base="sngan32", MODEL=dict(info_type="discrete", g_info_injection="cBN", info_num_discrete_c=1, info_dim_discrete_c=10),
                              LOSS=dict(infoGAN_loss_discrete_lambda=1.0)),
+    # BigGAN-deep (the reference's legacy variant carries the same code paths, models/big_resnet_deep_legacy.py:110-121,156-161,322-329)
+    "bigdeep32_info_cbn": dict(base="bigdeep32", MODEL=dict(info_type="discrete", g_info_injection="cBN", info_num_discrete_c=1, info_dim_discrete_c=10),
+                               LOSS=dict(infoGAN_loss_discrete_lambda=1.0)),
     # DCGAN with the configuration file's setting (configs/CIFAR10/DCGAN-Info.yaml): full-width deep_conv networks, batch-norm discriminator
     # (compact: initial state by formula, oracle/make_golden.py formula_state; large expected tensors as 4096 evenly spaced samples + their l2 norm)
     "dcgan32_info_cbn": dict(base="dcgan32", compact=True, MODEL=dict(info_type="discrete", g_info_injection="cBN", info_num_discrete_c=1, info_dim_discrete_c=10),

@@ -85,8 +85,22 @@ class Generator(nn.Module):
         self.bottom = 4
         self.num_blocks = len(self.in_dims)
         self.affine_input_dim = self.z_dim
-        if getattr(MODEL, "info_type", "N/A") != "N/A":
-            raise NotImplementedError("InfoGAN heads are outside the benchmarked hot path (SURVEY.md §8f)")
+        # InfoGAN (reference src/models/big_resnet_deep_legacy.py:110-121,156-161)
+        self.info_type = getattr(MODEL, "info_type", "N/A")
+        self.g_info_injection = getattr(MODEL, "g_info_injection", "N/A")
+        info_dim = 0
+        if self.info_type in ("discrete", "both"):
+            info_dim += MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c
+        if self.info_type in ("continuous", "both"):
+            info_dim += MODEL.info_num_conti_c
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                self.info_mix_linear = MODULES.g_linear(in_features=self.z_dim + info_dim, out_features=self.z_dim, bias=True)
+            elif self.g_info_injection == "cBN":
+                self.affine_input_dim += self.g_shared_dim
+                self.info_proj_linear = MODULES.g_linear(in_features=info_dim, out_features=self.g_shared_dim, bias=True)
+            else:
+                raise NotImplementedError(f"g_info_injection = {self.g_info_injection}")
         if self.g_cond_mtd != "W/O":
             self.affine_input_dim += self.g_shared_dim
             self.shared = ops.embedding(num_embeddings=self.num_classes, embedding_dim=self.g_shared_dim)
@@ -111,10 +125,19 @@ class Generator(nn.Module):
         dtype = self.compute_dtype
         bank = get_bank(self, dtype)
         slot = bank.begin_forward(_need_graph(self, z, shared_label))
+        affine_list = []
+        if self.info_type != "N/A":
+            if self.g_info_injection == "concat":
+                z = self.info_mix_linear.forward_rt(z, slot)
+            else:
+                z, z_info = z[:, :self.z_dim], z[:, self.z_dim:]
+                affine_list.append(self.info_proj_linear.forward_rt(z_info, slot))
         if self.g_cond_mtd != "W/O":
             if shared_label is None:
                 shared_label = self.shared(label)
-            z = torch.cat([shared_label, z], 1)
+            affine_list.append(shared_label)
+        if len(affine_list) > 0:
+            z = torch.cat(affine_list + [z], 1)
         affine = z
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)

@@ -456,7 +456,7 @@ def ada_filter_adjoint_case(shape, dev, seed=0):
 
 
 # ---- InfoGAN against the reference's vectors (tests/golden/info.npz, oracle/make_golden_info.py) -----------------------------------------------------------
-INFO_CASES = ["biggan32_info_cbn", "sngan32_info_concat", "sngan32_info_cbn", "dcgan32_info_cbn"]
+INFO_CASES = ["biggan32_info_cbn", "sngan32_info_concat", "sngan32_info_cbn", "bigdeep32_info_cbn", "dcgan32_info_cbn"]
 
 
 def info_case(tag, dev):

@@ -203,7 +203,7 @@ def test_emulated_ada_pipeline_matches_reference_vectors(installed):
 def test_emulated_infogan_updates_match_reference_vectors(installed, tag):
     """InfoGAN: generator code injection ("cBN" / "concat"), the discriminator's Q heads, the information losses and the Q heads' Adam with the generator's
     settings, through the interpreted kernel sources against the REAL reference (tests/golden/info.npz)"""
-    if tag in ("sngan32_info_cbn", "dcgan32_info_cbn") and os.environ.get("SG_EMU_NET") != "1":
+    if tag in ("sngan32_info_cbn", "bigdeep32_info_cbn", "dcgan32_info_cbn") and os.environ.get("SG_EMU_NET") != "1":
         pytest.skip("SG_EMU_NET=1 runs the remaining InfoGAN fixtures through the interpreter (full-width DCGAN: ~40 s)")
     AC.info_case(tag, torch.device("cpu"))
 
