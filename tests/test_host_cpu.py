@@ -373,3 +373,52 @@ def test_conv_rs96_index_model(relu, pool):
     m = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(m)
     assert m.run(N=1, H=4, SH=2, relu=relu, pool=pool, seed=3) == 0.0
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/configs"), reason="the reference checkout is only present in the authoring container")
+def test_every_non_stylegan_reference_config_maps_to_worker_and_model_options():
+    """studiogan_amd.config_map over EVERY configuration file of the reference whose backbone is not a StyleGAN one (145 files): each key / value on the
+    training-step path translates into worker.Worker / backbone / ops.Modules keyword arguments that exist -- no configuration asks for something the package
+    does not mirror; a handful of CIFAR10 ones are also BUILT (at width 8) through those arguments."""
+    import glob
+    import importlib
+    import inspect
+    import yaml
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import config_map as CM, ops
+    from studiogan_amd.worker import Worker
+    sig = set(inspect.signature(Worker.__init__).parameters)
+    files = sorted(glob.glob("/root/reference/src/configs/*/*.yaml"))
+    seen, flags = 0, set()
+    for f in files:
+        y = yaml.safe_load(open(f))
+        if "stylegan" in (y.get("MODEL") or {}).get("backbone", "resnet"):
+            with pytest.raises(NotImplementedError):
+                CM.model_args(y)
+            continue
+        kw = CM.worker_kwargs(y)
+        assert not (set(kw) - sig), (f, set(kw) - sig)
+        bb, mods, gen, dis = CM.model_args(y)
+        mod = importlib.import_module("studiogan_amd.backbones." + bb)
+        assert not (set(gen) - set(inspect.signature(mod.Generator.__init__).parameters)), f
+        assert not (set(dis) - set(inspect.signature(mod.Discriminator.__init__).parameters)), f
+        assert not (set(mods) - set(inspect.signature(ops.Modules.__init__).parameters)), f
+        flags |= {k for k, v in kw.items() if k.startswith("apply_") and v} | ({"info"} if kw["info_type"] != "N/A" else set())
+        seen += 1
+    assert seen >= 140
+    assert {"apply_diffaug", "apply_ada", "apply_apa", "apply_cr", "apply_bcr", "apply_zcr", "apply_gp", "apply_dra", "apply_maxgp", "apply_r1_reg", "apply_wc", "apply_fm",
+            "apply_lo", "apply_lecam", "apply_g_ema", "info"} <= flags
+    for name in ("BigGAN-Info", "SNGAN-ADA", "LOGAN", "DCGAN-Info", "ReACGAN-ADC-DiffAug", "MHGAN", "WGAN-WC", "BigGAN-Deep"):
+        y = yaml.safe_load(open(f"/root/reference/src/configs/CIFAR10/{name}.yaml"))
+        y.setdefault("MODEL", {})
+        for k in ("g_conv_dim", "d_conv_dim"):
+            if y["MODEL"].get(k, 64) != "N/A":
+                y["MODEL"][k] = 8
+        bb, mods, gen, dis = CM.model_args(y)
+        mod = importlib.import_module("studiogan_amd.backbones." + bb)
+        MOD, MODEL = ops.Modules(**mods), CM.model_namespace(y)
+        G = mod.Generator(mixed_precision=False, MODULES=MOD, MODEL=MODEL, **gen)
+        D = mod.Discriminator(mixed_precision=False, MODULES=MOD, MODEL=MODEL, **dis)
+        assert sum(p.numel() for p in G.parameters()) > 0 and sum(p.numel() for p in D.parameters()) > 0, name
+        if CM.worker_kwargs(y)["info_type"] != "N/A":
+            assert hasattr(D, "info_discrete_linear") and (hasattr(G, "info_proj_linear") or hasattr(G, "info_mix_linear")), name
