@@ -625,3 +625,52 @@ def logan_case(dev):
     for k, prm in G.named_parameters():
         C.check("G_grad/" + k, prm.grad, torch.from_numpy(z["G_grad/" + k]), 2e-2, floor=1e-2 * gmx)
     C.finish()
+
+
+def r1_with_heads_case(name, dev):
+    """R1 on a BigGAN discriminator with attention AND a classifier-style head (reference configs/*/MDGAN.yaml: `apply_r1_reg` with the multi-discriminator head; the
+    adversarial logit runs through linear1 as functional.LinearFn -> LinearDgradFn in the create_graph pass, then the per-class gather): penalty and every
+    parameter gradient against torch autograd's double backward over the oracle (networks of tests/golden/heads.npz)."""
+    import json
+    from util import Collector, GOLDEN
+    from test_model_gpu import build_from_yaml
+    from oracle import restate as O, make_golden as MG
+    from studiogan_amd import losses as SL
+    z = np.load(os.path.join(GOLDEN, "heads.npz"))
+    c = json.load(open(os.path.join(GOLDEN, "heads.json")))["cases"][name]
+    y = c["yaml"]
+    _, D = build_from_yaml(y, False, dev)
+    sd = {k[len(name) + 3:]: torch.from_numpy(z[k]) for k in z.files if k.startswith(name + "/P/") or k.startswith(name + "/B/")}
+    D.load_state_dict({k: v.to(dev) for k, v in sd.items()}, strict=True)
+    D.train()
+    P = {k[len(name) + 3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(name + "/P/")}
+    B = {k[len(name) + 3:]: torch.from_numpy(z[k]).clone() for k in z.files if k.startswith(name + "/B/")}
+    for k in P:
+        if k.endswith("sigma"):
+            P[k] = torch.full_like(P[k], 0.6)          # attention switched on
+    with torch.no_grad():
+        for k, prm in D.named_parameters():
+            prm.copy_(P[k].to(dev))
+    real, rl = torch.from_numpy(z[name + "/in/real"]), torch.from_numpy(z[name + "/in/rl"])
+    ocfg = MG.oracle_cfg(y)
+    dis = O.model_fns(ocfg)[1]
+    leaves = {k: v.clone().requires_grad_(True) for k, v in P.items()}
+
+    def dis_adv(x, l, Pp, Bb):
+        adv, h = dis(x, l, Pp, Bb)
+        return O.d_heads(adv, h, l, Pp, Bb, ocfg)["adv_output"], h
+    r_o, adv_o = O.r1_reg(dis_adv, real, rl, leaves, B)
+    (10.0 * r_o + torch.mean(torch.relu(1.0 - adv_o))).backward()
+    for prm in D.parameters():
+        prm.grad = None
+    xr = real.to(dev).requires_grad_(True)
+    out = D(xr, rl.to(dev))
+    r = SL.cal_r1_reg(adv_output=out["adv_output"], images=xr, device=dev)
+    (10.0 * r + SL.d_hinge(out["adv_output"], torch.full_like(out["adv_output"].detach(), -5.0))).backward()
+    C = Collector()
+    C.check(f"r1 [{name}] penalty", r, r_o, 5e-4)
+    gmax = max(float(v.grad.abs().max()) for v in leaves.values() if v.grad is not None)
+    for k, prm in D.named_parameters():
+        go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
+        C.check(f"r1 [{name}] grad " + k, prm.grad if prm.grad is not None else torch.zeros_like(prm), go, 1e-3, floor=1e-2 * gmax)
+    C.finish()

@@ -224,6 +224,12 @@ def test_info_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch
 
 
 @needs_emu
+def test_emulated_r1_on_the_mdgan_discriminator(installed):
+    """configs/*/MDGAN.yaml: R1 on a BigGAN discriminator with attention and the multi-discriminator head (the adversarial logit through LinearFn -> LinearDgradFn)"""
+    AC.r1_with_heads_case("md", torch.device("cpu"))
+
+
+@needs_emu
 def test_emulated_freeze_d(installed):
     AC.freeze_d_case("sngan32", torch.device("cpu"), 2)
 

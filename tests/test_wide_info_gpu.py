@@ -27,3 +27,10 @@ def test_logan_latent_optimisation(sg):
     """LOGAN (reference configs/CIFAR10/LOGAN.yaml; src/utils/losses.py:278-298): written after the round's last GPU second -- green on the CPU interpreter
     (tests/test_aug_cpu.py::test_emulated_logan_latent_optimisation), first GPU run = the driver's"""
     AC.logan_case(torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("name", ["md", "ac", "2c", "mh"])
+def test_r1_with_classifier_heads(sg, name):
+    """R1 through attention + the linear adversarial heads (reference configs/*/MDGAN.yaml uses it with the multi-discriminator head); interpreter-verified,
+    first GPU run = the driver's"""
+    AC.r1_with_heads_case(name, torch.device("cuda:0"))
