@@ -1,7 +1,7 @@
 """One training step (d_updates_per_step capped at 1 discriminator update + one generator update) of EVERY non-StyleGAN CIFAR10 configuration file of the reference,
 built at width 8 through studiogan_amd.config_map and run through the kernel SOURCES on the CPU interpreter (tests/hipemu): does every configuration's combination of
 heads / losses / regularisers / augmentations execute end to end with finite losses? (Parity of each ingredient is the business of the golden-vector tests; this is
-the integration sweep.)   usage: python tools/config_sweep_emulated.py [name ...] > profiles/<...>.txt      TEST INFRASTRUCTURE; needs /root/reference for the files."""
+the integration sweep.)   usage: python tools/config_sweep_emulated.py [--bf16] [name ...] > profiles/<...>.txt      TEST INFRASTRUCTURE; needs /root/reference for the files."""
 import glob
 import importlib
 import os
@@ -22,7 +22,8 @@ def main():
     import studiogan_amd  # noqa: F401
     from studiogan_amd import config_map as CM, ops
     from studiogan_amd.worker import Worker
-    only = set(sys.argv[1:])
+    mixed = "--bf16" in sys.argv[1:]
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))
     files = sorted(glob.glob("/root/reference/src/configs/CIFAR10/*.yaml"))
     torch.set_num_threads(1)
     dev = torch.device("cpu")
@@ -52,8 +53,8 @@ def main():
                 bb, mods, gen, dis = CM.model_args(y)
                 mod = importlib.import_module("studiogan_amd.backbones." + bb)
                 MOD, MODEL = ops.Modules(**mods), CM.model_namespace(y)
-                G = mod.Generator(mixed_precision=False, MODULES=MOD, MODEL=MODEL, **gen).to(dev)
-                D = mod.Discriminator(mixed_precision=False, MODULES=MOD, MODEL=MODEL, **dis).to(dev)
+                G = mod.Generator(mixed_precision=mixed, MODULES=MOD, MODEL=MODEL, **gen).to(dev)
+                D = mod.Discriminator(mixed_precision=mixed, MODULES=MOD, MODEL=MODEL, **dis).to(dev)
                 kw = CM.worker_kwargs(y)
                 w = Worker(G, D, **kw)
                 B = kw["batch_size"]
@@ -69,7 +70,7 @@ def main():
                 bad += 1
                 print(f"{name:24s} FAILED {type(e).__name__}: {str(e)[:300]}")
             sys.stdout.flush()
-    print(f"# {ok} configurations ran one step with finite results, {bad} did not")
+    print(f"# {'bf16' if mixed else 'fp32'}: {ok} configurations ran one step with finite results, {bad} did not")
 
 
 if __name__ == "__main__":
