@@ -1,7 +1,7 @@
 """One training step (d_updates_per_step capped at 1 discriminator update + one generator update) of EVERY non-StyleGAN CIFAR10 configuration file of the reference,
 built at width 8 through studiogan_amd.config_map and run through the kernel SOURCES on the CPU interpreter (tests/hipemu): does every configuration's combination of
 heads / losses / regularisers / augmentations execute end to end with finite losses? (Parity of each ingredient is the business of the golden-vector tests; this is
-the integration sweep.)   usage: python tools/config_sweep_emulated.py [--bf16] [name ...] > profiles/<...>.txt      TEST INFRASTRUCTURE; needs /root/reference for the files."""
+the integration sweep.)   usage: python tools/config_sweep_emulated.py [--bf16] [--dir=ImageNet] [--batch=2] [name ...] > profiles/<...>.txt      TEST INFRASTRUCTURE; needs /root/reference for the files."""
 import glob
 import importlib
 import os
@@ -23,8 +23,10 @@ def main():
     from studiogan_amd import config_map as CM, ops
     from studiogan_amd.worker import Worker
     mixed = "--bf16" in sys.argv[1:]
+    data = next((a[6:] for a in sys.argv[1:] if a.startswith("--dir=")), "CIFAR10")
+    batch = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--batch=")), "4"))
     only = set(a for a in sys.argv[1:] if not a.startswith("--"))
-    files = sorted(glob.glob("/root/reference/src/configs/CIFAR10/*.yaml"))
+    files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
     dev = torch.device("cpu")
     ok = bad = 0
@@ -42,9 +44,7 @@ def main():
                 y["MODEL"]["d_embed_dim"] = 16
             if y["MODEL"].get("g_shared_dim", "N/A") != "N/A":
                 y["MODEL"]["g_shared_dim"] = 16
-            if y["MODEL"].get("backbone", "resnet") == "big_resnet":
-                y["MODEL"]["z_dim"] = 40          # divisible by (blocks + 1) at 32 x 32
-            y.setdefault("OPTIMIZATION", {})["batch_size"] = 4
+            y.setdefault("OPTIMIZATION", {})["batch_size"] = batch
             y["OPTIMIZATION"]["d_updates_per_step"] = 1
             y["OPTIMIZATION"]["acml_steps"] = 1
             t = time.time()
@@ -58,7 +58,8 @@ def main():
                 kw = CM.worker_kwargs(y)
                 w = Worker(G, D, **kw)
                 B = kw["batch_size"]
-                real = (torch.randint(0, 256, (B, 3, 32, 32)).float() / 127.5 - 1.0, torch.randint(0, kw["num_classes"], (B,)))
+                S = (y.get("DATA") or {}).get("img_size", 32)
+                real = (torch.randint(0, 256, (B, 3, S, S)).float() / 127.5 - 1.0, torch.randint(0, kw["num_classes"], (B,)))
                 d, g = w.step(0, [real])
                 fin = bool(torch.isfinite(d)) and bool(torch.isfinite(g)) and all(bool(torch.isfinite(p).all()) for p in list(G.parameters()) + list(D.parameters()))
                 flags = [k[6:] for k, v in kw.items() if k.startswith("apply_") and v and k != "apply_g_ema"] + ([f"info:{kw['info_type']}"] if kw["info_type"] != "N/A" else [])
