@@ -104,3 +104,17 @@ def worker_kwargs(y):
               apply_lo=Ls["apply_lo"], lo_rate=_num(Ls["lo_rate"], 0.8), lo_steps4train=_num(Ls["lo_steps4train"], 2), lo_alpha=_num(Ls["lo_alpha"], 0.9),
               lo_beta=_num(Ls["lo_beta"], 0.1), lo_lambda=_num(Ls["lo_lambda"], 0.1), z_prior=M["z_prior"])
     return kw
+
+
+def build(y, device, mixed_precision=False, group=None):
+    """(Generator, Discriminator, Worker) of one configuration on `device`: what reference src/models/model.py:90-140 (load_generator_discriminator) followed by
+    src/worker.py:38-230 (WORKER.__init__) assemble from a Configurations object. Imports the backbones (and through them libsgamd.so) only here."""
+    import importlib
+    from . import ops
+    from .worker import Worker
+    backbone, modules, gen, dis = model_args(y)
+    mod = importlib.import_module(__package__ + ".backbones." + backbone)
+    MOD, MODEL = ops.Modules(**modules), model_namespace(y)
+    G = mod.Generator(mixed_precision=mixed_precision, MODULES=MOD, MODEL=MODEL, **gen).to(device)
+    D = mod.Discriminator(mixed_precision=mixed_precision, MODULES=MOD, MODEL=MODEL, **dis).to(device)
+    return G, D, Worker(G, D, group=group, **worker_kwargs(y))

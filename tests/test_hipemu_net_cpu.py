@@ -216,3 +216,26 @@ def test_emulated_second_order_through_attention(name, kind):
         c0 = E.counters()
         TB.r1_maxgp_case(name, kind, torch.device("cpu"))      # (bigdeep32: + the bottleneck blocks' channel-concat skip, functional.CatConvDgradFn)
         assert E.counters()["launches"] - c0["launches"] > 100
+
+
+def test_emulated_run_config_tool(tmp_path, monkeypatch, capsys):
+    """tools/run_config.py: a configuration file in the reference's YAML layout -> config_map.build -> two training steps (two discriminator updates each, R1 +
+    DiffAugment + EMA on a spectral-norm ResNet with a projection head) on the interpreter; one JSON line with finite losses."""
+    import json
+    import yaml
+    cfg = {"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+           "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "g_conv_dim": 8, "d_conv_dim": 8, "z_dim": 32,
+                     "apply_g_ema": True, "g_ema_decay": 0.9999, "g_ema_start": 0},
+           "LOSS": {"adv_loss": "hinge", "apply_r1_reg": True, "r1_lambda": 1.0, "r1_place": "inside_loop"},
+           "AUG": {"apply_diffaug": True, "diffaug_type": "diffaug"},
+           "OPTIMIZATION": {"batch_size": 4, "d_updates_per_step": 2, "beta1": 0.0, "beta2": 0.9}}
+    f = tmp_path / "Tiny-R1-DiffAug.yaml"
+    f.write_text(yaml.safe_dump(cfg))
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import run_config
+    monkeypatch.setattr(sys, "argv", ["run_config.py", str(f), "--emulate", "--steps", "1", "--warmup", "1"])
+    run_config.main()
+    line = [ln for ln in capsys.readouterr().out.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["backbone"] == "resnet" and out["batch"] == 4 and out["device"] == "interpreter"
+    assert out["d_loss"] == out["d_loss"] and out["g_loss"] == out["g_loss"] and abs(out["d_loss"]) < 1e4

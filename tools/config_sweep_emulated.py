@@ -3,7 +3,6 @@ built at width 8 through studiogan_amd.config_map and run through the kernel SOU
 heads / losses / regularisers / augmentations execute end to end with finite losses? (Parity of each ingredient is the business of the golden-vector tests; this is
 the integration sweep.)   usage: python tools/config_sweep_emulated.py [--bf16] [--dir=ImageNet] [--batch=2] [name ...] > profiles/<...>.txt      TEST INFRASTRUCTURE; needs /root/reference for the files."""
 import glob
-import importlib
 import os
 import sys
 import time
@@ -20,8 +19,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
 def main():
     import fullemu
     import studiogan_amd  # noqa: F401
-    from studiogan_amd import config_map as CM, ops
-    from studiogan_amd.worker import Worker
+    from studiogan_amd import config_map as CM
     mixed = "--bf16" in sys.argv[1:]
     data = next((a[6:] for a in sys.argv[1:] if a.startswith("--dir=")), "CIFAR10")
     batch = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--batch=")), "4"))
@@ -50,13 +48,9 @@ def main():
             t = time.time()
             try:
                 torch.manual_seed(0)
-                bb, mods, gen, dis = CM.model_args(y)
-                mod = importlib.import_module("studiogan_amd.backbones." + bb)
-                MOD, MODEL = ops.Modules(**mods), CM.model_namespace(y)
-                G = mod.Generator(mixed_precision=mixed, MODULES=MOD, MODEL=MODEL, **gen).to(dev)
-                D = mod.Discriminator(mixed_precision=mixed, MODULES=MOD, MODEL=MODEL, **dis).to(dev)
+                bb = CM.model_args(y)[0]
+                G, D, w = CM.build(y, dev, mixed_precision=mixed)
                 kw = CM.worker_kwargs(y)
-                w = Worker(G, D, **kw)
                 B = kw["batch_size"]
                 S = (y.get("DATA") or {}).get("img_size", 32)
                 real = (torch.randint(0, 256, (B, 3, S, S)).float() / 127.5 - 1.0, torch.randint(0, kw["num_classes"], (B,)))
