@@ -67,6 +67,78 @@ def make_GAN_untrainable(Gen, Gen_ema, Dis):
     Dis.apply(set_deterministic_op_trainable)
 
 
+def set_bn_trainable(m):
+    """reference src/utils/misc.py:236-238"""
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.train()
+
+
+def reset_bn_statistics(m):
+    """reference src/utils/misc.py:264-266"""
+    if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+        m.reset_running_stats()
+
+
+def apply_standing_statistics(generator, standing_max_batch, standing_step, z_dim, num_classes, device, z_prior="gaussian", world_size=1,
+                              distributed_data_parallel=False, MODEL=None):
+    """reference src/utils/misc.py:301-334: reset every batch norm's running statistics, then `standing_step` training-mode generator forwards over batches of a
+    random size in [1, standing_max_batch / world_size] (python `random`, like the reference) with 'totally_random' labels -- the running statistics (momentum 0.1)
+    the evaluation forwards then normalise with. Draw order of src/utils/sample.py:69-118: labels, latents, InfoGAN codes. Leaves the generator in eval mode."""
+    import random
+    generator.train()
+    generator.apply(reset_bn_statistics)
+    info_type = getattr(MODEL, "info_type", "N/A")
+    with torch.no_grad():
+        for _ in range(standing_step):
+            per_gpu = standing_max_batch // world_size
+            b = random.randint(1, per_gpu) if distributed_data_parallel else random.randint(1, per_gpu) * world_size
+            ys = torch.randint(low=0, high=max(num_classes, 1), size=(b,), dtype=torch.long, device=device)
+            if z_prior == "gaussian":
+                zs = torch.randn(b, z_dim, device=device)
+            elif z_prior == "uniform":
+                zs = torch.FloatTensor(b, z_dim).uniform_(-1.0, 1.0).to(device)
+            else:
+                raise NotImplementedError(z_prior)
+            if info_type in ("discrete", "both"):
+                disc = torch.randint(MODEL.info_dim_discrete_c, (b, MODEL.info_num_discrete_c), device=device)
+                zs = torch.cat((zs, torch.nn.functional.one_hot(disc, MODEL.info_dim_discrete_c).view(b, -1)), dim=1)
+            if info_type in ("continuous", "both"):
+                zs = torch.cat((zs, torch.rand(b, MODEL.info_num_conti_c, device=device) * 2 - 1), dim=1)
+            generator(zs, ys, eval=False)
+    generator.eval()
+
+
+class GeneratorController:
+    """reference src/utils/misc.py:63-107: puts the generator (the EMA twin when there is one, src/worker.py:159) into the state the evaluation forwards of
+    src/metrics/features.py:17-65 expect. standing_statistics: accumulate them on the first call (std_stat_counter <= 1), plain eval mode afterwards;
+    batch_statistics: batch norm stays in training mode without tracking; convolution / linear / embedding layers always stay in .train() so that spectral norm
+    keeps iterating (src/utils/misc.py:254-262)."""
+
+    def __init__(self, generator, batch_statistics, standing_statistics, standing_max_batch, standing_step, z_dim, num_classes, device, z_prior="gaussian",
+                 world_size=1, distributed_data_parallel=False, MODEL=None, std_stat_counter=0):
+        self.generator, self.batch_statistics, self.standing_statistics = generator, batch_statistics, standing_statistics
+        self.standing_max_batch, self.standing_step, self.std_stat_counter = standing_max_batch, standing_step, std_stat_counter
+        self.sample = dict(z_dim=z_dim, num_classes=num_classes, device=device, z_prior=z_prior, world_size=world_size,
+                           distributed_data_parallel=distributed_data_parallel, MODEL=MODEL)
+
+    def prepare_generator(self):
+        if self.standing_statistics:
+            if self.std_stat_counter > 1:
+                self.generator.eval()
+            else:
+                self.generator.train()
+                apply_standing_statistics(self.generator, self.standing_max_batch, self.standing_step, **self.sample)
+                self.generator.eval()
+            self.generator.apply(set_deterministic_op_trainable)
+        else:
+            self.generator.eval()
+            if self.batch_statistics:
+                self.generator.apply(set_bn_trainable)
+                self.generator.apply(untrack_bn_statistics)
+            self.generator.apply(set_deterministic_op_trainable)
+        return self.generator, None, None          # (generator, generator_mapping, generator_synthesis): the StyleGAN halves do not exist here
+
+
 def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
     """reference src/utils/sample.py:33-88 (gaussian prior, 'totally_random' labels), drawn on the device."""
     zs = torch.randn(batch_size, z_dim, device=device, generator=generator)

@@ -674,3 +674,59 @@ def r1_with_heads_case(name, dev):
         go = leaves[k].grad if leaves[k].grad is not None else torch.zeros_like(leaves[k])
         C.check(f"r1 [{name}] grad " + k, prm.grad if prm.grad is not None else torch.zeros_like(prm), go, 1e-3, floor=1e-2 * gmax)
     C.finish()
+
+
+# ---- the evaluation-side generator preparation against the reference's vectors (tests/golden/standing.npz, oracle/make_golden_standing.py) -----------------------
+STANDING_CASES = ["sngan", "biggan", "resgan"]
+
+
+def standing_case(name, dev):
+    """studiogan_amd.worker.GeneratorController.prepare_generator (reference src/utils/misc.py:63-107) in its three modes -- standing statistics (reset, then five
+    training-mode forwards over batches of 1..7 latents: the draws replayed from the fixture), batch statistics, plain evaluation -- on a generator that has trained a
+    little: every buffer afterwards (batch-norm running statistics and counters, spectral-norm vectors), the training flags of the leaf modules, and the evaluation-mode
+    image of fixed latents, against what the REAL reference left behind (fp32)."""
+    import json
+    import random
+    from util import Collector, GOLDEN
+    from studiogan_amd import config_map as CM
+    from studiogan_amd.worker import GeneratorController
+    z = np.load(os.path.join(GOLDEN, "standing.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "standing.json")))
+    c, pre = meta["cases"][name], name + "/"
+    y = c["yaml"]
+    seed = meta["seed"] + 20 + STANDING_CASES.index(name)
+    draws = []
+    while pre + f"draw{len(draws)}" in z.files:
+        draws.append(torch.from_numpy(z[pre + f"draw{len(draws)}"]))
+    C = Collector()
+    for mode in ("standing", "batch", "plain"):
+        G, _, _ = CM.build(y, dev)
+        G.load_state_dict({k[len(pre) + 5:]: torch.from_numpy(z[k]).to(dev) for k in z.files if k.startswith(pre + "init/")}, strict=True)
+        ctl = GeneratorController(G, batch_statistics=mode == "batch", standing_statistics=mode == "standing", standing_max_batch=meta["max_batch"],
+                                  standing_step=meta["steps"], z_dim=y["MODEL"]["z_dim"], num_classes=y["DATA"]["num_classes"], device=dev)
+        random.seed(seed)
+        with Replayed(draws), torch.no_grad():
+            G, _, _ = ctl.prepare_generator()
+        flags = sorted({(type(m).__name__.replace("SnConv2d", "Conv2d").replace("SnLinear", "Linear").replace("SnEmbedding", "Embedding"), m.training)
+                        for m in G.modules() if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding))})
+        want = sorted({(a, b) for a, b in c[mode + "_training_flags"] if a in ("BatchNorm2d", "Conv2d", "Linear", "Embedding")})
+        got = sorted({("BatchNorm2d" if isinstance(m, torch.nn.modules.batchnorm._BatchNorm) else "Conv2d" if isinstance(m, torch.nn.Conv2d) else
+                       "Linear" if isinstance(m, torch.nn.Linear) else "Embedding", m.training)
+                      for m in G.modules() if isinstance(m, (torch.nn.modules.batchnorm._BatchNorm, torch.nn.Conv2d, torch.nn.Linear, torch.nn.Embedding))})
+        assert got == want, (name, mode, got, want, flags)
+        with torch.no_grad():
+            img = G(torch.from_numpy(z[pre + "z_eval"]).to(dev), torch.from_numpy(z[pre + "y_eval"]).to(dev), eval=True)
+        C.check(f"{name} {mode} image", img, torch.from_numpy(z[pre + mode + "/image"]), 2e-4)
+        bufs = dict(G.named_buffers())
+        n = 0
+        for k in z.files:
+            if k.startswith(pre + mode + "/final/"):
+                kk = k[len(pre + mode + "/final/"):]
+                ref = torch.from_numpy(z[k])
+                if ref.dtype == torch.int64:
+                    assert int(bufs[kk]) == int(ref), (name, mode, kk, int(bufs[kk]), int(ref))
+                else:
+                    C.check(f"{name} {mode} {kk}", bufs[kk], ref, 2e-4, floor=1e-3)
+                n += 1
+        assert n > 0
+    C.finish()

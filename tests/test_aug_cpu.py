@@ -256,6 +256,30 @@ def test_logan_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatc
     torch.set_num_threads(nt)
 
 
+@pytest.mark.parametrize("name", AC.STANDING_CASES)
+def test_emulated_generator_preparation_for_evaluation(installed, name):
+    """worker.GeneratorController.prepare_generator: standing statistics (five training-mode forwards over batches of 1..7 latents), batch statistics, plain
+    evaluation -- buffers, training flags and the evaluation image against the REAL reference's (tests/golden/standing.npz)"""
+    if name != "biggan" and os.environ.get("SG_EMU_NET") != "1":
+        pytest.skip("SG_EMU_NET=1 runs the other two generators through the interpreter as well")
+    AC.standing_case(name, torch.device("cpu"))
+
+
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_standing_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
+    from oracle import make_golden_standing as MGS
+    from util import GOLDEN
+    monkeypatch.setattr(MGS, "OUT", str(tmp_path / "standing"))
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    MGS.main()
+    a, b = np.load(os.path.join(GOLDEN, "standing.npz")), np.load(tmp_path / "standing.npz")
+    assert sorted(a.files) == sorted(b.files)
+    for k in a.files:
+        assert np.array_equal(a[k], b[k]), k
+    torch.set_num_threads(nt)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json

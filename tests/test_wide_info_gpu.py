@@ -34,3 +34,10 @@ def test_r1_with_classifier_heads(sg, name):
     """R1 through attention + the linear adversarial heads (reference configs/*/MDGAN.yaml uses it with the multi-discriminator head); interpreter-verified,
     first GPU run = the driver's"""
     AC.r1_with_heads_case(name, torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("name", AC.STANDING_CASES)
+def test_generator_preparation_for_evaluation(sg, name):
+    """worker.GeneratorController.prepare_generator (reference src/utils/misc.py:63-107,301-334: standing statistics / batch statistics / plain evaluation in front of
+    the FID / IS feature extraction) against tests/golden/standing.npz; interpreter-verified, first GPU run = the driver's"""
+    AC.standing_case(name, torch.device("cuda:0"))

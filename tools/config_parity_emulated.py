@@ -1,0 +1,146 @@
+"""Architecture parity of EVERY non-StyleGAN configuration file against the REAL reference (imported on CPU, oracle/ref_import.py): for each distinct network pair a
+directory of `src/configs/` asks for (backbone x conditioning x heads x attention x image size x InfoGAN injection; channel widths cut to 8 so that the interpreter
+finishes), the reference's Generator / Discriminator are built by the reference's own code, their state is loaded (strict) into this package's networks built through
+studiogan_amd.config_map, and in training mode (batch statistics, one spectral-norm power iteration) the same latents / labels / images go through both:
+
+  * generator image, every non-empty entry of the discriminator's output dictionary                                  (forward)
+  * every parameter gradient of  sum(image * W)  and of  sum_k sum(entry_k * W_k)  with fixed random W               (first-order backward)
+
+are compared; this package's side runs the kernel SOURCES on the CPU interpreter (tests/hipemu). One row per distinct architecture with the worst relative error of each
+group (max|a - b| / max|b|; gradients: per tensor, with the test suite's floor of 1e-2 of the largest gradient in the network, so that the analytically-zero gradients --
+a convolution bias in front of a batch norm -- are not judged against their own rounding noise).
+   usage: python tools/config_parity_emulated.py [--dir=CIFAR10] [--batch=4] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+import glob
+import json
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+
+FLOAT_KEYS = ("h", "adv_output", "embed", "proxy", "cls_output", "mi_embed", "mi_proxy", "mi_cls_output", "info_discrete_c_logits", "info_conti_mu", "info_conti_var")
+
+
+def rel(a, b, floor=0.0):
+    a, b = a.detach().double().reshape(-1), b.detach().double().reshape(-1)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+
+
+def shrink(y):
+    y.setdefault("MODEL", {})
+    for k in ("g_conv_dim", "d_conv_dim"):
+        if y["MODEL"].get(k, 64) != "N/A":
+            y["MODEL"][k] = 8
+    if y["MODEL"].get("d_embed_dim", "N/A") != "N/A":
+        y["MODEL"]["d_embed_dim"] = 16
+    if y["MODEL"].get("g_shared_dim", "N/A") != "N/A":
+        y["MODEL"]["g_shared_dim"] = 16
+    return y
+
+
+def grads(net):
+    return {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()}
+
+
+def worst_grad(mine, ref):
+    top = max(float(v.abs().max()) for v in ref.values())
+    worst, where = 0.0, ""
+    for k, g in ref.items():
+        e = rel(mine[k], g, floor=1e-2 * top)
+        if e > worst:
+            worst, where = e, k
+    return worst, where
+
+
+def main():
+    import fullemu
+    from oracle import ref_import as R
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import config_map as CM
+    data = next((a[6:] for a in sys.argv[1:] if a.startswith("--dir=")), "CIFAR10")
+    batch = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--batch=")), "4"))
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))
+    files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
+    torch.set_num_threads(1)
+    dev = torch.device("cpu")
+    seen, n_ok, n_bad, worst_all = {}, 0, 0, 0.0
+    with fullemu.Installed(dma_late=1, greedy=1, seed=1):
+        for f in files:
+            name = os.path.basename(f)[:-5]
+            y = yaml.safe_load(open(f))
+            if "stylegan" in (y.get("MODEL") or {}).get("backbone", "resnet") or (only and name not in only):
+                continue
+            y = shrink(y)
+            sig = json.dumps(CM.model_args(y), sort_keys=True, default=str) + json.dumps(vars(CM.model_namespace(y)), sort_keys=True, default=str)
+            if sig in seen:
+                seen[sig].append(name)
+                continue
+            seen[sig] = [name]
+            t = time.time()
+            try:
+                torch.manual_seed(0)
+                cfgs = R.load_cfgs({k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")})
+                Gr, Dr = R.build_models(cfgs)
+                yb = dict(y)
+                yb["OPTIMIZATION"] = {**(y.get("OPTIMIZATION") or {}), "batch_size": batch}
+                G, D, _ = CM.build(yb, dev)
+                G.load_state_dict(Gr.state_dict(), strict=True)
+                D.load_state_dict(Dr.state_dict(), strict=True)
+                kw = CM.worker_kwargs(yb)
+                S, nc = (y.get("DATA") or {}).get("img_size", 32), kw["num_classes"]
+                info = 0
+                if kw["info_type"] in ("discrete", "both"):
+                    info += kw["info_num_discrete_c"] * kw["info_dim_discrete_c"]
+                if kw["info_type"] in ("continuous", "both"):
+                    info += kw["info_num_conti_c"]
+                g = torch.Generator().manual_seed(7)
+                z = torch.randn(batch, kw["z_dim"] + info, generator=g)
+                lab = torch.randint(0, nc, (batch,), generator=g)
+                x = torch.randint(0, 256, (batch, 3, S, S), generator=g).float() / 127.5 - 1.0
+                Wimg = torch.randn(batch, 3, S, S, generator=g)
+                # ---- generator
+                img_r = Gr(z, lab)
+                (img_r * Wimg).sum().backward()
+                img = G(z, lab)
+                (img * Wimg).sum().backward()
+                e_img = rel(img, img_r)
+                e_gg, w_gg = worst_grad(grads(G), grads(Gr))
+                # ---- discriminator
+                out_r = Dr(x, lab)
+                Wk = {k: torch.randn(out_r[k].shape, generator=g) for k in FLOAT_KEYS if torch.is_tensor(out_r.get(k)) and out_r[k].is_floating_point()}
+                sum((out_r[k] * Wk[k]).sum() for k in Wk).backward()
+                out = D(x, lab)
+                sum((out[k] * Wk[k]).sum() for k in Wk).backward()
+                e_out, w_out = 0.0, ""
+                for k in Wk:
+                    e = rel(out[k], out_r[k])
+                    if e > e_out:
+                        e_out, w_out = e, k
+                e_dg, w_dg = worst_grad(grads(D), grads(Dr))
+                worst = max(e_img, e_gg, e_out, e_dg)
+                worst_all = max(worst_all, worst)
+                good = worst <= 2e-3
+                n_ok += good
+                n_bad += not good
+                M = y["MODEL"]
+                print(f"{name:26s} {M.get('backbone', 'resnet'):26s} {S:4d}px g_cond {M.get('g_cond_mtd', 'W/O'):4s} d_cond {M.get('d_cond_mtd', 'W/O'):6s} aux {M.get('aux_cls_type', 'W/O'):4s} "
+                      f"attn {str(M.get('apply_attn', False)):5s} info {M.get('info_type', 'N/A'):10s} | image {e_img:.1e}  G grads {e_gg:.1e}  D outputs({len(Wk)}) {e_out:.1e} [{w_out}]  "
+                      f"D grads {e_dg:.1e} {'ok' if good else 'MISMATCH ' + w_gg + ' / ' + w_dg} {time.time() - t:5.1f} s")
+            except Exception as e:      # noqa: BLE001
+                n_bad += 1
+                print(f"{name:26s} FAILED {type(e).__name__}: {str(e)[:300]}")
+            sys.stdout.flush()
+    print(f"# {data}: {n_ok} distinct architectures agree with the REAL reference (forward + first-order backward, fp32, worst relative error {worst_all:.1e}), {n_bad} do not; "
+          f"{sum(len(v) for v in seen.values())} configuration files map onto them")
+    for v in seen.values():
+        print("#   " + v[0] + (" = " + ", ".join(v[1:]) if len(v) > 1 else ""))
+
+
+if __name__ == "__main__":
+    main()
