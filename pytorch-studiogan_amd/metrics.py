@@ -353,12 +353,14 @@ def softmax_rows(logits):
 
 @torch.no_grad()
 def generate_images_and_stack_features(generator, eval_model, num_generate, batch_size, z_dim, num_classes, quantize=True, world_size=1,
-                                       DDP=False, device="cuda", moments=None):
+                                       DDP=False, device="cuda", moments=None, z_prior="gaussian", truncation_factor=-1.0, MODEL=None):
     """reference src/metrics/features.py:17-65. Returns (features [n,2048], probs [n,1008], labels list).
     moments: optional `FeatureMoments` accumulator fed on the device. It receives exactly the rows the reference keeps
     (`fake_feats[:num_generate]` of the rank-major gathered stack, src/metrics/fid.py:68-69): the over-generated tail --
-    ceil(num_generate / batch) batches, `num_batches // world_size + 1` per rank under DDP -- is NOT accumulated."""
-    from .worker import sample_zy
+    ceil(num_generate / batch) batches, `num_batches // world_size + 1` per rank under DDP -- is NOT accumulated.
+    z_prior / truncation_factor / MODEL (InfoGAN codes behind z): the reference's evaluation-time sampling (src/utils/sample.py:90-118 with is_train=False)."""
+    from .worker import sample_zy, sample_latents
+    plain = z_prior == "gaussian" and truncation_factor == -1.0 and getattr(MODEL, "info_type", "N/A") == "N/A"
     num_batches = int(math.ceil(float(num_generate) / float(batch_size)))
     rank = 0
     if DDP:
@@ -371,7 +373,10 @@ def generate_images_and_stack_features(generator, eval_model, num_generate, batc
     keep = max(0, min(per_rank, num_generate - rank * per_rank))
     feats, probs, labels = [], [], []
     for b in range(num_batches):
-        zs, ys = sample_zy(batch_size, z_dim, num_classes, device)
+        if plain:
+            zs, ys = sample_zy(batch_size, z_dim, num_classes, device)
+        else:
+            zs, ys = sample_latents(batch_size, z_dim, num_classes, device, z_prior=z_prior, truncation_factor=truncation_factor, MODEL=MODEL)
         fake = generator(zs, ys, eval=True)
         f, logit = eval_model.get_outputs(fake, quantize=quantize)
         if moments is not None:

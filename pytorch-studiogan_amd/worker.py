@@ -79,31 +79,45 @@ def reset_bn_statistics(m):
         m.reset_running_stats()
 
 
+def sample_latents(batch_size, z_dim, num_classes, device, z_prior="gaussian", truncation_factor=-1.0, MODEL=None):
+    """(zs, fake_labels) of one evaluation / standing-statistics batch in the reference's draw order (src/utils/sample.py:69-118 with y_sampler "totally_random"):
+    labels on the device; latents -- N(0, I) on the device, the truncated normal of scipy on the host when truncation_factor > 0 (sample.py:27-40), U(-1, 1) on the
+    host for the uniform prior; then InfoGAN's discrete (one-hot) and continuous codes behind z."""
+    ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device)
+    if z_prior == "gaussian":
+        if truncation_factor == -1.0:
+            zs = torch.randn(batch_size, z_dim, device=device)
+        elif truncation_factor > 0:
+            from scipy.stats import truncnorm
+            zs = torch.FloatTensor(truncnorm.rvs(-truncation_factor, truncation_factor, size=[batch_size, z_dim])).to(device)
+        else:
+            raise ValueError("truncated_factor must be positive.")
+    elif z_prior == "uniform":
+        zs = torch.FloatTensor(batch_size, z_dim).uniform_(-1.0, 1.0).to(device)
+    else:
+        raise NotImplementedError(z_prior)
+    info_type = getattr(MODEL, "info_type", "N/A")
+    if info_type in ("discrete", "both"):
+        disc = torch.randint(MODEL.info_dim_discrete_c, (batch_size, MODEL.info_num_discrete_c), device=device)
+        zs = torch.cat((zs, torch.nn.functional.one_hot(disc, MODEL.info_dim_discrete_c).view(batch_size, -1)), dim=1)
+    if info_type in ("continuous", "both"):
+        zs = torch.cat((zs, torch.rand(batch_size, MODEL.info_num_conti_c, device=device) * 2 - 1), dim=1)
+    return zs, ys
+
+
 def apply_standing_statistics(generator, standing_max_batch, standing_step, z_dim, num_classes, device, z_prior="gaussian", world_size=1,
                               distributed_data_parallel=False, MODEL=None):
     """reference src/utils/misc.py:301-334: reset every batch norm's running statistics, then `standing_step` training-mode generator forwards over batches of a
     random size in [1, standing_max_batch / world_size] (python `random`, like the reference) with 'totally_random' labels -- the running statistics (momentum 0.1)
-    the evaluation forwards then normalise with. Draw order of src/utils/sample.py:69-118: labels, latents, InfoGAN codes. Leaves the generator in eval mode."""
+    the evaluation forwards then normalise with. Leaves the generator in eval mode."""
     import random
     generator.train()
     generator.apply(reset_bn_statistics)
-    info_type = getattr(MODEL, "info_type", "N/A")
     with torch.no_grad():
         for _ in range(standing_step):
             per_gpu = standing_max_batch // world_size
             b = random.randint(1, per_gpu) if distributed_data_parallel else random.randint(1, per_gpu) * world_size
-            ys = torch.randint(low=0, high=max(num_classes, 1), size=(b,), dtype=torch.long, device=device)
-            if z_prior == "gaussian":
-                zs = torch.randn(b, z_dim, device=device)
-            elif z_prior == "uniform":
-                zs = torch.FloatTensor(b, z_dim).uniform_(-1.0, 1.0).to(device)
-            else:
-                raise NotImplementedError(z_prior)
-            if info_type in ("discrete", "both"):
-                disc = torch.randint(MODEL.info_dim_discrete_c, (b, MODEL.info_num_discrete_c), device=device)
-                zs = torch.cat((zs, torch.nn.functional.one_hot(disc, MODEL.info_dim_discrete_c).view(b, -1)), dim=1)
-            if info_type in ("continuous", "both"):
-                zs = torch.cat((zs, torch.rand(b, MODEL.info_num_conti_c, device=device) * 2 - 1), dim=1)
+            zs, ys = sample_latents(b, z_dim, num_classes, device, z_prior=z_prior, MODEL=MODEL)
             generator(zs, ys, eval=False)
     generator.eval()
 

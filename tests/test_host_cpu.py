@@ -422,3 +422,38 @@ def test_every_non_stylegan_reference_config_maps_to_worker_and_model_options():
         assert sum(p.numel() for p in G.parameters()) > 0 and sum(p.numel() for p in D.parameters()) > 0, name
         if CM.worker_kwargs(y)["info_type"] != "N/A":
             assert hasattr(D, "info_discrete_linear") and (hasattr(G, "info_proj_linear") or hasattr(G, "info_mix_linear")), name
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+@pytest.mark.parametrize("prior,trunc,info", [("gaussian", -1.0, "N/A"), ("gaussian", 0.7, "N/A"), ("uniform", -1.0, "N/A"), ("gaussian", -1.0, "both"),
+                                              ("gaussian", -1.0, "discrete"), ("uniform", -1.0, "continuous")])
+def test_evaluation_time_sampling_consumes_the_generators_like_the_reference(prior, trunc, info):
+    """worker.sample_latents == what the reference's sample.generate_images(is_train=False) hands the generator (src/utils/sample.py:90-118,160): same labels, latents
+    (device normal / scipy's truncated normal / host uniform) and InfoGAN codes behind z under the same torch + numpy seeds -- pure host logic, runs on the CPU."""
+    import importlib
+    import types
+    import numpy as np
+    from oracle import ref_import as R
+    from studiogan_amd.worker import sample_latents
+    R._prepare()
+    sample = importlib.import_module("utils.sample")
+    MODEL = types.SimpleNamespace(info_type=info, info_num_discrete_c=3, info_dim_discrete_c=5, info_num_conti_c=2, backbone="resnet")
+    LOSS = types.SimpleNamespace(apply_lo=False, lo_steps4train=2, lo_steps4eval=2)
+    RUN = types.SimpleNamespace(langevin_sampling=False)
+    got = {}
+
+    def gen(zs, ys, eval):
+        got["zs"], got["ys"], got["eval"] = zs.clone(), ys.clone(), eval
+        return zs
+    torch.manual_seed(11)
+    np.random.seed(12)
+    sample.generate_images(z_prior=prior, truncation_factor=trunc, batch_size=6, z_dim=16, num_classes=10, y_sampler="totally_random", radius="N/A", generator=gen,
+                           discriminator=None, is_train=False, LOSS=LOSS, RUN=RUN, MODEL=MODEL, device="cpu", is_stylegan=False, generator_mapping=None,
+                           generator_synthesis=None, style_mixing_p=0.0, stylegan_update_emas=False, cal_trsp_cost=False)
+    torch.manual_seed(11)
+    np.random.seed(12)
+    zs, ys = sample_latents(6, 16, 10, torch.device("cpu"), z_prior=prior, truncation_factor=trunc, MODEL=MODEL)
+    assert got["eval"] is True
+    assert torch.equal(ys, got["ys"]) and zs.shape == got["zs"].shape and torch.equal(zs.float(), got["zs"].float())
+    if trunc > 0:
+        assert float(zs.abs().max()) <= trunc
