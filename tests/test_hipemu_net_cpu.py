@@ -239,3 +239,18 @@ def test_emulated_run_config_tool(tmp_path, monkeypatch, capsys):
     out = json.loads(line)
     assert out["backbone"] == "resnet" and out["batch"] == 4 and out["device"] == "interpreter"
     assert out["d_loss"] == out["d_loss"] and out["g_loss"] == out["g_loss"] and abs(out["d_loss"]) < 1e4
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/configs"), reason="the reference checkout is only present in the authoring container")
+def test_emulated_architecture_parity_against_the_reference_in_fp64(monkeypatch, capsys):
+    """tools/config_parity_emulated.py on two configuration files (the sweep over all 145: profiles/r05_config_parity_emulated.txt): the REAL reference's networks, run in
+    fp64, against this package's built through config_map from the same file and loaded with the same state -- image, discriminator outputs, every first-order
+    parameter gradient and the R1 penalty with ITS parameter gradients (double backward), kernels on the interpreter."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import config_parity_emulated as T
+    monkeypatch.setattr(sys, "argv", ["config_parity_emulated.py", "--dir=CIFAR10", "--batch=4", "--r1", "SNGAN", "ReACGAN-TAC"])
+    T.main()
+    out = capsys.readouterr().out
+    rows = [ln for ln in out.splitlines() if ln.startswith(("SNGAN ", "ReACGAN-TAC "))]
+    assert len(rows) == 2 and all(" ok " in r and "MISMATCH" not in r for r in rows), out
+    assert "2 distinct architectures agree" in out
