@@ -85,7 +85,11 @@ def main():
     second = "--r1" in sys.argv[1:]
     mixed = "--bf16" in sys.argv[1:]
     L2[0] = mixed
-    tol_f, tol_g = (5e-2, 1.5e-1) if mixed else (2e-3, 2e-3)          # bf16 compute: a screen for O(1) errors in rarely-run shapes, not a precision statement
+    # --bf16: this package's bf16 networks; the bracketed / "ref" columns then hold the REFERENCE's own mixed-precision run (its modules under torch.autocast(bfloat16) on
+    # the CPU) against the same fp64 twin -- at these widths and batches of 2-4 both sit at 1e-2 .. 1 from fp64: the screen asks for "no further than twice as far as the
+    # reference's autocast run", a search for gross errors in rarely-run shapes, not a precision statement
+    tol_f, tol_g = (3e-2, 1e-1) if mixed else (2e-3, 2e-3)
+    ref_lbl = "ref autocast bf16" if mixed else "ref fp32"
     if second:
         import importlib
         from studiogan_amd import losses as SL
@@ -137,8 +141,9 @@ def main():
                 # ---- generator
                 img_r = G64(z.double(), lab)
                 (img_r * Wimg.double()).sum().backward()
-                img32 = Gr(z, lab)
-                (img32 * Wimg).sum().backward()
+                with torch.autocast("cpu", dtype=torch.bfloat16, enabled=mixed):        # --bf16: the reference's own mixed-precision run is the noise floor
+                    img32 = Gr(z, lab)
+                (img32.float() * Wimg).sum().backward()
                 img = G(z, lab)
                 (img * Wimg).sum().backward()
                 e_img = rel(img, img_r)
@@ -149,8 +154,11 @@ def main():
                 out_r = D64(x.double(), lab)
                 Wk = {k: torch.randn(out_r[k].shape, generator=g) for k in FLOAT_KEYS if torch.is_tensor(out_r.get(k)) and out_r[k].is_floating_point()}
                 sum((out_r[k] * Wk[k].double()).sum() for k in Wk).backward()
-                out32 = Dr(x, lab)
-                sum((out32[k] * Wk[k]).sum() for k in Wk).backward()
+                with torch.autocast("cpu", dtype=torch.bfloat16, enabled=mixed):
+                    out32 = Dr(x, lab)
+                sum((out32[k].float() * Wk[k]).sum() for k in Wk).backward()
+                n_img = rel(img32, img_r)
+                n_out = max(rel(out32[k], out_r[k]) for k in Wk)
                 out = D(x, lab)
                 sum((out[k] * Wk[k]).sum() for k in Wk).backward()
                 e_out, w_out = 0.0, ""
@@ -163,7 +171,7 @@ def main():
                 m_dg = worst_grad(grads(D), grads(Dr))[0]
                 worst = max(e_img, e_gg, e_out, e_dg)
                 # agreement: 2e-3, or -- where the reference's own fp32 run is further than that from its fp64 run (an ill-conditioned gradient) -- twice the reference's distance
-                good = e_img <= tol_f and e_out <= tol_f and e_gg <= max(tol_g, 2 * n_gg) and e_dg <= max(tol_g, 2 * n_dg)
+                good = e_img <= max(tol_f, 2 * n_img) and e_out <= max(tol_f, 2 * n_out) and e_gg <= max(tol_g, 2 * n_gg) and e_dg <= max(tol_g, 2 * n_dg)
                 r1_txt = ""
                 if second:          # ---- R1 (reference src/utils/losses.py:355-361 over cal_deriv :301-316): the double backward of every discriminator family
                     vals, gr = [], []
@@ -179,15 +187,15 @@ def main():
                     n_r1g = worst_grad(gr[1], gr[0])[0]
                     worst = max(worst, e_r1, e_r1g)
                     good = good and e_r1 <= tol_f and e_r1g <= max(tol_g, 2 * n_r1g)
-                    r1_txt = f"  R1 {e_r1:.1e} its D grads {e_r1g:.1e} (ref fp32: {n_r1g:.1e})"
+                    r1_txt = f"  R1 {e_r1:.1e} its D grads {e_r1g:.1e} ({ref_lbl}: {n_r1g:.1e})"
                     w_dg = w_dg + " / r1:" + w_r1g
                 worst_all = max(worst_all, worst)
                 n_ok += good
                 n_bad += not good
                 M = y["MODEL"]
                 print(f"{name:26s} {M.get('backbone', 'resnet'):26s} {S:4d}px g_cond {M.get('g_cond_mtd', 'W/O'):4s} d_cond {M.get('d_cond_mtd', 'W/O'):6s} aux {M.get('aux_cls_type', 'W/O'):4s} "
-                      f"attn {str(M.get('apply_attn', False)):5s} info {M.get('info_type', 'N/A'):10s} | image {e_img:.1e}  G grads {e_gg:.1e} (ref fp32: {n_gg:.1e}, to it: {m_gg:.1e})  D outputs({len(Wk)}) {e_out:.1e} [{w_out}]  "
-                      f"D grads {e_dg:.1e} (ref fp32: {n_dg:.1e}, to it: {m_dg:.1e}){r1_txt} {'ok' if good else 'MISMATCH ' + w_gg + ' / ' + w_dg} {time.time() - t:5.1f} s")
+                      f"attn {str(M.get('apply_attn', False)):5s} info {M.get('info_type', 'N/A'):10s} | image {e_img:.1e} ({n_img:.1e})  G grads {e_gg:.1e} ({ref_lbl}: {n_gg:.1e}, to it: {m_gg:.1e})  D outputs({len(Wk)}) {e_out:.1e} ({n_out:.1e}) [{w_out}]  "
+                      f"D grads {e_dg:.1e} ({ref_lbl}: {n_dg:.1e}, to it: {m_dg:.1e}){r1_txt} {'ok' if good else 'MISMATCH ' + w_gg + ' / ' + w_dg} {time.time() - t:5.1f} s")
             except Exception as e:      # noqa: BLE001
                 n_bad += 1
                 print(f"{name:26s} FAILED {type(e).__name__}: {str(e)[:300]}")
