@@ -1,0 +1,228 @@
+"""Training-step parity of EVERY non-StyleGAN configuration file against the reference's OWN worker code: the unmodified `WORKER.train_discriminator` and
+`WORKER.train_generator` of reference src/worker.py:213-681 are run on the CPU (a WORKER object built by the reference's constructor with local_rank="cpu", the
+reference's Configurations / define_losses / define_augments / define_optimizer, the reference's networks, Adam and EMA) and, from the same initial state, the same real
+batches and the same torch seed, this package's `worker.Worker` built through `config_map.build` runs its two methods with the kernel SOURCES on the CPU interpreter.
+Both consume the CPU generator in the same order (latents, labels, InfoGAN codes, DiffAugment / ADA / CR / APA draws, gradient-penalty interpolation, LOGAN's masks), so
+no draw is injected or replayed; the only adaptation is that this package's latent sampler is switched to the reference's order of its two draws (labels first).
+
+Compared per configuration: the discriminator loss of the last of TWO discriminator updates (the first one's Adam step lies in between), every discriminator parameter
+gradient of that update and every discriminator parameter after both steps (+ weight clipping); the generator loss, every generator parameter gradient and every
+generator parameter after its step; the ADA / APA probability after the heuristic. Channel widths cut to 8; image sizes, class counts, heads, losses, regularisers and
+augmentations as the file says (ADA / APA strength raised from the files' 0.0 so that the pipelines actually fire).
+   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+import copy
+import glob
+import importlib
+import os
+import sys
+import time
+
+import torch
+import yaml
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+N_D = 2
+
+
+def rel(a, b, floor=0.0):
+    a, b = a.detach().double().reshape(-1), b.detach().double().reshape(-1)
+    return float((a - b).abs().max() / max(float(b.abs().max()), floor, 1e-30))
+
+
+def worst(mine, ref, frac=1e-2):
+    top = max(float(v.abs().max()) for v in ref.values())
+    w, where = 0.0, ""
+    for k, g in ref.items():
+        e = rel(mine[k], g, floor=frac * top)
+        if e > w:
+            w, where = e, k
+    return w, where
+
+
+def grads(net):
+    return {k: (p.grad.detach().clone() if p.grad is not None else torch.zeros_like(p)) for k, p in net.named_parameters()}
+
+
+def params(net):
+    return {k: p.detach().clone() for k, p in net.named_parameters()}
+
+
+class Loader:
+    """what the reference's DataLoader hands sample_data_basket: (images [n_d * acml * B, 3, S, S], labels) per draw"""
+
+    def __init__(self, baskets):
+        self.baskets = baskets
+
+    def __iter__(self):
+        return iter(self.baskets)
+
+
+def reference_worker(R, cfgs, Gr, Dr, baskets, aa_p):
+    """the reference's WORKER built by ITS constructor on the CPU (global_rank 1: no wandb session)"""
+    R._prepare()
+    W = importlib.import_module("worker")
+    ema_mod = importlib.import_module("utils.ema")
+    RUN = cfgs.RUN
+    for k, v in dict(mixed_precision=False, distributed_data_parallel=False, synchronized_bn=False, freezeD=-1, empty_cache=False, langevin_sampling=False,
+                     batch_statistics=False, train=True, project="x", entity="x", save_dir="/tmp").items():
+        setattr(RUN, k, v)
+    cfgs.OPTIMIZATION.world_size = 1
+    Gema, ema = None, None
+    if cfgs.MODEL.apply_g_ema:
+        Gema = copy.deepcopy(Gr)
+        ema = ema_mod.Ema(source=Gr, target=Gema, decay=cfgs.MODEL.g_ema_decay, start_iter=cfgs.MODEL.g_ema_start)
+    cfgs.define_optimizer(Gr, Dr)
+    w = W.WORKER(cfgs=cfgs, run_name="sweep", Gen=Gr, Gen_mapping=None, Gen_synthesis=None, Dis=Dr, Gen_ema=Gema, Gen_ema_mapping=None, Gen_ema_synthesis=None,
+                 ema=ema, eval_model=None, train_dataloader=Loader(baskets), eval_dataloader=None, global_rank=1, local_rank="cpu", mu=None, sigma=None, real_feats=None,
+                 logger=None, aa_p=aa_p, best_step=0, best_fid=None, best_ckpt_path=None, lecam_emas=None, num_eval={}, loss_list_dict={}, metric_dict_during_train={})
+    for name in ("cond_loss", "cond_loss_mi"):          # (the constructor hard-codes master_rank="cuda" for the contrastive losses' masks)
+        if hasattr(w, name) and hasattr(getattr(w, name), "master_rank"):
+            getattr(w, name).master_rank = "cpu"
+    w.topk = cfgs.OPTIMIZATION.batch_size
+    w.prepare_train_iter(0)
+    return w, Gema
+
+
+def main():
+    import fullemu
+    from oracle import ref_import as R
+    import studiogan_amd  # noqa: F401
+    from studiogan_amd import config_map as CM
+    from studiogan_amd import worker as SW
+    from config_parity_emulated import shrink
+    data = next((a[6:] for a in sys.argv[1:] if a.startswith("--dir=")), "CIFAR10")
+    batch = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--batch=")), "4"))
+    only = set(a for a in sys.argv[1:] if not a.startswith("--"))
+    global N_D
+    N_D = int(next((a[5:] for a in sys.argv[1:] if a.startswith("--nd=")), str(N_D)))
+    seed = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--seed=")), "77"))
+    files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
+    torch.set_num_threads(1)
+    dev = torch.device("cpu")
+    uniform = [False]
+
+    def sample_zy_reference_order(batch_size, z_dim, num_classes, device, generator=None):
+        ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device)
+        zs = None if uniform[0] else torch.randn(batch_size, z_dim, device=device)      # (the uniform prior is drawn by the caller, as in the reference)
+        return zs, ys
+    SW.sample_zy = sample_zy_reference_order
+    n_ok = n_bad = 0
+    worst_all = 0.0
+    with fullemu.Installed(dma_late=1, greedy=1, seed=1):
+        for f in files:
+            name = os.path.basename(f)[:-5]
+            y = yaml.safe_load(open(f))
+            if "stylegan" in (y.get("MODEL") or {}).get("backbone", "resnet") or (only and name not in only):
+                continue
+            y = shrink(y)
+            y.setdefault("OPTIMIZATION", {}).update(batch_size=batch, d_updates_per_step=N_D, acml_steps=1)
+            A = y.setdefault("AUG", {})
+            if A.get("apply_ada"):
+                A["ada_initial_augment_p"], A["ada_interval"] = 0.6, 1
+            if A.get("apply_apa"):
+                A["apa_initial_augment_p"], A["apa_interval"] = 0.5, 1
+            if (y.get("LOSS") or {}).get("apply_lecam"):
+                y["LOSS"]["lecam_ema_start_iter"] = 0          # (the files start the regulariser after 1000 steps: here it is live at step 1)
+            t = time.time()
+            try:
+                torch.manual_seed(0)
+                cfgs = R.load_cfgs({k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")})
+                Gr, Dr = R.build_models(cfgs)
+                g_state, d_state = copy.deepcopy(Gr.state_dict()), copy.deepcopy(Dr.state_dict())
+                kw = CM.worker_kwargs(y)
+                S, nc = (y.get("DATA") or {}).get("img_size", 32), kw["num_classes"]
+                uniform[0] = kw["z_prior"] == "uniform"
+                g = torch.Generator().manual_seed(11)
+                baskets = [(torch.randint(0, 256, (N_D * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (N_D * batch,), generator=g)) for _ in range(2)]
+                aa_p = A.get("ada_initial_augment_p", "N/A") if A.get("apply_ada") else A.get("apa_initial_augment_p", "N/A") if A.get("apply_apa") else "N/A"
+                step = 1
+                # ---- the reference's worker
+                rw, _ = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p)
+                torch.manual_seed(seed)
+                _, d_loss_r = rw.train_discriminator(step)
+                dg_r, dp_r = grads(Dr), params(Dr)
+                g_loss_r = rw.train_generator(step)
+                gg_r, gp_r = grads(Gr), params(Gr)
+                aa_r = float(rw.aa_p) if aa_p != "N/A" else None
+                # ---- this package's
+                G, D, w = CM.build(y, dev)
+                G.load_state_dict(g_state, strict=True)
+                D.load_state_dict(d_state, strict=True)
+                if w.Gen_ema is not None:
+                    w.Gen_ema.load_state_dict(g_state, strict=True)
+                reals = [(baskets[0][0][i * batch:(i + 1) * batch], baskets[0][1][i * batch:(i + 1) * batch]) for i in range(N_D)]
+                torch.manual_seed(seed)
+                d_loss = w.train_discriminator(step, reals)
+                dg, dp = grads(D), params(D)
+                g_loss = w.train_generator(step, real_batches=[(baskets[1][0][:batch], baskets[1][1][:batch])] if kw["apply_fm"] else None)
+                gg, gp = grads(G), params(G)
+                d_loss, d_loss_r, g_loss, g_loss_r = d_loss.detach(), d_loss_r.detach(), g_loss.detach(), g_loss_r.detach()
+                e_dl = abs(float(d_loss) - float(d_loss_r)) / max(abs(float(d_loss_r)), 1e-3)
+                e_gl = abs(float(g_loss) - float(g_loss_r)) / max(abs(float(g_loss_r)), 1e-3)
+                e_dg, w_dg = worst(dg, dg_r)
+                e_gg, w_gg = worst(gg, gg_r)
+                if "--verbose" in sys.argv[1:]:
+                    for tag, a, b in (("D", dg, dg_r), ("G", gg, gg_r)):
+                        top = max(float(v.abs().max()) for v in b.values())
+                        rows = sorted(((rel(a[k], b[k], floor=1e-2 * top), float((a[k] - b[k]).norm() / max(float(b[k].norm()), 1e-30)), float(b[k].abs().max()) / top, k) for k in b), reverse=True)[:6]
+                        for r in rows:
+                            print(f"    {tag} grad  max-rel {r[0]:.2e}  l2-rel {r[1]:.2e}  |g|/top {r[2]:.1e}  {r[3]}")
+                lr_d, lr_g = kw["d_lr"], kw["g_lr"]
+                # parameters after Adam: an element whose gradient is rounding noise moves by about +-lr per step with a sign two correct implementations need not share
+                # (printed in units of lr per step; bound 3: Adam's bias-corrected step can exceed lr in its first steps)
+                e_dp = max(float((dp[k] - dp_r[k]).abs().max()) for k in dp_r) / (N_D * lr_d)
+                e_gp = max(float((gp[k] - gp_r[k]).abs().max()) for k in gp_r) / lr_g
+                aa_txt, aa_ok = "", True
+                if aa_r is not None:
+                    aa_mine = float(w.aa_p)
+                    aa_ok = abs(aa_mine - aa_r) <= 1e-6
+                    aa_txt = f"  aa_p {aa_mine:.4f} / {aa_r:.4f}"
+                ok_first = e_dl <= 2e-3 and e_gl <= 2e-3 and e_dg <= 1e-2 and e_gg <= 1e-2 and e_dp <= 3.0 and e_gp <= 3.0 and aa_ok
+                good, cond_txt = ok_first, ""
+                if not ok_first and aa_ok and e_dl <= 2e-3 and e_gl <= 2e-3:
+                    # losses agree, gradients do not: is THIS input ill-conditioned (a ReLU pre-activation within rounding distance of zero in a small early layer)? The
+                    # reference's own movement under a perturbation of its initial weights by one fp32 rounding step (2e-7 relative) answers it: at a regular point the
+                    # gradients move by ~1e-6, at a tie by as much as two correct implementations differ
+                    n_dg = n_gg = 0.0
+                    for trial in range(8):          # (one perturbation lands on the other side of a tie about every second or third time)
+                        torch.manual_seed(0)
+                        cfgs2 = R.load_cfgs({k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")})
+                        G2, D2 = R.build_models(cfgs2)
+                        G2.load_state_dict(g_state, strict=True)
+                        D2.load_state_dict(d_state, strict=True)
+                        gp_ = torch.Generator().manual_seed(5 + trial)
+                        with torch.no_grad():
+                            for prm in list(G2.parameters()) + list(D2.parameters()):
+                                prm.mul_(1.0 + 2e-7 * torch.randn(prm.shape, generator=gp_))
+                        rw2, _ = reference_worker(R, cfgs2, G2, D2, baskets, aa_p)
+                        torch.manual_seed(seed)
+                        rw2.train_discriminator(step)
+                        n_dg = max(n_dg, worst(grads(D2), dg_r)[0])
+                        rw2.train_generator(step)
+                        n_gg = max(n_gg, worst(grads(G2), gg_r)[0])
+                    good = e_dg <= max(1e-2, 3 * n_dg) and e_gg <= max(1e-2, 3 * n_gg)
+                    cond_txt = f"  [ill-conditioned input: the reference's own gradients move by D {n_dg:.1e} / G {n_gg:.1e} under 2e-7 perturbations of its weights (worst of 8)]"
+                n_ok += good
+                n_bad += not good
+                worst_all = max(worst_all, e_dl, e_gl, e_dg, e_gg)
+                flags = [k[6:] for k, v in kw.items() if k.startswith("apply_") and v and k != "apply_g_ema"] + ([f"info:{kw['info_type']}"] if kw["info_type"] != "N/A" else [])
+                print(f"{name:26s} {kw['adv_loss']:12s} {kw['d_cond_mtd']:6s} {kw['aux_cls_type']:4s} {','.join(flags):24s} | D loss {float(d_loss):+.5e} ({e_dl:.1e})  D grads {e_dg:.1e}  "
+                      f"D params {e_dp:.2f} lr  | G loss {float(g_loss):+.5e} ({e_gl:.1e})  G grads {e_gg:.1e}  G params {e_gp:.2f} lr{aa_txt}{cond_txt}  "
+                      f"{'ok' if good else 'MISMATCH ' + w_dg + ' / ' + w_gg} {time.time() - t:5.1f} s")
+            except Exception as e:      # noqa: BLE001
+                n_bad += 1
+                import traceback
+                tb = traceback.extract_tb(e.__traceback__)[-1]
+                print(f"{name:26s} FAILED {type(e).__name__}: {str(e)[:240]}  [{os.path.basename(tb.filename)}:{tb.lineno}]")
+            sys.stdout.flush()
+    print(f"# {data}: {n_ok} configuration files: this package's training step agrees with the reference's own WORKER.train_discriminator / train_generator run on the CPU "
+          f"(losses <= 2e-3, gradients <= 1e-2 of the largest; worst {worst_all:.1e}), {n_bad} do not")
+
+
+if __name__ == "__main__":
+    main()
