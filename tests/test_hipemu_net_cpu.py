@@ -254,3 +254,19 @@ def test_emulated_architecture_parity_against_the_reference_in_fp64(monkeypatch,
     rows = [ln for ln in out.splitlines() if ln.startswith(("SNGAN ", "ReACGAN-TAC "))]
     assert len(rows) == 2 and all(" ok " in r and "MISMATCH" not in r for r in rows), out
     assert "2 distinct architectures agree" in out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/configs"), reason="the reference checkout is only present in the authoring container")
+def test_emulated_training_step_against_the_references_own_worker(monkeypatch, capsys):
+    """tools/config_worker_parity_emulated.py on two configuration files (the sweep over all of them: profiles/r05_config_worker_parity_emulated.txt): the reference's
+    UNMODIFIED WORKER.train_discriminator / train_generator (src/worker.py:213-681), run on the CPU from the reference's own constructor, against this package's Worker
+    from the same state, real batches and torch seed -- both consume the generator identically, no draw is injected: two discriminator updates (Adam in between) and one
+    generator update of SNGAN + DiffAugment + LeCam and of ReACGAN (D2D-CE head) + adaptive augmentation, kernels on the interpreter."""
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import config_worker_parity_emulated as T
+    monkeypatch.setattr(sys, "argv", ["config_worker_parity_emulated.py", "--dir=CIFAR10", "--batch=4", "SNGAN-DiffAug-LeCam", "ReACGAN-ADA"])
+    T.main()
+    out = capsys.readouterr().out
+    rows = [ln for ln in out.splitlines() if ln.startswith(("SNGAN-DiffAug-LeCam ", "ReACGAN-ADA "))]
+    assert len(rows) == 2 and all(r.rstrip().split("  ")[-2].strip().endswith("ok") or " ok " in r for r in rows) and not any("MISMATCH" in r or "FAILED" in r for r in rows), out
+    assert "2 configuration files" in out

@@ -156,16 +156,18 @@ def main():
                 n_gg = worst_grad(grads(Gr), grads(G64))[0]
                 m_gg = worst_grad(grads(G), grads(Gr))[0]
                 # ---- discriminator
-                out_r = D64(x.double(), lab)
+                x64, x32, xm = x.double().requires_grad_(True), x.clone().requires_grad_(True), x.clone().requires_grad_(True)      # (+ the gradient w.r.t. the images:
+                out_r = D64(x64, lab)                                                                                               #  what the generator update receives)
                 Wk = {k: torch.randn(out_r[k].shape, generator=g) for k in FLOAT_KEYS if torch.is_tensor(out_r.get(k)) and out_r[k].is_floating_point()}
                 sum((out_r[k] * Wk[k].double()).sum() for k in Wk).backward()
                 with torch.autocast("cpu", dtype=torch.bfloat16, enabled=mixed):
-                    out32 = Dr(x, lab)
+                    out32 = Dr(x32, lab)
                 sum((out32[k].float() * Wk[k]).sum() for k in Wk).backward()
                 n_img = rel(img32, img_r)
                 n_out = max(rel(out32[k], out_r[k]) for k in Wk)
-                out = D(x, lab)
+                out = D(xm, lab)
                 sum((out[k] * Wk[k]).sum() for k in Wk).backward()
+                e_dx, n_dx = rel(xm.grad, x64.grad), rel(x32.grad, x64.grad)
                 e_out, w_out = 0.0, ""
                 for k in Wk:
                     e = rel(out[k], out_r[k])
@@ -174,9 +176,9 @@ def main():
                 e_dg, w_dg = worst_grad(grads(D), grads(D64))
                 n_dg = worst_grad(grads(Dr), grads(D64))[0]
                 m_dg = worst_grad(grads(D), grads(Dr))[0]
-                worst = max(e_img, e_gg, e_out, e_dg)
+                worst = max(e_img, e_gg, e_out, e_dg, e_dx)
                 # agreement: 2e-3, or -- where the reference's own fp32 run is further than that from its fp64 run (an ill-conditioned gradient) -- twice the reference's distance
-                good = e_img <= max(tol_f, 2 * n_img) and e_out <= max(tol_f, 2 * n_out) and e_gg <= max(tol_g, 2 * n_gg) and e_dg <= max(tol_g, 2 * n_dg)
+                good = e_img <= max(tol_f, 2 * n_img) and e_out <= max(tol_f, 2 * n_out) and e_dx <= max(tol_g, 2 * n_dx) and e_gg <= max(tol_g, 2 * n_gg) and e_dg <= max(tol_g, 2 * n_dg)
                 r1_txt = ""
                 if second:          # ---- R1 (reference src/utils/losses.py:355-361 over cal_deriv :301-316): the double backward of every discriminator family
                     vals, gr = [], []
@@ -200,7 +202,7 @@ def main():
                 M = y["MODEL"]
                 print(f"{name:26s} {M.get('backbone', 'resnet'):26s} {S:4d}px g_cond {M.get('g_cond_mtd', 'W/O'):4s} d_cond {M.get('d_cond_mtd', 'W/O'):6s} aux {M.get('aux_cls_type', 'W/O'):4s} "
                       f"attn {str(M.get('apply_attn', False)):5s} info {M.get('info_type', 'N/A'):10s} | image {e_img:.1e} ({n_img:.1e})  G grads {e_gg:.1e} ({ref_lbl}: {n_gg:.1e}, to it: {m_gg:.1e})  D outputs({len(Wk)}) {e_out:.1e} ({n_out:.1e}) [{w_out}]  "
-                      f"D grads {e_dg:.1e} ({ref_lbl}: {n_dg:.1e}, to it: {m_dg:.1e}){r1_txt} {'ok' if good else 'MISMATCH ' + w_gg + ' / ' + w_dg} {time.time() - t:5.1f} s")
+                      f"D grads {e_dg:.1e} ({ref_lbl}: {n_dg:.1e}, to it: {m_dg:.1e})  dD/dx {e_dx:.1e} ({n_dx:.1e}){r1_txt} {'ok' if good else 'MISMATCH ' + w_gg + ' / ' + w_dg} {time.time() - t:5.1f} s")
             except Exception as e:      # noqa: BLE001
                 n_bad += 1
                 print(f"{name:26s} FAILED {type(e).__name__}: {str(e)[:300]}")
