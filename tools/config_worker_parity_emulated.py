@@ -9,7 +9,7 @@ Compared per configuration: the discriminator loss of the last of TWO discrimina
 gradient of that update and every discriminator parameter after both steps (+ weight clipping); the generator loss, every generator parameter gradient and every
 generator parameter after its step; the ADA / APA probability after the heuristic. Channel widths cut to 8; image sizes, class counts, heads, losses, regularisers and
 augmentations as the file says (ADA / APA strength raised from the files' 0.0 so that the pipelines actually fire).
-   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
 import copy
 import glob
 import importlib
@@ -101,6 +101,7 @@ def main():
     global N_D
     N_D = int(next((a[5:] for a in sys.argv[1:] if a.startswith("--nd=")), str(N_D)))
     seed = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--seed=")), "77"))
+    acml = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--acml=")), "1"))          # gradient accumulation (OPTIMIZATION.acml_steps): micro-batches per update
     files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
     dev = torch.device("cpu")
@@ -120,7 +121,7 @@ def main():
             if "stylegan" in (y.get("MODEL") or {}).get("backbone", "resnet") or (only and name not in only):
                 continue
             y = shrink(y)
-            y.setdefault("OPTIMIZATION", {}).update(batch_size=batch, d_updates_per_step=N_D, acml_steps=1)
+            y.setdefault("OPTIMIZATION", {}).update(batch_size=batch, d_updates_per_step=N_D, acml_steps=acml)
             A = y.setdefault("AUG", {})
             if A.get("apply_ada"):
                 A["ada_initial_augment_p"], A["ada_interval"] = 0.6, 1
@@ -138,7 +139,8 @@ def main():
                 S, nc = (y.get("DATA") or {}).get("img_size", 32), kw["num_classes"]
                 uniform[0] = kw["z_prior"] == "uniform"
                 g = torch.Generator().manual_seed(11)
-                baskets = [(torch.randint(0, 256, (N_D * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (N_D * batch,), generator=g)) for _ in range(2)]
+                nb = N_D * acml
+                baskets = [(torch.randint(0, 256, (nb * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (nb * batch,), generator=g)) for _ in range(1 + acml)]
                 aa_p = A.get("ada_initial_augment_p", "N/A") if A.get("apply_ada") else A.get("apa_initial_augment_p", "N/A") if A.get("apply_apa") else "N/A"
                 step = 1
                 # ---- the reference's worker
@@ -155,11 +157,11 @@ def main():
                 D.load_state_dict(d_state, strict=True)
                 if w.Gen_ema is not None:
                     w.Gen_ema.load_state_dict(g_state, strict=True)
-                reals = [(baskets[0][0][i * batch:(i + 1) * batch], baskets[0][1][i * batch:(i + 1) * batch]) for i in range(N_D)]
+                reals = [(baskets[0][0][i * batch:(i + 1) * batch], baskets[0][1][i * batch:(i + 1) * batch]) for i in range(nb)]
                 torch.manual_seed(seed)
                 d_loss = w.train_discriminator(step, reals)
                 dg, dp = grads(D), params(D)
-                g_loss = w.train_generator(step, real_batches=[(baskets[1][0][:batch], baskets[1][1][:batch])] if kw["apply_fm"] else None)
+                g_loss = w.train_generator(step, real_batches=[(baskets[1 + i][0][:batch], baskets[1 + i][1][:batch]) for i in range(acml)] if kw["apply_fm"] else None)
                 gg, gp = grads(G), params(G)
                 d_loss, d_loss_r, g_loss, g_loss_r = d_loss.detach(), d_loss_r.detach(), g_loss.detach(), g_loss_r.detach()
                 e_dl = abs(float(d_loss) - float(d_loss_r)) / max(abs(float(d_loss_r)), 1e-3)
