@@ -9,7 +9,7 @@ Compared per configuration: the discriminator loss of the last of TWO discrimina
 gradient of that update and every discriminator parameter after both steps (+ weight clipping); the generator loss, every generator parameter gradient and every
 generator parameter after its step; the ADA / APA probability after the heuristic. Channel widths cut to 8; image sizes, class counts, heads, losses, regularisers and
 augmentations as the file says (ADA / APA strength raised from the files' 0.0 so that the pipelines actually fire).
-   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--steps=1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
 import copy
 import glob
 import importlib
@@ -101,6 +101,7 @@ def main():
     global N_D
     N_D = int(next((a[5:] for a in sys.argv[1:] if a.startswith("--nd=")), str(N_D)))
     seed = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--seed=")), "77"))
+    n_steps = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--steps=")), "1"))      # consecutive steps (the comparison is made after the last one)
     acml = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--acml=")), "1"))          # gradient accumulation (OPTIMIZATION.acml_steps): micro-batches per update
     files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
@@ -140,16 +141,18 @@ def main():
                 uniform[0] = kw["z_prior"] == "uniform"
                 g = torch.Generator().manual_seed(11)
                 nb = N_D * acml
-                baskets = [(torch.randint(0, 256, (nb * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (nb * batch,), generator=g)) for _ in range(1 + acml)]
+                baskets = [(torch.randint(0, 256, (nb * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (nb * batch,), generator=g)) for _ in range(n_steps * (1 + acml))]
                 aa_p = A.get("ada_initial_augment_p", "N/A") if A.get("apply_ada") else A.get("apa_initial_augment_p", "N/A") if A.get("apply_apa") else "N/A"
-                step = 1
+                fm = kw["apply_fm"]
+                per_step = 1 + (acml if fm else 0)          # baskets a step draws: one for its discriminator updates, one per micro-step of the feature-matching term
                 # ---- the reference's worker
-                rw, _ = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p)
+                rw, Gema_r = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p)
                 torch.manual_seed(seed)
-                _, d_loss_r = rw.train_discriminator(step)
-                dg_r, dp_r = grads(Dr), params(Dr)
-                g_loss_r = rw.train_generator(step)
-                gg_r, gp_r = grads(Gr), params(Gr)
+                for step in range(1, n_steps + 1):
+                    _, d_loss_r = rw.train_discriminator(step)
+                    dg_r, dp_r = grads(Dr), params(Dr)
+                    g_loss_r = rw.train_generator(step)
+                    gg_r, gp_r = grads(Gr), params(Gr)
                 aa_r = float(rw.aa_p) if aa_p != "N/A" else None
                 # ---- this package's
                 G, D, w = CM.build(y, dev)
@@ -157,12 +160,14 @@ def main():
                 D.load_state_dict(d_state, strict=True)
                 if w.Gen_ema is not None:
                     w.Gen_ema.load_state_dict(g_state, strict=True)
-                reals = [(baskets[0][0][i * batch:(i + 1) * batch], baskets[0][1][i * batch:(i + 1) * batch]) for i in range(nb)]
                 torch.manual_seed(seed)
-                d_loss = w.train_discriminator(step, reals)
-                dg, dp = grads(D), params(D)
-                g_loss = w.train_generator(step, real_batches=[(baskets[1 + i][0][:batch], baskets[1 + i][1][:batch]) for i in range(acml)] if kw["apply_fm"] else None)
-                gg, gp = grads(G), params(G)
+                for step in range(1, n_steps + 1):
+                    b0 = (step - 1) * per_step
+                    reals = [(baskets[b0][0][i * batch:(i + 1) * batch], baskets[b0][1][i * batch:(i + 1) * batch]) for i in range(nb)]
+                    d_loss = w.train_discriminator(step, reals)
+                    dg, dp = grads(D), params(D)
+                    g_loss = w.train_generator(step, real_batches=[(baskets[b0 + 1 + i][0][:batch], baskets[b0 + 1 + i][1][:batch]) for i in range(acml)] if fm else None)
+                    gg, gp = grads(G), params(G)
                 d_loss, d_loss_r, g_loss, g_loss_r = d_loss.detach(), d_loss_r.detach(), g_loss.detach(), g_loss_r.detach()
                 e_dl = abs(float(d_loss) - float(d_loss_r)) / max(abs(float(d_loss_r)), 1e-3)
                 e_gl = abs(float(g_loss) - float(g_loss_r)) / max(abs(float(g_loss_r)), 1e-3)
@@ -177,13 +182,21 @@ def main():
                 lr_d, lr_g = kw["d_lr"], kw["g_lr"]
                 # parameters after Adam: an element whose gradient is rounding noise moves by about +-lr per step with a sign two correct implementations need not share
                 # (printed in units of lr per step; bound 3: Adam's bias-corrected step can exceed lr in its first steps)
-                e_dp = max(float((dp[k] - dp_r[k]).abs().max()) for k in dp_r) / (N_D * lr_d)
-                e_gp = max(float((gp[k] - gp_r[k]).abs().max()) for k in gp_r) / lr_g
+                e_dp = max(float((dp[k] - dp_r[k]).abs().max()) for k in dp_r) / (N_D * n_steps * lr_d)
+                e_gp = max(float((gp[k] - gp_r[k]).abs().max()) for k in gp_r) / (n_steps * lr_g)
                 aa_txt, aa_ok = "", True
+                if Gema_r is not None and w.Gen_ema is not None:          # the EMA twin (reference src/utils/ema.py:27-40): parameters in units of lr per step, buffers relative
+                    pe, pr = dict(w.Gen_ema.named_parameters()), dict(Gema_r.named_parameters())
+                    e_ema = max(float((pe[k].detach() - pr[k].detach()).abs().max()) for k in pr) / (n_steps * lr_g)
+                    be, br = dict(w.Gen_ema.named_buffers()), dict(Gema_r.named_buffers())
+                    e_emb = max([rel(be[k].float(), br[k].float(), floor=1e-3) for k in br if "num_batches" not in k and k in be] + [0.0])
+                    nb_ok = all(int(be[k]) == int(br[k]) for k in br if "num_batches" in k and k in be)
+                    aa_ok = e_ema <= 3.0 and e_emb <= 1e-3 and nb_ok
+                    aa_txt = f"  EMA {e_ema:.2f} lr, buffers {e_emb:.1e}"
                 if aa_r is not None:
                     aa_mine = float(w.aa_p)
-                    aa_ok = abs(aa_mine - aa_r) <= 1e-6
-                    aa_txt = f"  aa_p {aa_mine:.4f} / {aa_r:.4f}"
+                    aa_ok = aa_ok and abs(aa_mine - aa_r) <= 1e-6
+                    aa_txt += f"  aa_p {aa_mine:.6f} / {aa_r:.6f}"
                 ok_first = e_dl <= 2e-3 and e_gl <= 2e-3 and e_dg <= 1e-2 and e_gg <= 1e-2 and e_dp <= 3.0 and e_gp <= 3.0 and aa_ok
                 good, cond_txt = ok_first, ""
                 if not ok_first and aa_ok and e_dl <= 2e-3 and e_gl <= 2e-3:
