@@ -9,7 +9,7 @@ Compared per configuration: the discriminator loss of the last of TWO discrimina
 gradient of that update and every discriminator parameter after both steps (+ weight clipping); the generator loss, every generator parameter gradient and every
 generator parameter after its step; the ADA / APA probability after the heuristic. Channel widths cut to 8; image sizes, class counts, heads, losses, regularisers and
 augmentations as the file says (ADA / APA strength raised from the files' 0.0 so that the pipelines actually fire).
-   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--steps=1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--steps=1] [--freezeD=-1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
 import copy
 import glob
 import importlib
@@ -62,13 +62,13 @@ class Loader:
         return iter(self.baskets)
 
 
-def reference_worker(R, cfgs, Gr, Dr, baskets, aa_p):
+def reference_worker(R, cfgs, Gr, Dr, baskets, aa_p, freeze_d=-1):
     """the reference's WORKER built by ITS constructor on the CPU (global_rank 1: no wandb session)"""
     R._prepare()
     W = importlib.import_module("worker")
     ema_mod = importlib.import_module("utils.ema")
     RUN = cfgs.RUN
-    for k, v in dict(mixed_precision=False, distributed_data_parallel=False, synchronized_bn=False, freezeD=-1, empty_cache=False, langevin_sampling=False,
+    for k, v in dict(mixed_precision=False, distributed_data_parallel=False, synchronized_bn=False, freezeD=freeze_d, empty_cache=False, langevin_sampling=False,
                      batch_statistics=False, train=True, project="x", entity="x", save_dir="/tmp").items():
         setattr(RUN, k, v)
     cfgs.OPTIMIZATION.world_size = 1
@@ -102,6 +102,7 @@ def main():
     N_D = int(next((a[5:] for a in sys.argv[1:] if a.startswith("--nd=")), str(N_D)))
     seed = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--seed=")), "77"))
     n_steps = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--steps=")), "1"))      # consecutive steps (the comparison is made after the last one)
+    freeze_d = int(next((a[10:] for a in sys.argv[1:] if a.startswith("--freezeD=")), "-1"))      # RUN.freezeD: the first N discriminator blocks frozen (src/utils/misc.py:190-216)
     acml = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--acml=")), "1"))          # gradient accumulation (OPTIMIZATION.acml_steps): micro-batches per update
     files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
@@ -146,7 +147,7 @@ def main():
                 fm = kw["apply_fm"]
                 per_step = 1 + (acml if fm else 0)          # baskets a step draws: one for its discriminator updates, one per micro-step of the feature-matching term
                 # ---- the reference's worker
-                rw, Gema_r = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p)
+                rw, Gema_r = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p, freeze_d)
                 torch.manual_seed(seed)
                 for step in range(1, n_steps + 1):
                     _, d_loss_r = rw.train_discriminator(step)
@@ -156,6 +157,7 @@ def main():
                 aa_r = float(rw.aa_p) if aa_p != "N/A" else None
                 # ---- this package's
                 G, D, w = CM.build(y, dev)
+                w.freezeD = freeze_d
                 G.load_state_dict(g_state, strict=True)
                 D.load_state_dict(d_state, strict=True)
                 if w.Gen_ema is not None:
@@ -216,7 +218,7 @@ def main():
                         with torch.no_grad():
                             for prm in list(G2.parameters()) + list(D2.parameters()):
                                 prm.mul_(1.0 + 2e-6 * torch.randn(prm.shape, generator=gp_))
-                        rw2, _ = reference_worker(R, cfgs2, G2, D2, baskets, aa_p)
+                        rw2, _ = reference_worker(R, cfgs2, G2, D2, baskets, aa_p, freeze_d)
                         torch.manual_seed(seed)
                         rw2.train_discriminator(step)
                         n_dg = max(n_dg, worst(grads(D2), dg_r)[0])
