@@ -173,6 +173,12 @@ def main():
                 d_loss, d_loss_r, g_loss, g_loss_r = d_loss.detach(), d_loss_r.detach(), g_loss.detach(), g_loss_r.detach()
                 e_dl = abs(float(d_loss) - float(d_loss_r)) / max(abs(float(d_loss_r)), 1e-3)
                 e_gl = abs(float(g_loss) - float(g_loss_r)) / max(abs(float(g_loss_r)), 1e-3)
+                if kw["info_type"] != "N/A":
+                    # InfoGAN's Q heads sit in the GENERATOR's optimiser (src/config.py:499-517): in a discriminator update they are frozen and their .grad is whatever the
+                    # last generator update left (the reference) or zero (this package's fused discriminator Adam walks over them with exact zeros) -- not a gradient of
+                    # this update on either side
+                    for k in [k for k in dg_r if k.startswith(("info_discrete_linear", "info_conti_mu_linear", "info_conti_var_linear"))]:
+                        dg_r.pop(k), dg.pop(k)
                 e_dg, w_dg = worst(dg, dg_r)
                 e_gg, w_gg = worst(gg, gg_r)
                 if "--verbose" in sys.argv[1:]:
@@ -186,20 +192,21 @@ def main():
                 # (printed in units of lr per step; bound 3: Adam's bias-corrected step can exceed lr in its first steps)
                 e_dp = max(float((dp[k] - dp_r[k]).abs().max()) for k in dp_r) / (N_D * n_steps * lr_d)
                 e_gp = max(float((gp[k] - gp_r[k]).abs().max()) for k in gp_r) / (n_steps * lr_g)
-                aa_txt, aa_ok = "", True
+                aa_txt, aa_ok, ema_ok, e_emb = "", True, True, 0.0
                 if Gema_r is not None and w.Gen_ema is not None:          # the EMA twin (reference src/utils/ema.py:27-40): parameters in units of lr per step, buffers relative
                     pe, pr = dict(w.Gen_ema.named_parameters()), dict(Gema_r.named_parameters())
                     e_ema = max(float((pe[k].detach() - pr[k].detach()).abs().max()) for k in pr) / (n_steps * lr_g)
                     be, br = dict(w.Gen_ema.named_buffers()), dict(Gema_r.named_buffers())
                     e_emb = max([rel(be[k].float(), br[k].float(), floor=1e-3) for k in br if "num_batches" not in k and k in be] + [0.0])
                     nb_ok = all(int(be[k]) == int(br[k]) for k in br if "num_batches" in k and k in be)
-                    aa_ok = e_ema <= 3.0 and e_emb <= 1e-3 and nb_ok
+                    aa_ok = nb_ok
+                    ema_ok = e_ema <= 3.0 and e_emb <= 1e-3
                     aa_txt = f"  EMA {e_ema:.2f} lr, buffers {e_emb:.1e}"
                 if aa_r is not None:
                     aa_mine = float(w.aa_p)
                     aa_ok = aa_ok and abs(aa_mine - aa_r) <= 1e-6
                     aa_txt += f"  aa_p {aa_mine:.6f} / {aa_r:.6f}"
-                ok_first = e_dl <= 2e-3 and e_gl <= 2e-3 and e_dg <= 1e-2 and e_gg <= 1e-2 and e_dp <= 3.0 and e_gp <= 3.0 and aa_ok
+                ok_first = e_dl <= 2e-3 and e_gl <= 2e-3 and e_dg <= 1e-2 and e_gg <= 1e-2 and e_dp <= 3.0 and e_gp <= 3.0 and aa_ok and ema_ok
                 good, cond_txt = ok_first, ""
                 if not ok_first and aa_ok and e_dl <= 2e-3 and e_gl <= 2e-3:
                     # losses agree, gradients do not: is THIS input ill-conditioned (a ReLU pre-activation within rounding distance of zero in a small early layer)? The
@@ -220,11 +227,13 @@ def main():
                                 prm.mul_(1.0 + 2e-6 * torch.randn(prm.shape, generator=gp_))
                         rw2, _ = reference_worker(R, cfgs2, G2, D2, baskets, aa_p, freeze_d)
                         torch.manual_seed(seed)
-                        rw2.train_discriminator(step)
-                        n_dg = max(n_dg, worst(grads(D2), dg_r)[0])
-                        rw2.train_generator(step)
+                        for st in range(1, n_steps + 1):
+                            rw2.train_discriminator(st)
+                            if st == n_steps:
+                                n_dg = max(n_dg, worst({k: v for k, v in grads(D2).items() if k in dg_r}, dg_r)[0])
+                            rw2.train_generator(st)
                         n_gg = max(n_gg, worst(grads(G2), gg_r)[0])
-                    good = e_dg <= max(1e-2, 3 * n_dg) and e_gg <= max(1e-2, 3 * n_gg)
+                    good = e_dg <= max(1e-2, 3 * n_dg) and e_gg <= max(1e-2, 3 * n_gg) and e_emb <= 1e-2      # (after a near-tie the twins' running statistics drift apart with the weights)
                     cond_txt = f"  [ill-conditioned input: the reference's own gradients move by D {n_dg:.1e} / G {n_gg:.1e} under 2e-6 perturbations of its weights (worst of 8)]"
                 n_ok += good
                 n_bad += not good
