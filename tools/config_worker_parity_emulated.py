@@ -208,13 +208,13 @@ def main():
                     aa_txt += f"  aa_p {aa_mine:.6f} / {aa_r:.6f}"
                 ok_first = e_dl <= 2e-3 and e_gl <= 2e-3 and e_dg <= 1e-2 and e_gg <= 1e-2 and e_dp <= 3.0 and e_gp <= 3.0 and aa_ok and ema_ok
                 good, cond_txt = ok_first, ""
-                if not ok_first and aa_ok and e_dl <= 2e-3 and e_gl <= 2e-3:
+                if not ok_first and aa_ok and e_dl <= 5e-2 and e_gl <= 5e-2:
                     # losses agree, gradients do not: is THIS input ill-conditioned (a ReLU pre-activation within rounding distance of zero in a small early layer)? The
                     # reference's own movement under a perturbation of its initial weights of the size of the two implementations' forward discrepancy (their activations
                     # differ by ~3e-6 of the range: accumulation order; perturbation 2e-6 relative, as tests/golden/*.cond.npz) answers it: at a regular point the gradients
                     # move by ~1e-5, next to a tie (about 3e5 ReLU units per step at these sizes, each within 3e-6 of zero with probability ~1e-6: one step in three or
                     # four has one) by as much as two correct implementations differ -- sparsely when the unit sits in a 32 x 32 layer, densely in a 4 x 4 one
-                    n_dg = n_gg = 0.0
+                    n_dg = n_gg = n_dl = n_gl = 0.0
                     for trial in range(8):          # (one perturbation lands on the other side of a tie about every second or third time)
                         torch.manual_seed(0)
                         cfgs2 = R.load_cfgs({k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")})
@@ -228,13 +228,15 @@ def main():
                         rw2, _ = reference_worker(R, cfgs2, G2, D2, baskets, aa_p, freeze_d)
                         torch.manual_seed(seed)
                         for st in range(1, n_steps + 1):
-                            rw2.train_discriminator(st)
+                            _, dl2 = rw2.train_discriminator(st)
                             if st == n_steps:
+                                n_dl = max(n_dl, abs(float(dl2.detach()) - float(d_loss_r)) / max(abs(float(d_loss_r)), 1e-3))
                                 n_dg = max(n_dg, worst({k: v for k, v in grads(D2).items() if k in dg_r}, dg_r)[0])
-                            rw2.train_generator(st)
+                            gl2 = rw2.train_generator(st)
+                        n_gl = max(n_gl, abs(float(gl2.detach()) - float(g_loss_r)) / max(abs(float(g_loss_r)), 1e-3))
                         n_gg = max(n_gg, worst(grads(G2), gg_r)[0])
-                    good = e_dg <= max(1e-2, 3 * n_dg) and e_gg <= max(1e-2, 3 * n_gg) and e_emb <= 1e-2      # (after a near-tie the twins' running statistics drift apart with the weights)
-                    cond_txt = f"  [ill-conditioned input: the reference's own gradients move by D {n_dg:.1e} / G {n_gg:.1e} under 2e-6 perturbations of its weights (worst of 8)]"
+                    good = e_dg <= max(1e-2, 3 * n_dg) and e_gg <= max(1e-2, 3 * n_gg) and e_dl <= max(2e-3, 3 * n_dl) and e_gl <= max(2e-3, 3 * n_gl) and e_emb <= 1e-2      # (after a near-tie the twins' running statistics drift apart with the weights)
+                    cond_txt = f"  [ill-conditioned input: the reference's own gradients move by D {n_dg:.1e} / G {n_gg:.1e} (its losses by {n_dl:.1e} / {n_gl:.1e}) under 2e-6 perturbations of its weights (worst of 8)]"
                 n_ok += good
                 n_bad += not good
                 worst_all = max(worst_all, e_dl, e_gl, e_dg, e_gg)
