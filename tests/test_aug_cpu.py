@@ -280,6 +280,71 @@ def test_standing_golden_vectors_regenerate_from_the_reference(tmp_path, monkeyp
     torch.set_num_threads(nt)
 
 
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_emulated_logan_latent_optimisation_at_evaluation_time(installed, monkeypatch):
+    """metrics.generate_images_and_stack_features(latent_opt=...): LOGAN's step of the latents at EVALUATION time (reference src/utils/sample.py:96,123-135 with
+    LOSS.lo_steps4eval; generator and discriminator in eval mode, the create_graph pass through batch norm on running statistics) against the REAL reference's
+    sample.generate_images(is_train=False) under the same seed: the latents the generator finally receives and its images. (lo_alpha raised so that the step is visible:
+    at this width the latent gradient is ~6e7 and the configured step ~1e-9.)"""
+    import copy
+    import importlib
+    import types
+    from oracle import make_golden_logan as MGL
+    from studiogan_amd import config_map as CM, metrics as M
+    ref_import._prepare()
+    sample = importlib.import_module("utils.sample")
+    y = MGL.YAML
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    cfgs = ref_import.load_cfgs(y)
+    cfgs.define_losses()
+    cfgs.LOSS.lo_alpha, cfgs.LOSS.lo_beta = 2e7, 0.1
+    torch.manual_seed(3)
+    Gr, Dr = ref_import.build_models(cfgs)
+    with torch.no_grad():
+        for _ in range(2):          # running statistics worth evaluating with
+            Gr(torch.rand(4, 32) * 2 - 1, torch.randint(0, 10, (4,)))
+    gs, ds = copy.deepcopy(Gr.state_dict()), copy.deepcopy(Dr.state_dict())
+    Gr.eval(), Dr.eval()
+    got = {}
+
+    class Cap(torch.nn.Module):
+        def __init__(self, g):
+            super().__init__()
+            self.g = g
+
+        def forward(self, zs, ys, eval=False):
+            got["zs"] = zs.detach().clone()
+            return self.g(zs, ys, eval=eval)
+    torch.manual_seed(21)
+    img_r = sample.generate_images(z_prior="uniform", truncation_factor=-1.0, batch_size=4, z_dim=32, num_classes=10, y_sampler="totally_random", radius="N/A", generator=Cap(Gr),
+                                   discriminator=Dr, is_train=False, LOSS=cfgs.LOSS, RUN=types.SimpleNamespace(langevin_sampling=False), MODEL=cfgs.MODEL, device="cpu",
+                                   is_stylegan=False, generator_mapping=None, generator_synthesis=None, style_mixing_p=0.0, stylegan_update_emas=False, cal_trsp_cost=False)[0].detach()
+    zs_r = got["zs"]
+    torch.manual_seed(21)
+    torch.randint(low=0, high=10, size=(4,), dtype=torch.long)
+    z0 = torch.FloatTensor(4, 32).uniform_(-1.0, 1.0)
+    torch.set_num_threads(nt)
+    assert float((zs_r - z0).abs().max()) > 1e-2          # the reference's latents did move
+
+    class Stub:
+        def get_outputs(self, x, quantize=True):
+            got["img"] = x.detach().clone()
+            return torch.zeros(x.shape[0], 8), torch.zeros(x.shape[0], 8)
+    monkeypatch.setattr(M, "softmax_rows", lambda t: t)
+    dev = torch.device("cpu")
+    G, D, _ = CM.build(y, dev)
+    G.load_state_dict(gs, strict=True), D.load_state_dict(ds, strict=True)
+    G.eval(), D.eval()
+    torch.manual_seed(21)
+    LS = y["LOSS"]
+    M.generate_images_and_stack_features(Cap(G), Stub(), 4, 4, 32, 10, device=dev, z_prior="uniform",
+                                         latent_opt=dict(discriminator=D, lo_rate=LS["lo_rate"], lo_steps=LS["lo_steps4eval"], lo_alpha=2e7, lo_beta=0.1))
+    step_err = float(((got["zs"] - z0) - (zs_r - z0)).abs().max() / (zs_r - z0).abs().max())
+    assert step_err <= 1e-4, step_err
+    assert float((got["img"] - img_r).abs().max()) <= 1e-5
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json
