@@ -71,6 +71,31 @@ def latent_optimise(zs, fake_labels, generator, discriminator, batch_size, lo_ra
     return zs, None
 
 
+def langevin_sampling(zs, z_dim, fake_labels, generator, discriminator, batch_size, langevin_rate, langevin_noise_std, langevin_decay, langevin_decay_steps,
+                      langevin_steps, device):
+    """Langevin dynamics on the latents at evaluation time, reference src/utils/sample.py:195-216 (RUN.langevin_sampling): `langevin_steps` steps down the energy
+    -log N(z; 0, I) - D(G(z)) with Gaussian noise of covariance langevin_noise_std * I, the rate (and the noise scale) decayed every `langevin_decay_steps` steps. The
+    gradient runs through the generator and the discriminator in eval mode (the reference takes it with cal_deriv, i.e. with a graph nothing ever differentiates: here
+    it is a plain first-order gradient, so conditional generators -- whose batch norm has no second-order pass -- work too); the prior and the noise come from the same
+    torch.distributions objects as in the reference, so a seeded run consumes the generator identically."""
+    from torch.distributions import multivariate_normal as MN
+    scaler = 1.0
+    decaying = langevin_decay > 0 and langevin_decay_steps > 0
+    loc, eye = torch.zeros(z_dim, device=device), torch.eye(z_dim, device=device)
+    prior = MN.MultivariateNormal(loc=loc, covariance_matrix=eye)
+    noise = MN.MultivariateNormal(loc=loc, covariance_matrix=eye * langevin_noise_std)
+    for i in range(langevin_steps):
+        zs = zs.detach().requires_grad_(True)
+        adv = discriminator(generator(zs, fake_labels, eval=True), fake_labels, eval=True)["adv_output"]
+        energy = -prior.log_prob(zs) - adv
+        z_grads = autograd.grad(outputs=energy, inputs=zs, grad_outputs=torch.ones(energy.size(), device=energy.device))[0]
+        zs = zs - 0.5 * langevin_rate * z_grads + (langevin_rate ** 0.5) * noise.sample([batch_size]) * scaler
+        if decaying and (i + 1) % langevin_decay_steps == 0:
+            langevin_rate *= langevin_decay
+            scaler *= langevin_decay
+    return zs
+
+
 def normal_nll_loss(x, mu, var):
     """reference src/utils/losses.py:369-375 (InfoGAN's continuous codes)"""
     return F.NormalNllFn.apply(x, mu, var)

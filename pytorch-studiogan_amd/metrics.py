@@ -353,16 +353,18 @@ def softmax_rows(logits):
 
 @torch.no_grad()
 def generate_images_and_stack_features(generator, eval_model, num_generate, batch_size, z_dim, num_classes, quantize=True, world_size=1,
-                                       DDP=False, device="cuda", moments=None, z_prior="gaussian", truncation_factor=-1.0, MODEL=None, latent_opt=None):
+                                       DDP=False, device="cuda", moments=None, z_prior="gaussian", truncation_factor=-1.0, MODEL=None, latent_opt=None, langevin=None):
     """reference src/metrics/features.py:17-65. Returns (features [n,2048], probs [n,1008], labels list).
     moments: optional `FeatureMoments` accumulator fed on the device. It receives exactly the rows the reference keeps
     (`fake_feats[:num_generate]` of the rank-major gathered stack, src/metrics/fid.py:68-69): the over-generated tail --
     ceil(num_generate / batch) batches, `num_batches // world_size + 1` per rank under DDP -- is NOT accumulated.
     z_prior / truncation_factor / MODEL (InfoGAN codes behind z): the reference's evaluation-time sampling (src/utils/sample.py:90-118 with is_train=False).
     latent_opt: LOGAN at evaluation time (src/utils/sample.py:96,123-135 with LOSS.lo_steps4eval): dict(discriminator=, lo_rate=, lo_steps=, lo_alpha=, lo_beta=) -- the
-    latents take their step along d D(G(z)) / dz (the one place of this function that runs with gradients enabled) before the images are generated."""
+    latents take their step along d D(G(z)) / dz (the one place of this function that runs with gradients enabled) before the images are generated.
+    langevin: RUN.langevin_sampling (src/utils/sample.py:136-148,195-216): dict(discriminator=, langevin_rate=, langevin_noise_std=, langevin_decay=, langevin_decay_steps=,
+    langevin_steps=) -- losses.langevin_sampling on the drawn latents."""
     from .worker import sample_zy, sample_latents
-    plain = z_prior == "gaussian" and truncation_factor == -1.0 and getattr(MODEL, "info_type", "N/A") == "N/A" and latent_opt is None
+    plain = z_prior == "gaussian" and truncation_factor == -1.0 and getattr(MODEL, "info_type", "N/A") == "N/A" and latent_opt is None and langevin is None
     num_batches = int(math.ceil(float(num_generate) / float(batch_size)))
     rank = 0
     if DDP:
@@ -385,6 +387,13 @@ def generate_images_and_stack_features(generator, eval_model, num_generate, batc
                 zs, _ = latent_optimise(zs=zs, fake_labels=ys, generator=generator, discriminator=latent_opt["discriminator"], batch_size=zs.shape[0],
                                         lo_rate=latent_opt["lo_rate"], lo_steps=latent_opt["lo_steps"], lo_alpha=latent_opt["lo_alpha"], lo_beta=latent_opt["lo_beta"],
                                         eval=True, cal_trsp_cost=False, device=device)
+            zs = zs.detach()
+        if langevin is not None:          # src/utils/sample.py:136-148 (RUN.langevin_sampling; exclusive with latent optimisation, src/config.py:650-651)
+            from .losses import langevin_sampling
+            with torch.enable_grad():
+                zs = langevin_sampling(zs=zs, z_dim=z_dim, fake_labels=ys, generator=generator, discriminator=langevin["discriminator"], batch_size=zs.shape[0],
+                                       langevin_rate=langevin["langevin_rate"], langevin_noise_std=langevin["langevin_noise_std"], langevin_decay=langevin["langevin_decay"],
+                                       langevin_decay_steps=langevin["langevin_decay_steps"], langevin_steps=langevin["langevin_steps"], device=device)
             zs = zs.detach()
         fake = generator(zs, ys, eval=True)
         f, logit = eval_model.get_outputs(fake, quantize=quantize)

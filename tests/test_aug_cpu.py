@@ -345,6 +345,45 @@ def test_emulated_logan_latent_optimisation_at_evaluation_time(installed, monkey
     assert float((got["img"] - img_r).abs().max()) <= 1e-5
 
 
+@pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
+def test_emulated_langevin_sampling_matches_the_reference(installed):
+    """losses.langevin_sampling (reference src/utils/sample.py:195-216, RUN.langevin_sampling): four steps with a decay after every second one on a conditional
+    generator + projection discriminator in eval mode, against the REAL reference's function under the same seed (the noise comes from the same torch.distributions
+    objects). The rate is tiny because the energy gradient of these width-8 networks is ~1e9."""
+    import copy
+    import importlib
+    from studiogan_amd import config_map as CM, losses as SL
+    ref_import._prepare()
+    sample = importlib.import_module("utils.sample")
+    y = {"DATA": {"name": "CIFAR10", "img_size": 32, "num_classes": 10},
+         "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 32, "g_conv_dim": 8, "d_conv_dim": 8}}
+    nt = torch.get_num_threads()
+    torch.set_num_threads(_NT)
+    cfgs = ref_import.load_cfgs(y)
+    torch.manual_seed(3)
+    Gr, Dr = ref_import.build_models(cfgs)
+    with torch.no_grad():
+        for _ in range(40):
+            Gr(torch.randn(8, 32), torch.randint(0, 10, (8,)))
+    gs, ds = copy.deepcopy(Gr.state_dict()), copy.deepcopy(Dr.state_dict())
+    Gr.eval(), Dr.eval()
+    g = torch.Generator().manual_seed(5)
+    z0, lab = torch.randn(4, 32, generator=g), torch.randint(0, 10, (4,), generator=g)
+    kw = dict(z_dim=32, fake_labels=lab, batch_size=4, langevin_rate=1e-11, langevin_noise_std=0.1, langevin_decay=0.5, langevin_decay_steps=2, langevin_steps=4)
+    torch.manual_seed(9)
+    zr = sample.langevin_sampling(zs=z0.clone(), generator=Gr, discriminator=Dr, device="cpu", **kw).detach()
+    torch.set_num_threads(nt)
+    dev = torch.device("cpu")
+    G, D, _ = CM.build(y, dev)
+    G.load_state_dict(gs, strict=True), D.load_state_dict(ds, strict=True)
+    G.eval(), D.eval()
+    torch.manual_seed(9)
+    zm = SL.langevin_sampling(zs=z0.clone(), generator=G, discriminator=D, device=dev, **kw).detach()
+    move = float((zr - z0).abs().max())
+    assert move > 1e-2
+    assert float((zm - zr).abs().max()) <= 1e-4 * move, (float((zm - zr).abs().max()), move)
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json
