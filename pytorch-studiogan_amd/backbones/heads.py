@@ -13,13 +13,6 @@ HEADS = ("W/O", "PD", "AC", "2C", "D2DCE", "MH", "MD")
 def build_heads(self, MODULES, feat_dim, d_cond_mtd, aux_cls_type, d_embed_dim, num_classes, MODEL):
     if d_cond_mtd not in HEADS or aux_cls_type not in ("W/O", "N/A", "TAC", "ADC"):
         raise NotImplementedError(f"d_cond_mtd {d_cond_mtd} / aux_cls_type {aux_cls_type}")
-    # Q head network of InfoGAN (reference src/models/big_resnet.py:337-344; parameters owned by the GENERATOR's optimiser, src/config.py:501-512)
-    info_type = getattr(MODEL, "info_type", "N/A")
-    if info_type in ("discrete", "both"):
-        self.info_discrete_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c, bias=False)
-    if info_type in ("continuous", "both"):
-        self.info_conti_mu_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
-        self.info_conti_var_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
     if d_cond_mtd == "MH":
         self.linear1 = MODULES.d_linear(in_features=feat_dim, out_features=1 + num_classes, bias=True)
     elif d_cond_mtd == "MD":
@@ -43,6 +36,14 @@ def build_heads(self, MODULES, feat_dim, d_cond_mtd, aux_cls_type, d_embed_dim, 
             self.embedding_mi = MODULES.d_embedding(num_classes, d_embed_dim)
         else:
             raise NotImplementedError
+    # Q head network of InfoGAN, built LAST like the reference's (src/models/big_resnet.py:337-344): a seeded construction then draws every layer's initial weights in
+    # the reference's order (tests/aug_checks.py config_step_case relies on it); parameters owned by the GENERATOR's optimiser (src/config.py:501-512)
+    info_type = getattr(MODEL, "info_type", "N/A")
+    if info_type in ("discrete", "both"):
+        self.info_discrete_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_discrete_c * MODEL.info_dim_discrete_c, bias=False)
+    if info_type in ("continuous", "both"):
+        self.info_conti_mu_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
+        self.info_conti_var_linear = MODULES.d_linear(in_features=feat_dim, out_features=MODEL.info_num_conti_c, bias=False)
 
 
 def _embed(module, label, slot):

@@ -730,3 +730,100 @@ def standing_case(name, dev):
                 n += 1
         assert n > 0
     C.finish()
+
+
+# ---- one training step of a reference configuration file against what the reference's OWN worker produced (tests/golden/config_steps.npz, tools/config_worker_parity_emulated.py --emit) ---
+class ReplayedAll:
+    """torch.rand / randn / randint / FloatTensor(...).uniform_() hand out the draws the reference's worker consumed, in its order, on whatever device is asked for
+    (shape-checked; both call forms of torch.randint)"""
+
+    def __init__(self, draws):
+        self.it = iter(draws)
+
+    def __enter__(self):
+        self.saved = (torch.rand, torch.randn, torch.randint, torch.FloatTensor)
+        it = self.it
+
+        def nxt(shape, dev):
+            d = next(it)
+            if len(shape) == 1 and isinstance(shape[0], (list, tuple, torch.Size)):
+                shape = tuple(shape[0])
+            assert tuple(d.shape) == tuple(shape), (tuple(d.shape), tuple(shape))
+            return d.to(dev) if dev is not None else d
+
+        def rand(*size, dtype=None, device=None, **kw):
+            return nxt(size, device)
+
+        def randint(*a, size=None, device=None, low=None, high=None, **kw):
+            if size is None:
+                size = next(x for x in a if isinstance(x, (list, tuple, torch.Size)))
+            return nxt(tuple(size), device)
+
+        class FT:
+            def __init__(self, *size):
+                self.size = size
+
+            def uniform_(self, a=0.0, b=1.0):
+                return nxt(self.size, None)
+        torch.rand, torch.randn, torch.randint, torch.FloatTensor = rand, rand, randint, FT
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn, torch.randint, torch.FloatTensor = self.saved
+        if a[0] is None:
+            assert next(self.it, None) is None, "the step consumed fewer draws than the reference's"
+
+
+def config_step_names(fixture="config_steps"):
+    import json
+    from util import GOLDEN
+    p = os.path.join(GOLDEN, fixture + ".json")
+    return sorted(json.load(open(p))["cases"]) if os.path.exists(p) else []
+
+
+def config_step_case(name, dev, fixture="config_steps"):
+    """One training step (two discriminator updates with Adam in between, one generator update) of the reference configuration file `name` -- networks at width 8 built
+    through config_map.build under torch.manual_seed(0), which reproduces the reference's initialisation bit for bit -- fed the draws the reference's UNMODIFIED
+    WORKER.train_discriminator / train_generator consumed when it ran this file on the CPU (latents, labels, InfoGAN codes, augmentation and gradient-penalty draws: recorded
+    in call order by tools/config_worker_parity_emulated.py --emit): the losses of the last updates and the l2 norms of the two networks' gradients against the reference's.
+    Rows the tool found ill-conditioned (a ReLU near-tie at this input; full-width DCGAN's batch norm over four samples) are held to their losses only."""
+    import json
+    from util import GOLDEN
+    from studiogan_amd import config_map as CM
+    from studiogan_amd import worker as SW
+    meta = json.load(open(os.path.join(GOLDEN, fixture + ".json")))
+    z = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    c = meta["cases"][name]
+    y, batch, n_d = c["yaml"], meta["batch"], meta["n_d"]
+    draws = [torch.from_numpy(z[f"{name}/draw{i}"]) for i in range(c["draws"])]
+    torch.manual_seed(0)
+    G, D, w = CM.build(y, dev)
+    kw = CM.worker_kwargs(y)
+    S, nc = (y.get("DATA") or {}).get("img_size", 32), kw["num_classes"]
+    g = torch.Generator().manual_seed(11)
+    baskets = [(torch.randint(0, 256, (n_d * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (n_d * batch,), generator=g)) for _ in range(2)]
+    reals = [(baskets[0][0][i * batch:(i + 1) * batch].to(dev), baskets[0][1][i * batch:(i + 1) * batch].to(dev)) for i in range(n_d)]
+    fm = [(baskets[1][0][:batch].to(dev), baskets[1][1][:batch].to(dev))] if kw["apply_fm"] else None
+    uniform = kw["z_prior"] == "uniform"
+
+    def sample_zy_reference_order(batch_size, z_dim, num_classes, device, generator=None):      # the reference draws the labels first (src/utils/sample.py:69-76)
+        ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device)
+        return (None if uniform else torch.randn(batch_size, z_dim, device=device)), ys
+    saved = SW.sample_zy
+    SW.sample_zy = sample_zy_reference_order
+    try:
+        with ReplayedAll(draws):
+            d_loss = w.train_discriminator(1, reals)
+            dn = torch.stack([p.grad.double().norm() for p in D.parameters() if p.grad is not None]).norm()
+            g_loss = w.train_generator(1, real_batches=fm)
+            gn = torch.stack([p.grad.double().norm() for p in G.parameters() if p.grad is not None]).norm()
+    finally:
+        SW.sample_zy = saved
+    rel_ = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-3)
+    e = {"d_loss": rel_(d_loss.detach(), z[f"{name}/d_loss"]), "g_loss": rel_(g_loss.detach(), z[f"{name}/g_loss"]),
+         "d_grad_norm": rel_(dn, z[f"{name}/d_grad_norm"]), "g_grad_norm": rel_(gn, z[f"{name}/g_grad_norm"])}
+    print(name, {k: f"{v:.1e}" for k, v in e.items()}, "ill-conditioned" if c["ill_conditioned"] else "")
+    if c["ill_conditioned"]:
+        assert e["d_loss"] <= 5e-2 and e["g_loss"] <= 5e-2, (name, e)
+    else:
+        assert e["d_loss"] <= 2e-3 and e["g_loss"] <= 2e-3 and e["d_grad_norm"] <= 1e-2 and e["g_grad_norm"] <= 1e-2, (name, e)

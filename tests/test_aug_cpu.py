@@ -384,6 +384,15 @@ def test_emulated_langevin_sampling_matches_the_reference(installed):
     assert float((zm - zr).abs().max()) <= 1e-4 * move, (float((zm - zr).abs().max()), move)
 
 
+@pytest.mark.parametrize("name", ["ReACGAN-ADC-DiffAug", "BigGAN-Info", "WGAN-GP"])
+def test_emulated_config_steps_against_the_references_worker(installed, name):
+    """tests/golden/config_steps.npz (all 55 CIFAR10 files on the GPU: tests/test_wide_zz_config_steps_gpu.py): the draws the reference's own worker consumed, replayed
+    into this package's Worker on networks rebuilt from the seed -- three files here (all 55 ran on the interpreter when the fixture was written)"""
+    if name not in AC.config_step_names():
+        pytest.skip("fixture without this file")
+    AC.config_step_case(name, torch.device("cpu"))
+
+
 def test_consistency_oracle_reproduces_the_reference_vectors():
     """oracle/restate.py d_consistency_loss / g_consistency_loss on the committed networks and draws == the reference's values in the fixture"""
     import json

@@ -457,3 +457,38 @@ def test_evaluation_time_sampling_consumes_the_generators_like_the_reference(pri
     assert torch.equal(ys, got["ys"]) and zs.shape == got["zs"].shape and torch.equal(zs.float(), got["zs"].float())
     if trunc > 0:
         assert float(zs.abs().max()) <= trunc
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/configs"), reason="the reference checkout is only present in the authoring container")
+def test_seeded_construction_reproduces_the_references_initialisation():
+    """config_map.build under torch.manual_seed(s) == the reference's Generator / Discriminator built by ITS code under the same seed, bit for bit (every layer is created,
+    and its initial weights and spectral-norm vectors drawn, in the reference's order): all 55 non-StyleGAN CIFAR10 configuration files at width 8. Host logic only (the
+    construction runs on the CPU; nothing is launched). tests/aug_checks.py config_step_case relies on it: its fixture stores no weights."""
+    import glob
+    import yaml
+    from oracle import ref_import as R
+    from studiogan_amd import config_map as CM
+    n = 0
+    for f in sorted(glob.glob("/root/reference/src/configs/CIFAR10/*.yaml")):
+        y = yaml.safe_load(open(f))
+        if "stylegan" in (y.get("MODEL") or {}).get("backbone", "resnet"):
+            continue
+        M = y.setdefault("MODEL", {})
+        for k in ("g_conv_dim", "d_conv_dim"):
+            if M.get(k, 64) != "N/A":
+                M[k] = 8
+        for k in ("d_embed_dim", "g_shared_dim"):
+            if M.get(k, "N/A") != "N/A":
+                M[k] = 16
+        if M.get("backbone") == "deep_conv" and n > 0 and "Info" not in f:
+            continue          # (full-width DCGAN: one plain file and the InfoGAN one are enough)
+        torch.manual_seed(5)
+        cfgs = R.load_cfgs({k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")})
+        Gr, Dr = R.build_models(cfgs)
+        torch.manual_seed(5)
+        G, D, _ = CM.build(y, torch.device("cpu"))
+        sg, sd = G.state_dict(), D.state_dict()
+        assert all(torch.equal(sg[k], v) for k, v in Gr.state_dict().items()), os.path.basename(f)
+        assert all(torch.equal(sd[k], v) for k, v in Dr.state_dict().items()), os.path.basename(f)
+        n += 1
+    assert n >= 50

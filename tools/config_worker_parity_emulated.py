@@ -9,7 +9,7 @@ Compared per configuration: the discriminator loss of the last of TWO discrimina
 gradient of that update and every discriminator parameter after both steps (+ weight clipping); the generator loss, every generator parameter gradient and every
 generator parameter after its step; the ADA / APA probability after the heuristic. Channel widths cut to 8; image sizes, class counts, heads, losses, regularisers and
 augmentations as the file says (ADA / APA strength raised from the files' 0.0 so that the pipelines actually fire).
-   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--steps=1] [--freezeD=-1] [--seed=77] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
+   usage: python tools/config_worker_parity_emulated.py [--dir=CIFAR10] [--batch=4] [--nd=2] [--acml=1] [--steps=1] [--freezeD=-1] [--seed=77] [--emit=config_steps] [--verbose] [name ...]        TEST INFRASTRUCTURE; needs /root/reference."""
 import copy
 import glob
 import importlib
@@ -50,6 +50,39 @@ def grads(net):
 
 def params(net):
     return {k: p.detach().clone() for k, p in net.named_parameters()}
+
+
+class RecordedDraws:
+    """every torch.rand / randn / randint / FloatTensor(...).uniform_() result in call order (--emit: the draws the reference's step consumed, for tests/golden/config_steps.npz)"""
+
+    def __init__(self):
+        self.draws = []
+
+    def __enter__(self):
+        self.saved = (torch.rand, torch.randn, torch.randint, torch.FloatTensor)
+        draws = self.draws
+
+        def wrap(fn):
+            def inner(*a, **k):
+                t = fn(*a, **k)
+                draws.append(t.detach().clone().cpu())
+                return t
+            return inner
+        FT0 = torch.FloatTensor
+
+        class FT:
+            def __init__(self, *size):
+                self.t = FT0(*size)
+
+            def uniform_(self, a=0.0, b=1.0):
+                t = self.t.uniform_(a, b)
+                draws.append(t.clone())
+                return t
+        torch.rand, torch.randn, torch.randint, torch.FloatTensor = wrap(torch.rand), wrap(torch.randn), wrap(torch.randint), FT
+        return self
+
+    def __exit__(self, *a):
+        torch.rand, torch.randn, torch.randint, torch.FloatTensor = self.saved
 
 
 class Loader:
@@ -103,6 +136,8 @@ def main():
     seed = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--seed=")), "77"))
     n_steps = int(next((a[8:] for a in sys.argv[1:] if a.startswith("--steps=")), "1"))      # consecutive steps (the comparison is made after the last one)
     freeze_d = int(next((a[10:] for a in sys.argv[1:] if a.startswith("--freezeD=")), "-1"))      # RUN.freezeD: the first N discriminator blocks frozen (src/utils/misc.py:190-216)
+    emit = next((a[7:] for a in sys.argv[1:] if a.startswith("--emit=")), None)      # write tests/golden/<emit>.npz / .json: draws + losses + gradient norms per file
+    emitted, emit_meta = {}, {}
     acml = int(next((a[7:] for a in sys.argv[1:] if a.startswith("--acml=")), "1"))          # gradient accumulation (OPTIMIZATION.acml_steps): micro-batches per update
     files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
@@ -149,11 +184,13 @@ def main():
                 # ---- the reference's worker
                 rw, Gema_r = reference_worker(R, cfgs, Gr, Dr, baskets, aa_p, freeze_d)
                 torch.manual_seed(seed)
-                for step in range(1, n_steps + 1):
-                    _, d_loss_r = rw.train_discriminator(step)
-                    dg_r, dp_r = grads(Dr), params(Dr)
-                    g_loss_r = rw.train_generator(step)
-                    gg_r, gp_r = grads(Gr), params(Gr)
+                rec = RecordedDraws()
+                with rec:
+                    for step in range(1, n_steps + 1):
+                        _, d_loss_r = rw.train_discriminator(step)
+                        dg_r, dp_r = grads(Dr), params(Dr)
+                        g_loss_r = rw.train_generator(step)
+                        gg_r, gp_r = grads(Gr), params(Gr)
                 aa_r = float(rw.aa_p) if aa_p != "N/A" else None
                 # ---- this package's
                 G, D, w = CM.build(y, dev)
@@ -240,6 +277,13 @@ def main():
                 n_ok += good
                 n_bad += not good
                 worst_all = max(worst_all, e_dl, e_gl, e_dg, e_gg)
+                if emit and good:
+                    for i, dr in enumerate(rec.draws):
+                        emitted[f"{name}/draw{i}"] = dr.numpy()
+                    emitted[f"{name}/d_loss"], emitted[f"{name}/g_loss"] = d_loss_r.cpu().numpy(), g_loss_r.cpu().numpy()
+                    emitted[f"{name}/d_grad_norm"] = torch.stack([v.double().norm() for v in dg_r.values()]).norm().numpy()
+                    emitted[f"{name}/g_grad_norm"] = torch.stack([v.double().norm() for v in gg_r.values()]).norm().numpy()
+                    emit_meta[name] = {"yaml": {k: v for k, v in y.items() if k in ("DATA", "MODEL", "LOSS", "OPTIMIZATION", "AUG")}, "ill_conditioned": bool(cond_txt), "draws": len(rec.draws)}
                 flags = [k[6:] for k, v in kw.items() if k.startswith("apply_") and v and k != "apply_g_ema"] + ([f"info:{kw['info_type']}"] if kw["info_type"] != "N/A" else [])
                 print(f"{name:26s} {kw['adv_loss']:12s} {kw['d_cond_mtd']:6s} {kw['aux_cls_type']:4s} {','.join(flags):24s} | D loss {float(d_loss):+.5e} ({e_dl:.1e})  D grads {e_dg:.1e}  "
                       f"D params {e_dp:.2f} lr  | G loss {float(g_loss):+.5e} ({e_gl:.1e})  G grads {e_gg:.1e}  G params {e_gp:.2f} lr{aa_txt}{cond_txt}  "
@@ -250,6 +294,13 @@ def main():
                 tb = traceback.extract_tb(e.__traceback__)[-1]
                 print(f"{name:26s} FAILED {type(e).__name__}: {str(e)[:240]}  [{os.path.basename(tb.filename)}:{tb.lineno}]")
             sys.stdout.flush()
+    if emit:
+        import json
+        import numpy as np
+        out = os.path.join(ROOT, "tests", "golden", emit)
+        np.savez_compressed(out + ".npz", **emitted)
+        json.dump({"dir": data, "batch": batch, "n_d": N_D, "seed": seed, "cases": emit_meta}, open(out + ".json", "w"), indent=1)
+        print(f"# wrote {out}.npz ({os.path.getsize(out + '.npz') // 1024} KiB), {len(emit_meta)} files")
     print(f"# {data}: {n_ok} configuration files: this package's training step agrees with the reference's own WORKER.train_discriminator / train_generator run on the CPU "
           f"(losses <= 2e-3, gradients <= 1e-2 of the largest; worst {worst_all:.1e}), {n_bad} do not")
 
