@@ -270,3 +270,23 @@ def test_emulated_training_step_against_the_references_own_worker(monkeypatch, c
     rows = [ln for ln in out.splitlines() if ln.startswith(("SNGAN-DiffAug-LeCam ", "ReACGAN-ADA "))]
     assert len(rows) == 2 and all(r.rstrip().split("  ")[-2].strip().endswith("ok") or " ok " in r for r in rows) and not any("MISMATCH" in r or "FAILED" in r for r in rows), out
     assert "2 configuration files" in out
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src/configs"), reason="the reference checkout is only present in the authoring container")
+def test_config_steps_fixture_regenerates_from_the_reference(tmp_path, monkeypatch, capsys):
+    """tests/golden/config_steps.npz: two of its 55 files re-emitted by tools/config_worker_parity_emulated.py from the reference's own worker -- the recorded draws are
+    bit-identical to the committed ones, the losses and gradient norms agree to the last digits a re-run of torch's CPU kernels keeps"""
+    import numpy as np
+    sys.path.insert(0, os.path.join(os.path.dirname(HERE), "tools"))
+    import config_worker_parity_emulated as T
+    out = str(tmp_path / "steps")
+    monkeypatch.setattr(sys, "argv", ["config_worker_parity_emulated.py", "--dir=CIFAR10", "--batch=4", "--emit=" + out, "SNGAN-DiffAug", "ContraGAN-TAC"])
+    T.main()
+    capsys.readouterr()
+    a, b = np.load(os.path.join(HERE, "golden", "config_steps.npz")), np.load(out + ".npz")
+    assert len(b.files) > 10
+    for k in b.files:
+        if "/draw" in k:
+            assert np.array_equal(a[k], b[k]), k
+        else:
+            assert np.allclose(a[k], b[k], rtol=1e-5, atol=0), (k, a[k], b[k])

@@ -297,7 +297,7 @@ def main():
     if emit:
         import json
         import numpy as np
-        out = os.path.join(ROOT, "tests", "golden", emit)
+        out = emit if os.sep in emit else os.path.join(ROOT, "tests", "golden", emit)
         np.savez_compressed(out + ".npz", **emitted)
         json.dump({"dir": data, "batch": batch, "n_d": N_D, "seed": seed, "cases": emit_meta}, open(out + ".json", "w"), indent=1)
         print(f"# wrote {out}.npz ({os.path.getsize(out + '.npz') // 1024} KiB), {len(emit_meta)} files")
