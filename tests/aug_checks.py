@@ -826,4 +826,6 @@ def config_step_case(name, dev, fixture="config_steps"):
     if c["ill_conditioned"]:
         assert e["d_loss"] <= 5e-2 and e["g_loss"] <= 5e-2, (name, e)
     else:
-        assert e["d_loss"] <= 2e-3 and e["g_loss"] <= 2e-3 and e["d_grad_norm"] <= 1e-2 and e["g_grad_norm"] <= 1e-2, (name, e)
+        # (gradient norms: 3e-2 -- another implementation's rounding can put a different ReLU unit on the other side of zero: tools/config_worker_parity_emulated.py measures
+        # what one such unit does to a whole-network norm: <= 1e-2; the interpreter's values are <= 1.6e-3)
+        assert e["d_loss"] <= 2e-3 and e["g_loss"] <= 2e-3 and e["d_grad_norm"] <= 3e-2 and e["g_grad_norm"] <= 3e-2, (name, e)
