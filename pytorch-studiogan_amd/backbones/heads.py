@@ -65,10 +65,11 @@ def apply_heads(self, h, label, slot, adc_fake=False, hw=None):
     if info_type != "N/A":
         if hw is None:
             raise RuntimeError("apply_heads: the Q heads need the number of pooled positions (hw)")
-        inv = getattr(self, "_sg_info_inv", None)
-        if inv is None or inv.device != h.device or float(inv) != 1.0 / hw:
-            inv = torch.full((1,), 1.0 / hw, dtype=torch.float32, device=h.device)
-            self.__dict__["_sg_info_inv"] = inv
+        cached = getattr(self, "_sg_info_inv", None)          # keyed on the Python ints: no device read-back per forward
+        if cached is None or cached[0] != (int(hw), h.device):
+            cached = ((int(hw), h.device), torch.full((1,), 1.0 / hw, dtype=torch.float32, device=h.device))
+            self.__dict__["_sg_info_inv"] = cached
+        inv = cached[1]
         hm = F.ScalePtrFn.apply(h, inv)                          # h / (bottom_h * bottom_w)
         if info_type in ("discrete", "both"):
             info_discrete_c_logits = self.info_discrete_linear.forward_rt(hm, slot)

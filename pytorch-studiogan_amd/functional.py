@@ -2195,19 +2195,41 @@ class FeatureMatchingFn(torch.autograd.Function):
         return None, df * g
 
 
-def select_rows(flag, a, b):
-    """out[n] = a[n] if flag[n] else b[n] for fp32 tensors of one shape (adaptive pseudo augmentation, reference src/utils/apa_aug.py:14-21). No gradient:
-    the reference hands it the detached fake batch and the real batch (src/worker.py:274)."""
-    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
-        raise RuntimeError("select_rows: two fp32 tensors of one shape expected")
-    a, b = _c(a.detach()), _c(b.detach())
-    f = _c(flag.to(torch.uint8))
+def _select_rows_raw(f, a, b):
     N = a.shape[0]
-    if f.numel() != N:
-        raise RuntimeError("select_rows: one flag per row expected")
     out = torch.empty_like(a)
     L.call("sg_select_rows", L.ptr(f), L.ptr(a), L.ptr(b), L.ptr(out), N, a.numel() // N, L.stream())
     return out
+
+
+class SelectRowsFn(torch.autograd.Function):
+    """out[n] = a[n] if flag[n] else b[n]; differentiable in b (the real batch: the reference's fake * flag + real * (1 - flag) keeps the graph to real_images, which
+    R1 differentiates twice, src/worker.py:274,379-381). The backward is the same launch on (0, g) and is itself a SelectRowsFn, so create_graph passes run through it."""
+
+    @staticmethod
+    def forward(ctx, f, a, b):
+        ctx.save_for_backward(f)
+        return _select_rows_raw(f, a, b)
+
+    @staticmethod
+    def backward(ctx, g):
+        (f,) = ctx.saved_tensors
+        g = _c(g)
+        return None, None, SelectRowsFn.apply(f, torch.zeros_like(g), g)
+
+
+def select_rows(flag, a, b):
+    """out[n] = a[n] if flag[n] else b[n] for fp32 tensors of one shape (adaptive pseudo augmentation, reference src/utils/apa_aug.py:14-21). a (the detached fake
+    batch, src/worker.py:274) carries no gradient; b (the real batch) does when it requires one."""
+    if a.shape != b.shape or a.dtype != torch.float32 or b.dtype != torch.float32:
+        raise RuntimeError("select_rows: two fp32 tensors of one shape expected")
+    f = _c(flag.to(torch.uint8))
+    if f.numel() != a.shape[0]:
+        raise RuntimeError("select_rows: one flag per row expected")
+    a = _c(a.detach())
+    if b.requires_grad and torch.is_grad_enabled():
+        return SelectRowsFn.apply(f, a, _c(b))
+    return _select_rows_raw(f, a, _c(b.detach()))
 
 
 def sign_count_(acc, logits):

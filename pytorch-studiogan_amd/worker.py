@@ -153,10 +153,16 @@ class GeneratorController:
         return self.generator, None, None          # (generator, generator_mapping, generator_synthesis): the StyleGAN halves do not exist here
 
 
-def sample_zy(batch_size, z_dim, num_classes, device, generator=None):
-    """reference src/utils/sample.py:33-88 (gaussian prior, 'totally_random' labels), drawn on the device."""
-    zs = torch.randn(batch_size, z_dim, device=device, generator=generator)
+def sample_zy(batch_size, z_dim, num_classes, device, generator=None, z_prior="gaussian"):
+    """reference src/utils/sample.py:69-76 ('totally_random' labels): the LABELS are drawn first, then the latents -- N(0, I) on the device, U(-1, 1) on the
+    host generator for the uniform prior (nothing else is drawn for it) -- so a seeded run consumes the generators in the reference's order."""
     ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device, generator=generator)
+    if z_prior == "gaussian":
+        zs = torch.randn(batch_size, z_dim, device=device, generator=generator)
+    elif z_prior == "uniform":
+        zs = torch.FloatTensor(batch_size, z_dim).uniform_(-1.0, 1.0).to(device)
+    else:
+        raise NotImplementedError(z_prior)
     return zs, ys
 
 
@@ -217,6 +223,8 @@ class Worker:
         self.apply_cr, self.cr_lambda = apply_cr, cr_lambda
         self.apply_bcr, self.real_lambda, self.fake_lambda = apply_bcr, real_lambda, fake_lambda
         self.apply_zcr, self.radius, self.g_lambda, self.d_lambda = apply_zcr, radius, g_lambda, d_lambda
+        if apply_zcr and info_type != "N/A":          # the reference's zs_eps (src/utils/sample.py:79-83) keeps width z_dim while zs gets the codes appended (:113-118)
+            raise NotImplementedError("apply_zcr with InfoGAN codes: the perturbed latents would lack the codes (the reference fails there as well)")
         assert not (apply_cr and apply_bcr), "CR and bCR share cfgs.AUG.parallel_augment: one of them (reference src/config.py:596-626)"
         self.parallel_augment = self._augmenter(cr_aug_type if apply_cr else bcr_aug_type, "cr_aug_type / bcr_aug_type") if (apply_cr or apply_bcr) else None
         self.apply_dra, self.dra_lambda = apply_dra, dra_lambda
@@ -309,14 +317,13 @@ class Worker:
             eps = ent[2] if len(ent) > 2 else None
             info = ent[3] if len(ent) > 3 else None
         else:
-            zs, ys = sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device)
-            if self.z_prior == "uniform":          # src/utils/sample.py:75-76 (drawn on the CPU generator like the reference)
-                zs = torch.FloatTensor(self.batch_size, self.z_dim).uniform_(-1.0, 1.0).to(self.device)
-            elif self.z_prior != "gaussian":
-                raise NotImplementedError(self.z_prior)
+            zs, ys = sample_zy(self.batch_size, self.z_dim, self.num_classes, self.device, z_prior=self.z_prior)
             eps = None
-        if self.apply_zcr and eps is None:
-            eps = zs + self.radius * torch.randn(zs.shape[0], self.z_dim, device=zs.device)
+        if self.apply_zcr and eps is None:          # src/utils/sample.py:79-83: the perturbation follows the prior
+            if self.z_prior == "uniform":
+                eps = zs + self.radius * torch.FloatTensor(zs.shape[0], self.z_dim).uniform_(-1.0, 1.0).to(zs.device)
+            else:
+                eps = zs + self.radius * torch.randn(zs.shape[0], self.z_dim, device=zs.device)
         self.info_codes = (None, None)
         if self.info_type != "N/A":          # src/utils/sample.py:113-118: the codes ride behind z
             B = zs.shape[0]

@@ -272,6 +272,16 @@ def apa_case(i, dev):
     with Replayed([_t(z, p + "coin")]):
         y = apa_aug.apply_apa_aug(real, fake, float(z[p + "p"]), dev)
     assert torch.equal(y.cpu(), _t(z, p + "y")), i
+    # the real batch stays differentiable through the select (reference: fake * flag + real * (1 - flag); R1 on top of APA differentiates it twice, src/worker.py:274,379-381)
+    rq = real.detach().clone().requires_grad_(True)
+    with Replayed([_t(z, p + "coin")]):
+        yq = apa_aug.apply_apa_aug(rq, fake, float(z[p + "p"]), dev)
+    keep = (_t(z, p + "coin") >= float(z[p + "p"])).to(dev).float().reshape(-1, 1, 1, 1)
+    wgt = torch.arange(yq.numel(), device=dev, dtype=torch.float32).reshape(yq.shape) / yq.numel()
+    (g1,) = torch.autograd.grad((yq * yq * wgt).sum(), rq, create_graph=True)        # d/d real = 2 * y * wgt on the kept rows
+    assert torch.equal(g1.detach(), (2 * yq.detach() * wgt) * keep), i
+    (g2,) = torch.autograd.grad(g1.sum(), rq)                                        # second order: 2 * wgt on the kept rows
+    assert torch.equal(g2, 2 * wgt * keep), i
     acc = torch.zeros(2, dtype=torch.float32, device=dev)
     lg = torch.tensor([0.5, -1.0, 0.0, 2.0, -0.1, 3.0, 1e-9], device=dev)
     F.sign_count_(acc, lg)
@@ -581,7 +591,13 @@ def logan_case(dev):
     """studiogan_amd.worker.Worker(apply_lo=True): one discriminator and one generator update of the LOGAN configuration (unconditional ResNet generator with batch
     norm, spectral-norm discriminator, uniform prior) whose losses back-propagate THROUGH d D(G(z)) / dz -- the create_graph pass runs through the generator's
     differentiable data-gradient operators (LinearDgradFn, ConvDgradFn, BNBwdFn, TanhGradFn) and the discriminator's: moved latents, transport cost, loss and every
-    gradient against the REAL reference's double backward (fp32)."""
+    gradient against the REAL reference's double backward (fp32).
+
+    Tolerances (round 6, measured on the MI355X: profiles/r06_logan_tie.txt): the fixture's discriminator-side latents put ONE ReLU input of the discriminator at
+    2.5e-7 (1.2e-7 of its tensor's range; with ~1e6 ReLU inputs per pass no seed in 200 avoids such a unit). torch's fp32 on a CPU, fp64 and the CPU interpreter all
+    land on one side of it, the MFMA's summation order on the other: d D(G(z)) / dz moves by 2.5e-3 and the discriminator's gradients by up to 5e-3 -- while the same
+    kernels meet the fp64 oracle at 1e-6 on the latents scaled by 1.0001, 0.9999, 0.9 (tools/diag_logan2.py) and on the generator-side latents of this fixture. The
+    discriminator-side bounds are therefore the generator side's (2e-2 of the largest gradient: one flipped unit of this 8-channel network, not rounding noise)."""
     import importlib
     import json
     import types
@@ -609,11 +625,11 @@ def logan_case(dev):
     s0, s1 = meta["mask_seeds"]
     with Replayed([torch.from_numpy(z[f"mask_draw/{s0}"])]):
         d_loss = w.train_discriminator(0, [(ins["real0"], ins["rl0"])], [(ins["z0"], ins["fl0"])])
-    C.check("d transport cost", w.trsp_cost, torch.from_numpy(z["d_trsp_cost"]), 2e-4)
+    C.check("d transport cost", w.trsp_cost, torch.from_numpy(z["d_trsp_cost"]), 1e-3)
     C.check("d_loss", d_loss, torch.from_numpy(z["d_loss"]), 2e-4)
     dmax = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("D_grad/"))
     for k, prm in D.named_parameters():
-        C.check("D_grad/" + k, prm.grad, torch.from_numpy(z["D_grad/" + k]), 1e-3, floor=1e-2 * dmax)
+        C.check("D_grad/" + k, prm.grad, torch.from_numpy(z["D_grad/" + k]), 2e-2, floor=1e-2 * dmax)
     with torch.no_grad():           # the generator side of the fixture ran on the un-stepped discriminator
         for k, prm in D.named_parameters():
             prm.copy_(d_init[k])
@@ -624,6 +640,66 @@ def logan_case(dev):
     gmx = max(float(np.abs(z[k]).max()) for k in z.files if k.startswith("G_grad/"))
     for k, prm in G.named_parameters():
         C.check("G_grad/" + k, prm.grad, torch.from_numpy(z["G_grad/" + k]), 2e-2, floor=1e-2 * gmx)
+    C.finish()
+
+
+def logan_oracle_case(dev, scale):
+    """The discriminator update of logan_case on the fixture's latents times `scale`, against the fp64 CPU ORACLE's double backward (oracle/restate.py networks +
+    the five lines of src/utils/losses.py:278-298 restated on them) at rounding-level bounds: the tight counterpart of logan_case's discriminator side, on inputs
+    whose ReLU inputs stay clear of zero on this hardware (measured: profiles/r06_logan_tie.txt -- 0.9, 0.9999, 1.0001 agree to 1e-6, the exact fixture latents do not)."""
+    import importlib
+    import json
+    import types
+    from util import Collector, GOLDEN, hyper
+    from oracle import restate as O, make_golden as MG
+    from studiogan_amd import ops
+    from studiogan_amd.worker import Worker
+    z = np.load(os.path.join(GOLDEN, "logan.npz"))
+    meta = json.load(open(os.path.join(GOLDEN, "logan.json")))
+    y = meta["yaml"]
+    M, Dt, Ls = y["MODEL"], y["DATA"], y["LOSS"]
+    MODEL = types.SimpleNamespace(info_type="N/A", g_info_injection="N/A")
+    bb = importlib.import_module("studiogan_amd.backbones.resnet")
+    MOD = ops.Modules(apply_g_sn=False, apply_d_sn=True, g_cond_mtd="W/O", backbone="resnet")
+    G = bb.Generator(M["z_dim"], "N/A", Dt["img_size"], M["g_conv_dim"], False, ["N/A"], "W/O", Dt["num_classes"], "ortho", "N/A", False, MOD, MODEL).to(dev)
+    D = bb.Discriminator(Dt["img_size"], M["d_conv_dim"], True, False, ["N/A"], "W/O", "W/O", "N/A", False, Dt["num_classes"], "ortho", "N/A", False, MOD, MODEL).to(dev)
+    gsd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("G_init/")}
+    dsd = {k[7:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("D_init/")}
+    G.load_state_dict({k: v.to(dev) for k, v in gsd.items()}, strict=True)
+    D.load_state_dict({k: v.to(dev) for k, v in dsd.items()}, strict=True)
+    opt = hyper(y)
+    w = Worker(G, D, opt["z_dim"], Dt["num_classes"], y["OPTIMIZATION"]["batch_size"], "hinge", opt["g_lr"], opt["d_lr"], opt["beta1"], opt["beta2"],
+               d_updates_per_step=1, apply_lo=True, lo_rate=Ls["lo_rate"], lo_steps4train=Ls["lo_steps4train"], lo_alpha=Ls["lo_alpha"], lo_beta=Ls["lo_beta"],
+               lo_lambda=Ls["lo_lambda"], z_prior="uniform")
+    real, rl, fl = torch.from_numpy(z["in/real0"]), torch.from_numpy(z["in/rl0"]), torch.from_numpy(z["in/fl0"])
+    z0 = torch.from_numpy(z["in/z0"]) * scale
+    draw = torch.from_numpy(z[f"mask_draw/{meta['mask_seeds'][0]}"])
+    # ---- oracle, fp64 ----
+    gen, dis = O.model_fns(MG.oracle_cfg(y))
+    pg, pd = {k for k, _ in G.named_parameters()}, {k for k, _ in D.named_parameters()}
+    f64 = lambda v: v.clone().double() if v.is_floating_point() else v.clone()
+    GP, GB = {k: f64(v) for k, v in gsd.items() if k in pg}, {k: f64(v) for k, v in gsd.items() if k not in pg}
+    DP, DB = {k: f64(v).requires_grad_(True) for k, v in dsd.items() if k in pd}, {k: f64(v) for k, v in dsd.items() if k not in pd}
+    zc = z0.double().requires_grad_(True)
+    adv, _ = dis(gen(zc, fl, GP, GB, "untrack"), fl, DP, DB)
+    zg = torch.autograd.grad(adv.sum(), zc, create_graph=True)[0]
+    delta = Ls["lo_alpha"] * zg / (Ls["lo_beta"] + (zg.norm(2, dim=1) ** 2).unsqueeze(1))
+    zs_o = torch.clamp(zc + (draw > 1 - Ls["lo_rate"]).double() * delta, -1.0, 1.0)
+    cost_o = (delta.norm(2, dim=1) ** 2).mean()
+    fake_o = gen(zs_o, fl, GP, GB, "untrack")
+    rd, _ = dis(real.double(), rl, DP, DB)
+    fd, _ = dis(fake_o, fl, DP, DB)
+    loss_o = O.d_loss("hinge", rd, fd) + Ls["lo_lambda"] * cost_o
+    grads_o = dict(zip(DP, torch.autograd.grad(loss_o, list(DP.values()))))
+    # ---- product ----
+    C = Collector()
+    with Replayed([draw]):
+        d_loss = w.train_discriminator(0, [(real.to(dev), rl.to(dev))], [(z0.to(dev), fl.to(dev))])
+    C.check("d transport cost", w.trsp_cost, cost_o.detach(), 2e-5)
+    C.check("d_loss", d_loss, loss_o.detach(), 2e-5)
+    dmax = max(float(g.abs().max()) for g in grads_o.values())
+    for k, prm in D.named_parameters():
+        C.check("D_grad/" + k, prm.grad, grads_o[k], 1e-4, floor=1e-2 * dmax)
     C.finish()
 
 
@@ -804,21 +880,11 @@ def config_step_case(name, dev, fixture="config_steps"):
     baskets = [(torch.randint(0, 256, (n_d * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (n_d * batch,), generator=g)) for _ in range(2)]
     reals = [(baskets[0][0][i * batch:(i + 1) * batch].to(dev), baskets[0][1][i * batch:(i + 1) * batch].to(dev)) for i in range(n_d)]
     fm = [(baskets[1][0][:batch].to(dev), baskets[1][1][:batch].to(dev))] if kw["apply_fm"] else None
-    uniform = kw["z_prior"] == "uniform"
-
-    def sample_zy_reference_order(batch_size, z_dim, num_classes, device, generator=None):      # the reference draws the labels first (src/utils/sample.py:69-76)
-        ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device)
-        return (None if uniform else torch.randn(batch_size, z_dim, device=device)), ys
-    saved = SW.sample_zy
-    SW.sample_zy = sample_zy_reference_order
-    try:
-        with ReplayedAll(draws):
-            d_loss = w.train_discriminator(1, reals)
-            dn = torch.stack([p.grad.double().norm() for p in D.parameters() if p.grad is not None]).norm()
-            g_loss = w.train_generator(1, real_batches=fm)
-            gn = torch.stack([p.grad.double().norm() for p in G.parameters() if p.grad is not None]).norm()
-    finally:
-        SW.sample_zy = saved
+    with ReplayedAll(draws):          # (worker.sample_zy draws labels first, then the latents: the reference's order, src/utils/sample.py:69-76)
+        d_loss = w.train_discriminator(1, reals)
+        dn = torch.stack([p.grad.double().norm() for p in D.parameters() if p.grad is not None]).norm()
+        g_loss = w.train_generator(1, real_batches=fm)
+        gn = torch.stack([p.grad.double().norm() for p in G.parameters() if p.grad is not None]).norm()
     rel_ = lambda a, b: abs(float(a) - float(b)) / max(abs(float(b)), 1e-3)
     e = {"d_loss": rel_(d_loss.detach(), z[f"{name}/d_loss"]), "g_loss": rel_(g_loss.detach(), z[f"{name}/g_loss"]),
          "d_grad_norm": rel_(dn, z[f"{name}/d_grad_norm"]), "g_grad_norm": rel_(gn, z[f"{name}/g_grad_norm"])}

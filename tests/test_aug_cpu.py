@@ -241,6 +241,11 @@ def test_emulated_logan_latent_optimisation(installed):
     AC.logan_case(torch.device("cpu"))
 
 
+def test_emulated_logan_discriminator_side_against_the_oracle(installed):
+    """the GPU suite's tight discriminator-side LOGAN check (fp64 oracle double backward, scaled latents) on the interpreter"""
+    AC.logan_oracle_case(torch.device("cpu"), 0.9)
+
+
 @pytest.mark.skipif(not ref_import.available(), reason="the reference checkout is only present in the authoring container")
 def test_logan_golden_vectors_regenerate_from_the_reference(tmp_path, monkeypatch):
     from oracle import make_golden_logan as MGL

@@ -24,9 +24,15 @@ def test_freeze_d(sg, name):
 
 
 def test_logan_latent_optimisation(sg):
-    """LOGAN (reference configs/CIFAR10/LOGAN.yaml; src/utils/losses.py:278-298): written after the round's last GPU second -- green on the CPU interpreter
-    (tests/test_aug_cpu.py::test_emulated_logan_latent_optimisation), first GPU run = the driver's"""
+    """LOGAN (reference configs/CIFAR10/LOGAN.yaml; src/utils/losses.py:278-298): against the REAL reference's vectors; the discriminator side's bounds are one flipped
+    ReLU unit wide (see aug_checks.logan_case; profiles/r06_logan_tie.txt), the tight bounds sit in the oracle test below"""
     AC.logan_case(torch.device("cuda:0"))
+
+
+@pytest.mark.parametrize("scale", [0.9, 1.0001])
+def test_logan_discriminator_side_against_the_oracle(sg, scale):
+    """the same update on latents clear of the fixture's ReLU tie, against the fp64 oracle's double backward at rounding-level bounds (1e-4 of the largest gradient)"""
+    AC.logan_oracle_case(torch.device("cuda:0"), scale)
 
 
 @pytest.mark.parametrize("name", ["md", "ac", "2c", "mh"])

@@ -142,13 +142,6 @@ def main():
     files = sorted(glob.glob(f"/root/reference/src/configs/{data}/*.yaml"))
     torch.set_num_threads(1)
     dev = torch.device("cpu")
-    uniform = [False]
-
-    def sample_zy_reference_order(batch_size, z_dim, num_classes, device, generator=None):
-        ys = torch.randint(low=0, high=max(num_classes, 1), size=(batch_size,), dtype=torch.long, device=device)
-        zs = None if uniform[0] else torch.randn(batch_size, z_dim, device=device)      # (the uniform prior is drawn by the caller, as in the reference)
-        return zs, ys
-    SW.sample_zy = sample_zy_reference_order
     n_ok = n_bad = 0
     worst_all = 0.0
     with fullemu.Installed(dma_late=1, greedy=1, seed=1):
@@ -174,7 +167,6 @@ def main():
                 g_state, d_state = copy.deepcopy(Gr.state_dict()), copy.deepcopy(Dr.state_dict())
                 kw = CM.worker_kwargs(y)
                 S, nc = (y.get("DATA") or {}).get("img_size", 32), kw["num_classes"]
-                uniform[0] = kw["z_prior"] == "uniform"
                 g = torch.Generator().manual_seed(11)
                 nb = N_D * acml
                 baskets = [(torch.randint(0, 256, (nb * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (nb * batch,), generator=g)) for _ in range(n_steps * (1 + acml))]
