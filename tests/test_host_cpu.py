@@ -2,6 +2,7 @@
 import copy
 import os
 import re
+import sys
 
 import pytest
 import torch
@@ -492,3 +493,95 @@ def test_seeded_construction_reproduces_the_references_initialisation():
         assert all(torch.equal(sd[k], v) for k, v in Dr.state_dict().items()), os.path.basename(f)
         n += 1
     assert n >= 50
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="reference checkout not present")
+def test_reference_worker_drives_amd_backbones(tmp_path):
+    """The seam crossed with the REFERENCE's driver on top: `src/models/big_resnet_amd.py` is the three-line file a maintainer adds (written
+    here into a second portion of the reference's `models` namespace package), `config.ops` / `config.losses` are this package's modules, and then nothing but
+    reference code runs: `Configurations` (define_modules, define_losses, define_optimizer), `models.model.load_generator_discriminator`
+    (src/models/model.py:19-22 `__import__("models." + backbone)`), `utils.ema.Ema`, `WORKER.__init__`, and the unmodified `WORKER.train_discriminator` /
+    `WORKER.train_generator` (src/worker.py:213-681: sample.generate_images, misc.toggle_grad / make_GAN_trainable / untrack_bn_statistics, torch.optim.Adam, Ema.update)
+    for ImageNet/BigGAN-256.yaml (C3: 128 x 128, cBN + PD + attention, hinge, EMA, two discriminator updates) at width 8, batch 4. The kernels execute on the CPU
+    interpreter (tests/hipemu). Compared with the same driver over the reference's own networks from the same initial state, seed and baskets: losses, every
+    gradient of the last discriminator update and of the generator update, parameters after Adam (in units of lr), the EMA twin."""
+    import importlib
+    import logging
+    import yaml
+    sys.path.insert(0, os.path.join(ROOT, "tests", "hipemu"))
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import emu
+    if not emu.available():
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    import fullemu
+    from oracle import ref_import as R
+    from studiogan_amd import ops as sg_ops, losses as sg_losses
+    from config_worker_parity_emulated import reference_worker, grads, params, worst, N_D
+    from config_parity_emulated import shrink
+    R._prepare()
+    import config
+    y = shrink(yaml.safe_load(open("/root/reference/src/configs/ImageNet/BigGAN-256.yaml")))
+    batch = 4
+    y["OPTIMIZATION"].update(batch_size=batch, d_updates_per_step=N_D)
+    y["MODEL"].update(g_ema_start=0, g_ema_decay=0.9)          # (the file starts the average after 20000 steps: here it is live at step 1)
+    S, nc = y["DATA"]["img_size"], y["DATA"]["num_classes"]
+    g = torch.Generator().manual_seed(11)
+    baskets = [(torch.randint(0, 256, (N_D * batch, 3, S, S), generator=g).float() / 127.5 - 1.0, torch.randint(0, nc, (N_D * batch,), generator=g))]
+    nt = torch.get_num_threads()
+
+    def drive(cfgs, Gen, Dis):
+        w, Gema = reference_worker(R, cfgs, Gen, Dis, baskets, "N/A")
+        torch.manual_seed(77)
+        _, d_loss = w.train_discriminator(1)
+        dg = grads(Dis)
+        g_loss = w.train_generator(1)
+        return dict(d_loss=float(d_loss.detach()), g_loss=float(g_loss.detach()), dg=dg, gg=grads(Gen), dp=params(Dis), gp=params(Gen), ema=params(Gema))
+
+    # ---- the reference's driver over the reference's networks
+    torch.manual_seed(0)
+    cfgs_r = R.load_cfgs(y)
+    Gr, Dr = R.build_models(cfgs_r)
+    g_state, d_state = copy.deepcopy(Gr.state_dict()), copy.deepcopy(Dr.state_dict())
+    ref = drive(cfgs_r, Gr, Dr)
+    # ---- the same driver over this package's networks, found through the reference's own import
+    (tmp_path / "models").mkdir()
+    (tmp_path / "models" / "big_resnet_amd.py").write_text(
+        f"import sys; sys.path.insert(0, {ROOT!r})\n"
+        "import studiogan_amd\n"
+        "from studiogan_amd.backbones.big_resnet import Generator, Discriminator\n")
+    saved = (config.ops, config.losses)
+    sys.path.insert(0, str(tmp_path))
+    try:
+        config.ops, config.losses = sg_ops, sg_losses           # INTEGRATION.md §3 / §4: the two import lines of src/config.py
+        y2 = copy.deepcopy(y)
+        y2["MODEL"]["backbone"] = "big_resnet_amd"
+        cfgs = R.load_cfgs(y2)
+        cfgs.update_cfgs({"mixed_precision": False, "distributed_data_parallel": False, "synchronized_bn": False}, super="RUN")      # (what src/main.py's flags set)
+        assert cfgs.MODULES.d_conv2d is sg_ops.snconv2d and cfgs.MODULES.g_bn is sg_ops.ConditionalBatchNorm2d
+        model = importlib.import_module("models.model")
+        torch.set_num_threads(1)
+        with fullemu.Installed(dma_late=1, greedy=1, seed=1) as E:
+            Gen, _, _, Dis, _, _, _, _ = model.load_generator_discriminator(cfgs.DATA, cfgs.OPTIMIZATION, cfgs.MODEL, cfgs.STYLEGAN, cfgs.MODULES, cfgs.RUN, "cpu",
+                                                                            logging.getLogger("seam-test"))
+            assert type(Gen).__module__ == "studiogan_amd.backbones.big_resnet" and sys.modules["models.big_resnet_amd"].Generator is type(Gen)
+            Gen.load_state_dict(g_state, strict=True)
+            Dis.load_state_dict(d_state, strict=True)
+            launches0 = E.counters()["launches"]
+            mine = drive(cfgs, Gen, Dis)
+            assert cfgs.LOSS.d_loss is sg_losses.d_hinge and isinstance(cfgs.OPTIMIZATION.d_optimizer, torch.optim.Adam)
+            assert E.counters()["launches"] - launches0 > 500, "the update did not run through the kernels"
+    finally:
+        torch.set_num_threads(nt)
+        config.ops, config.losses = saved
+        sys.path.remove(str(tmp_path))
+        sys.modules.pop("models.big_resnet_amd", None)
+    lr_d, lr_g = y["OPTIMIZATION"]["d_lr"], y["OPTIMIZATION"]["g_lr"]
+    e = dict(d_loss=abs(mine["d_loss"] - ref["d_loss"]) / max(abs(ref["d_loss"]), 1e-3), g_loss=abs(mine["g_loss"] - ref["g_loss"]) / max(abs(ref["g_loss"]), 1e-3),
+             d_grads=worst(mine["dg"], ref["dg"])[0], g_grads=worst(mine["gg"], ref["gg"])[0],
+             d_params_lr=max(float((mine["dp"][k] - ref["dp"][k]).abs().max()) for k in ref["dp"]) / (N_D * lr_d),
+             g_params_lr=max(float((mine["gp"][k] - ref["gp"][k]).abs().max()) for k in ref["gp"]) / lr_g,
+             ema_lr=max(float((mine["ema"][k] - ref["ema"][k]).abs().max()) for k in ref["ema"]) / lr_g)
+    print({k: f"{v:.2e}" for k, v in e.items()})
+    # (fp32 both sides; bounds of tools/config_worker_parity_emulated.py: an element whose gradient is rounding noise moves by about +-lr per Adam step either way)
+    assert e["d_loss"] <= 2e-3 and e["g_loss"] <= 2e-3 and e["d_grads"] <= 1e-2 and e["g_grads"] <= 1e-2, e
+    assert e["d_params_lr"] <= 3.0 and e["g_params_lr"] <= 3.0 and e["ema_lr"] <= 3.0, e
