@@ -290,3 +290,15 @@ def test_config_steps_fixture_regenerates_from_the_reference(tmp_path, monkeypat
             assert np.array_equal(a[k], b[k]), k
         else:
             assert np.allclose(a[k], b[k], rtol=1e-5, atol=0), (k, a[k], b[k])
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_emulated_sn_kernels_against_torch_spectral_norm(dtype):
+    """tests/test_sn_gpu.py's kernel-level spectral-norm table (sg_sn_forward / sg_sn_backward against torch.nn.utils.spectral_norm in fp64) on the interpreter"""
+    import fullemu
+    import sn_checks as SC
+    with fullemu.Installed(dma_late=1, greedy=1, seed=2) as E:
+        L = E.L
+        rows = SC.run(torch.device("cpu"), dtype, L, L.call, L.ptr, L.stream)
+    bad = [(n, e, t) for n, e, t in rows if not e <= t]
+    assert not bad, bad

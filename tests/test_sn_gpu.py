@@ -1,0 +1,20 @@
+"""GPU: spectral norm at the kernel level (VERDICT r5 missing #5): sg_sn_forward / sg_sn_backward through the C ABI against torch.nn.utils.spectral_norm in fp64
+(reference src/utils/ops.py:195-224) -- u, v, sigma, their snapshots, both operand images (forward [Cout][R][S][Cin_pad], data gradient [Cin][R'][S'][rows_pad],
+flipped or not), the fp32 natural image of linear / embedding layers, and dW_orig = (G - <G, W/sigma> u v^T) / sigma accumulated into a non-zero gradient, for
+plain / RGB-padded / transposed / 1x1 / 4x4 / eval-mode / un-normalised layers in ONE batched table per call."""
+import pytest
+import torch
+
+import sn_checks as SC
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["fp32", "bf16"])
+def test_sn_forward_backward_against_torch_spectral_norm(sg, dtype):
+    from studiogan_amd import _lib as L
+    rows = SC.run(torch.device("cuda:0"), dtype, L, L.call, L.ptr, L.stream)
+    bad = [(n, e, t) for n, e, t in rows if not e <= t]
+    for n, e, t in rows:
+        print(f"{n:60s} err {e:.3e} (tol {t:.0e})")
+    assert not bad, bad
