@@ -242,6 +242,33 @@ int sg_allreduce_flat(sg_comm_t comm, void* buf, long long count, int dtype, sg_
  * statistics when running_mean != NULL), count = rows * nranks; partial = fp64 scratch [2*C] */
 int sg_bn_stats_sync(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_comm_t comm, float eps, float momentum,
                      float* mean, float* invstd, float* running_mean, float* running_var, sg_stream_t s);
+/* reduce-scatter / all-gather halves of the gradient exchange (the sharded optimizer step: every rank reduces and updates 1/world of the arena, then the updated
+ * parameters are gathered; the gather can stay in flight behind the next forward of the OTHER network). In place: the shard of rank r is
+ * buf[r * per_rank, (r + 1) * per_rank); count = per_rank elements, fp32. */
+int sg_reduce_scatter_flat(sg_comm_t comm, float* buf, long long per_rank, sg_stream_t s);
+int sg_allgather_flat(sg_comm_t comm, float* buf, long long per_rank, sg_stream_t s);
+
+/* ---- peer-store mailboxes: the sync-BN exchange FUSED INTO the statistics kernel (csrc/p2p.hip). Each rank owns a fine-grained device buffer
+ * that every peer maps through an IPC handle; sg_bn_finalize_p2p's kernel writes this rank's 2*C partial sums into every peer's buffer (xGMI stores,
+ * 8-byte {epoch | payload} granules), waits for the peers' granules of the same call and finalises mean / invstd / running statistics of the global
+ * batch in the same launch -- one xGMI round trip instead of a collective call between two kernels (replaces SyncBatchNorm's all_gather, reference
+ * src/models/model.py:161-165). Calls must be issued in the same order on every rank. ---- */
+typedef void* sg_p2p_t;
+/* allocates this rank's mailbox (room for max_doubles values per call) and returns its 64-byte IPC handle for the host to hand to every peer */
+int sg_p2p_create(int world, int rank, long long max_doubles, sg_p2p_t* out, void* handle_out64);
+/* handles: world x 64 bytes in rank order (entry [rank] is ignored) */
+int sg_p2p_connect(sg_p2p_t p, const void* handles);
+int sg_p2p_destroy(sg_p2p_t p);
+/* number of granule waits that ran into the spin limit so far (a peer died or skipped a call): 0 on a healthy job */
+int sg_p2p_timeouts(sg_p2p_t p, int* count);
+/* in-place sum of n <= max_doubles doubles over the ranks in rank order (bit-identical on every rank); one launch */
+int sg_p2p_allreduce_f64(sg_p2p_t p, double* buf, int n, sg_stream_t s);
+/* partial [2*C]: this rank's sums; count = local rows x world. Exchange + finalize in ONE kernel */
+int sg_bn_finalize_p2p(sg_p2p_t p, const double* partial, double count, int C, float eps, float momentum, float* mean, float* invstd,
+                       float* running_mean, float* running_var, sg_stream_t s);
+/* sg_bn_stats_sync over the mailboxes: local partial sums, then the fused exchange + finalize */
+int sg_bn_stats_sync_p2p(int dtype, const void* x, int ldx, long long rows, int C, double* partial, sg_p2p_t p, float eps, float momentum,
+                         float* mean, float* invstd, float* running_mean, float* running_var, sg_stream_t s);
 /* eval mode: mean/invstd from running stats */
 int sg_bn_from_running(const float* running_mean, const float* running_var, int C, float eps, float* mean, float* invstd, sg_stream_t s);
 /* y = relu?( (x-mean)*invstd * gain + bias ), gain/bias either per-channel [C] (stride_n = 0) or per-sample [N][C] */

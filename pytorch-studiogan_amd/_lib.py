@@ -144,6 +144,15 @@ _PROTOS = {
     "sg_comm_destroy": [_vp],
     "sg_allreduce_flat": [_vp, _vp, _ll, _i, _vp],
     "sg_bn_stats_sync": [_i, _vp, _i, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_reduce_scatter_flat": [_vp, _vp, _ll, _vp],
+    "sg_allgather_flat": [_vp, _vp, _ll, _vp],
+    "sg_p2p_create": [_i, _i, _ll, C.POINTER(_vp), _vp],
+    "sg_p2p_connect": [_vp, _vp],
+    "sg_p2p_destroy": [_vp],
+    "sg_p2p_timeouts": [_vp, C.POINTER(_i)],
+    "sg_p2p_allreduce_f64": [_vp, _vp, _i, _vp],
+    "sg_bn_finalize_p2p": [_vp, _vp, C.c_double, _i, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_bn_stats_sync_p2p": [_i, _vp, _i, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
     "sg_bn_from_running": [_vp, _vp, _i, _f, _vp, _vp, _vp],
     "sg_bn_apply": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp],
     "sg_bn_bwd_reduce": [_i, _vp, _vp, _i, _ll, _i, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp],
@@ -272,7 +281,7 @@ def check(rc, name=""):
 
 # Entry points that write parameters / buffers of a network through raw pointers (invisible to torch's version counters): every call moves the
 # epoch the weight bank's frozen-network cache is keyed on (bank.WeightBank.begin_forward).
-_STATE_WRITERS = frozenset(("sg_adam_ema", "sg_ema_lerp", "sg_allreduce_flat", "sg_clamp_flat"))
+_STATE_WRITERS = frozenset(("sg_adam_ema", "sg_ema_lerp", "sg_allreduce_flat", "sg_clamp_flat", "sg_allgather_flat"))
 write_epoch = [0]
 
 

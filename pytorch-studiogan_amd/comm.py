@@ -1,4 +1,5 @@
-"""Native RCCL communicator of libsgamd.so (include/sgamd.h: sg_comm_*, sg_allreduce_flat, sg_bn_stats_sync): the data-parallel
+"""Native communicators of libsgamd.so (include/sgamd.h: sg_comm_*, sg_allreduce_flat, sg_reduce_scatter_flat / sg_allgather_flat, sg_bn_stats_sync over RCCL;
+sg_p2p_* peer-store mailboxes with the sync-BN exchange fused into the statistics kernel): the data-parallel
 exchanges of the training step -- gradient all-reduce of the flat arena, sync-BN statistics -- issued through the C ABI on HIP
 streams instead of torch.distributed collectives. Replaces DistributedDataParallel / SyncBatchNorm of reference
 src/models/model.py:157-180.
@@ -102,6 +103,59 @@ class NativeComm:
                 setattr(self, name, C.c_void_p())
 
 
+class P2PMailbox:
+    """Peer-store mailboxes of csrc/p2p.hip for `group`: sync-BN's exchange fused into the statistics kernel (sg_bn_finalize_p2p) and the one-launch tiny
+    all-reduce of the backward pass's channel terms (sg_p2p_allreduce_f64). torch.distributed is used ONCE, to hand the 64-byte IPC handles around (any
+    backend: the data path never touches it) -- so two processes on ONE GPU exercise the very kernels eight GPUs run over xGMI."""
+
+    MAX_DOUBLES = 8192          # 2 x C of the widest batch norm (BigGAN-deep at ch 128: C = 2048) with room to spare; 5 x C of the second-order terms up to C = 1638
+
+    def __init__(self, group=None):
+        ddp = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if ddp else 1
+        self.rank = dist.get_rank(group) if ddp else 0
+        self.handle = C.c_void_p()
+        mine = (C.c_char * 64)()
+        L.call("sg_p2p_create", self.world, self.rank, self.MAX_DOUBLES, C.byref(self.handle), mine)
+        if self.world > 1:
+            box = [None] * self.world
+            dist.all_gather_object(box, bytes(mine.raw), group=group)
+            L.call("sg_p2p_connect", self.handle, (C.c_char * (64 * self.world)).from_buffer_copy(b"".join(box)))
+
+    def allreduce_f64_(self, t):
+        """in-place sum of a small fp64 CUDA tensor over the ranks (rank order on every rank: bit-identical replicas), one launch on the current stream"""
+        assert t.is_cuda and t.is_contiguous() and t.dtype == torch.float64 and t.numel() <= self.MAX_DOUBLES
+        L.call("sg_p2p_allreduce_f64", self.handle, t.data_ptr(), t.numel(), L.stream())
+        return t
+
+    def timeouts(self):
+        n = C.c_int(0)
+        L.call("sg_p2p_timeouts", self.handle, C.byref(n))
+        return n.value
+
+    def close(self):
+        if self.handle:
+            L.call("sg_p2p_destroy", self.handle)
+            self.handle = C.c_void_p()
+
+
+_P2P = {}          # group key -> P2PMailbox
+
+
+def enable_p2p(group=None):
+    """Create (once) the peer-store mailboxes serving `group`: from then on functional.BNFn exchanges sync-BN statistics inside its finalize kernel and the
+    backward's channel terms with one sg_p2p_allreduce_f64 launch instead of a collective call (RCCL or torch.distributed). Independent of enable():
+    the gradient exchange keeps its RCCL communicator."""
+    k = _key(group)
+    if k not in _P2P:
+        _P2P[k] = P2PMailbox(None if k == "world" else group)
+    return _P2P[k]
+
+
+def p2p_for(group):
+    return _P2P.get(_key(group)) if _P2P else None
+
+
 def enable(group=None, device=None):
     """Create (once) and register the native communicator serving `group`; returns it."""
     k = _key(group)
@@ -116,6 +170,7 @@ def native_for(group):
 
 
 def disable_all():
-    for c in _REGISTRY.values():
+    for c in list(_REGISTRY.values()) + list(_P2P.values()):
         c.close()
     _REGISTRY.clear()
+    _P2P.clear()

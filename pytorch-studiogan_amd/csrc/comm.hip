@@ -19,12 +19,15 @@ typedef int (*fn_get_uid)(sg_nccl_uid*);
 typedef int (*fn_init_rank)(sg_nccl_comm*, int, sg_nccl_uid, int);
 typedef int (*fn_destroy)(sg_nccl_comm);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, sg_nccl_comm, hipStream_t);
+typedef int (*fn_reduce_scatter)(const void*, void*, size_t, int, int, sg_nccl_comm, hipStream_t);
+typedef int (*fn_allgather)(const void*, void*, size_t, int, sg_nccl_comm, hipStream_t);
+typedef int (*fn_rank)(const sg_nccl_comm, int*);
 typedef int (*fn_count)(const sg_nccl_comm, int*);
 typedef const char* (*fn_errstr)(int);
 
 static void* g_rccl = nullptr;
 static fn_get_uid p_get_uid; static fn_init_rank p_init_rank; static fn_destroy p_destroy; static fn_allreduce p_allreduce;
-static fn_count p_count; static fn_errstr p_errstr;
+static fn_count p_count; static fn_errstr p_errstr; static fn_reduce_scatter p_reduce_scatter; static fn_allgather p_allgather; static fn_rank p_rank;
 
 static int rccl_load() {
   if (g_rccl) return 0;
@@ -40,6 +43,9 @@ static int rccl_load() {
   p_allreduce = (fn_allreduce)dlsym(g_rccl, "ncclAllReduce");
   p_count = (fn_count)dlsym(g_rccl, "ncclCommCount");
   p_errstr = (fn_errstr)dlsym(g_rccl, "ncclGetErrorString");
+  p_reduce_scatter = (fn_reduce_scatter)dlsym(g_rccl, "ncclReduceScatter");
+  p_allgather = (fn_allgather)dlsym(g_rccl, "ncclAllGather");
+  p_rank = (fn_rank)dlsym(g_rccl, "ncclCommUserRank");
   if (!p_get_uid || !p_init_rank || !p_destroy || !p_allreduce || !p_count) {
     sg_set_error("sg_comm: RCCL symbols missing");
     dlclose(g_rccl);
@@ -89,6 +95,23 @@ extern "C" int sg_allreduce_flat(sg_comm_t comm, void* buf, long long count, int
   SG_CHECK(dtype == SG_DTYPE_F32 || dtype == SG_DTYPE_F64, "sg_allreduce_flat: fp32 or fp64 buffers only");
   const int nccl_dt = dtype == SG_DTYPE_F32 ? 7 : 8;      // ncclFloat32 / ncclFloat64 (rccl.h)
   if (int rc = p_allreduce(buf, buf, (size_t)count, nccl_dt, 0 /* ncclSum */, comm, (hipStream_t)s)) return rccl_fail("sg_allreduce_flat", rc);
+  return 0;
+}
+// The two halves of the sharded gradient exchange, in place on the flat arenas: rank r's shard is buf[r * per_rank, (r + 1) * per_rank).
+// RCCL's in-place conventions: reduce-scatter with recvbuff == sendbuff + rank * recvcount, all-gather with sendbuff == recvbuff + rank * sendcount.
+extern "C" int sg_reduce_scatter_flat(sg_comm_t comm, float* buf, long long per_rank, sg_stream_t s) {
+  SG_CHECK(comm && buf && per_rank > 0 && g_rccl && p_reduce_scatter && p_rank, "sg_reduce_scatter_flat: bad arguments / no communicator");
+  int rank = 0;
+  if (int rc = p_rank(comm, &rank)) return rccl_fail("sg_reduce_scatter_flat", rc);
+  if (int rc = p_reduce_scatter(buf, buf + (size_t)rank * per_rank, (size_t)per_rank, 7 /* ncclFloat32 */, 0 /* ncclSum */, comm, (hipStream_t)s))
+    return rccl_fail("sg_reduce_scatter_flat", rc);
+  return 0;
+}
+extern "C" int sg_allgather_flat(sg_comm_t comm, float* buf, long long per_rank, sg_stream_t s) {
+  SG_CHECK(comm && buf && per_rank > 0 && g_rccl && p_allgather && p_rank, "sg_allgather_flat: bad arguments / no communicator");
+  int rank = 0;
+  if (int rc = p_rank(comm, &rank)) return rccl_fail("sg_allgather_flat", rc);
+  if (int rc = p_allgather(buf + (size_t)rank * per_rank, buf, (size_t)per_rank, 7 /* ncclFloat32 */, comm, (hipStream_t)s)) return rccl_fail("sg_allgather_flat", rc);
   return 0;
 }
 // Batch statistics of a (data-parallel) batch: partial[2C] fp64 scratch (overwritten). comm == NULL: single rank. `rows` is the

@@ -1066,8 +1066,11 @@ def _allreduce_sum(t, group):
     """sum over the data-parallel ranks: the C ABI's RCCL entry point when a native communicator serves the group (comm.enable),
     torch.distributed otherwise."""
     nc = _comm.native_for(group)
+    pp = _comm.p2p_for(group) if (t.dtype == torch.float64 and t.numel() <= _comm.P2PMailbox.MAX_DOUBLES) else None
     with _comm.exposed():          # on the compute stream: the whole collective is exposed (bench.py exposed_comm_ms_per_step)
-        if nc is not None:
+        if pp is not None:         # peer-store mailboxes: one launch, one xGMI round trip (csrc/p2p.hip)
+            pp.allreduce_f64_(t)
+        elif nc is not None:
             nc.allreduce_(t)
         else:
             dist.all_reduce(t, group=None if group is True else group)
@@ -1098,7 +1101,19 @@ class BNFn(torch.autograd.Function):
             rm = running_mean if cfg.track else None
             rv = running_var if cfg.track else None
             nc = _comm.native_for(cfg.group) if ws > 1 else None
-            if fused is not None:
+            pp = _comm.p2p_for(cfg.group) if (ws > 1 and 2 * Cc <= _comm.P2PMailbox.MAX_DOUBLES) else None
+            if pp is not None:
+                # sync-BN with the exchange FUSED INTO the finalize kernel: this rank's partial sums go straight into every peer's HBM (csrc/p2p.hip), the same
+                # launch waits for the peers' and writes mean / invstd / running statistics of the global batch
+                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                if fused is not None:
+                    L.call("sg_bn_stats_from_tiles", fused[0].data_ptr(), fused[1], Cc, L.ptr(partial), L.stream())
+                else:
+                    L.call("sg_bn_partial_stats", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), L.stream())
+                count *= ws
+                with _comm.exposed():
+                    L.call("sg_bn_finalize_p2p", pp.handle, L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
+            elif fused is not None:
                 partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
                 L.call("sg_bn_stats_from_tiles", fused[0].data_ptr(), fused[1], Cc, L.ptr(partial), L.stream())
                 if ws > 1:

@@ -34,12 +34,12 @@ def build(opt="-O1", jobs=None):
     hdrs = [os.path.join(emu.SRC, f) for f in sorted(os.listdir(emu.SRC)) if f.endswith(".h")] + [os.path.join(HERE, "include", "hip", "hip_runtime.h"),
                                                                                                    os.path.join(emu.REPO if hasattr(emu, "REPO") else translate.REPO, "include", "sgamd.h")]
     hh = _sha(hdrs, opt)
-    units = [f[:-4] for f in sorted(os.listdir(emu.SRC)) if f.endswith(".hip")]
+    units = [f[:-4] for f in sorted(os.listdir(emu.SRC)) if f.endswith(".hip") and f != "p2p.hip"]      # (p2p.hip: IPC peer memory, not emulated -- p2p_stub.cpp keeps the ABI complete)
     common = [emu.CXX, "-x", "c++", "-std=c++17", "-fPIC", "-ffp-contract=off", "-I" + os.path.join(HERE, "include"), "-I" + emu.SRC,
               "-Wno-unknown-attributes", "-Wno-unused-value"]
     todo, objs = [], []
-    for u in units + ["rt"]:
-        src = os.path.join(HERE, "rt.cpp") if u == "rt" else os.path.join(emu.SRC, u + ".hip")
+    for u in units + ["rt", "p2p_stub"]:
+        src = os.path.join(HERE, u + ".cpp") if u in ("rt", "p2p_stub") else os.path.join(emu.SRC, u + ".hip")
         o = os.path.join(OBJ, "%s_%s.o" % (u, _sha([src], hh)))
         objs.append(o)
         if not os.path.exists(o):

@@ -29,20 +29,20 @@ def _free_port():
     return p
 
 
-def _run(rank, world, port, name, desync, ret, steps=1):
+def _run(rank, world, port, name, desync, ret, steps=1, p2p=False):
     sys.path.insert(0, os.path.dirname(HERE))
     sys.path.insert(0, HERE)
     os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
     if world > 1:
         dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        ret[rank] = _job(rank, world, name, desync, steps)
+        ret[rank] = _job(rank, world, name, desync, steps, p2p)
     finally:
         if world > 1:
             dist.destroy_process_group()
 
 
-def _job(rank, world, name, desync, steps=1):
+def _job(rank, world, name, desync, steps=1, p2p=False):
     import studiogan_amd  # noqa: F401
     from studiogan_amd import ops
     from studiogan_amd.worker import Worker
@@ -56,6 +56,17 @@ def _job(rank, world, name, desync, steps=1):
     G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
     D.load_state_dict({k: v.to(dev) for k, v in sub(fix, "D_init/").items()}, strict=True)
     group = dist.group.WORLD if world > 1 else None
+    box = None
+    if p2p and world > 1:
+        # sync-BN through the peer-store mailboxes (csrc/p2p.hip): the exchange runs INSIDE the finalize kernel, over IPC-mapped device memory -- the two
+        # processes share one GPU here, the kernels and the protocol are the ones N GPUs run over xGMI. (gloo only hands the 64-byte handles around.)
+        from studiogan_amd import comm
+        box = comm.enable_p2p(group)
+        v = torch.arange(1, 1001, dtype=torch.float64, device=dev) * (rank + 1) + 0.125 * rank
+        for _ in range(5):                     # back-to-back calls: the two-slot epoch protocol
+            box.allreduce_f64_(v)
+        torch.cuda.synchronize()
+        p2p_vec = v.cpu()
     caught = None
     if desync and rank == 1:                       # what per-rank seeding does to an un-broadcast model (reference src/loader.py:99)
         with torch.no_grad():
@@ -95,13 +106,18 @@ def _job(rank, world, name, desync, steps=1):
         early = {"D": dict(w.d_optimizer.exchange_stats), "G": dict(w.g_optimizer.exchange_stats)}
     state = {"D/" + k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
     state.update({"G/" + k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
-    return {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught, "early": early}
+    out = {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught, "early": early}
+    if box is not None:
+        out["p2p_vec"], out["p2p_timeouts"] = p2p_vec, box.timeouts()
+        from studiogan_amd import comm
+        comm.disable_all()
+    return out
 
 
-def _spawn(world, name, desync=False, steps=1):
+def _spawn(world, name, desync=False, steps=1, p2p=False):
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_run, args=(world, _free_port(), name, desync, ret, steps), nprocs=world, join=True)
+    mp.spawn(_run, args=(world, _free_port(), name, desync, ret, steps, p2p), nprocs=world, join=True)
     return dict(ret)
 
 
@@ -125,6 +141,40 @@ def test_two_ranks_on_one_gpu_equal_the_full_batch_step(sg, name):
     for k, v in full["state"].items():
         if v.dtype.is_floating_point:
             # (an element whose gradient is rounding noise -- e.g. a conv bias in front of a BN -- moves by +-lr with either sign)
+            C.check("state " + k, a["state"][k], v, 2e-3, floor=0.05, abs_ok=2.2 * lr)
+        else:
+            assert torch.equal(a["state"][k], v), k
+    C.finish()
+
+
+@pytest.mark.parametrize("name", ["resgan32", "biggan32"])
+def test_two_ranks_sync_bn_fused_peer_store_exchange(sg, name):
+    """The north star's "cross-rank mean/var reduction fused into the BN kernel" (csrc/p2p.hip): two PROCESSES on this GPU map each other's mailbox through IPC handles;
+    functional.BNFn's statistics go out as peer stores from inside sg_bn_finalize_p2p's kernel, the backward's channel terms through sg_p2p_allreduce_f64 -- no collective
+    library in the sync-BN path. Checked: five back-to-back tiny all-reduces are exact (epoch / two-slot protocol), no granule wait ran into its limit, both ranks end
+    BIT-identical, and the two-rank step equals the full-batch single-rank step (the bounds of test_two_ranks_on_one_gpu_equal_the_full_batch_step)."""
+    from util import Collector, load_golden, hyper
+    full = _spawn(1, name)[0]
+    two = _spawn(2, name, p2p=True)
+    a, b = two[0], two[1]
+    base = torch.arange(1, 1001, dtype=torch.float64)
+    want = (base * 1 + 0.0) + (base * 2 + 0.125)
+    for _ in range(4):
+        want = want * 2
+    assert torch.equal(a["p2p_vec"], want) and torch.equal(b["p2p_vec"], want)
+    assert a["p2p_timeouts"] == 0 and b["p2p_timeouts"] == 0
+    for k in a["state"]:
+        assert torch.equal(a["state"][k], b["state"][k]), f"replicas diverged: {k}"
+    C = Collector()
+    gm = max(float(v.abs().max()) for v in full["d_grad"].values())
+    for k, v in full["d_grad"].items():
+        C.check("D grad " + k, a["d_grad"][k], v, 2e-4, floor=1e-2 * gm)
+    gm = max(float(v.abs().max()) for v in full["g_grad"].values())
+    for k, v in full["g_grad"].items():
+        C.check("G grad " + k, a["g_grad"][k], v, 5e-3, floor=1e-2 * gm)
+    lr = max(hyper(load_golden(name)[1]["yaml"])[k] for k in ("g_lr", "d_lr"))
+    for k, v in full["state"].items():
+        if v.dtype.is_floating_point:
             C.check("state " + k, a["state"][k], v, 2e-3, floor=0.05, abs_ok=2.2 * lr)
         else:
             assert torch.equal(a["state"][k], v), k
