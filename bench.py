@@ -396,8 +396,12 @@ def main():
     ap.add_argument("--fid-samples", type=int, default=50000, help="samples of the FID feature-extraction leg (0 = skip)")
     ap.add_argument("--cpu-batch", type=int, default=8)
     ap.add_argument("--no-extras", action="store_true", help="skip the extra workloads (C2 fp32, C5 WGAN-GP, C4 per GPU)")
-    ap.add_argument("--native-comm", action="store_true", help="gradient / sync-BN exchanges through libsgamd.so's own RCCL communicator "
-                    "(sg_allreduce_flat on HIP streams) instead of torch.distributed's nccl backend (same RCCL underneath); also SG_NATIVE_COMM=1")
+    ap.add_argument("--native-comm", action="store_true", help="same as --comm native")
+    ap.add_argument("--comm", choices=["auto", "native", "torch"], default=os.environ.get("SG_COMM", "auto"),
+                    help="N > 1: who carries the exchanges. auto (default): libsgamd.so's own RCCL communicators for the gradient arena (sg_allreduce_flat on HIP "
+                         "streams) and the peer-store mailboxes for sync-BN (exchange fused into the statistics kernel), each kept only if its self-test agrees with "
+                         "torch.distributed on EVERY rank -- otherwise that exchange falls back to torch.distributed's nccl backend and the line says so; native: the "
+                         "same without the fallback (a failing self-test aborts); torch: torch.distributed only")
     ap.add_argument("--strong", action="store_true", help="strong scaling: --batch is the GLOBAL batch, every rank takes batch / world of it (what the reference does: "
                     "src/loader.py:162 divides the configured batch over the ranks); default is weak scaling (--batch per GPU)")
     ap.add_argument("--strict", action="store_true", help="exit non-zero when an extra workload / leg fails (the line is still printed)")
@@ -451,15 +455,66 @@ def main():
     from studiogan_amd import ops
     from studiogan_amd.worker import Worker
 
-    rccl_ranks = None
-    if world > 1 and (args.native_comm or os.environ.get("SG_NATIVE_COMM") == "1") and not one_dev:
-        # the exchanges through the C ABI (sg_allreduce_flat / sync-BN all-reduces on HIP streams) instead of torch.distributed
+    rccl_ranks, bn_exchange, comm_notes = None, None, []
+    if args.native_comm or os.environ.get("SG_NATIVE_COMM") == "1":
+        args.comm = "native"
+    if world > 1 and args.comm != "torch":
         from studiogan_amd import comm as sg_comm
-        nc = sg_comm.enable(group, device=device)
-        n = ctypes.c_int(0)
-        L.call("sg_comm_size", nc.handle, ctypes.byref(n))
-        rccl_ranks = n.value
-        assert rccl_ranks == world, f"native communicator has {rccl_ranks} ranks, job has {world}"
+
+        def agreed(ok):          # a path is used only if EVERY rank saw it pass (one MIN all-reduce through torch.distributed)
+            t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if not one_dev else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            return bool(int(t.item()))
+        want = world * (world + 1) / 2.0
+        # 1. gradient arena: the C ABI's own RCCL communicators (RCCL refuses two ranks on one device: not on the one-device plumbing run)
+        if not one_dev:
+            ok, why = False, ""
+            try:
+                nc = sg_comm.enable(group, device=device)
+                n = ctypes.c_int(0)
+                L.call("sg_comm_size", nc.handle, ctypes.byref(n))
+                t = torch.full((4096,), float(rank + 1), device=device)
+                nc.allreduce_(t)
+                t2 = torch.full((4096,), float(rank + 1), device=device)
+                nc.stream.wait_stream(torch.cuda.current_stream())
+                nc.allreduce_(t2, stream=nc.stream.cuda_stream, grad=True)          # (the gradient communicator, on its side stream)
+                torch.cuda.synchronize()
+                ok = n.value == world and bool((t == want).all()) and bool((t2 == want).all())
+                why = "" if ok else f"self-test mismatch (ranks {n.value}, sum {float(t[0])} / {float(t2[0])}, expected {want})"
+            except Exception as e:      # noqa: BLE001
+                why = f"{type(e).__name__}: {str(e)[:200]}"
+            if agreed(ok):
+                rccl_ranks = world
+            else:
+                comm_notes.append("native RCCL communicator rejected: " + (why or "another rank failed its self-test"))
+                sg_comm._REGISTRY.clear()
+                if args.comm == "native":
+                    raise SystemExit("bench.py --comm native: " + comm_notes[-1])
+        # 2. sync-BN: peer-store mailboxes, the exchange fused into the finalize kernel (csrc/p2p.hip)
+        ok, why = False, ""
+        try:
+            box = sg_comm.enable_p2p(group)
+            v = torch.full((64,), float(rank + 1), dtype=torch.float64, device=device)
+            for _ in range(3):
+                v.fill_(float(rank + 1))
+                box.allreduce_f64_(v)
+            torch.cuda.synchronize()
+            ok = bool((v == want).all()) and box.timeouts() == 0
+            why = "" if ok else f"self-test mismatch (sum {float(v[0])}, expected {want}, timeouts {box.timeouts()})"
+        except Exception as e:      # noqa: BLE001
+            why = f"{type(e).__name__}: {str(e)[:200]}"
+        if agreed(ok):
+            bn_exchange = "peer-store mailboxes, exchange fused into the statistics kernel (sg_bn_finalize_p2p / sg_p2p_allreduce_f64)"
+        else:
+            comm_notes.append("peer-store mailboxes rejected: " + (why or "another rank failed its self-test"))
+            sg_comm._P2P.clear()
+            if args.comm == "native":
+                raise SystemExit("bench.py --comm native: " + comm_notes[-1])
+        if rank == 0:
+            for note in comm_notes:
+                sys.stderr.write("[bench] " + note + "\n")
+    if world > 1 and bn_exchange is None:
+        bn_exchange = "RCCL all-reduce between the statistics kernels (sg_bn_stats_sync)" if rccl_ranks else "torch.distributed all-reduce between the statistics kernels"
     wl = WORKLOADS[args.workload]
     mixed = not args.fp32
     torch.manual_seed(1234)  # identical initial weights on every rank (what DDP's initial broadcast guarantees)
@@ -674,7 +729,7 @@ def main():
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else ""),
                    "exchange": None if world == 1 else ("libsgamd sg_allreduce_flat (native RCCL communicator)" if rccl_ranks else
                                                         ("gloo (one-device plumbing run)" if one_dev else "torch.distributed nccl backend (= RCCL)")),
-                   "rccl_ranks": rccl_ranks,
+                   "rccl_ranks": rccl_ranks, "sync_bn_exchange": bn_exchange, "comm_notes": comm_notes or None,
                    # time the compute stream spent waiting for collectives (sync-BN all-reduces run on it; waits on the gradient reductions in
                    # FusedAdam.step), max over ranks: hipEvent pairs around every such point (studiogan_amd.comm.exposed)
                    "exposed_comm_ms_per_step": None if exposed_comm_ms is None else round(exposed_comm_ms / args.steps, 3)},

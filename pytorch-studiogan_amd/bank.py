@@ -77,6 +77,25 @@ class ParamArena:
         a, o = arena_of(p)
         return a.grad[o:o + p.numel()].view(p.shape)
 
+    # -- a write to `data` still in flight on another stream (optim.FusedAdam's sharded step leaves the all-gather of the updated parameters, and the EMA lerp
+    #    behind it, on the communicator's side stream so that they overlap the next forward of the OTHER network): everything that reads the parameters through
+    #    this package -- the weight bank's spectral-norm passes, the optimizer, checkpointing helpers -- calls wait_ready() first.
+    pending = None
+
+    def defer(self, waiter):
+        """waiter: a torch.cuda.Event recorded behind the write, or any object with .wait() (a torch.distributed Work)"""
+        self.wait_ready()
+        self.pending = waiter
+
+    def wait_ready(self):
+        w = self.pending
+        if w is not None:
+            self.pending = None
+            if isinstance(w, torch.cuda.Event):
+                torch.cuda.current_stream().wait_event(w)
+            else:
+                w.wait()
+
     def intact(self):
         p, o = self.params[0], self.offsets[0]
         q, oq = self.params[-1], self.offsets[-1]
@@ -414,6 +433,7 @@ class WeightBank:
 
     def begin_forward(self, need_graph):
         """One spectral-norm power iteration + weight image emission for every layer; returns the slot."""
+        self.params.wait_ready()          # (a deferred all-gather of this network's parameters: optim.FusedAdam sharded step)
         if need_graph:
             phys = self._free_graph_slot()
             phys.dwt_zeroed = False
@@ -545,6 +565,7 @@ class WeightBank:
         callback at the end of the pass (no arguments) takes whatever is left."""
         if lo is None:
             self._cb_queued = False
+        self.params.wait_ready()
         for slot in self.slots[1:]:
             if not slot.pending:
                 continue

@@ -95,6 +95,16 @@ class NativeComm:
                stream if stream is not None else L.stream())
         return t
 
+    def reduce_scatter_(self, flat, per_rank, stream=None):
+        """in place on the gradient communicator: afterwards flat[rank * per_rank : (rank + 1) * per_rank] holds the sum over the ranks of that range"""
+        assert flat.is_cuda and flat.is_contiguous() and flat.dtype == torch.float32 and flat.numel() >= per_rank * self.world
+        L.call("sg_reduce_scatter_flat", self.grad_handle, flat.data_ptr(), per_rank, stream if stream is not None else L.stream())
+
+    def allgather_(self, flat, per_rank, stream=None):
+        """in place on the gradient communicator: every rank's range [rank * per_rank, (rank + 1) * per_rank) of flat reaches every rank"""
+        assert flat.is_cuda and flat.is_contiguous() and flat.dtype == torch.float32 and flat.numel() >= per_rank * self.world
+        L.call("sg_allgather_flat", self.grad_handle, flat.data_ptr(), per_rank, stream if stream is not None else L.stream())
+
     def close(self):
         for name in ("handle", "grad_handle"):
             h = getattr(self, name, None)

@@ -153,7 +153,7 @@ def _arena_for(params):
 class FusedAdam(torch.optim.Optimizer):
     """torch.optim.Adam semantics (no amsgrad) for ALL parameters of one network in one launch."""
 
-    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.0, comm_chunks=4):
+    def __init__(self, params, lr=2e-4, betas=(0.5, 0.999), eps=1e-6, weight_decay=0.0, comm_chunks=4, sharded=None):
         defaults = dict(lr=lr, betas=tuple(betas), eps=eps, weight_decay=weight_decay)
         super().__init__(params, defaults)
         assert len(self.param_groups) == 1, "one parameter group per network"
@@ -161,6 +161,10 @@ class FusedAdam(torch.optim.Optimizer):
         self._m = self._v = None
         self._t = 0
         self.comm_chunks = comm_chunks
+        # sharded step (SG_SHARDED_ADAM=1 or sharded=True; world > 1 only): reduce-scatter of the gradient arena -> Adam on this rank's 1/world of it -> all-gather
+        # of the updated parameters, the gather (and the EMA lerp behind it) left in flight behind the next forward of the OTHER network. Same bytes on the wire as
+        # the all-reduce, half of them off the critical path, 1/world of the optimizer's HBM traffic per rank.
+        self.sharded = (os.environ.get("SG_SHARDED_ADAM") == "1") if sharded is None else bool(sharded)
         self._replicas_checked = False
         self._module = None
         self._plan = None
@@ -242,6 +246,7 @@ class FusedAdam(torch.optim.Optimizer):
     #    state_dict() emits per-parameter copies of the arena slices and load_state_dict() copies them back.
     def state_dict(self):
         a = self._state()
+        a.wait_ready()
         step = torch.tensor(float(self._t), dtype=torch.float32)
         for p, o in zip(a.params, a.offsets):
             n = p.numel()
@@ -276,6 +281,7 @@ class FusedAdam(torch.optim.Optimizer):
     def clamp_(self, bound):
         """Weight clipping of every parameter of the network to [-bound, bound] (reference src/worker.py:489-492) as one pass over the parameter arena."""
         a = self._state()
+        a.wait_ready()
         L.call("sg_clamp_flat", a.data.data_ptr(), a.numel, -float(bound), float(bound), L.stream())
 
     def zero_grad(self, set_to_none=False):
@@ -290,6 +296,7 @@ class FusedAdam(torch.optim.Optimizer):
     def step(self, closure=None, ema=None, iteration=None, group=None):
         """ema: optional `Ema` whose target shares this network's arena layout -> fused into the same launch."""
         a = self._state()
+        a.wait_ready()
         g = self.param_groups[0]
         for p, o in zip(a.params, a.offsets):
             if p.grad is None or p.grad.data_ptr() != a.grad.data_ptr() + 4 * o:
@@ -337,6 +344,8 @@ class FusedAdam(torch.optim.Optimizer):
             self.exchange_stats["late_elems"] += n
         if n == 0:
             pass
+        elif world > 1 and self.sharded and n == a.numel:
+            self._step_sharded(a, g, world, group, nc, ema, decay, st)
         elif nc is not None:
             # the same pipeline through the C ABI (sg_allreduce_flat): the reductions queue on the communicator's side stream behind
             # an event that marks "gradients complete"; the Adam launch of chunk i waits for ITS reduction only
@@ -368,6 +377,79 @@ class FusedAdam(torch.optim.Optimizer):
                    g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t, decay, 1.0, st)
         if ema is not None:
             ema.update_buffers(decay)
+
+
+    def _step_sharded(self, a, g, world, group, nc, ema, decay, st):
+        """reduce-scatter -> Adam on this rank's shard -> all-gather (see __init__). The arena is cut into world ranges of `per` elements (16-byte aligned) plus a
+        tail of < 4 * world elements that every rank reduces and updates redundantly. Native communicator: both collectives on its side stream, the gather and the
+        EMA lerp stay in flight (ParamArena.defer); torch.distributed: reduce_scatter_tensor / all_gather_into_tensor where the backend has them (nccl = RCCL), an
+        all-reduce + all_gather otherwise (gloo: the CPU / one-device tests)."""
+        n = a.numel
+        rank = dist.get_rank(group)
+        per = (n // (4 * world)) * 4
+        body = per * world
+        lo, hi = rank * per, (rank + 1) * per
+        main = torch.cuda.current_stream() if a.data.is_cuda else None
+        hyper = (g["lr"], g["betas"][0], g["betas"][1], g["eps"], g["weight_decay"], self._t)
+
+        def adam(lo_, hi_):
+            if hi_ > lo_:
+                L.call("sg_adam_ema", a.data.data_ptr() + 4 * lo_, a.grad.data_ptr() + 4 * lo_, self._m.data_ptr() + 4 * lo_, self._v.data_ptr() + 4 * lo_, None,
+                       hi_ - lo_, *hyper, 0.0, 1.0 / world, st)
+        ema_args = None
+        if ema is not None:
+            ema_args = (a.data.data_ptr(), ema.target_arena().data.data_ptr(), n, decay)
+        if nc is not None:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            nc.stream.wait_event(ready)
+            if per:
+                nc.reduce_scatter_(a.grad, per, stream=nc.stream.cuda_stream)
+            if n > body:
+                nc.allreduce_(a.grad[body:n], stream=nc.stream.cuda_stream, grad=True)
+            ev = torch.cuda.Event()
+            ev.record(nc.stream)
+            with _comm.exposed():
+                main.wait_event(ev)                      # exposed: the reduce-scatter only
+            adam(lo, hi)
+            adam(body, n)
+            upd = torch.cuda.Event()
+            upd.record(main)
+            nc.stream.wait_event(upd)
+            if per:
+                nc.allgather_(a.data, per, stream=nc.stream.cuda_stream)
+            if ema_args is not None:                     # p_ema = lerp(p, p_ema, decay) over the gathered parameters, behind the gather on the same stream
+                L.call("sg_ema_lerp", *ema_args, nc.stream.cuda_stream)
+            done = torch.cuda.Event()
+            done.record(nc.stream)
+            a.defer(done)
+            if ema is not None:
+                ema.target_arena().defer(done)
+            return
+        gshard = a.grad[lo:hi]
+        has_rs = dist.get_backend(group) == "nccl"
+        with _comm.exposed():
+            if per and has_rs:
+                dist.reduce_scatter_tensor(gshard, a.grad[:body], group=group)
+            elif per:
+                dist.all_reduce(a.grad[:body], group=group)
+            if n > body:
+                dist.all_reduce(a.grad[body:n], group=group)
+        adam(lo, hi)
+        adam(body, n)
+        if per:
+            if has_rs:
+                work = dist.all_gather_into_tensor(a.data[:body], a.data[lo:hi].clone(), group=group, async_op=ema_args is None)
+                if ema_args is None and work is not None:
+                    a.defer(work)
+            else:
+                parts = [torch.empty_like(gshard) for _ in range(world)]
+                dist.all_gather(parts, a.data[lo:hi].clone(), group=group)
+                for r, t in enumerate(parts):
+                    if r != rank:
+                        a.data[r * per:(r + 1) * per].copy_(t)
+        if ema_args is not None:
+            L.call("sg_ema_lerp", *ema_args, st)
 
 
 class Ema:

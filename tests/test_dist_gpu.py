@@ -85,7 +85,8 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
                 m.sync_group = True
     opt = hyper(y)
     w = Worker(G, D, opt["z_dim"], y["DATA"]["num_classes"], meta["batch"] // world, opt["adv_loss"], opt["g_lr"], opt["d_lr"], opt["beta1"],
-               opt["beta2"], d_updates_per_step=1, apply_g_ema=False, group=group)      # Worker.__init__ runs sync_replicas(G / D, group)
+               opt["beta2"], d_updates_per_step=1, apply_g_ema=os.environ.get("SG_TEST_EMA") == "1", g_ema_decay=0.9, g_ema_start=0,
+               group=group)      # Worker.__init__ runs sync_replicas(G / D, group)
     ins = sub(fix, "in/")
     h = meta["batch"] // world
     sl = slice(rank * h, (rank + 1) * h)
@@ -106,6 +107,8 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
         early = {"D": dict(w.d_optimizer.exchange_stats), "G": dict(w.g_optimizer.exchange_stats)}
     state = {"D/" + k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
     state.update({"G/" + k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
+    if w.Gen_ema is not None:
+        state.update({"G_ema/" + k: v.detach().cpu().clone() for k, v in w.Gen_ema.state_dict().items()})
     out = {"state": state, "d_grad": d_grad, "g_grad": g_grad, "caught": caught, "early": early}
     if box is not None:
         out["p2p_vec"], out["p2p_timeouts"] = p2p_vec, box.timeouts()
@@ -179,6 +182,33 @@ def test_two_ranks_sync_bn_fused_peer_store_exchange(sg, name):
         else:
             assert torch.equal(a["state"][k], v), k
     C.finish()
+
+
+@pytest.mark.parametrize("name", ["biggan32", "resgan32"])
+def test_sharded_optimizer_step_equals_the_allreduce_step(sg, name, monkeypatch):
+    """FusedAdam's sharded step (SG_SHARDED_ADAM=1: reduce-scatter -> Adam on this rank's 1/world of the arena -> all-gather of the updated parameters, EMA lerped
+    over the gathered arena) against the all-reduce step, two ranks, three updates of both networks with the EMA twin on: the two RANKS bit-identical in every
+    parameter, buffer and EMA parameter; the two SCHEMES equal up to what two separate runs of one scheme differ by (fp64 atomics in the BN statistics make a run
+    not bit-reproducible; an element whose gradient is rounding noise then moves by +-lr per update with either sign -- the bound of
+    test_early_gradient_exchange_matches_the_exchange_in_step). Adam is element-wise, so the shard boundaries themselves change nothing."""
+    monkeypatch.setenv("SG_TEST_EMA", "1")
+    monkeypatch.setenv("SG_SHARDED_ADAM", "1")
+    on = _spawn(2, name, steps=3)
+    monkeypatch.setenv("SG_SHARDED_ADAM", "0")
+    off = _spawn(2, name, steps=3)
+    assert any(k.startswith("G_ema/") for k in on[0]["state"])
+    n_diff = 0
+    for k in on[0]["state"]:
+        assert torch.equal(on[0]["state"][k], on[1]["state"][k]), f"replicas diverged under the sharded step: {k}"
+        a, b = on[0]["state"][k], off[0]["state"][k]
+        if not torch.equal(a, b):
+            # two separate runs are not bit-identical run to run (fp64 atomics in the BN statistics): bounded like test_early_gradient_exchange
+            n_diff += 1
+            if a.dtype.is_floating_point:
+                assert float((a - b).abs().max()) <= 2e-3 * max(float(b.abs().max()), 0.05) + 3 * 2.2 * 2e-4, k
+            else:
+                raise AssertionError(k)
+    print("tensors not bit-identical between the two schemes:", n_diff, "of", len(on[0]["state"]))
 
 
 def test_desynchronised_replicas_are_caught_and_repaired(sg):
