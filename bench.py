@@ -648,8 +648,8 @@ def main():
         make_GAN_untrainable(G, w.Gen_ema, D)
         per_rank = (args.fid_samples + world - 1) // world
         fid = {}
-        for name, idt in (("f32", torch.float32), ("bf16", torch.bfloat16)):
-            model = M.LoadEvalModel(device=device, state_dict=M.synthetic_state_dict(0), dtype=idt)   # seeded random Inception weights (the real ones need network access)
+        for name, idt, fmode in (("f32", torch.float32, "exact"), ("f32_bf16x3", torch.float32, "bf16x3"), ("bf16", torch.bfloat16, "exact")):
+            model = M.LoadEvalModel(device=device, state_dict=M.synthetic_state_dict(0), dtype=idt, f32_mode=fmode)   # seeded random Inception weights (the real ones need network access)
             M.generate_images_and_stack_features(w.Gen_ema, model, 2 * args.batch, args.batch, wl["z_dim"], wl["classes"], device=device)  # warm-up
             barrier()
             mom = M.FeatureMoments(2048, device)
@@ -667,11 +667,15 @@ def main():
             del model, feats, probs
         fid = {"metric": "FID-50k feature-extract samples/sec", "samples": per_rank * world, "batch": args.batch,
                "value": fid["f32"]["samples_per_sec"], "unit": "samples/sec", "inception_f32": fid["f32"], "inception_bf16": fid["bf16"],
+               # fp32 tensors, every Inception convolution's operands split into two bf16 terms in registers and contracted with three bf16 MFMAs per k-tile (fp32
+               # accumulation; functional.f32_mode, csrc/gemm_core.h SPLIT): pool3 features within 6e-6 of the fp32 oracle (tests/test_eval_gpu.py, bound 2e-4 as for
+               # the exact path). NOT the headline value: `value` stays the exact-fp32-MFMA run.
+               "inception_f32_bf16x3": dict(fid["f32_bf16x3"], note="fp32 storage, bf16x3 split-precision MFMA arithmetic (~2^-16 per product): not the headline value"),
                "includes": "G_ema forward (bf16) + on-device quantize/resize + InceptionV3 + softmax + fp64 moment accumulation",
                # algorithmic work per sample: G forward 42.24 GFLOP + InceptionV3 at 299^2 11.4 GFLOP
                "roofline_bf16": {"bound": "mfma", "gflop_per_sample": 53.64, "achieved": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3, 1), "unit": "TFLOP/s",
                                  "peak": 2500.0, "frac": round(fid["bf16"]["samples_per_sec"] * 53.64 / 1e3 / 2500.0, 4),
-                                 "kernel_trace": "profiles/r05_fid_leg_kerneltrace.txt (tools/fid_leg.py under rocprofv3 --kernel-trace --stats)"},
+                                 "kernel_trace": "profiles/r06_fid_leg_f32_exact_kerneltrace.txt / r06_fid_leg_f32_bf16x3_kerneltrace.txt (tools/fid_leg.py under rocprofv3 --kernel-trace --stats)"},
                # the headline value's own roofline: G_ema runs in bf16 (42.24 GFLOP per sample on the bf16 MFMA), InceptionV3 in fp32 (11.4 GFLOP per sample on the
                # fp32 MFMA, 157.3 TFLOP/s): the time each half would need at its peak, summed, over the measured time per sample
                "roofline_f32": {"bound": "mfma", "gflop_per_sample_bf16_generator": 42.24, "gflop_per_sample_f32_inception": 11.4,

@@ -74,6 +74,11 @@ typedef struct {
   int ldo, ldr, ldm;
 } sg_conv_fwd_desc;
 int sg_conv2d_fwd(const sg_conv_fwd_desc* d, sg_stream_t stream);
+/* fp32 arithmetic of sg_conv2d_fwd's generic engine (process-wide; default 0): 0 = v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain; 3 = "bf16x3": each fp32
+ * operand element is split into two bf16 terms in registers and a 16-wide k-tile runs as three bf16 MFMAs with fp32 accumulation (~2^-16 relative per
+ * product, 5.3x the matrix-pipe rate). fp32 tensors in and out either way. Used by the FID / IS feature extractor (metrics.InceptionV3 f32_mode). */
+int sg_set_f32_mode(int mode);
+int sg_get_f32_mode(void);
 
 /* Residual-block tail in ONE launch (bf16): out = epilogue( alpha * [ conv3x3(x; w) + conv1x1(up2?(x2); w2) ] + bias + bias2 ).
  * Replaces `x0 = conv2d0(x0); out = x + x0` of the reference's blocks (src/models/big_resnet.py:28-42 GenBlock with nearest x2 on the

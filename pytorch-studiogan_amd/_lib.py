@@ -144,6 +144,8 @@ _PROTOS = {
     "sg_comm_destroy": [_vp],
     "sg_allreduce_flat": [_vp, _vp, _ll, _i, _vp],
     "sg_bn_stats_sync": [_i, _vp, _i, _ll, _i, _vp, _vp, _f, _f, _vp, _vp, _vp, _vp, _vp],
+    "sg_set_f32_mode": [_i],
+    "sg_get_f32_mode": [],
     "sg_reduce_scatter_flat": [_vp, _vp, _ll, _vp],
     "sg_allgather_flat": [_vp, _vp, _ll, _vp],
     "sg_p2p_create": [_i, _i, _ll, C.POINTER(_vp), _vp],

@@ -401,10 +401,33 @@ __device__ __forceinline__ float frag_mc_f32(const char* tile, int pitch, int ro
   return *(const float*)(tile + (kk * 2 + (l >> 5)) * pitch + (row0 + (l & 31)) * 4);
 }
 
+// fp32 [row][k] image, SPLIT = 3 ("bf16x3"): the 8 consecutive k of row (l & 31) that a 32x32x16 bf16 MFMA wants from this lane, as two bf16 vectors
+// x = hi + lo + O(2^-17 |x|): hi = bf16(x) (round to nearest even), lo = bf16(x - hi). Two ds_read_b128 (80-byte pitch: conflict-free per 16-lane group).
+__device__ __forceinline__ void frag_kc_f32_split(const char* tile, int row0, bf16x8_t& hi, bf16x8_t& lo) {
+  const int l = threadIdx.x & 63;
+  const char* p = tile + (row0 + (l & 31)) * SG_KC_STRIDE + 32 * (l >> 5);
+  const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 16);
+  float x[8] = {a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+  u32x4 h, r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t hp = pack2bf(x[2 * e], x[2 * e + 1]);
+    const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
+    h[e] = hp;
+    r[e] = pack2bf(x[2 * e] - h0, x[2 * e + 1] - h1);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, r);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------------
-template <typename T, class LP, class LQ, int BI, int BJ, int WI, int WJ, bool TR>
+// SPLIT (fp32 operands in the [row][k] form only): 0 = v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (64 cycles per SIMD and k-pair: 1/16 of the bf16 rate);
+// 3 = "bf16x3": every fp32 operand element is split into two bf16 terms at fragment time and a k-tile of 16 runs as THREE v_mfma_f32_32x32x16_bf16
+// (lo*hi + hi*lo + hi*hi, fp32 accumulation) = 96 cycles per SIMD instead of 512. Dropped: lo*lo and the second-order split remainders, ~2^-16 relative per
+// product with random sign -- 60x finer than the TF32 convolutions (10-bit mantissa) torch runs the reference's "fp32" evaluation with on its usual hardware.
+template <typename T, class LP, class LQ, int BI, int BJ, int WI, int WJ, bool TR, int SPLIT = 0>
 __global__ __launch_bounds__(256) void sg_gemm_kernel(LP lp, LQ lq, Epilogue<T> epi, int I, int J, int K,
                                                        int klen, int tilesI, int tilesJ) {
   constexpr int VEC = ET<T>::VEC, BK = ET<T>::BK, ES = sizeof(T);
@@ -505,6 +528,20 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(LP lp, LQ lq, Epilogue<T> 
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
+    } else if constexpr (SPLIT == 3 && LP::KC && LQ::KC) {
+      bf16x8_t ph[TI], pl[TI], qh[TJ], ql[TJ];
+#pragma unroll
+      for (int a = 0; a < TI; a++) frag_kc_f32_split(ps, wi0 + a * 32, ph[a], pl[a]);
+#pragma unroll
+      for (int b = 0; b < TJ; b++) frag_kc_f32_split(qs, wj0 + b * 32, qh[b], ql[b]);
+#pragma unroll
+      for (int a = 0; a < TI; a++)
+#pragma unroll
+        for (int b = 0; b < TJ; b++) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pl[a], qh[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[a], ql[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ph[a], qh[b], acc[a][b], 0, 0, 0);
+        }
     } else {
 #pragma unroll
       for (int kk = 0; kk < 8; kk++) {
@@ -551,7 +588,7 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(LP lp, LQ lq, Epilogue<T> 
 // host-side launch helper -------------------------------------------------------------------------
 struct SgTileCfg { int BI, BJ; };
 
-template <typename T, class LP, class LQ, int BI, int BJ, int WI, int WJ, bool TR = true>
+template <typename T, class LP, class LQ, int BI, int BJ, int WI, int WJ, bool TR = true, int SPLIT = 0>
 static inline void sg_launch_gemm(const LP& lp, const LQ& lq, const Epilogue<T>& epi, int I, int J, int K,
                                   int splits, int batch, hipStream_t stream) {
   constexpr int BK = ET<T>::BK;
@@ -563,6 +600,6 @@ static inline void sg_launch_gemm(const LP& lp, const LQ& lq, const Epilogue<T>&
     splits = (K + klen - 1) / klen;
   } else splits = 1;
   dim3 grid(tilesI * tilesJ, splits, batch);
-  hipLaunchKernelGGL((sg_gemm_kernel<T, LP, LQ, BI, BJ, WI, WJ, TR>), grid, dim3(256), 0, stream, lp, lq, epi, I, J, K, klen,
+  hipLaunchKernelGGL((sg_gemm_kernel<T, LP, LQ, BI, BJ, WI, WJ, TR, SPLIT>), grid, dim3(256), 0, stream, lp, lq, epi, I, J, K, klen,
                      tilesI, tilesJ);
 }

@@ -68,6 +68,27 @@ def _take_stats(x):
 # ---------------------------------------------------------------------------------------------------------
 # raw launch helpers (also used directly by the kernel-level tests)
 # ---------------------------------------------------------------------------------------------------------
+class f32_mode:
+    """with f32_mode("bf16x3"): the generic engine's fp32 forward convolutions (all-vector operands) run as three bf16 MFMAs per 16-wide k-tile on operands split
+    into two bf16 terms in registers -- fp32 tensors in and out, fp32 accumulation, ~2^-16 relative per product, 5.3x the matrix-pipe rate of the exact fp32 MFMA
+    (csrc/gemm_core.h SPLIT, sg_set_f32_mode). "exact" (the default everywhere) = v_mfma_f32_32x32x2_f32. Process-wide switch: restored on exit."""
+    MODES = {"exact": 0, "bf16x3": 3}
+
+    def __init__(self, mode):
+        if mode not in self.MODES:
+            raise ValueError(f"f32_mode: {mode!r} (one of {sorted(self.MODES)})")
+        self.mode = self.MODES[mode]
+
+    def __enter__(self):
+        self.saved = L.lib().sg_get_f32_mode()
+        L.call("sg_set_f32_mode", self.mode)
+        return self
+
+    def __exit__(self, *exc):
+        L.call("sg_set_f32_mode", self.saved)
+        return False
+
+
 def conv2d_raw(x, w_ptr, Cin, Cout, R, S, stride=1, pad_h=0, pad_w=0, pix_flags=0, epi_flags=0, bias=None, res=None, mask=None,
                alpha=1.0, beta=1.0, alpha_ptr=None, out=None, ldx=None, transposed_out_hw=None, out_coff=0, x_coff=0, desc=None):
     """x: [N,Hs,Ws,ldx] NHWC; returns [N,Ho',Wo',Cout]. w_ptr -> [Cout][R*S*Cin] in x.dtype."""

@@ -138,8 +138,13 @@ class InceptionV3:
     inference only, BN folded into the convolutions at load time. `state_dict` uses torchvision's key names, i.e. the
     reference's `pt_inception-2015-12-05-6726825d.pth` loads as is."""
 
-    def __init__(self, state_dict, device, dtype=torch.float32):
+    def __init__(self, state_dict, device, dtype=torch.float32, f32_mode="exact"):
+        """f32_mode (dtype fp32 only): "exact" = fp32 MFMA; "bf16x3" = fp32 tensors, every convolution's operands split into two bf16 terms in registers and
+        contracted with three bf16 MFMAs per k-tile (functional.f32_mode): ~2^-16 relative per product, measured 3e-6 on the pool3 features against the oracle."""
         self.device, self.dtype = device, dtype
+        if f32_mode not in F.f32_mode.MODES:
+            raise ValueError(f"InceptionV3: f32_mode {f32_mode!r}")
+        self.f32_mode = f32_mode if dtype == torch.float32 else "exact"
         self.w, self.b = {}, {}
         with torch.no_grad():
             for name, (_, cin, cout, kh, kw, stride, ph, pw) in SPEC.items():
@@ -225,6 +230,12 @@ class InceptionV3:
     @torch.no_grad()
     def forward_nhwc(self, x):
         """x: [B,299,299,3] NHWC in the compute dtype, values in [-1,1] -> (pool3 features [B,2048], logits [B,1008]), fp32."""
+        if self.f32_mode != "exact":
+            with F.f32_mode(self.f32_mode):
+                return self._forward_nhwc(x)
+        return self._forward_nhwc(x)
+
+    def _forward_nhwc(self, x):
         x = self._bc(self._bc(self._bc(x, "Conv2d_1a_3x3"), "Conv2d_2a_3x3"), "Conv2d_2b_3x3")
         x = self._pool(x, 3, 2, 0, 0)
         x = self._bc(self._bc(x, "Conv2d_3b_1x1"), "Conv2d_4a_3x3")
@@ -315,7 +326,7 @@ class LoadEvalModel:
     "clean" (PIL bicubic) and "friendly" (PIL bilinear), reference src/utils/resize.py:49-69."""
 
     def __init__(self, eval_backbone="InceptionV3_tf", post_resizer="legacy", world_size=1, distributed_data_parallel=False, device="cuda",
-                 state_dict=None, dtype=torch.float32, weights_path=None):
+                 state_dict=None, dtype=torch.float32, weights_path=None, f32_mode="exact"):
         """state_dict: tensors under torchvision's inception_v3 names, checked against inception_manifest() like the reference's strict load
         (anything else raises); weights_path: the published file itself, additionally checked against the sha256 prefix in its name.
         `self.weights_pinned` says which: True only for a hash-verified file -- FID / IS values from any other weights (the seeded random
@@ -332,7 +343,7 @@ class LoadEvalModel:
         validate_inception_state_dict(state_dict)
         self.eval_backbone, self.post_resizer, self.device = eval_backbone, post_resizer, torch.device(device)
         self.res = 299
-        self.model = InceptionV3(state_dict, self.device, dtype)
+        self.model = InceptionV3(state_dict, self.device, dtype, f32_mode=f32_mode)      # f32_mode: InceptionV3.__init__
         self.dtype = dtype
 
     def eval(self):

@@ -47,6 +47,30 @@ def test_inception_features_at_full_input_size(sg):
         check(f"299^2 B=32 logits {dtype}", logit, logit_o, tol)
 
 
+def test_inception_features_bf16x3_split_mode(sg):
+    """InceptionV3 in fp32 with every convolution in the "bf16x3" arithmetic (fp32 tensors, operands split into two bf16 terms in registers, three bf16 MFMAs per
+    k-tile: functional.f32_mode, csrc/gemm_core.h SPLIT) at the real evaluation geometry: the same 2e-4 bound against the CPU oracle as the exact fp32 path --
+    measured 4e-6 (features) / 3e-6 (logits), i.e. 50x inside it and ~100x finer than TF32 -- and the mode must actually have run (results differ from the exact
+    path's by more than fp32 rounding, the library's switch is back at "exact" afterwards)."""
+    from studiogan_amd import metrics as M, _lib as L
+    dev = torch.device("cuda:0")
+    sd = OI.random_state_dict(1)
+    g = torch.Generator().manual_seed(8)
+    x = torch.rand(32, 3, 299, 299, generator=g) * 2 - 1
+    feat_o, logit_o = OI.inception_forward(x, sd)
+    xn = x.to(dev).permute(0, 2, 3, 1).contiguous()
+    out = {}
+    for mode in ("exact", "bf16x3"):
+        model = M.InceptionV3(sd, dev, torch.float32, f32_mode=mode)
+        out[mode] = model.forward_nhwc(xn)
+        torch.cuda.synchronize()
+        assert L.lib().sg_get_f32_mode() == 0
+    check("299^2 B=32 pool3 features fp32 bf16x3", out["bf16x3"][0], feat_o, 2e-4)
+    check("299^2 B=32 logits fp32 bf16x3", out["bf16x3"][1], logit_o, 2e-4)
+    d = float((out["bf16x3"][0] - out["exact"][0]).abs().max() / out["exact"][0].abs().max())
+    assert 1e-7 < d < 1e-4, d
+
+
 def test_preprocess_bit_exact_quantisation(sg):
     from studiogan_amd import metrics as M
     dev = torch.device("cuda:0")
@@ -287,7 +311,17 @@ def test_pool2d_vector_kernel_matches_torch_and_scalar(sg, cfg):
     y32 = torch.zeros(N, OH, OH, ldy, dtype=torch.float32, device=d)
     x32 = xd.float()
     L.call("sg_pool2d", L.F32, L.ptr(x32), L.ptr(y32), N, H, W, C, k, stride, pad, mode, ldy, coff, L.stream())
+    # (round 6) fp32 takes the 4-channels-per-thread kernel k_pool2d_f4; SG_POOL_SCALAR=1 selects the scalar one: bit-identical, and equal to torch's fp32 pooling
+    import os
+    y32s = torch.zeros_like(y32)
+    os.environ["SG_POOL_SCALAR"] = "1"
+    try:
+        L.call("sg_pool2d", L.F32, L.ptr(x32), L.ptr(y32s), N, H, W, C, k, stride, pad, mode, ldy, coff, L.stream())
+    finally:
+        del os.environ["SG_POOL_SCALAR"]
     torch.cuda.synchronize()
+    assert torch.equal(y32, y32s), "fp32 vector and scalar pooling kernels disagree"
+    check(f"pool2d fp32 {cfg}", y32[..., coff:coff + C].cpu().permute(0, 3, 1, 2), ref, 1e-6)
     out = y[..., coff:coff + C].float().cpu().permute(0, 3, 1, 2)
     check(f"pool2d bf16 {cfg}", out, ref.to(torch.bfloat16).float(), 1e-6 if mode == 0 else 4e-3)
     assert torch.equal(y[..., coff:coff + C], y32[..., coff:coff + C].to(torch.bfloat16)), "vector and scalar kernels disagree"

@@ -302,3 +302,14 @@ def test_emulated_sn_kernels_against_torch_spectral_norm(dtype):
         rows = SC.run(torch.device("cpu"), dtype, L, L.call, L.ptr, L.stream)
     bad = [(n, e, t) for n, e, t in rows if not e <= t]
     assert not bad, bad
+
+
+@pytest.mark.parametrize("case", [(2, 64, 96, 9, 9, 3, 3, 1, (1, 1)), (1, 128, 160, 9, 9, 1, 7, 1, (0, 3)), (2, 48, 32, 7, 7, 5, 5, 2, (2, 2))])
+def test_emulated_conv_fwd_f32_bf16x3_split(case):
+    """the generic engine's "bf16x3" fp32 mode (csrc/gemm_core.h SPLIT: fp32 operands split into two bf16 terms at fragment time, three bf16 MFMAs per k-tile) on
+    the interpreter against F.conv2d in fp64, next to the exact fp32 MFMA path (tests/test_kernels_gpu.py::test_conv_fwd_f32_bf16x3_split on the GPU)"""
+    import fullemu
+    import test_kernels_gpu as TK
+    with fullemu.Installed(dma_late=1, greedy=1, seed=4):
+        e_exact, e_split = TK.f32_split_case(torch.device("cpu"), case, sync=lambda: None)
+    assert e_exact <= 2e-6 and e_split <= 2e-5 and e_split > e_exact, (e_exact, e_split)

@@ -126,6 +126,42 @@ def test_conv_fwd_dgrad_wgrad(sg, dtype, case):
         check(f"conv wgrad {case} no_tr={no_tr}", dw.cpu().permute(0, 3, 1, 2), wr.grad, tol)
 
 
+def f32_split_case(d, case, sync=lambda: torch.cuda.synchronize()):
+    """fp32 forward convolution in the two arithmetic modes of the generic engine against F.conv2d in fp64: exact (fp32 MFMA) and "bf16x3" (operands split into
+    two bf16 terms in registers, three bf16 MFMAs per k-tile, csrc/gemm_core.h SPLIT). Returns (error exact, error bf16x3), both relative to the largest output."""
+    from studiogan_amd import functional as F, _lib as L
+    N, Cin, Cout, H, W, R, S, stride, (ph, pw) = case
+    x = rnd((N, Cin, H, W), torch.float32, 21)
+    w = rnd((Cout, Cin, R, S), torch.float32, 22, 0.2)
+    bias = rnd((Cout,), torch.float32, 23)
+    yref = TF.conv2d(x.double(), w.double(), bias.double(), stride=stride, padding=(ph, pw))
+    w_fwd = w.permute(0, 2, 3, 1).contiguous().to(d)
+    xd = nhwc(x).to(d)
+    errs = []
+    for mode in ("exact", "bf16x3"):
+        with F.f32_mode(mode):
+            assert L.lib().sg_get_f32_mode() == F.f32_mode.MODES[mode]
+            y = F.conv2d_raw(xd, w_fwd.data_ptr(), Cin, Cout, R, S, stride, ph, pw, 0, L.EPI_RELU, bias=bias.to(d))
+        sync()
+        assert L.lib().sg_get_f32_mode() == 0
+        errs.append(float((nchw(y.float().cpu()).double() - torch.relu(yref)).abs().max() / yref.abs().max()))
+    return errs
+
+
+# Inception-like shapes on the all-vector path: 1x1 / 3x3 / 1x7 / 7x1 / 5x5, stride 2, couts that pad the 128 / 96 / 32-wide tiles, K from 64 to 3456
+F32_SPLIT_CASES = [(2, 64, 96, 17, 17, 3, 3, 1, (1, 1)), (2, 192, 32, 9, 9, 1, 1, 1, (0, 0)), (1, 128, 160, 17, 17, 1, 7, 1, (0, 3)), (1, 160, 192, 17, 17, 7, 1, 1, (3, 0)),
+                   (2, 48, 64, 13, 13, 5, 5, 1, (2, 2)), (2, 288, 384, 17, 17, 3, 3, 2, (0, 0)), (1, 384, 384, 8, 8, 3, 3, 1, (1, 1))]
+
+
+@pytest.mark.parametrize("case", F32_SPLIT_CASES)
+def test_conv_fwd_f32_bf16x3_split(sg, case):
+    """bound: 2e-5 of the largest output for the split mode (measured <= 6e-6), 2e-6 for the exact one -- and the split must not be the exact kernel in disguise"""
+    e_exact, e_split = f32_split_case(dev(), case)
+    print(f"{case}: exact {e_exact:.2e}  bf16x3 {e_split:.2e}")
+    assert e_exact <= 2e-6 and e_split <= 2e-5, (e_exact, e_split)
+    assert e_split > e_exact
+
+
 @pytest.mark.parametrize("dtype", DT)
 @pytest.mark.parametrize("case", [(2, 16, 24, 4, 4, 4, 2, 1), (3, 64, 32, 8, 8, 4, 2, 1), (2, 8, 8, 5, 6, 3, 1, 1), (1, 12, 20, 3, 3, 5, 3, 2)])
 def test_conv_transpose(sg, dtype, case):

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--samples", type=int, default=5120)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--f32-mode", default="exact", choices=["exact", "bf16x3"], help="fp32 Inception: exact fp32 MFMA or the bf16x3 split (functional.f32_mode)")
     args = ap.parse_args()
     from studiogan_amd import metrics as M
     dev = torch.device("cuda:0")
@@ -30,7 +31,7 @@ def main():
     for p in G.parameters():
         p.requires_grad_(False)
     idt = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model = M.LoadEvalModel(device=dev, state_dict=M.synthetic_state_dict(0), dtype=idt)
+    model = M.LoadEvalModel(device=dev, state_dict=M.synthetic_state_dict(0), dtype=idt, f32_mode=args.f32_mode)
     M.generate_images_and_stack_features(G, model, 2 * args.batch, args.batch, wl["z_dim"], wl["classes"], device=dev)
     torch.cuda.synchronize()
     mom = M.FeatureMoments(2048, dev)
@@ -41,7 +42,7 @@ def main():
     dt = time.perf_counter() - t0
     sps = args.samples / dt
     tf = sps * (G_FWD_GFLOP + INCEPTION_GFLOP) / 1e3
-    print(json.dumps({"metric": "FID feature-extract samples/sec", "value": round(sps, 1), "samples": args.samples, "inception_dtype": args.dtype,
+    print(json.dumps({"metric": "FID feature-extract samples/sec", "value": round(sps, 1), "samples": args.samples, "inception_dtype": args.dtype, "f32_mode": args.f32_mode if args.dtype == "f32" else None,
                       "roofline": {"bound": "mfma", "achieved": round(tf, 1), "unit": "TFLOP/s", "peak": 2500.0, "frac": round(tf / 2500.0, 4),
                                    "gflop_per_sample": {"generator_forward_bf16": G_FWD_GFLOP, "inception_v3": INCEPTION_GFLOP},
                                    "note": "fp32 Inception runs on the exact-fp32 MFMA path (157 TFLOP/s peak): its frac is against the bf16 peak only for comparability"}}))
