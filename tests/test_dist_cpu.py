@@ -2,7 +2,7 @@
  * chunking + pipelined all-reduce of the flat gradient arena used by FusedAdam (studiogan_amd/optim.py),
  * the sync-BN contract: all-reducing the per-rank fp64 partial sums {sum x, sum x^2} (count * world) and the backward
    channel terms reproduces full-batch batch-norm forward/backward exactly (what sg_bn_partial_stats / sg_bn_finalize /
-   sg_bn_bwd_finalize compute around the all-reduce in studiogan_amd/functional.py:BNFn),
+   sg_bn_bwd_finalize compute around the all-reduce in studiogan_amd/functional/norm.py:BNFn),
  * gradient averaging across ranks == full-batch gradient for a mean-reduced loss."""
 import os
 import socket
