@@ -570,7 +570,7 @@ def main():
     # summary carries the hash of the kernel sources it was taken on; a summary of OTHER sources is reported as stale, never silently used as current
     pmc_tab, pmc_src, pmc_sha, cur_sha = None, None, None, csrc_sha16()
     try:
-        pmc_name = next(n for n in ("r05_conv_hbm_traffic_pmc.json", "r04_conv_hbm_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
+        pmc_name = next(n for n in ("r06_conv_hbm_traffic_pmc.json", "r05_conv_hbm_traffic_pmc.json", "r04_conv_hbm_traffic_pmc.json") if os.path.exists(os.path.join(ROOT, "profiles", n)))
         pj = json.load(open(os.path.join(ROOT, "profiles", pmc_name)))
         pmc_tab, pmc_sha = pj.get("per_kernel"), pj.get("csrc_sha16")
         pmc_src = "profiles/" + pmc_name
