@@ -242,3 +242,47 @@ def test_exchange_plan_ranges_gloo():
         assert ok_early, "ranges sent from the backward must hold the all-reduced sum"
         assert ok_head, "the head of the arena must be left to step()"
         assert n_after == 3 and done_lo == 8000 and armed is False
+
+
+def _emulated_step_job(rank, world):
+    """one D + one G update (and two more with the EMA twin) of the width-8 ResNet fixture on `world` ranks, the kernels on the CPU interpreter"""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.join(here, "hipemu")]
+    import fullemu
+    import test_dist_gpu as TD
+    torch.set_num_threads(1)
+    os.environ["SG_TEST_DEVICE"] = "cpu"
+    with fullemu.Installed(dma_late=1, greedy=1, seed=5):
+        out = TD._job(rank, world, "resgan32", False, steps=2)
+    return {"state": {k: v.clone() for k, v in out["state"].items()}}
+
+
+@pytest.mark.parametrize("sharded", ["0", "1"])
+def test_two_ranks_emulated_training_step_equals_full_batch(sharded, monkeypatch):
+    """The world > 1 PRODUCT path on the CPU: two gloo ranks run worker.Worker's updates with the kernel SOURCES on the interpreter (tests/hipemu) -- sync-BN statistics
+    and backward terms all-reduced between the kernels, the gradient arena exchanged by FusedAdam (chunked all-reduce, or SG_SHARDED_ADAM=1: reduce-scatter emulation -> Adam on
+    this rank's shard -> all-gather), the EMA twin -- against the single-rank run over the full batch: both ranks bit-identical, equal to the full batch up to the +-lr
+    kicks of noise-gradient elements (the bounds of tests/test_dist_gpu.py, which runs the same job on the GPU)."""
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path[:0] = [here, os.path.join(here, "hipemu")]
+    import emu
+    if not emu.available():
+        pytest.skip("host clang++ of the ROCm toolchain not found")
+    import fullemu
+    fullemu.build()                      # (once, in the parent: the ranks find the cached library)
+    monkeypatch.setenv("SG_TEST_EMA", "1")
+    monkeypatch.setenv("SG_SHARDED_ADAM", sharded)
+    two = _spawn(_emulated_step_job, 2)
+    monkeypatch.setenv("SG_SHARDED_ADAM", "0")
+    full = _spawn(_emulated_step_job, 1)[0]
+    a, b = two[0]["state"], two[1]["state"]
+    assert any(k.startswith("G_ema/") for k in a)
+    for k in a:
+        assert torch.equal(a[k], b[k]), f"replicas diverged: {k}"
+        if a[k].dtype.is_floating_point:
+            err = float((a[k] - full["state"][k]).abs().max())
+            assert err <= 2e-3 * max(float(full["state"][k].abs().max()), 0.05) + 2 * 2.2 * 2e-4, (k, err)
+        else:
+            assert torch.equal(a[k], full["state"][k]), k

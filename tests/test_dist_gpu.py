@@ -49,7 +49,8 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
     from studiogan_amd.optim import sync_replicas
     from util import load_golden, sub, hyper
     from test_model_gpu import build_from_yaml
-    dev = torch.device("cuda:0")
+    dev = torch.device(os.environ.get("SG_TEST_DEVICE", "cuda:0"))      # ("cpu": the package bound to the interpreted library, tests/test_dist_cpu.py)
+    sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
     fix, meta = load_golden(name)
     y = meta["yaml"]
     G, D = build_from_yaml(y, False, dev)
@@ -65,7 +66,7 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
         v = torch.arange(1, 1001, dtype=torch.float64, device=dev) * (rank + 1) + 0.125 * rank
         for _ in range(5):                     # back-to-back calls: the two-slot epoch protocol
             box.allreduce_f64_(v)
-        torch.cuda.synchronize()
+        sync()
         p2p_vec = v.cpu()
     caught = None
     if desync and rank == 1:                       # what per-rank seeding does to an un-broadcast model (reference src/loader.py:99)
@@ -94,7 +95,7 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
     w.train_discriminator(0, [(put("real0"), put("rl0"))], [(put("z0"), put("fl0"))])
     d_grad = {k: p.grad.detach().cpu().clone() / world for k, p in D.named_parameters()}      # the arena holds the all-reduced SUM
     w.train_generator(0, [(put("z1"), put("fl1"))])
-    torch.cuda.synchronize()
+    sync()
     g_grad = {k: p.grad.detach().cpu().clone() / world for k, p in G.named_parameters()}
     early = None
     if steps > 1:
@@ -103,7 +104,7 @@ def _job(rank, world, name, desync, steps=1, p2p=False):
         for it in range(1, steps):
             w.train_discriminator(it, [(put("real0"), put("rl0"))], [(put(f"z{it % 2}"), put(f"fl{it % 2}"))])
             w.train_generator(it, [(put("z1"), put("fl1"))])
-        torch.cuda.synchronize()
+        sync()
         early = {"D": dict(w.d_optimizer.exchange_stats), "G": dict(w.g_optimizer.exchange_stats)}
     state = {"D/" + k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
     state.update({"G/" + k: v.detach().cpu().clone() for k, v in G.state_dict().items()})
