@@ -7,63 +7,57 @@ import torch
 from .. import _lib as L
 
 
+def _ints(value, what, allowed):
+    """an int or a sequence of ints -> tuple, its length one of `allowed` (a lone int counts as length 1)"""
+    seq = (value,) if isinstance(value, int) else value
+    ok = isinstance(seq, (list, tuple)) and len(seq) in allowed and all(isinstance(v, int) and not isinstance(v, bool) for v in seq)
+    if not ok:
+        raise AssertionError(f"{what}: an int or {' / '.join(str(a) for a in allowed if a > 1)} ints expected, got {value!r}")
+    return tuple(seq)
+
+
 def _parse_scaling(scaling):
-    if isinstance(scaling, int):
-        scaling = [scaling, scaling]
-    if not (isinstance(scaling, (list, tuple)) and all(isinstance(v, int) for v in scaling) and len(scaling) == 2):
-        raise AssertionError("scaling must be an int or a pair of ints")
-    sx, sy = scaling
-    if sx < 1 or sy < 1:
-        raise AssertionError("scaling factors must be >= 1")
+    """-> (x factor, y factor), each >= 1 (the plugin's own check: upfirdn2d.cpp:35-36)"""
+    v = _ints(scaling, "up / down factor", (1, 2))
+    sx, sy = v * 2 if len(v) == 1 else v
+    if min(sx, sy) < 1:
+        raise AssertionError("up / down factors must be >= 1")
     return sx, sy
 
 
 def _parse_padding(padding):
-    if isinstance(padding, int):
-        padding = [padding, padding]
-    if not (isinstance(padding, (list, tuple)) and all(isinstance(v, int) for v in padding)):
-        raise AssertionError("padding must be an int or a list of ints")
-    if len(padding) == 2:
-        px, py = padding
-        padding = [px, px, py, py]
-    if len(padding) != 4:
-        raise AssertionError("padding must have 1, 2 or 4 entries")
-    return tuple(padding)      # padx0, padx1, pady0, pady1
+    """-> (padx0, padx1, pady0, pady1) from one value, (x, y) or all four"""
+    v = _ints(padding, "padding", (1, 2, 4))
+    return {1: lambda a: (a[0],) * 4, 2: lambda a: (a[0], a[0], a[1], a[1]), 4: tuple}[len(v)](v)
 
 
 def _get_filter_size(f):
+    """(taps along x, taps along y) of a filter constant; None is the 1 x 1 identity"""
     if f is None:
         return 1, 1
-    if not (isinstance(f, torch.Tensor) and f.dim() in (1, 2)):
-        raise AssertionError("filter must be a 1-D or 2-D tensor")
-    fw, fh = int(f.shape[-1]), int(f.shape[0])
-    if fw < 1 or fh < 1:
-        raise AssertionError("empty filter")
-    return fw, fh
+    if not isinstance(f, torch.Tensor) or f.dim() not in (1, 2) or f.numel() == 0:
+        raise AssertionError("filter must be a non-empty 1-D or 2-D tensor")
+    return int(f.shape[-1]), int(f.shape[0])
 
 
 def setup_filter(f, device=torch.device("cpu"), normalize=True, flip_filter=False, gain=1, separable=None):
-    """Filter constant for upfirdn2d (reference upfirdn2d.py:70-114): float32; scalars / vectors of >= 8 taps stay separable (1-D) unless asked
-    otherwise, shorter vectors become their outer product; normalised to unit sum; gain spread over the dimensions."""
-    if f is None:
-        f = 1
-    f = torch.as_tensor(f, dtype=torch.float32)
-    if f.dim() not in (0, 1, 2) or f.numel() == 0:
+    """Filter constant for upfirdn2d with the reference's contract (upfirdn2d.py:70-114): a float32 tensor that is 1-D when the filter is applied separably
+    (the default for vectors of >= 8 taps) and the 2-D outer product otherwise; unit sum when `normalize`; `gain` enters as gain ** (ndim / 2) so that a separable
+    filter, applied once per axis, carries it exactly once."""
+    taps = torch.as_tensor(1 if f is None else f, dtype=torch.float32)
+    if taps.dim() > 2 or taps.numel() == 0:
         raise AssertionError("filter must be a non-empty scalar, vector or matrix")
-    if f.dim() == 0:
-        f = f[np.newaxis]
-    if separable is None:
-        separable = f.dim() == 1 and f.numel() >= 8
-    if f.dim() == 1 and not separable:
-        f = f.ger(f)
-    if f.dim() != (1 if separable else 2):
-        raise AssertionError("separable filters are 1-D, full filters 2-D")
+    taps = taps.reshape(1) if taps.dim() == 0 else taps
+    keep_1d = (taps.dim() == 1 and taps.numel() >= 8) if separable is None else bool(separable)
+    if keep_1d and taps.dim() != 1:
+        raise AssertionError("a separable filter is given by its 1-D taps")
+    if not keep_1d and taps.dim() == 1:
+        taps = torch.outer(taps, taps)
     if normalize:
-        f = f / f.sum()
+        taps = taps / taps.sum()
     if flip_filter:
-        f = f.flip(list(range(f.dim())))
-    f = f * (gain ** (f.dim() / 2))
-    return f.to(device=device)
+        taps = torch.flip(taps, dims=tuple(range(taps.dim())))
+    return (taps * float(gain) ** (taps.dim() / 2)).to(device=device)
 
 
 def _launch(x, f2d, upx, upy, downx, downy, padx0, padx1, pady0, pady1, flip_filter, gain):

@@ -106,7 +106,8 @@ def test_attention_input_gradient_chain_matches_autograd_sum(sg, mixed):
     x, lab = fix["in/real0"].clone(), fix["in/rl0"]
     sd = {k: v.clone() for k, v in D.state_dict().items()}
     got, with_res = [], []
-    orig, keep = F._conv_dgrad, F._GRAD_LINK[0]
+    FC = F.conv                    # (the operator-family module whose functions look `_conv_dgrad` up: round 6's split of functional.py)
+    orig, keep = FC._conv_dgrad, F._GRAD_LINK[0]
     try:
         for on in (False, True):
             n = [0]
@@ -114,7 +115,7 @@ def test_attention_input_gradient_chain_matches_autograd_sum(sg, mixed):
             def counting(dy, xx, rt, slot, cfg, res=None):
                 n[0] += (res is not None) and cfg.R == 1 and not cfg.in_relu
                 return orig(dy, xx, rt, slot, cfg, res=res)
-            F._conv_dgrad, F._GRAD_LINK[0] = counting, on
+            FC._conv_dgrad, F._GRAD_LINK[0] = counting, on
             D.load_state_dict(sd)      # same power-iteration state for both passes
             for p in D.parameters():
                 p.grad = None
@@ -124,7 +125,7 @@ def test_attention_input_gradient_chain_matches_autograd_sum(sg, mixed):
             got.append({"dx": xd.grad.float().cpu(), **{k: p.grad.float().cpu() for k, p in D.named_parameters()}})
             with_res.append(n[0])
     finally:
-        F._conv_dgrad, F._GRAD_LINK[0] = orig, keep
+        FC._conv_dgrad, F._GRAD_LINK[0] = orig, keep
     assert with_res == [0, 3], with_res
     C = Collector()
     for k in got[0]:
