@@ -555,9 +555,13 @@ def main():
     if world > 1:
         exposed_comm_ms = sg_comm_t.timing_ms()
         sg_comm_t.timing(False)
-        tx = torch.tensor([exposed_comm_ms], dtype=torch.float64, device=device)
+        # a peer-store exchange whose partner never arrived trips a bounded spin and poisons the statistics instead of hanging: must not have happened
+        box_ = sg_comm_t.p2p_for(group)
+        p2p_timeouts = box_.timeouts() if box_ is not None else 0
+        tx = torch.tensor([exposed_comm_ms, float(p2p_timeouts)], dtype=torch.float64, device=device)
         dist.all_reduce(tx, op=dist.ReduceOp.MAX)
-        exposed_comm_ms = float(tx.item())
+        exposed_comm_ms, p2p_timeouts = float(tx[0].item()), int(tx[1].item())
+        assert p2p_timeouts == 0, f"{p2p_timeouts} peer-store granule waits ran into their spin limit during the timed steps"
     # the step must have produced numbers: finite losses of the last timed step (read AFTER the timed region: a host sync)
     d_last, g_last = (float(last[0]), float(last[1])) if last is not None else (float("nan"), float("nan"))
     import math
