@@ -145,6 +145,12 @@ EXTRAS = {
                                      "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 128, "g_conv_dim": 64, "d_conv_dim": 64}},
                                batch=256, mixed=False, n_d=5, loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999, gp=False, ema=False,
                                desc="SNGAN CIFAR-10 32x32 cBN+PD hinge, batch 256, fp32 (C2)"),
+    # C2 once more with the generic engine's fp32 convolutions on the bf16x3 split-precision path (fp32 tensors, three bf16 MFMAs per k-tile on operands split in
+    # registers: functional.f32_mode; forward, data gradient and weight gradient). NOT the exact-fp32 figure above: its own line, its own label.
+    "sngan32_bs256_fp32_bf16x3": dict(yaml={"DATA": {"img_size": 32, "num_classes": 10},
+                                            "MODEL": {"backbone": "resnet", "g_cond_mtd": "cBN", "d_cond_mtd": "PD", "apply_d_sn": True, "z_dim": 128, "g_conv_dim": 64, "d_conv_dim": 64}},
+                                      batch=256, mixed=False, n_d=5, loss="hinge", g_lr=2e-4, d_lr=2e-4, beta1=0.5, beta2=0.999, gp=False, ema=False, f32_mode="bf16x3",
+                                      desc="SNGAN CIFAR-10 32x32 cBN+PD hinge, batch 256, fp32 tensors with bf16x3 split-precision convolution arithmetic (C2 variant)"),
     # C5: configs/CIFAR10/WGAN-GP.yaml at img_size 128 (ResNet, unconditional, BN in D, wasserstein + gradient penalty: double backward), bf16
     "wgangp128_bs64_bf16": dict(yaml={"DATA": {"img_size": 128, "num_classes": 1000},
                                       "MODEL": {"backbone": "resnet", "z_dim": 128, "g_conv_dim": 64, "d_conv_dim": 64}},
@@ -195,19 +201,23 @@ def run_extra(name, device, steps=None, warmup=None):
     w = Worker(G, D, y["MODEL"].get("z_dim", 128), y["DATA"]["num_classes"], e["batch"], e["loss"], e["g_lr"], e["d_lr"], e["beta1"], e["beta2"],
                d_updates_per_step=e["n_d"], apply_g_ema=e["ema"], g_ema_decay=0.9999, g_ema_start=20000, apply_gp=e["gp"], gp_lambda=10.0)
     pool = generator_real_pool(G, min(32, e["n_d"] * (warmup + steps)), e["batch"], y["MODEL"].get("z_dim", 128), y["DATA"]["num_classes"], device, 77)
-    for i in range(warmup):
-        w.step(i, baskets(pool, i, e["n_d"]))
-    torch.cuda.synchronize()
-    L.call("sg_prof_enable", 1)
-    t0 = time.perf_counter()
-    last = None
-    for i in range(steps):
-        last = w.step(warmup + i, baskets(pool, warmup + i, e["n_d"]))
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    pr = (ctypes.c_double * 9)()
-    L.call("sg_prof_collect", pr, 3)
-    L.call("sg_prof_enable", 0)
+    L.call("sg_set_f32_mode", 3 if e.get("f32_mode") == "bf16x3" else 0)
+    try:
+        for i in range(warmup):
+            w.step(i, baskets(pool, i, e["n_d"]))
+        torch.cuda.synchronize()
+        L.call("sg_prof_enable", 1)
+        t0 = time.perf_counter()
+        last = None
+        for i in range(steps):
+            last = w.step(warmup + i, baskets(pool, warmup + i, e["n_d"]))
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        pr = (ctypes.c_double * 9)()
+        L.call("sg_prof_collect", pr, 3)
+        L.call("sg_prof_enable", 0)
+    finally:
+        L.call("sg_set_f32_mode", 0)
     d_l, g_l = float(last[0]), float(last[1])
     assert math.isfinite(d_l) and math.isfinite(g_l), f"{name}: non-finite losses D {d_l} G {g_l}"
     conv_ms, conv_fl = pr[1] + pr[4], pr[2] + pr[5]
@@ -217,7 +227,7 @@ def run_extra(name, device, steps=None, warmup=None):
         assert d_l > 1e-2, f"{name}: the discriminator saturated (d_loss {d_l}): its backward would multiply zero gradients"
     del w, G, D, pool
     torch.cuda.empty_cache()
-    return {"workload": e["desc"], "dtype": "bf16" if e["mixed"] else "f32", "per_gpu_batch": e["batch"], "d_updates_per_step": e["n_d"], "steps": steps,
+    return {"workload": e["desc"], "dtype": "bf16" if e["mixed"] else ("f32 tensors, bf16x3 arithmetic" if e.get("f32_mode") == "bf16x3" else "f32"), "per_gpu_batch": e["batch"], "d_updates_per_step": e["n_d"], "steps": steps,
             "images_per_sec": round(e["batch"] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 2),
             "conv_engine_tflops": round(tf, 1), "conv_engine_frac_of_peak": round(tf / peak, 4), "peak_tflops": peak,
             "conv_ms_per_step": round(conv_ms / steps, 2), "step_conv_gflop_per_image": round(conv_fl / steps / e["batch"] / 1e9, 2),

@@ -272,6 +272,10 @@ def lib():
             fn.argtypes = args
             fn.restype = _i
         l.sg_conv_rs_launches.restype = _ll
+        # SG_F32_MODE=bf16x3: the fp32 convolutions (forward, data gradient, weight gradient) of the generic engine process-wide on the split-precision
+        # path (functional.f32_mode is the scoped form); default = exact fp32 MFMA
+        if os.environ.get("SG_F32_MODE", "exact") == "bf16x3":
+            l.sg_set_f32_mode(3)
         _lib = l
     return _lib
 

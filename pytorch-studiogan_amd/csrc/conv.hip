@@ -4,14 +4,14 @@
 #include "conv_common.h"
 #include "conv_v2.h"
 
-// fp32 arithmetic mode of the generic engine's forward convolutions (sg_set_f32_mode): 0 = exact fp32 MFMA, 3 = bf16x3 split (gemm_core.h SPLIT)
-static int g_f32_mode = 0;
+// fp32 arithmetic mode of the generic engine's convolutions -- forward, data gradient (here) and weight gradient (conv_wgrad.hip) -- (sg_set_f32_mode): 0 = exact fp32 MFMA, 3 = bf16x3 split (gemm_core.h SPLIT)
+int g_sg_f32_mode = 0;
 extern "C" int sg_set_f32_mode(int mode) {
   SG_CHECK(mode == 0 || mode == 3, "sg_set_f32_mode: 0 (exact fp32 MFMA) or 3 (bf16x3 split)");
-  g_f32_mode = mode;
+  g_sg_f32_mode = mode;
   return 0;
 }
-extern "C" int sg_get_f32_mode() { return g_f32_mode; }
+extern "C" int sg_get_f32_mode() { return g_sg_f32_mode; }
 
 template <typename T, bool FAST>
 static void conv_fwd_launch(const sg_conv_fwd_desc* d, const Epilogue<T>& e, int I, int J, int K, int pflags, hipStream_t st) {
@@ -24,7 +24,7 @@ static void conv_fwd_launch(const sg_conv_fwd_desc* d, const Epilogue<T>& e, int
   fill_geom<T>(lq.g, d->x, d->N, d->Hs, d->Ws, d->C, d->ldx, d->Ho, d->Wo, d->R, d->S, d->stride, d->pad_h, d->pad_w, pflags);
   lq.rows = J; lq.K = K;
   if constexpr (sizeof(T) == 4 && FAST) {
-    if (g_f32_mode == 3) {      // fp32 in / fp32 out, three bf16 MFMAs per k-tile (all-vector operands only: the Inception stack, the fp32 backbones' aligned layers)
+    if (g_sg_f32_mode == 3) {      // fp32 in / fp32 out, three bf16 MFMAs per k-tile (all-vector operands only: the Inception stack, the fp32 backbones' aligned layers)
       if (I <= 32) sg_launch_gemm<T, LP, LQ, 32, 256, 1, 4, true, 3>(lp, lq, e, I, J, K, 1, 1, st);
       else if (I % 128 != 0 && (I % 96 == 0 || (I < 128 && I > 64))) sg_launch_gemm<T, LP, LQ, 96, 256, 1, 4, true, 3>(lp, lq, e, I, J, K, 1, 1, st);
       else sg_launch_gemm<T, LP, LQ, 128, 128, 2, 2, true, 3>(lp, lq, e, I, J, K, 1, 1, st);

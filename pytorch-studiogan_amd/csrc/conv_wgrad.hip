@@ -257,6 +257,15 @@ static void conv_wgrad_launch(const sg_conv_wgrad_desc* d, const Epilogue<T>& e,
   LM lq;
   fill_geom<T>(lq.g, d->dy, d->N, d->gHs, d->gWs, d->Cout, d->ldg, d->Ho, d->Wo, 1, 1, 1, 0, 0, d->g_flags & ~SG_PIX_QUAD);
   lq.rows = J; lq.K = K;
+  if constexpr (sizeof(T) == 4 && FAST) {
+    if (g_sg_f32_mode == 3) {      // bf16x3 split (gemm_core.h SPLIT): fp32 operands, three bf16 MFMAs per 16 pixels of the reduction
+      if (BI == 32) sg_launch_gemm<T, LM, LM, 32, 256, 1, 4, TR, 3>(lp, lq, e, I, J, K, splits, 1, st);
+      else if (BJ == 32) sg_launch_gemm<T, LM, LM, 256, 32, 4, 1, TR, 3>(lp, lq, e, I, J, K, splits, 1, st);
+      else if (BJ == 96) sg_launch_gemm<T, LM, LM, 256, 96, 4, 1, TR, 3>(lp, lq, e, I, J, K, splits, 1, st);
+      else sg_launch_gemm<T, LM, LM, 128, 128, 2, 2, TR, 3>(lp, lq, e, I, J, K, splits, 1, st);
+      return;
+    }
+  }
   if (BI == 32) sg_launch_gemm<T, LM, LM, 32, 256, 1, 4, TR>(lp, lq, e, I, J, K, splits, 1, st);
   else if (BJ == 32) sg_launch_gemm<T, LM, LM, 256, 32, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);
   else if (BJ == 96) sg_launch_gemm<T, LM, LM, 256, 96, 4, 1, TR>(lp, lq, e, I, J, K, splits, 1, st);

@@ -420,10 +420,29 @@ __device__ __forceinline__ void frag_kc_f32_split(const char* tile, int row0, bf
   lo = __builtin_bit_cast(bf16x8_t, r);
 }
 
+// the same from a [k][row] image (weight gradient: k = pixel): eight ds_read_b32 at the image pitch; neighbouring lanes read neighbouring rows (conflict-free)
+__device__ __forceinline__ void frag_mc_f32_split(const char* tile, int pitch, int row0, bf16x8_t& hi, bf16x8_t& lo) {
+  const int l = threadIdx.x & 63;
+  const char* p = tile + (8 * (l >> 5)) * pitch + (row0 + (l & 31)) * 4;
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; e++) x[e] = *(const float*)(p + e * pitch);
+  u32x4 h, r;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const uint32_t hp = pack2bf(x[2 * e], x[2 * e + 1]);
+    const float h0 = __uint_as_float(hp << 16), h1 = __uint_as_float(hp & 0xffff0000u);
+    h[e] = hp;
+    r[e] = pack2bf(x[2 * e] - h0, x[2 * e + 1] - h1);
+  }
+  hi = __builtin_bit_cast(bf16x8_t, h);
+  lo = __builtin_bit_cast(bf16x8_t, r);
+}
+
 // ---------------------------------------------------------------------------------------------------
 // The kernel
 // ---------------------------------------------------------------------------------------------------
-// SPLIT (fp32 operands in the [row][k] form only): 0 = v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (64 cycles per SIMD and k-pair: 1/16 of the bf16 rate);
+// SPLIT (fp32 operands, either LDS form): 0 = v_mfma_f32_32x32x2_f32, the exact fp32 FMA chain (64 cycles per SIMD and k-pair: 1/16 of the bf16 rate);
 // 3 = "bf16x3": every fp32 operand element is split into two bf16 terms at fragment time and a k-tile of 16 runs as THREE v_mfma_f32_32x32x16_bf16
 // (lo*hi + hi*lo + hi*hi, fp32 accumulation) = 96 cycles per SIMD instead of 512. Dropped: lo*lo and the second-order split remainders, ~2^-16 relative per
 // product with random sign -- 60x finer than the TF32 convolutions (10-bit mantissa) torch runs the reference's "fp32" evaluation with on its usual hardware.
@@ -528,12 +547,16 @@ __global__ __launch_bounds__(256) void sg_gemm_kernel(LP lp, LQ lq, Epilogue<T> 
           for (int b = 0; b < TJ; b++)
             acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
       }
-    } else if constexpr (SPLIT == 3 && LP::KC && LQ::KC) {
+    } else if constexpr (SPLIT == 3) {
       bf16x8_t ph[TI], pl[TI], qh[TJ], ql[TJ];
 #pragma unroll
-      for (int a = 0; a < TI; a++) frag_kc_f32_split(ps, wi0 + a * 32, ph[a], pl[a]);
+      for (int a = 0; a < TI; a++) {
+        if constexpr (LP::KC) frag_kc_f32_split(ps, wi0 + a * 32, ph[a], pl[a]); else frag_mc_f32_split(ps, P_PITCH, wi0 + a * 32, ph[a], pl[a]);
+      }
 #pragma unroll
-      for (int b = 0; b < TJ; b++) frag_kc_f32_split(qs, wj0 + b * 32, qh[b], ql[b]);
+      for (int b = 0; b < TJ; b++) {
+        if constexpr (LQ::KC) frag_kc_f32_split(qs, wj0 + b * 32, qh[b], ql[b]); else frag_mc_f32_split(qs, Q_PITCH, wj0 + b * 32, qh[b], ql[b]);
+      }
 #pragma unroll
       for (int a = 0; a < TI; a++)
 #pragma unroll

@@ -312,4 +312,6 @@ def test_emulated_conv_fwd_f32_bf16x3_split(case):
     import test_kernels_gpu as TK
     with fullemu.Installed(dma_late=1, greedy=1, seed=4):
         e_exact, e_split = TK.f32_split_case(torch.device("cpu"), case, sync=lambda: None)
+        w_exact, w_split = TK.f32_split_wgrad_case(torch.device("cpu"), case, sync=lambda: None)
     assert e_exact <= 2e-6 and e_split <= 2e-5 and e_split > e_exact, (e_exact, e_split)
+    assert w_exact <= 4e-6 and w_split <= 2e-5 and w_split > w_exact, (w_exact, w_split)

@@ -148,6 +148,26 @@ def f32_split_case(d, case, sync=lambda: torch.cuda.synchronize()):
     return errs
 
 
+def f32_split_wgrad_case(d, case, sync=lambda: torch.cuda.synchronize()):
+    """fp32 weight gradient (reduction over pixels: [k][row] LDS images, csrc/gemm_core.h frag_mc_f32_split) in the two modes against autograd in fp64"""
+    from studiogan_amd import functional as F
+    N, Cin, Cout, H, W, R, S, stride, (ph, pw) = case
+    x = rnd((N, Cin, H, W), torch.float32, 31)
+    w = rnd((Cout, Cin, R, S), torch.float32, 32, 0.2).double().requires_grad_(True)
+    y = TF.conv2d(x.double(), w, None, stride=stride, padding=(ph, pw))
+    gy = rnd(tuple(y.shape), torch.float32, 33)
+    y.backward(gy.double())
+    xd, gyd = nhwc(x).to(d), nhwc(gy).to(d)
+    errs = []
+    for mode in ("exact", "bf16x3"):
+        dw = torch.zeros((Cout, R, S, Cin), dtype=torch.float32, device=d)
+        with F.f32_mode(mode):
+            F.conv2d_wgrad_raw(xd, gyd, dw.data_ptr(), Cin, Cout, R, S, y.shape[2], y.shape[3], stride, ph, pw)
+        sync()
+        errs.append(float((dw.cpu().permute(0, 3, 1, 2).double() - w.grad).abs().max() / w.grad.abs().max()))
+    return errs
+
+
 # Inception-like shapes on the all-vector path: 1x1 / 3x3 / 1x7 / 7x1 / 5x5, stride 2, couts that pad the 128 / 96 / 32-wide tiles, K from 64 to 3456
 F32_SPLIT_CASES = [(2, 64, 96, 17, 17, 3, 3, 1, (1, 1)), (2, 192, 32, 9, 9, 1, 1, 1, (0, 0)), (1, 128, 160, 17, 17, 1, 7, 1, (0, 3)), (1, 160, 192, 17, 17, 7, 1, 1, (3, 0)),
                    (2, 48, 64, 13, 13, 5, 5, 1, (2, 2)), (2, 288, 384, 17, 17, 3, 3, 2, (0, 0)), (1, 384, 384, 8, 8, 3, 3, 1, (1, 1))]
@@ -160,6 +180,9 @@ def test_conv_fwd_f32_bf16x3_split(sg, case):
     print(f"{case}: exact {e_exact:.2e}  bf16x3 {e_split:.2e}")
     assert e_exact <= 2e-6 and e_split <= 2e-5, (e_exact, e_split)
     assert e_split > e_exact
+    w_exact, w_split = f32_split_wgrad_case(dev(), case)
+    print(f"{case}: weight gradient exact {w_exact:.2e}  bf16x3 {w_split:.2e}")
+    assert w_exact <= 4e-6 and w_split <= 2e-5 and w_split > w_exact, (w_exact, w_split)
 
 
 @pytest.mark.parametrize("dtype", DT)

@@ -43,8 +43,9 @@ def test_training_step_vs_golden(sg, name, mixed):
     step_vs_golden(name, mixed)
 
 
-def step_vs_golden(name, mixed, dev=None):
-    """dev: the GPU, or the CPU when the package is bound to the emulated library (tests/test_hipemu_net_cpu.py)"""
+def step_vs_golden(name, mixed, dev=None, gscale=1.0):
+    """dev: the GPU, or the CPU when the package is bound to the emulated library (tests/test_hipemu_net_cpu.py). gscale: factor on the gradient / final-state
+    bounds (1 = the exact arithmetic's; the bf16x3 fp32 mode carries ~5x the forward rounding noise and flips that many more ReLU units of the small fixtures)"""
     from studiogan_amd.worker import Worker
     dev = dev or torch.device("cuda:0")
     fix, meta = load_golden(name)
@@ -61,7 +62,7 @@ def step_vs_golden(name, mixed, dev=None):
     ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
     exp = sub(fix, "exp/")
     t1 = 2e-4 if not mixed else 6e-2   # first-forward quantities
-    t2 = 1e-3 if not mixed else 8e-2   # gradients / state after SN- and BN-state dependent steps
+    t2 = (1e-3 if not mixed else 8e-2) * gscale   # gradients / state after SN- and BN-state dependent steps
     # bf16 forward quantities against the reference's fp32 golden chain, relative-L2 (2e-2). Measured on the MI355X (profiles/r06_bf16_step_tables.txt):
     # images 0.7-1.6e-2, logits 0.05-1.1e-2 on every fixture held to 2e-2 here -- C3 at full width (biggan128w): images 1.58e-2 / 1.50e-2, logits 1.2e-3, which IS the
     # reference graph's own bf16 floor (its emulated-bf16 run against its fp32 run: 1.73e-2, profiles/r02_bf16_noise_floor.txt). The exceptions carry their measured
@@ -89,7 +90,7 @@ def step_vs_golden(name, mixed, dev=None):
             # gradients are still in the arena (the optimizer does not clear them); tensors that are analytically
             # zero are judged against 1e-3 of the network's gradient scale instead of their own rounding noise
             for k, p in D.named_parameters():
-                C.check("D_grad0/" + k, p.grad, exp["D_grad0/" + k], (3e-3 if wide else t2) if not mixed else (0.4 if wide else 0.25), floor=1e-2 * dmax, l2=l2,
+                C.check("D_grad0/" + k, p.grad, exp["D_grad0/" + k], (3e-3 * gscale if wide else t2) if not mixed else (0.4 if wide else 0.25), floor=1e-2 * dmax, l2=l2,
                         noise=nz("D_grad0/" + k))
     ema_before = {k: v.detach().clone() for k, v in w.Gen_ema.named_parameters()}
     w.train_generator(0, [(ins[f"z{n_d}"], ins[f"fl{n_d}"])])
@@ -98,11 +99,11 @@ def step_vs_golden(name, mixed, dev=None):
     # sits within rounding distance of 0 moves these gradients by ~1e-2 (measured on the ORACLE by perturbing D's
     # weights by 1e-6, see DESIGN.md "conditioning of the step test"); tight gradient parity is asserted on
     # single forward/backward passes in test_blocks_gpu.py instead.
-    tg = 2e-2 if not mixed else 0.45   # bf16 vs the fp32 golden chain: mask-flip noise of two D updates + the G pass (tight bf16 parity: test_bf16_vs_emulating_oracle)
+    tg = 2e-2 * gscale if not mixed else 0.45   # bf16 vs the fp32 golden chain: mask-flip noise of two D updates + the G pass (tight bf16 parity: test_bf16_vs_emulating_oracle)
     if wide:
         # full-width DCGAN: measured on the oracle alone, the +-0.3 lr differences Adam makes out of rounding noise in D move
         # these gradients by 4-10 % (test_training_step_stagewise_vs_oracle holds the same update to 1e-2 after a re-sync)
-        tg = 0.15 if not mixed else 0.6
+        tg = 0.15 * gscale if not mixed else 0.6
         if mixed and opt["apply_gp"]:
             # WGAN-GP critic (no SN, BN at batch 2): the fp32 ORACLE's generator gradient moves by 14-17 % under a 1e-7 weight perturbation
             # (tests/golden/wgangp128w.cond.npz) -- after two bf16 D updates this comparison is a finiteness / sanity bound only
