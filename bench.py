@@ -654,6 +654,23 @@ def main():
                 gbps = by / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
                 hbm[name] = {"ms_per_step": round(ms / hsteps, 3), "GB_per_step": round(by / hsteps / 1e9, 3), "GBps": round(gbps, 1),
                              "frac_of_8TBps": round(gbps / 8000.0, 3), "calls_per_step": round(n_l / hsteps, 1)}
+            if args.workload == "biggan128" and hbm["attention_scores"]["ms_per_step"] > 0:
+                # The attention core is NOT an HBM family (scores / probabilities never leave the chip): its roofs are the matrix pipe and v_exp_f32. Both attention layers of
+                # C3 sit at 64 x 64 with 192 channels (reference src/utils/ops.py:83-103: theta / phi 24 wide, g 96 wide, keys max-pooled to 1024). Per image and forward:
+                # QK^T + PV = 2 * 4096 * 1024 * (24 + 96); the fused backward recomputes the scores in both of its kernels: q side QK^T + dO g^T + dS phi, k side the same two
+                # products + dS^T theta + P^T dO. Per step: (n_d + 1) G + (2 n_d + 1) D forwards, 1 G + (2 n_d + 1) D backwards (a D update's backward crosses the attention of its real and its fake forward). One exponential per score per kernel that forms P.
+                hw, keys, dqk, dv = 4096, 1024, 24, 96
+                fwd = 2.0 * hw * keys * (dqk + dv)
+                bwd = 2.0 * hw * keys * ((dqk + dv + dqk) + (dqk + dv + dqk + dv))
+                n_f, n_b = 3 * n_d + 2, 2 * n_d + 2
+                flop = args.batch * (n_f * fwd + n_b * bwd)
+                exps = args.batch * hw * keys * (n_f + 2 * n_b)
+                a_ms = hbm["attention_scores"]["ms_per_step"]
+                hbm["attention_scores"]["compute_roof"] = {
+                    "gflop_per_step": round(flop / 1e9, 1), "tflops": round(flop / (a_ms * 1e-3) / 1e12, 1), "frac_of_mfma_peak": round(flop / (a_ms * 1e-3) / 1e12 / PEAK_BF16_TFLOPS, 4),
+                    "exp_per_step": exps, "exp_bound_ms": round(exps / 9.8e12 * 1e3, 3),
+                    "note": "unpadded dims (the kernels pad theta / phi from 24 to 32 channels); v_exp_f32 at 1/4 rate = 9.8e12 per second chip-wide; frac_of_8TBps above is kept "
+                            "only to show that HBM is not the roof"}
     # ---- second metric: FID-50k feature extraction (reference src/metrics/features.py:17-65) ------------------------
     fid = None
     if args.fid_samples > 0 and args.workload == "biggan128":
