@@ -222,6 +222,8 @@ def run_extra(name, device, steps=None, warmup=None):
     assert math.isfinite(d_l) and math.isfinite(g_l), f"{name}: non-finite losses D {d_l} G {g_l}"
     conv_ms, conv_fl = pr[1] + pr[4], pr[2] + pr[5]
     peak = PEAK_BF16_TFLOPS if e["mixed"] else PEAK_F32_TFLOPS
+    if e.get("f32_mode") == "bf16x3":
+        peak = round(PEAK_BF16_TFLOPS / 3.0, 1)      # three bf16 MFMAs per fp32-equivalent MAC: the matrix pipe's ceiling for this arithmetic
     tf = conv_fl / (conv_ms * 1e-3) / 1e12 if conv_ms > 0 else 0.0
     if e["loss"] == "hinge":
         assert d_l > 1e-2, f"{name}: the discriminator saturated (d_loss {d_l}): its backward would multiply zero gradients"
