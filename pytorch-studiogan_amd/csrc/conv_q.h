@@ -34,6 +34,7 @@ struct ConvQParams {
   int nslice;             // C / 32
   int npx;                // patch pixels (multiple of 16) >= BJ + 2 Wl + 16
   int bj;                 // pixel tile: 256 or 128
+  int gj;                 // tile order: pixel tiles per group (1 = cout tiles / phases of ONE pixel tile are neighbours; > 1 = weight-stationary groups, see the kernel)
   int patchb;             // bytes of one patch buffer (npx * 64)
   int flags;              // SG_PIX_RELU
   unsigned xbytes, wbytes;
@@ -85,10 +86,24 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(NPMIN > 0 ?
     const int xcd = bid & 7, q = nt >> 3, r = nt & 7;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  // the phases and cout tiles of one pixel tile are neighbours in launch order: they share the patch through the XCD's L2
-  const int tI = bid % tilesI;
-  const int rest = bid / tilesI;
-  const int ph = rest % nph, tJ = rest / nph;
+  // gj == 1: the phases and cout tiles of one pixel tile are neighbours in launch order: they share the patch through the XCD's L2. That order walks through
+  // ALL weight sets (cout tile, phase) once per pixel tile: fine while the whole quad image stays in the 4 MB L2, but the deep layers' images are 19-75 MB and every
+  // pixel tile then streams them from the Infinity Cache again (profiles/r06_quad_dispatch_traffic_q.txt: 1.7-3.7 GB of L2 misses per launch for 0.1 GB of tensors).
+  // gj > 1: groups of gj pixel tiles; inside a group the pixel tile runs fastest, so the gj workgroups that start together share ONE weight set and walk its
+  // channel slices in step (one L2 miss per gj readers), while the group's patches (gj x <= 0.5 MB) stay in L2 for the other weight sets.
+  int tI, ph, tJ;
+  if (p.gj > 1) {
+    const int nI = tilesI * nph, per = nI * p.gj;
+    const int grp = bid / per, r = bid - grp * per;
+    const int left = tilesJ - grp * p.gj, gs = left < p.gj ? left : p.gj;
+    const int iI = r / gs;
+    tJ = grp * p.gj + (r - iI * gs);
+    tI = iI % tilesI; ph = iI / tilesI;
+  } else {
+    tI = bid % tilesI;
+    const int rest = bid / tilesI;
+    ph = rest % nph; tJ = rest / nph;
+  }
   const int i0 = tI * BI, j0 = tJ * BJ;
   char* const pbufs = smem + p.wgt_off;
   float* sbias = (float*)(smem + p.bias_off);

@@ -196,6 +196,9 @@ static bool convq_plan(const sg_convq_desc* d, ConvQParams& p, Epilogue<bf16_t>&
     if (const char* bj = getenv("SG_CONV_Q_BJ")) { if (bj[0] == '1') p.bj = 128; else if (bj[0] == '2') p.bj = 256; }
   }
   p.npx = ((p.bj + 2 * d->Wl + 16) + 15) & ~15;
+  // tile order (conv_q.h): weight-stationary groups once the quad image no longer fits the L2 next to the patches (SG_CONV_Q_GJ=n forces n: A/B)
+  p.gj = wbytes > (2ll << 20) ? 8 : 1;
+  if (const char* gj = getenv("SG_CONV_Q_GJ")) { const int v = atoi(gj); if (v >= 1 && v <= 64) p.gj = v; }
   p.flags = d->pix_flags;
   p.xbytes = (unsigned)xbytes; p.wbytes = (unsigned)wbytes;
   p.wgt_off = p.zero_off = p.bias_off = 0;

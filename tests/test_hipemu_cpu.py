@@ -229,6 +229,24 @@ def test_conv_q_is_schedule_independent(cq, form, shape):
         assert np.array_equal(v, ref), k
 
 
+@pytest.mark.parametrize("form", [emu.Q_POOL, emu.Q_UP])
+@pytest.mark.parametrize("shape", [(3, 16, 16, 64, 192), (5, 8, 8, 32, 96)])      # 3 and 2 pixel tiles (the second: ragged last tile), two / one cout tiles
+def test_conv_q_tile_order_groups(cq, form, shape):
+    """conv_q.h's weight-stationary tile order (gj > 1: groups of pixel tiles share one weight set; round 6, the deep layers' L2 misses) is a pure renumbering of the
+    workgroups: bit-identical output for group sizes that divide the pixel tiles, that leave a ragged last group, and that exceed them"""
+    N, Hl, Wl, Cin, Cout = shape
+    rng = np.random.default_rng(41)
+    x, _ = _qdata(form, shape, 41)
+    w9 = emu.to_bf16((0.1 * rng.standard_normal((Cout, 3, 3, Cin))).astype(np.float32))
+    wq = emu.quad_pack(cq, w9, form)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    emu.config(cq, dma_late=1, greedy=1, seed=5)
+    ref = emu.conv_q(cq, form, x, wq, Cout, relu_in=True, bias=bias, env={"SG_CONV_Q_BJ": "256", "SG_CONV_Q_GJ": "1"}).copy()
+    for gj in ("2", "3", "8"):
+        out = emu.conv_q(cq, form, x, wq, Cout, relu_in=True, bias=bias, env={"SG_CONV_Q_BJ": "256", "SG_CONV_Q_GJ": gj})
+        assert np.array_equal(out, ref), (form, shape, gj)
+
+
 # ---- conv_v4.h (3x3 halo kernel of the <= 384-channel layers) -----------------------------------------------------------------------------------------------
 V4_CASES = [
     # N, H, C, Cout, relu_in, up, pool
