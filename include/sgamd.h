@@ -196,6 +196,12 @@ typedef struct {
   int epi_flags; int splits; int no_tr;
 } sg_gemm_desc;
 int sg_gemm(const sg_gemm_desc* d, sg_stream_t stream);
+/* n small fp32 linear layers in ONE launch: out[b][o] = bias[o] + sum_k w[o][k] y[b][k], b < B (the same B for every item).
+ * Replaces the per-layer gain(y) / bias(y) products of ConditionalBatchNorm2d (reference src/utils/ops.py:21-27, the ten conditional batch norms of a BigGAN
+ * generator forward, src/models/big_resnet.py:139-163): every conditioning vector is known when the forward starts. items_dev: the table in device
+ * memory, items_host: the same table on the host. */
+typedef struct { const float* w; const float* y; const float* bias; float* out; int rows, K, ldy, ldo; } sg_linear_item;
+int sg_linear_group(const sg_linear_item* items_dev, const sg_linear_item* items_host, int n, int B, sg_stream_t stream);
 
 /* ---- layout / elementwise ------------------------------------------------------------------------------ */
 /* fp32 NCHW -> T NHWC (ldo = channel pitch of the destination) */

@@ -59,6 +59,10 @@ class QuadItem(C.Structure):
     _fields_ = [("src", _vp), ("dst", _vp), ("M", _i), ("Cs", _i), ("mode", _i), ("pad_", _i)]
 
 
+class LinearItem(C.Structure):
+    _fields_ = [("w", _vp), ("y", _vp), ("bias", _vp), ("out", _vp), ("rows", _i), ("K", _i), ("ldy", _i), ("ldo", _i)]
+
+
 class GemmDesc(C.Structure):
     _fields_ = [("dtype", _i), ("p_form", _i), ("q_form", _i), ("I", _i), ("J", _i), ("K", _i), ("batch", _i),
                 ("p", _vp), ("p_bstride", _ll), ("ldp", _i), ("q", _vp), ("q_bstride", _ll), ("ldq", _i),
@@ -113,6 +117,7 @@ _PROTOS = {
     "sg_bn_stats_from_tiles": [_vp, _i, _i, _vp, _vp],
     "sg_quad_pack": [_i, _i, _vp, _vp, _i, _i, _vp],
     "sg_quad_pack_batch": [_i, _vp, C.POINTER(QuadItem), _i, _vp],
+    "sg_linear_group": [_vp, C.POINTER(LinearItem), _i, _i, _vp],
     "sg_conv2d_q_wgrad_plan": [C.POINTER(ConvQWgradDesc), C.POINTER(_i), C.POINTER(_ll)],
     "sg_conv2d_q_wgrad": [C.POINTER(ConvQWgradDesc), _vp],
     "sg_prof_collect_ex": [C.POINTER(C.c_double), _i],

@@ -148,6 +148,16 @@ class Generator(nn.Module):
         else:
             affines = [torch.cat(affine_list + [item], 1) for item in zs[1:]]
 
+        # every conditional batch norm's [1 + gain(y) | bias(y)] rows in ONE launch: all conditioning vectors exist before the first block runs
+        pairs, counter = [], 0
+        for blocklist in self.blocks:
+            for block in blocklist:
+                if not isinstance(block, ops.SelfAttention):
+                    if isinstance(block.bn1, ops.ConditionalBatchNorm2d):
+                        pairs += [(block.bn1, affines[counter]), (block.bn2, affines[counter])]
+                    counter += 1
+        F.cbn_prefetch(slot, pairs)
+
         act = self.linear0.forward_rt(z0, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
         act = ops.block_boundary(self, -1, act)

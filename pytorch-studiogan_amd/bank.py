@@ -443,6 +443,7 @@ class WeightBank:
             phys.live = weakref.ref(slot)
         else:
             slot = self.slots[0]
+        slot.cbn_rows = None              # (functional.cbn_prefetch: the conditional batch norms' affine rows of THIS forward)
         flags = tuple(bool(r.module().training) for r in self.layers)
         # A frozen network run without a graph (the evaluation generator of the FID / IS loop, reference src/metrics/features.py:17-65: one forward per
         # batch of 50 k samples) gets the SAME weight images every time: no power iteration (eval mode), same weights. Slot 0 keeps them until

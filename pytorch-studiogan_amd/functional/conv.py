@@ -1,4 +1,6 @@
 """convolution / transposed convolution / linear / embedding autograd functions over the weight bank (csrc/conv*.h, wgrad*.h, gemm_core.h; reference src/utils/ops.py:165-224)."""
+import ctypes
+
 from ._base import *  # noqa: F401,F403  (shared helpers, switches, raw launch wrappers, torch / _lib / comm)
 
 # ---------------------------------------------------------------------------------------------------------
@@ -584,33 +586,137 @@ class CbnAffineFn(torch.autograd.Function):
     def backward(ctx, dgb):
         _first_order_only("CbnAffineFn")
         (y,) = ctx.saved_tensors
-        rt_g, rt_b, slot = ctx.rt_g, ctx.rt_b, ctx.slot
-        bank = rt_g.bank()
-        dgb = _c(dgb.float())
-        B, K = y.shape
-        C = rt_g.rows
-        pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
-        # (a frozen half -- only one of the two weights requires a gradient -- gets none: the merged 2 C-row GEMM is taken when BOTH want theirs)
-        dg = bank.dwt(slot, rt_g) if ctx.needs_input_grad[1] else None
-        db = bank.dwt(slot, rt_b) if ctx.needs_input_grad[2] else None
-        both = dg is not None and db is not None
-        adjacent = ctx.adjacent and (not both or db == dg + 4 * C * K)
-        dy = None
-        if ctx.needs_input_grad[0]:
-            dy = torch.empty((B, K), dtype=torch.float32, device=y.device)
-            if adjacent:      # dy[b][k] = sum over the 2 C rows of dgb[b][o] W[o][k]
-                gemm_dgrad_rows(pg, dgb, dy, B, K, 2 * C)
-            else:
-                gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, C)
-                gemm_raw(L.F32, pb, 1, K, dgb.data_ptr() + 4 * C, 0, 2 * C, dy, K, K, B, C, res=dy, ldr=K)
-        if both and adjacent:      # dW[o][k] = sum_b dgb[b][o] y[b][k], o over the 2 C rows
-            gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, 2 * C, B)
-        else:
-            if dg is not None:
-                gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, C, B)
-            if db is not None:
-                gemm_raw(L.F32, y, 1, K, dgb.data_ptr() + 4 * C, 1, 2 * C, db, K, K, C, B)
+        dy = _cbn_affine_backward(y, dgb, ctx.rt_g, ctx.rt_b, ctx.slot, ctx.adjacent, ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2])
         return dy, None, None, None, None, None, None
+
+
+def _cbn_affine_backward(y, dgb, rt_g, rt_b, slot, fwd_adjacent, need_y, need_g, need_b):
+    """backward of one conditional batch norm's [1 + gain(y) | bias(y)] product: -> dy ([B][K] or None); the weight gradients go into the bank's scratch"""
+    bank = rt_g.bank()
+    dgb = _c(dgb.float())
+    B, K = y.shape
+    C = rt_g.rows
+    pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
+    # (a frozen half -- only one of the two weights requires a gradient -- gets none: the merged 2 C-row GEMM is taken when BOTH want theirs; ADVICE r4)
+    dg = bank.dwt(slot, rt_g) if need_g else None
+    db = bank.dwt(slot, rt_b) if need_b else None
+    both = dg is not None and db is not None
+    adjacent = fwd_adjacent and (not both or db == dg + 4 * C * K)
+    dy = None
+    if need_y:
+        dy = torch.empty((B, K), dtype=torch.float32, device=y.device)
+        if adjacent:      # dy[b][k] = sum over the 2 C rows of dgb[b][o] W[o][k]
+            gemm_dgrad_rows(pg, dgb, dy, B, K, 2 * C)
+        else:
+            gemm_raw(L.F32, pg, 1, K, dgb, 0, 2 * C, dy, K, K, B, C)
+            gemm_raw(L.F32, pb, 1, K, dgb.data_ptr() + 4 * C, 0, 2 * C, dy, K, K, B, C, res=dy, ldr=K)
+    if both and adjacent:      # dW[o][k] = sum_b dgb[b][o] y[b][k], o over the 2 C rows
+        gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, 2 * C, B)
+    else:
+        if dg is not None:
+            gemm_raw(L.F32, y, 1, K, dgb, 1, 2 * C, dg, K, K, C, B)
+        if db is not None:
+            gemm_raw(L.F32, y, 1, K, dgb.data_ptr() + 4 * C, 1, 2 * C, db, K, K, C, B)
+    return dy
+
+
+class CbnAffineGroupFn(torch.autograd.Function):
+    """The [1 + gain(y) | bias(y)] products of ALL conditional batch norms of a generator forward in one launch (csrc/linear_group.hip): every conditioning
+    vector is known when the forward starts (reference src/models/big_resnet.py:139-163), and each product on its own is a 32 us launch of a few workgroups.
+    apply(slot, metas, yidx, *tensors): metas[i] = (rt_gain, rt_bias, const2) of layer i, yidx[i] = which conditioning vector it reads,
+    tensors = (y_0 .. y_{G-1}, gain_w_0, bias_w_0, gain_w_1, ...). Returns one packed [B][2 C_i] tensor per layer (what BNFn takes with cfg.packed).
+    The backward runs layer by layer (CbnAffineFn's launches) once every layer's gradient has arrived."""
+
+    @staticmethod
+    def forward(ctx, slot, metas, yidx, *tensors):
+        G = len(tensors) - 2 * len(metas)
+        ys = [_c(t.float()) for t in tensors[:G]]
+        B, K = ys[0].shape
+        bank = metas[0][0].bank()
+        dev = ys[0].device
+        n = len(metas)
+        total = sum(2 * m[0].rows for m in metas)
+        out_all = torch.empty(B * total, dtype=torch.float32, device=dev)
+        arr = (L.LinearItem * (2 * n))()
+        outs, adj, off, k = [], [], 0, 0
+        for i, (rt_g, rt_b, const2) in enumerate(metas):
+            C = rt_g.rows
+            y = ys[yidx[i]]
+            assert y.shape == (B, K) and rt_g.cols == K and rt_b.cols == K and rt_b.rows == C
+            pg, pb = bank.w_f32(slot, rt_g), bank.w_f32(slot, rt_b)
+            a = pb == pg + 4 * C * K
+            adj.append(a)
+            base = out_all.data_ptr() + 4 * off
+            parts = [(pg, 2 * C, const2.data_ptr(), base)] if a else [(pg, C, const2.data_ptr(), base), (pb, C, const2.data_ptr() + 4 * C, base + 4 * C)]
+            for (w, rows, bias, o) in parts:
+                it = arr[k]
+                it.w, it.y, it.bias, it.out, it.rows, it.K, it.ldy, it.ldo = w, y.data_ptr(), bias, o, rows, K, K, 2 * C
+                k += 1
+            outs.append(out_all[off:off + B * 2 * C].view(B, 2 * C))
+            off += B * 2 * C
+        # the device copy of the table is kept per set of addresses: in steady state the caching allocator hands every step the same blocks, so the upload
+        # (a pageable host-to-device copy) happens during warm-up only
+        raw = bytes(bytearray(arr)[:k * ctypes.sizeof(L.LinearItem)])
+        cache = bank.__dict__.setdefault("_linear_group_tabs", {})
+        tab = cache.get(raw)
+        if tab is None:
+            if len(cache) >= 64:
+                cache.clear()
+            tab = cache[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+        L.call("sg_linear_group", tab.data_ptr(), arr, k, B, L.stream())
+        ctx.save_for_backward(*ys)
+        ctx.metas, ctx.yidx, ctx.slot, ctx.adj, ctx.G = metas, yidx, slot, adj, G
+        ctx._keep = out_all
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *dgbs):
+        _first_order_only("CbnAffineGroupFn")
+        ys = ctx.saved_tensors
+        G, n = ctx.G, len(ctx.metas)
+        dys = [None] * G
+        for i, ((rt_g, rt_b, _), dgb) in enumerate(zip(ctx.metas, dgbs)):
+            if dgb is None:
+                continue
+            g = ctx.yidx[i]
+            dy = _cbn_affine_backward(ys[g], dgb, rt_g, rt_b, ctx.slot, ctx.adj[i], ctx.needs_input_grad[3 + g],
+                                      ctx.needs_input_grad[3 + G + 2 * i], ctx.needs_input_grad[3 + G + 2 * i + 1])
+            if dy is not None:
+                dys[g] = dy if dys[g] is None else dys[g].add_(dy)
+        return (None, None, None) + tuple(dys) + (None,) * (2 * n)
+
+
+def cbn_prefetch(slot, pairs):
+    """pairs = [(ConditionalBatchNorm2d module, conditioning vector)] of a generator forward, in any order: one launch computes every layer's packed
+    [1 + gain | bias] rows; each module's forward_nhwc then finds its rows in slot.cbn_rows (ops.ConditionalBatchNorm2d). Layers that do not qualify
+    (a linear with a bias, SG_CBN_MERGED=0 / SG_CBN_GROUP=0) are left to their own launches."""
+    slot.cbn_rows = {}
+    if not (_CBN_GROUP[0] and _CBN_MERGED[0]):
+        return
+    ok = [(m, y) for (m, y) in pairs if m.gain.bias is None and m.bias.bias is None and m.gain.__dict__.get("_sg_rt") is not None]
+    if len(ok) < 2:
+        return
+    ys, yidx = [], []
+    for _, y in ok:
+        for j, t in enumerate(ys):
+            if t is y:
+                yidx.append(j)
+                break
+        else:
+            yidx.append(len(ys))
+            ys.append(y)
+    if any(t.shape != ys[0].shape for t in ys):
+        return
+    metas = [(m.gain._sg_rt, m.bias._sg_rt, m._ones2) for m, _ in ok]
+    ws = []
+    for m, _ in ok:
+        ws += [m.gain.master_weight, m.bias.master_weight]
+    outs = CbnAffineGroupFn.apply(slot, metas, yidx, *ys, *ws)
+    for (m, _), o in zip(ok, outs):
+        slot.cbn_rows[id(m)] = o
+
+
+_CBN_GROUP = [os.environ.get("SG_CBN_GROUP", "1") != "0"]      # all conditional batch norms' affine rows of a generator forward in one launch (CbnAffineGroupFn)
 
 
 class EmbeddingFn(torch.autograd.Function):
@@ -664,4 +770,4 @@ class SNEmbeddingFn(torch.autograd.Function):
         return None, None, None, None
 
 
-__all__ = ['CatConvDgradFn', 'CatConvFn', 'CbnAffineFn', 'ConvCfg', 'ConvDgradFn', 'ConvFn', 'ConvSkipFn', 'ConvTransposeFn', 'EmbeddingFn', 'GradLink', 'LinearDgradFn', 'LinearFn', 'SNEmbeddingFn', 'SliceUpFn', '_GRAD_LINK', '_QUAD', '_SKIP_FUSION', '_conv_dgrad', '_conv_fwd', '_conv_wgrad', '_quad_form']
+__all__ = ['CatConvDgradFn', 'CatConvFn', 'CbnAffineFn', 'CbnAffineGroupFn', 'cbn_prefetch', '_CBN_GROUP', 'ConvCfg', 'ConvDgradFn', 'ConvFn', 'ConvSkipFn', 'ConvTransposeFn', 'EmbeddingFn', 'GradLink', 'LinearDgradFn', 'LinearFn', 'SNEmbeddingFn', 'SliceUpFn', '_GRAD_LINK', '_QUAD', '_SKIP_FUSION', '_conv_dgrad', '_conv_fwd', '_conv_wgrad', '_quad_form']

@@ -247,6 +247,11 @@ class ConditionalBatchNorm2d(nn.Module):
         self.register_buffer("_ones2", torch.cat([torch.ones(out_features), torch.zeros(out_features)]), persistent=False)
 
     def forward_nhwc(self, x, y, slot=None, relu=False, link=None):
+        pre = slot.__dict__.get("cbn_rows") if slot is not None else None
+        if pre:
+            gb = pre.pop(id(self), None)      # computed with every other conditional batch norm of this forward (functional.cbn_prefetch)
+            if gb is not None:
+                return self.bn.forward_nhwc(x, gb, None, relu, link, packed=True)
         if F._CBN_MERGED[0] and self.gain.bias is None and self.bias.bias is None:
             # [1 + gain(y) | bias(y)] as one GEMM over the two adjacent weight images (functional.CbnAffineFn); the '1 +' rides in its epilogue bias
             rt_g, rt_b = self.gain._sg_rt, self.bias._sg_rt

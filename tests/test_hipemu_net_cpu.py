@@ -63,6 +63,51 @@ def test_emulated_fp32_training_step_vs_golden(name):
     _step(name, False)
 
 
+def test_emulated_grouped_cbn_affine_equals_per_layer():
+    """functional.cbn_prefetch / CbnAffineGroupFn (csrc/linear_group.hip: every conditional batch norm's [1 + gain(y) | bias(y)] rows of a generator forward in one
+    launch) against the per-layer GEMMs it replaces: the generated images, the gradient w.r.t. z and every parameter gradient of the generator (the conditional
+    batch norms' linears among them) of the biggan32 fixture, fp32; and the launch really happened"""
+    import fullemu
+    import test_model_gpu as TM
+    from util import load_golden, sub
+    from studiogan_amd import functional as F
+    dev = torch.device("cpu")
+    fix, meta = load_golden("biggan32")
+    y = meta["yaml"]
+    ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+    res, calls = {}, {True: 0, False: 0}
+    with fullemu.Installed(dma_late=1, greedy=1, seed=3) as E:
+        call0 = E.L.call
+        for grouped in (True, False):
+            F._CBN_GROUP[0] = grouped
+
+            def counting(name, *a, _g=grouped):
+                calls[_g] += name == "sg_linear_group"
+                return call0(name, *a)
+            E.L.call = counting
+            try:
+                G, _ = TM.build_from_yaml(y, False, dev)
+                G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+                G.train()
+                z = ins["z0"].clone().requires_grad_(True)
+                img = G(z, ins["fl0"])
+                (img * torch.linspace(-1, 1, img.numel()).view_as(img)).sum().backward()
+                grads = {k: p.grad.clone() for k, p in G.named_parameters() if p.grad is not None}
+                res[grouped] = (img.detach().clone(), z.grad.clone(), grads)
+            finally:
+                F._CBN_GROUP[0] = True
+                E.L.call = call0
+    assert calls == {True: 1, False: 0}
+    a, b = res[True], res[False]
+    assert torch.allclose(a[0], b[0], rtol=0, atol=2e-5 * b[0].abs().max().item())      # (one FMA chain against the f32 MFMA's summation: fp32 rounding, 2e-6 measured)
+    assert torch.allclose(a[1], b[1], rtol=0, atol=2e-4 * b[1].abs().max().item() + 1e-12)
+    assert a[2].keys() == b[2].keys() and any(".bn1.gain." in k for k in a[2])
+    for k in a[2]:
+        if ".conv2d" in k and k.endswith(".bias"):      # a bias in front of a batch norm: its true gradient is zero, what is there is rounding noise
+            continue
+        assert torch.allclose(a[2][k], b[2][k], rtol=0, atol=2e-4 * b[2][k].abs().max().item() + 1e-12), k
+
+
 def test_emulated_frozen_network_weight_image_cache():
     """bank.WeightBank.begin_forward keeps the emitted weight images of a frozen network (eval mode, no graph: the evaluation generator of the FID
     loop) until something writes its parameters: hits give bit-identical images, a torch-side write (in-place op, load_state_dict), a raw-pointer

@@ -55,6 +55,35 @@ def test_gemm_forms(sg, dtype, pf, qf, I, J, K, batch):
         check(f"gemm p{pf}q{qf} {I}x{J}x{K} b{batch} no_tr={no_tr}", out, ref, 2e-4 if dtype == torch.float32 else 2e-3)
 
 
+def test_linear_group(sg):
+    """sg_linear_group (csrc/linear_group.hip): several small fp32 linear layers of different widths on shared / separate inputs in one launch, against fp64
+    (ragged row tiles, a batch that is not a multiple of the tile, a K that is not a multiple of the k-chunk, an item without a bias)"""
+    import ctypes
+    from studiogan_amd import _lib as L
+    d = dev()
+    B, K = 100, 148
+    ys = [rnd((B, K), torch.float32, 10 + g).to(d) for g in range(2)]
+    spec = [(3072, 0, True), (192, 0, True), (70, 1, False), (1, 1, True)]
+    arr = (L.LinearItem * len(spec))()
+    keep, refs, outs = [], [], []
+    for i, (rows, g, has_bias) in enumerate(spec):
+        w = rnd((rows, K), torch.float32, 20 + i).to(d)
+        b = rnd((rows,), torch.float32, 30 + i).to(d) if has_bias else None
+        ldo = rows + 8
+        o = torch.full((B, ldo), 7.0, dtype=torch.float32, device=d)
+        it = arr[i]
+        it.w, it.y, it.bias, it.out, it.rows, it.K, it.ldy, it.ldo = w.data_ptr(), ys[g].data_ptr(), (b.data_ptr() if has_bias else None), o.data_ptr(), rows, K, K, ldo
+        keep += [w, b]
+        outs.append(o)
+        refs.append(ys[g].double() @ w.double().t() + (b.double() if has_bias else 0.0))
+    tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(d)
+    L.call("sg_linear_group", tab.data_ptr(), arr, len(spec), B, L.stream())
+    torch.cuda.synchronize()
+    for i, (rows, g, has_bias) in enumerate(spec):
+        check(f"linear_group item {i} rows {rows}", outs[i][:, :rows], refs[i], 2e-5)
+        assert (outs[i][:, rows:] == 7.0).all()          # nothing written past an item's rows
+
+
 def _conv_ref(x, w, stride, pad, relu_in=False, up=False, pool=False, bias=None, res=None):
     x = x.double()
     if relu_in:
