@@ -40,7 +40,7 @@ typedef __attribute__((address_space(3))) void* sg_lptr_t;
 // buffers, reused as the output staging area; sbias: BI floats in LDS (valid when epi.bias).
 // VMAP (conv_q.h, UP form): the tile's rows are positions of a LOW-resolution grid and the output / mask / residual tensors are one parity
 // view of the tensor at twice the resolution: global row of tile row jg = ((jg >> vlog) << (vlog + 2)) + ((jg & (2^vlog - 1)) << 1) + vadd.
-template <int BI, int BJ, int NW, int TI, int TJ, bool VMAP = false>
+template <int BI, int BJ, int NW, int TI, int TJ, bool VMAP = false, bool NOSTORE = false>      // NOSTORE: ablation only (conv_v4.h ABL bit 5)
 __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* smem, const float* sbias, const Epilogue<bf16_t>& epi,
                                                  int i0, int j0, int wi0, int wj0, float al, bool active = true, int vlog = 0, int vadd = 0,
                                                  float* stats = nullptr, int stats_C = 0, int stats_row = 0) {
@@ -208,7 +208,10 @@ __device__ __forceinline__ void sg_conv_epilogue(f32x16 (&acc)[TI][TJ], char* sm
     for (int idx = tid; idx < rows_out * CPR; idx += 64 * NW) {
       const int r = idx / CPR, c = idx - r * CPR;
       const int jg = jbase + r;
-      if (jg < Jout && c < ncr) *(u32x4*)(o + grow(jg) * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
+      if (NOSTORE) {
+        const u32x4 v = *(const u32x4*)(smem + r * CP + c * 16);
+        if (v[0] == 0x12345678u && v[1] == 0x9abcdef0u) *(u32x4*)(o + grow(jg) * epi.ldo + i0 + c * 8) = v;      // (never: keeps the read alive)
+      } else if (jg < Jout && c < ncr) *(u32x4*)(o + grow(jg) * epi.ldo + i0 + c * 8) = *(const u32x4*)(smem + r * CP + c * 16);
     }
   }
 }

@@ -55,7 +55,10 @@ struct ConvV4Params {
 //
 // Measured and removed in round 5 (profiles/r05_variant_ab_layer_tables_b.txt): a fourth weight buffer with the tiles three taps ahead -- +1.0 % on the layer
 // table: the counted wait in front of a tap's barrier is not the weight tile's latency.
-template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
+// ABL (measurement aid, tools/sessions/r6u.sh; never launched by the product): compile-time ablation of one cost at a time -- bit 0: no epilogue (the accumulators
+// are kept alive by a store that never happens), bit 1: no patch reload at the slice boundaries (one barrier instead of the full stop), bit 2: no weight DMA inside
+// the loop (every tap re-reads the prologue's tiles), bit 3: no barrier at the end of a tap, bit 4: no fragment reads (the MFMAs run on the first tap's registers), bit 5: the epilogue without its global stores. Results are wrong by construction; what is read off is the time.
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int ABL = 0>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 3 : 2, TJW == 2 ? 3 : 2))) void sg_conv_v4_kernel(ConvV4Params p, Epilogue<bf16_t> epi, int tilesI, int tilesJ) {
   static_assert(TJW == 2, "256-pixel tiles (the 512-pixel instantiation was measured no faster and removed in round 5)");
   static_assert(!SKIP || !UP, "the fused skip is built for the plain tile");
@@ -200,6 +203,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
   weight_tile(0, 0, 0);
   weight_tile(1, 0, 1);
   __syncthreads();
+  bf16x8_t pf0[2][TI], qf0[2][TJ];      // (ABL bit 4 only)
   for (int s = 0; s < nslice; s++) {
     const bool next_slice = s + 1 < nslice;
 #pragma unroll
@@ -207,9 +211,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
       // weights LA taps ahead: buffer (t + LA) % 3 = (t - 1) % 3 was read during the previous tap, every wave is past its barrier (9 % 3 == 0: the ring restarts every slice)
       const bool issue = (t + LA < 9) || next_slice;
       const int ibuf = (t + LA) % 3;
-      if (t + LA < 9) weight_tile(ibuf, s, t + LA);
-      else if (next_slice) weight_tile(ibuf, s + 1, t + LA - 9);
-      const char* ps = pbufs + (t % 3) * PB;
+      if constexpr (!(ABL & 4)) {
+        if (t + LA < 9) weight_tile(ibuf, s, t + LA);
+        else if (next_slice) weight_tile(ibuf, s + 1, t + LA - 9);
+      }
+      const char* ps = pbufs + ((ABL & 4) ? (t & 1) : (t % 3)) * PB;
       const int tr = t / 3, ts = t % 3;                          // compile-time after unrolling
       unsigned qa[TJ];
 #pragma unroll
@@ -232,37 +238,70 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
         a = ((qinv[b] >> t) & 1u) ? (unsigned)p.zero_off : a;
         qa[b] = a;
       }
+      // Round 6: the fragments of BOTH k-steps of the tap are requested up front (10 ds_read_b128 in flight), then the 4 NB MFMAs run behind counted waits.
+      // Left to the scheduler the loop kept ONE weight-fragment register: read, s_waitcnt lgkmcnt(0), two MFMAs, read the next into the same register, full wait, ...
+      // -- six exposed LDS round trips per tap (profiles/r06_conv_v4_loop_isa_before.txt). The scheduling barriers pin the order as written.
+      bf16x8_t pf[2][TI], qf[2][TJ];
+      if ((ABL & 16) && (s | t)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+          for (int a = 0; a < TI; a++) pf[ks][a] = pf0[ks][a];
+#pragma unroll
+          for (int b = 0; b < TJ; b++) qf[ks][b] = qf0[ks][b];
+        }
+      } else
 #pragma unroll
       for (int ks = 0; ks < 2; ks++) {
-        bf16x8_t pf[TI], qf[TJ];
 #pragma unroll
         for (int a = 0; a < TI; a++) {
           u32x4 v = *(const u32x4*)(ps + (wa[a] ^ (unsigned)(ks * 32)));
-          pf[a] = __builtin_bit_cast(bf16x8_t, v);
+          pf[ks][a] = __builtin_bit_cast(bf16x8_t, v);
         }
 #pragma unroll
         for (int b = 0; b < TJ; b++) {
           u32x4 v = *(const u32x4*)(smem + (qa[b] ^ (unsigned)(ks * 32)));
-          if (RELU) v = relu16<bf16_t>(v);
-          qf[b] = __builtin_bit_cast(bf16x8_t, v);
+          qf[ks][b] = __builtin_bit_cast(bf16x8_t, v);
+        }
+      }
+      if ((ABL & 16) && !(s | t)) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ks++) {
+#pragma unroll
+          for (int a = 0; a < TI; a++) pf0[ks][a] = pf[ks][a];
+#pragma unroll
+          for (int b = 0; b < TJ; b++) qf0[ks][b] = qf[ks][b];
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        if (RELU) {
+#pragma unroll
+          for (int b = 0; b < TJ; b++) qf[ks][b] = __builtin_bit_cast(bf16x8_t, relu16<bf16_t>(__builtin_bit_cast(u32x4, qf[ks][b])));
         }
 #pragma unroll
         for (int a = 0; a < TI; a++)
 #pragma unroll
           for (int b = 0; b < TJ; b++)
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[a], qf[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(pf[ks][a], qf[ks][b], acc[a][b], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
       }
       if (t == 8 && next_slice) {
         // slice boundary: the patch is single-buffered -- everyone must be done reading it, then it is reloaded (a full stop for this
         // workgroup; the other two workgroups of the CU keep the matrix pipe busy)
         __syncthreads();
-        patch_slice(s + 1);
-        __syncthreads();
+        if constexpr (!(ABL & 2)) {
+          patch_slice(s + 1);
+          __syncthreads();
+        }
       } else {
-        if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
+        if constexpr (!(ABL & 4)) {
+          if (!issue) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (two) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+        }
+        if constexpr (!(ABL & 8)) __builtin_amdgcn_s_barrier();
       }
     }
   }
@@ -357,7 +396,18 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(TJW == 2 ? 
 
   float al = epi.alpha;
   if (epi.alpha_ptr) al *= *epi.alpha_ptr;
-  if constexpr (TJW == 2) {
+  if constexpr (ABL & 1) {
+    float t = 0.f;
+#pragma unroll
+    for (int a = 0; a < TI; a++)
+#pragma unroll
+      for (int b = 0; b < TJ; b++)
+#pragma unroll
+        for (int r = 0; r < 16; r++) t += acc[a][b][r];
+    if (t == 1234.5f) *(float*)epi.out = t;
+  } else if constexpr ((ABL & 32) != 0) {
+    sg_conv_epilogue<BI, BJ, NW, TI, TJ, false, true>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
+  } else if constexpr (TJW == 2) {
     sg_conv_epilogue<BI, BJ, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, true, 0, 0, p.stats, p.I, tJ);
   } else {   // 512-pixel tile, 256-row staging area: waves 0, 1 then waves 2, 3
     sg_conv_epilogue<BI, 256, NW, TI, TJ>(acc, smem, sbias, epi, i0, j0, 0, wj0, al, wave < 2);
@@ -378,18 +428,18 @@ static inline int sg_conv_v4_lds(int NB, int npx, int* wgt_off, int* zero_off, i
   if (bias_off) *bias_off = body + 128;
   return body + 128 + BI * 4;
 }
-template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false>
+template <int NB, bool RELU, bool UP, int TJW, bool SKIP = false, int ABL = 0>
 static inline int sg_launch_conv_v4r(ConvV4Params p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const int lds = sg_conv_v4_lds(NB, p.npx, &p.wgt_off, &p.zero_off, &p.bias_off, SKIP ? (p.up2 ? 3 * 64 * 64 : 2 * 256 * 64) : 0);
   if (lds > 80 * 1024) return -1;
   static bool attr_done = false;
   if (!attr_done) {
-    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
+    if (hipFuncSetAttribute((const void*)sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024) != hipSuccess) return -1;
     attr_done = true;
   }
   const int BI = 32 * NB, BJ = 128 * TJW;
   const int tilesI = (p.I + BI - 1) / BI, tilesJ = (p.J + BJ - 1) / BJ;
-  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
+  hipLaunchKernelGGL((sg_conv_v4_kernel<NB, RELU, UP, TJW, SKIP, ABL>), dim3(tilesI * tilesJ), dim3(256), lds, st, p, e, tilesI, tilesJ);
   return 0;
 }
 template <int NB>
@@ -400,6 +450,24 @@ static inline int sg_launch_conv_v4_skip(const ConvV4Params& p, const Epilogue<b
 template <int NB, int TJW>
 static inline int sg_launch_conv_v4(const ConvV4Params& p, const Epilogue<bf16_t>& e, hipStream_t st) {
   const bool up = (p.flags & SG_PIX_UPSAMPLE) != 0, relu = (p.flags & SG_PIX_RELU) != 0;
+  if constexpr (NB == 3 && TJW == 2) {
+    if (!up && !relu) {          // ablation instantiations (see the kernel): SG_V4_ABLATE = bit mask, plain 96-cout tiles only
+      static int abl = -1;
+      if (abl < 0) { const char* ev = getenv("SG_V4_ABLATE"); abl = ev ? atoi(ev) : 0; }
+      switch (abl) {
+        case 1: return sg_launch_conv_v4r<3, false, false, 2, false, 1>(p, e, st);
+        case 2: return sg_launch_conv_v4r<3, false, false, 2, false, 2>(p, e, st);
+        case 3: return sg_launch_conv_v4r<3, false, false, 2, false, 3>(p, e, st);
+        case 4: return sg_launch_conv_v4r<3, false, false, 2, false, 4>(p, e, st);
+        case 6: return sg_launch_conv_v4r<3, false, false, 2, false, 6>(p, e, st);
+        case 7: return sg_launch_conv_v4r<3, false, false, 2, false, 7>(p, e, st);
+        case 15: return sg_launch_conv_v4r<3, false, false, 2, false, 15>(p, e, st);
+        case 32: return sg_launch_conv_v4r<3, false, false, 2, false, 32>(p, e, st);
+        case 31: return sg_launch_conv_v4r<3, false, false, 2, false, 31>(p, e, st);
+        default: break;
+      }
+    }
+  }
   if (relu) return up ? sg_launch_conv_v4r<NB, true, true, TJW>(p, e, st) : sg_launch_conv_v4r<NB, true, false, TJW>(p, e, st);
   return up ? sg_launch_conv_v4r<NB, false, true, TJW>(p, e, st) : sg_launch_conv_v4r<NB, false, false, TJW>(p, e, st);
 }
