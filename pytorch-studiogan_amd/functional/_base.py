@@ -34,6 +34,37 @@ def _c(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# Small zero-initialised scratch (batch-norm partial sums, per-sample reduction buffers, head scratch): ~110 torch.zeros() per BigGAN-128 step, each its own
+# fill launch (4-5 us of a busy stream; 4400 of them per WGAN-GP step). They are carved out of ONE zeroed block per device instead -- a fresh 8 MiB block (one fill)
+# whenever the current one is used up; a piece is handed out once and never again, and the block lives as long as any piece of it does.
+_ZERO_POOL = {}
+_ZERO_POOL_BYTES = 8 << 20
+_ZERO_POOL_ON = [os.environ.get("SG_ZERO_POOL", "1") != "0"]
+
+
+def zeros_small(shape, dtype, device):
+    if isinstance(shape, int):
+        shape = (shape,)
+    n = 1
+    for d in shape:
+        n *= int(d)
+    nbytes = n * torch.empty((), dtype=dtype).element_size()
+    if not _ZERO_POOL_ON[0] or nbytes == 0 or nbytes > (_ZERO_POOL_BYTES >> 1) or torch.device(device).type != "cuda":
+        return torch.zeros(shape, dtype=dtype, device=device)
+    key = torch.device(device)
+    ent = _ZERO_POOL.get(key)
+    step = (nbytes + 255) & ~255
+    if ent is None or ent[1] + step > _ZERO_POOL_BYTES:
+        ent = _ZERO_POOL[key] = [torch.zeros(_ZERO_POOL_BYTES, dtype=torch.uint8, device=device), 0]
+    off = ent[1]
+    ent[1] = off + step
+    return ent[0][off:off + nbytes].view(dtype).view(shape)
+
+
+def zeros_like_small(t):
+    return zeros_small(tuple(t.shape), t.dtype, t.device)
+
+
 # Batch-norm statistics taken in the producing convolution's epilogue (csrc/conv_v2.h sg_conv_epilogue `stats`): the convolution offers them,
 # the batch norm that runs as the VERY NEXT operator on exactly that tensor takes them (its statistics pass over the activation is then one
 # small reduction over per-tile sums). _SEQ counts convolution / batch-norm forwards; an offer is only good for the operator right behind it.
@@ -292,4 +323,4 @@ def gemm_dgrad_rows(w_ptr, dy, dx, B, K, O):
     return dx
 
 
-__all__ = ['L', '_BN_FUSED_STATS', '_CBN_MERGED', '_DGRAD_SPLITK', '_SEQ', '_STATS_OFFER', '_c', '_comm', '_first_order_only', '_offer_stats', '_param_grad_wanted', '_take_stats', '_tick', 'conv2d_q_raw', 'conv2d_q_wgrad_raw', 'conv2d_raw', 'conv2d_skip_raw', 'conv2d_wgrad_raw', 'dist', 'ensure_grad', 'f32_mode', 'gemm_dgrad_rows', 'gemm_raw', 'os', 'quad_pack_raw', 'torch']
+__all__ = ['L', 'zeros_small', 'zeros_like_small', '_BN_FUSED_STATS', '_CBN_MERGED', '_DGRAD_SPLITK', '_SEQ', '_STATS_OFFER', '_c', '_comm', '_first_order_only', '_offer_stats', '_param_grad_wanted', '_take_stats', '_tick', 'conv2d_q_raw', 'conv2d_q_wgrad_raw', 'conv2d_raw', 'conv2d_skip_raw', 'conv2d_wgrad_raw', 'dist', 'ensure_grad', 'f32_mode', 'gemm_dgrad_rows', 'gemm_raw', 'os', 'quad_pack_raw', 'torch']

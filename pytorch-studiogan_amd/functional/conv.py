@@ -696,6 +696,10 @@ def cbn_prefetch(slot, pairs):
     ok = [(m, y) for (m, y) in pairs if m.gain.bias is None and m.bias.bias is None and m.gain.__dict__.get("_sg_rt") is not None]
     if len(ok) < 2:
         return
+    if ok[0][0].gain._sg_rt.bank().exchange is not None:
+        # early gradient exchange (optim.ExchangePlan, SG_EARLY_EXCHANGE=1): a block's arena range is sent when the backward leaves the block, and the grouped
+        # function's backward -- all layers at once -- only runs when the LAST conditional batch norm has delivered its gradient: the layers keep their own launches
+        return
     ys, yidx = [], []
     for _, y in ok:
         for j, t in enumerate(ys):

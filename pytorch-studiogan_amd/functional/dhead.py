@@ -82,7 +82,7 @@ class PDHeadFn(torch.autograd.Function):
         dadv = _c(dadv.float())
         dh = torch.empty_like(h)
         train_w = ctx.needs_input_grad[1]
-        dw1_dummy = None if train_w else torch.zeros(Cc, dtype=torch.float32, device=h.device)   # kept alive until after the launch
+        dw1_dummy = None if train_w else zeros_small(Cc, torch.float32, h.device)   # kept alive until after the launch
         dw1 = bank.dwt(slot, rt_lin) if train_w else L.ptr(dw1_dummy)
         db1 = L.ptr(ensure_grad(ctx.b1)) if (ctx.b1 is not None and train_w) else None
         demb = torch.empty_like(emb) if emb is not None else None
@@ -104,8 +104,8 @@ class PDHeadBwdFn(torch.autograd.Function):
         Cc = rt_lin.cols
         dev = dadv.device
         dh = torch.empty((B, Cc), dtype=torch.float32, device=dev)
-        scratch = torch.zeros(Cc + 1, dtype=torch.float32, device=dev)
-        hz = torch.zeros((B, Cc), dtype=torch.float32, device=dev)
+        scratch = zeros_small(Cc + 1, torch.float32, dev)
+        hz = zeros_small((B, Cc), torch.float32, dev)
         demb = torch.empty((B, Cc), dtype=torch.float32, device=dev) if emb is not None else None
         L.call("sg_pd_head_bwd", L.ptr(hz), bank.w_f32(slot, rt_lin), L.ptr(emb), L.ptr(dadv), L.ptr(dh), L.ptr(scratch), None, L.ptr(demb), B, Cc, L.stream())
         ctx.save_for_backward(dadv, emb, labels)
@@ -125,7 +125,7 @@ class PDHeadBwdFn(torch.autograd.Function):
             g_dadv = torch.empty(B, dtype=torch.float32, device=dev)
             L.call("sg_pd_head_fwd", L.ptr(ddh), bank.w_f32(slot, rt_lin), None, L.ptr(emb), L.ptr(g_dadv), B, Cc, L.stream())
         if ctx.needs_input_grad[1] or ctx.needs_input_grad[2]:
-            dw1_dummy = None if ctx.needs_input_grad[1] else torch.zeros(Cc, dtype=torch.float32, device=dev)   # kept alive until after the launch
+            dw1_dummy = None if ctx.needs_input_grad[1] else zeros_small(Cc, torch.float32, dev)   # kept alive until after the launch
             dw1 = bank.dwt(slot, rt_lin) if ctx.needs_input_grad[1] else L.ptr(dw1_dummy)
             demb = torch.empty((B, Cc), dtype=torch.float32, device=dev) if emb is not None else None
             scratch = torch.empty((B, Cc), dtype=torch.float32, device=dev)

@@ -61,7 +61,7 @@ class BNFn(torch.autograd.Function):
             if pp is not None:
                 # sync-BN with the exchange FUSED INTO the finalize kernel: this rank's partial sums go straight into every peer's HBM (csrc/p2p.hip), the same
                 # launch waits for the peers' and writes mean / invstd / running statistics of the global batch
-                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                partial = zeros_small(2 * Cc, torch.float64, dev)
                 if fused is not None:
                     L.call("sg_bn_stats_from_tiles", fused[0].data_ptr(), fused[1], Cc, L.ptr(partial), L.stream())
                 else:
@@ -70,7 +70,7 @@ class BNFn(torch.autograd.Function):
                 with _comm.exposed():
                     L.call("sg_bn_finalize_p2p", pp.handle, L.ptr(partial), count, Cc, cfg.eps, cfg.momentum, L.ptr(mean), L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
             elif fused is not None:
-                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                partial = zeros_small(2 * Cc, torch.float64, dev)
                 L.call("sg_bn_stats_from_tiles", fused[0].data_ptr(), fused[1], Cc, L.ptr(partial), L.stream())
                 if ws > 1:
                     _allreduce_sum(partial, cfg.group)
@@ -83,7 +83,7 @@ class BNFn(torch.autograd.Function):
                        L.ptr(invstd), L.ptr(rm), L.ptr(rv), L.stream())
                 count *= ws
             else:
-                partial = torch.zeros(2 * Cc, dtype=torch.float64, device=dev)
+                partial = zeros_small(2 * Cc, torch.float64, dev)
                 L.call("sg_bn_partial_stats", L.dt(x), L.ptr(x), Cc, N * HW, Cc, L.ptr(partial), L.stream())
                 if ws > 1:
                     dist.all_reduce(partial, group=None if cfg.group is True else cfg.group)
@@ -128,13 +128,13 @@ class BNFn(torch.autograd.Function):
         skip_dx = ctx.link.take() if ctx.link is not None else None     # the skip path's gradient w.r.t. this same input (GradLink)
         if skip_dx is not None and not ctx.needs_input_grad[0]:
             raise RuntimeError("GradLink: a skip gradient was handed over but this batch norm's input needs no gradient")
-        sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
+        sums = zeros_small((N, Cc, 2), torch.float32, dev)
         bptr = (L.ptr(gain) + 4 * Cc) if cfg.packed else L.ptr(bias)       # packed cBN rows: [gain(C) | bias(C)], pitch gsn = 2 C
         L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, HW, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), bptr, gsn,
                1 if cfg.relu else 0, L.ptr(sums), L.stream())
         chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
-        dgain = torch.zeros_like(gain) if (gain is not None and ctx.needs_input_grad[1]) else None
-        dbias = torch.zeros_like(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dgain = zeros_like_small(gain) if (gain is not None and ctx.needs_input_grad[1]) else None
+        dbias = zeros_like_small(bias) if (bias is not None and ctx.needs_input_grad[2]) else None
         dbptr = ((L.ptr(dgain) + 4 * Cc) if dgain is not None else None) if cfg.packed else L.ptr(dbias)
         L.call("sg_bn_bwd_finalize", L.ptr(sums), N, Cc, L.ptr(gain), gsn, L.ptr(dgain), dbptr, L.ptr(chan), L.stream())
         dx = None
@@ -157,7 +157,7 @@ class BNBwdFn(torch.autograd.Function):
         dy = _c(dy)
         N, H, W, Cc = x.shape
         dev = x.device
-        sums = torch.zeros((N, Cc, 2), dtype=torch.float32, device=dev)
+        sums = zeros_small((N, Cc, 2), torch.float32, dev)
         L.call("sg_bn_bwd_reduce", L.dt(x), L.ptr(x), L.ptr(dy), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), 0,
                1 if cfg.relu else 0, L.ptr(sums), L.stream())
         chan = torch.empty(2 * Cc, dtype=torch.float64, device=dev)
@@ -179,7 +179,7 @@ class BNBwdFn(torch.autograd.Function):
         N, H, W, Cc = x.shape
         dev = x.device
         relu = 1 if cfg.relu else 0
-        sums = torch.zeros((N, Cc, 5), dtype=torch.float32, device=dev)
+        sums = zeros_small((N, Cc, 5), torch.float32, dev)
         L.call("sg_bn_bwd2_reduce", L.dt(x), L.ptr(x), L.ptr(dy), L.ptr(u), N, H * W, Cc, L.ptr(mean), L.ptr(invstd), L.ptr(gain), L.ptr(bias), relu,
                L.ptr(sums), L.stream())
         chan_local = torch.empty(5 * Cc, dtype=torch.float64, device=dev)
@@ -196,7 +196,7 @@ class BNBwdFn(torch.autograd.Function):
                    L.ptr(gain), L.ptr(bias), relu, L.ptr(chan), ctx.count, use_batch, L.stream())
         dgain = None
         if gain is not None and ctx.needs_input_grad[2]:
-            dgain = torch.zeros_like(gain)
+            dgain = zeros_like_small(gain)
             L.call("sg_bn_bwd2_dgain", L.ptr(chan_local), L.ptr(chan), ctx.count, L.ptr(invstd), Cc, use_batch, L.ptr(dgain), L.stream())
         return g_dy, g_x, dgain, None, None, None, None, None
 
