@@ -204,7 +204,7 @@ typedef struct { const float* w; const float* y; const float* bias; float* out; 
 int sg_linear_group(const sg_linear_item* items_dev, const sg_linear_item* items_host, int n, int B, sg_stream_t stream);
 
 /* ---- layout / elementwise ------------------------------------------------------------------------------ */
-/* fp32 NCHW -> T NHWC (ldo = channel pitch of the destination) */
+/* fp32 NCHW -> T NHWC (ldo = channel pitch of the destination; ldo > C: channels C .. ldo - 1 of every row are written as zeros) */
 int sg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int ldo, sg_stream_t s);
 /* T NHWC -> fp32 NCHW, optional tanh */
 int sg_nhwc_to_nchw(int dtype, const void* src, float* dst, int N, int C, int H, int W, int lds, int apply_tanh, sg_stream_t s);

@@ -163,17 +163,18 @@ class Generator(nn.Module):
         act = ops.block_boundary(self, -1, act)
         counter = 0
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
-        for bi, blocklist in enumerate(self.blocks):
-            for block in blocklist:
-                if isinstance(block, ops.SelfAttention):
-                    act = block.forward_nhwc(act, slot)
-                else:
-                    act = block.forward_nhwc(act, affines[counter], slot)
-                    counter += 1
-            if nxt is not None:
-                act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
-            act = ops.block_boundary(self, bi, act)
-        act = self.bn4.forward_nhwc(act, relu=True)
+        with ops.bump_batches_tracked(self):      # (every batch norm of the network runs once below: their counters move in one launch)
+            for bi, blocklist in enumerate(self.blocks):
+                for block in blocklist:
+                    if isinstance(block, ops.SelfAttention):
+                        act = block.forward_nhwc(act, slot)
+                    else:
+                        act = block.forward_nhwc(act, affines[counter], slot)
+                        counter += 1
+                if nxt is not None:
+                    act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
+                act = ops.block_boundary(self, bi, act)
+            act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)
 

@@ -133,18 +133,37 @@ class BufferArena:
         self.data = torch.zeros(max(total, 4), device=dev, dtype=torch.float32)
         self.numel = total
         self.bufs = [b for _, b in bufs]
+        # the int64 buffers (BatchNorm's num_batches_tracked) side by side as well: the EMA twin copies them in one launch and a generator forward bumps all of
+        # them in one launch (ops.bump_batches_tracked) instead of one tiny kernel per batch norm -- 44 launches per BigGAN-128 step
+        ib = [(n, b) for n, b in named_buffers if b is not None and b.dtype == torch.int64]
+        self.inames = [n for n, _ in ib]
+        self.ibufs = [b for _, b in ib]
+        self.ioffsets, itotal = [], 0
+        for b in self.ibufs:
+            self.ioffsets.append(itotal)
+            itotal += b.numel()
+        self.idata = torch.zeros(max(itotal, 1), device=dev, dtype=torch.int64)
+        self.inumel = itotal
         with torch.no_grad():
             for b, o in zip(self.bufs, self.offsets):
                 view = self.data[o:o + b.numel()].view(b.shape)
                 view.copy_(b)
                 b.set_(view)  # in place: the module's registered buffer object now aliases the arena
+            for b, o in zip(self.ibufs, self.ioffsets):
+                view = self.idata[o:o + b.numel()].view(b.shape)
+                view.copy_(b)
+                b.set_(view)
 
     def intact(self, root):
         bufs = [b for _, b in root.named_buffers() if b is not None and b.dtype == torch.float32]
         if len(bufs) != len(self.bufs):
             return False
         base = self.data.data_ptr()
-        return all(b.data_ptr() == base + 4 * o for b, o in zip(bufs, self.offsets))
+        if not all(b.data_ptr() == base + 4 * o for b, o in zip(bufs, self.offsets)):
+            return False
+        ib = [b for _, b in root.named_buffers() if b is not None and b.dtype == torch.int64]
+        ibase = self.idata.data_ptr()
+        return len(ib) == len(self.ibufs) and all(b.data_ptr() == ibase + 8 * o for b, o in zip(ib, self.ioffsets))
 
 
 def get_buffer_arena(root):

@@ -24,9 +24,33 @@ template <typename T> __global__ void k_nchw_to_nhwc(const float* src, T* dst, i
     dst[((long long)n * HW + hw) * ldo + c] = from_f<T>(src[i]);
   }
 }
+// padded rows (ldo > C: the RGB image as 8-channel pixels): a thread owns one PIXEL -- C coalesced plane reads, one contiguous row store that carries the zero
+// padding, so the destination needs no fill launch in front (round 6: the scattered 2-byte stores + the fill were 54 us per image batch, seven times per C3 step)
+template <typename T> __global__ void k_nchw_to_nhwc_pad(const float* src, T* dst, int N, int C, int HW, int ldo) {
+  const long long total = (long long)N * HW;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < total; i += (long long)gridDim.x * blockDim.x) {
+    const int hw = (int)(i % HW); const long long n = i / HW;
+    const float* sp = src + n * C * HW + hw;
+    T* dp = dst + i * ldo;
+    if (sizeof(T) == 2 && ldo == 8 && C <= 8) {
+      float v[8];
+#pragma unroll
+      for (int c = 0; c < 8; c++) v[c] = c < C ? sp[(long long)c * HW] : 0.f;
+      u32x4 o = {pack2bf(v[0], v[1]), pack2bf(v[2], v[3]), pack2bf(v[4], v[5]), pack2bf(v[6], v[7])};
+      *(u32x4*)dp = o;
+    } else {
+      for (int c = 0; c < ldo; c++) dp[c] = from_f<T>(c < C ? sp[(long long)c * HW] : 0.f);
+    }
+  }
+}
 extern "C" int sg_nchw_to_nhwc(int dtype, const float* src, void* dst, int N, int C, int H, int W, int ldo, sg_stream_t s) {
-  SG_CHECK(src && dst, "sg_nchw_to_nhwc: null");
+  SG_CHECK(src && dst && ldo >= C, "sg_nchw_to_nhwc: null / ldo < C");
   long long total = (long long)N * C * H * W;
+  if (ldo > C) {      // every one of the ldo channels of a row is written (zeros behind C)
+    DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_to_nhwc_pad<T>, dim3(nblk((long long)N * H * W, 256)), dim3(256), 0, (hipStream_t)s, src, (T*)dst, N, C, H * W, ldo));
+    SG_LAUNCH_CHECK();
+    return 0;
+  }
   DISPATCH_T(dtype, hipLaunchKernelGGL(k_nchw_to_nhwc<T>, dim3(nblk(total, 256)), dim3(256), 0, (hipStream_t)s, src, (T*)dst, N, C, H * W, ldo));
   SG_LAUNCH_CHECK();
   return 0;

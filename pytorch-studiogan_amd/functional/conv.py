@@ -177,7 +177,7 @@ class ConvFn(torch.autograd.Function):
             res = _c(res)
         bias_k = bias
         if bias is not None and rt.rows_pad != rt.rows:      # padded output channels: the epilogue reads rows_pad bias entries
-            bias_k = torch.zeros(rt.rows_pad, dtype=torch.float32, device=x.device)
+            bias_k = zeros_small(rt.rows_pad, torch.float32, x.device)
             bias_k[:rt.rows].copy_(bias.detach())
         _tick()
         y = _conv_fwd(x, rt, slot, cfg, bias_k, res, stats=cfg.stats)
@@ -294,7 +294,7 @@ class ConvSkipFn(torch.autograd.Function):
         want0 = ctx.b0 is not None and ctx.needs_input_grad[5]
         shared_db = None
         if want2 and want0 and ctx.needs_input_grad[2] and ctx.needs_input_grad[4] and rt2.rows_pad == rt2.rows and rt0.rows == rt2.rows:
-            shared_db = torch.zeros(rt2.rows, dtype=torch.float32, device=dy.device)
+            shared_db = zeros_small(rt2.rows, torch.float32, dy.device)
         for inp, rt, cfg, w_i, b_i, wp, bp in ((h, rt2, cfg2, 2, 3, ctx.w2, ctx.b2), (x, rt0, cfg0, 4, 5, ctx.w0, ctx.b0)):
             k = 0 if inp is h else 1
             N, Hs, Ws, Cin = inp.shape

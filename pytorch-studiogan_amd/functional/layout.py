@@ -13,7 +13,7 @@ class NchwToNhwcFn(torch.autograd.Function):
         x = _c(x)
         N, Cc, H, W = x.shape
         ld = max(cpad, Cc)
-        y = (torch.zeros if ld > Cc else torch.empty)((N, H, W, ld), dtype=dtype, device=x.device)
+        y = torch.empty((N, H, W, ld), dtype=dtype, device=x.device)      # (sg_nchw_to_nhwc writes the zero padding of ld > C rows itself)
         L.call("sg_nchw_to_nhwc", L.dt(dtype), L.ptr(x), L.ptr(y), N, Cc, H, W, ld, L.stream())
         ctx.channels = Cc
         return y

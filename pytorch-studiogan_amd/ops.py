@@ -207,6 +207,43 @@ class Embedding(_WeightLayerMixin, nn.Embedding):
         return F.SNEmbeddingFn.apply(self.weight_orig, idx.reshape(-1), rt, slot).reshape(*idx.shape, self.embedding_dim)
 
 
+_NBT_BULK = [False]      # True while a network forward runs whose batch norms' num_batches_tracked were bumped in one launch (bump_batches_tracked)
+
+
+class bump_batches_tracked:
+    """with bump_batches_tracked(network): every BatchNorm2d of `network` is about to run exactly once in training mode with tracked statistics (a generator
+    forward): their num_batches_tracked buffers -- adjacent int64 words of the network's buffer arena -- take their + 1 in ONE launch, and the modules skip their
+    own. Anything else (a frozen or non-tracking batch norm, an arena that .to() / deepcopy replaced, foreign int64 buffers) leaves the per-module increments on."""
+
+    def __init__(self, root):
+        self.on = False
+        bns = root.__dict__.get("_sg_bn_list")
+        if bns is None:
+            bns = [m for m in root.modules() if isinstance(m, BatchNorm2d)]
+            root.__dict__["_sg_bn_list"] = bns
+        if not bns or _NBT_BULK[0]:
+            return
+        for m in bns:
+            if not (m.training and m.track_running_stats and m.running_mean is not None and m.num_batches_tracked is not None):
+                return
+        from .bank import get_buffer_arena
+        ar = get_buffer_arena(root)
+        if ar.inumel != len(bns) or any(b is not m.num_batches_tracked for b, m in zip(ar.ibufs, bns)):
+            return
+        with torch.no_grad():
+            ar.idata.add_(1)
+        self.on = True
+
+    def __enter__(self):
+        if self.on:
+            _NBT_BULK[0] = True
+        return self
+
+    def __exit__(self, *a):
+        if self.on:
+            _NBT_BULK[0] = False
+
+
 class BatchNorm2d(nn.BatchNorm2d):
     """nn.BatchNorm2d(eps=1e-4, momentum=0.1) semantics (reference src/utils/ops.py:227-228) incl. the
     track_running_stats toggling the driver does (reference src/utils/misc.py:239-267)."""
@@ -223,7 +260,7 @@ class BatchNorm2d(nn.BatchNorm2d):
     def forward_nhwc(self, x, gain=None, bias=None, relu=False, link=None, packed=False):
         cfg = self._cfg(relu)
         cfg.packed = packed
-        if cfg.track and self.num_batches_tracked is not None:
+        if cfg.track and self.num_batches_tracked is not None and not _NBT_BULK[0]:
             self.num_batches_tracked.add_(1)
         if gain is None and self.affine:
             gain, bias = self.weight, self.bias

@@ -484,9 +484,16 @@ class Ema:
         sb, tb = self._buffers()
         if sb.numel:
             L.call("sg_ema_lerp", sb.data.data_ptr(), tb.data.data_ptr(), sb.numel, decay, L.stream())
+        if sb.inames == tb.inames and sb.inumel == tb.inumel:
+            if sb.inumel:
+                tb.idata.copy_(sb.idata)  # every num_batches_tracked at once
+        else:
+            for (n_t, b_t), (n_s, b_s) in zip(self.target.named_buffers(), self.source.named_buffers()):
+                if b_t.dtype == torch.int64:
+                    b_t.copy_(b_s)  # num_batches_tracked
         for (n_t, b_t), (n_s, b_s) in zip(self.target.named_buffers(), self.source.named_buffers()):
-            if b_t.dtype != torch.float32:
-                b_t.copy_(b_s)  # num_batches_tracked
+            if b_t.dtype not in (torch.float32, torch.int64):
+                b_t.copy_(b_s)
 
     @torch.no_grad()
     def update(self, iter=None):

@@ -108,6 +108,43 @@ def test_emulated_grouped_cbn_affine_equals_per_layer():
         assert torch.allclose(a[2][k], b[2][k], rtol=0, atol=2e-4 * b[2][k].abs().max().item() + 1e-12), k
 
 
+def test_emulated_batch_norm_counters_in_one_launch():
+    """ops.bump_batches_tracked: a generator forward in training mode moves every BatchNorm2d.num_batches_tracked by one (one add over the int64 words of the
+    buffer arena); with one batch norm frozen the modules fall back to their own increments and the frozen one stays; the EMA twin's buffer update copies them"""
+    import copy
+    import fullemu
+    import test_model_gpu as TM
+    from util import load_golden, sub
+    from studiogan_amd import ops, optim
+    dev = torch.device("cpu")
+    fix, meta = load_golden("biggan32")
+    ins = {k: v.to(dev) for k, v in sub(fix, "in/").items()}
+    with fullemu.Installed(dma_late=1, greedy=1, seed=4):
+        G, _ = TM.build_from_yaml(meta["yaml"], False, dev)
+        G.load_state_dict({k: v.to(dev) for k, v in sub(fix, "G_init/").items()}, strict=True)
+        G.train()
+        bns = [m for m in G.modules() if isinstance(m, ops.BatchNorm2d)]
+        assert len(bns) >= 7
+        base = [int(m.num_batches_tracked) for m in bns]
+        with torch.no_grad():
+            G(ins["z0"], ins["fl0"])
+            G(ins["z0"], ins["fl0"])
+        assert [int(m.num_batches_tracked) for m in bns] == [b + 2 for b in base]
+        assert not ops._NBT_BULK[0]
+        bns[2].eval()
+        with torch.no_grad():
+            G(ins["z0"], ins["fl0"])
+        assert [int(m.num_batches_tracked) for m in bns] == [b + (2 if i == 2 else 3) for i, b in enumerate(base)]
+        bns[2].train()
+        Ge = copy.deepcopy(G)
+        with torch.no_grad():
+            G(ins["z0"], ins["fl0"])
+        ema = optim.Ema(G, Ge, 0.9, 0)
+        ema.update_buffers(0.9)
+        assert [int(m.num_batches_tracked) for m in Ge.modules() if isinstance(m, ops.BatchNorm2d)] == [int(m.num_batches_tracked) for m in bns]
+        assert sorted(G.state_dict().keys()) == sorted(Ge.state_dict().keys())
+
+
 def test_emulated_frozen_network_weight_image_cache():
     """bank.WeightBank.begin_forward keeps the emitted weight images of a frozen network (eval mode, no graph: the evaluation generator of the FID
     loop) until something writes its parameters: hits give bit-identical images, a torch-side write (in-place op, load_state_dict), a raw-pointer
