@@ -139,20 +139,31 @@ class Generator(nn.Module):
         if len(affine_list) > 0:
             z = torch.cat(affine_list + [z], 1)
         affine = z
+        # every conditional batch norm's [1 + gain(y) | bias(y)] rows in ONE launch (functional.cbn_prefetch): BigGAN-deep conditions all of them -- four per block --
+        # on the same vector
+        pairs = []
+        for blocklist in self.blocks:
+            for block in blocklist:
+                if not isinstance(block, ops.SelfAttention):
+                    for bn in (block.bn1, block.bn2, block.bn3, block.bn4):
+                        if isinstance(bn, ops.ConditionalBatchNorm2d):
+                            pairs.append((bn, affine))
+        F.cbn_prefetch(slot, pairs)
         act = self.linear0.forward_rt(z, slot)
         act = F.NchwToNhwcFn.apply(act.view(-1, self.in_dims[0], self.bottom, self.bottom), dtype)
         act = ops.block_boundary(self, -1, act)
         nxt = bank.boundaries(self.blocks) if bank.exchange is not None else None
-        for bi, blocklist in enumerate(self.blocks):
-            for block in blocklist:
-                if isinstance(block, ops.SelfAttention):
-                    act = block.forward_nhwc(act, slot)
-                else:
-                    act = block.forward_nhwc(act, affine, slot)
-            if nxt is not None:
-                act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
-            act = ops.block_boundary(self, bi, act)
-        act = self.bn4.forward_nhwc(act, relu=True)
+        with ops.bump_batches_tracked(self):      # (every batch norm of the network runs once below: their counters move in one launch)
+            for bi, blocklist in enumerate(self.blocks):
+                for block in blocklist:
+                    if isinstance(block, ops.SelfAttention):
+                        act = block.forward_nhwc(act, slot)
+                    else:
+                        act = block.forward_nhwc(act, affine, slot)
+                if nxt is not None:
+                    act = bank.mark(act, nxt[bi])      # data parallelism: the backward's return to this point releases the gradients behind it
+                act = ops.block_boundary(self, bi, act)
+            act = self.bn4.forward_nhwc(act, relu=True)
         act = self.conv2d5.forward_nhwc(act, slot)
         return F.NhwcToNchwFn.apply(act, True, 3)
 

@@ -56,6 +56,7 @@ def main():
         F.quad_pack_raw(wd.data_ptr(), qd, 2 if pool else 3, Cin, Cout)
         dw = torch.zeros(Cout, 9, Cin, device=dev)
         relu = pool      # D tails read relu(h); G heads read the BN output (ReLU fused upstream)
+        use_mask = relu and os.environ.get("SG_QB_NOMASK") != "1"      # SG_QB_NOMASK=1: the data gradient without its ReLU-mask operand (what the mask tile costs)
         pf = (L.PIX_RELU if relu else 0) | (0 if pool else L.PIX_UPSAMPLE)
         ef = L.EPI_POOL if pool else 0
         qform, dform = (L.Q_POOL, L.Q_UP) if pool else (L.Q_UP, L.Q_POOL)
@@ -63,8 +64,8 @@ def main():
         f0 = timeit(lambda: F.conv2d_raw(x, w.data_ptr(), Cin, Cout, 3, 3, 1, 1, 1, pf, ef, bias=bias, alpha=0.25 if pool else 1.0))
         f1 = timeit(lambda: F.conv2d_q_raw(x, qf.data_ptr(), qform, Cin, Cout, L.PIX_RELU if relu else 0, 0, bias=bias))
         d0 = timeit(lambda: F.conv2d_raw(gy, wd.data_ptr(), Cout, Cin, 3, 3, 1, 1, 1, L.PIX_UPSAMPLE if pool else 0, 0 if pool else L.EPI_POOL,
-                                         mask=x if relu else None, alpha=0.25 if pool else 1.0))
-        d1 = timeit(lambda: F.conv2d_q_raw(gy, qd.data_ptr(), dform, Cout, Cin, 0, 0, mask=x if relu else None))
+                                         mask=x if use_mask else None, alpha=0.25 if pool else 1.0))
+        d1 = timeit(lambda: F.conv2d_q_raw(gy, qd.data_ptr(), dform, Cout, Cin, 0, 0, mask=x if use_mask else None))
         g0 = timeit(lambda: F.conv2d_wgrad_raw(x, gy, dw.data_ptr(), Cin, Cout, 3, 3, Hf, Hf, 1, 1, 1, pf, L.PIX_UPSAMPLE if pool else 0,
                                                alpha=0.25 if pool else 1.0))
         g1 = timeit(lambda: F.conv2d_q_wgrad_raw(x, gy, dw.data_ptr(), qform, Cin, Cout, L.PIX_RELU if relu else 0))
