@@ -778,6 +778,11 @@ def main():
                      "executed_frac": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12 / peak, 4) if conv_ms > 0 else None,
                      "frac_basis": "frac: algorithmic FLOPs of the reference's op graph (3x3 convolutions over the fine grid) / hipEvent time = SURVEY 8(d); "
                                    "executed_frac: MFMAs issued / the same time = matrix-pipe utilisation (quad launches execute 16/36 of the algorithmic MACs)",
+                     # what this chip sustains on the SAME loop with every memory operation removed (profiles/r06_conv_v4_ablation_u.txt, SG_V4_ABLATE=31: twelve waves per
+                     # CU issuing v_mfma_f32_32x32x16_bf16 from registers on real activations, no LDS reads, no DMA, no barrier, no epilogue): 1430-1620 TFLOP/s -- the
+                     # clocks the power limit leaves under sustained matrix load. A measured context figure, never the denominator of frac.
+                     "mfma_only_loop_tflops_measured": [1430, 1620],
+                     "executed_frac_of_mfma_only_loop": round(conv_exec_flop / (conv_ms * 1e-3) / 1e12 / 1525.0, 4) if conv_ms > 0 else None,
                      "dominant_kernel": dominant,
                      "traffic": traffic, "traffic_unit": "HBM bytes per launch", "traffic_source": traffic_src,
                      "pmc_csrc_sha16": pmc_sha, "csrc_sha16": cur_sha,
