@@ -376,8 +376,13 @@ __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int
 // LDS per block keeps the occupancy of a streaming kernel (a first version staged whole rows: 55 KB, two blocks per CU, SLOWER than
 // the kernels it replaced -- session J). Natural-layout weights (linear, embedding) take the same walk without the staging.
 // Transposed-convolution weights and RS > 16 stay with the old kernels.
+#ifndef SNB_CW
 #define SNB_CW 128
-#define SNB_ST 136                                               // 128 + 8: pitch = 8 (mod 32)
+#endif
+#ifndef SNB_ST
+#define SNB_ST (SNB_CW + 8)
+#endif
+// (SNB_ST = chunk + 8 floats: pitch = 8 (mod 32))
 __host__ __device__ __forceinline__ bool snb_row_ok(const sg_sn_bwd_layer& l) {
   if (l.trans) return false;
   if (l.natural == 1) return true;
@@ -440,7 +445,7 @@ template <bool APPLY> __global__ __launch_bounds__(256) void k_snb_rows(const sg
         int rs = rs2_init, c = c2_init;
         for (int j = j_init; j < RS * SNB_CW; j += 1024) {
           if (c < cw) *(f32x4*)(tile + rs * SNB_ST + c) = *(const f32x4*)(grow + (long long)rs * cp + c);
-          rs += 8;                                               // 1024 / SNB_CW
+          rs += 1024 / SNB_CW;
         }
       }
       __syncthreads();
