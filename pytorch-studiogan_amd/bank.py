@@ -388,10 +388,9 @@ class WeightBank:
 
     # -- forward ------------------------------------------------------------------------------------------
     def _desc(self, slot, flags):
-        """-> (host table, device table, groups): the layers in table order = convolutions first, then linear / embedding layers; groups = [(first, count)] of
-        the two runs. sg_sn_forward sizes its launches by the largest layer of the table it is given: one [24576 x 20] linear layer (a generator's linear0) in
-        a table of [1536 x 13824] convolutions made k_sn_pack_dgrad a grid of 1.7 M workgroups, 97 % of them empty (869 us per generator forward, round 5:
-        tools/sn_bench.py) -- each kind gets its own call."""
+        """-> (host table, device table, groups): the layers in table order = convolutions first, then linear / embedding layers; groups = [(first, count)] = one run.
+        (Until round 6 sg_sn_forward sized its grids by the largest layer of the table, and a generator's [24576 x 20] linear0 next to [1536 x 13824] convolutions had to go
+        through a call of its own; the launches are flat tile tables now -- csrc/sn.hip sn_flat -- and every layer kind shares one call.)"""
         ent = slot.desc_cache.get(flags)
         if ent is not None:
             return ent
@@ -399,7 +398,6 @@ class WeightBank:
         arr = (L.SnLayer * n)()
         es = self.es
         order = [r for r in self.layers if r.kind == "conv"] + [r for r in self.layers if r.kind != "conv"]
-        nconv = sum(1 for r in self.layers if r.kind == "conv")
         pi_of = {r.index: pi for r, pi in zip(self.layers, flags)}
         for pos, r in enumerate(order):
             pi = pi_of[r.index]
@@ -422,13 +420,7 @@ class WeightBank:
             d.trans, d.dgrad_noflip = r.trans, r.noflip
             d.Cin_pad = r.cin_pad
         dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
-        groups = [g for g in ((0, nconv), (nconv, n - nconv)) if g[1] > 0]
-        if len(groups) == 2:
-            # (a second call costs ~30 us of launches: taken only when a linear / embedding layer would inflate the convolutions' grids -- BigGAN's generator;
-            # its discriminator's [1000 x 1536] embedding and [1 x 1536] linear sit inside the convolutions' extent and stay in their table)
-            cr, cc = max(r.rows for r in order[:nconv]), max(r.cols for r in order[:nconv])
-            if all(r.rows <= cr and r.cols <= cc for r in order[nconv:]):
-                groups = [(0, n)]
+        groups = [(0, n)]
         ent = (arr, dev_tab, groups)
         slot.desc_cache[flags] = ent
         return ent

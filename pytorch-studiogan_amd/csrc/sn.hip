@@ -21,17 +21,61 @@ template <class LAYER> __device__ __forceinline__ long long sn_widx(const LAYER&
   return ((long long)c * l.rows + o) * l.RS + rs;
 }
 
-// grid (col tiles of 1024, SN_SPLITS, layers): partial[split][k] = sum over the split's rows of W[o][k] u[o].
+// Flat work tables (round 6). The launches below used to be (tiles of the LARGEST layer) x layers: a table that holds [1536 x 13824] convolutions next to [96 x 864] ones, a
+// [24576 x 20] linear layer and a [1000 x 1536] embedding is mostly empty workgroups (and needed two calls to keep the linear layers from inflating the convolutions' grids).
+// Here every launch is a 1-D grid of exactly the tiles that exist: the host sums the per-layer tile counts into `start` (kernel argument by value, scalar loads), a workgroup
+// finds its layer by bisection.
+#define SN_MAXL 64
+struct sn_flat { int n; int start[SN_MAXL + 1]; };
+__device__ __forceinline__ int sn_find(const sn_flat& F, int b) {     // the layer li with start[li] <= b < start[li + 1] (empty layers have start[li] == start[li + 1])
+  int lo = 0, hi = F.n;
+  while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (b >= F.start[mid]) lo = mid; else hi = mid; }
+  return lo;
+}
+__host__ __device__ __forceinline__ bool sn_wtu_skinny(const sg_sn_layer& l) { return !l.trans && (l.cols & 3) == 0 && l.cols <= 64 && ((uintptr_t)l.w & 15) == 0; }
+
+// flat grid of (col tiles of 1024) x SN_SPLITS per power-iterating layer: partial[split][k] = sum over the split's rows of W[o][k] u[o].
 // A thread owns 4 adjacent columns (one 16-byte load per row, 4 KB contiguous per row and block) and keeps 8 rows in flight (16 measured SLOWER, 129 -> 153 us per launch, session r3n): the
 // one-float-per-thread column walk this replaces touched 1 KB per 55 KB row and ran at 0.35-0.95 TB/s (r01 kernel trace).
-__global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* work) {
-  const sg_sn_layer l = L[blockIdx.z];
+__global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* work, const sn_flat F) {
+  const int li = sn_find(F, blockIdx.x);
+  const sg_sn_layer l = L[li];
   if (!l.apply_sn || !l.do_power_iter) return;
+  const int tiles_x = (l.cols + 1023) >> 10, local = blockIdx.x - F.start[li];
+  const int by = local / tiles_x, bx = local - by * tiles_x;
   const int per = (l.rows + SN_SPLITS - 1) / SN_SPLITS;
-  int o0 = blockIdx.y * per, o1 = o0 + per; if (o1 > l.rows) o1 = l.rows;
-  float* out = work + l.work_off + (long long)blockIdx.y * l.cols;
+  int o0 = by * per, o1 = o0 + per; if (o1 > l.rows) o1 = l.rows;
+  float* out = work + l.work_off + (long long)by * l.cols;
+  if (sn_wtu_skinny(l)) {
+    // tall and skinny (BigGAN's linear0: 24576 x 20): the column-owner mapping below leaves 5 threads walking 1536 rows each -- 119 us for 2 MB (round 6 trace of
+    // tools/sn_bench.py). Here R = 256 / (cols / 4) threads share a column vector, each takes every R-th row of the split, and the R partial sums meet in LDS in
+    // lane order (fixed order: deterministic).
+    __shared__ f32x4 red[256];
+    const int c4 = l.cols >> 2, R = 256 / c4;
+    const int r = threadIdx.x / c4, k4 = threadIdx.x - r * c4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (r < R) {
+      const float* wp = l.w + 4 * k4;
+      int o = o0 + r;
+      for (; o + 3 * R < o1; o += 4 * R) {
+        const f32x4 w0 = *(const f32x4*)(wp + (long long)o * l.cols), w1 = *(const f32x4*)(wp + (long long)(o + R) * l.cols);
+        const f32x4 w2 = *(const f32x4*)(wp + (long long)(o + 2 * R) * l.cols), w3 = *(const f32x4*)(wp + (long long)(o + 3 * R) * l.cols);
+        const float u0 = l.u[o], u1 = l.u[o + R], u2 = l.u[o + 2 * R], u3 = l.u[o + 3 * R];
+        acc += w0 * u0; acc += w1 * u1; acc += w2 * u2; acc += w3 * u3;
+      }
+      for (; o < o1; o += R) acc += *(const f32x4*)(wp + (long long)o * l.cols) * l.u[o];
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    if (r == 0 && k4 < c4) {
+      f32x4 t = red[k4];
+      for (int q = 1; q < R; q++) t += red[q * c4 + k4];
+      out[4 * k4] = t[0]; out[4 * k4 + 1] = t[1]; out[4 * k4 + 2] = t[2]; out[4 * k4 + 3] = t[3];
+    }
+    return;
+  }
   if (!l.trans && (l.cols & 3) == 0 && ((uintptr_t)l.w & 15) == 0) {
-    const int k = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int k = (bx * 256 + threadIdx.x) * 4;
     if (k >= l.cols) return;
     const float* wp = l.w + k;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -50,7 +94,7 @@ __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* wor
     out[k] = acc[0]; out[k + 1] = acc[1]; out[k + 2] = acc[2]; out[k + 3] = acc[3];   // (work offsets are only 4-byte aligned)
     return;
   }
-  for (int k = blockIdx.x * 1024 + threadIdx.x; k < l.cols && k < (blockIdx.x + 1) * 1024; k += 256) {
+  for (int k = bx * 1024 + threadIdx.x; k < l.cols && k < (bx + 1) * 1024; k += 256) {
     float acc = 0.f;
     for (int o = o0; o < o1; o++) acc += l.w[sn_widx(l, o, k)] * l.u[o];
     out[k] = acc;
@@ -80,11 +124,12 @@ __global__ __launch_bounds__(256) void k_sn_v(const sg_sn_layer* L, float* work,
     for (int e = 0; e < 8; e++) { const int k = k0 + 256 * e; if (k < l.cols) l.v[k] = t[e] * inv; }
   }
 }
-// grid (row tiles of 4, layers): one wave per row, t_u[o] = W[o,:] . v
-__global__ __launch_bounds__(256) void k_sn_wv(const sg_sn_layer* L, float* work) {
-  const sg_sn_layer l = L[blockIdx.y];
+// flat grid of (row tiles of 4) per SN layer: one wave per row, t_u[o] = W[o,:] . v
+__global__ __launch_bounds__(256) void k_sn_wv(const sg_sn_layer* L, float* work, const sn_flat F) {
+  const int li = sn_find(F, blockIdx.x);
+  const sg_sn_layer l = L[li];
   if (!l.apply_sn) return;
-  const int o = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int o = (blockIdx.x - F.start[li]) * 4 + (threadIdx.x >> 6);
   if (o >= l.rows) return;
   const int lane = threadIdx.x & 63;
   float acc = 0.f;
@@ -114,12 +159,26 @@ __global__ __launch_bounds__(256) void k_sn_u(const sg_sn_layer* L, float* work,
   const float* tu = work + l.work_off + (long long)SN_SPLITS * l.cols;
   float sig;
   if (l.do_power_iter) {
+    // (eight loads in flight per thread: a 24576-row linear layer is 96 trips of this one block; one load per trip was most of the kernel's 67 us on the
+    // generator's linear table -- round 6 trace of tools/sn_bench.py. Same per-thread summation order.)
     float nn = 0.f;
-    for (int o = threadIdx.x; o < l.rows; o += 256) nn += tu[o] * tu[o];
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? tu[o] : 0.f; }
+#pragma unroll
+      for (int e = 0; e < 8; e++) nn += t[e] * t[e];
+    }
     nn = block_sum_256(nn, sm);
     const float inv = 1.f / fmaxf(sqrtf(nn), eps);
     float dot = 0.f;
-    for (int o = threadIdx.x; o < l.rows; o += 256) { const float un = tu[o] * inv; l.u[o] = un; dot += un * tu[o]; }
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? tu[o] : 0.f; }
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; if (o < l.rows) { const float un = t[e] * inv; l.u[o] = un; dot += un * t[e]; } }
+    }
     sig = block_sum_256(dot, sm);
   } else {
     float dot = 0.f;
@@ -127,7 +186,15 @@ __global__ __launch_bounds__(256) void k_sn_u(const sg_sn_layer* L, float* work,
     sig = block_sum_256(dot, sm);
   }
   if (threadIdx.x == 0) l.sigma[0] = sig;
-  if (l.u_snap) for (int o = threadIdx.x; o < l.rows; o += 256) l.u_snap[o] = l.u[o];
+  if (l.u_snap) {
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+      float t[8];
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? l.u[o] : 0.f; }
+#pragma unroll
+      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; if (o < l.rows) l.u_snap[o] = t[e]; }
+    }
+  }
   if (l.v_snap) {
     // eight loads in flight per thread: one load -> store per iteration (the two vectors may alias as far as the compiler knows) was 54
     // dependent round trips on a 13824-column layer, most of this kernel's 48 us
@@ -163,10 +230,12 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack(const sg_
 //  * k_sn_pack_rows: one block per weight row -> fp32 natural copy and the forward image [o][rs][c]; the [c][rs] -> [rs][c]
 //    shuffle of the row goes through LDS so both the read and the write are contiguous.
 //  * k_sn_pack_dgrad: 64(o) x 128(k) tiles transposed through LDS -> data-gradient image [c][rs'][o], 128-byte rows of o.
-template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(const sg_sn_layer* L) {
+template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(const sg_sn_layer* L, const sn_flat F) {
   extern __shared__ __attribute__((aligned(16))) char sn_raw[];
   T* row = (T*)sn_raw;
-  const sg_sn_layer l = L[blockIdx.y];
+  const int li = sn_find(F, blockIdx.x);
+  const sg_sn_layer l = L[li];
+  const int nblk = F.start[li + 1] - F.start[li];          // workgroups of this layer (<= 2048: rows beyond that are walked)
   const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;
   const float sig = l.sigma[0];
   const float inv = 1.f / sig;
@@ -175,7 +244,7 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(cons
   // the write side 8 outputs of one tap (cp % 8 == 0: eight consecutive image elements share their tap), gathered from the LDS row
   const bool vec = !l.trans && (l.cols % 4 == 0) && (cp % 8 == 0) && sizeof(T) == 2 && ((reinterpret_cast<uintptr_t>(l.w) & 15) == 0) &&
                    (!l.w_f32 || (reinterpret_cast<uintptr_t>(l.w_f32) & 15) == 0) && (!l.w_fwd || (reinterpret_cast<uintptr_t>(l.w_fwd) & 15) == 0);
-  for (int o = blockIdx.x; o < rows_out; o += gridDim.x) {
+  for (int o = blockIdx.x - F.start[li]; o < rows_out; o += nblk) {
     if (vec) {
       const float* src = l.w + (long long)o * l.cols;
       for (int k = threadIdx.x * 4; k < l.cols; k += 1024) {
@@ -231,14 +300,54 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_rows(cons
   }
   (void)inv;
 }
-template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(const sg_sn_layer* L) {
+// The data-gradient image of a layer whose forward image [o][rs][c] was just written by k_sn_pack_rows is a transposition of THAT image (the same bf16 values, 2 bytes
+// read per element instead of the master's 4, no division): `elem` = bytes per image element.
+__host__ __device__ __forceinline__ bool sn_dgrad_from_image(const sg_sn_layer& l, int elem) {
+  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows, cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin;
+  return elem == 2 && l.w_fwd && !l.trans && (rows_out % 8 == 0) && (cp % 8 == 0) && ((reinterpret_cast<uintptr_t>(l.w_fwd) & 15) == 0) &&
+         ((reinterpret_cast<uintptr_t>(l.w_dgrad) & 15) == 0);
+}
+__host__ __device__ __forceinline__ int sn_dgrad_extent(const sg_sn_layer& l, int elem) {      // columns the 128-wide tiles of a layer walk
+  return sn_dgrad_from_image(l, elem) ? l.RS * (l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin) : l.cols;
+}
+template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(const sg_sn_layer* L, const sn_flat F) {
   __shared__ T tile[64][130];
-  const sg_sn_layer l = L[blockIdx.z];
+  const int li = sn_find(F, blockIdx.x);
+  const sg_sn_layer l = L[li];
   if (!l.w_dgrad) return;
-  const int o0 = blockIdx.y * 64, k0 = blockIdx.x * 128;
+  const bool img = sn_dgrad_from_image(l, (int)sizeof(T));
+  const int tiles_k = (sn_dgrad_extent(l, (int)sizeof(T)) + 127) >> 7, local = blockIdx.x - F.start[li];
+  const int by = local / tiles_k, bx = local - by * tiles_k;
+  const int o0 = by * 64, k0 = bx * 128;
+  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;    // pitch of the image; columns >= rows stay zero
+  if (img) {      // (tiles over rows_out: the zero rows of the forward image's padding become the zero columns of this one)
+    const int cp = l.Cin_pad > l.Cin ? l.Cin_pad : l.Cin, colsp = l.RS * cp;
+    for (int e = threadIdx.x; e < 64 * 16; e += 256) {
+      const int oo = e >> 4, jj = (e & 15) * 8, o = o0 + oo, j = k0 + jj;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (o < rows_out && j < colsp) v = *(const u32x4*)((const bf16_t*)l.w_fwd + (long long)o * colsp + j);
+      uint32_t* tp = (uint32_t*)&tile[oo][jj];
+      tp[0] = v[0]; tp[1] = v[1]; tp[2] = v[2]; tp[3] = v[3];
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < 8 * 128; e += 256) {
+      const int og = e & 7, jj = e >> 3, o = o0 + og * 8, j = k0 + jj;
+      if (j < colsp && o < rows_out) {
+        const int rs = j / cp, c = j - rs * cp;
+        if (c < l.Cin) {
+          const bf16_t* tp = (const bf16_t*)&tile[0][0];
+          uint32_t w4[4];
+#pragma unroll
+          for (int i = 0; i < 4; i++) w4[i] = (uint32_t)tp[(og * 8 + 2 * i) * 130 + jj] | ((uint32_t)tp[(og * 8 + 2 * i + 1) * 130 + jj] << 16);
+          u32x4 v = {w4[0], w4[1], w4[2], w4[3]};
+          *(u32x4*)((bf16_t*)l.w_dgrad + ((long long)c * l.RS + (l.dgrad_noflip ? rs : (l.RS - 1 - rs))) * rows_out + o) = v;
+        }
+      }
+    }
+    return;
+  }
   if (o0 >= l.rows || k0 >= l.cols) return;
   const float sig = l.sigma[0];
-  const int rows_out = l.rows_pad > l.rows ? l.rows_pad : l.rows;    // pitch of the image; columns >= rows stay zero
   // fast path (round 2): 16-byte accesses on both sides -- 4 fp32 per lane in, 8 couts of one (c, tap) row per lane out
   const bool vec = sizeof(T) == 2 && !l.trans && (l.cols % 4 == 0) && (rows_out % 8 == 0) && ((reinterpret_cast<uintptr_t>(l.w) & 15) == 0) &&
                    ((reinterpret_cast<uintptr_t>(l.w_dgrad) & 15) == 0);
@@ -289,18 +398,18 @@ template <typename T> __global__ __launch_bounds__(256) void k_sn_pack_dgrad(con
   }
 }
 template <typename T> static void sn_pack_launch(const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, int max_rows_out, int max_rows, int max_cols, long long max_elems, hipStream_t st) {
-  bool any_dg = false;
-  int dg_rows = 1, dg_cols = 1;      // the data-gradient images' launch is sized by the layers that HAVE one
-  for (int i = 0; i < n; i++)
-    if (layers_host[i].w_dgrad) {
-      any_dg = true;
-      if (layers_host[i].rows > dg_rows) dg_rows = layers_host[i].rows;
-      if (layers_host[i].cols > dg_cols) dg_cols = layers_host[i].cols;
-    }
   if ((size_t)max_cols * sizeof(T) <= 60 * 1024) {
-    int gx = max_rows_out; if (gx > 2048) gx = 2048;
-    hipLaunchKernelGGL(k_sn_pack_rows<T>, dim3(gx, n), dim3(256), (size_t)max_cols * sizeof(T), st, layers_dev);
-    if (any_dg) hipLaunchKernelGGL(k_sn_pack_dgrad<T>, dim3((dg_cols + 127) / 128, (dg_rows + 63) / 64, n), dim3(256), 0, st, layers_dev);
+    sn_flat Fr, Fd;
+    Fr.n = Fd.n = n; Fr.start[0] = Fd.start[0] = 0;
+    for (int i = 0; i < n; i++) {
+      const sg_sn_layer& l = layers_host[i];
+      const int ro = l.rows_pad > l.rows ? l.rows_pad : l.rows;
+      Fr.start[i + 1] = Fr.start[i] + (ro > 2048 ? 2048 : ro);
+      const bool img = sn_dgrad_from_image(l, (int)sizeof(T));
+      Fd.start[i + 1] = Fd.start[i] + (l.w_dgrad ? ((sn_dgrad_extent(l, (int)sizeof(T)) + 127) / 128) * (((img ? ro : l.rows) + 63) / 64) : 0);
+    }
+    hipLaunchKernelGGL(k_sn_pack_rows<T>, dim3(Fr.start[n]), dim3(256), (size_t)max_cols * sizeof(T), st, layers_dev, Fr);
+    if (Fd.start[n] > 0) hipLaunchKernelGGL(k_sn_pack_dgrad<T>, dim3(Fd.start[n]), dim3(256), 0, st, layers_dev, Fd);
   } else {
     long long tiles = (max_elems + 256 * 8 - 1) / (256 * 8); if (tiles > 4096) tiles = 4096;
     hipLaunchKernelGGL(k_sn_pack<T>, dim3((int)tiles, n), dim3(256), 0, st, layers_dev);
@@ -320,11 +429,18 @@ template <typename T> static void sn_forward_range(const sg_sn_layer* layers_dev
     const long long e = (long long)ro * l.cols;
     if (e > max_elems) max_elems = e;
   }
+  sn_flat Fu, Fv;
+  Fu.n = Fv.n = n; Fu.start[0] = Fv.start[0] = 0;
+  for (int i = 0; i < n; i++) {
+    const sg_sn_layer& l = layers_host[i];
+    Fu.start[i + 1] = Fu.start[i] + (l.apply_sn && l.do_power_iter ? ((l.cols + 1023) / 1024) * SN_SPLITS : 0);
+    Fv.start[i + 1] = Fv.start[i] + (l.apply_sn ? (l.rows + 3) / 4 : 0);
+  }
   if (any_pi) {
-    hipLaunchKernelGGL(k_sn_wtu, dim3((max_cols + 1023) / 1024, SN_SPLITS, n), dim3(256), 0, st, layers_dev, work);
+    hipLaunchKernelGGL(k_sn_wtu, dim3(Fu.start[n]), dim3(256), 0, st, layers_dev, work, Fu);
     hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
   }
-  if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3((max_rows + 3) / 4, n), dim3(256), 0, st, layers_dev, work);
+  if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3(Fv.start[n]), dim3(256), 0, st, layers_dev, work, Fv);
   hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
   sn_pack_launch<T>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
 }
@@ -352,8 +468,11 @@ extern "C" int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_
     bytes += e * (4.0 * ((l.apply_sn && l.do_power_iter ? 1 : 0) + (l.apply_sn ? 1 : 0) + 1) + (l.w_fwd ? es : 0.0) + (l.w_dgrad ? es : 0.0) + (l.w_f32 ? 4.0 : 0.0));
   }
   SgProfScope prof(st, bytes, 3);
-  if (dtype == SG_DTYPE_F32) sn_forward_range<float>(layers_dev, layers_host, n, eps, work, st);
-  else sn_forward_range<bf16_t>(layers_dev, layers_host, n, eps, work, st);
+  for (int i0 = 0; i0 < n; i0 += SN_MAXL) {        // (a flat table holds SN_MAXL layers)
+    const int cnt = n - i0 < SN_MAXL ? n - i0 : SN_MAXL;
+    if (dtype == SG_DTYPE_F32) sn_forward_range<float>(layers_dev + i0, layers_host + i0, cnt, eps, work, st);
+    else sn_forward_range<bf16_t>(layers_dev + i0, layers_host + i0, cnt, eps, work, st);
+  }
   SG_LAUNCH_CHECK();
   return 0;
 }
@@ -376,8 +495,10 @@ __device__ __forceinline__ long long snb_src_index(const sg_sn_bwd_layer& l, int
 // LDS per block keeps the occupancy of a streaming kernel (a first version staged whole rows: 55 KB, two blocks per CU, SLOWER than
 // the kernels it replaced -- session J). Natural-layout weights (linear, embedding) take the same walk without the staging.
 // Transposed-convolution weights and RS > 16 stay with the old kernels.
+// (chunk of 256 channels = 1 KB runs, 17 KB of LDS: 128 -> 256 took the backward of BigGAN-128's G / D tables from 466 / 574 us to 421 / 519 us, 512 lost a third to occupancy --
+// round 6, tools/sn_bench.py over three builds)
 #ifndef SNB_CW
-#define SNB_CW 128
+#define SNB_CW 256
 #endif
 #ifndef SNB_ST
 #define SNB_ST (SNB_CW + 8)
