@@ -557,12 +557,26 @@ def main():
     if world > 1:
         from studiogan_amd import comm as sg_comm_t
         sg_comm_t.timing(True)          # event pairs on the compute stream around every wait on a collective (comm.exposed)
+    # host lead: how far ahead of the GPU the launching thread runs. One event per step (recorded on the compute stream, no sync) + the host clock at the moment the step's
+    # launches have all been issued; lead_i = (GPU finish of step i) - (host finished issuing step i). A lead near zero = the GPU waits for the host in that step.
+    ev0 = torch.cuda.Event(enable_timing=True)
+    ev_steps, host_done = [], []
     t0 = time.perf_counter()
+    ev0.record()
     last = None
     for i in range(args.steps):
         last = w.step(args.warmup + i, baskets(pool, args.warmup + i, n_d))
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        ev_steps.append(e)
+        host_done.append(time.perf_counter() - t0)
     barrier()
     elapsed = time.perf_counter() - t0
+    gpu_done = [ev0.elapsed_time(e) for e in ev_steps]
+    host_lead = {"host_issue_ms_per_step": round(1e3 * host_done[-1] / args.steps, 3),
+                 "gpu_minus_host_ms_per_step_end": [round(g - 1e3 * h, 2) for g, h in zip(gpu_done, host_done)][:32],
+                 "note": "per timed step: GPU completion time of the step minus the host time at which its last launch was issued (both from the start of the timed region); "
+                         "positive and growing = the host runs ahead and the step is GPU-bound"}
     exposed_comm_ms = None
     if world > 1:
         exposed_comm_ms = sg_comm_t.timing_ms()
@@ -762,6 +776,7 @@ def main():
         "data_note": f"{len(pool)} distinct real baskets per rank, cycled: uint8-grid samples of a frozen copy of the initial generator "
                      "(keeps the hinge active: d_loss > 1e-2 is asserted on the last timed step); z / labels drawn on the device every update",
         "last_step_losses": {"d_loss": round(d_last, 5), "g_loss": round(g_last, 5)},
+        "host_lead": host_lead,
         "config": {"workload": wl["desc"], "per_gpu_batch": args.batch, "global_batch": global_batch, "d_updates_per_step": wl["n_d"],
                    "parallelism": f"dp{world}" + (" (RCCL grad all-reduce + sync-BN)" if world > 1 else ""),
                    "exchange": None if world == 1 else ("libsgamd sg_allreduce_flat (native RCCL communicator)" if rccl_ranks else

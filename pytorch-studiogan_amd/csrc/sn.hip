@@ -100,28 +100,41 @@ __global__ __launch_bounds__(256) void k_sn_wtu(const sg_sn_layer* L, float* wor
     out[k] = acc;
   }
 }
+// One workgroup per layer finishes a power-iteration vector (k_sn_v, k_sn_u): these are latency chains (a 13824-column layer was 54 dependent trips of 16 loads at 256 threads,
+// 27 us per launch with the matrix-sized passes waiting behind it -- r7b trace), so the workgroup is as wide as the hardware allows. Fixed summation order.
+#define SN_NT 1024
+__device__ __forceinline__ float block_sum_nt(float v, float* sm /* SN_NT / 64 floats */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float t = sm[0];
+#pragma unroll
+  for (int w = 1; w < SN_NT / 64; w++) t += sm[w];
+  return t;
+}
 // grid (layers): v = normalize(sum of partials)
-__global__ __launch_bounds__(256) void k_sn_v(const sg_sn_layer* L, float* work, float eps) {
-  __shared__ float sm[4];
+__global__ __launch_bounds__(SN_NT) void k_sn_v(const sg_sn_layer* L, float* work, float eps) {
+  __shared__ float sm[SN_NT / 64];
   const sg_sn_layer l = L[blockIdx.x];
   if (!l.apply_sn || !l.do_power_iter) return;
   float* part = work + l.work_off;
   float nn = 0.f;
-  for (int k = threadIdx.x; k < l.cols; k += 256) {
+  for (int k = threadIdx.x; k < l.cols; k += SN_NT) {
     float t = 0.f;
 #pragma unroll
     for (int s = 0; s < SN_SPLITS; s++) t += part[(long long)s * l.cols + k];
     part[k] = t;  // same thread re-reads it below
     nn += t * t;
   }
-  nn = block_sum_256(nn, sm);
+  nn = block_sum_nt(nn, sm);
   const float inv = 1.f / fmaxf(sqrtf(nn), eps);
-  for (int k0 = threadIdx.x; k0 < l.cols; k0 += 256 * 8) {
+  for (int k0 = threadIdx.x; k0 < l.cols; k0 += SN_NT * 8) {
     float t[8];
 #pragma unroll
-    for (int e = 0; e < 8; e++) { const int k = k0 + 256 * e; t[e] = k < l.cols ? part[k] : 0.f; }
+    for (int e = 0; e < 8; e++) { const int k = k0 + SN_NT * e; t[e] = k < l.cols ? part[k] : 0.f; }
 #pragma unroll
-    for (int e = 0; e < 8; e++) { const int k = k0 + 256 * e; if (k < l.cols) l.v[k] = t[e] * inv; }
+    for (int e = 0; e < 8; e++) { const int k = k0 + SN_NT * e; if (k < l.cols) l.v[k] = t[e] * inv; }
   }
 }
 // flat grid of (row tiles of 4) per SN layer: one wave per row, t_u[o] = W[o,:] . v
@@ -152,8 +165,8 @@ __global__ __launch_bounds__(256) void k_sn_wv(const sg_sn_layer* L, float* work
   if (lane == 0) work[l.work_off + (long long)SN_SPLITS * l.cols + o] = acc;
 }
 // grid (layers): u, sigma
-__global__ __launch_bounds__(256) void k_sn_u(const sg_sn_layer* L, float* work, float eps) {
-  __shared__ float sm[4];
+__global__ __launch_bounds__(SN_NT) void k_sn_u(const sg_sn_layer* L, float* work, float eps) {
+  __shared__ float sm[SN_NT / 64];
   const sg_sn_layer l = L[blockIdx.x];
   if (!l.apply_sn) { if (threadIdx.x == 0) l.sigma[0] = 1.f; return; }
   const float* tu = work + l.work_off + (long long)SN_SPLITS * l.cols;
@@ -162,48 +175,48 @@ __global__ __launch_bounds__(256) void k_sn_u(const sg_sn_layer* L, float* work,
     // (eight loads in flight per thread: a 24576-row linear layer is 96 trips of this one block; one load per trip was most of the kernel's 67 us on the
     // generator's linear table -- round 6 trace of tools/sn_bench.py. Same per-thread summation order.)
     float nn = 0.f;
-    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += SN_NT * 8) {
       float t[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? tu[o] : 0.f; }
+      for (int e = 0; e < 8; e++) { const int o = o0 + SN_NT * e; t[e] = o < l.rows ? tu[o] : 0.f; }
 #pragma unroll
       for (int e = 0; e < 8; e++) nn += t[e] * t[e];
     }
-    nn = block_sum_256(nn, sm);
+    nn = block_sum_nt(nn, sm);
     const float inv = 1.f / fmaxf(sqrtf(nn), eps);
     float dot = 0.f;
-    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += SN_NT * 8) {
       float t[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? tu[o] : 0.f; }
+      for (int e = 0; e < 8; e++) { const int o = o0 + SN_NT * e; t[e] = o < l.rows ? tu[o] : 0.f; }
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; if (o < l.rows) { const float un = t[e] * inv; l.u[o] = un; dot += un * t[e]; } }
+      for (int e = 0; e < 8; e++) { const int o = o0 + SN_NT * e; if (o < l.rows) { const float un = t[e] * inv; l.u[o] = un; dot += un * t[e]; } }
     }
-    sig = block_sum_256(dot, sm);
+    sig = block_sum_nt(dot, sm);
   } else {
     float dot = 0.f;
-    for (int o = threadIdx.x; o < l.rows; o += 256) dot += l.u[o] * tu[o];
-    sig = block_sum_256(dot, sm);
+    for (int o = threadIdx.x; o < l.rows; o += SN_NT) dot += l.u[o] * tu[o];
+    sig = block_sum_nt(dot, sm);
   }
   if (threadIdx.x == 0) l.sigma[0] = sig;
   if (l.u_snap) {
-    for (int o0 = threadIdx.x; o0 < l.rows; o0 += 256 * 8) {
+    for (int o0 = threadIdx.x; o0 < l.rows; o0 += SN_NT * 8) {
       float t[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; t[e] = o < l.rows ? l.u[o] : 0.f; }
+      for (int e = 0; e < 8; e++) { const int o = o0 + SN_NT * e; t[e] = o < l.rows ? l.u[o] : 0.f; }
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int o = o0 + 256 * e; if (o < l.rows) l.u_snap[o] = t[e]; }
+      for (int e = 0; e < 8; e++) { const int o = o0 + SN_NT * e; if (o < l.rows) l.u_snap[o] = t[e]; }
     }
   }
   if (l.v_snap) {
     // eight loads in flight per thread: one load -> store per iteration (the two vectors may alias as far as the compiler knows) was 54
     // dependent round trips on a 13824-column layer, most of this kernel's 48 us
-    for (int k0 = threadIdx.x; k0 < l.cols; k0 += 256 * 8) {
+    for (int k0 = threadIdx.x; k0 < l.cols; k0 += SN_NT * 8) {
       float t[8];
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int k = k0 + 256 * e; t[e] = k < l.cols ? l.v[k] : 0.f; }
+      for (int e = 0; e < 8; e++) { const int k = k0 + SN_NT * e; t[e] = k < l.cols ? l.v[k] : 0.f; }
 #pragma unroll
-      for (int e = 0; e < 8; e++) { const int k = k0 + 256 * e; if (k < l.cols) l.v_snap[k] = t[e]; }
+      for (int e = 0; e < 8; e++) { const int k = k0 + SN_NT * e; if (k < l.cols) l.v_snap[k] = t[e]; }
     }
   }
 }
@@ -438,10 +451,10 @@ template <typename T> static void sn_forward_range(const sg_sn_layer* layers_dev
   }
   if (any_pi) {
     hipLaunchKernelGGL(k_sn_wtu, dim3(Fu.start[n]), dim3(256), 0, st, layers_dev, work, Fu);
-    hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+    hipLaunchKernelGGL(k_sn_v, dim3(n), dim3(SN_NT), 0, st, layers_dev, work, eps);
   }
   if (any_sn) hipLaunchKernelGGL(k_sn_wv, dim3(Fv.start[n]), dim3(256), 0, st, layers_dev, work, Fv);
-  hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(256), 0, st, layers_dev, work, eps);
+  hipLaunchKernelGGL(k_sn_u, dim3(n), dim3(SN_NT), 0, st, layers_dev, work, eps);
   sn_pack_launch<T>(layers_dev, layers_host, n, max_rows_out, max_rows, max_cols, max_elems, st);
 }
 // (Round 5, measured and removed: walking the table in runs of layers that fit the 256 MB Infinity Cache, each run through its whole launch sequence, so that the
