@@ -553,7 +553,12 @@ def main():
     barrier()
     if rank == 0:
         sys.stderr.write(f"[bench] warmup {args.warmup} step(s): {time.perf_counter() - tw:.2f}s\n")
-    L.call("sg_prof_enable", 1)
+    # Event pairs in the TIMED region: around every launch of the dominant kernel (sg_conv2d_q, bit 2 of sg_prof_enable) and nothing else. Pairs around every engine launch
+    # (~360 per step, the arrangement until round 6) are ~720 barrier packets per step: a traced run showed 5-20 us of idle in front of every bracketed kernel, ~3 ms per step
+    # (tools/kt_gaps.py, profiles/r06_step_gaps_*.txt) -- the instrument slowed what it measured. The engine's other families, the family total and the HBM-bound families
+    # are measured the same way on `psteps` further steps AFTER the timed region. SG_BENCH_PROF_ALL=1 restores the old arrangement (same-box A/B).
+    prof_all = os.environ.get("SG_BENCH_PROF_ALL") == "1"
+    L.call("sg_prof_enable", 1 if prof_all else 4)
     if world > 1:
         from studiogan_amd import comm as sg_comm_t
         sg_comm_t.timing(True)          # event pairs on the compute stream around every wait on a collective (comm.exposed)
@@ -606,12 +611,11 @@ def main():
         pmc_src = "profiles/" + pmc_name
     except Exception:
         pass
-    per_kernel = per_kernel_table(L, args.steps, PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS, pmc_tab)
+    per_kernel_timed = per_kernel_table(L, args.steps, PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS, pmc_tab)      # (prof_all: every family; else the dominant kernel's rows)
     prof4 = (ctypes.c_double * 12)()
     L.call("sg_prof_collect_ex", prof4, 3)
     L.call("sg_prof_enable", 0)
-    prof = [prof4[(i // 3) * 4 + (i % 3)] for i in range(9)]          # {launches, ms, algorithmic flops} per kind, as before
-    conv_exec_flop = prof4[3] + prof4[7]
+    per_kernel, psteps = per_kernel_timed, args.steps          # (replaced below by the profiled steps' table unless prof_all)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -655,14 +659,19 @@ def main():
     # ---- HBM-bound kernel families of the step: algorithmic bytes / hipEvent time per family over two more steps --------
     hbm = None
     if rank == 0 or world > 1:
-        L.call("sg_prof_enable", 2)          # bit 1: spectral norm, batch norm, attention score kernels, Adam / EMA
+        L.call("sg_prof_enable", 2 if prof_all else 3)          # bit 1: spectral norm, batch norm, attention score kernels, Adam / EMA; bit 0: every engine launch
         hsteps = 2
         for i in range(hsteps):
             w.step(args.warmup + args.steps + i, baskets(pool, args.warmup + args.steps + i, n_d))
         barrier()
-        ph = (ctypes.c_double * 21)()
-        L.call("sg_prof_collect", ph, 7)
+        if not prof_all:
+            per_kernel, psteps = per_kernel_table(L, hsteps, PEAK_BF16_TFLOPS if mixed else PEAK_F32_TFLOPS, pmc_tab), hsteps
+        ph4 = (ctypes.c_double * 28)()
+        L.call("sg_prof_collect_ex", ph4, 7)
         L.call("sg_prof_enable", 0)
+        ph = [ph4[(i // 3) * 4 + (i % 3)] for i in range(21)]          # {launches, ms, algorithmic work} per kind
+        if not prof_all:
+            prof4 = ph4          # kinds 0-2 of the profiled steps
         if rank == 0:
             hbm = {"peak_GBps": 8000.0, "steps": hsteps, "note": "algorithmic bytes (each tensor of the family read / written once per pass) / hipEvent time on the launch stream"}
             for kind, name in ((3, "spectral_norm"), (4, "batch_norm"), (5, "attention_scores"), (6, "adam_ema")):
@@ -739,6 +748,8 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
+    prof = [prof4[(i // 3) * 4 + (i % 3)] for i in range(9)]          # {launches, ms, algorithmic flops} per kind of the engine, over psteps steps
+    conv_exec_flop = prof4[3] + prof4[7]
     n_launch = prof[0] + prof[3]
     conv_ms = prof[1] + prof[4]
     conv_flop = prof[2] + prof[5]
@@ -754,8 +765,14 @@ def main():
     # the dominant kernel: sg_conv_q_kernel with and without the fused skip are ONE kernel template (two profiler tags)
     dominant = None
     if per_kernel:
-        fam = {}
+        # which family is the largest: the full table (profiled steps); its figures: the timed region's event pairs when that family is the one bracketed there
+        fam_full = {}
         for k, v in per_kernel.items():
+            fam_full.setdefault(k.split("<")[0].strip(), []).append(v)
+        dname_full = max(fam_full.items(), key=lambda kv: sum(r["ms_per_step"] for r in kv[1]))[0]
+        dom_src = per_kernel_timed if any(k.split("<")[0].strip() == dname_full for k in per_kernel_timed) else per_kernel
+        fam = {}
+        for k, v in dom_src.items():
             fam.setdefault(k.split("<")[0].strip(), []).append(v)
         dname, rows = max(fam.items(), key=lambda kv: sum(r["ms_per_step"] for r in kv[1]))
         dms = sum(r["ms_per_step"] for r in rows)
@@ -764,7 +781,8 @@ def main():
         dex = sum((r["executed_tflops"] or 0.0) * r["ms_per_step"] for r in rows) / dms if dms > 0 else 0.0
         dab = sum(r["algorithmic_MB_per_launch"] * r["launches_per_step"] for r in rows)
         dpb = sum(r.get("pmc_MB_per_launch", 0.0) * r["launches_per_step"] for r in rows) if all("pmc_MB_per_launch" in r for r in rows) else None
-        dominant = {"kernel": dname + (" (plain + fused-skip instantiations)" if len(rows) > 1 else ""), "ms_per_step": round(dms, 3), "launches_per_step": round(dn, 1),
+        dominant = {"kernel": dname + (" (plain + fused-skip instantiations)" if len(rows) > 1 else ""),
+                    "measured_in_timed_region": dom_src is per_kernel_timed, "ms_per_step": round(dms, 3), "launches_per_step": round(dn, 1),
                     "frac": round(dalg / peak_for(mixed), 4), "executed_frac": round(dex / peak_for(mixed), 4), "tflops": round(dalg, 1), "executed_tflops": round(dex, 1),
                     "algorithmic_MB_per_launch": round(dab / dn, 1) if dn else None,
                     "pmc_bytes_over_algorithmic": round(dpb / dab, 3) if (dpb and dab) else None}
@@ -806,13 +824,18 @@ def main():
                                  "pmc_stale = that summary was taken on other kernel sources than this run's (csrc hashes differ or the summary predates the hash)",
                      "kernel": "convolution engine (family; per_kernel has the members, dominant_kernel the largest): sg_conv_q_kernel / sg_wgrad_ql_kernel (3x3 next to a 2x resampling as 4x4-stride-2 / four 2x2 phase convolutions) / sg_conv_v4_kernel (3x3 halo, <= 384 channels, G tails with the 1x1 skip fused) / sg_conv_v3_kernel (3x3 halo, deep layers) / sg_conv_sk_kernel (1x1, stem) / sg_conv_rs_kernel (RGB layers) / sg_conv_v2_kernel / sg_wgrad_v3l_kernel / sg_wgrad_sk_kernel / sg_wgrad_v2_kernel / sg_gemm_kernel",
                      "per_kernel": per_kernel, "per_kernel_pmc_source": pmc_src,
-                     "launches_per_step": round(n_launch / args.steps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
+                     "launches_per_step": round(n_launch / psteps, 1), "avg_launch_ms": round(conv_ms / max(n_launch, 1), 4),
                      "algorithmic_gflop_per_launch": round(conv_flop / max(n_launch, 1) / 1e9, 3),
                      "algorithmic_bytes_per_launch": round(sum(v["algorithmic_MB_per_launch"] * 1e6 * v["launches_per_step"] for v in per_kernel.values()) /
                                                            max(sum(v["launches_per_step"] for v in per_kernel.values()), 1e-9)) if per_kernel else None,
                      "flop_count_note": "2*I*J*K on the launched (padded) dims: RGB layers run with 8 padded channels, < 1 % above the unpadded count over the step",
-                     "conv_ms_per_step": round(conv_ms / args.steps, 2),
-                     "gemm_ms_per_step": round(prof[7] / args.steps, 2)},
+                     "conv_ms_per_step": round(conv_ms / psteps, 2),
+                     "gemm_ms_per_step": round(prof[7] / psteps, 2),
+                     "measured_on": ("event pairs around every engine launch of the timed region (SG_BENCH_PROF_ALL=1)" if prof_all else
+                                     f"dominant_kernel: hipEvent pairs around every launch of that kernel IN the timed region ({args.steps} steps). Family total, per_kernel and "
+                                     f"roofline_hbm: event pairs around every launch of {psteps} further steps run right after the timed region -- bracketing every engine "
+                                     "launch inside the timed region costs ~3 ms of dispatch gaps per step (two barrier packets per launch; tools/kt_gaps.py, "
+                                     "profiles/r06_step_gaps_*.txt), i.e. the instrument slowed `value`")},
     }
     if hbm is not None:
         out["roofline_hbm"] = hbm

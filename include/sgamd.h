@@ -56,7 +56,9 @@ const char* sg_last_error(void);
 int sg_version(void);
 /* launch profiler used by bench.py's roofline leg: hipEvent pairs around every contraction-engine launch, recorded on the
  * launch stream. collect: out[kind*3+{0,1,2}] = {launches, total ms, algorithmic FLOPs}; kind 0 = conv fwd/dgrad,
- * 1 = conv wgrad, 2 = gemm. Synchronise the device before collecting. */
+ * 1 = conv wgrad, 2 = gemm. Synchronise the device before collecting.
+ * `on` is a bit set: 1 = the contraction engine (kinds 0-2), 2 = the HBM-bound families (kinds 3-6: spectral norm, batch norm, attention, Adam / EMA),
+ * 4 = sg_conv2d_q's launches alone (bench.py's timed region: the dominant kernel, without the dispatch gaps event pairs around every launch would cost). */
 int sg_prof_enable(int on);
 int sg_prof_collect(double* out, int nkinds);
 

@@ -156,6 +156,7 @@ __device__ __forceinline__ float block_max_256(float v, float* sm) {
 extern "C" void sg_set_error(const char* msg);
 extern int g_sg_f32_mode;      // fp32 arithmetic of the generic engine (conv.hip sg_set_f32_mode): 0 exact fp32 MFMA, 3 bf16x3 split
 extern "C" int sg_prof_begin(hipStream_t st, double flops, int kind);
+extern "C" int sg_prof_begin_q(hipStream_t st, double flops, int kind);
 extern "C" void sg_prof_end(hipStream_t st, int slot);
 extern "C" void sg_prof_set_executed(int slot, double flops);
 extern "C" void sg_prof_tag(int slot, int engine, double alg_bytes);

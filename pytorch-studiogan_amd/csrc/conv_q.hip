@@ -241,7 +241,7 @@ extern "C" int sg_conv2d_q(const sg_convq_desc* d, sg_stream_t stream) {
   hipStream_t st = (hipStream_t)stream;
   // algorithmic work = the 3x3 convolution over the fine grid this launch stands for; executed = 16 C MACs per low-resolution position
   const double c2 = d->x2 ? (double)d->C2 : 0.0;      // the fused skip stands for a 1x1 convolution over the fine grid
-  const int prof = sg_prof_begin(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
+  const int prof = sg_prof_begin_q(st, 2.0 * (double)d->Cout * 4.0 * (double)p.J * (9.0 * (double)d->C + c2), 0);
   sg_prof_set_executed(prof, 2.0 * (double)d->Cout * (double)p.J * (16.0 * (double)d->C + 4.0 * c2));
   // double-buffered-patch variant (conv_q.h NPMIN; two workgroups per CU). Measured (profiles/r04_quad_bench_l_db.txt): slower than the three
   // single-buffered workgroups everywhere (sum of the C3 layers 4.79 -> 5.07 ms forward, 4.97 -> 5.43 ms data gradient) EXCEPT on the 4 x 4
