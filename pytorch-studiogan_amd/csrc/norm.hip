@@ -199,7 +199,7 @@ template <typename T> static bool vec_ok(const void* a, const void* b, int C) {
 // Streaming variant: grid (pixel chunks, N). A thread owns ONE 16-byte channel vector of ONE sample, so its
 // scale/shift (8 or 4 channels) are computed once and the loop body is load -> fma -> store (the generic kernel
 // re-reads 4 parameters per channel per element, which made it VALU/L1-bound at ~40 % of HBM speed).
-template <typename T> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb) {
+template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb) {
   constexpr int V = ET<T>::VEC;
   const int CV = C / V;
   const int n = blockIdx.y;
@@ -229,29 +229,45 @@ template <typename T> __global__ __launch_bounds__(256) void k_bn_apply_stream(c
       if (relu) v = fmaxf(v, 0.f);
       xv[e] = v;
     }
-    *(u32x4*)(ys + pix * C) = pack16<T>(xv);
+    const u32x4 o = pack16<T>(xv);
+    if (NT) __builtin_nontemporal_store(o, (u32x4*)(ys + pix * C)); else *(u32x4*)(ys + pix * C) = o;
   };
   long long pix = p0 + pl;
-  for (; pix + 3ll * lanes_p < p1; pix += 4ll * lanes_p) {
-    u32x4 r[4];
+  for (; pix + (long long)(UN - 1) * lanes_p < p1; pix += (long long)UN * lanes_p) {
+    u32x4 r[UN];
 #pragma unroll
-    for (int i = 0; i < 4; i++) r[i] = *(const u32x4*)(xs + (pix + (long long)i * lanes_p) * C);
+    for (int i = 0; i < UN; i++) r[i] = NT ? __builtin_nontemporal_load((const u32x4*)(xs + (pix + (long long)i * lanes_p) * C)) : *(const u32x4*)(xs + (pix + (long long)i * lanes_p) * C);
 #pragma unroll
-    for (int i = 0; i < 4; i++) one(r[i], pix + (long long)i * lanes_p);
+    for (int i = 0; i < UN; i++) one(r[i], pix + (long long)i * lanes_p);
   }
   for (; pix < p1; pix += lanes_p) one(*(const u32x4*)(xs + pix * C), pix);
+}
+template <typename T> static void bn_apply_stream_launch(int variant, dim3 grid, dim3 blk, hipStream_t st, const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain,
+                                                         const float* bias, int gsn, int relu, int ppb) {
+  if (variant == 0) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else if (variant == 1) hipLaunchKernelGGL((k_bn_apply_stream<T, 8, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else if (variant == 2) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else hipLaunchKernelGGL((k_bn_apply_stream<T, 8, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
 }
 extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s) {
   SgProfScope prof((hipStream_t)s, 2.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
   SG_CHECK(x && y && mean && invstd, "sg_bn_apply: null");
   DISPATCH_T(dtype, {
     const int CV = C / ET<T>::VEC;
-    if (vec_ok<T>(x, y, C) && CV <= 256 && N <= 65535 && HW >= 64) {
+    if (vec_ok<T>(x, y, C) && CV <= 256 && N <= 65535 && HW >= 16) {      // (HW 64 -> 16: the 4 x 4 maps of a generator's first block took the generic kernel at 0.56 TB/s, 45 us for 25 MB)
       const int lanes_p = 256 / CV;
-      long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
+      // Variant 0 = four loads in flight, 1 = eight, 2 = four + non-temporal accesses, 3 = eight + non-temporal; `want` workgroups. Measured per shape (tools/bn_bench.py,
+      // profiles/r06_bn_apply_variants_r7f.txt): tensors far beyond the 256 MB Infinity Cache (BigGAN-128's 128^2 and 64^2 maps at batch 256: 805 / 403 MB) stream 7-12 % faster
+      // with non-temporal accesses, eight loads in flight and 4096 workgroups (4.64 -> 4.98, 4.74 -> 5.32 TB/s); smaller ones lose with any of the three (their output is the next
+      // kernel's input and should stay on the die). SG_BN_APPLY="<variant><workgroups / 1024>" forces one choice (A/B).
+      static const char* ev = getenv("SG_BN_APPLY");
+      const bool huge = 2.0 * N * (double)HW * C * sizeof(T) >= 600e6;
+      const int variant = ev && ev[0] >= '0' && ev[0] <= '3' ? ev[0] - '0' : (huge ? 3 : 0);
+      const long long want = ev && ev[0] && ev[1] >= '1' && ev[1] <= '9' ? 1024ll * (ev[1] - '0') : (huge ? 4096 : 2048);
+      long long chunks = want / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
       const int gx = (int)((HW + ppb - 1) / ppb);
-      hipLaunchKernelGGL(k_bn_apply_stream<T>, dim3(gx, N), dim3(CV * lanes_p), 0, (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb);
+      bn_apply_stream_launch<T>(variant, dim3(gx, N), dim3(CV * lanes_p), (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb);
     } else if (vec_ok<T>(x, y, C)) hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
     else hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
   });
@@ -347,7 +363,7 @@ extern "C" int sg_bn_bwd_reduce(int dtype, const void* x, const void* dy, int N,
   DISPATCH_T(dtype, {
     constexpr int V = ET<T>::VEC;
     const int CV = C / V;
-    if (vec_ok<T>(x, dy, C) && CV <= 256 && HW >= 64) {
+    if (vec_ok<T>(x, dy, C) && CV <= 256 && HW >= 16) {
       const int lanes_p = 256 / CV;
       long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 8 * lanes_p) ppb = 8 * lanes_p;
@@ -497,7 +513,7 @@ extern "C" int sg_bn_bwd_apply_res(int dtype, const void* x, const void* dy, voi
   SG_CHECK(!res || ((((uintptr_t)res) & 15) == 0), "sg_bn_bwd_apply_res: res must be 16-byte aligned");
   DISPATCH_T(dtype, {
     const int CV = C / ET<T>::VEC;
-    if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0) && CV <= 256 && N <= 65535 && HW >= 64) {
+    if (vec_ok<T>(x, dy, C) && ((((uintptr_t)dx) & 15) == 0) && CV <= 256 && N <= 65535 && HW >= 16) {
       const int lanes_p = 256 / CV;
       long long chunks = 2048 / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
