@@ -59,8 +59,19 @@ __device__ __forceinline__ u32x4 at_gfrag(const bf16_t* base, long long row, int
   u32x4 z = {0u, 0u, 0u, 0u};
   return (c < C) ? *(const u32x4*)(base + row * ld + c) : z;
 }
-__device__ __forceinline__ float at_half_max(float v) { return fmaxf(v, __shfl_xor(v, 32, 64)); }
-__device__ __forceinline__ float at_half_sum(float v) { return v + __shfl_xor(v, 32, 64); }
+// exchange between the two lane halves of a query: v_permlane32_swap_b32 (gfx950) swaps lanes 32-63 of one register with lanes 0-31 of another in the vector pipe; with both
+// registers = v, every lane ends up holding {its own value, its partner's} in the pair, in either order -- which a maximum or a sum does not care about. (__shfl_xor(v, 32) is a
+// ds_bpermute_b32: an LDS round trip on the per-block MFMA -> max -> exp -> MFMA chain of the streaming forward.)
+__device__ __forceinline__ float at_half_max(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float at_half_sum(float v) {
+  const uint32_t u = __float_as_uint(v);
+  const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 // 16 fp32 values of one query (keys {0-3, 8-11, 16-19, 24-27} + 4 h of a 32-key block) -> 16 CONTIGUOUS bf16 keys (16 h ..)
 __device__ __forceinline__ void at_store16(bf16_t* dst, const float* p, int h) {
   uint32_t own[8];

@@ -591,6 +591,18 @@ inline uint32_t __float_as_uint(float f) { uint32_t u; memcpy(&u, &f, 4); return
 inline float __int_as_float(int u) { float f; memcpy(&f, &u, 4); return f; }
 inline int __float_as_int(float f) { int u; memcpy(&u, &f, 4); return u; }
 template <class T> inline T __shfl_xor(T v, int m, int = 64) { return hipemu::shfl_idx(v, hipemu::g_cur->lane ^ m); }
+// v_permlane32_swap_b32 vdst, vsrc: lanes 32-63 of vdst <-> lanes 0-31 of vsrc; returns {new vdst, new vsrc}
+struct hipemu_u32x2 { uint32_t v[2]; uint32_t operator[](int i) const { return v[i]; } };
+inline hipemu_u32x2 hipemu_permlane32_swap(uint32_t vdst, uint32_t vsrc, bool, bool) {
+  const int lane = hipemu::g_cur->lane;
+  const uint32_t give = lane < 32 ? vsrc : vdst;          // what this lane hands to its partner (lane ^ 32)
+  const uint32_t got = hipemu::shfl_idx(give, lane ^ 32);
+  hipemu_u32x2 r;
+  r.v[0] = lane < 32 ? vdst : got;
+  r.v[1] = lane < 32 ? got : vsrc;
+  return r;
+}
+#define __builtin_amdgcn_permlane32_swap hipemu_permlane32_swap
 template <class T> inline T __shfl(T v, int s, int = 64) { return hipemu::shfl_idx(v, s); }
 template <class T> inline T __shfl_down(T v, int d, int = 64) { const int s = hipemu::g_cur->lane + d; return hipemu::shfl_idx(v, s < 64 ? s : hipemu::g_cur->lane); }
 template <class T> inline T hipemu_atomic_rmw(T* p, T v, T (*op)(T, T)) {       // compare-and-swap loop on the value's bit pattern (float / double / integers)
