@@ -206,13 +206,19 @@ def run_extra(name, device, steps=None, warmup=None):
         for i in range(warmup):
             w.step(i, baskets(pool, i, e["n_d"]))
         torch.cuda.synchronize()
-        L.call("sg_prof_enable", 1)
         t0 = time.perf_counter()
         last = None
         for i in range(steps):
             last = w.step(warmup + i, baskets(pool, warmup + i, e["n_d"]))
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
+        # the convolution engine's share: event pairs around every engine launch of ONE further step (inside the timed steps the pairs -- two barrier packets per launch,
+        # thousands per step on the small-batch configurations -- would slow what is timed: profiles/r06_bench_instrumentation_ab_r7e.txt)
+        psteps = 1
+        L.call("sg_prof_enable", 1)
+        for i in range(psteps):
+            w.step(warmup + steps + i, baskets(pool, warmup + steps + i, e["n_d"]))
+        torch.cuda.synchronize()
         pr = (ctypes.c_double * 9)()
         L.call("sg_prof_collect", pr, 3)
         L.call("sg_prof_enable", 0)
@@ -232,7 +238,8 @@ def run_extra(name, device, steps=None, warmup=None):
     return {"workload": e["desc"], "dtype": "bf16" if e["mixed"] else ("f32 tensors, bf16x3 arithmetic" if e.get("f32_mode") == "bf16x3" else "f32"), "per_gpu_batch": e["batch"], "d_updates_per_step": e["n_d"], "steps": steps,
             "images_per_sec": round(e["batch"] * steps / dt, 1), "ms_per_step": round(1e3 * dt / steps, 2),
             "conv_engine_tflops": round(tf, 1), "conv_engine_frac_of_peak": round(tf / peak, 4), "peak_tflops": peak,
-            "conv_ms_per_step": round(conv_ms / steps, 2), "step_conv_gflop_per_image": round(conv_fl / steps / e["batch"] / 1e9, 2),
+            "conv_ms_per_step": round(conv_ms / psteps, 2), "step_conv_gflop_per_image": round(conv_fl / psteps / e["batch"] / 1e9, 2),
+            "conv_measured_on": f"{psteps} profiled step after the {steps} timed ones",
             "last_step_losses": {"d_loss": round(d_l, 5), "g_loss": round(g_l, 5)}}
 
 
