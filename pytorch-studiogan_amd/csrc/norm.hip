@@ -256,14 +256,14 @@ extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long H
     const int CV = C / ET<T>::VEC;
     if (vec_ok<T>(x, y, C) && CV <= 256 && N <= 65535 && HW >= 16) {      // (HW 64 -> 16: the 4 x 4 maps of a generator's first block took the generic kernel at 0.56 TB/s, 45 us for 25 MB)
       const int lanes_p = 256 / CV;
-      // Variant 0 = four loads in flight, 1 = eight, 2 = four + non-temporal accesses, 3 = eight + non-temporal; `want` workgroups. Measured per shape (tools/bn_bench.py,
-      // profiles/r06_bn_apply_variants_r7f.txt): tensors far beyond the 256 MB Infinity Cache (BigGAN-128's 128^2 and 64^2 maps at batch 256: 805 / 403 MB) stream 7-12 % faster
-      // with non-temporal accesses, eight loads in flight and 4096 workgroups (4.64 -> 4.98, 4.74 -> 5.32 TB/s); smaller ones lose with any of the three (their output is the next
-      // kernel's input and should stay on the die). SG_BN_APPLY="<variant><workgroups / 1024>" forces one choice (A/B).
+      // Variant 0 = four loads in flight, 1 = eight, 2 = four + non-temporal accesses, 3 = eight + non-temporal; `want` workgroups (SG_BN_APPLY="<variant><workgroups / 1024>", A/B).
+      // Measured (tools/bn_bench.py, profiles/r06_bn_apply_variants_r7f.txt): ALONE, this pass streams tensors far beyond the 256 MB Infinity Cache 7-12 % faster with non-temporal
+      // accesses, eight loads in flight and 4096 workgroups (4.64 -> 5.10 TB/s on BigGAN-128's 128^2 maps). IN THE STEP that choice loses: three same-box alternations,
+      // 126.9 / 128.4 / 128.3 ms against 127.6 / 126.7 / 126.8 ms with plain accesses -- the convolution that consumes the output slows down by more (+0.9 ms of engine time) than the
+      // pass gains (-0.1 ms): its first reads no longer find the tail of the map on the die (profiles/r06_bn_apply_step_ab_r7l.txt). The default therefore stays variant 0.
       static const char* ev = getenv("SG_BN_APPLY");
-      const bool huge = 2.0 * N * (double)HW * C * sizeof(T) >= 600e6;
-      const int variant = ev && ev[0] >= '0' && ev[0] <= '3' ? ev[0] - '0' : (huge ? 3 : 0);
-      const long long want = ev && ev[0] && ev[1] >= '1' && ev[1] <= '9' ? 1024ll * (ev[1] - '0') : (huge ? 4096 : 2048);
+      const int variant = ev && ev[0] >= '0' && ev[0] <= '3' ? ev[0] - '0' : 0;
+      const long long want = ev && ev[0] && ev[1] >= '1' && ev[1] <= '9' ? 1024ll * (ev[1] - '0') : 2048;
       long long chunks = want / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
       const int gx = (int)((HW + ppb - 1) / ppb);
