@@ -166,3 +166,30 @@ def run(dev, dtype, L, call, ptr, stream, seed=0):
         tag = f"{i}:{r['kind']} {r['rows']}x{r['cin']}x{r['RS']}" + "".join(f" {k}" for k in r["opt"])
         rows_out.append((tag + " dW_orig", rel(r["dw_d"], r["gref"]), 1e-5))
     return rows_out
+
+
+def forward_table(dev, dtype, L, call, ptr, stream, shapes, seed, split_at=None):
+    """sg_sn_forward on a table of plain convolution layers `shapes` = [(rows, cin, R)]; split_at = None: ONE call; an index: two calls ([0, split_at), [split_at, n)) on the
+    same table. -> per layer (u, v, sigma, forward image, data-gradient image) as CPU tensors."""
+    g = torch.Generator().manual_seed(seed)
+    n = len(shapes)
+    arr = (L.SnLayer * n)()
+    recs, work_floats = [], 0
+    for i, (rows, cin, R) in enumerate(shapes):
+        RS, cols = R * R, cin * R * R
+        r = dict(w=(torch.randn(rows, cin, R, R, generator=g) * 0.1).to(dev), u=nn.functional.normalize(torch.randn(rows, generator=g), dim=0).to(dev),
+                 v=nn.functional.normalize(torch.randn(cols, generator=g), dim=0).to(dev), sigma=torch.zeros(1, device=dev),
+                 us=torch.zeros(rows, device=dev), vs=torch.zeros(cols, device=dev),
+                 fwd=torch.zeros(_align(rows * cols, 16), device=dev, dtype=dtype), dg=torch.zeros(_align(rows * cols, 16), device=dev, dtype=dtype))
+        d = arr[i]
+        d.w, d.u, d.v, d.sigma, d.u_snap, d.v_snap, d.w_fwd, d.w_dgrad = ptr(r["w"]), ptr(r["u"]), ptr(r["v"]), ptr(r["sigma"]), ptr(r["us"]), ptr(r["vs"]), ptr(r["fwd"]), ptr(r["dg"])
+        d.rows, d.cols, d.Cin, d.RS = rows, cols, cin, RS
+        d.do_power_iter, d.apply_sn, d.rows_pad, d.work_off, d.trans, d.dgrad_noflip, d.Cin_pad = 1, 1, rows, work_floats, 0, 0, cin
+        work_floats += SPLITS * cols + rows
+        recs.append(r)
+    work = torch.zeros(work_floats + 64, device=dev)
+    tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(dev)
+    esz = ctypes.sizeof(L.SnLayer)
+    for first, count in ([(0, n)] if split_at is None else [(0, split_at), (split_at, n - split_at)]):
+        call("sg_sn_forward", L.dt(dtype), tab.data_ptr() + first * esz, ctypes.cast(ctypes.addressof(arr) + first * esz, ctypes.POINTER(L.SnLayer)), count, 1e-6, ptr(work), work.numel(), stream())
+    return [tuple(r[k].detach().float().cpu().clone() for k in ("u", "v", "sigma", "fwd", "dg")) for r in recs]

@@ -386,6 +386,21 @@ def test_emulated_sn_kernels_against_torch_spectral_norm(dtype):
     assert not bad, bad
 
 
+def test_emulated_sn_forward_table_longer_than_one_flat_tile_table():
+    """tests/test_sn_gpu.py's 70-layer table (csrc/sn.hip walks it in runs of SN_MAXL = 64) on the interpreter: one call = two calls on the halves, bit for bit"""
+    import fullemu
+    import sn_checks as SC
+    shapes = [(16 + 8 * (i % 3), 8 + 8 * (i % 2), 3 if i % 5 else 1) for i in range(70)]
+    with fullemu.Installed(dma_late=1, greedy=1, seed=3) as E:
+        L = E.L
+        one = SC.forward_table(torch.device("cpu"), torch.bfloat16, L, L.call, L.ptr, L.stream, shapes, seed=5)
+        two = SC.forward_table(torch.device("cpu"), torch.bfloat16, L, L.call, L.ptr, L.stream, shapes, seed=5, split_at=37)
+    for i, (x, y) in enumerate(zip(one, two)):
+        for name, p, q in zip(("u", "v", "sigma", "w_fwd", "w_dgrad"), x, y):
+            assert torch.equal(p, q), (i, shapes[i], name)
+    assert all(float(x[2]) > 0 for x in one)
+
+
 @pytest.mark.parametrize("case", [(2, 64, 96, 9, 9, 3, 3, 1, (1, 1)), (1, 128, 160, 9, 9, 1, 7, 1, (0, 3)), (2, 48, 32, 7, 7, 5, 5, 2, (2, 2))])
 def test_emulated_conv_fwd_f32_bf16x3_split(case):
     """the generic engine's "bf16x3" fp32 mode (csrc/gemm_core.h SPLIT: fp32 operands split into two bf16 terms at fragment time, three bf16 MFMAs per k-tile) on

@@ -18,3 +18,16 @@ def test_sn_forward_backward_against_torch_spectral_norm(sg, dtype):
     for n, e, t in rows:
         print(f"{n:60s} err {e:.3e} (tol {t:.0e})")
     assert not bad, bad
+
+
+def test_sn_forward_table_longer_than_one_flat_tile_table(sg):
+    """csrc/sn.hip walks a table in runs of SN_MAXL = 64 layers (one flat tile table per run): 70 layers in ONE call = the same table handed over as [0, 37) + [37, 70), bit for bit."""
+    from studiogan_amd import _lib as L
+    dev = torch.device("cuda:0")
+    shapes = [(16 + 8 * (i % 3), 8 + 8 * (i % 2), 3 if i % 5 else 1) for i in range(70)]
+    one = SC.forward_table(dev, torch.bfloat16, L, L.call, L.ptr, L.stream, shapes, seed=5)
+    two = SC.forward_table(dev, torch.bfloat16, L, L.call, L.ptr, L.stream, shapes, seed=5, split_at=37)
+    for i, (a, b) in enumerate(zip(one, two)):
+        for name, x, y in zip(("u", "v", "sigma", "w_fwd", "w_dgrad"), a, b):
+            assert torch.equal(x, y), (i, shapes[i], name)
+    assert all(float(a[2]) > 0 for a in one)
