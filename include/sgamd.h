@@ -331,14 +331,15 @@ typedef struct {
   int do_power_iter;  /* module.training */
   int apply_sn;       /* 0: plain layer, only emit operand images with sigma = 1 */
   int rows_pad;       /* w_fwd gets rows_pad >= rows rows (extra rows zero) ; 0 = rows */
-  long long work_off; /* this layer's slice of work[]: needs 8*cols + rows floats */
+  long long work_off; /* this layer's slice of work[]: needs 16*cols + rows floats (16 = the row groups of the W^T u pass) */
   int trans;          /* 1: ConvTranspose2d weight [Cin][Cout][R][S] (spectral norm over dim 1, rows = Cout) */
   int dgrad_noflip;   /* 1: w_dgrad = [Cin][r][s][Cout] without the spatial flip (strided / transposed convolutions) */
   int Cin_pad;        /* >= Cin (0 = Cin): channel pitch of w_fwd ([Cout][R][S][Cin_pad], zero filled) -- thin inputs (RGB) are
                          carried as 8-channel tensors so the 16-byte loaders apply; w_dgrad is [Cin][R][S][max(rows,rows_pad)] */
 } sg_sn_layer;
-/* runs all layers of a network in 4 batched launches. `layers` is a DEVICE array of n descriptors;
- * work[] is a device scratch; each layer owns the slice [work_off, work_off + 8*cols + rows) */
+/* runs all layers of a network in six batched launches (W^T u, v, W v, u / sigma, forward images, data-gradient images), each a flat table of exactly the tiles
+ * its layers have (any mix of layer shapes in one call; tables longer than 64 layers are walked in runs of 64). `layers` is a DEVICE array of n descriptors;
+ * work[] is a device scratch; each layer owns the slice [work_off, work_off + 16*cols + rows) */
 int sg_sn_forward(int dtype, const sg_sn_layer* layers_dev, const sg_sn_layer* layers_host, int n, float eps, float* work, long long work_floats, sg_stream_t s);
 
 typedef struct {
