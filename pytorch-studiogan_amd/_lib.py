@@ -308,6 +308,17 @@ def stream():
     return torch.cuda.current_stream().cuda_stream
 
 
+def upload_bytes(raw, device):
+    """A descriptor table (bytes-like) -> uint8 tensor on `device`, WITHOUT stalling the launching thread. A host-to-device copy from pageable memory blocks the host until
+    the stream has reached the copy: one such upload inside a training step collapses the host's lead over the GPU to zero (round 6, tools/host_probe.py: the first steps
+    after a synchronisation were issued in ~110 ms instead of ~22 ms because of ONE table upload per step). From pinned memory the copy is queued like a kernel; torch's
+    caching host allocator keeps the staging block alive until the copy has run."""
+    t = torch.frombuffer(bytearray(raw), dtype=torch.uint8)
+    if torch.device(device).type == "cuda":
+        return t.pin_memory().to(device, non_blocking=True)
+    return t.to(device)
+
+
 def dt(t):
     """SG dtype code of a tensor / torch dtype."""
     d = t if isinstance(t, torch.dtype) else t.dtype

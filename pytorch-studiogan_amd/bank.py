@@ -419,7 +419,7 @@ class WeightBank:
             d.work_off = r.work_off
             d.trans, d.dgrad_noflip = r.trans, r.noflip
             d.Cin_pad = r.cin_pad
-        dev_tab = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
+        dev_tab = L.upload_bytes(arr, self.device)
         groups = [(0, n)]
         ent = (arr, dev_tab, groups)
         slot.desc_cache[flags] = ent
@@ -542,7 +542,7 @@ class WeightBank:
                 else:
                     it.src, it.M, it.Cs = self.w_dgrad(slot, r), r.cin_pad, r.rows_pad
                 it.dst, it.mode = ent[0].data_ptr(), mode
-            tab = (arr, torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device))
+            tab = (arr, L.upload_bytes(arr, self.device))
             slot.quad_tab[keys] = tab
         L.call("sg_quad_pack_batch", self.sgdt, tab[1].data_ptr(), tab[0], len(keys), L.stream())
         for k in keys:
@@ -613,7 +613,7 @@ class WeightBank:
             if ent[2] != grads:  # gradient tensors may be re-created by zero_grad(set_to_none=True)
                 for j, gp in enumerate(grads):
                     arr[j].dw = gp
-                ent[1] = torch.frombuffer(bytearray(arr), dtype=torch.uint8).to(self.device)
+                ent[1] = L.upload_bytes(arr, self.device)
                 ent[2] = grads
             L.call("sg_sn_backward", ent[1].data_ptr(), arr, len(key), self.work.data_ptr(), self.work.numel(), L.stream())
 

@@ -655,14 +655,14 @@ class CbnAffineGroupFn(torch.autograd.Function):
             outs.append(out_all[off:off + B * 2 * C].view(B, 2 * C))
             off += B * 2 * C
         # the device copy of the table is kept per set of addresses: in steady state the caching allocator hands every step the same blocks, so the upload
-        # (a pageable host-to-device copy) happens during warm-up only
+        # happens during warm-up only (and from pinned memory: L.upload_bytes)
         raw = bytes(bytearray(arr)[:k * ctypes.sizeof(L.LinearItem)])
         cache = bank.__dict__.setdefault("_linear_group_tabs", {})
         tab = cache.get(raw)
         if tab is None:
             if len(cache) >= 64:
                 cache.clear()
-            tab = cache[raw] = torch.frombuffer(bytearray(raw), dtype=torch.uint8).to(dev)
+            tab = cache[raw] = L.upload_bytes(raw, dev)
         L.call("sg_linear_group", tab.data_ptr(), arr, k, B, L.stream())
         ctx.save_for_backward(*ys)
         ctx.metas, ctx.yidx, ctx.slot, ctx.adj, ctx.G = metas, yidx, slot, adj, G

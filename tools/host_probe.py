@@ -16,6 +16,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--gc", default="default", choices=["default", "freeze", "disable"], help="freeze: gc.collect() + gc.freeze() after the warm-up steps; disable: gc.disable()")
     args = ap.parse_args()
     from studiogan_amd import _lib as L
     from studiogan_amd.worker import Worker
@@ -38,13 +39,41 @@ def main():
             e = acc[name]
             e[0] += 1; e[1] += dt; e[2] = max(e[2], dt)
     L.call = timed
+    # host-to-device uploads (Tensor.to from a CPU tensor): from pageable memory they block the host until the stream has reached them
+    up = [0, 0.0]
+    orig_to = torch.Tensor.to
+
+    def to_timed(self, *a, **k):
+        if self.device.type != "cpu":
+            return orig_to(self, *a, **k)
+        t = time.perf_counter()
+        try:
+            return orig_to(self, *a, **k)
+        finally:
+            up[0] += 1; up[1] += time.perf_counter() - t
+    torch.Tensor.to = to_timed
     for i in range(args.warmup):
         w.step(i, bench.baskets(pool, i, n_d))
     torch.cuda.synchronize()
+    import gc
+    gc_log = []
+
+    def on_gc(phase, info, _t=[0.0]):
+        if phase == "start":
+            _t[0] = time.perf_counter()
+        else:
+            gc_log.append((info["generation"], time.perf_counter() - _t[0], info.get("collected", 0)))
+    gc.callbacks.append(on_gc)
+    if args.gc == "freeze":
+        gc.collect(); gc.freeze()
+    elif args.gc == "disable":
+        gc.disable()
+    print(f"gc mode {args.gc}: thresholds {gc.get_threshold()}, counts {gc.get_count()}, tracked objects {len(gc.get_objects())}")
     ev0 = torch.cuda.Event(enable_timing=True)
     ev0.record()
     t0 = time.perf_counter()
     evs = []
+    seg_prev = torch.cuda.memory_stats().get("segment.all.allocated", 0)
     for i in range(args.steps):
         acc.clear()
         ts = time.perf_counter()
@@ -53,6 +82,14 @@ def main():
         e = torch.cuda.Event(enable_timing=True); e.record(); evs.append((e, time.perf_counter() - t0))
         inside = sum(v[1] for v in acc.values())
         top = sorted(acc.items(), key=lambda kv: -kv[1][1])[:4]
+        print(f"step {i}: garbage collections " + (", ".join(f"gen{g} {t * 1e3:.1f} ms" for g, t, _ in gc_log) or "none"))
+        gc_log.clear()
+        print(f"step {i}: Tensor.to() from CPU tensors: {up[0]} calls, {up[1] * 1e3:.1f} ms")
+        up[0], up[1] = 0, 0.0
+        st = torch.cuda.memory_stats()
+        seg = st.get("segment.all.allocated", 0)
+        print(f"step {i}: new allocator segments (hipMalloc) {seg - seg_prev}, reserved {st.get('reserved_bytes.all.current', 0) / 2**30:.1f} GiB, peak allocated {st.get('allocated_bytes.all.peak', 0) / 2**30:.1f} GiB")
+        seg_prev = seg
         print(f"step {i}: host {host * 1e3:7.1f} ms, inside C-ABI calls {inside * 1e3:7.1f} ms ({sum(v[0] for v in acc.values())} calls) | " +
               " | ".join(f"{k} n={v[0]} {v[1] * 1e3:.1f} ms max {v[2] * 1e3:.2f}" for k, v in top))
     torch.cuda.synchronize()
