@@ -199,10 +199,12 @@ template <typename T> static bool vec_ok(const void* a, const void* b, int C) {
 // Streaming variant: grid (pixel chunks, N). A thread owns ONE 16-byte channel vector of ONE sample, so its
 // scale/shift (8 or 4 channels) are computed once and the loop body is load -> fma -> store (the generic kernel
 // re-reads 4 parameters per channel per element, which made it VALU/L1-bound at ~40 % of HBM speed).
-template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb) {
+template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb, int rev) {
   constexpr int V = ET<T>::VEC;
   const int CV = C / V;
-  const int n = blockIdx.y;
+  // rev: workgroups walk the tensor back to front (the LAST stores of the pass then cover the START of the map, which is where the convolution behind it begins to read)
+  const int n = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
+  const int bxr = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
   const int lanes_p = blockDim.x / CV;                // pixels per block iteration (blockDim.x == CV * lanes_p)
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
   float mu[V], is[V], ga[V], bi[V];
@@ -213,7 +215,7 @@ template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_
     ga[e] = gain ? gain[(long long)n * gsn + c] : 1.f;
     bi[e] = bias ? bias[(long long)n * gsn + c] : 0.f;
   }
-  const long long p0 = (long long)blockIdx.x * ppb;
+  const long long p0 = (long long)bxr * ppb;
   long long p1 = p0 + ppb; if (p1 > HW) p1 = HW;
   const T* xs = x + (long long)n * HW * C + cv * V;
   T* ys = y + (long long)n * HW * C + cv * V;
@@ -243,11 +245,11 @@ template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_
   for (; pix < p1; pix += lanes_p) one(*(const u32x4*)(xs + pix * C), pix);
 }
 template <typename T> static void bn_apply_stream_launch(int variant, dim3 grid, dim3 blk, hipStream_t st, const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain,
-                                                         const float* bias, int gsn, int relu, int ppb) {
-  if (variant == 0) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
-  else if (variant == 1) hipLaunchKernelGGL((k_bn_apply_stream<T, 8, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
-  else if (variant == 2) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
-  else hipLaunchKernelGGL((k_bn_apply_stream<T, 8, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+                                                         const float* bias, int gsn, int relu, int ppb, int rev) {
+  if (variant == 0) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
+  else if (variant == 1) hipLaunchKernelGGL((k_bn_apply_stream<T, 8, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
+  else if (variant == 2) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
+  else hipLaunchKernelGGL((k_bn_apply_stream<T, 8, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
 }
 extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s) {
   SgProfScope prof((hipStream_t)s, 2.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
@@ -267,7 +269,8 @@ extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long H
       long long chunks = want / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
       const int gx = (int)((HW + ppb - 1) / ppb);
-      bn_apply_stream_launch<T>(variant, dim3(gx, N), dim3(CV * lanes_p), (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb);
+      static const char* evr = getenv("SG_BN_APPLY_REV");      // "1": back to front (A/B)
+      bn_apply_stream_launch<T>(variant, dim3(gx, N), dim3(CV * lanes_p), (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb, evr && evr[0] == '1' ? 1 : 0);
     } else if (vec_ok<T>(x, y, C)) hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
     else hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
   });
