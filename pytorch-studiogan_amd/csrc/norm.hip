@@ -199,12 +199,10 @@ template <typename T> static bool vec_ok(const void* a, const void* b, int C) {
 // Streaming variant: grid (pixel chunks, N). A thread owns ONE 16-byte channel vector of ONE sample, so its
 // scale/shift (8 or 4 channels) are computed once and the loop body is load -> fma -> store (the generic kernel
 // re-reads 4 parameters per channel per element, which made it VALU/L1-bound at ~40 % of HBM speed).
-template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb, int rev) {
+template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_bn_apply_stream(const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gsn, int relu, int ppb) {
   constexpr int V = ET<T>::VEC;
   const int CV = C / V;
-  // rev: workgroups walk the tensor back to front (the LAST stores of the pass then cover the START of the map, which is where the convolution behind it begins to read)
-  const int n = rev ? (int)gridDim.y - 1 - (int)blockIdx.y : (int)blockIdx.y;
-  const int bxr = rev ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
+  const int n = blockIdx.y;
   const int lanes_p = blockDim.x / CV;                // pixels per block iteration (blockDim.x == CV * lanes_p)
   const int cv = threadIdx.x % CV, pl = threadIdx.x / CV;
   float mu[V], is[V], ga[V], bi[V];
@@ -215,7 +213,7 @@ template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_
     ga[e] = gain ? gain[(long long)n * gsn + c] : 1.f;
     bi[e] = bias ? bias[(long long)n * gsn + c] : 0.f;
   }
-  const long long p0 = (long long)bxr * ppb;
+  const long long p0 = (long long)blockIdx.x * ppb;
   long long p1 = p0 + ppb; if (p1 > HW) p1 = HW;
   const T* xs = x + (long long)n * HW * C + cv * V;
   T* ys = y + (long long)n * HW * C + cv * V;
@@ -245,11 +243,11 @@ template <typename T, int UN, bool NT> __global__ __launch_bounds__(256) void k_
   for (; pix < p1; pix += lanes_p) one(*(const u32x4*)(xs + pix * C), pix);
 }
 template <typename T> static void bn_apply_stream_launch(int variant, dim3 grid, dim3 blk, hipStream_t st, const T* x, T* y, long long HW, int C, const float* mean, const float* invstd, const float* gain,
-                                                         const float* bias, int gsn, int relu, int ppb, int rev) {
-  if (variant == 0) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
-  else if (variant == 1) hipLaunchKernelGGL((k_bn_apply_stream<T, 8, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
-  else if (variant == 2) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
-  else hipLaunchKernelGGL((k_bn_apply_stream<T, 8, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb, rev);
+                                                         const float* bias, int gsn, int relu, int ppb) {
+  if (variant == 0) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else if (variant == 1) hipLaunchKernelGGL((k_bn_apply_stream<T, 8, false>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else if (variant == 2) hipLaunchKernelGGL((k_bn_apply_stream<T, 4, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
+  else hipLaunchKernelGGL((k_bn_apply_stream<T, 8, true>), grid, blk, 0, st, x, y, HW, C, mean, invstd, gain, bias, gsn, relu, ppb);
 }
 extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long HW, int C, const float* mean, const float* invstd, const float* gain, const float* bias, int gb_stride_n, int relu, sg_stream_t s) {
   SgProfScope prof((hipStream_t)s, 2.0 * N * (double)HW * C * (dtype == SG_DTYPE_BF16 ? 2.0 : 4.0), 4);
@@ -260,17 +258,17 @@ extern "C" int sg_bn_apply(int dtype, const void* x, void* y, int N, long long H
       const int lanes_p = 256 / CV;
       // Variant 0 = four loads in flight, 1 = eight, 2 = four + non-temporal accesses, 3 = eight + non-temporal; `want` workgroups (SG_BN_APPLY="<variant><workgroups / 1024>", A/B).
       // Measured (tools/bn_bench.py, profiles/r06_bn_apply_variants_r7f.txt): ALONE, this pass streams tensors far beyond the 256 MB Infinity Cache 7-12 % faster with non-temporal
-      // accesses, eight loads in flight and 4096 workgroups (4.64 -> 5.10 TB/s on BigGAN-128's 128^2 maps). IN THE STEP that choice loses: three same-box alternations,
-      // 126.9 / 128.4 / 128.3 ms against 127.6 / 126.7 / 126.8 ms with plain accesses -- the convolution that consumes the output slows down by more (+0.9 ms of engine time) than the
-      // pass gains (-0.1 ms): its first reads no longer find the tail of the map on the die (profiles/r06_bn_apply_step_ab_r7l.txt). The default therefore stays variant 0.
+      // accesses, eight loads in flight and 4096 workgroups (4.64 -> 5.10 TB/s on BigGAN-128's 128^2 maps). IN THE STEP no gain could be shown: A, B, A, B
+      // alternations read +1.0 ms for the non-temporal arm (profiles/r06_bn_apply_step_ab_r7l.txt), but an ABBA series showed every second PROCESS on such a box running 1.5 ms
+      // faster whatever the variant (profiles/r06_bn_apply_reverse_walk_r7r.txt): corrected, the effect lies between -0.9 and +0.2 ms. Unresolved, so the default stays variant 0
+      // (the pass's output is the next convolution's input; what it leaves in the Infinity Cache may matter as much as its own 0.1 ms).
       static const char* ev = getenv("SG_BN_APPLY");
       const int variant = ev && ev[0] >= '0' && ev[0] <= '3' ? ev[0] - '0' : 0;
       const long long want = ev && ev[0] && ev[1] >= '1' && ev[1] <= '9' ? 1024ll * (ev[1] - '0') : 2048;
       long long chunks = want / N; if (chunks < 1) chunks = 1;
       long long ppb = (HW + chunks - 1) / chunks; if (ppb < 4 * lanes_p) ppb = 4 * lanes_p;
       const int gx = (int)((HW + ppb - 1) / ppb);
-      static const char* evr = getenv("SG_BN_APPLY_REV");      // "1": back to front (A/B)
-      bn_apply_stream_launch<T>(variant, dim3(gx, N), dim3(CV * lanes_p), (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb, evr && evr[0] == '1' ? 1 : 0);
+      bn_apply_stream_launch<T>(variant, dim3(gx, N), dim3(CV * lanes_p), (hipStream_t)s, (const T*)x, (T*)y, HW, C, mean, invstd, gain, bias, gb_stride_n, relu, (int)ppb);
     } else if (vec_ok<T>(x, y, C)) hipLaunchKernelGGL((k_bn_apply<T, true>), dim3(grid_for((long long)N * HW * C / ET<T>::VEC)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
     else hipLaunchKernelGGL((k_bn_apply<T, false>), dim3(grid_for((long long)N * HW * C)), dim3(256), 0, (hipStream_t)s, (const T*)x, (T*)y, N, HW, C, mean, invstd, gain, bias, gb_stride_n, relu);
   });
